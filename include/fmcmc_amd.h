@@ -1,0 +1,185 @@
+/* fmcmc_amd.h — C-ABI of the MI355X-native many-chain Metropolis-Hastings engine.
+ *
+ * fmcmc (USCbiostats/fmcmc v0.6-0) is interpreted R and has NO FFI for its hot path:
+ * the boundary is the R closure protocol of the per-chain loop,
+ *     draws[i,] <- kernel$proposal(environment())   R/mcmc.R:752
+ *     logpost[i] <- f(theta1)                        R/mcmc.R:754
+ *     klogratio <- kernel$logratio(environment())    R/mcmc.R:768
+ * which cannot cross to a GPU.  The drop-in therefore replaces the WHOLE loop body of
+ * MCMC_without_conv_checker (R/mcmc.R:720-838) for all chains of a call at once; the
+ * entry points below are what an R `.Call` shim binds (INTEGRATION.md shows the stub).
+ * Every struct is plain-old-data: plain pointers, sizes and scalars, no torch types.
+ *
+ * Two pointer domains, same structs:
+ *   *_host entry points: every pointer is HOST memory; the library stages to/from HBM.
+ *   *_dev  entry points: every pointer is DEVICE memory (hipMalloc / a torch tensor's
+ *                        data_ptr); the call only enqueues work on `stream`.
+ *
+ * Layouts (chosen so that one chain's block is exactly an R column-major matrix):
+ *   X        [p][n]       column-major n x p design matrix (no intercept column)
+ *   initial/theta0 [C][k] one row per chain (R: initial[c, ])
+ *   samples  [C][k][S]    ans of chain c = column-major S x k matrix (R/mcmc.R:728,778)
+ *   draws    [C][k][S]    proposals (R/mcmc.R:731,752)
+ *   logpost  [C][S]       f(theta1) per kept row (R/mcmc.R:730,754)
+ *   Sigma    [C][kf][kf]  row-major per chain; kernel_adapt: covariance (R/kernel_adapt.R:148),
+ *                         kernel_ram: lower-triangular factor (R/kernel_ram.R:141)
+ *   S = floor((nsteps - burnin) / thin) kept rows: 1-based rows r = burnin + j*thin
+ *   (R/mcmc.R:786-813).
+ */
+#ifndef FMCMC_AMD_H
+#define FMCMC_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FMCMC_ABI_VERSION 1
+#define FMCMC_MAX_K 64 /* parameters per chain supported by the device kernels */
+
+/* ---- log-posterior families: the `fun` argument of MCMC() (R/mcmc.R:327) ---------- */
+enum {
+  /* sum(dnorm(y - (b0 + X b), sd = sigma, log = TRUE)); theta = (b0?, b[p], sigma).
+   * README.md:128-139 (guard=1: non-finite -> -Inf) and :356-361 (guard=0). */
+  FMCMC_FAM_GAUSSIAN_LINREG = 1,
+  /* sum(logp[y==1]) + sum(logq[y==0]) - sum(beta^2)/prior_div; theta = (b0?, b[p]).
+   * vignettes/workflow-with-fmcmc.Rmd:35-41. */
+  FMCMC_FAM_LOGISTIC = 2,
+  /* sum(log(dnorm(D, mu, sigma))); theta = (mu, sigma); D passed as y, p = 0.
+   * R/mcmc.R:141-144. */
+  FMCMC_FAM_IID_NORMAL = 3
+};
+
+typedef struct fmcmc_model {
+  int32_t family;     /* FMCMC_FAM_* */
+  int32_t p;          /* covariate columns in X (0 allowed) */
+  int64_t n;          /* observations */
+  const double* X;    /* [p][n] column-major, may be NULL when p == 0 */
+  const double* y;    /* [n] response / 0-1 outcome / data vector */
+  int32_t intercept;  /* 1: theta[0] is an intercept (implicit column of ones) */
+  int32_t guard;      /* 1: non-finite log-posterior is returned as -Inf (README.md:133-136) */
+  double prior_div;   /* logistic: prior -sum(beta^2)/prior_div; 0 = flat */
+} fmcmc_model;
+
+/* ---- transition kernels: the `kernel` argument (R/kernel_*.R) --------------------- */
+enum {
+  FMCMC_KERNEL_NORMAL = 1,            /* R/kernel_normal.R:26-82   */
+  FMCMC_KERNEL_NORMAL_REFLECTIVE = 2, /* R/kernel_normal.R:96-177  */
+  FMCMC_KERNEL_ADAPT = 3,             /* R/kernel_adapt.R:54-202   */
+  FMCMC_KERNEL_RAM = 4                /* R/kernel_ram.R:65-181     */
+};
+enum { FMCMC_SCHEME_JOINT = 0, FMCMC_SCHEME_ORDERED = 1 }; /* R/kernel.R:94-104 */
+
+typedef struct fmcmc_kernel {
+  int32_t kind;         /* FMCMC_KERNEL_* */
+  int32_t k;            /* number of parameters (length of theta) */
+  const double* mu;     /* [k] proposal mean (already recycled: R/kernel.R:3-17) */
+  const double* scale;  /* [k] proposal sd (normal kernels) */
+  const double* lb;     /* [k] lower bounds, -DBL_MAX when unbounded (R/kernel.R:25-41) */
+  const double* ub;     /* [k] upper bounds */
+  const uint8_t* fixed; /* [k] 1 = parameter never updated */
+  int32_t scheme;       /* FMCMC_SCHEME_* (normal kernels) */
+  int32_t freq;         /* adapt/ram: adaptation frequency (only 1 supported on device) */
+  int32_t warmup;       /* adapt/ram */
+  int32_t bw;           /* adapt: window (only 0 supported on device) */
+  double until;         /* adapt/ram: stop adapting when abs_iter >= until (Inf allowed) */
+  double eps;           /* adapt/ram: initial Sigma = eps * I */
+  double arate;         /* ram: target acceptance rate */
+  double Sd;            /* adapt: scaling (unused on the recursive path, kept for write-back) */
+} fmcmc_kernel;
+
+/* ---- one call of MCMC_without_conv_checker over all chains ------------------------ */
+enum { FMCMC_RNG_PHILOX = 0, FMCMC_RNG_FED = 1 };
+
+typedef struct fmcmc_run {
+  int64_t nchains;      /* chains in THIS call (the shard) */
+  int64_t nsteps;       /* R's nsteps: rows of ans before burn-in/thinning; loop runs i = 2..nsteps */
+  int64_t burnin;
+  int64_t thin;
+  uint64_t seed;        /* Philox key */
+  int64_t chain_base;   /* global id of local chain 0 (sharding never changes results) */
+  int64_t step_base;    /* MH iterations already done by these chains in earlier calls/bulks */
+  int32_t rng_mode;     /* FMCMC_RNG_* */
+  int32_t reserved;
+  /* FMCMC_RNG_FED: host-generated variates in R's own draw order (bit-exact fmcmc replay):
+   * fed_logu [C][nsteps] (entry i-1 is R[i]); fed_z [C][nsteps][kz] proposal variates of step i
+   * (kz = free parameters; normal/adapt: N(0,1); ram: Student-t).  NULL in PHILOX mode. */
+  const double* fed_logu;
+  const double* fed_z;
+} fmcmc_run;
+
+/* Per-chain state carried from call to call: chain restart by value (R/mcmc.R:344-422) plus
+ * the kernel environments that persist across bulks (R/kernel.R:218-237). In/out. */
+typedef struct fmcmc_state {
+  double* theta0;      /* [C][k]  in: initial; out: last row of ans */
+  double* f0;          /* [C]     out: log-posterior of theta0 */
+  int64_t* abs_iter;   /* [C]     adapt/ram: kernel's abs_iter (0 for a fresh kernel) */
+  double* Sigma;       /* [C][kf][kf] adapt/ram (kf = number of non-fixed parameters); NULL otherwise */
+  double* mean_prev;   /* [C][kf] adapt: Mean_t_prev */
+  int32_t* have_mean;  /* [C]     adapt: 0 while Mean_t_prev is NULL (R/kernel_adapt.R:130) */
+  int32_t* nerrors;    /* [C]     ram: failed factor updates (R/kernel_ram.R:143) */
+  int32_t fresh;       /* 1: kernel state is uninitialised; the engine sets Sigma = eps*I etc. */
+  int32_t reserved;
+} fmcmc_state;
+
+enum {
+  FMCMC_CHAIN_OK = 0,
+  FMCMC_CHAIN_NAN_LOGPOST = 1, /* fun(par) is undefined: R/mcmc.R:758-765 */
+  FMCMC_CHAIN_NAN_RATIO = 2,   /* f1 - f0 is NaN (e.g. -Inf - -Inf): R's `if (NA)` error */
+  FMCMC_CHAIN_NOT_PD = 3       /* proposal covariance not positive definite (MASS::mvrnorm error) */
+};
+
+typedef struct fmcmc_out {
+  double* samples;        /* [C][k][S] */
+  double* logpost;        /* [C][S] or NULL */
+  double* draws;          /* [C][k][S] or NULL */
+  int64_t* accept_count;  /* [C] accepted proposals in this call */
+  uint32_t* accept_bits;  /* [C][ceil(nsteps/32)] bit (i-1) set iff loop step i accepted; or NULL */
+  int32_t* status;        /* [C] FMCMC_CHAIN_* */
+  int64_t* status_step;   /* [C] loop index i at which status was raised */
+  double* status_theta;   /* [C][k] theta1 at that step */
+} fmcmc_out;
+
+/* Return codes */
+enum {
+  FMCMC_OK = 0,
+  FMCMC_ERR_ARG = 1,     /* invalid argument; message mirrors the reference's stop() text */
+  FMCMC_ERR_DEVICE = 2,  /* HIP runtime failure / no device */
+  FMCMC_ERR_CHAIN = 3,   /* at least one chain raised a FMCMC_CHAIN_* status */
+  FMCMC_ERR_UNSUPPORTED = 4
+};
+
+int fmcmc_abi_version(void);
+const char* fmcmc_last_error(void);
+int fmcmc_device_count(void);
+int64_t fmcmc_kept_rows(int64_t nsteps, int64_t burnin, int64_t thin);
+
+/* Validates a call exactly like R/mcmc.R:501-520 and the kernel initialisers
+ * (R/kernel_normal.R:134-135, R/kernel.R:9,129-132); no GPU needed. */
+int fmcmc_validate(const fmcmc_model* model, const fmcmc_kernel* kernel, const fmcmc_run* run);
+
+/* The hot path. Replaces R/mcmc.R:720-838 x R/kernel_*.R for all chains of the call. */
+int fmcmc_mcmc_run_dev(const fmcmc_model* model, const fmcmc_kernel* kernel,
+                       const fmcmc_run* run, fmcmc_state* state, fmcmc_out* out,
+                       void* hip_stream);
+int fmcmc_mcmc_run_host(const fmcmc_model* model, const fmcmc_kernel* kernel,
+                        const fmcmc_run* run, fmcmc_state* state, fmcmc_out* out,
+                        int device);
+
+/* Gelman-Rubin partial sums over local chains (R/convergence.R:191-246 -> coda::gelman.diag).
+ * Window = kept rows [row0, row0+N) of each chain. partial has fmcmc_gelman_partial_len(p)
+ * doubles: {m, sum xbar[p], sum xbar xbar^T[p*p], sum S_c[p*p], sum s2[p], sum s2^2[p],
+ * sum s2*xbar[p], sum s2*xbar^2[p]}.  Partials of different GPUs add (one all-reduce). */
+int64_t fmcmc_gelman_partial_len(int32_t p);
+int fmcmc_gelman_partial_dev(const double* samples, int64_t nchains, int32_t k, int64_t S,
+                             int64_t row0, int64_t N, const int32_t* cols, int32_t p,
+                             double* partial, void* hip_stream);
+/* Host finish: psrf[p][2] (point est., upper CI is NaN here), mpsrf. */
+int fmcmc_gelman_finish(const double* partial, int32_t p, int64_t N, double* psrf,
+                        double* mpsrf);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FMCMC_AMD_H */

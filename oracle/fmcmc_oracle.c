@@ -1,0 +1,875 @@
+/* fmcmc_oracle.c — TEST INFRASTRUCTURE.  CPU restatement of fmcmc's hot path.
+ *
+ * This file is the checker, never the product: only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load it.  Nothing under fmcmc_amd/ links or imports it.
+ *
+ * WHAT IT RESTATES (reference = /root/reference, USCbiostats/fmcmc v0.6-0, pure R):
+ *   R/mcmc.R:720-838        single-chain MH loop, burn-in, thinning       -> chain_run()
+ *   R/kernel_normal.R:37-73, :109-165   kernel_normal(_reflective)        -> propose_normal()
+ *   R/kernel.R:450-493      reflect_on_boundaries                         -> reflect()
+ *   R/kernel_adapt.R:84-182 kernel_adapt (bw = 0 recursive path, freq=1)  -> propose_adapt()
+ *   R/recursive.R:112-118, :124-128  cov_recursive / mean_recursive       -> cov_recursive1()
+ *   R/kernel_ram.R:90-160   kernel_ram                                    -> propose_ram()
+ *   R/convergence.R:191-246 convergence_gelman -> coda::gelman.diag       -> fmcmc_oracle_gelman()
+ *   user `fun`: README.md:128-139,:356-361 (Gaussian linear regression),
+ *               vignettes/workflow-with-fmcmc.Rmd:35-41 (logistic), R/mcmc.R:141-144 (iid normal)
+ *
+ * TWO MODES, one algorithm:
+ *   rng_mode = ORACLE_RNG_RMT, math_mode = ORACLE_MATH_R
+ *       fmcmc's bit-exact twin: R's Mersenne-Twister/inversion stream in R's serial draw order
+ *       (accept uniforms first, chains one after another), libm, long-double sums, R's own
+ *       operation order.  PINNED against the reference's printed outputs G1-G5
+ *       (README.md:183-201, :315-339, :388-412, :245-246; R/mcmc_info.R:503-543) by
+ *       tests/test_oracle_golden.py.
+ *   rng_mode = ORACLE_RNG_PHILOX, math_mode = ORACLE_MATH_CANON
+ *       the HIP engine's bit-exact twin: Philox stream (include/fmh_philox.h), deterministic
+ *       math (include/fmh_detmath.h), the engine's canonical summation tree (512 lanes,
+ *       xor-butterfly), Cholesky instead of eigen for mvrnorm, rank-1 factor update for RAM.
+ *   Third-party arithmetic not under /root/reference and how it is pinned: see r_rng.c
+ *   (base R RNG: pinned by KATs + G1-G5), MASS::mvrnorm -> LAPACK dsyevr (parity UNPINNED at
+ *   bit level, statistical only: G6), coda::gelman.diag mpsrf (pinned by G2/G3), psrf
+ *   univariate branch (UNPINNED), Matrix::nearPD fallback (UNPINNED, never triggered).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+
+#include "../include/fmcmc_amd.h"
+#include "../include/fmh_detmath.h"
+#include "../include/fmh_philox.h"
+#include "r_rng.h"
+
+#define ORACLE_RNG_PHILOX 0
+#define ORACLE_RNG_RMT 1
+#define ORACLE_MATH_CANON 0
+#define ORACLE_MATH_R 1
+#define ORACLE_LANES 512
+#define MAXK FMCMC_MAX_K
+
+typedef struct {
+  int rng_mode, math_mode;
+  r_rng* g;
+  uint64_t seed;
+} ocfg;
+
+/* ------------------------------------------------------------------------------------------
+ * log-posterior families
+ * ---------------------------------------------------------------------------------------- */
+
+/* canonical 512-lane xor-butterfly tree (DESIGN.md "canonical reduction") */
+static double tree512(double* acc) {
+  for (int s = 1; s < ORACLE_LANES; s <<= 1)
+    for (int l = 0; l < ORACLE_LANES; l += 2 * s) acc[l] = acc[l] + acc[l + s];
+  return acc[0];
+}
+
+/* R's dnorm(x, 0, sigma, log = TRUE) (nmath/dnorm.c), x already y - mu */
+static double r_dnorm0_log(double x, double sigma) {
+  if (isnan(x) || isnan(sigma)) return x + sigma;
+  if (sigma < 0) return NAN;
+  if (!isfinite(sigma)) return -INFINITY;
+  if (!isfinite(x) && 0.0 == x) return NAN;
+  if (sigma == 0) return (x == 0) ? INFINITY : -INFINITY;
+  x = x / sigma;
+  if (!isfinite(x)) return -INFINITY;
+  x = fabs(x);
+  if (x >= 2 * sqrt(DBL_MAX)) return -INFINITY;
+  return -(0.918938533204672741780329736406 + 0.5 * x * x + log(sigma));
+}
+
+/* R's dnorm(x, mu, sigma, log = FALSE) */
+static double r_dnorm(double x, double mu, double sigma) {
+  if (isnan(x) || isnan(mu) || isnan(sigma)) return x + mu + sigma;
+  if (sigma < 0) return NAN;
+  if (!isfinite(sigma)) return 0.0;
+  if (!isfinite(x) && mu == x) return NAN;
+  if (sigma == 0) return (x == mu) ? INFINITY : 0.0;
+  x = (x - mu) / sigma;
+  if (!isfinite(x)) return 0.0;
+  x = fabs(x);
+  if (x >= 2 * sqrt(DBL_MAX)) return 0.0;
+  const double M_1_SQRT_2PI_ = 0.398942280401432677939946059934;
+  if (x < 5) return M_1_SQRT_2PI_ * exp(-0.5 * x * x) / sigma;
+  if (x > sqrt(-2 * M_LN2 * (DBL_MIN_EXP + 1 - DBL_MANT_DIG))) return 0.0;
+  double x1 = ldexp(nearbyint(ldexp(x, 16)), -16);
+  double x2 = x - x1;
+  return M_1_SQRT_2PI_ / sigma * (exp(-0.5 * x1 * x1) * exp((-0.5 * x2 - x1) * x2));
+}
+
+static double logpost_R(const fmcmc_model* m, const double* th) {
+  const int64_t n = m->n;
+  const int p = m->p, ic = m->intercept ? 1 : 0;
+  if (m->family == FMCMC_FAM_GAUSSIAN_LINREG) {
+    /* README.md:130-131: sum(dnorm(y. - (p[1] + X.*p[2]), sd = p[3], log = TRUE)) */
+    double sigma = th[ic + p];
+    long double s = 0.0L;
+    for (int64_t i = 0; i < n; i++) {
+      double mu = ic ? th[0] : 0.0;
+      for (int j = 0; j < p; j++) {
+        double t = m->X[(int64_t)j * n + i] * th[ic + j];
+        mu = (ic || j > 0) ? mu + t : t;
+      }
+      s += (long double)r_dnorm0_log(m->y[i] - mu, sigma);
+    }
+    double f = (double)s;
+    if (m->guard && !isfinite(f)) return -INFINITY;
+    return f;
+  }
+  if (m->family == FMCMC_FAM_IID_NORMAL) {
+    /* R/mcmc.R:141-144: sum(log(dnorm(D, x[1], x[2]))) */
+    long double s = 0.0L;
+    for (int64_t i = 0; i < n; i++) s += (long double)log(r_dnorm(m->y[i], th[0], th[1]));
+    double f = (double)s;
+    if (m->guard && !isfinite(f)) return -INFINITY;
+    return f;
+  }
+  if (m->family == FMCMC_FAM_LOGISTIC) {
+    /* vignettes/workflow-with-fmcmc.Rmd:35-41 */
+    long double s1 = 0.0L, s0 = 0.0L;
+    for (int64_t i = 0; i < n; i++) {
+      double eta = ic ? th[0] : 0.0;
+      for (int j = 0; j < p; j++) eta += m->X[(int64_t)j * n + i] * th[ic + j];
+      if (m->y[i] == 1.0) {
+        double logp = (eta < 0) ? eta - log1p(exp(eta)) : -log1p(exp(-eta));
+        s1 += (long double)logp;
+      } else if (m->y[i] == 0.0) {
+        double logq = (eta < 0) ? -log1p(exp(eta)) : -eta - log1p(exp(-eta));
+        s0 += (long double)logq;
+      }
+    }
+    double logl = (double)s1 + (double)s0;
+    if (m->prior_div != 0.0) {
+      long double ss = 0.0L;
+      for (int j = 0; j < ic + p; j++) ss += (long double)(th[j] * th[j]);
+      logl = logl - (double)ss / m->prior_div;
+    }
+    if (m->guard && !isfinite(logl)) return -INFINITY;
+    return logl;
+  }
+  return NAN;
+}
+
+static double logpost_canon(const fmcmc_model* m, const double* th) {
+  const int64_t n = m->n;
+  const int p = m->p, ic = m->intercept ? 1 : 0;
+  double acc[ORACLE_LANES];
+  for (int l = 0; l < ORACLE_LANES; l++) acc[l] = 0.0;
+  if (m->family == FMCMC_FAM_GAUSSIAN_LINREG || m->family == FMCMC_FAM_IID_NORMAL) {
+    int pp = (m->family == FMCMC_FAM_IID_NORMAL) ? 0 : p;
+    int icc = (m->family == FMCMC_FAM_IID_NORMAL) ? 1 : ic;
+    double sigma = th[icc + pp];
+    for (int64_t i = 0; i < n; i++) {
+      double mu = icc ? th[0] : 0.0;
+      for (int j = 0; j < pp; j++) mu = fmh_fma(m->X[(int64_t)j * n + i], th[icc + j], mu);
+      double r = m->y[i] - mu;
+      int l = (int)(i & (ORACLE_LANES - 1));
+      acc[l] = fmh_fma(r, r, acc[l]);
+    }
+    double ssr = tree512(acc);
+    double f;
+    if (sigma < 0.0 || fmh_isnan(sigma)) {
+      f = fmh_nan();
+    } else if (sigma == 0.0) {
+      f = -fmh_inf();
+    } else {
+      double t1 = fmh_log(sigma) + FMH_LN_SQRT_2PI;
+      double q = (0.5 * ssr) / (sigma * sigma);
+      f = -((double)n * t1) - q;
+    }
+    if (m->guard && !fmh_isfinite(f)) return -fmh_inf();
+    return f;
+  }
+  if (m->family == FMCMC_FAM_LOGISTIC) {
+    for (int64_t i = 0; i < n; i++) {
+      double eta = ic ? th[0] : 0.0;
+      for (int j = 0; j < p; j++) eta = fmh_fma(m->X[(int64_t)j * n + i], th[ic + j], eta);
+      double s = (m->y[i] != 0.0) ? eta : -eta; /* logq(eta) == logp(-eta) exactly */
+      double a = (s < 0.0) ? s : -s;            /* -|s| */
+      double l1 = fmh_log1p(fmh_exp(a));
+      double term = (s < 0.0) ? (s - l1) : (-l1);
+      int l = (int)(i & (ORACLE_LANES - 1));
+      acc[l] = acc[l] + term;
+    }
+    double ll = tree512(acc);
+    if (m->prior_div != 0.0) {
+      double ss = 0.0;
+      for (int j = 0; j < ic + p; j++) ss = fmh_fma(th[j], th[j], ss);
+      ll = ll - ss / m->prior_div;
+    }
+    if (m->guard && !fmh_isfinite(ll)) return -fmh_inf();
+    return ll;
+  }
+  return fmh_nan();
+}
+
+static double logpost(const ocfg* cfg, const fmcmc_model* m, const double* th) {
+  return cfg->math_mode == ORACLE_MATH_R ? logpost_R(m, th) : logpost_canon(m, th);
+}
+
+/* exported for tests */
+double fmcmc_oracle_logpost(const fmcmc_model* m, const double* theta, int math_mode) {
+  ocfg c; c.rng_mode = 0; c.math_mode = math_mode; c.g = NULL; c.seed = 0;
+  return logpost(&c, m, theta);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * reflect_on_boundaries  (R/kernel.R:450-493)
+ * ---------------------------------------------------------------------------------------- */
+/* R's %% and %/% on doubles (arithmetic.c myfmod/myfloor), positive operands */
+static double r_fmod(double x1, double x2) {
+  if (x2 == 0.0) return NAN;
+  if (fabs(x2) * DBL_EPSILON > 1 && isfinite(x1) && fabs(x1) <= fabs(x2))
+    return (fabs(x1) == fabs(x2)) ? 0 : (((x1 < 0 && x2 > 0) || (x2 < 0 && x1 > 0)) ? x1 + x2 : x1);
+  double q = x1 / x2;
+  double tmp = x1 - floor(q) * x2;
+  q = floor(tmp / x2);
+  return tmp - q * x2;
+}
+static double r_intdiv(double x1, double x2) {
+  double q = x1 / x2;
+  if (x2 == 0.0 || fabs(q) * DBL_EPSILON > 1 || !isfinite(q)) return q;
+  if (fabs(q) < 1) return (q < 0) ? -1 : (((x1 < 0 && x2 > 0) || (x1 > 0 && x2 < 0)) ? -1 : 0);
+  long double tmp = (long double)x1 - floor(q) * (long double)x2;
+  return (double)(floor(q) + floorl(tmp / x2));
+}
+
+static double reflect1(double x, double lb, double ub, int math_mode) {
+  double d = ub - lb;
+  if (x > ub) {
+    double e = x - ub;
+    if (math_mode == ORACLE_MATH_R) {
+      double odd = r_fmod(r_intdiv(e, d), 2.0);
+      double dm = r_fmod(e, d);
+      return (lb + dm) * odd + (ub - dm) * (1 - odd);
+    } else {
+      double q = e / d, fq = __builtin_floor(q);
+      double tmp = fmh_fma(-fq, d, e);
+      double q2 = __builtin_floor(tmp / d);
+      double dm = fmh_fma(-q2, d, tmp);
+      double idiv = fq + q2;
+      double odd = idiv - 2.0 * __builtin_floor(0.5 * idiv);
+      return (odd != 0.0) ? (lb + dm) : (ub - dm);
+    }
+  }
+  if (x < lb) {
+    double e = lb - x;
+    if (math_mode == ORACLE_MATH_R) {
+      double odd = r_fmod(r_intdiv(e, d), 2.0);
+      double dm = r_fmod(e, d);
+      return (ub - dm) * odd + (lb + dm) * (1 - odd);
+    } else {
+      double q = e / d, fq = __builtin_floor(q);
+      double tmp = fmh_fma(-fq, d, e);
+      double q2 = __builtin_floor(tmp / d);
+      double dm = fmh_fma(-q2, d, tmp);
+      double idiv = fq + q2;
+      double odd = idiv - 2.0 * __builtin_floor(0.5 * idiv);
+      return (odd != 0.0) ? (ub - dm) : (lb + dm);
+    }
+  }
+  return x;
+}
+
+void fmcmc_oracle_reflect(double* x, const double* lb, const double* ub, const int32_t* which,
+                          int nwhich, int math_mode) {
+  for (int a = 0; a < nwhich; a++) {
+    int j = which[a];
+    x[j] = reflect1(x[j], lb[j], ub[j], math_mode);
+  }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * recursive mean / covariance  (R/recursive.R:124-128, :112-118), single new row
+ * ---------------------------------------------------------------------------------------- */
+void fmcmc_oracle_mean_recursive(const double* x, const double* mean_prev, double t, int k,
+                                 double* mean_out) {
+  for (int a = 0; a < k; a++) mean_out[a] = (mean_prev[a] * t + x[a]) / (t + 1);
+}
+
+/* cov [k][k] row-major, in/out. Ik is a k x k matrix (R passes diag(k)*eps of the kernel). */
+void fmcmc_oracle_cov_recursive(const double* x, double* cov, const double* mean_prev,
+                                const double* mean_t, double t, double eps, double Sd,
+                                const double* Ik, int k) {
+  double c1 = (t - 1) / t, c2 = Sd / t;
+  for (int a = 0; a < k; a++)
+    for (int b = 0; b < k; b++) {
+      double inner = t * (mean_prev[a] * mean_prev[b]) - (t + 1) * (mean_t[a] * mean_t[b]) +
+                     x[a] * x[b] + eps * Ik[a * k + b];
+      cov[a * k + b] = c1 * cov[a * k + b] + c2 * inner;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * small dense helpers
+ * ---------------------------------------------------------------------------------------- */
+/* lower Cholesky, row-major; returns 0 ok, 1 not PD. canonical op order (fma). */
+static int chol_lower_canon(const double* A, double* L, int k) {
+  for (int a = 0; a < k * k; a++) L[a] = 0.0;
+  for (int j = 0; j < k; j++) {
+    double d = A[j * k + j];
+    for (int b = 0; b < j; b++) d = fmh_fma(-L[j * k + b], L[j * k + b], d);
+    if (!(d > 0.0) || !fmh_isfinite(d)) return 1;
+    double ljj = fmh_sqrt(d);
+    L[j * k + j] = ljj;
+    for (int i = j + 1; i < k; i++) {
+      double s = A[i * k + j];
+      for (int b = 0; b < j; b++) s = fmh_fma(-L[i * k + b], L[j * k + b], s);
+      L[i * k + j] = s / ljj;
+    }
+  }
+  return 0;
+}
+/* plain (no fma) lower Cholesky for the R-faithful mode */
+static int chol_lower_plain(const double* A, double* L, int k) {
+  for (int a = 0; a < k * k; a++) L[a] = 0.0;
+  for (int j = 0; j < k; j++) {
+    double d = A[j * k + j];
+    for (int b = 0; b < j; b++) d -= L[j * k + b] * L[j * k + b];
+    if (!(d > 0.0) || !isfinite(d)) return 1;
+    double ljj = sqrt(d);
+    L[j * k + j] = ljj;
+    for (int i = j + 1; i < k; i++) {
+      double s = A[i * k + j];
+      for (int b = 0; b < j; b++) s -= L[i * k + b] * L[j * k + b];
+      L[i * k + j] = s / ljj;
+    }
+  }
+  return 0;
+}
+
+/* cyclic Jacobi eigen-decomposition of a symmetric matrix; values sorted decreasing,
+ * V columns = eigenvectors (row-major V[a*k+j] = component a of vector j). */
+static void jacobi_eig(const double* Ain, int k, double* ev, double* V) {
+  double A[MAXK * MAXK];
+  memcpy(A, Ain, sizeof(double) * k * k);
+  for (int a = 0; a < k; a++)
+    for (int b = 0; b < k; b++) V[a * k + b] = (a == b) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 100; sweep++) {
+    double off = 0.0;
+    for (int a = 0; a < k; a++)
+      for (int b = a + 1; b < k; b++) off += A[a * k + b] * A[a * k + b];
+    if (off < 1e-300) break;
+    for (int p = 0; p < k; p++)
+      for (int q = p + 1; q < k; q++) {
+        double apq = A[p * k + q];
+        if (fabs(apq) < 1e-300) continue;
+        double theta = (A[q * k + q] - A[p * k + p]) / (2.0 * apq);
+        double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int r = 0; r < k; r++) {
+          double arp = A[r * k + p], arq = A[r * k + q];
+          A[r * k + p] = c * arp - s * arq;
+          A[r * k + q] = s * arp + c * arq;
+        }
+        for (int r = 0; r < k; r++) {
+          double apr = A[p * k + r], aqr = A[q * k + r];
+          A[p * k + r] = c * apr - s * aqr;
+          A[q * k + r] = s * apr + c * aqr;
+        }
+        for (int r = 0; r < k; r++) {
+          double vrp = V[r * k + p], vrq = V[r * k + q];
+          V[r * k + p] = c * vrp - s * vrq;
+          V[r * k + q] = s * vrp + c * vrq;
+        }
+      }
+  }
+  for (int a = 0; a < k; a++) ev[a] = A[a * k + a];
+  /* sort decreasing (selection) */
+  for (int a = 0; a < k; a++) {
+    int best = a;
+    for (int b = a + 1; b < k; b++)
+      if (ev[b] > ev[best]) best = b;
+    if (best != a) {
+      double t = ev[a]; ev[a] = ev[best]; ev[best] = t;
+      for (int r = 0; r < k; r++) {
+        double u = V[r * k + a]; V[r * k + a] = V[r * k + best]; V[r * k + best] = u;
+      }
+    }
+  }
+}
+
+double fmcmc_oracle_top_eig_sym(const double* A, int k) {
+  double ev[MAXK], V[MAXK * MAXK];
+  jacobi_eig(A, k, ev, V);
+  return ev[0];
+}
+
+/* ------------------------------------------------------------------------------------------
+ * per-chain kernel state
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  int k, kf;
+  int which[MAXK];
+  double Sigma[MAXK * MAXK]; /* [kf][kf] row-major */
+  double mean_prev[MAXK];
+  int have_mean;
+  int64_t abs_iter;
+  int nerrors;
+  double run_sum[MAXK];        /* canonical: sum of ans rows 1..i-1 over free params */
+  long double run_sum_ld[MAXK]; /* R mode */
+} kstate;
+
+/* draw helpers ---------------------------------------------------------------------------- */
+static double draw_normal(const ocfg* cfg, uint32_t step, uint32_t chain, uint32_t j) {
+  if (cfg->rng_mode == ORACLE_RNG_RMT) return r_norm_rand(cfg->g);
+  return fmh_normal(cfg->seed, step, chain, j);
+}
+static double draw_t(const ocfg* cfg, uint32_t step, uint32_t chain, uint32_t j, double df) {
+  if (cfg->rng_mode == ORACLE_RNG_RMT) return r_rt(cfg->g, df);
+  return fmh_student_t(cfg->seed, step, chain, j, df);
+}
+
+/* kernel_normal / kernel_normal_reflective proposal (R/kernel_normal.R:65-72, :146-164) */
+static void propose_normal(const ocfg* cfg, const fmcmc_kernel* kn, const kstate* ks, int64_t i,
+                           uint32_t step, uint32_t chain, const double* theta0, double* theta1) {
+  for (int a = 0; a < kn->k; a++) theta1[a] = theta0[a];
+  int upd[MAXK], nupd = 0;
+  if (kn->scheme == FMCMC_SCHEME_ORDERED) {
+    /* R/kernel.R:101-104: row r of the plan updates which(!fixed)[(r-1) mod kf] */
+    upd[nupd++] = ks->which[(int)((i - 1) % ks->kf)];
+  } else {
+    for (int a = 0; a < ks->kf; a++) upd[nupd++] = ks->which[a];
+  }
+  for (int a = 0; a < nupd; a++) {
+    int j = upd[a];
+    double z = draw_normal(cfg, step, chain, (uint32_t)a);
+    theta1[j] = theta1[j] + (kn->mu[j] + kn->scale[j] * z);
+  }
+  if (kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE)
+    for (int a = 0; a < nupd; a++) {
+      int j = upd[a];
+      theta1[j] = reflect1(theta1[j], kn->lb[j], kn->ub[j], cfg->math_mode);
+    }
+}
+
+/* kernel_adapt proposal (R/kernel_adapt.R:117-180), bw = 0, freq = 1. Returns chain status. */
+static int propose_adapt(const ocfg* cfg, const fmcmc_kernel* kn, kstate* ks, int64_t i,
+                         uint32_t step, uint32_t chain, const double* theta0, double* theta1) {
+  const int kf = ks->kf;
+  if (kn->until > (double)ks->abs_iter && ks->abs_iter > kn->warmup && i > 2 &&
+      (i % kn->freq) == 0) {
+    double x[MAXK], mean_t[MAXK], Ik[MAXK * MAXK];
+    for (int a = 0; a < kf; a++) x[a] = theta0[ks->which[a]]; /* ans[i-1, which.] */
+    if (!ks->have_mean) { /* colMeans(ans[1:(i-1), which.]) :130-131 */
+      for (int a = 0; a < kf; a++)
+        ks->mean_prev[a] = (cfg->math_mode == ORACLE_MATH_R)
+                               ? (double)(ks->run_sum_ld[a] / (long double)(i - 1))
+                               : ks->run_sum[a] / (double)(i - 1);
+      ks->have_mean = 1;
+    }
+    double t = (double)(ks->abs_iter - kn->freq);
+    fmcmc_oracle_mean_recursive(x, ks->mean_prev, t, kf, mean_t);
+    for (int a = 0; a < kf; a++)
+      for (int b = 0; b < kf; b++) Ik[a * kf + b] = (a == b) ? 1.0 * kn->eps : 0.0;
+    /* eps = 1e-5 and Sd = 1 (the default of cov_recursive; kernel's Sd is NOT passed) :148-156 */
+    fmcmc_oracle_cov_recursive(x, ks->Sigma, ks->mean_prev, mean_t, t, 1e-5, 1.0, Ik, kf);
+    for (int a = 0; a < kf; a++) ks->mean_prev[a] = mean_t[a];
+  }
+  ks->abs_iter += 1;
+  double z[MAXK], delta[MAXK];
+  for (int a = 0; a < kf; a++) z[a] = draw_normal(cfg, step, chain, (uint32_t)a);
+  if (cfg->math_mode == ORACLE_MATH_R) {
+    /* MASS::mvrnorm: mu + V diag(sqrt(pmax(ev,0))) z, eigenvalues decreasing */
+    double ev[MAXK], V[MAXK * MAXK];
+    jacobi_eig(ks->Sigma, kf, ev, V);
+    if (ev[kf - 1] < -1e-6 * fabs(ev[0])) return FMCMC_CHAIN_NOT_PD;
+    for (int a = 0; a < kf; a++) {
+      double s = 0.0;
+      for (int b = 0; b < kf; b++) s += V[a * kf + b] * (sqrt(ev[b] > 0 ? ev[b] : 0.0) * z[b]);
+      delta[a] = kn->mu[ks->which[a]] + s;
+    }
+  } else {
+    double L[MAXK * MAXK];
+    if (chol_lower_canon(ks->Sigma, L, kf)) return FMCMC_CHAIN_NOT_PD;
+    for (int a = 0; a < kf; a++) {
+      double s = 0.0;
+      for (int b = 0; b <= a; b++) s = fmh_fma(L[a * kf + b], z[b], s);
+      delta[a] = kn->mu[ks->which[a]] + s;
+    }
+  }
+  for (int a = 0; a < kn->k; a++) theta1[a] = theta0[a];
+  for (int a = 0; a < kf; a++) theta1[ks->which[a]] = theta0[ks->which[a]] + delta[a];
+  for (int a = 0; a < kf; a++) {
+    int j = ks->which[a];
+    theta1[j] = reflect1(theta1[j], kn->lb[j], kn->ub[j], cfg->math_mode);
+  }
+  return FMCMC_CHAIN_OK;
+}
+
+/* canonical rank-1 update/downdate of a lower factor: L L^T + sgn * w w^T. 0 ok, 1 failed. */
+static int chol_rank1_canon(double* L, double* w, int k, int sgn) {
+  for (int j = 0; j < k; j++) {
+    double ljj = L[j * k + j], xj = w[j];
+    double r2 = (sgn > 0) ? fmh_fma(xj, xj, ljj * ljj) : fmh_fma(-xj, xj, ljj * ljj);
+    if (!(r2 > 0.0) || !fmh_isfinite(r2)) return 1;
+    double r = fmh_sqrt(r2);
+    double c = r / ljj, s = xj / ljj;
+    L[j * k + j] = r;
+    for (int i = j + 1; i < k; i++) {
+      double lij = L[i * k + j];
+      double ln = ((sgn > 0) ? fmh_fma(s, w[i], lij) : fmh_fma(-s, w[i], lij)) / c;
+      w[i] = fmh_fma(-s, ln, c * w[i]);
+      L[i * k + j] = ln;
+    }
+  }
+  return 0;
+}
+
+/* kernel_ram proposal (R/kernel_ram.R:123-158). f0 = current log-posterior. */
+static int propose_ram(const ocfg* cfg, const fmcmc_model* m, const fmcmc_kernel* kn, kstate* ks,
+                       int64_t i, uint32_t step, uint32_t chain, const double* theta0, double f0,
+                       double* theta1 /* in: previous theta1; out: new proposal */) {
+  const int kf = ks->kf;
+  double U[MAXK], v[MAXK];
+  for (int a = 0; a < kf; a++) U[a] = draw_t(cfg, step, chain, (uint32_t)a, (double)kf);
+  if (cfg->math_mode == ORACLE_MATH_R) {
+    for (int a = 0; a < kf; a++) {
+      double s = 0.0;
+      for (int b = 0; b < kf; b++) s += ks->Sigma[a * kf + b] * U[b];
+      v[a] = s;
+    }
+  } else {
+    for (int a = 0; a < kf; a++) {
+      double s = 0.0;
+      for (int b = 0; b <= a; b++) s = fmh_fma(ks->Sigma[a * kf + b], U[b], s);
+      v[a] = s;
+    }
+  }
+  for (int a = 0; a < kf; a++) theta1[ks->which[a]] = theta0[ks->which[a]] + v[a];
+
+  if (kn->until > (double)ks->abs_iter && ks->abs_iter > kn->warmup && (i % kn->freq) == 0) {
+    double f1u = logpost(cfg, m, theta1); /* un-reflected proposal :132 */
+    double a_n, eta;
+    if (cfg->math_mode == ORACLE_MATH_R) {
+      a_n = exp(f1u - f0); /* min(1, NaN) is NaN in R, then !is.finite -> 0 :132-134 */
+      if (a_n > 1.0) a_n = 1.0;
+      if (!isfinite(a_n)) a_n = 0.0;
+      eta = pow((double)i, -2.0 / 3.0) * (double)kf;
+      if (eta > 1.0) eta = 1.0;
+      /* Sigma %*% (Ik + eta*(a_n-arate)*UU^T/||U||^2) %*% t(Sigma); t(chol()) :136-146 */
+      double nrm = 0.0;
+      for (int a = 0; a < kf; a++) nrm += U[a] * U[a];
+      nrm = sqrt(nrm);
+      double nrm2 = nrm * nrm;
+      double M[MAXK * MAXK], T[MAXK * MAXK], S2[MAXK * MAXK], L[MAXK * MAXK];
+      for (int a = 0; a < kf; a++)
+        for (int b = 0; b < kf; b++)
+          M[a * kf + b] = ((a == b) ? 1.0 : 0.0) + eta * (a_n - kn->arate) * (U[a] * U[b]) / nrm2;
+      for (int a = 0; a < kf; a++)
+        for (int b = 0; b < kf; b++) {
+          double s = 0.0;
+          for (int c = 0; c < kf; c++) s += ks->Sigma[a * kf + c] * M[c * kf + b];
+          T[a * kf + b] = s;
+        }
+      for (int a = 0; a < kf; a++)
+        for (int b = 0; b < kf; b++) {
+          double s = 0.0;
+          for (int c = 0; c < kf; c++) s += T[a * kf + c] * ks->Sigma[b * kf + c];
+          S2[a * kf + b] = s;
+        }
+      if (chol_lower_plain(S2, L, kf)) {
+        ks->nerrors += 1; /* Matrix::nearPD fallback is not restated (parity unpinned) */
+      } else {
+        memcpy(ks->Sigma, L, sizeof(double) * kf * kf);
+      }
+    } else {
+      a_n = fmh_exp(f1u - f0);
+      if (fmh_isnan(a_n)) a_n = 0.0;
+      else if (a_n > 1.0) a_n = 1.0;
+      eta = (double)kf * fmh_exp((-2.0 / 3.0) * fmh_log((double)i));
+      if (eta > 1.0) eta = 1.0;
+      double nrm2 = 0.0;
+      for (int a = 0; a < kf; a++) nrm2 = fmh_fma(U[a], U[a], nrm2);
+      double cp = (eta * (a_n - kn->arate)) / nrm2;
+      if (cp != 0.0 && fmh_isfinite(cp)) {
+        double L[MAXK * MAXK], w[MAXK];
+        memcpy(L, ks->Sigma, sizeof(double) * kf * kf);
+        double sc = fmh_sqrt(fmh_abs(cp));
+        for (int a = 0; a < kf; a++) w[a] = sc * v[a];
+        if (chol_rank1_canon(L, w, kf, cp > 0.0 ? 1 : -1)) ks->nerrors += 1;
+        else memcpy(ks->Sigma, L, sizeof(double) * kf * kf);
+      }
+    }
+  }
+  ks->abs_iter += 1;
+  for (int a = 0; a < kf; a++) {
+    int j = ks->which[a];
+    theta1[j] = reflect1(theta1[j], kn->lb[j], kn->ub[j], cfg->math_mode);
+  }
+  return FMCMC_CHAIN_OK;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * the run: MCMC_without_conv_checker over all chains of the call (R/mcmc.R:643-673 serial
+ * fan-out: chains share ONE R stream sequentially) x single-chain loop (R/mcmc.R:720-838)
+ * ---------------------------------------------------------------------------------------- */
+int64_t fmcmc_oracle_kept_rows(int64_t nsteps, int64_t burnin, int64_t thin) {
+  return (nsteps - burnin) / thin;
+}
+
+int fmcmc_oracle_run(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_run* run,
+                     fmcmc_state* st, fmcmc_out* out, int rng_mode, int math_mode, r_rng* g) {
+  const int k = kn->k;
+  if (k > MAXK || k < 1) return FMCMC_ERR_ARG;
+  if (run->burnin >= run->nsteps || run->thin >= run->nsteps || run->thin < 1) return FMCMC_ERR_ARG;
+  if ((kn->kind == FMCMC_KERNEL_ADAPT || kn->kind == FMCMC_KERNEL_RAM) &&
+      (kn->freq != 1 || kn->bw != 0))
+    return FMCMC_ERR_UNSUPPORTED;
+  ocfg cfg; cfg.rng_mode = rng_mode; cfg.math_mode = math_mode; cfg.g = g; cfg.seed = run->seed;
+  const int64_t C = run->nchains, nsteps = run->nsteps;
+  const int64_t S = fmcmc_oracle_kept_rows(nsteps, run->burnin, run->thin);
+  const int64_t nwords = (nsteps + 31) / 32;
+  int any_err = 0;
+  double* logu = (double*)malloc(sizeof(double) * (size_t)(nsteps + 1));
+
+  kstate ks;
+  ks.k = k; ks.kf = 0;
+  for (int a = 0; a < k; a++)
+    if (!kn->fixed[a]) ks.which[ks.kf++] = a;
+  const int kf = ks.kf;
+  if (kf == 0) { free(logu); return FMCMC_ERR_ARG; }
+  for (int a = 0; a < k; a++)
+    if (kn->kind != FMCMC_KERNEL_NORMAL && !(kn->ub[a] > kn->lb[a])) { free(logu); return FMCMC_ERR_ARG; }
+
+  for (int64_t c = 0; c < C; c++) {
+    const uint32_t chain = (uint32_t)(run->chain_base + c);
+    /* load kernel state */
+    ks.abs_iter = 0; ks.have_mean = 0; ks.nerrors = 0;
+    if (kn->kind == FMCMC_KERNEL_ADAPT || kn->kind == FMCMC_KERNEL_RAM) {
+      if (st->fresh) {
+        for (int a = 0; a < kf; a++)
+          for (int b = 0; b < kf; b++) ks.Sigma[a * kf + b] = (a == b) ? 1.0 * kn->eps : 0.0;
+      } else {
+        memcpy(ks.Sigma, st->Sigma + c * kf * kf, sizeof(double) * kf * kf);
+        ks.abs_iter = st->abs_iter[c];
+        if (st->nerrors) ks.nerrors = st->nerrors[c];
+        if (kn->kind == FMCMC_KERNEL_ADAPT) {
+          ks.have_mean = st->have_mean[c];
+          memcpy(ks.mean_prev, st->mean_prev + c * kf, sizeof(double) * kf);
+        }
+      }
+    }
+    double theta0[MAXK], theta1[MAXK];
+    for (int a = 0; a < k; a++) theta0[a] = theta1[a] = st->theta0[c * k + a];
+
+    /* R <- log(runif(nsteps)) drawn up front (R/mcmc.R:726); R[1] is never used */
+    if (rng_mode == ORACLE_RNG_RMT)
+      for (int64_t i = 1; i <= nsteps; i++) logu[i] = log(r_unif_rand(g));
+
+    double* ans = out->samples + c * k * S;
+    double* drw = out->draws ? out->draws + c * k * S : NULL;
+    double* lp = out->logpost ? out->logpost + c * S : NULL;
+    uint32_t* bits = out->accept_bits ? out->accept_bits + c * nwords : NULL;
+    if (bits) memset(bits, 0, sizeof(uint32_t) * (size_t)nwords);
+    for (int64_t s = 0; s < S * k; s++) ans[s] = NAN;
+    out->status[c] = FMCMC_CHAIN_OK;
+    out->status_step[c] = 0;
+    int64_t nacc = 0;
+
+    double f0 = logpost(&cfg, m, theta0), f1 = f0;
+    for (int a = 0; a < kf; a++) {
+      ks.run_sum[a] = theta0[ks.which[a]];
+      ks.run_sum_ld[a] = (long double)theta0[ks.which[a]];
+    }
+#define STORE_ROW(i_, th_state, th_draw, lpv)                                        \
+  do {                                                                               \
+    int64_t r_ = (i_);                                                               \
+    if (r_ > run->burnin && ((r_ - run->burnin) % run->thin) == 0) {                 \
+      int64_t s_ = (r_ - run->burnin) / run->thin - 1;                               \
+      for (int a_ = 0; a_ < k; a_++) {                                               \
+        ans[a_ * S + s_] = (th_state)[a_];                                           \
+        if (drw) drw[a_ * S + s_] = (th_draw)[a_];                                   \
+      }                                                                              \
+      if (lp) lp[s_] = (lpv);                                                        \
+    }                                                                                \
+  } while (0)
+    STORE_ROW(1, theta0, theta0, f0);
+
+    for (int64_t i = 2; i <= nsteps; i++) {
+      const uint32_t step = (uint32_t)(run->step_base + i);
+      int status = FMCMC_CHAIN_OK;
+      if (kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE)
+        propose_normal(&cfg, kn, &ks, i, step, chain, theta0, theta1);
+      else if (kn->kind == FMCMC_KERNEL_ADAPT)
+        status = propose_adapt(&cfg, kn, &ks, i, step, chain, theta0, theta1);
+      else
+        status = propose_ram(&cfg, m, kn, &ks, i, step, chain, theta0, f0, theta1);
+      if (status == FMCMC_CHAIN_OK) {
+        f1 = logpost(&cfg, m, theta1);
+        if (isnan(f1)) status = FMCMC_CHAIN_NAN_LOGPOST; /* R/mcmc.R:758-765 */
+      }
+      double ratio = f1 - f0; /* kernel$logratio :768, R/kernel.R:302-303 */
+      if (status == FMCMC_CHAIN_OK && isnan(ratio)) status = FMCMC_CHAIN_NAN_RATIO;
+      if (status != FMCMC_CHAIN_OK) {
+        out->status[c] = status;
+        out->status_step[c] = i;
+        for (int a = 0; a < k; a++) out->status_theta[c * k + a] = theta1[a];
+        any_err = 1;
+        break;
+      }
+      double lu = (rng_mode == ORACLE_RNG_RMT) ? logu[i] : fmh_log_accept_u(cfg.seed, step, chain);
+      if (lu < ratio) { /* strict < :770 */
+        for (int a = 0; a < k; a++) theta0[a] = theta1[a];
+        f0 = f1;
+        nacc++;
+        if (bits) bits[(i - 1) >> 5] |= (1u << ((i - 1) & 31));
+      }
+      STORE_ROW(i, theta0, theta1, f1);
+      for (int a = 0; a < kf; a++) {
+        ks.run_sum[a] = ks.run_sum[a] + theta0[ks.which[a]];
+        ks.run_sum_ld[a] += (long double)theta0[ks.which[a]];
+      }
+    }
+    out->accept_count[c] = nacc;
+    /* write state back */
+    for (int a = 0; a < k; a++) st->theta0[c * k + a] = theta0[a];
+    st->f0[c] = f0;
+    if (kn->kind == FMCMC_KERNEL_ADAPT || kn->kind == FMCMC_KERNEL_RAM) {
+      memcpy(st->Sigma + c * kf * kf, ks.Sigma, sizeof(double) * kf * kf);
+      st->abs_iter[c] = ks.abs_iter;
+      if (st->nerrors) st->nerrors[c] = ks.nerrors;
+      if (kn->kind == FMCMC_KERNEL_ADAPT) {
+        st->have_mean[c] = ks.have_mean;
+        memcpy(st->mean_prev + c * kf, ks.mean_prev, sizeof(double) * kf);
+      }
+    }
+  }
+  free(logu);
+  return any_err ? FMCMC_ERR_CHAIN : FMCMC_OK;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * coda::gelman.diag(x, transform = FALSE, autoburnin handled by caller, multivariate = TRUE)
+ * (arithmetic lives in coda, not under /root/reference; restated from Brooks & Gelman 1998 as
+ * coda implements it; mpsrf pinned by README.md:315-339,:388-412)
+ * x: [m][p][N] (per chain, column-major N x p).  psrf: [p] point estimates.
+ * ---------------------------------------------------------------------------------------- */
+int fmcmc_oracle_gelman(const double* x, int64_t mch, int p, int64_t N, double* psrf, double* mpsrf) {
+  if (mch < 2 || N < 2 || p < 1 || p > MAXK) return 1;
+  double* xbar = (double*)calloc((size_t)(mch * p), sizeof(double));
+  double* W = (double*)calloc((size_t)(p * p), sizeof(double));
+  double* B = (double*)calloc((size_t)(p * p), sizeof(double));
+  double* s2 = (double*)calloc((size_t)(mch * p), sizeof(double));
+  double* Sc = (double*)calloc((size_t)(p * p), sizeof(double));
+  for (int64_t c = 0; c < mch; c++) {
+    const double* xc = x + c * p * N;
+    for (int a = 0; a < p; a++) {
+      long double s = 0.0L;
+      for (int64_t t = 0; t < N; t++) s += xc[a * N + t];
+      xbar[c * p + a] = (double)(s / N);
+    }
+    for (int a = 0; a < p; a++)
+      for (int b = a; b < p; b++) {
+        long double s = 0.0L;
+        for (int64_t t = 0; t < N; t++)
+          s += (long double)(xc[a * N + t] - xbar[c * p + a]) * (xc[b * N + t] - xbar[c * p + b]);
+        Sc[a * p + b] = Sc[b * p + a] = (double)(s / (N - 1));
+      }
+    for (int a = 0; a < p; a++) s2[c * p + a] = Sc[a * p + a];
+    for (int a = 0; a < p * p; a++) W[a] += Sc[a] / (double)mch;
+  }
+  double* mu = (double*)calloc((size_t)p, sizeof(double));
+  for (int a = 0; a < p; a++) {
+    double s = 0.0;
+    for (int64_t c = 0; c < mch; c++) s += xbar[c * p + a];
+    mu[a] = s / (double)mch;
+  }
+  for (int a = 0; a < p; a++)
+    for (int b = 0; b < p; b++) {
+      double s = 0.0;
+      for (int64_t c = 0; c < mch; c++) s += (xbar[c * p + a] - mu[a]) * (xbar[c * p + b] - mu[b]);
+      B[a * p + b] = (double)N * s / (double)(mch - 1);
+    }
+  /* univariate psrf */
+  for (int a = 0; a < p; a++) {
+    double w = W[a * p + a], b = B[a * p + a];
+    double ms2 = 0, mx = 0, mx2 = 0;
+    for (int64_t c = 0; c < mch; c++) {
+      ms2 += s2[c * p + a]; mx += xbar[c * p + a]; mx2 += xbar[c * p + a] * xbar[c * p + a];
+    }
+    ms2 /= mch; mx /= mch; mx2 /= mch;
+    double var_s2 = 0, cov_s2_x2 = 0, cov_s2_x = 0;
+    for (int64_t c = 0; c < mch; c++) {
+      double d = s2[c * p + a] - ms2;
+      var_s2 += d * d;
+      cov_s2_x2 += d * (xbar[c * p + a] * xbar[c * p + a] - mx2);
+      cov_s2_x += d * (xbar[c * p + a] - mx);
+    }
+    var_s2 /= (mch - 1); cov_s2_x2 /= (mch - 1); cov_s2_x /= (mch - 1);
+    double var_w = var_s2 / mch;
+    double var_b = (2 * b * b) / (mch - 1);
+    double cov_wb = ((double)N / mch) * (cov_s2_x2 - 2 * mu[a] * cov_s2_x);
+    double V = (N - 1) * w / N + (1 + 1.0 / mch) * b / N;
+    double var_V = ((double)(N - 1) * (N - 1) * var_w + (1 + 1.0 / mch) * (1 + 1.0 / mch) * var_b +
+                    2.0 * (N - 1) * (1 + 1.0 / mch) * cov_wb) / ((double)N * N);
+    double df_V = (2 * V * V) / var_V;
+    double df_adj = (df_V + 3) / (df_V + 1);
+    double R2_fixed = (double)(N - 1) / N;
+    double R2_random = (1 + 1.0 / mch) * (1.0 / N) * (b / w);
+    psrf[a] = sqrt(df_adj * (R2_fixed + R2_random));
+  }
+  /* multivariate: largest eigenvalue of W^{-1} B via CW = chol(W) (upper), as coda does */
+  int rc = 0;
+  if (p > 1) {
+    double L[MAXK * MAXK], Y[MAXK * MAXK], Z[MAXK * MAXK];
+    if (chol_lower_plain(W, L, p)) {
+      rc = 2;
+      *mpsrf = NAN;
+    } else {
+      /* Y = L^{-1} B ; Z = L^{-1} Y^T  => Z = L^{-1} B L^{-T} */
+      for (int col = 0; col < p; col++)
+        for (int a = 0; a < p; a++) {
+          double s = B[a * p + col];
+          for (int b = 0; b < a; b++) s -= L[a * p + b] * Y[b * p + col];
+          Y[a * p + col] = s / L[a * p + a];
+        }
+      for (int col = 0; col < p; col++)
+        for (int a = 0; a < p; a++) {
+          double s = Y[col * p + a]; /* Y^T[a][col] */
+          for (int b = 0; b < a; b++) s -= L[a * p + b] * Z[b * p + col];
+          Z[a * p + col] = s / L[a * p + a];
+        }
+      for (int a = 0; a < p; a++)
+        for (int b = a + 1; b < p; b++) {
+          double t = 0.5 * (Z[a * p + b] + Z[b * p + a]);
+          Z[a * p + b] = Z[b * p + a] = t;
+        }
+      double emax = fmcmc_oracle_top_eig_sym(Z, p);
+      *mpsrf = sqrt((1.0 - 1.0 / N) + (1.0 + 1.0 / p) * emax / N);
+    }
+  } else {
+    *mpsrf = NAN;
+  }
+  free(xbar); free(W); free(B); free(s2); free(Sc); free(mu);
+  return rc;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * test hooks for include/fmh_detmath.h and include/fmh_philox.h (vectorised over n inputs)
+ * ---------------------------------------------------------------------------------------- */
+void fmcmc_oracle_detmath(int which, const double* x, double* out, int64_t n) {
+  for (int64_t i = 0; i < n; i++) {
+    switch (which) {
+      case 0: out[i] = fmh_log(x[i]); break;
+      case 1: out[i] = fmh_exp(x[i]); break;
+      case 2: out[i] = fmh_log1p(x[i]); break;
+      case 3: out[i] = fmh_qnorm(x[i]); break;
+      default: out[i] = NAN;
+    }
+  }
+}
+void fmcmc_oracle_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                         uint32_t k1, uint32_t* out4) {
+  fmh_u32x4 r = fmh_philox4x32_10(c0, c1, c2, c3, k0, k1);
+  for (int a = 0; a < 4; a++) out4[a] = r.v[a];
+}
+/* canonical draws: kind 0 = log accept u, 1 = normal j, 2 = student t (df) j */
+double fmcmc_oracle_canon_draw(int kind, uint64_t seed, uint32_t step, uint32_t chain, uint32_t j,
+                               double df) {
+  if (kind == 0) return fmh_log_accept_u(seed, step, chain);
+  if (kind == 1) return fmh_normal(seed, step, chain, j);
+  return fmh_student_t(seed, step, chain, j, df);
+}
+int fmcmc_oracle_cpu_has_fma(void) { return __builtin_cpu_supports("fma") ? 1 : 0; }
