@@ -1,0 +1,35 @@
+"""Builds the HIP engine in-tree: fmcmc_amd/lib/libfmcmc_amd.so (gfx950 only)."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SRC = [os.path.join(HERE, "csrc", "mh_engine.hip"), os.path.join(HERE, "csrc", "gelman.hip")]
+DEPS = [os.path.join(ROOT, "include", f) for f in ("fmcmc_amd.h", "fmh_detmath.h", "fmh_philox.h")]
+OUT = os.path.join(HERE, "lib", "libfmcmc_amd.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+         "-Wno-unused-value", "-Wno-unused-result"]
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.exists(f) and os.path.getmtime(f) > t for f in SRC + DEPS)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return OUT
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    src = [s for s in SRC if os.path.exists(s)]
+    cmd = [HIPCC] + FLAGS + src + ["-o", OUT]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force=True, verbose=True)

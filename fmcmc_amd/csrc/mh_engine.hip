@@ -1,0 +1,903 @@
+// mh_engine.hip — gfx950 (MI355X) many-chain Metropolis-Hastings sweep kernels + C-ABI.
+//
+// Replaces, for ALL chains of a call at once, the per-chain loop of the reference
+//   R/mcmc.R:720-838 (loop, accept, burn-in/thin)  x  R/kernel_normal.R / R/kernel_adapt.R /
+//   R/kernel_ram.R / R/recursive.R / R/kernel.R:450-493 (proposal kernels).
+//
+// Execution model (DESIGN.md has the full picture):
+//   * one 512-thread workgroup (8 wavefronts) owns CW chains; its 512 threads ARE the 512
+//     "canonical lanes" of the log-posterior reduction: observation i belongs to lane i mod 512,
+//     each lane accumulates its observations in index order with fma, lanes are combined by an
+//     xor-butterfly tree (levels 1..32 inside a wavefront, 64..256 across the 8 wavefronts).
+//     The CPU oracle mirrors exactly this tree, so accept decisions are bit-identical.
+//   * every data value loaded by a thread is applied to all CW chains of the workgroup
+//     (register/L2 traffic amortised over chains);
+//   * per-chain "scalar" work (proposal, adaptation, accept) is done by the chain's owner
+//     wavefront, lanes = parameters (one lane per row of Sigma / S);
+//   * RNG = Philox4x32-10 counter stream (include/fmh_philox.h) or host-fed variates.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (explicit fma only).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <math.h>
+#include <float.h>
+#include <vector>
+
+#include "../../include/fmcmc_amd.h"
+#include "../../include/fmh_detmath.h"
+#include "../../include/fmh_philox.h"
+
+namespace {
+
+constexpr int NT = 512;       // threads per workgroup == canonical lanes
+constexpr int NW = NT / 64;   // wavefronts per workgroup
+constexpr int MAXK = FMCMC_MAX_K;
+
+thread_local char g_err[1024] = "";
+void set_err(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+void set_err(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+struct SweepArgs {
+  // model
+  int family, p, intercept, guard;
+  long long n;
+  const double* X;
+  const double* y;
+  double prior_div;
+  // kernel
+  int kind, k, scheme, warmup;
+  double until, eps, arate;
+  const double* mu;
+  const double* scale;
+  const double* lb;
+  const double* ub;
+  const uint8_t* fixed;
+  // run
+  long long nchains, nsteps, burnin, thin, S, chain_base, step_base;
+  unsigned long long seed;
+  int rng_mode, fresh, ram_bounded, kz;
+  const double* fed_logu;
+  const double* fed_z;
+  // state
+  double* theta0;
+  double* f0;
+  long long* abs_iter;
+  double* Sigma;
+  double* mean_prev;
+  int* have_mean;
+  int* nerrors;
+  // out
+  double* samples;
+  double* logpost;
+  double* draws;
+  long long* accept_count;
+  unsigned int* accept_bits;
+  int* status;
+  long long* status_step;
+  double* status_theta;
+};
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
+
+// canonical reflect (twin of oracle reflect1, MATH_CANON branch; R/kernel.R:450-493)
+__device__ __forceinline__ double reflect1(double x, double lb, double ub) {
+  double d = ub - lb;
+  if (x > ub) {
+    double e = x - ub;
+    double q = e / d, fq = __builtin_floor(q);
+    double tmp = fmh_fma(-fq, d, e);
+    double q2 = __builtin_floor(tmp / d);
+    double dm = fmh_fma(-q2, d, tmp);
+    double idiv = fq + q2;
+    double odd = idiv - 2.0 * __builtin_floor(0.5 * idiv);
+    return (odd != 0.0) ? (lb + dm) : (ub - dm);
+  }
+  if (x < lb) {
+    double e = lb - x;
+    double q = e / d, fq = __builtin_floor(q);
+    double tmp = fmh_fma(-fq, d, e);
+    double q2 = __builtin_floor(tmp / d);
+    double dm = fmh_fma(-q2, d, tmp);
+    double idiv = fq + q2;
+    double odd = idiv - 2.0 * __builtin_floor(0.5 * idiv);
+    return (odd != 0.0) ? (ub - dm) : (lb + dm);
+  }
+  return x;
+}
+
+// Per-chain LDS block layout (doubles). LD = kf|1 keeps column walks conflict-free.
+struct ChainLds {
+  double* th0;   // [k]
+  double* th1;   // [k]
+  double* vz;    // [kf] z / U
+  double* vv;    // [kf] v = S U, or x (adapt)
+  double* vmp;   // [kf] mean_prev
+  double* vmt;   // [kf] mean_t
+  double* vrs;   // [kf] running sum of ans rows (adapt)
+  double* SigA;  // [kf*LD]
+  double* SigB;  // [kf*LD] adapt: Cholesky factor; ram: the other buffer of S
+  double* sc;    // scalars: 0 f0, 1 f1
+};
+
+__host__ __device__ inline int chain_lds_doubles(int k, int kf, int kind) {
+  int LD = kf | 1;
+  int mats = (kind == FMCMC_KERNEL_ADAPT || kind == FMCMC_KERNEL_RAM) ? 2 * kf * LD : 0;
+  return 2 * k + 5 * kf + mats + 4;
+}
+
+__device__ __forceinline__ ChainLds chain_lds(double* base, int k, int kf, int kind) {
+  ChainLds c;
+  int LD = kf | 1;
+  c.th0 = base;
+  c.th1 = c.th0 + k;
+  c.vz = c.th1 + k;
+  c.vv = c.vz + kf;
+  c.vmp = c.vv + kf;
+  c.vmt = c.vmp + kf;
+  c.vrs = c.vmt + kf;
+  c.SigA = c.vrs + kf;
+  int mats = (kind == FMCMC_KERNEL_ADAPT || kind == FMCMC_KERNEL_RAM) ? kf * LD : 0;
+  c.SigB = c.SigA + mats;
+  c.sc = c.SigB + mats;
+  return c;
+}
+
+// ---- workgroup-collective log-posterior partial sums -------------------------------------
+// Every thread accumulates its canonical lane for all CW chains, then the wavefront butterfly
+// (levels 1..32) runs and lane 0 of each wavefront publishes its partial to s_part[w][c].
+template <int CW>
+__device__ __forceinline__ void eval_partials(const SweepArgs& A, double* const* th /*[CW] -> theta in LDS*/,
+                                              double* s_part) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long n = A.n;
+  const int p = (A.family == FMCMC_FAM_IID_NORMAL) ? 0 : A.p;
+  const int ic = (A.family == FMCMC_FAM_IID_NORMAL) ? 1 : A.intercept;
+  double acc[CW];
+#pragma unroll
+  for (int c = 0; c < CW; c++) acc[c] = 0.0;
+  if (A.family == FMCMC_FAM_LOGISTIC) {
+    for (long long i = tid; i < n; i += NT) {
+      double eta[CW];
+#pragma unroll
+      for (int c = 0; c < CW; c++) eta[c] = ic ? th[c][0] : 0.0;
+      for (int j = 0; j < p; j++) {
+        double x = A.X[(long long)j * n + i];
+#pragma unroll
+        for (int c = 0; c < CW; c++) eta[c] = fmh_fma(x, th[c][ic + j], eta[c]);
+      }
+      const bool y1 = (A.y[i] != 0.0);
+#pragma unroll
+      for (int c = 0; c < CW; c++) {
+        double s = y1 ? eta[c] : -eta[c];
+        double a = (s < 0.0) ? s : -s;
+        double l1 = fmh_log1p(fmh_exp(a));
+        double term = (s < 0.0) ? (s - l1) : (-l1);
+        acc[c] = acc[c] + term;
+      }
+    }
+  } else {
+    for (long long i = tid; i < n; i += NT) {
+      double mu[CW];
+#pragma unroll
+      for (int c = 0; c < CW; c++) mu[c] = ic ? th[c][0] : 0.0;
+      for (int j = 0; j < p; j++) {
+        double x = A.X[(long long)j * n + i];
+#pragma unroll
+        for (int c = 0; c < CW; c++) mu[c] = fmh_fma(x, th[c][ic + j], mu[c]);
+      }
+      const double yv = A.y[i];
+#pragma unroll
+      for (int c = 0; c < CW; c++) {
+        double r = yv - mu[c];
+        acc[c] = fmh_fma(r, r, acc[c]);
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CW; c++) {
+    double v = acc[c];
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) v = v + __shfl_xor(v, s, 64);
+    if (lane == 0) s_part[wave * CW + c] = v;
+  }
+}
+
+// levels 64,128,256 of the canonical tree + the family's closed form. Uniform over the wave.
+template <int CW>
+__device__ __forceinline__ double finish_logpost(const SweepArgs& A, const double* th, const double* s_part, int c) {
+  double w0 = s_part[0 * CW + c], w1 = s_part[1 * CW + c], w2 = s_part[2 * CW + c], w3 = s_part[3 * CW + c];
+  double w4 = s_part[4 * CW + c], w5 = s_part[5 * CW + c], w6 = s_part[6 * CW + c], w7 = s_part[7 * CW + c];
+  double tot = ((w0 + w1) + (w2 + w3)) + ((w4 + w5) + (w6 + w7));
+  double f;
+  if (A.family == FMCMC_FAM_LOGISTIC) {
+    f = tot;
+    if (A.prior_div != 0.0) {
+      double ss = 0.0;
+      const int nb = A.intercept + A.p;
+      for (int j = 0; j < nb; j++) ss = fmh_fma(th[j], th[j], ss);
+      f = f - ss / A.prior_div;
+    }
+  } else {
+    const int pp = (A.family == FMCMC_FAM_IID_NORMAL) ? 0 : A.p;
+    const int ic = (A.family == FMCMC_FAM_IID_NORMAL) ? 1 : A.intercept;
+    const double sigma = th[ic + pp];
+    if (sigma < 0.0 || fmh_isnan(sigma)) {
+      f = fmh_nan();
+    } else if (sigma == 0.0) {
+      f = -fmh_inf();
+    } else {
+      double t1 = fmh_log(sigma) + FMH_LN_SQRT_2PI;
+      double q = (0.5 * tot) / (sigma * sigma);
+      f = -((double)A.n * t1) - q;
+    }
+  }
+  if (A.guard && !fmh_isfinite(f)) f = -fmh_inf();
+  return f;
+}
+
+// ---- the sweep kernel ----------------------------------------------------------------------
+template <int CW>
+__global__ __launch_bounds__(NT) void mh_sweep_kernel(const SweepArgs A) {
+  extern __shared__ double smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int k = A.k;
+  // ---- shared layout: kernel parameters, which[], partials, then CW chain blocks
+  double* s_mu = smem;
+  double* s_scale = s_mu + k;
+  double* s_lb = s_scale + k;
+  double* s_ub = s_lb + k;
+  int* s_which = (int*)(s_ub + k);          // [k] ints (k/2+1 doubles)
+  double* s_part = s_ub + k + (k / 2 + 1);  // [NW*CW]
+  int* s_flag = (int*)(s_part + NW * CW);   // [2] ints
+  double* s_chains = s_part + NW * CW + 1;
+
+  __shared__ int s_kf;
+  if (tid == 0) {
+    int kf = 0;
+    for (int j = 0; j < k; j++)
+      if (!A.fixed[j]) s_which[kf++] = j;
+    s_kf = kf;
+    s_flag[0] = 0;
+  }
+  if (tid < k) {
+    s_mu[tid] = A.mu[tid];
+    s_scale[tid] = A.scale[tid];
+    s_lb[tid] = A.lb[tid];
+    s_ub[tid] = A.ub[tid];
+  }
+  __syncthreads();
+  const int kf = s_kf;
+  const int LD = kf | 1;
+  const int CHS = chain_lds_doubles(k, kf, A.kind);
+  const long long cg0 = (long long)blockIdx.x * CW;  // first local chain of this workgroup
+  const int ncw = (int)((A.nchains - cg0 < CW) ? (A.nchains - cg0) : CW);
+  const bool adaptive = (A.kind == FMCMC_KERNEL_ADAPT || A.kind == FMCMC_KERNEL_RAM);
+
+  // owner wavefront of chain c is wave c (CW <= NW)
+  const int myc = wave;                 // chain slot owned by this wavefront
+  const bool owner = (myc < ncw);
+  const long long cl = cg0 + myc;       // local chain index
+  const unsigned int cgid = (unsigned int)(A.chain_base + cl);
+  ChainLds L = chain_lds(s_chains + (owner ? myc : 0) * CHS, k, kf, A.kind);
+
+  double* thp[CW];
+#pragma unroll
+  for (int c = 0; c < CW; c++) thp[c] = s_chains + (c < ncw ? c : 0) * CHS + k;  // th1 of chain c
+
+  // ---- per-chain registers of the owner wavefront (uniform across its lanes)
+  double f0 = 0.0, f1 = 0.0;
+  long long abs_iter = 0, nacc = 0;
+  int have_mean = 0, nerr = 0, status = FMCMC_CHAIN_OK;
+  unsigned int bitword = 0;
+  double* Scur = L.SigA;   // ram: current factor buffer
+  double* Salt = L.SigB;
+
+  if (owner) {
+    if (lane < k) {
+      double t = A.theta0[cl * k + lane];
+      L.th0[lane] = t;
+      L.th1[lane] = t;
+    }
+    if (adaptive) {
+      if (A.fresh) {
+        for (int e = lane; e < kf * LD; e += 64) {
+          int a = e / LD, b = e % LD;
+          L.SigA[e] = (a == b) ? 1.0 * A.eps : 0.0;
+          L.SigB[e] = 0.0;
+        }
+      } else {
+        for (int e = lane; e < kf * LD; e += 64) {
+          int a = e / LD, b = e % LD;
+          L.SigA[e] = (b < kf) ? A.Sigma[(cl * kf + a) * kf + b] : 0.0;
+          L.SigB[e] = 0.0;
+        }
+        abs_iter = A.abs_iter[cl];
+        if (A.nerrors) nerr = A.nerrors[cl];
+        if (A.kind == FMCMC_KERNEL_ADAPT) {
+          have_mean = A.have_mean[cl];
+          if (lane < kf) L.vmp[lane] = A.mean_prev[cl * kf + lane];
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- row 1: f0 = f(initial)
+  eval_partials<CW>(A, thp, s_part);
+  __syncthreads();
+  const long long S = A.S;
+  auto store_row = [&](long long r, double lpv) {
+    if (r > A.burnin && ((r - A.burnin) % A.thin) == 0) {
+      long long s = (r - A.burnin) / A.thin - 1;
+      if (lane < k) {
+        A.samples[(cl * k + lane) * S + s] = L.th0[lane];
+        if (A.draws) A.draws[(cl * k + lane) * S + s] = L.th1[lane];
+      }
+      if (A.logpost && lane == 0) A.logpost[cl * S + s] = lpv;
+    }
+  };
+  if (owner) {
+    f0 = finish_logpost<CW>(A, L.th1, s_part, myc);
+    f1 = f0;
+    if (lane < kf) L.vrs[lane] = L.th0[s_which[lane]];
+    store_row(1, f0);
+  }
+
+  // ---- main loop
+  for (long long i = 2; i <= A.nsteps; i++) {
+    const unsigned int step = (unsigned int)(A.step_base + i);
+    bool ram_gate = false;
+    // ================= scalar phase A: proposal =================
+    if (owner && status == FMCMC_CHAIN_OK) {
+      if (A.kind == FMCMC_KERNEL_NORMAL || A.kind == FMCMC_KERNEL_NORMAL_REFLECTIVE) {
+        if (lane < k) L.th1[lane] = L.th0[lane];
+        wave_sync();
+        const bool refl = (A.kind == FMCMC_KERNEL_NORMAL_REFLECTIVE);
+        const int nupd = (A.scheme == FMCMC_SCHEME_ORDERED) ? 1 : kf;
+        if (lane < nupd) {
+          int j = (A.scheme == FMCMC_SCHEME_ORDERED) ? s_which[(int)((i - 1) % kf)] : s_which[lane];
+          double z = (A.rng_mode == FMCMC_RNG_FED)
+                         ? A.fed_z[(cl * A.nsteps + (i - 1)) * A.kz + lane]
+                         : fmh_normal(A.seed, step, cgid, (unsigned int)lane);
+          double t = L.th0[j] + (s_mu[j] + s_scale[j] * z);
+          if (refl) t = reflect1(t, s_lb[j], s_ub[j]);
+          L.th1[j] = t;
+        }
+      } else if (A.kind == FMCMC_KERNEL_ADAPT) {
+        // R/kernel_adapt.R:117-166 (bw = 0, freq = 1)
+        if (A.until > (double)abs_iter && abs_iter > A.warmup && i > 2) {
+          const double t = (double)(abs_iter - 1);
+          double x = 0, mp = 0, mt = 0;
+          if (lane < kf) {
+            x = L.th0[s_which[lane]];
+            mp = have_mean ? L.vmp[lane] : (L.vrs[lane] / (double)(i - 1));
+            mt = (mp * t + x) / (t + 1);
+            L.vv[lane] = x;
+            L.vmp[lane] = mp;
+            L.vmt[lane] = mt;
+          }
+          wave_sync();
+          if (lane < kf) {
+            const double c1 = (t - 1) / t, c2 = 1.0 / t;
+            for (int b = 0; b < kf; b++) {
+              double ik = (b == lane) ? 1.0 * A.eps : 0.0;
+              double inner = t * (mp * L.vmp[b]) - (t + 1) * (mt * L.vmt[b]) + x * L.vv[b] + 1e-5 * ik;
+              L.SigA[lane * LD + b] = c1 * L.SigA[lane * LD + b] + c2 * inner;
+            }
+          }
+          wave_sync();
+          if (lane < kf) L.vmp[lane] = mt;
+          have_mean = 1;
+        }
+        abs_iter += 1;
+        if (lane < kf)
+          L.vz[lane] = (A.rng_mode == FMCMC_RNG_FED)
+                           ? A.fed_z[(cl * A.nsteps + (i - 1)) * A.kz + lane]
+                           : fmh_normal(A.seed, step, cgid, (unsigned int)lane);
+        wave_sync();
+        // left-looking Cholesky, lane = row (twin of oracle chol_lower_canon)
+        bool notpd = false;
+        for (int j = 0; j < kf; j++) {
+          double s = 0.0;
+          if (lane >= j && lane < kf) {
+            s = L.SigA[lane * LD + j];
+            for (int b = 0; b < j; b++) s = fmh_fma(-L.SigB[lane * LD + b], L.SigB[j * LD + b], s);
+          }
+          double d = shfl_d(s, j);
+          if (!(d > 0.0) || !fmh_isfinite(d)) { notpd = true; break; }
+          double ljj = fmh_sqrt(d);
+          if (lane == j) L.SigB[j * LD + j] = ljj;
+          else if (lane > j && lane < kf) L.SigB[lane * LD + j] = s / ljj;
+          wave_sync();
+        }
+        if (notpd) {
+          status = FMCMC_CHAIN_NOT_PD;
+        } else {
+          if (lane < k) L.th1[lane] = L.th0[lane];
+          wave_sync();
+          if (lane < kf) {
+            double s = 0.0;
+            for (int b = 0; b <= lane; b++) s = fmh_fma(L.SigB[lane * LD + b], L.vz[b], s);
+            int j = s_which[lane];
+            double t = L.th0[j] + (s_mu[j] + s);
+            L.th1[j] = reflect1(t, s_lb[j], s_ub[j]);
+          }
+        }
+      } else {  // RAM, R/kernel_ram.R:123-126
+        if (lane < kf)
+          L.vz[lane] = (A.rng_mode == FMCMC_RNG_FED)
+                           ? A.fed_z[(cl * A.nsteps + (i - 1)) * A.kz + lane]
+                           : fmh_student_t(A.seed, step, cgid, (unsigned int)lane, (double)kf);
+        wave_sync();
+        if (lane < kf) {
+          double s = 0.0;
+          for (int b = 0; b <= lane; b++) s = fmh_fma(Scur[lane * LD + b], L.vz[b], s);
+          L.vv[lane] = s;
+          int j = s_which[lane];
+          L.th1[j] = L.th0[j] + s;
+        }
+        ram_gate = (A.until > (double)abs_iter && abs_iter > A.warmup);
+      }
+      if (status != FMCMC_CHAIN_OK) {  // raised inside the proposal (NOT_PD)
+        if (lane == 0) { A.status[cl] = status; A.status_step[cl] = i; }
+        if (lane < k) A.status_theta[cl * k + lane] = L.th1[lane];
+      }
+    }
+    __syncthreads();
+    // ================= collective evaluation of f(theta1) =================
+    eval_partials<CW>(A, thp, s_part);
+    __syncthreads();
+    // ================= scalar phase B: RAM adaptation (needs f(theta1) un-reflected) =================
+    if (A.kind == FMCMC_KERNEL_RAM) {
+      bool changed = false;
+      if (owner && status == FMCMC_CHAIN_OK) {
+        if (ram_gate) {
+          double f1u = finish_logpost<CW>(A, L.th1, s_part, myc);
+          double a_n = fmh_exp(f1u - f0);
+          if (fmh_isnan(a_n)) a_n = 0.0;
+          else if (a_n > 1.0) a_n = 1.0;
+          double eta = (double)kf * fmh_exp((-2.0 / 3.0) * fmh_log((double)i));
+          if (eta > 1.0) eta = 1.0;
+          double nrm2 = 0.0;
+          for (int b = 0; b < kf; b++) nrm2 = fmh_fma(L.vz[b], L.vz[b], nrm2);
+          double cp = (eta * (a_n - A.arate)) / nrm2;
+          if (cp != 0.0 && fmh_isfinite(cp)) {
+            const bool up = cp > 0.0;
+            const double scl = fmh_sqrt(fmh_abs(cp));
+            double w = (lane < kf) ? scl * L.vv[lane] : 0.0;
+            bool fail = false;
+            for (int j = 0; j < kf; j++) {
+              double ljj = Scur[j * LD + j];
+              double xj = shfl_d(w, j);
+              double r2 = up ? fmh_fma(xj, xj, ljj * ljj) : fmh_fma(-xj, xj, ljj * ljj);
+              if (!(r2 > 0.0) || !fmh_isfinite(r2)) { fail = true; break; }
+              double r = fmh_sqrt(r2);
+              double cc = r / ljj, ss = xj / ljj;
+              if (lane == j) {
+                Salt[j * LD + j] = r;
+              } else if (lane > j && lane < kf) {
+                double lij = Scur[lane * LD + j];
+                double ln = (up ? fmh_fma(ss, w, lij) : fmh_fma(-ss, w, lij)) / cc;
+                w = fmh_fma(-ss, ln, cc * w);
+                Salt[lane * LD + j] = ln;
+              }
+            }
+            wave_sync();
+            if (fail) {
+              nerr += 1;
+            } else {
+              double* t = Scur; Scur = Salt; Salt = t;
+            }
+          }
+        }
+        abs_iter += 1;
+        if (A.ram_bounded) {
+          if (lane < kf) {
+            int j = s_which[lane];
+            double t0 = L.th1[j];
+            double t1 = reflect1(t0, s_lb[j], s_ub[j]);
+            if (!(t1 == t0)) { L.th1[j] = t1; changed = true; }
+          }
+          if (__any(changed)) s_flag[0] = 1;
+        }
+      }
+      if (A.ram_bounded) {  // uniform over the workgroup (launch-time constant)
+        __syncthreads();
+        const bool again = (s_flag[0] != 0);
+        __syncthreads();
+        if (again) {
+          if (tid == 0) s_flag[0] = 0;
+          eval_partials<CW>(A, thp, s_part);
+          __syncthreads();
+        }
+      }
+    }
+    // ================= scalar phase C: accept / store (R/mcmc.R:754-778) =================
+    if (owner && status == FMCMC_CHAIN_OK) {
+      f1 = finish_logpost<CW>(A, L.th1, s_part, myc);
+      if (fmh_isnan(f1)) status = FMCMC_CHAIN_NAN_LOGPOST;
+      const double ratio = f1 - f0;
+      if (status == FMCMC_CHAIN_OK && fmh_isnan(ratio)) status = FMCMC_CHAIN_NAN_RATIO;
+      if (status != FMCMC_CHAIN_OK) {
+        if (lane == 0) { A.status[cl] = status; A.status_step[cl] = i; }
+        if (lane < k) A.status_theta[cl * k + lane] = L.th1[lane];
+      } else {
+        const double lu = (A.rng_mode == FMCMC_RNG_FED) ? A.fed_logu[cl * A.nsteps + (i - 1)]
+                                                        : fmh_log_accept_u(A.seed, step, cgid);
+        if (lu < ratio) {
+          if (lane < k) L.th0[lane] = L.th1[lane];
+          f0 = f1;
+          nacc += 1;
+          bitword |= (1u << ((i - 1) & 31));
+        }
+        wave_sync();
+        store_row(i, f1);
+        if (A.kind == FMCMC_KERNEL_ADAPT && lane < kf) L.vrs[lane] = L.vrs[lane] + L.th0[s_which[lane]];
+      }
+    }
+    if (owner && A.accept_bits && lane == 0 && (((i - 1) & 31) == 31 || i == A.nsteps)) {
+      A.accept_bits[cl * ((A.nsteps + 31) / 32) + ((i - 1) >> 5)] = bitword;
+      bitword = 0;
+    }
+  }
+
+  // ---- write state back
+  if (owner) {
+    if (lane < k) A.theta0[cl * k + lane] = L.th0[lane];
+    if (lane == 0) {
+      A.f0[cl] = f0;
+      A.accept_count[cl] = nacc;
+      if (status == FMCMC_CHAIN_OK) { A.status[cl] = FMCMC_CHAIN_OK; A.status_step[cl] = 0; }
+      if (adaptive) {
+        A.abs_iter[cl] = abs_iter;
+        if (A.nerrors) A.nerrors[cl] = nerr;
+        if (A.kind == FMCMC_KERNEL_ADAPT) A.have_mean[cl] = have_mean;
+      }
+    }
+    if (adaptive) {
+      wave_sync();
+      const double* Sfin = (A.kind == FMCMC_KERNEL_RAM) ? Scur : L.SigA;
+      for (int e = lane; e < kf * kf; e += 64) {
+        int a = e / kf, b = e % kf;
+        A.Sigma[(cl * kf + a) * kf + b] = Sfin[a * LD + b];
+      }
+      if (A.kind == FMCMC_KERNEL_ADAPT && lane < kf) A.mean_prev[cl * kf + lane] = L.vmp[lane];
+    }
+  }
+}
+
+// diagnostic: evaluates include/fmh_detmath.h / fmh_philox.h on the device (tests compare bitwise
+// with the host build of the same headers)
+__global__ void detmath_kernel(int which, const double* x, double* out, long long n,
+                               unsigned long long seed) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double v = x[i], r;
+  switch (which) {
+    case 0: r = fmh_log(v); break;
+    case 1: r = fmh_exp(v); break;
+    case 2: r = fmh_log1p(v); break;
+    case 3: r = fmh_qnorm(v); break;
+    case 4: r = fmh_log_accept_u(seed, (unsigned)(i & 0xffff), (unsigned)(i >> 16)); break;
+    case 5: r = fmh_normal(seed, (unsigned)(i & 0xffff), (unsigned)(i >> 16), (unsigned)(i % 7)); break;
+    case 6: r = fmh_student_t(seed, (unsigned)(i & 0xffff), (unsigned)(i >> 16), (unsigned)(i % 7), v); break;
+    case 7: r = fmh_sqrt(v); break;
+    case 8: r = 1.0 / v; break;
+    default: r = fmh_nan();
+  }
+  out[i] = r;
+}
+
+size_t sweep_lds_bytes(int k, int kf, int kind, int CW) {
+  size_t d = 4 * (size_t)k + (k / 2 + 1) + (size_t)NW * CW + 1 + (size_t)CW * chain_lds_doubles(k, kf, kind);
+  return d * sizeof(double);
+}
+
+}  // namespace
+
+// ==============================================================================================
+// C-ABI
+// ==============================================================================================
+extern "C" {
+
+int fmcmc_abi_version(void) { return FMCMC_ABI_VERSION; }
+const char* fmcmc_last_error(void) { return g_err; }
+
+int fmcmc_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int64_t fmcmc_kept_rows(int64_t nsteps, int64_t burnin, int64_t thin) {
+  if (thin < 1 || burnin >= nsteps) return 0;
+  return (nsteps - burnin) / thin;
+}
+
+static int count_free(const fmcmc_kernel* kn, const uint8_t* fixed_host) {
+  int kf = 0;
+  for (int j = 0; j < kn->k; j++)
+    if (!fixed_host[j]) kf++;
+  return kf;
+}
+
+// Argument checks with the reference's own messages (R/mcmc.R:501-520, R/kernel.R:9,129-132,
+// R/kernel_normal.R:134-135). Pointers inside `kernel` must be HOST pointers here.
+int fmcmc_validate(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_run* run) {
+  if (!m || !kn || !run) { set_err("null argument"); return FMCMC_ERR_ARG; }
+  if (run->nchains < 1) { set_err("`nchains` must be an integer greater than 1."); return FMCMC_ERR_ARG; }
+  if (run->burnin >= run->nsteps) {
+    set_err("-burnin- (%lld) cannot be >= than -nsteps- (%lld).", (long long)run->burnin, (long long)run->nsteps);
+    return FMCMC_ERR_ARG;
+  }
+  if (run->thin >= run->nsteps) {
+    set_err("-thin- (%lld) cannot be > than -nsteps- (%lld).", (long long)run->thin, (long long)run->nsteps);
+    return FMCMC_ERR_ARG;
+  }
+  if (run->thin < 1) { set_err("-thin- should be >= 1."); return FMCMC_ERR_ARG; }
+  if (kn->k < 1 || kn->k > FMCMC_MAX_K) {
+    set_err("number of parameters k=%d outside [1, %d]", kn->k, FMCMC_MAX_K);
+    return FMCMC_ERR_UNSUPPORTED;
+  }
+  int kexp = -1;
+  switch (m->family) {
+    case FMCMC_FAM_GAUSSIAN_LINREG: kexp = (m->intercept ? 1 : 0) + m->p + 1; break;
+    case FMCMC_FAM_LOGISTIC: kexp = (m->intercept ? 1 : 0) + m->p; break;
+    case FMCMC_FAM_IID_NORMAL: kexp = 2; break;
+    default: set_err("unknown log-posterior family %d", m->family); return FMCMC_ERR_ARG;
+  }
+  if (kexp != kn->k) {
+    set_err("Incorrect length of -initial-: the model has %d parameters, the kernel %d.", kexp, kn->k);
+    return FMCMC_ERR_ARG;
+  }
+  if (m->n < 1) { set_err("the model needs at least one observation"); return FMCMC_ERR_ARG; }
+  if (kn->kind < FMCMC_KERNEL_NORMAL || kn->kind > FMCMC_KERNEL_RAM) {
+    set_err("unknown kernel kind %d", kn->kind);
+    return FMCMC_ERR_ARG;
+  }
+  if (kn->fixed && kn->lb && kn->ub) {
+    int kf = count_free(kn, kn->fixed);
+    if (kf == 0) {
+      set_err("The number of parameters to update, i.e. not fixed, cannot be zero. "
+              "Check the value -fixed- in the kernel initialization.");
+      return FMCMC_ERR_ARG;
+    }
+    if (kn->kind != FMCMC_KERNEL_NORMAL)
+      for (int j = 0; j < kn->k; j++)
+        if (!(kn->ub[j] > kn->lb[j])) { set_err("-ub- cannot be <= than -lb-."); return FMCMC_ERR_ARG; }
+  }
+  if ((kn->kind == FMCMC_KERNEL_ADAPT || kn->kind == FMCMC_KERNEL_RAM) && (kn->freq != 1 || kn->bw != 0)) {
+    set_err("device kernels support freq = 1 and bw = 0 only (got freq=%d, bw=%d)", kn->freq, kn->bw);
+    return FMCMC_ERR_UNSUPPORTED;
+  }
+  if (kn->kind == FMCMC_KERNEL_ADAPT && kn->bw > 0 && kn->bw > kn->warmup) {
+    set_err("The `warmup` parameter must be greater than `bw`.");
+    return FMCMC_ERR_ARG;
+  }
+  if (run->rng_mode == FMCMC_RNG_FED && (!run->fed_logu || !run->fed_z)) {
+    set_err("rng_mode = FED needs fed_logu and fed_z");
+    return FMCMC_ERR_ARG;
+  }
+  return FMCMC_OK;
+}
+
+// kernel->fixed etc. are DEVICE pointers here; kf and bounds info come via `kf`/`ram_bounded`.
+static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_run* run,
+                        fmcmc_state* st, fmcmc_out* out, int kf, int ram_bounded, hipStream_t stream) {
+  SweepArgs A;
+  memset(&A, 0, sizeof(A));
+  A.family = m->family; A.p = m->p; A.intercept = m->intercept ? 1 : 0; A.guard = m->guard ? 1 : 0;
+  A.n = m->n; A.X = m->X; A.y = m->y; A.prior_div = m->prior_div;
+  A.kind = kn->kind; A.k = kn->k; A.scheme = kn->scheme; A.warmup = kn->warmup;
+  A.until = kn->until; A.eps = kn->eps; A.arate = kn->arate;
+  A.mu = kn->mu; A.scale = kn->scale; A.lb = kn->lb; A.ub = kn->ub; A.fixed = kn->fixed;
+  A.nchains = run->nchains; A.nsteps = run->nsteps; A.burnin = run->burnin; A.thin = run->thin;
+  A.S = fmcmc_kept_rows(run->nsteps, run->burnin, run->thin);
+  A.chain_base = run->chain_base; A.step_base = run->step_base; A.seed = run->seed;
+  A.rng_mode = run->rng_mode; A.fresh = st->fresh; A.ram_bounded = ram_bounded;
+  A.kz = (kn->scheme == FMCMC_SCHEME_ORDERED && kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE) ? 1 : kf;
+  A.fed_logu = run->fed_logu; A.fed_z = run->fed_z;
+  A.theta0 = st->theta0; A.f0 = st->f0; A.abs_iter = (long long*)st->abs_iter; A.Sigma = st->Sigma;
+  A.mean_prev = st->mean_prev; A.have_mean = st->have_mean; A.nerrors = st->nerrors;
+  A.samples = out->samples; A.logpost = out->logpost; A.draws = out->draws;
+  A.accept_count = (long long*)out->accept_count; A.accept_bits = out->accept_bits;
+  A.status = out->status; A.status_step = (long long*)out->status_step; A.status_theta = out->status_theta;
+
+  // chains per workgroup: fill the 256 CUs first, then stack chains on a workgroup
+  int dev = 0, ncu = 256;
+  hipGetDevice(&dev);
+  hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  if (ncu <= 0) ncu = 256;
+  int cw = 1;
+  while (cw < NW && (long long)cw * ncu < run->nchains) cw <<= 1;
+  while (cw > 1 && sweep_lds_bytes(kn->k, kf, kn->kind, cw) > 150 * 1024) cw >>= 1;
+  size_t lds = sweep_lds_bytes(kn->k, kf, kn->kind, cw);
+  if (lds > 160 * 1024) { set_err("LDS budget exceeded (k=%d)", kn->k); return FMCMC_ERR_UNSUPPORTED; }
+  const long long nblk = (run->nchains + cw - 1) / cw;
+  hipError_t e = hipSuccess;
+#define LAUNCH(CWV)                                                                                  \
+  do {                                                                                               \
+    if (lds > 48 * 1024)                                                                             \
+      e = hipFuncSetAttribute((const void*)mh_sweep_kernel<CWV>,                                    \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
+    if (e == hipSuccess)                                                                             \
+      hipLaunchKernelGGL(mh_sweep_kernel<CWV>, dim3((unsigned)nblk), dim3(NT), lds, stream, A);     \
+  } while (0)
+  switch (cw) {
+    case 1: LAUNCH(1); break;
+    case 2: LAUNCH(2); break;
+    case 4: LAUNCH(4); break;
+    default: LAUNCH(8); break;
+  }
+#undef LAUNCH
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e != hipSuccess) { set_err("HIP launch failed: %s", hipGetErrorString(e)); return FMCMC_ERR_DEVICE; }
+  return FMCMC_OK;
+}
+
+int fmcmc_detmath_dev(int which, const double* x, double* out, int64_t n, uint64_t seed, void* hip_stream) {
+  if (n <= 0) return FMCMC_OK;
+  hipLaunchKernelGGL(detmath_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream,
+                     which, x, out, (long long)n, (unsigned long long)seed);
+  return hipGetLastError() == hipSuccess ? FMCMC_OK : FMCMC_ERR_DEVICE;
+}
+
+int fmcmc_mcmc_run_dev(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_run* run,
+                       fmcmc_state* st, fmcmc_out* out, void* hip_stream) {
+  if (!m || !kn || !run || !st || !out) { set_err("null argument"); return FMCMC_ERR_ARG; }
+  // `fixed`, `lb`, `ub` live on the device: fetch the few bytes the launch geometry needs.
+  uint8_t fx[MAXK];
+  double lb[MAXK], ub[MAXK];
+  if (kn->k < 1 || kn->k > MAXK) { set_err("k=%d outside [1,%d]", kn->k, MAXK); return FMCMC_ERR_UNSUPPORTED; }
+  hipStream_t stream = (hipStream_t)hip_stream;
+  if (hipMemcpyAsync(fx, kn->fixed, kn->k, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+      hipMemcpyAsync(lb, kn->lb, kn->k * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+      hipMemcpyAsync(ub, kn->ub, kn->k * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+      hipStreamSynchronize(stream) != hipSuccess) {
+    set_err("cannot read kernel parameters from device memory");
+    return FMCMC_ERR_DEVICE;
+  }
+  fmcmc_kernel kh = *kn;
+  kh.fixed = fx; kh.lb = lb; kh.ub = ub;
+  int rc = fmcmc_validate(m, &kh, run);
+  if (rc != FMCMC_OK) return rc;
+  int kf = count_free(kn, fx);
+  int bounded = 0;
+  for (int j = 0; j < kn->k; j++)
+    if (!fx[j] && (lb[j] > -DBL_MAX || ub[j] < DBL_MAX)) bounded = 1;
+  return launch_sweep(m, kn, run, st, out, kf, bounded, stream);
+}
+
+#define HCHK(x)                                                                    \
+  do {                                                                             \
+    hipError_t e_ = (x);                                                           \
+    if (e_ != hipSuccess) {                                                        \
+      set_err("%s failed: %s", #x, hipGetErrorString(e_));                         \
+      rc = FMCMC_ERR_DEVICE;                                                       \
+      goto done;                                                                   \
+    }                                                                              \
+  } while (0)
+
+int fmcmc_mcmc_run_host(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_run* run,
+                        fmcmc_state* st, fmcmc_out* out, int device) {
+  if (!m || !kn || !run || !st || !out) { set_err("null argument"); return FMCMC_ERR_ARG; }
+  int rc = fmcmc_validate(m, kn, run);
+  if (rc != FMCMC_OK) return rc;
+  if (fmcmc_device_count() < 1) { set_err("no HIP device: the engine has no CPU fallback"); return FMCMC_ERR_DEVICE; }
+  const int k = kn->k;
+  const int kf = count_free(kn, kn->fixed);
+  const int64_t C = run->nchains, S = fmcmc_kept_rows(run->nsteps, run->burnin, run->thin);
+  const int64_t nwords = (run->nsteps + 31) / 32;
+  const bool adaptive = (kn->kind == FMCMC_KERNEL_ADAPT || kn->kind == FMCMC_KERNEL_RAM);
+  std::vector<void*> allocs;
+  auto dalloc = [&](size_t bytes) -> void* {
+    void* p = nullptr;
+    if (bytes == 0) bytes = 8;
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    allocs.push_back(p);
+    return p;
+  };
+  fmcmc_model dm = *m;
+  fmcmc_kernel dk = *kn;
+  fmcmc_run dr = *run;
+  fmcmc_state ds = *st;
+  fmcmc_out dout = *out;
+  hipStream_t stream = nullptr;
+  int bounded = 0;
+  for (int j = 0; j < k; j++)
+    if (!kn->fixed[j] && (kn->lb[j] > -DBL_MAX || kn->ub[j] < DBL_MAX)) bounded = 1;
+
+  HCHK(hipSetDevice(device));
+  HCHK(hipStreamCreate(&stream));
+#define UP(dst, src, bytes)                                                                  \
+  do {                                                                                       \
+    void* p_ = dalloc(bytes);                                                                \
+    if (!p_) { set_err("hipMalloc(%zu) failed", (size_t)(bytes)); rc = FMCMC_ERR_DEVICE; goto done; } \
+    if ((src) != nullptr) HCHK(hipMemcpyAsync(p_, (src), (bytes), hipMemcpyHostToDevice, stream)); \
+    dst = (decltype(dst))p_;                                                                 \
+  } while (0)
+  if (m->p > 0) UP(dm.X, m->X, sizeof(double) * (size_t)m->p * m->n);
+  UP(dm.y, m->y, sizeof(double) * (size_t)m->n);
+  UP(dk.mu, kn->mu, sizeof(double) * k);
+  UP(dk.scale, kn->scale, sizeof(double) * k);
+  UP(dk.lb, kn->lb, sizeof(double) * k);
+  UP(dk.ub, kn->ub, sizeof(double) * k);
+  UP(dk.fixed, kn->fixed, (size_t)k);
+  if (run->rng_mode == FMCMC_RNG_FED) {
+    const int kz = (kn->scheme == FMCMC_SCHEME_ORDERED && kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE) ? 1 : kf;
+    UP(dr.fed_logu, run->fed_logu, sizeof(double) * (size_t)C * run->nsteps);
+    UP(dr.fed_z, run->fed_z, sizeof(double) * (size_t)C * run->nsteps * kz);
+  }
+  UP(ds.theta0, st->theta0, sizeof(double) * (size_t)C * k);
+  UP(ds.f0, (double*)nullptr, sizeof(double) * (size_t)C);
+  if (adaptive) {
+    UP(ds.abs_iter, st->fresh ? nullptr : st->abs_iter, sizeof(int64_t) * (size_t)C);
+    UP(ds.Sigma, st->fresh ? nullptr : st->Sigma, sizeof(double) * (size_t)C * kf * kf);
+    UP(ds.mean_prev, st->fresh ? nullptr : st->mean_prev, sizeof(double) * (size_t)C * kf);
+    UP(ds.have_mean, st->fresh ? nullptr : st->have_mean, sizeof(int32_t) * (size_t)C);
+    UP(ds.nerrors, (st->fresh || !st->nerrors) ? nullptr : st->nerrors, sizeof(int32_t) * (size_t)C);
+    if (st->fresh || !st->nerrors) HCHK(hipMemsetAsync(ds.nerrors, 0, sizeof(int32_t) * (size_t)C, stream));
+  }
+  UP(dout.samples, (double*)nullptr, sizeof(double) * (size_t)C * k * S);
+  HCHK(hipMemsetAsync(dout.samples, 0xff, sizeof(double) * (size_t)C * k * S, stream));  // NaN fill
+  if (out->logpost) UP(dout.logpost, (double*)nullptr, sizeof(double) * (size_t)C * S);
+  if (out->draws) UP(dout.draws, (double*)nullptr, sizeof(double) * (size_t)C * k * S);
+  UP(dout.accept_count, (int64_t*)nullptr, sizeof(int64_t) * (size_t)C);
+  if (out->accept_bits) UP(dout.accept_bits, (uint32_t*)nullptr, sizeof(uint32_t) * (size_t)C * nwords);
+  UP(dout.status, (int32_t*)nullptr, sizeof(int32_t) * (size_t)C);
+  UP(dout.status_step, (int64_t*)nullptr, sizeof(int64_t) * (size_t)C);
+  UP(dout.status_theta, (double*)nullptr, sizeof(double) * (size_t)C * k);
+  HCHK(hipMemsetAsync(dout.status_theta, 0, sizeof(double) * (size_t)C * k, stream));
+#undef UP
+  rc = launch_sweep(&dm, &dk, &dr, &ds, &dout, kf, bounded, stream);
+  if (rc != FMCMC_OK) goto done;
+#define DOWN(dst, src, bytes) HCHK(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, stream))
+  DOWN(st->theta0, ds.theta0, sizeof(double) * (size_t)C * k);
+  DOWN(st->f0, ds.f0, sizeof(double) * (size_t)C);
+  if (adaptive) {
+    DOWN(st->abs_iter, ds.abs_iter, sizeof(int64_t) * (size_t)C);
+    DOWN(st->Sigma, ds.Sigma, sizeof(double) * (size_t)C * kf * kf);
+    DOWN(st->mean_prev, ds.mean_prev, sizeof(double) * (size_t)C * kf);
+    DOWN(st->have_mean, ds.have_mean, sizeof(int32_t) * (size_t)C);
+    if (st->nerrors) DOWN(st->nerrors, ds.nerrors, sizeof(int32_t) * (size_t)C);
+  }
+  DOWN(out->samples, dout.samples, sizeof(double) * (size_t)C * k * S);
+  if (out->logpost) DOWN(out->logpost, dout.logpost, sizeof(double) * (size_t)C * S);
+  if (out->draws) DOWN(out->draws, dout.draws, sizeof(double) * (size_t)C * k * S);
+  DOWN(out->accept_count, dout.accept_count, sizeof(int64_t) * (size_t)C);
+  if (out->accept_bits) DOWN(out->accept_bits, dout.accept_bits, sizeof(uint32_t) * (size_t)C * nwords);
+  DOWN(out->status, dout.status, sizeof(int32_t) * (size_t)C);
+  DOWN(out->status_step, dout.status_step, sizeof(int64_t) * (size_t)C);
+  DOWN(out->status_theta, dout.status_theta, sizeof(double) * (size_t)C * k);
+#undef DOWN
+  HCHK(hipStreamSynchronize(stream));
+  st->fresh = 0;
+  for (int64_t c = 0; c < C; c++)
+    if (out->status[c] != FMCMC_CHAIN_OK) {
+      // message of R/mcmc.R:759-765
+      set_err("fun(par) is undefined (chain %lld, status %d). Check either -fun- or the -lb- and -ub- "
+              "parameters. This error ocurred during step i = %lld",
+              (long long)(run->chain_base + c), out->status[c], (long long)out->status_step[c]);
+      rc = FMCMC_ERR_CHAIN;
+      break;
+    }
+done:
+  for (void* p : allocs) hipFree(p);
+  if (stream) hipStreamDestroy(stream);
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,188 @@
+"""Device-level front end of the HIP engine: torch tensors are only used as HBM buffers whose
+data_ptr() goes through the C-ABI (include/fmcmc_amd.h, fmcmc_mcmc_run_dev).  One call ==
+one MCMC_without_conv_checker over all local chains (R/mcmc.R:485-838)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _abi as abi
+
+DBL_MAX = float(np.finfo(np.float64).max)
+
+
+def _dev(device=None):
+    if not torch.cuda.is_available():
+        raise RuntimeError("fmcmc_amd needs an AMD GPU (HIP device); there is no CPU fallback.")
+    if device is None:
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device(device)
+
+
+def _t(a, dtype, device):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(device).contiguous()
+
+
+class DeviceModel:
+    """Shared read-only data of a log-posterior family, resident in HBM (fmcmc_model)."""
+
+    def __init__(self, family, X, y, intercept=True, guard=True, prior_div=0.0, device=None):
+        self.device = _dev(device)
+        if torch.is_tensor(y):
+            y = y.to(self.device, torch.float64).contiguous()
+        else:
+            y = _t(np.asarray(y, dtype=np.float64), torch.float64, self.device)
+        n = y.shape[0]
+        if X is None:
+            Xc, p = None, 0
+        else:
+            if torch.is_tensor(X):
+                X = X.to(self.device, torch.float64)
+                if X.ndim == 1:
+                    X = X[:, None]
+                Xc = X.t().contiguous()  # [p][n] == column-major n x p
+            else:
+                X = np.asarray(X, dtype=np.float64)
+                if X.ndim == 1:
+                    X = X[:, None]
+                Xc = _t(X.T, torch.float64, self.device)
+            p = Xc.shape[0]
+            if Xc.shape[1] != n:
+                raise ValueError("X has %d rows but y has %d" % (Xc.shape[1], n))
+            if p == 0:
+                Xc = None
+        self.family, self.Xc, self.y, self.n, self.p = family, Xc, y, int(n), int(p)
+        self.intercept, self.guard, self.prior_div = int(bool(intercept)), int(bool(guard)), float(prior_div)
+
+    @property
+    def k(self):
+        if self.family == abi.FAM_GAUSSIAN_LINREG:
+            return self.intercept + self.p + 1
+        if self.family == abi.FAM_LOGISTIC:
+            return self.intercept + self.p
+        return 2
+
+    def c(self):
+        return abi.Model(self.family, self.p, self.n, self.Xc.data_ptr() if self.Xc is not None else None,
+                         self.y.data_ptr(), self.intercept, self.guard, self.prior_div)
+
+
+class KernelSpec:
+    """Expanded (recycled) kernel parameters on the device (fmcmc_kernel)."""
+
+    def __init__(self, kind, k, mu, scale, lb, ub, fixed, scheme=abi.SCHEME_JOINT, freq=1, warmup=0,
+                 bw=0, until=float("inf"), eps=1e-4, arate=0.234, Sd=0.0, device=None):
+        self.device = _dev(device)
+        self.kind, self.k = int(kind), int(k)
+        self.h_fixed = np.ascontiguousarray(np.asarray(fixed, dtype=np.uint8))
+        self.kf = int((self.h_fixed == 0).sum())
+        self.mu = _t(mu, torch.float64, self.device)
+        self.scale = _t(scale, torch.float64, self.device)
+        self.lb = _t(lb, torch.float64, self.device)
+        self.ub = _t(ub, torch.float64, self.device)
+        self.fixed = _t(self.h_fixed, torch.uint8, self.device)
+        self.scheme, self.freq, self.warmup, self.bw = int(scheme), int(freq), int(warmup), int(bw)
+        self.until, self.eps, self.arate, self.Sd = float(until), float(eps), float(arate), float(Sd)
+
+    def c(self):
+        return abi.Kernel(self.kind, self.k, self.mu.data_ptr(), self.scale.data_ptr(), self.lb.data_ptr(),
+                          self.ub.data_ptr(), self.fixed.data_ptr(), self.scheme, self.freq, self.warmup,
+                          self.bw, self.until, self.eps, self.arate, self.Sd)
+
+
+class ChainState:
+    """fmcmc_state in HBM: last row of every chain + the kernels' persistent environments."""
+
+    def __init__(self, initial, kf, device=None):
+        self.device = _dev(device)
+        th = torch.as_tensor(np.ascontiguousarray(initial), dtype=torch.float64) if not torch.is_tensor(initial) else initial
+        self.theta0 = th.to(self.device, torch.float64).contiguous().clone()
+        Cn = self.theta0.shape[0]
+        z = dict(device=self.device)
+        self.f0 = torch.zeros(Cn, dtype=torch.float64, **z)
+        self.abs_iter = torch.zeros(Cn, dtype=torch.int64, **z)
+        self.Sigma = torch.zeros(Cn, kf, kf, dtype=torch.float64, **z)
+        self.mean_prev = torch.zeros(Cn, kf, dtype=torch.float64, **z)
+        self.have_mean = torch.zeros(Cn, dtype=torch.int32, **z)
+        self.nerrors = torch.zeros(Cn, dtype=torch.int32, **z)
+        self.fresh = 1
+        self.step_base = 0
+
+    def c(self):
+        return abi.State(self.theta0.data_ptr(), self.f0.data_ptr(), self.abs_iter.data_ptr(),
+                         self.Sigma.data_ptr(), self.mean_prev.data_ptr(), self.have_mean.data_ptr(),
+                         self.nerrors.data_ptr(), self.fresh, 0)
+
+
+class SweepResult:
+    pass
+
+
+def kept_rows(nsteps, burnin, thin):
+    return (nsteps - burnin) // thin
+
+
+def sweep(model, kernel, state, nsteps, burnin=0, thin=1, seed=0, chain_base=0,
+          want_logpost=True, want_draws=True, want_bits=True, fed_logu=None, fed_z=None,
+          stream=None, check=True):
+    """Enqueue one sweep (all local chains, nsteps iterations) and return the output tensors.
+
+    Raises ValueError for argument errors (messages mirror the reference's stop() texts) and
+    RuntimeError for chain errors ("fun(par) is undefined", R/mcmc.R:758-765)."""
+    L = abi.lib()
+    dev = state.device
+    Cn, k = state.theta0.shape
+    S = kept_rows(nsteps, burnin, thin)
+    if S < 0:
+        S = 0
+    nwords = (nsteps + 31) // 32
+    out = SweepResult()
+    f64 = dict(dtype=torch.float64, device=dev)
+    out.samples = torch.full((Cn, k, max(S, 0)), float("nan"), **f64)
+    out.logpost = torch.empty((Cn, S), **f64) if want_logpost else None
+    out.draws = torch.empty((Cn, k, S), **f64) if want_draws else None
+    out.accept_count = torch.zeros(Cn, dtype=torch.int64, device=dev)
+    out.accept_bits = torch.zeros((Cn, nwords), dtype=torch.int32, device=dev) if want_bits else None
+    out.status = torch.zeros(Cn, dtype=torch.int32, device=dev)
+    out.status_step = torch.zeros(Cn, dtype=torch.int64, device=dev)
+    out.status_theta = torch.zeros((Cn, k), **f64)
+    rng_mode = abi.RNG_FED if fed_logu is not None else abi.RNG_PHILOX
+    crun = abi.Run(Cn, nsteps, burnin, thin, seed & 0xFFFFFFFFFFFFFFFF, chain_base, state.step_base,
+                   rng_mode, 0, fed_logu.data_ptr() if fed_logu is not None else None,
+                   fed_z.data_ptr() if fed_z is not None else None)
+    cout = abi.Out(out.samples.data_ptr(), out.logpost.data_ptr() if want_logpost else None,
+                   out.draws.data_ptr() if want_draws else None, out.accept_count.data_ptr(),
+                   out.accept_bits.data_ptr() if want_bits else None, out.status.data_ptr(),
+                   out.status_step.data_ptr(), out.status_theta.data_ptr())
+    cm, ck, cs = model.c(), kernel.c(), state.c()
+    if stream is None:
+        stream = torch.cuda.current_stream(dev)
+    with torch.cuda.device(dev):
+        rc = L.fmcmc_mcmc_run_dev(C.byref(cm), C.byref(ck), C.byref(crun), C.byref(cs), C.byref(cout),
+                                  C.c_void_p(stream.cuda_stream))
+    if rc in (abi.ERR_ARG, abi.ERR_UNSUPPORTED):
+        raise ValueError(abi.last_error())
+    if rc != abi.OK:
+        raise RuntimeError("fmcmc_mcmc_run_dev failed (%d): %s" % (rc, abi.last_error()))
+    state.fresh = 0
+    state.step_base += nsteps
+    out.iters = burnin + thin * np.arange(1, S + 1)
+    out.thin, out.nsteps, out.burnin = thin, nsteps, burnin
+    if check:
+        raise_on_chain_error(out, chain_base)
+    return out
+
+
+def raise_on_chain_error(out, chain_base=0):
+    st = out.status.cpu().numpy()
+    bad = np.nonzero(st)[0]
+    if bad.size:
+        c = int(bad[0])
+        step = int(out.status_step[c].item())
+        theta = out.status_theta[c].cpu().numpy()
+        what = {abi.CHAIN_NAN_LOGPOST: "fun(par) is undefined (NaN).",
+                abi.CHAIN_NAN_RATIO: "fun(par) is undefined (f1 - f0 is NaN).",
+                abi.CHAIN_NOT_PD: "'Sigma' is not positive definite."}.get(int(st[c]), "chain error.")
+        raise RuntimeError(
+            "%s Check either -fun- or the -lb- and -ub- parameters. This error ocurred during step i = %d "
+            "(chain %d) and proposal parameters theta1 = %s" % (what, step, chain_base + c, np.array2string(theta, precision=4)))

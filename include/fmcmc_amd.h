@@ -172,12 +172,25 @@ int fmcmc_mcmc_run_host(const fmcmc_model* model, const fmcmc_kernel* kernel,
  * doubles: {m, sum xbar[p], sum xbar xbar^T[p*p], sum S_c[p*p], sum s2[p], sum s2^2[p],
  * sum s2*xbar[p], sum s2*xbar^2[p]}.  Partials of different GPUs add (one all-reduce). */
 int64_t fmcmc_gelman_partial_len(int32_t p);
+/* doubles of scratch (device) the partial kernel needs: per chain xbar[p] and S_c[p][p] */
+int64_t fmcmc_gelman_work_len(int64_t nchains, int32_t p);
+/* cols[p]: parameter indices to test (the free parameters, R/mcmc.R:950-968), device int32.
+ * center[p] (device, may be NULL): xbar sums are accumulated relative to it (all ranks must
+ * pass the same vector); it only limits cancellation, R-hat is shift-invariant. */
 int fmcmc_gelman_partial_dev(const double* samples, int64_t nchains, int32_t k, int64_t S,
                              int64_t row0, int64_t N, const int32_t* cols, int32_t p,
-                             double* partial, void* hip_stream);
-/* Host finish: psrf[p][2] (point est., upper CI is NaN here), mpsrf. */
+                             const double* center, double* work, double* partial,
+                             void* hip_stream);
+/* Host finish on the (all-reduced) partial: psrf[p] point estimates, *mpsrf (NaN if p == 1).
+ * Returns FMCMC_ERR_CHAIN when W is not positive definite (gelman.diag would fail). */
 int fmcmc_gelman_finish(const double* partial, int32_t p, int64_t N, double* psrf,
                         double* mpsrf);
+
+/* Diagnostic: evaluate the canonical math / RNG primitives on the device, element-wise
+ * (which: 0 log, 1 exp, 2 log1p, 3 qnorm, 4 log accept-u, 5 normal, 6 student-t(df=x), 7 sqrt,
+ * 8 reciprocal). Used by tests to prove host/device bit-equality of include/fmh_*.h. */
+int fmcmc_detmath_dev(int which, const double* x, double* out, int64_t n, uint64_t seed,
+                      void* hip_stream);
 
 #ifdef __cplusplus
 }

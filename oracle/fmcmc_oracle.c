@@ -865,6 +865,20 @@ void fmcmc_oracle_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uin
   fmh_u32x4 r = fmh_philox4x32_10(c0, c1, c2, c3, k0, k1);
   for (int a = 0; a < 4; a++) out4[a] = r.v[a];
 }
+/* twin of the device diagnostic fmcmc_detmath_dev (which 4..8) */
+void fmcmc_oracle_detmath_rng(int which, const double* x, double* out, int64_t n, uint64_t seed) {
+  for (int64_t i = 0; i < n; i++) {
+    uint32_t step = (uint32_t)(i & 0xffff), chain = (uint32_t)(i >> 16), j = (uint32_t)(i % 7);
+    switch (which) {
+      case 4: out[i] = fmh_log_accept_u(seed, step, chain); break;
+      case 5: out[i] = fmh_normal(seed, step, chain, j); break;
+      case 6: out[i] = fmh_student_t(seed, step, chain, j, x[i]); break;
+      case 7: out[i] = fmh_sqrt(x[i]); break;
+      case 8: out[i] = 1.0 / x[i]; break;
+      default: out[i] = NAN;
+    }
+  }
+}
 /* canonical draws: kind 0 = log accept u, 1 = normal j, 2 = student t (df) j */
 double fmcmc_oracle_canon_draw(int kind, uint64_t seed, uint32_t step, uint32_t chain, uint32_t j,
                                double df) {

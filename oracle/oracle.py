@@ -111,6 +111,7 @@ def lib():
         L.fmcmc_oracle_gelman.restype = C.c_int
         L.fmcmc_oracle_gelman.argtypes = [_dp, C.c_int64, C.c_int, C.c_int64, _dp, _dp]
         L.fmcmc_oracle_detmath.argtypes = [C.c_int, _dp, _dp, C.c_int64]
+        L.fmcmc_oracle_detmath_rng.argtypes = [C.c_int, _dp, _dp, C.c_int64, C.c_uint64]
         L.fmcmc_oracle_philox.argtypes = [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)]
         L.fmcmc_oracle_canon_draw.restype = C.c_double
         L.fmcmc_oracle_canon_draw.argtypes = [C.c_int, C.c_uint64, C.c_uint32, C.c_uint32,

@@ -1,0 +1,198 @@
+"""GPU parity: the HIP engine (through the C-ABI) must be BIT-IDENTICAL to the oracle's
+PHILOX/canonical mode on the same seeded inputs: samples, proposals, log-posteriors, accept
+bitmap and the persistent kernel state.  All tests here need a real MI355X."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import synth_linreg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def E():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from fmcmc_amd import engine, _abi
+    _abi.lib()
+    return engine
+
+
+def _bits_equal(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+    b = np.ascontiguousarray(b, dtype=np.float64).view(np.uint64)
+    return np.array_equal(a, b)
+
+
+def run_both(E, O, fam, X, y, kind, k, initial, nsteps, burnin=0, thin=1, seed=1215, chain_base=0,
+             calls=1, intercept=True, guard=True, prior_div=0.0, **kw):
+    """Runs `calls` consecutive sweeps on GPU and oracle; asserts bit-equality after each."""
+    from fmcmc_amd import _abi as abi
+    om = O.Model(fam, X, y, intercept=intercept, guard=guard, prior_div=prior_div)
+    ok = O.Kernel(kind, k, **kw)
+    gm = E.DeviceModel(fam, X, y, intercept=intercept, guard=guard, prior_div=prior_div)
+    gk = E.KernelSpec(kind, k, ok.mu, ok.scale, ok.lb, ok.ub, ok.fixed, scheme=ok.scheme, freq=ok.freq,
+                      warmup=ok.warmup, bw=ok.bw, until=ok.until, eps=ok.eps, arate=ok.arate, Sd=ok.Sd)
+    initial = np.ascontiguousarray(initial, dtype=np.float64)
+    ost = O.ChainState(initial, ok.kf)
+    gst = E.ChainState(initial, ok.kf)
+    res = None
+    for _ in range(calls):
+        ro = O.run(om, ok, nsteps=nsteps, burnin=burnin, thin=thin, seed=seed, chain_base=chain_base,
+                   state=ost)
+        rg = E.sweep(gm, gk, gst, nsteps, burnin=burnin, thin=thin, seed=seed, chain_base=chain_base,
+                     check=False)
+        import torch
+        torch.cuda.synchronize()
+        assert np.array_equal(rg.status.cpu().numpy(), ro.status)
+        assert np.array_equal(rg.accept_bits.cpu().numpy().view(np.uint32), ro.accept_bits), "accept bitmap"
+        assert np.array_equal(rg.accept_count.cpu().numpy(), ro.accept_count)
+        good = ro.status == 0
+        assert _bits_equal(rg.samples.cpu().numpy()[good], ro.samples_cks[good]), "samples"
+        assert _bits_equal(rg.draws.cpu().numpy()[good], ro.draws_cks[good]), "draws"
+        assert _bits_equal(rg.logpost.cpu().numpy()[good], ro.logpost[good]), "logpost"
+        assert _bits_equal(gst.theta0.cpu().numpy(), ost.theta0)
+        assert _bits_equal(gst.f0.cpu().numpy()[good], ost.f0[good])
+        if kind in (O.K_ADAPT, O.K_RAM):
+            assert np.array_equal(gst.abs_iter.cpu().numpy(), ost.abs_iter)
+            assert _bits_equal(gst.Sigma.cpu().numpy(), ost.Sigma), "Sigma"
+            assert np.array_equal(gst.nerrors.cpu().numpy(), ost.nerrors)
+        if kind == O.K_ADAPT:
+            assert np.array_equal(gst.have_mean.cpu().numpy(), ost.have_mean)
+            hm = ost.have_mean.astype(bool)
+            assert _bits_equal(gst.mean_prev.cpu().numpy()[hm], ost.mean_prev[hm])
+        res = (rg, ro)
+    return res
+
+
+def jitter_init(base, C, seed):
+    rng = np.random.default_rng(seed)
+    return np.asarray(base)[None, :] + 0.1 * rng.standard_normal((C, len(base)))
+
+
+def test_detmath_device_equals_host(E, O):
+    """include/fmh_detmath.h + fmh_philox.h: device bits == host bits, 1M points each."""
+    import torch
+    from fmcmc_amd import _abi as abi
+    rng = np.random.default_rng(7)
+    n = 1 << 20
+    cases = {0: np.exp(rng.uniform(-700, 700, n)), 1: rng.uniform(-745, 709, n),
+             2: np.concatenate([rng.uniform(-0.999, 50, n // 2), rng.uniform(-1e-3, 1e-3, n // 2)]),
+             3: np.concatenate([rng.uniform(0, 1, n // 2), np.exp(rng.uniform(-36, 0, n // 2))]),
+             4: np.zeros(n), 5: np.zeros(n), 6: rng.integers(1, 60, n).astype(np.float64),
+             7: np.exp(rng.uniform(-700, 700, n)), 8: np.exp(rng.uniform(-700, 700, n))}
+    for which, x in cases.items():
+        x = np.ascontiguousarray(x)
+        xd = torch.as_tensor(x).cuda()
+        od = torch.empty_like(xd)
+        rc = abi.lib().fmcmc_detmath_dev(which, xd.data_ptr(), od.data_ptr(), n, 99, None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        host = np.empty(n)
+        if which < 4:
+            O.lib().fmcmc_oracle_detmath(which, O._p(x), O._p(host), n)
+        else:
+            O.lib().fmcmc_oracle_detmath_rng(which, O._p(x), O._p(host), n, 99)
+        assert _bits_equal(od.cpu().numpy(), host), "detmath function %d differs between host and device" % which
+
+
+@pytest.mark.parametrize("C,n,p", [(1, 200, 1), (3, 1000, 1), (5, 777, 3), (64, 2048, 3), (300, 1000, 2)])
+def test_normal_linreg(E, O, C, n, p):
+    X, y = synth_linreg(n, p, 11 + n)
+    init = jitter_init([0.0] * (p + 1) + [float(np.std(y))], C, 5)
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, p + 2, init, nsteps=300, scale=0.05)
+
+
+def test_readme_first_run_philox(E, O, readme_data):
+    X, y = readme_data
+    rg, ro = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 3, [[0, 0, O.r_sd(y)]] * 2, nsteps=2000)
+    assert ro.accept_count.sum() > 0
+
+
+def test_burnin_thin_and_continuation(E, O):
+    X, y = synth_linreg(1500, 3, 3)
+    init = jitter_init([0, 0, 0, 0, 4.0], 7, 1)
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=257, burnin=50, thin=7, calls=3,
+             scale=0.03)
+
+
+def test_chain_base_sharding_invariance(E, O):
+    """chains [4,8) of an 8-chain job run as their own shard give the same bits."""
+    X, y = synth_linreg(900, 2, 9)
+    init = jitter_init([0, 0, 0, 4.0], 8, 2)
+    rg_all, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 4, init, nsteps=200, scale=0.05)
+    rg_hi, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 4, init[4:], nsteps=200, scale=0.05,
+                        chain_base=4)
+    assert _bits_equal(rg_all.samples.cpu().numpy()[4:], rg_hi.samples.cpu().numpy())
+
+
+def test_fixed_and_ordered(E, O):
+    X, y = synth_linreg(600, 2, 4)
+    init = jitter_init([0, 0, 0, 4.0], 4, 3)
+    rg, ro = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 4, init, nsteps=300, scale=0.05,
+                      fixed=[False, True, False, False])
+    assert np.all(ro.samples[:, :, 1] == init[:, 1][:, None])  # fixed parameter never moves
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 4, init, nsteps=300, scale=0.1, scheme="ordered")
+
+
+def test_reflective(E, O, readme_data):
+    X, y = readme_data
+    rg, ro = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL_REFLECTIVE, 3, [[0, 0, O.r_sd(y)]] * 3,
+                      nsteps=1500, guard=False, scale=0.5, ub=5.0, lb=[-5.0, 0.0, 0.0])
+    d = ro.draws
+    assert d[:, :, 0].min() >= -5 and d.max() <= 5 and d[:, :, 1:].min() >= 0
+
+
+def test_adapt(E, O):
+    X, y = synth_linreg(800, 3, 21)
+    init = jitter_init([3, 2, -1, .5, 4.0], 6, 4)
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_ADAPT, 5, init, nsteps=400, calls=2, warmup=100)
+
+
+def test_ram(E, O):
+    X, y = synth_linreg(800, 3, 22)
+    init = jitter_init([3, 2, -1, .5, 4.0], 6, 5)
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, 5, init, nsteps=400, calls=2)
+
+
+def test_ram_bounded(E, O, readme_data):
+    X, y = readme_data
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, 3, [[3, 2, 4.0]] * 4, nsteps=600, ub=[3.3, 5, 5],
+             lb=[-5.0, 0.0, 0.0])
+
+
+def test_ram_k20(E, O):
+    X, y = synth_linreg(1000, 7, 23)
+    init = jitter_init([3, 2, -1, .5, .25, -.75, 1.5, -2, 4.0], 5, 6)
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, 9, init, nsteps=300)
+
+
+def test_logistic(E, O):
+    rng = np.random.default_rng(31)
+    n, p = 1200, 4
+    X = rng.standard_normal((n, p))
+    beta = np.array([-1, .5, -.5, .25, -.25])
+    y = (rng.uniform(size=n) < 1 / (1 + np.exp(-(beta[0] + X @ beta[1:])))).astype(np.float64)
+    init = jitter_init(beta, 5, 8)
+    run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_NORMAL_REFLECTIVE, 5, init, nsteps=300, prior_div=8.0,
+             scale=0.05, lb=-5.0, ub=5.0)
+
+
+def test_iid_normal(E, O):
+    rng = np.random.default_rng(1231)
+    D = rng.normal(2.6, 3, 1000)
+    run_both(E, O, O.FAM_IID_NORMAL, None, D, O.K_NORMAL_REFLECTIVE, 2, [[1.0, 1.0]] * 3, nsteps=500,
+             guard=False, scale=0.1, lb=0.0, ub=10.0)
+
+
+def test_nan_logpost_is_reported(E, O):
+    """README.md:356-361 ll without the guard: sigma < 0 -> NaN -> 'fun(par) is undefined'."""
+    X, y = synth_linreg(300, 1, 2)
+    rg, ro = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 3, [[0, 0, 0.05]] * 2, nsteps=200,
+                      guard=False, scale=1.0)
+    assert (ro.status == 1).any()
+    with pytest.raises(RuntimeError, match="undefined"):
+        E.raise_on_chain_error(rg)
