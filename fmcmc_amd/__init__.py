@@ -1,0 +1,13 @@
+"""fmcmc_amd: MI355X-native many-chain Metropolis-Hastings engine, a drop-in for the hot path of
+USCbiostats/fmcmc (MCMC(), kernel_*(), convergence_gelman()).  See DESIGN.md / INTEGRATION.md."""
+from .kernels import (kernel_normal, kernel_normal_reflective, kernel_adapt, kernel_am, kernel_ram,
+                      fmcmc_kernel, check_dimensions, process_bounds)
+from .models import gaussian_linreg, logistic, iid_normal, LogPosterior
+from .mcmc import (MCMC, MCMC_without_conv_checker, MCMC_with_conv_checker, Mcmc, McmcList, check_initial,
+                   append_chains, get_logpost, get_draws, get_elapsed, shard_bounds, DeviceChains)
+from .convergence import convergence_gelman
+
+__all__ = ["MCMC", "MCMC_without_conv_checker", "MCMC_with_conv_checker", "kernel_normal",
+           "kernel_normal_reflective", "kernel_adapt", "kernel_am", "kernel_ram", "gaussian_linreg",
+           "logistic", "iid_normal", "convergence_gelman", "Mcmc", "McmcList", "check_initial",
+           "append_chains", "get_logpost", "get_draws", "get_elapsed", "shard_bounds"]

@@ -22,6 +22,7 @@
 #include <string.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <math.h>
 #include <float.h>
 #include <vector>
@@ -63,7 +64,7 @@ struct SweepArgs {
   // run
   long long nchains, nsteps, burnin, thin, S, chain_base, step_base;
   unsigned long long seed;
-  int rng_mode, fresh, ram_bounded, kz;
+  int rng_mode, fresh, ram_bounded, kz, tb;
   const double* fed_logu;
   const double* fed_z;
   // state
@@ -155,7 +156,7 @@ __device__ __forceinline__ ChainLds chain_lds(double* base, int k, int kf, int k
   return c;
 }
 
-// ---- workgroup-collective log-posterior partial sums -------------------------------------
+// ---- workgroup-collective log-posterior partial sums (streamed variant) ------------------
 // Every thread accumulates its canonical lane for all CW chains, then the wavefront butterfly
 // (levels 1..32) runs and lane 0 of each wavefront publishes its partial to s_part[w][c].
 template <int CW>
@@ -215,12 +216,8 @@ __device__ __forceinline__ void eval_partials(const SweepArgs& A, double* const*
   }
 }
 
-// levels 64,128,256 of the canonical tree + the family's closed form. Uniform over the wave.
-template <int CW>
-__device__ __forceinline__ double finish_logpost(const SweepArgs& A, const double* th, const double* s_part, int c) {
-  double w0 = s_part[0 * CW + c], w1 = s_part[1 * CW + c], w2 = s_part[2 * CW + c], w3 = s_part[3 * CW + c];
-  double w4 = s_part[4 * CW + c], w5 = s_part[5 * CW + c], w6 = s_part[6 * CW + c], w7 = s_part[7 * CW + c];
-  double tot = ((w0 + w1) + (w2 + w3)) + ((w4 + w5) + (w6 + w7));
+// closed form of the family given the canonical total `tot`. Uniform over the wave.
+__device__ __forceinline__ double finish_logpost(const SweepArgs& A, const double* th, double tot) {
   double f;
   if (A.family == FMCMC_FAM_LOGISTIC) {
     f = tot;
@@ -249,12 +246,23 @@ __device__ __forceinline__ double finish_logpost(const SweepArgs& A, const doubl
 }
 
 // ---- the sweep kernel ----------------------------------------------------------------------
-template <int CW>
-__global__ __launch_bounds__(NT) void mh_sweep_kernel(const SweepArgs A) {
+// P < 0 : streamed evaluation (any family, any n, p: data re-read from L2 every step)
+// P >= 0: register-resident Gaussian linear regression with P covariates: each thread keeps its
+//         OPT observations (x[P], y) in VGPRs for the whole sweep; n in (512*(OPT-4), 512*OPT].
+constexpr int RES_MASKED = 4;  // trailing observation slots that carry a validity mask
+
+// KIND > 0 compiles exactly one proposal kernel in (resident variants); KIND == 0 keeps all four
+// behind the runtime A.kind (streamed variants).
+template <int CW, int P, int OPT, int KIND>
+__global__ __launch_bounds__(NT) void mh_sweep_kernel(const SweepArgs A0) {
+  constexpr bool RESIDENT = (P >= 0);
+  SweepArgs A = A0;
+  if constexpr (KIND > 0) A.kind = KIND;
   extern __shared__ double smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int k = A.k;
-  // ---- shared layout: kernel parameters, which[], partials, then CW chain blocks
+  const int TB = A.tb, kz = A.kz;
+  // ---- shared layout: kernel parameters, which[], partials, RNG tile, then CW chain blocks
   double* s_mu = smem;
   double* s_scale = s_mu + k;
   double* s_lb = s_scale + k;
@@ -262,7 +270,10 @@ __global__ __launch_bounds__(NT) void mh_sweep_kernel(const SweepArgs A) {
   int* s_which = (int*)(s_ub + k);          // [k] ints (k/2+1 doubles)
   double* s_part = s_ub + k + (k / 2 + 1);  // [NW*CW]
   int* s_flag = (int*)(s_part + NW * CW);   // [2] ints
-  double* s_chains = s_part + NW * CW + 1;
+  double* s_zt = s_part + NW * CW + 1;      // [CW][TB][kz] proposal variates of the tile
+  double* s_lu = s_zt + CW * TB * kz;       // [CW][TB]     log accept uniforms of the tile
+  double* s_tr = s_lu + CW * TB;            // RESIDENT: [CW][NT] lane partials
+  double* s_chains = s_tr + (RESIDENT ? CW * NT : 0);
 
   __shared__ int s_kf;
   if (tid == 0) {
@@ -296,6 +307,74 @@ __global__ __launch_bounds__(NT) void mh_sweep_kernel(const SweepArgs A) {
   double* thp[CW];
 #pragma unroll
   for (int c = 0; c < CW; c++) thp[c] = s_chains + (c < ncw ? c : 0) * CHS + k;  // th1 of chain c
+
+  // ---- RESIDENT: this thread's observations live in registers for the whole sweep
+  constexpr int PR = RESIDENT ? (P > 0 ? P : 1) : 1;
+  constexpr int OR = RESIDENT ? OPT : 1;
+  double xr[OR][PR];
+  double yr[OR];
+  double wm[RES_MASKED];
+  if constexpr (RESIDENT) {
+#pragma unroll
+    for (int s = 0; s < OPT; s++) {
+      const long long i = (long long)tid + (long long)NT * s;
+      const bool valid = i < A.n;
+      yr[s] = valid ? A.y[i] : 0.0;
+#pragma unroll
+      for (int j = 0; j < P; j++) xr[s][j] = valid ? A.X[(long long)j * A.n + i] : 0.0;
+      if (s >= OPT - RES_MASKED) wm[s - (OPT - RES_MASKED)] = valid ? 1.0 : 0.0;
+    }
+  }
+
+  // collective evaluation of f(theta1) for all chains of the workgroup; on return s_part holds
+  // what finish needs (streamed: 8 wave partials per chain; resident: 2 half totals per chain)
+  auto evaluate = [&]() {
+    if constexpr (RESIDENT) {
+      double m0[CW], bb[CW][PR], acc[CW];
+#pragma unroll
+      for (int c = 0; c < CW; c++) {
+        m0[c] = A.intercept ? thp[c][0] : 0.0;
+#pragma unroll
+        for (int j = 0; j < P; j++) bb[c][j] = thp[c][A.intercept + j];
+        acc[c] = 0.0;
+      }
+#pragma unroll
+      for (int s = 0; s < OPT; s++) {
+#pragma unroll
+        for (int c = 0; c < CW; c++) {
+          double m = m0[c];
+#pragma unroll
+          for (int j = 0; j < P; j++) m = fmh_fma(xr[s][j], bb[c][j], m);
+          double r = yr[s] - m;
+          if (s >= OPT - RES_MASKED) acc[c] = fmh_fma(r * wm[s - (OPT - RES_MASKED)], r, acc[c]);
+          else acc[c] = fmh_fma(r, r, acc[c]);
+        }
+      }
+      // canonical tree through LDS: lane partials -> [chain][lane]; wave (c, h) folds 256 lanes
+#pragma unroll
+      for (int c = 0; c < CW; c++) s_tr[c * NT + tid] = acc[c];
+      __syncthreads();
+      for (int job = wave; job < 2 * CW; job += NW) {
+        const int c = job % CW, h = job / CW;
+        const double* src = s_tr + c * NT + 256 * h + 4 * lane;
+        double v = (src[0] + src[1]) + (src[2] + src[3]);      // levels 1, 2
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) v = v + __shfl_xor(v, sft, 64);  // levels 4..128
+        if (lane == 0) s_part[h * CW + c] = v;
+      }
+    } else {
+      eval_partials<CW>(A, thp, s_part);
+    }
+  };
+  auto total_of = [&](int c) -> double {
+    if constexpr (RESIDENT) {
+      return s_part[0 * CW + c] + s_part[1 * CW + c];           // level 256
+    } else {
+      double w0 = s_part[0 * CW + c], w1 = s_part[1 * CW + c], w2 = s_part[2 * CW + c], w3 = s_part[3 * CW + c];
+      double w4 = s_part[4 * CW + c], w5 = s_part[5 * CW + c], w6 = s_part[6 * CW + c], w7 = s_part[7 * CW + c];
+      return ((w0 + w1) + (w2 + w3)) + ((w4 + w5) + (w6 + w7));  // levels 64, 128, 256
+    }
+  };
 
   // ---- per-chain registers of the owner wavefront (uniform across its lanes)
   double f0 = 0.0, f1 = 0.0;
@@ -336,30 +415,71 @@ __global__ __launch_bounds__(NT) void mh_sweep_kernel(const SweepArgs A) {
   __syncthreads();
 
   // ---- row 1: f0 = f(initial)
-  eval_partials<CW>(A, thp, s_part);
+  evaluate();
   __syncthreads();
   const long long S = A.S;
-  auto store_row = [&](long long r, double lpv) {
-    if (r > A.burnin && ((r - A.burnin) % A.thin) == 0) {
-      long long s = (r - A.burnin) / A.thin - 1;
-      if (lane < k) {
-        A.samples[(cl * k + lane) * S + s] = L.th0[lane];
-        if (A.draws) A.draws[(cl * k + lane) * S + s] = L.th1[lane];
+  // row bookkeeping without integer division: `thin_ctr` counts rows since the last kept one
+  const int nsteps = (int)A.nsteps, burnin = (int)A.burnin, thin = (int)A.thin;
+  int thin_ctr = 0;       // (r - burnin) mod thin for r > burnin
+  long long srow = 0;     // next kept-row index
+  double* const out_s = A.samples + (cl * k + (lane < k ? lane : 0)) * S;
+  double* const out_d = A.draws ? A.draws + (cl * k + (lane < k ? lane : 0)) * S : nullptr;
+  double* const out_l = A.logpost ? A.logpost + cl * S : nullptr;
+  auto store_row = [&](int r, double lpv) {
+    if (r > burnin) {
+      thin_ctr += 1;
+      if (thin_ctr == thin) {
+        thin_ctr = 0;
+        if (lane < k) {
+          out_s[srow] = L.th0[lane];
+          if (out_d) out_d[srow] = L.th1[lane];
+        }
+        if (out_l && lane == 0) out_l[srow] = lpv;
+        srow += 1;
       }
-      if (A.logpost && lane == 0) A.logpost[cl * S + s] = lpv;
     }
   };
   if (owner) {
-    f0 = finish_logpost<CW>(A, L.th1, s_part, myc);
+    f0 = finish_logpost(A, L.th1, total_of(myc));
     f1 = f0;
     if (lane < kf) L.vrs[lane] = L.th0[s_which[lane]];
     store_row(1, f0);
   }
 
   // ---- main loop
-  for (long long i = 2; i <= A.nsteps; i++) {
-    const unsigned int step = (unsigned int)(A.step_base + i);
+  int tt = -1;         // position inside the RNG tile
+  int ord = 0;         // ordered scheme: (i - 1) mod kf
+  for (int i = 2; i <= nsteps; i++) {
+    tt = (tt + 1 == TB) ? 0 : tt + 1;
+    ord = (ord + 1 == kf) ? 0 : ord + 1;
     bool ram_gate = false;
+    // ================= RNG tile: all 512 threads draw the variates of the next TB steps ===========
+    if (tt == 0) {
+      __syncthreads();  // owners are done with the previous tile (and with s_part)
+      const int per_c = TB * (kz + 1);
+      for (int idx = tid; idx < CW * per_c; idx += NT) {
+        const int c = idx / per_c, rem = idx - c * per_c;
+        const int t = rem / (kz + 1), a = rem - t * (kz + 1);
+        const long long ii = (long long)i + t;
+        if (c < ncw && ii <= A.nsteps) {
+          const long long clc = cg0 + c;
+          const unsigned int cg = (unsigned int)(A.chain_base + clc);
+          const unsigned int st = (unsigned int)(A.step_base + ii);
+          double v;
+          if (a == kz) {
+            v = (A.rng_mode == FMCMC_RNG_FED) ? A.fed_logu[clc * A.nsteps + (ii - 1)] : fmh_log_accept_u(A.seed, st, cg);
+            s_lu[c * TB + t] = v;
+          } else {
+            if (A.rng_mode == FMCMC_RNG_FED) v = A.fed_z[(clc * A.nsteps + (ii - 1)) * kz + a];
+            else if (A.kind == FMCMC_KERNEL_RAM) v = fmh_student_t(A.seed, st, cg, (unsigned int)a, (double)kf);
+            else v = fmh_normal(A.seed, st, cg, (unsigned int)a);
+            s_zt[(c * TB + t) * kz + a] = v;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    const double* zt = s_zt + ((owner ? myc : 0) * TB + tt) * kz;
     // ================= scalar phase A: proposal =================
     if (owner && status == FMCMC_CHAIN_OK) {
       if (A.kind == FMCMC_KERNEL_NORMAL || A.kind == FMCMC_KERNEL_NORMAL_REFLECTIVE) {
@@ -368,10 +488,8 @@ __global__ __launch_bounds__(NT) void mh_sweep_kernel(const SweepArgs A) {
         const bool refl = (A.kind == FMCMC_KERNEL_NORMAL_REFLECTIVE);
         const int nupd = (A.scheme == FMCMC_SCHEME_ORDERED) ? 1 : kf;
         if (lane < nupd) {
-          int j = (A.scheme == FMCMC_SCHEME_ORDERED) ? s_which[(int)((i - 1) % kf)] : s_which[lane];
-          double z = (A.rng_mode == FMCMC_RNG_FED)
-                         ? A.fed_z[(cl * A.nsteps + (i - 1)) * A.kz + lane]
-                         : fmh_normal(A.seed, step, cgid, (unsigned int)lane);
+          int j = (A.scheme == FMCMC_SCHEME_ORDERED) ? s_which[ord] : s_which[lane];
+          double z = zt[lane];
           double t = L.th0[j] + (s_mu[j] + s_scale[j] * z);
           if (refl) t = reflect1(t, s_lb[j], s_ub[j]);
           L.th1[j] = t;
@@ -403,11 +521,6 @@ __global__ __launch_bounds__(NT) void mh_sweep_kernel(const SweepArgs A) {
           have_mean = 1;
         }
         abs_iter += 1;
-        if (lane < kf)
-          L.vz[lane] = (A.rng_mode == FMCMC_RNG_FED)
-                           ? A.fed_z[(cl * A.nsteps + (i - 1)) * A.kz + lane]
-                           : fmh_normal(A.seed, step, cgid, (unsigned int)lane);
-        wave_sync();
         // left-looking Cholesky, lane = row (twin of oracle chol_lower_canon)
         bool notpd = false;
         for (int j = 0; j < kf; j++) {
@@ -430,21 +543,16 @@ __global__ __launch_bounds__(NT) void mh_sweep_kernel(const SweepArgs A) {
           wave_sync();
           if (lane < kf) {
             double s = 0.0;
-            for (int b = 0; b <= lane; b++) s = fmh_fma(L.SigB[lane * LD + b], L.vz[b], s);
+            for (int b = 0; b <= lane; b++) s = fmh_fma(L.SigB[lane * LD + b], zt[b], s);
             int j = s_which[lane];
             double t = L.th0[j] + (s_mu[j] + s);
             L.th1[j] = reflect1(t, s_lb[j], s_ub[j]);
           }
         }
       } else {  // RAM, R/kernel_ram.R:123-126
-        if (lane < kf)
-          L.vz[lane] = (A.rng_mode == FMCMC_RNG_FED)
-                           ? A.fed_z[(cl * A.nsteps + (i - 1)) * A.kz + lane]
-                           : fmh_student_t(A.seed, step, cgid, (unsigned int)lane, (double)kf);
-        wave_sync();
         if (lane < kf) {
           double s = 0.0;
-          for (int b = 0; b <= lane; b++) s = fmh_fma(Scur[lane * LD + b], L.vz[b], s);
+          for (int b = 0; b <= lane; b++) s = fmh_fma(Scur[lane * LD + b], zt[b], s);
           L.vv[lane] = s;
           int j = s_which[lane];
           L.th1[j] = L.th0[j] + s;
@@ -458,21 +566,21 @@ __global__ __launch_bounds__(NT) void mh_sweep_kernel(const SweepArgs A) {
     }
     __syncthreads();
     // ================= collective evaluation of f(theta1) =================
-    eval_partials<CW>(A, thp, s_part);
+    evaluate();
     __syncthreads();
     // ================= scalar phase B: RAM adaptation (needs f(theta1) un-reflected) =================
     if (A.kind == FMCMC_KERNEL_RAM) {
       bool changed = false;
       if (owner && status == FMCMC_CHAIN_OK) {
         if (ram_gate) {
-          double f1u = finish_logpost<CW>(A, L.th1, s_part, myc);
+          double f1u = finish_logpost(A, L.th1, total_of(myc));
           double a_n = fmh_exp(f1u - f0);
           if (fmh_isnan(a_n)) a_n = 0.0;
           else if (a_n > 1.0) a_n = 1.0;
           double eta = (double)kf * fmh_exp((-2.0 / 3.0) * fmh_log((double)i));
           if (eta > 1.0) eta = 1.0;
           double nrm2 = 0.0;
-          for (int b = 0; b < kf; b++) nrm2 = fmh_fma(L.vz[b], L.vz[b], nrm2);
+          for (int b = 0; b < kf; b++) nrm2 = fmh_fma(zt[b], zt[b], nrm2);
           double cp = (eta * (a_n - A.arate)) / nrm2;
           if (cp != 0.0 && fmh_isfinite(cp)) {
             const bool up = cp > 0.0;
@@ -520,14 +628,14 @@ __global__ __launch_bounds__(NT) void mh_sweep_kernel(const SweepArgs A) {
         __syncthreads();
         if (again) {
           if (tid == 0) s_flag[0] = 0;
-          eval_partials<CW>(A, thp, s_part);
+          evaluate();
           __syncthreads();
         }
       }
     }
     // ================= scalar phase C: accept / store (R/mcmc.R:754-778) =================
     if (owner && status == FMCMC_CHAIN_OK) {
-      f1 = finish_logpost<CW>(A, L.th1, s_part, myc);
+      f1 = finish_logpost(A, L.th1, total_of(myc));
       if (fmh_isnan(f1)) status = FMCMC_CHAIN_NAN_LOGPOST;
       const double ratio = f1 - f0;
       if (status == FMCMC_CHAIN_OK && fmh_isnan(ratio)) status = FMCMC_CHAIN_NAN_RATIO;
@@ -535,8 +643,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_kernel(const SweepArgs A) {
         if (lane == 0) { A.status[cl] = status; A.status_step[cl] = i; }
         if (lane < k) A.status_theta[cl * k + lane] = L.th1[lane];
       } else {
-        const double lu = (A.rng_mode == FMCMC_RNG_FED) ? A.fed_logu[cl * A.nsteps + (i - 1)]
-                                                        : fmh_log_accept_u(A.seed, step, cgid);
+        const double lu = s_lu[myc * TB + tt];
         if (lu < ratio) {
           if (lane < k) L.th0[lane] = L.th1[lane];
           f0 = f1;
@@ -548,8 +655,8 @@ __global__ __launch_bounds__(NT) void mh_sweep_kernel(const SweepArgs A) {
         if (A.kind == FMCMC_KERNEL_ADAPT && lane < kf) L.vrs[lane] = L.vrs[lane] + L.th0[s_which[lane]];
       }
     }
-    if (owner && A.accept_bits && lane == 0 && (((i - 1) & 31) == 31 || i == A.nsteps)) {
-      A.accept_bits[cl * ((A.nsteps + 31) / 32) + ((i - 1) >> 5)] = bitword;
+    if (owner && A.accept_bits && lane == 0 && (((i - 1) & 31) == 31 || i == nsteps)) {
+      A.accept_bits[cl * (long long)((nsteps + 31) >> 5) + ((i - 1) >> 5)] = bitword;
       bitword = 0;
     }
   }
@@ -601,8 +708,9 @@ __global__ void detmath_kernel(int which, const double* x, double* out, long lon
   out[i] = r;
 }
 
-size_t sweep_lds_bytes(int k, int kf, int kind, int CW) {
-  size_t d = 4 * (size_t)k + (k / 2 + 1) + (size_t)NW * CW + 1 + (size_t)CW * chain_lds_doubles(k, kf, kind);
+size_t sweep_lds_bytes(int k, int kf, int kind, int CW, int tb, int kz, bool resident) {
+  size_t d = 4 * (size_t)k + (k / 2 + 1) + (size_t)NW * CW + 1 + (size_t)CW * tb * (kz + 1) +
+             (resident ? (size_t)CW * NT : 0) + (size_t)CW * chain_lds_doubles(k, kf, kind);
   return d * sizeof(double);
 }
 
@@ -716,32 +824,62 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcm
   A.accept_count = (long long*)out->accept_count; A.accept_bits = out->accept_bits;
   A.status = out->status; A.status_step = (long long*)out->status_step; A.status_theta = out->status_theta;
 
-  // chains per workgroup: fill the 256 CUs first, then stack chains on a workgroup
+  // ---- launch geometry
   int dev = 0, ncu = 256;
-  hipGetDevice(&dev);
-  hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
   if (ncu <= 0) ncu = 256;
+  // register-resident variant: Gaussian linreg whose data fits the VGPR budget of 512 threads
+  int res_p = -1, res_opt = 0;
+  const char* force = getenv("FMCMC_AMD_FORCE_STREAMED");
+  if (!(force && force[0] == '1') && m->family == FMCMC_FAM_GAUSSIAN_LINREG) {
+    static const int variants[][2] = {{1, 4}, {3, 20}};
+    for (auto& v : variants)
+      if (m->p == v[0] && m->n > (long long)NT * (v[1] - RES_MASKED) && m->n <= (long long)NT * v[1]) {
+        res_p = v[0];
+        res_opt = v[1];
+      }
+  }
+  const bool resident = res_p >= 0;
+  // chains per workgroup: fill the CUs first, then stack chains on a workgroup
   int cw = 1;
-  while (cw < NW && (long long)cw * ncu < run->nchains) cw <<= 1;
-  while (cw > 1 && sweep_lds_bytes(kn->k, kf, kn->kind, cw) > 150 * 1024) cw >>= 1;
-  size_t lds = sweep_lds_bytes(kn->k, kf, kn->kind, cw);
+  if (resident) {
+    cw = 4;
+  } else {
+    while (cw < NW && (long long)cw * ncu < run->nchains) cw <<= 1;
+  }
+  int tb = 32;
+  while (tb > 1 && sweep_lds_bytes(kn->k, kf, kn->kind, cw, tb, A.kz, resident) > 60 * 1024) tb >>= 1;
+  while (cw > 1 && !resident && sweep_lds_bytes(kn->k, kf, kn->kind, cw, tb, A.kz, resident) > 150 * 1024) cw >>= 1;
+  A.tb = tb;
+  size_t lds = sweep_lds_bytes(kn->k, kf, kn->kind, cw, tb, A.kz, resident);
   if (lds > 160 * 1024) { set_err("LDS budget exceeded (k=%d)", kn->k); return FMCMC_ERR_UNSUPPORTED; }
   const long long nblk = (run->nchains + cw - 1) / cw;
   hipError_t e = hipSuccess;
-#define LAUNCH(CWV)                                                                                  \
+#define LAUNCH(CWV, PV, OV, KV)                                                                      \
   do {                                                                                               \
     if (lds > 48 * 1024)                                                                             \
-      e = hipFuncSetAttribute((const void*)mh_sweep_kernel<CWV>,                                    \
+      e = hipFuncSetAttribute((const void*)mh_sweep_kernel<CWV, PV, OV, KV>,                        \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
     if (e == hipSuccess)                                                                             \
-      hipLaunchKernelGGL(mh_sweep_kernel<CWV>, dim3((unsigned)nblk), dim3(NT), lds, stream, A);     \
+      hipLaunchKernelGGL((mh_sweep_kernel<CWV, PV, OV, KV>), dim3((unsigned)nblk), dim3(NT), lds, stream, A); \
   } while (0)
-  switch (cw) {
-    case 1: LAUNCH(1); break;
-    case 2: LAUNCH(2); break;
-    case 4: LAUNCH(4); break;
-    default: LAUNCH(8); break;
+#define LAUNCH_KIND(CWV, PV, OV)                                                                     \
+  switch (kn->kind) {                                                                                \
+    case FMCMC_KERNEL_NORMAL: LAUNCH(CWV, PV, OV, 1); break;                                         \
+    case FMCMC_KERNEL_NORMAL_REFLECTIVE: LAUNCH(CWV, PV, OV, 2); break;                              \
+    case FMCMC_KERNEL_ADAPT: LAUNCH(CWV, PV, OV, 3); break;                                          \
+    default: LAUNCH(CWV, PV, OV, 4); break;                                                          \
   }
+  if (resident && res_p == 1) { LAUNCH_KIND(4, 1, 4); }
+  else if (resident && res_p == 3) { LAUNCH_KIND(4, 3, 20); }
+  else switch (cw) {
+    case 1: LAUNCH(1, -1, 0, 0); break;
+    case 2: LAUNCH(2, -1, 0, 0); break;
+    case 4: LAUNCH(4, -1, 0, 0); break;
+    default: LAUNCH(8, -1, 0, 0); break;
+  }
+#undef LAUNCH_KIND
 #undef LAUNCH
   if (e == hipSuccess) e = hipGetLastError();
   if (e != hipSuccess) { set_err("HIP launch failed: %s", hipGetErrorString(e)); return FMCMC_ERR_DEVICE; }

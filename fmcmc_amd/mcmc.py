@@ -1,0 +1,347 @@
+"""MCMC() and its helpers with the reference's signatures (R/mcmc.R:325-340).
+
+  MCMC / MCMC.default / .mcmc / .mcmc.list   R/mcmc.R:325-479  -> MCMC
+  MCMC_without_conv_checker                  R/mcmc.R:485-838  -> MCMC_without_conv_checker
+  MCMC_with_conv_checker                     R/mcmc.R:841-1019 -> MCMC_with_conv_checker
+  check_initial                              R/checks.R:22-58  -> check_initial
+  append_chains                              R/append_chains.R -> append_chains
+  MCMC_OUTPUT logpost / draws                R/mcmc.R:822-823, R/mcmc_info.R:351-365 -> get_logpost / get_draws
+
+The per-chain loop itself (R/mcmc.R:720-838) is NOT here: it is the HIP sweep kernel reached through
+engine.sweep() -> C-ABI fmcmc_mcmc_run_dev.  `multicore`/`cl` select nothing on a GPU (all chains of
+the call already run concurrently); with torch.distributed initialised the chains are sharded over
+the ranks in contiguous blocks (one process per GPU) and RCCL is used only by the Gelman check.
+"""
+import time
+import warnings
+
+import numpy as np
+
+from . import _abi as abi
+from . import engine
+from .kernels import fmcmc_kernel, kernel_normal
+from .models import LogPosterior
+
+
+# ------------------------------------------------------------------------------ coda-like containers
+class Mcmc:
+    """coda::mcmc: data [niter x nvar] + mcpar = (start, end, thin)."""
+
+    def __init__(self, data, start=1, end=None, thin=1, varnames=None):
+        self.data = np.asarray(data, dtype=np.float64)
+        if self.data.ndim == 1:
+            self.data = self.data[:, None]
+        n = self.data.shape[0]
+        if end is None:
+            end = start + (n - 1) * thin
+        if n and (end - start) // thin + 1 != n:
+            raise ValueError("Start, end and thin incompatible with data")
+        self.mcpar = (int(start), int(end), int(thin))
+        self.varnames = list(varnames) if varnames is not None else ["par%d" % (j + 1) for j in range(self.data.shape[1])]
+        self.iters = start + thin * np.arange(n)
+
+    niter = property(lambda self: self.data.shape[0])
+    nvar = property(lambda self: self.data.shape[1])
+    nchain = property(lambda self: 1)
+    thin = property(lambda self: self.mcpar[2])
+    start = property(lambda self: self.mcpar[0])
+    end = property(lambda self: self.mcpar[1])
+
+    def __array__(self, dtype=None):
+        return self.data if dtype is None else self.data.astype(dtype)
+
+    def __len__(self):
+        return self.niter
+
+    def tail(self, n):
+        """utils::tail as fmcmc uses it (R/mcmc.R:362,406): the last n+1 rows."""
+        return self.data[-(n + 1):]
+
+    def __repr__(self):
+        return "<Mcmc niter=%d nvar=%d mcpar=%s>" % (self.niter, self.nvar, self.mcpar)
+
+
+class McmcList(list):
+    """coda::mcmc.list."""
+    nchain = property(lambda self: len(self))
+    nvar = property(lambda self: self[0].nvar)
+    niter = property(lambda self: self[0].niter)
+    thin = property(lambda self: self[0].thin)
+    iters = property(lambda self: self[0].iters)
+
+    def as_array(self):
+        return np.stack([m.data for m in self])  # [C][S][k]
+
+
+def check_initial(initial, nchains):
+    """R/checks.R:22-58. Returns (matrix [nchains x k], names)."""
+    names = None
+    if isinstance(initial, dict):
+        names, initial = list(initial.keys()), list(initial.values())
+    if isinstance(initial, McmcList):
+        return np.stack([m.data[-1] for m in initial]), initial[0].varnames
+    a = np.asarray(initial, dtype=np.float64)
+    if a.ndim <= 1:
+        a = np.atleast_1d(a)
+        if nchains > 1:
+            warnings.warn("While using multiple chains, a single initial point has been passed via `initial`: c(%s). "
+                          "The values will be recycled. Ideally you would want to start each chain from different "
+                          "locations." % ", ".join(repr(float(v)) for v in a))
+        if a.size == 0:
+            raise ValueError("The `initial` vector is of length zero.")
+        a = np.tile(a, (nchains, 1))
+    elif a.ndim != 2:
+        raise ValueError("When `initial` is not a numeric vector, it should be a matrix. Right now it is an "
+                         "object of class `%s`." % type(initial).__name__)
+    elif a.shape[0] != nchains:
+        raise ValueError("The number of rows of `initial` (%d) must coincide with the number of chains (%d)."
+                         % (a.shape[0], nchains))
+    if names is None:
+        names = ["par%d" % (j + 1) for j in range(a.shape[1])]
+    return np.ascontiguousarray(a), names
+
+
+def append_chains(*chains):
+    """R/append_chains.R:64-143 (iteration labels continue across runs)."""
+    chains = [c for c in chains if c is not None and len(c) > 0]
+    if not chains:
+        raise ValueError("No method available to append these chains.")
+    if len(chains) == 1:
+        return chains[0]
+    if isinstance(chains[0], McmcList):
+        ns = [len(c) for c in chains]
+        if len(set(ns)) != 1:
+            raise ValueError("All mcmc.list objects must have the same number of chains. The passed objects have "
+                             "%s respectively." % ", ".join(map(str, ns)))
+        return McmcList(append_chains(*[c[i] for c in chains]) for i in range(ns[0]))
+    thins = [c.thin for c in chains]
+    if len(set(thins)) != 1:
+        raise ValueError("All `mcmc` objects have to have the same `thin` parameter.Observed: %s respectively."
+                         % ", ".join(map(str, thins)))
+    nv = [c.nvar for c in chains]
+    if len(set(nv)) != 1:
+        raise ValueError("All `mcmc` objects have to have the same number of parameters.Observed: %s respectively."
+                         % ", ".join(map(str, nv)))
+    data = np.concatenate([c.data for c in chains], axis=0)
+    start, thin = chains[0].start, thins[0]
+    end = start + (data.shape[0] - 1) * thin
+    return Mcmc(data, start=start, end=end, thin=thin, varnames=chains[0].varnames)
+
+
+# ------------------------------------------------------------------------------ MCMC_OUTPUT (R/mcmc_info.R)
+class _Output:
+    def __init__(self):
+        self.clear()
+
+    def clear(self):
+        self.logpost, self.draws, self.elapsed, self.nchains = None, None, None, 0
+        self.accept_count, self.kernel = None, None
+
+
+MCMC_OUTPUT = _Output()
+
+
+def get_logpost():
+    """R/mcmc_info.R:351-355: vector (one chain) or list of vectors."""
+    lp = MCMC_OUTPUT.logpost
+    if lp is None:
+        raise RuntimeError("-logpost- not found in MCMC_OUTPUT.")
+    return lp[0] if len(lp) == 1 else lp
+
+
+def get_draws():
+    """R/mcmc_info.R:361-365: proposed states."""
+    d = MCMC_OUTPUT.draws
+    if d is None:
+        raise RuntimeError("-draws- not found in MCMC_OUTPUT.")
+    return d[0] if len(d) == 1 else d
+
+
+def get_elapsed():
+    return MCMC_OUTPUT.elapsed
+
+
+# ------------------------------------------------------------------------------ sharding (one process per GPU)
+def shard_bounds(nchains, world, rank):
+    """Contiguous chain blocks: chain c lives on rank floor(c * world / nchains)'s block."""
+    return (rank * nchains) // world, ((rank + 1) * nchains) // world
+
+
+def _dist():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist, dist.get_rank(), dist.get_world_size()
+    return None, 0, 1
+
+
+# ------------------------------------------------------------------------------ device-side result of one call
+class DeviceChains:
+    """Samples of the local chains, resident in HBM: samples [C][k][S] (+ logpost, draws)."""
+
+    def __init__(self, samples, logpost, draws, iters, thin, names, chain_base, nchains_total):
+        self.samples, self.logpost, self.draws = samples, logpost, draws
+        self.iters, self.thin, self.names = np.asarray(iters), thin, names
+        self.chain_base, self.nchains_total = chain_base, nchains_total
+
+    def append(self, other):
+        import torch
+        iters = np.concatenate([self.iters, other.iters - other.iters[0] + self.iters[-1] + self.thin])
+        cat = lambda a, b: None if a is None or b is None else torch.cat([a, b], dim=-1)
+        return DeviceChains(cat(self.samples, other.samples), cat(self.logpost, other.logpost),
+                            cat(self.draws, other.draws), iters, self.thin, self.names, self.chain_base,
+                            self.nchains_total)
+
+    def to_host(self):
+        s = self.samples.cpu().numpy()  # [C][k][S]
+        start, end = (int(self.iters[0]), int(self.iters[-1])) if self.iters.size else (1, 0)
+        chains = [Mcmc(s[c].T.copy(), start=start, end=end, thin=self.thin, varnames=self.names)
+                  for c in range(s.shape[0])]
+        return chains[0] if (len(chains) == 1 and self.nchains_total == 1) else McmcList(chains)
+
+
+def _validate_common(nsteps, nchains, burnin, thin, multicore):
+    if multicore and nchains == 1:
+        raise ValueError("When `multicore = TRUE`, `nchains` should be greater than 1.")
+    if nchains < 1:
+        raise ValueError("`nchains` must be an integer greater than 1.")
+    if burnin >= nsteps:
+        raise ValueError("-burnin- (%d) cannot be >= than -nsteps- (%d)." % (burnin, nsteps))
+    if thin >= nsteps:
+        raise ValueError("-thin- (%d) cannot be > than -nsteps- (%d)." % (thin, nsteps))
+    if thin < 1:
+        raise ValueError("-thin- should be >= 1.")
+
+
+def _run_call(initial_local, fun, nsteps, burnin, thin, kernel, seed, chain_base, nchains_total, names,
+              device, want_logpost=True, want_draws=True):
+    """One MCMC_without_conv_checker over the local chains -> DeviceChains."""
+    gm = fun.device_model(device)
+    kernel._init(initial_local.shape[1])
+    if kernel._spec is None or kernel._spec.device != gm.device:
+        kernel._spec = kernel.spec(gm.device)
+    st = kernel.state_for(initial_local, gm.device)
+    out = engine.sweep(gm, kernel._spec, st, nsteps, burnin=burnin, thin=thin, seed=seed, chain_base=chain_base,
+                       want_logpost=want_logpost, want_draws=want_draws, want_bits=False)
+    dc = DeviceChains(out.samples, out.logpost, out.draws, out.iters, thin, names, chain_base, nchains_total)
+    dc.accept_count = out.accept_count
+    return dc
+
+
+def MCMC_without_conv_checker(initial, fun, nsteps, nchains=1, burnin=0, thin=1, kernel=None, multicore=False,
+                              conv_checker=None, cl=None, progress=False, chain_id=1, seed=0, device=None,
+                              _return_device=False):
+    """R/mcmc.R:485-838 for all chains at once."""
+    if kernel is None:
+        kernel = kernel_normal()
+    if not isinstance(fun, LogPosterior):
+        raise TypeError("-fun- must be one of the engine's closed-form families (gaussian_linreg, logistic, "
+                        "iid_normal): an arbitrary closure cannot run inside the fused GPU kernel.")
+    if not isinstance(kernel, fmcmc_kernel):
+        raise TypeError("-kernel- must be an fmcmc_kernel (kernel_normal, kernel_normal_reflective, kernel_adapt, kernel_ram).")
+    init, names = check_initial(initial, nchains)
+    _validate_common(nsteps, nchains, burnin, thin, multicore)
+    if init.shape[1] != fun.k:
+        raise ValueError("Incorrect length of -initial-: the model has %d parameters, got %d." % (fun.k, init.shape[1]))
+    dist, rank, world = _dist()
+    lo, hi = shard_bounds(nchains, world, rank)
+    dc = _run_call(init[lo:hi], fun, nsteps, burnin, thin, kernel, seed, lo, nchains, names, device)
+    _store_output(dc, kernel)
+    return dc if _return_device else dc.to_host()
+
+
+def _store_output(dc, kernel):
+    lp = dc.logpost.cpu().numpy() if dc.logpost is not None else None
+    dr = dc.draws.cpu().numpy() if dc.draws is not None else None
+    MCMC_OUTPUT.logpost = [lp[c] for c in range(lp.shape[0])] if lp is not None else None
+    MCMC_OUTPUT.draws = [dr[c].T.copy() for c in range(dr.shape[0])] if dr is not None else None
+    MCMC_OUTPUT.nchains = dc.samples.shape[0]
+    MCMC_OUTPUT.kernel = kernel
+
+
+def MCMC_with_conv_checker(initial, fun, nsteps, nchains, burnin, thin, kernel, multicore, conv_checker, cl=None,
+                           progress=False, chain_id=1, seed=0, device=None, _return_device=False, verbose=True):
+    """R/mcmc.R:841-1019: run in bulks of `freq`, restart every chain from its last row, stop when the
+    checker says so."""
+    if conv_checker is None:
+        raise ValueError("The convergence checker for this call cannot be null.")
+    freq = getattr(conv_checker, "freq", None)
+    if freq is None:
+        freq = nsteps // 2
+        warnings.warn("The -conv_checker- function has no freq attribute. Default value set to be %d" % freq)
+    if freq * 2 > nsteps:
+        freq = 0
+    if freq > 0:
+        bulks = [freq] * ((nsteps - burnin) // freq)
+        if (nsteps - burnin) % freq:
+            bulks.append((nsteps - burnin) - sum(bulks))
+    else:
+        bulks = [nsteps]
+    bulks[0] += burnin
+    if kernel is None:
+        kernel = kernel_normal()
+    init, names = check_initial(initial, nchains)
+    dist, rank, world = _dist()
+    lo, hi = shard_bounds(nchains, world, rank)
+    init_local = init[lo:hi]
+    conv_checker.flush()
+    ans = None
+    converged = False
+    free = None
+    for bi, nb in enumerate(bulks):
+        if bi > 0:
+            burnin = 0
+            init_local = kernel._state.theta0  # last row of each chain (R/mcmc.R:908-911)
+        _validate_common(nb, nchains, burnin, thin, multicore)
+        tmp = _run_call(init_local, fun, nb, burnin, thin, kernel, seed, lo, nchains, names, device)
+        ans = tmp if ans is None else ans.append(tmp)
+        if free is None:
+            free = np.nonzero(~kernel.fixed)[0]
+        converged = conv_checker.check_device(ans, free)
+        msg = conv_checker.msg
+        total = sum(bulks[:bi + 1])
+        if converged:
+            if verbose and rank == 0:
+                print("Convergence has been reached with %d steps. %s(%d final count of samples)."
+                      % (total, (msg + " ") if msg else "", ans.samples.shape[-1]))
+            break
+        elif verbose and rank == 0:
+            print("No convergence yet (steps count: %d). %sTrying with the next bulk." % (total, (msg + " ") if msg else ""))
+    if not converged and verbose and rank == 0:
+        print("No convergence reached after %d steps (%d final count of samples)." % (sum(bulks[:bi + 1]), ans.samples.shape[-1]))
+    ans.converged = converged
+    _store_output(ans, kernel)
+    return ans if _return_device else ans.to_host()
+
+
+_seed_counter = [int(time.time_ns()) & 0xFFFFFFFF]
+
+
+def MCMC(initial, fun, nsteps, *, seed=None, nchains=1, burnin=0, thin=1, kernel=None, multicore=False,
+         conv_checker=None, cl=None, progress=False, chain_id=1, device=None, _return_device=False):
+    """Drop-in for fmcmc::MCMC (R/mcmc.R:325-340).
+
+    initial: vector, [nchains x k] matrix, or a previous result (Mcmc: its last `nchains` rows,
+    R/mcmc.R:344-378; McmcList: each chain's last row, :382-422).  fun: gaussian_linreg / logistic /
+    iid_normal object.  seed: Philox key (None: a fresh one per call)."""
+    MCMC_OUTPUT.clear()
+    t0 = time.time()
+    if isinstance(initial, Mcmc):
+        initial = initial.tail(nchains - 1)
+        if initial.shape[0] == 1:
+            initial = initial[0]
+    elif isinstance(initial, McmcList):
+        if nchains != len(initial):
+            raise ValueError("The parameter `nchains` must equal the number of chains passed by `initial`.")
+    if seed is None:
+        _seed_counter[0] = (_seed_counter[0] * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+        seed = _seed_counter[0]
+    if kernel is None:
+        kernel = kernel_normal()
+    if conv_checker is not None:
+        ans = MCMC_with_conv_checker(initial, fun, nsteps, nchains, burnin, thin, kernel, multicore, conv_checker,
+                                     cl, progress, chain_id, seed=seed, device=device, _return_device=_return_device)
+    else:
+        ans = MCMC_without_conv_checker(initial, fun, nsteps, nchains, burnin, thin, kernel, multicore, None, cl,
+                                        progress, chain_id, seed=seed, device=device, _return_device=_return_device)
+    MCMC_OUTPUT.elapsed = time.time() - t0
+    return ans

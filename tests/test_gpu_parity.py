@@ -196,3 +196,39 @@ def test_nan_logpost_is_reported(E, O):
     assert (ro.status == 1).any()
     with pytest.raises(RuntimeError, match="undefined"):
         E.raise_on_chain_error(rg)
+
+
+# ---- the register-resident variant of the headline shape (n = 10,000, 3 covariates, k = 5)
+@pytest.mark.parametrize("kind", ["normal", "reflective", "adapt", "ram"])
+def test_resident_headline_shape(E, O, kind):
+    X, y = synth_linreg(10000, 3, 20260102)
+    C = 9  # not a multiple of the 4 chains per workgroup
+    init = jitter_init([0, 0, 0, 0, float(np.std(y))], C, 12)
+    init[:, -1] = np.abs(init[:, -1])
+    if kind == "normal":
+        run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=150, calls=2, scale=0.02)
+    elif kind == "reflective":
+        run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL_REFLECTIVE, 5, init, nsteps=150, scale=0.3,
+                 lb=[-5, -5, -5, -5, 0.1], ub=[5, 5, 5, 5, 5.0], guard=False)
+    elif kind == "adapt":
+        run_both(E, O, O.FAM_LINREG, X, y, O.K_ADAPT, 5, init, nsteps=160, calls=2, warmup=40)
+    else:
+        run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, 5, init, nsteps=150, calls=2)
+
+
+@pytest.mark.parametrize("n", [8193, 9000, 10240])
+def test_resident_edge_sizes(E, O, n):
+    """n range of the (P=3, OPT=20) variant: masks on the trailing observation slots."""
+    X, y = synth_linreg(n, 3, n)
+    init = jitter_init([0, 0, 0, 0, float(np.std(y))], 5, 13)
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=60, scale=0.02)
+
+
+def test_streamed_equals_resident(E, O, monkeypatch):
+    """Same bits from the streamed and the register-resident evaluation."""
+    X, y = synth_linreg(10000, 3, 20260102)
+    init = jitter_init([0, 0, 0, 0, float(np.std(y))], 6, 14)
+    a, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=100, scale=0.02)
+    monkeypatch.setenv("FMCMC_AMD_FORCE_STREAMED", "1")
+    b, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=100, scale=0.02)
+    assert _bits_equal(a.samples.cpu().numpy(), b.samples.cpu().numpy())
