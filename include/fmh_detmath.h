@@ -44,6 +44,16 @@ FMH_HD uint64_t fmh_d2u(double x) {
 FMH_HD double fmh_u2d(uint64_t u) {
   union { double d; uint64_t u; } v; v.u = u; return v.d;
 }
+/* FMH_K(c): a literal constant the device compiler must materialise AT THE USE (two 32-bit moves)
+ * instead of hoisting it out of the caller's loop into a long-lived register pair: inside the
+ * MH sweep kernel such hoisted constants get spilled and every reload is a memory round trip.
+ * Value-transparent (the bits are unchanged), identity on the host. */
+#if defined(__HIP_DEVICE_COMPILE__)
+FMH_HD double fmh_opaque_(double c) { asm volatile("" : "+s"(c)); return c; }
+#define FMH_K(c) fmh_opaque_(c)
+#else
+#define FMH_K(c) (c)
+#endif
 FMH_HD double fmh_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 FMH_HD double fmh_sqrt(double a) { return __builtin_sqrt(a); }
 FMH_HD double fmh_abs(double a) { return __builtin_fabs(a); }
@@ -69,15 +79,15 @@ FMH_HD double fmh_log_core_(double f, int k, double extra) {
   double s = f / (2.0 + f);
   double z = s * s;
   double w = z * z;
-  double t1 = w * fmh_fma(w, fmh_fma(w, Lg6, Lg4), Lg2);
-  double t2 = z * fmh_fma(w, fmh_fma(w, fmh_fma(w, Lg7, Lg5), Lg3), Lg1);
+  double t1 = w * fmh_fma(w, fmh_fma(w, FMH_K(Lg6), FMH_K(Lg4)), FMH_K(Lg2));
+  double t2 = z * fmh_fma(w, fmh_fma(w, fmh_fma(w, FMH_K(Lg7), FMH_K(Lg5)), FMH_K(Lg3)), FMH_K(Lg1));
   double R = t2 + t1;
   double hfsq = 0.5 * f * f;
   double dk = (double)k;
   /* log = k*ln2_hi - ((hfsq - (s*(hfsq+R) + (k*ln2_lo + extra))) - f) */
-  double lo = fmh_fma(dk, FMH_LN2_LO, extra);
+  double lo = fmh_fma(dk, FMH_K(FMH_LN2_LO), extra);
   double inner = fmh_fma(s, hfsq + R, lo);
-  return dk * FMH_LN2_HI - ((hfsq - inner) - f);
+  return dk * FMH_K(FMH_LN2_HI) - ((hfsq - inner) - f);
 }
 
 /* Split a positive finite normal/subnormal x into k and m = x / 2^k with
