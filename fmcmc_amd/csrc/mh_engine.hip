@@ -746,6 +746,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_kernel(const SweepArgs A0) {
 // Random variates come from HBM (rng_fill_kernel or host-fed), prefetched one step ahead into registers.
 // ==============================================================================================
 constexpr int PIPE_KMAX = 16; // parameters per chain supported by this kernel
+constexpr int PIPE_TRS = 66;  // row stride (doubles) of the transposed lane-partial tile
 
 // Canonical Philox stream materialised in HBM for the pipelined kernel (same layout as FED mode):
 // logu[c][i-1] = log accept-uniform of loop step i, z[c][i-1][a] = a-th proposal variate of step i.
@@ -797,8 +798,12 @@ __global__ __launch_bounds__(NT) void mh_sweep_pipe(const SweepArgs A) {
   const int k = A.k, kz = A.kz;
   double* s_th1 = smem;                            // [CW][PIPE_KMAX] proposals read by the evaluation
   double* s_par = s_th1 + CW * PIPE_KMAX;          // [4][PIPE_KMAX]  mu, scale, lb, ub
-  double* s_tr = s_par + 4 * PIPE_KMAX;            // [CW][NT] lane partials
-  double* s_y = s_tr + CW * NT;                    // [OPT/2][NT][2] this workgroup's copy of y
+  double* s_tr = s_par + 4 * PIPE_KMAX;            // [CW][8][PIPE_TRS] lane partials, transposed (below)
+  double* s_y = s_tr + CW * 8 * PIPE_TRS;          // [OPT/2][NT][2] this workgroup's copy of y
+  // Lane partial of canonical lane l goes to T[l & 7][l >> 3] (row stride PIPE_TRS = 66 doubles): the 64
+  // b64 writes of a wavefront and the owner's 8 column reads T[j][q] are both bank-conflict free, whereas
+  // the plain [lane] layout makes the fold (8 consecutive doubles per lane) a 16-way conflict.
+  const int tr_slot = (tid & 7) * PIPE_TRS + (tid >> 3);
   const long long cg0 = (long long)blockIdx.x * CW;
   const int ncw = (int)((A.nchains - cg0 < CW) ? (A.nchains - cg0) : CW);
   const int nsteps = (int)A.nsteps, burnin = (int)A.burnin, thin = (int)A.thin;
@@ -897,13 +902,15 @@ __global__ __launch_bounds__(NT) void mh_sweep_pipe(const SweepArgs A) {
       // ILP, the temporaries push the owner state into scratch and every store pays a memory round trip
       __builtin_amdgcn_sched_barrier(0);
     }
-    s_tr[(2 * g) * NT + tid] = a0;
-    s_tr[(2 * g + 1) * NT + tid] = a1;
+    s_tr[(2 * g) * (8 * PIPE_TRS) + tr_slot] = a0;
+    s_tr[(2 * g + 1) * (8 * PIPE_TRS) + tr_slot] = a1;
   };
   // canonical tree over the 512 lane partials of this owner's chain
   auto fold_partials = [&]() -> double {
-    const double* src = s_tr + myc * NT + 8 * lane;
-    double v = ((src[0] + src[1]) + (src[2] + src[3])) + ((src[4] + src[5]) + (src[6] + src[7]));  // levels 1,2,4
+    const double* src = s_tr + myc * (8 * PIPE_TRS) + lane;  // this lane folds canonical lanes 8*lane .. 8*lane+7
+    const double v0 = src[0 * PIPE_TRS], v1 = src[1 * PIPE_TRS], v2 = src[2 * PIPE_TRS], v3 = src[3 * PIPE_TRS];
+    const double v4 = src[4 * PIPE_TRS], v5 = src[5 * PIPE_TRS], v6 = src[6 * PIPE_TRS], v7 = src[7 * PIPE_TRS];
+    double v = ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7));  // levels 1,2,4
     return wave_xor_sum(v);                                                                         // levels 8..256
   };
   auto logpost_of = [&](double tot, double sigma) -> double {
@@ -1023,7 +1030,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_pipe(const SweepArgs A) {
   }
 }
 
-size_t pipe_lds_bytes(int opt) { return sizeof(double) * ((size_t)8 * PIPE_KMAX + 4 * NT + (size_t)opt * NT); }
+size_t pipe_lds_bytes(int opt) { return sizeof(double) * ((size_t)8 * PIPE_KMAX + 4 * 8 * PIPE_TRS + (size_t)opt * NT); }
 
 // diagnostic: evaluates include/fmh_detmath.h / fmh_philox.h on the device (tests compare bitwise
 // with the host build of the same headers)
