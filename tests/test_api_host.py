@@ -1,0 +1,122 @@
+"""Host-side logic of the drop-in API (no GPU): constructors, argument contracts and the bookkeeping
+around the hot path, against the reference's documented behaviour."""
+import warnings
+
+import numpy as np
+import pytest
+
+import fmcmc_amd as f
+from fmcmc_amd.convergence import _window
+from fmcmc_amd.mcmc import Mcmc, McmcList
+
+
+def test_kernel_constructors_expand_like_the_reference():
+    k = f.kernel_normal_reflective(ub=5.0, lb=[-5.0, 0.0, 0.0], scale=0.05)
+    assert k.k is None                       # lazily initialised on first use (R/kernel_normal.R:39)
+    k._init(3)
+    assert list(k.lb) == [-5, 0, 0] and list(k.ub) == [5, 5, 5] and list(k.scale) == [.05] * 3 and k.k == 3
+    k2 = f.kernel_normal_reflective(lb=[np.nan, 0.0], ub=np.nan)      # R/kernel.R:25-41
+    k2._init(2)
+    assert k2.lb[0] == -np.finfo(float).max and k2.ub[1] == np.finfo(float).max
+    ka = f.kernel_adapt()
+    ka._init(5)
+    assert ka.warmup == 500 and ka.eps == 1e-4 and abs(ka.Sd - 5.76 / 5) < 1e-15   # R/kernel_adapt.R:61,113-114
+    kr = f.kernel_ram(fixed=[False, True, False])
+    kr._init(3)
+    assert kr.k == 2 and list(kr.which_) == [0, 2] and kr.arate == 0.234
+    ko = f.kernel_normal(scheme="ordered")
+    ko._init(4)
+    assert ko.k == 1                          # k <<- sum(update_sequence[1,])
+
+
+@pytest.mark.parametrize("make,msg", [
+    (lambda: f.kernel_normal_reflective(lb=1.0, ub=1.0)._init(2), "-ub- cannot be <= than -lb-."),
+    (lambda: f.kernel_normal(fixed=True)._init(3), "cannot be zero"),
+    (lambda: f.kernel_normal(scale=[1.0, 2.0])._init(3), "Incorrect length of -scale-."),
+    (lambda: f.kernel_adapt(bw=600, warmup=500), "The `warmup` parameter must be greater than `bw`."),
+    (lambda: f.kernel_normal(scheme="sideways")._init(2), "-scheme- update must be"),
+])
+def test_kernel_errors(make, msg):
+    """test-kernels.R:14-86."""
+    with pytest.raises(ValueError, match=msg.replace("(", r"\(").replace(")", r"\)")):
+        make()
+
+
+def test_check_initial():
+    """R/checks.R:22-58, test-checks.R:31-41."""
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        a, names = f.check_initial([1.0, 2.0], 3)
+    assert a.shape == (3, 2) and names == ["par1", "par2"] and any("recycled" in str(x.message) for x in w)
+    a, names = f.check_initial({"mu": 1.0, "sigma": 2.0}, 1)
+    assert names == ["mu", "sigma"]
+    with pytest.raises(ValueError, match="must coincide with the number of chains"):
+        f.check_initial(np.zeros((2, 3)), 3)
+    with pytest.raises(ValueError, match="length zero"):
+        f.check_initial([], 1)
+
+
+def test_mcmc_argument_checks_come_before_the_gpu():
+    """test-mcmc.R:3-23: same messages, raised without touching a device."""
+    fun = f.gaussian_linreg(np.arange(5.0), np.arange(5.0))
+    for kw, msg in ((dict(burnin=10), "burnin"), (dict(thin=10), "thin"), (dict(thin=0), "-thin- should be >= 1"),
+                    (dict(multicore=True), "`nchains` should be greater than 1"), (dict(nchains=0), "`nchains` must be")):
+        with pytest.raises(ValueError, match=msg):
+            f.MCMC([0, 0, 1.0], fun, 10, **kw)
+    with pytest.raises(TypeError, match="closed-form families"):
+        f.MCMC([0, 0, 1.0], lambda p: 0.0, 10)
+    with pytest.raises(ValueError, match="Incorrect length of -initial-"):
+        f.MCMC([0, 0, 0, 1.0], fun, 10)
+
+
+def test_mcmc_containers_and_append_chains():
+    """R/append_chains.R:90-143, test-append_chains.R:10-60."""
+    a = Mcmc(np.arange(20.0).reshape(10, 2), start=1, end=10, thin=1)
+    b = Mcmc(np.arange(20.0, 40.0).reshape(10, 2), start=1, end=10, thin=1)
+    ab = f.append_chains(a, b)
+    assert ab.niter == 20 and ab.mcpar == (1, 20, 1) and list(ab.iters) == list(range(1, 21))
+    t1 = Mcmc(np.zeros((5, 1)), start=12, end=20, thin=2)
+    t2 = Mcmc(np.ones((3, 1)), start=2, end=6, thin=2)
+    t12 = f.append_chains(t1, t2)
+    assert list(t12.iters) == [12, 14, 16, 18, 20, 22, 24, 26]
+    with pytest.raises(ValueError, match="same `thin`"):
+        f.append_chains(a, t1)
+    la = f.append_chains(McmcList([a, a]), McmcList([b, b]))
+    assert la.nchain == 2 and la[1].niter == 20
+    assert a.tail(0).shape == (1, 2) and a.tail(2).shape == (3, 2)   # utils::tail as fmcmc uses it
+    with pytest.raises(ValueError):
+        Mcmc(np.zeros((4, 1)), start=1, end=10, thin=1)
+
+
+def test_shard_bounds_partition_the_chains():
+    for C in (1, 7, 1024, 4096):
+        for W in (1, 2, 3, 8):
+            b = [f.shard_bounds(C, W, r) for r in range(W)]
+            assert b[0][0] == 0 and b[-1][1] == C and all(b[i][1] == b[i + 1][0] for i in range(W - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_gelman_window_is_codas_autoburnin():
+    assert _window(np.arange(1, 201)) == (100, 100)        # keep iterations >= end/2 + 1 = 101
+    assert _window(np.arange(1, 202)) == (101, 100)        # odd end: >= 101.5
+    assert _window(np.arange(150, 201)) == (0, 51)          # start >= end/2: everything
+    assert _window(np.arange(10, 1001, 10)) == (50, 50)     # thinned labels
+
+
+def test_model_families_definitions():
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((50, 2)); y = rng.standard_normal(50)
+    fun = f.gaussian_linreg(X, y)
+    th = np.array([0.1, 0.2, -0.3, 1.5])
+    from scipy.stats import norm
+    assert abs(fun(th) - norm.logpdf(y - (th[0] + X @ th[1:3]), scale=th[3]).sum()) < 1e-9
+    assert fun([0, 0, 0, -1.0]) == -np.inf and f.gaussian_linreg(X, y, guard=False)([0, 0, 0, 0.0]) == -np.inf
+    assert np.isnan(f.gaussian_linreg(X, y, guard=False)([0, 0, 0, -1.0]))
+    yb = (rng.uniform(size=50) < 0.5).astype(float)
+    lg = f.logistic(np.column_stack([np.ones(50), X]), yb)
+    b = np.array([0.3, -0.2, 0.1])
+    eta = np.column_stack([np.ones(50), X]) @ b
+    ref = np.sum(yb * (-np.log1p(np.exp(-eta))) + (1 - yb) * (-np.log1p(np.exp(eta)))) - np.sum(b ** 2) / 8
+    assert abs(lg(b) - ref) < 1e-9 and lg.k == 3
+    assert f.iid_normal(y).k == 2

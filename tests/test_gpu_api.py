@@ -1,0 +1,192 @@
+"""GPU tests of the drop-in API layer and of the strongest parity statements:
+ * the engine, fed R's own Mersenne-Twister draw stream, reproduces the outputs fmcmc PRINTS (README);
+ * MCMC(..., conv_checker = convergence_gelman()) stops at the same bulk with the same R-hat history as
+   the oracle's restatement of MCMC_with_conv_checker;
+ * the committed golden vectors of the canonical stream."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import synth_linreg
+
+pytestmark = pytest.mark.gpu
+G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "readme_goldens.json")))
+
+
+@pytest.fixture(scope="module")
+def E():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from fmcmc_amd import engine
+    return engine
+
+
+def sig(x, d):
+    return float("%.*g" % (d, x))
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def fed_stream(O, g, nsteps, kz, ram_df=None):
+    """R's draw order for one chain (R/mcmc.R:726 then the kernel's draws per step)."""
+    logu = np.log(g.runif(nsteps))
+    z = np.zeros((nsteps, kz))
+    for i in range(1, nsteps):  # rows 1.. hold the variates of loop steps 2..
+        z[i] = g.rt(kz, ram_df) if ram_df else g.rnorm(kz)
+    return logu, z
+
+
+def test_fed_replay_reproduces_the_readme_on_the_gpu(E, O, readme_data):
+    import torch
+    from fmcmc_amd import _abi as abi
+    X, y = readme_data
+    gm = E.DeviceModel(abi.FAM_GAUSSIAN_LINREG, X, y, intercept=True, guard=True)
+    big = E.DBL_MAX
+    g = O.RRng(1215)
+
+    def run(kind, scale, init, ram=False):
+        logu, z = fed_stream(O, g, 5000, 3, ram_df=3.0 if ram else None)
+        gk = E.KernelSpec(kind, 3, np.zeros(3), np.full(3, scale), np.full(3, -big), np.full(3, big),
+                          np.zeros(3, np.uint8), warmup=0)
+        st = E.ChainState(np.asarray(init, dtype=np.float64)[None, :], 3)
+        r = E.sweep(gm, gk, st, 5000, fed_logu=torch.as_tensor(logu[None, :]).cuda().contiguous(),
+                    fed_z=torch.as_tensor(z[None, :, :]).cuda().contiguous())
+        torch.cuda.synchronize()
+        return r, st
+
+    # README.md:156-201 (G1)
+    r1, _ = run(abi.KERNEL_NORMAL, 1.0, [0, 0, O.r_sd(y)])
+    s = r1.samples.cpu().numpy()[0].T
+    assert [sig(v, 4) for v in s.mean(0)] == G["G1"]["mean"]
+    assert [sig(v, 4) for v in s.std(0, ddof=1)] == [sig(v, 4) for v in G["G1"]["sd"]]
+    q = np.quantile(s[:, 0], [.025, .25, .5, .75, .975])
+    assert [sig(v, 4) for v in q] == G["G1"]["q_par1"]
+    assert list(O.accept_steps(r1.accept_bits.cpu().numpy().view(np.uint32)[0])) == [
+        3, 5, 8, 10, 14, 32, 67, 544, 786, 834, 1598, 2764, 3693, 3826, 4039, 4514, 4613, 4776, 4898, 4916, 4950]
+    # README.md:209-246 (G4): kernel_normal(scale=.05) from the last row, then kernel_ram()
+    r2, _ = run(abi.KERNEL_NORMAL, 0.05, s[-1])
+    s2 = r2.samples.cpu().numpy()[0].T
+    assert int(r2.accept_count[0]) == 3641
+    r3, st3 = run(abi.KERNEL_RAM, 1.0, s2[-1], ram=True)
+    assert int(r3.accept_count[0]) == 1761
+    assert sig(1761 / 4999, 7) == G["G4"]["ram_accept_rate"]
+    assert np.allclose(st3.Sigma.cpu().numpy()[0], [[0.18001104, 0, 0], [0.01481571, 0.17576006, 0],
+                                                    [0.00806067, -0.00281060, 0.11951173]], atol=5e-9)
+
+
+def test_committed_golden_vectors(E, O):
+    from golden.make_philox_vectors import cases, make_inputs, kernel_kwargs, hexbits
+    from fmcmc_amd import _abi as abi
+    import torch
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "philox_vectors.json")))
+    for name, spec in cases().items():
+        X, y, init = make_inputs(spec)
+        kind, kw = kernel_kwargs(O, spec)
+        ok = O.Kernel(kind, spec["p"] + 2, **kw)
+        gk = E.KernelSpec(kind, ok.k, ok.mu, ok.scale, ok.lb, ok.ub, ok.fixed, warmup=ok.warmup, eps=ok.eps, arate=ok.arate)
+        st = E.ChainState(init, ok.kf)
+        r = E.sweep(E.DeviceModel(abi.FAM_GAUSSIAN_LINREG, X, y), gk, st, spec["nsteps"], seed=spec["seed"])
+        torch.cuda.synchronize()
+        samples = r.samples.cpu().numpy().transpose(0, 2, 1)
+        draws = r.draws.cpu().numpy().transpose(0, 2, 1)
+        got = {"accept_count": [int(v) for v in r.accept_count.cpu().numpy()],
+               "accept_bits": [int(v) for v in r.accept_bits.cpu().numpy().view(np.uint32).ravel()],
+               "last_row": hexbits(samples[:, -1, :]), "logpost_last": hexbits(r.logpost.cpu().numpy()[:, -1]),
+               "sample_checksum": hexbits([samples.sum(), np.abs(draws).sum()])}
+        for key in ("accept_count", "accept_bits", "last_row", "logpost_last"):
+            assert got[key] == fx[name][key], (name, key)
+
+
+def test_gelman_partial_kernel(E, O):
+    import torch
+    from fmcmc_amd import _abi as abi
+    from test_abi import numpy_gelman_partial
+    rng = np.random.default_rng(3)
+    Cn, k, S = 37, 6, 500
+    x = rng.standard_normal((Cn, k, S)) * 0.5 + rng.standard_normal((Cn, k, 1)) * 0.2 + 3.0
+    cols = np.array([0, 2, 3, 5], dtype=np.int32)
+    row0, N = 250, 250
+    xd = torch.as_tensor(x).cuda()
+    cd = torch.as_tensor(cols).cuda()
+    center = torch.as_tensor(x[0, cols, row0]).cuda()
+    L = abi.lib()
+    p = len(cols)
+    part = torch.zeros(int(L.fmcmc_gelman_partial_len(p)), dtype=torch.float64, device="cuda")
+    work = torch.empty(int(L.fmcmc_gelman_work_len(Cn, p)), dtype=torch.float64, device="cuda")
+    rc = L.fmcmc_gelman_partial_dev(xd.data_ptr(), Cn, k, S, row0, N, cd.data_ptr(), p, center.data_ptr(),
+                                    work.data_ptr(), part.data_ptr(), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    win = x[:, cols, row0:].transpose(0, 2, 1)  # [m][N][p]
+    ref = numpy_gelman_partial(win, x[0, cols, row0])
+    assert np.allclose(part.cpu().numpy(), ref, rtol=1e-10, atol=1e-12)
+    psrf = np.empty(p); mps = C.c_double(); dp = C.POINTER(C.c_double)
+    pn = part.cpu().numpy()
+    assert L.fmcmc_gelman_finish(pn.ctypes.data_as(dp), p, N, psrf.ctypes.data_as(dp), C.byref(mps)) == 0
+    opsrf, ompsrf = O.gelman(win)
+    assert np.allclose(psrf, opsrf, rtol=1e-9) and abs(mps.value - ompsrf) < 1e-9 * ompsrf
+
+
+def test_mcmc_api_end_to_end(E, O, readme_data):
+    import fmcmc_amd as f
+    X, y = readme_data
+    fun = f.gaussian_linreg(X, y)
+    kern = f.kernel_normal(scale=0.05)
+    ans = f.MCMC([0, 0, O.r_sd(y)], fun, 2000, seed=1215, kernel=kern)
+    assert isinstance(ans, f.Mcmc) and ans.mcpar == (1, 2000, 1) and ans.data.shape == (2000, 3)
+    ro = O.run(O.Model(O.FAM_LINREG, X, y), O.Kernel(O.K_NORMAL, 3, scale=0.05), [0, 0, O.r_sd(y)], nsteps=2000, seed=1215)
+    assert np.array_equal(_bits(ans.data), _bits(ro.samples[0]))
+    assert np.array_equal(_bits(f.get_logpost()), _bits(ro.logpost[0]))
+    assert np.array_equal(_bits(f.get_draws()), _bits(ro.draws[0]))
+    # restart from the previous result with burn-in and thinning (R/mcmc.R:344-378)
+    ans2 = f.MCMC(ans, fun, 1000, seed=7, kernel=f.kernel_adapt(warmup=100), burnin=100, thin=10)
+    assert ans2.mcpar == (110, 1000, 10) and ans2.niter == 90
+    assert np.isfinite(ans2.data).all() and abs(ans2.data[:, 0].mean() - 3.1) < 0.5
+    # several chains, kernel state persists in the kernel object like in R (vignette workflow)
+    kr = f.kernel_ram()
+    l1 = f.MCMC(np.tile([3, 2, 4.0], (4, 1)), fun, 500, seed=3, nchains=4, kernel=kr)
+    assert isinstance(l1, f.McmcList) and l1.nchain == 4 and list(kr.abs_iter) == [499] * 4
+    l2 = f.MCMC(l1, fun, 500, seed=3, nchains=4, kernel=kr)
+    assert list(kr.abs_iter) == [998] * 4 and kr[2].Sigma.shape == (3, 3) and len(f.get_logpost()) == 4
+    with pytest.raises(RuntimeError, match="undefined"):
+        f.MCMC([0, 0, 0.05], f.gaussian_linreg(X, y, guard=False), 300, seed=1, kernel=f.kernel_normal(scale=1.0))
+
+
+def test_mcmc_autostop_matches_the_oracle(E, O, readme_data):
+    """MCMC_with_conv_checker + convergence_gelman (R/mcmc.R:841-1019, R/convergence.R:191-246)."""
+    import fmcmc_amd as f
+    X, y = readme_data
+    init = np.tile([0, 0, O.r_sd(y)], (4, 1)) + 0.3 * np.random.default_rng(2).standard_normal((4, 3))
+    chk = f.convergence_gelman(200, threshold=1.10)
+    ans = f.MCMC(init, f.gaussian_linreg(X, y), 5000, seed=99, nchains=4, kernel=f.kernel_normal(scale=0.05),
+                 conv_checker=chk)
+    ro = O.mcmc_with_conv_checker(O.Model(O.FAM_LINREG, X, y), O.Kernel(O.K_NORMAL, 3, scale=0.05), init, 5000, 4, 200,
+                                  seed=99)
+    assert [h[0] for h in chk.history] == [h[0] for h in ro.history]
+    assert np.allclose([h[1] for h in chk.history], [h[1] for h in ro.history], rtol=1e-8)
+    assert ans.niter == ro.samples.shape[1] and ans.nchain == 4
+    assert np.array_equal(_bits(ans.as_array()), _bits(ro.samples))
+    assert list(ans.iters) == list(ro.iters)
+
+
+def test_logistic_and_large_k_ram(E, O):
+    """BASELINE configs 4 and 5 in miniature: kernel_ram at k = 50, logistic with reflective bounds."""
+    from test_gpu_parity import run_both, jitter_init
+    rng = np.random.default_rng(8)
+    n, p = 400, 48
+    X = rng.standard_normal((n, p)); beta = rng.standard_normal(p + 1)
+    y = beta[0] + X @ beta[1:] + 2.0 * rng.standard_normal(n)
+    init = jitter_init(np.concatenate([beta, [2.0]]), 3, 4)
+    init[:, -1] = np.abs(init[:, -1])
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, p + 2, init, nsteps=120, calls=2)
+    n, p = 3000, 5
+    X = rng.standard_normal((n, p)); b = np.array([-1, .5, -.5, .25, -.25, 1.0])
+    yb = (rng.uniform(size=n) < 1 / (1 + np.exp(-(b[0] + X @ b[1:])))).astype(np.float64)
+    run_both(E, O, O.FAM_LOGISTIC, X, yb, O.K_NORMAL_REFLECTIVE, 6, jitter_init(b, 9, 5), nsteps=150, thin=10,
+             prior_div=8.0, scale=0.01, lb=-5.0, ub=5.0)
