@@ -775,6 +775,11 @@ __global__ __launch_bounds__(256) void rng_fill_kernel(unsigned long long seed, 
   }
 }
 
+__device__ __forceinline__ unsigned long long clk() {  // diagnostic stamp (debug mode 8 only)
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  return t;
+}
 __device__ __forceinline__ double uniform_d(double v) {  // pin a wave-uniform double into SGPRs
   unsigned long long u = (unsigned long long)__double_as_longlong(v);
   unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
@@ -1030,6 +1035,255 @@ __global__ __launch_bounds__(NT) void mh_sweep_pipe(const SweepArgs A) {
   }
 }
 
+// ==============================================================================================
+// Wave-specialised resident kernel (the headline path).
+//
+//   768 threads = 12 wavefronts per workgroup, 3 per SIMD:
+//     waves 0..7  COMPUTE: hold the x columns of their 64 canonical lanes in VGPRs (y in LDS) and do nothing
+//                 but evaluate: for version v, for chain c: wait ready[c] >= v, read theta1[c], 20 observations
+//                 x (3 fma + sub + fma), write the lane partial, arrive on done[c].
+//     waves 8..11 OWNERS (one per chain): wait done[c] == 8 v, fold the 512 partials (canonical tree), closed
+//                 form, accept, propose, prefetch, publish theta1[c] (ready[c] = v + 1), then store the row.
+//   No s_barrier in the steady state: producers/consumers meet on LDS sequence words, so an owner's
+//   latency-bound phase overlaps the evaluation of the OTHER three chains, and on every SIMD the owner's
+//   dependency stalls are filled by the two compute waves' independent FMAs (hardware multithreading instead
+//   of compiler interleaving).  Register budget: 12 waves -> 168 VGPRs; one chain per evaluation pass keeps the
+//   compute role at 120 (data) + ~30: 148 VGPRs, no scratch.
+//   FMCMC_AMD_DEBUG_MODE=8 stamps (s_memtime) flag-wait / work time per wave into the draws buffer.
+// ==============================================================================================
+constexpr int SPEC_NT = 768;
+constexpr int SPEC_NCW = 8;   // compute wavefronts
+
+__device__ __forceinline__ unsigned lds_ld_u32(const unsigned* p) {
+  unsigned v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(size_t)p) : "memory");
+  return v;
+}
+
+template <int P, int OPT, int KIND>
+__global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
+  constexpr int CW = 4;
+  static_assert(OPT % 2 == 0, "OPT must be even (y is read back in pairs)");
+  extern __shared__ double smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int k = A.k, kz = A.kz;
+  double* s_th1 = smem;                            // [CW][PIPE_KMAX] proposals read by the evaluation
+  double* s_par = s_th1 + CW * PIPE_KMAX;          // [4][PIPE_KMAX]  mu, scale, lb, ub
+  unsigned* s_ready = (unsigned*)(s_par + 4 * PIPE_KMAX);  // [CW] version of theta1[c] that is published
+  unsigned* s_done = s_ready + CW;                         // [CW] partial arrivals (8 per version)
+  double* s_tr = s_par + 4 * PIPE_KMAX + CW;       // [CW][8][PIPE_TRS] lane partials, transposed
+  double* s_y = s_tr + CW * 8 * PIPE_TRS;          // [OPT/2][NT][2] this workgroup's copy of y
+  const long long cg0 = (long long)blockIdx.x * CW;
+  const int ncw = (int)((A.nchains - cg0 < CW) ? (A.nchains - cg0) : CW);
+  const int nsteps = (int)A.nsteps, burnin = (int)A.burnin, thin = (int)A.thin;
+  const int ic = A.intercept;
+  const bool dbg = (A.debug & 8) != 0;
+
+  // ---- cooperative set-up (all 12 waves): y -> LDS, kernel constants, initial theta1, flags
+  for (int e = tid; e < OPT * NT; e += SPEC_NT) {
+    const int s = e / NT, t = e - s * NT;
+    const long long i = (long long)t + (long long)NT * s;
+    s_y[((s >> 1) * NT + t) * 2 + (s & 1)] = (i < A.n) ? A.y[i] : 0.0;
+  }
+  if (tid < k) {
+    s_par[0 * PIPE_KMAX + tid] = A.mu[tid];
+    s_par[1 * PIPE_KMAX + tid] = A.scale[tid];
+    s_par[2 * PIPE_KMAX + tid] = A.lb[tid];
+    s_par[3 * PIPE_KMAX + tid] = A.ub[tid];
+  }
+  if (tid < CW * PIPE_KMAX) {
+    const int c = tid / PIPE_KMAX, j = tid - c * PIPE_KMAX;
+    s_th1[tid] = (c < ncw && j < k) ? A.theta0[(cg0 + c) * k + j] : 0.0;
+  }
+  if (tid < CW) { s_ready[tid] = 1u; s_done[tid] = 0u; }
+  __syncthreads();
+
+  if (wave < SPEC_NCW) {
+    // =========================== COMPUTE ROLE ===========================
+    double xr[OPT][P > 0 ? P : 1];
+    double wlast = 1.0;
+#pragma unroll
+    for (int s = 0; s < OPT; s++) {
+      const long long i = (long long)tid + (long long)NT * s;
+      const bool valid = i < A.n;
+#pragma unroll
+      for (int j = 0; j < P; j++) xr[s][j] = valid ? A.X[(long long)j * A.n + i] : 0.0;
+      if (s == OPT - 1) wlast = valid ? 1.0 : 0.0;
+    }
+    const int tr_slot = (tid & 7) * PIPE_TRS + (tid >> 3);
+    const double2* yp = reinterpret_cast<const double2*>(s_y) + tid;
+    unsigned long long tw = 0, te = 0;
+    for (int v = 1; v <= nsteps; v++) {
+      for (int c = 0; c < ncw; c++) {
+        unsigned long long t_a = dbg ? clk() : 0;
+        while (lds_ld_u32(&s_ready[c]) < (unsigned)v) __builtin_amdgcn_s_sleep(1);
+        unsigned long long t_b = dbg ? clk() : 0;
+        const double* t0 = s_th1 + c * PIPE_KMAX;
+        const double m00 = ic ? t0[0] : 0.0;
+        double b0[P > 0 ? P : 1];
+#pragma unroll
+        for (int j = 0; j < P; j++) b0[j] = t0[ic + j];
+        double a0 = 0.0;
+        double2 yy = yp[0];
+#pragma unroll
+        for (int s2 = 0; s2 < OPT / 2; s2++) {
+          const double2 ynext = yp[(s2 + 1 < OPT / 2 ? s2 + 1 : s2) * NT];
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            const int s = 2 * s2 + h;
+            const double yv = h ? yy.y : yy.x;
+            double m0 = m00;
+#pragma unroll
+            for (int j = 0; j < P; j++) m0 = fmh_fma(xr[s][j], b0[j], m0);
+            const double r0 = yv - m0;
+            if (s == OPT - 1) a0 = fmh_fma(r0 * wlast, r0, a0);
+            else a0 = fmh_fma(r0, r0, a0);
+          }
+          yy = ynext;
+        }
+        s_tr[c * (8 * PIPE_TRS) + tr_slot] = a0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // partials landed before the arrival is visible
+        if (lane == 0) __hip_atomic_fetch_add(&s_done[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (dbg) { unsigned long long t_c = clk(); tw += t_b - t_a; te += t_c - t_b; }
+      }
+    }
+    if (dbg && lane == 0 && A.draws) {
+      double* d = A.draws + ((long long)blockIdx.x * 12 + wave) * 4;
+      d[0] = (double)tw; d[1] = (double)te; d[2] = 0.0; d[3] = (double)nsteps;
+    }
+    return;
+  }
+
+  // =========================== OWNER ROLE ===========================
+  const int myc = wave - SPEC_NCW;
+  if (myc >= ncw) return;
+  const int cl = __builtin_amdgcn_readfirstlane((int)cg0 + myc);
+  const bool plane = (lane < k);
+  const int jl = plane ? lane : 0;
+  const bool fixed_l = A.fixed[jl] != 0;
+  int zidx = 0;
+  for (int j = 0; j < jl; j++) zidx += A.fixed[j] ? 0 : 1;
+  double th0 = plane ? A.theta0[(long long)cl * k + lane] : 0.0;
+  double th1 = th0;
+  double f0 = 0.0;
+  int nacc = 0, status = FMCMC_CHAIN_OK, thin_ctr = 0;
+  unsigned int srow8 = 0, bitword = 0;
+  const unsigned int sd_off = (unsigned int)((((long long)cl * k + jl) * A.S) * 8);
+  const unsigned int z_off = (unsigned int)((((long long)cl * nsteps) * kz + zidx) * 8);
+  const unsigned int lp_off = (unsigned int)(((long long)cl * A.S) * 8);
+  const double* const lu_row = A.fed_logu + (long long)cl * nsteps;
+  const double dn = uniform_d((double)A.n);
+  auto ld_z = [&](int row) -> double {
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(A.fed_z) + (z_off + (unsigned int)row * (unsigned int)(kz * 8)));
+  };
+  double z_nx = (plane && !fixed_l && nsteps >= 2) ? ld_z(1) : 0.0;   // variates of the NEXT proposal / decision
+  double lu_nx = (nsteps >= 2) ? lu_row[1] : 0.0;
+
+  auto logpost_of = [&](double tot, double sigma) -> double {
+    double f;
+    if (sigma < 0.0 || fmh_isnan(sigma)) {
+      f = fmh_nan();
+    } else if (sigma == 0.0) {
+      f = -fmh_inf();
+    } else {
+      double t1 = fmh_log(sigma) + FMH_K(FMH_LN_SQRT_2PI);
+      double q = (0.5 * tot) / (sigma * sigma);
+      f = -(dn * t1) - q;
+    }
+    if (A.guard && !fmh_isfinite(f)) f = -fmh_inf();
+    return f;
+  };
+  auto flush_bits = [&](int i) {
+    if (A.accept_bits && lane == 0)
+      A.accept_bits[(long long)cl * ((nsteps + 31) >> 5) + ((i - 1) >> 5)] = bitword;
+    bitword = 0;
+  };
+
+  unsigned long long tw = 0, tp = 0, tst = 0;
+  for (int v = 1; v <= nsteps; v++) {
+    // ---- wait for the 8 compute waves' partials of version v
+    unsigned long long t_a = dbg ? clk() : 0;
+    while (lds_ld_u32(&s_done[myc]) < 8u * (unsigned)v) __builtin_amdgcn_s_sleep(1);
+    unsigned long long t_b = dbg ? clk() : 0;
+    const double* src = s_tr + myc * (8 * PIPE_TRS) + lane;  // this lane folds canonical lanes 8*lane .. 8*lane+7
+    const double v0 = src[0 * PIPE_TRS], v1 = src[1 * PIPE_TRS], v2 = src[2 * PIPE_TRS], v3 = src[3 * PIPE_TRS];
+    const double v4 = src[4 * PIPE_TRS], v5 = src[5 * PIPE_TRS], v6 = src[6 * PIPE_TRS], v7 = src[7 * PIPE_TRS];
+    const double tot = wave_xor_sum(((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7)));
+    const double sigma = readlane_d(th1, k - 1);
+    const double f1 = logpost_of(tot, sigma);
+    const double th1_eval = th1;
+    bool keep_row = false;
+    if (v == 1) {                       // row 1: f0 = f(initial)
+      f0 = uniform_d(f1);
+      keep_row = true;
+    } else if (status == FMCMC_CHAIN_OK) {
+      const double ratio = f1 - f0;
+      if (fmh_isnan(f1) || fmh_isnan(ratio)) {
+        status = fmh_isnan(f1) ? FMCMC_CHAIN_NAN_LOGPOST : FMCMC_CHAIN_NAN_RATIO;
+        if (lane == 0) { A.status[cl] = status; A.status_step[cl] = v; }
+        if (plane) A.status_theta[(long long)cl * k + lane] = th1;
+        flush_bits(v);
+      } else {
+        const double lu = lu_nx;
+        lu_nx = lu_row[v < nsteps ? v : nsteps - 1];   // log u of step v + 1 (clamped), consumed a step later
+        if (lu < ratio) {
+          th0 = th1;
+          f0 = uniform_d(f1);
+          nacc += 1;
+          bitword |= (1u << ((v - 1) & 31));
+        }
+        keep_row = true;
+      }
+    }
+    const double th0_row = th0;
+    // ---- proposal of step v + 1, published for the compute waves
+    if (v < nsteps) {
+      if (status == FMCMC_CHAIN_OK && plane) {
+        double t = th0;
+        if (!fixed_l) {
+          t = th0 + (s_par[0 * PIPE_KMAX + lane] + s_par[1 * PIPE_KMAX + lane] * z_nx);
+          if (KIND == FMCMC_KERNEL_NORMAL_REFLECTIVE) t = reflect1(t, s_par[2 * PIPE_KMAX + lane], s_par[3 * PIPE_KMAX + lane]);
+          z_nx = ld_z(v + 1 < nsteps ? v + 1 : nsteps - 1);   // row of step v + 2 (clamped), awaited a step later
+        }
+        th1 = t;
+        s_th1[myc * PIPE_KMAX + lane] = t;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_store(&s_ready[myc], (unsigned)(v + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    unsigned long long t_c = dbg ? clk() : 0;
+    // ---- stores last (off the compute waves' critical path)
+    if (keep_row && v > burnin && !(dbg && A.draws)) {
+      thin_ctr += 1;
+      if (thin_ctr == thin) {
+        thin_ctr = 0;
+        if (plane) {
+          *reinterpret_cast<double*>(reinterpret_cast<char*>(A.samples) + (sd_off + srow8)) = th0_row;
+          if (A.draws) *reinterpret_cast<double*>(reinterpret_cast<char*>(A.draws) + (sd_off + srow8)) = th1_eval;
+        }
+        if (A.logpost && lane == 0) *reinterpret_cast<double*>(reinterpret_cast<char*>(A.logpost) + (lp_off + srow8)) = f1;
+        srow8 += 8;
+      }
+    }
+    if (status == FMCMC_CHAIN_OK && v >= 2 && (((v - 1) & 31) == 31 || v == nsteps)) flush_bits(v);
+    if (dbg) { unsigned long long t_d = clk(); tw += t_b - t_a; tp += t_c - t_b; tst += t_d - t_c; }
+  }
+  if (dbg && lane == 0 && A.draws) {
+    double* d = A.draws + ((long long)blockIdx.x * 12 + wave) * 4;
+    d[0] = (double)tw; d[1] = (double)tp; d[2] = (double)tst; d[3] = (double)nsteps;
+  }
+  // ---- write state back
+  if (plane) A.theta0[(long long)cl * k + lane] = th0;
+  if (lane == 0) {
+    A.f0[cl] = f0;
+    A.accept_count[cl] = nacc;
+    if (status == FMCMC_CHAIN_OK) { A.status[cl] = FMCMC_CHAIN_OK; A.status_step[cl] = 0; }
+  }
+}
+
+size_t spec_lds_bytes(int opt) { return sizeof(double) * ((size_t)8 * PIPE_KMAX + 4 + 4 * 8 * PIPE_TRS + (size_t)opt * NT); }
+
 size_t pipe_lds_bytes(int opt) { return sizeof(double) * ((size_t)8 * PIPE_KMAX + 4 * 8 * PIPE_TRS + (size_t)opt * NT); }
 
 // diagnostic: evaluates include/fmh_detmath.h / fmh_philox.h on the device (tests compare bitwise
@@ -1253,6 +1507,23 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcm
       if (e == hipSuccess)                                                                             \
         hipLaunchKernelGGL((mh_sweep_pipe<PV, OV, KV>), dim3((unsigned)pblk), dim3(NT), plds, stream, A); \
     } while (0)
+    const char* nospec = getenv("FMCMC_AMD_NO_SPEC");
+    if (!(nospec && nospec[0] == '1')) {
+      const size_t slds = spec_lds_bytes(pipe_opt);
+#define LAUNCH_SPEC(PV, OV, KV)                                                                        \
+      do {                                                                                             \
+        if (slds > 48 * 1024)                                                                          \
+          e = hipFuncSetAttribute((const void*)mh_sweep_spec<PV, OV, KV>,                             \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds);              \
+        if (e == hipSuccess)                                                                           \
+          hipLaunchKernelGGL((mh_sweep_spec<PV, OV, KV>), dim3((unsigned)pblk), dim3(SPEC_NT), slds, stream, A); \
+      } while (0)
+      if (pipe_opt == 20 && kn->kind == FMCMC_KERNEL_NORMAL) LAUNCH_SPEC(3, 20, 1);
+      else if (pipe_opt == 20) LAUNCH_SPEC(3, 20, 2);
+      else if (kn->kind == FMCMC_KERNEL_NORMAL) LAUNCH_SPEC(1, 2, 1);
+      else LAUNCH_SPEC(1, 2, 2);
+#undef LAUNCH_SPEC
+    } else
     if (pipe_opt == 20 && kn->kind == FMCMC_KERNEL_NORMAL) LAUNCH_PIPE(3, 20, 1);
     else if (pipe_opt == 20) LAUNCH_PIPE(3, 20, 2);
     else if (kn->kind == FMCMC_KERNEL_NORMAL) LAUNCH_PIPE(1, 2, 1);

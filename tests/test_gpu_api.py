@@ -190,3 +190,39 @@ def test_logistic_and_large_k_ram(E, O):
     yb = (rng.uniform(size=n) < 1 / (1 + np.exp(-(b[0] + X @ b[1:])))).astype(np.float64)
     run_both(E, O, O.FAM_LOGISTIC, X, yb, O.K_NORMAL_REFLECTIVE, 6, jitter_init(b, 9, 5), nsteps=150, thin=10,
              prior_div=8.0, scale=0.01, lb=-5.0, ub=5.0)
+
+
+def test_host_pointer_entry_point(E, O):
+    """fmcmc_mcmc_run_host: the call an R `.Call` shim makes (all pointers are host memory)."""
+    from fmcmc_amd import _abi as abi
+    X, y = synth_linreg(1500, 2, 5)
+    Cn, k, nsteps, burnin, thin = 5, 4, 300, 20, 3
+    init = np.ascontiguousarray(np.array([0, 0, 0, 4.0])[None, :] + 0.1 * np.random.default_rng(0).standard_normal((Cn, k)))
+    for kind, okw in ((O.K_NORMAL, dict(scale=0.05)), (O.K_ADAPT, dict(warmup=50)), (O.K_RAM, {})):
+        ok = O.Kernel(kind, k, **okw)
+        ro = O.run(O.Model(O.FAM_LINREG, X, y), ok, init, nsteps=nsteps, burnin=burnin, thin=thin, seed=77)
+        S = (nsteps - burnin) // thin
+        Xc = np.ascontiguousarray(X.T); yc = np.ascontiguousarray(y)
+        th = init.copy(); f0 = np.zeros(Cn); abs_iter = np.zeros(Cn, np.int64)
+        Sig = np.zeros((Cn, k, k)); mp = np.zeros((Cn, k)); hm = np.zeros(Cn, np.int32); ne = np.zeros(Cn, np.int32)
+        samples = np.empty((Cn, k, S)); lp = np.empty((Cn, S)); dr = np.empty((Cn, k, S))
+        acc = np.zeros(Cn, np.int64); bits = np.zeros((Cn, (nsteps + 31) // 32), np.uint32)
+        status = np.zeros(Cn, np.int32); sstep = np.zeros(Cn, np.int64); stheta = np.zeros((Cn, k))
+        P = lambda a: a.ctypes.data
+        m = abi.Model(abi.FAM_GAUSSIAN_LINREG, 2, 1500, P(Xc), P(yc), 1, 1, 0.0)
+        kk = abi.Kernel(kind, k, P(ok.mu), P(ok.scale), P(ok.lb), P(ok.ub), P(ok.fixed), 0, 1, ok.warmup, 0, ok.until,
+                        ok.eps, ok.arate, ok.Sd)
+        r = abi.Run(Cn, nsteps, burnin, thin, 77, 0, 0, 0, 0, None, None)
+        st = abi.State(P(th), P(f0), P(abs_iter), P(Sig), P(mp), P(hm), P(ne), 1, 0)
+        out = abi.Out(P(samples), P(lp), P(dr), P(acc), P(bits), P(status), P(sstep), P(stheta))
+        rc = abi.lib().fmcmc_mcmc_run_host(C.byref(m), C.byref(kk), C.byref(r), C.byref(st), C.byref(out), 0)
+        assert rc == 0, abi.last_error()
+        assert np.array_equal(_bits(samples), _bits(ro.samples_cks)) and np.array_equal(_bits(lp), _bits(ro.logpost))
+        assert np.array_equal(_bits(dr), _bits(ro.draws_cks)) and np.array_equal(bits, ro.accept_bits)
+        assert np.array_equal(_bits(th), _bits(ro.state.theta0)) and np.array_equal(acc, ro.accept_count)
+        if kind != O.K_NORMAL:
+            assert np.array_equal(_bits(Sig), _bits(ro.state.Sigma)) and np.array_equal(abs_iter, ro.state.abs_iter)
+    # argument errors come back through the return code + fmcmc_last_error()
+    r_bad = abi.Run(Cn, 10, 10, 1, 77, 0, 0, 0, 0, None, None)
+    assert abi.lib().fmcmc_mcmc_run_host(C.byref(m), C.byref(kk), C.byref(r_bad), C.byref(st), C.byref(out), 0) == abi.ERR_ARG
+    assert "-burnin- (10) cannot be >= than -nsteps- (10)." in abi.last_error()
