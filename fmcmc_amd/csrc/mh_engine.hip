@@ -236,16 +236,31 @@ __device__ __forceinline__ void eval_partials(const SweepArgs& A, double* const*
       }
     }
   } else {
+    // Memory-level parallelism: the data comes from L2 (latency ~1 us under load), so every thread keeps a
+    // batch of JB independent column loads in flight before the FMAs that consume them; a dependent
+    // load-use chain per (observation, column) left < 16 KB in flight per CU (10x below the L2 rate at k = 50).
+    constexpr int JB = 8;
     for (long long i = tid; i < n; i += NT) {
       double mu[CW];
 #pragma unroll
       for (int c = 0; c < CW; c++) mu[c] = ic ? th[c][0] : 0.0;
-      for (int j = 0; j < p; j++) {
+      const double yv = A.y[i];
+      int j = 0;
+      for (; j + JB <= p; j += JB) {
+        double xb[JB];
+#pragma unroll
+        for (int u = 0; u < JB; u++) xb[u] = A.X[(long long)(j + u) * n + i];
+#pragma unroll
+        for (int u = 0; u < JB; u++) {
+#pragma unroll
+          for (int c = 0; c < CW; c++) mu[c] = fmh_fma(xb[u], th[c][ic + j + u], mu[c]);
+        }
+      }
+      for (; j < p; j++) {
         double x = A.X[(long long)j * n + i];
 #pragma unroll
         for (int c = 0; c < CW; c++) mu[c] = fmh_fma(x, th[c][ic + j], mu[c]);
       }
-      const double yv = A.y[i];
 #pragma unroll
       for (int c = 0; c < CW; c++) {
         double r = yv - mu[c];
@@ -1125,10 +1140,16 @@ __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
 #pragma unroll
         for (int j = 0; j < P; j++) b0[j] = t0[ic + j];
         double a0 = 0.0;
-        double2 yy = yp[0];
+        // y pairs come from LDS three pairs (~30 FMAs) ahead of their use: LDS latency is ~130 cycles and only two
+        // compute waves share the SIMD, so a one-pair lookahead leaves the FMA pipe waiting on lgkmcnt
+        constexpr int YD = 3;
+        double2 yq[YD];
+#pragma unroll
+        for (int d = 0; d < YD; d++) yq[d] = yp[(d < OPT / 2 ? d : OPT / 2 - 1) * NT];
 #pragma unroll
         for (int s2 = 0; s2 < OPT / 2; s2++) {
-          const double2 ynext = yp[(s2 + 1 < OPT / 2 ? s2 + 1 : s2) * NT];
+          const double2 yy = yq[s2 % YD];
+          if (s2 + YD < OPT / 2) yq[s2 % YD] = yp[(s2 + YD) * NT];
 #pragma unroll
           for (int h = 0; h < 2; h++) {
             const int s = 2 * s2 + h;
@@ -1140,7 +1161,6 @@ __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
             if (s == OPT - 1) a0 = fmh_fma(r0 * wlast, r0, a0);
             else a0 = fmh_fma(r0, r0, a0);
           }
-          yy = ynext;
         }
         s_tr[c * (8 * PIPE_TRS) + tr_slot] = a0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // partials landed before the arrival is visible
