@@ -769,8 +769,8 @@ constexpr int PIPE_TRS = 66;  // row stride (doubles) of the transposed lane-par
 // to the observation data.  48 B per chain-step at k = 5: noise next to the 8 TB/s of HBM.
 __global__ __launch_bounds__(256) void rng_fill_kernel(unsigned long long seed, long long step_base,
                                                        long long chain_base, long long nchains,
-                                                       long long nsteps, int kz, double* __restrict__ logu,
-                                                       double* __restrict__ z) {
+                                                       long long nsteps, int kz, int student_df,
+                                                       double* __restrict__ logu, double* __restrict__ z) {
   const long long item = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (item >= nchains * nsteps) return;
   const long long c = item / nsteps;
@@ -782,6 +782,10 @@ __global__ __launch_bounds__(256) void rng_fill_kernel(unsigned long long seed, 
     return;
   }
   logu[item] = fmh_log_accept_u(seed, st, cg);
+  if (student_df > 0) {  // kernel_ram: qfun = rt(k, k)
+    for (int a = 0; a < kz; a++) z[item * kz + a] = fmh_student_t(seed, st, cg, (unsigned int)a, (double)student_df);
+    return;
+  }
   for (int b = 0; 2 * b < kz; b++) {
     double u0, u1;
     fmh_uniform2(seed, st, cg, (unsigned int)b, FMH_STREAM_NORMAL, &u0, &u1);
@@ -1075,6 +1079,267 @@ __device__ __forceinline__ unsigned lds_ld_u32(const unsigned* p) {
   return v;
 }
 
+constexpr int SPEC_ALD = PIPE_KMAX + 1;                       // row stride of the k x k matrices in LDS
+constexpr int SPEC_ADS = 7 * PIPE_KMAX + 2 * PIPE_KMAX * SPEC_ALD;  // doubles of adaptive state per chain
+
+// Owner role of the specialised kernel for kernel_adapt (R/kernel_adapt.R:117-180) and kernel_ram
+// (R/kernel_ram.R:123-158, unbounded parameters): same wave-collective arithmetic as mh_sweep_kernel (lanes = rows
+// of Sigma / S, twin of the oracle's propose_adapt / propose_ram), state in LDS, variates from the HBM stream.
+template <int KIND>
+__device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc, int cl, double* s_th1, double* s_par,
+                                                    unsigned* s_ready, unsigned* s_done, double* s_tr, double* ad) {
+  const int lane = threadIdx.x & 63;
+  const int k = A.k, kz = A.kz, nsteps = (int)A.nsteps, burnin = (int)A.burnin, thin = (int)A.thin;
+  constexpr int LD = SPEC_ALD;
+  double* th0 = ad;                    // [k]
+  double* th1 = th0 + PIPE_KMAX;       // [k]
+  double* vz = th1 + PIPE_KMAX;        // [kf] z / U of the pending proposal
+  double* vv = vz + PIPE_KMAX;         // [kf] S U, or x
+  double* vmp = vv + PIPE_KMAX;        // [kf] mean_prev
+  double* vmt = vmp + PIPE_KMAX;       // [kf] mean_t
+  double* vrs = vmt + PIPE_KMAX;       // [kf] running sum of ans rows
+  double* SigA = vrs + PIPE_KMAX;      // [kf][LD]
+  double* SigB = SigA + PIPE_KMAX * LD;
+  __shared__ int s_which[4][PIPE_KMAX];
+  int kf = 0;
+  for (int j = 0; j < k; j++)
+    if (!A.fixed[j]) { if (lane == 0) s_which[myc][kf] = j; kf++; }
+  const int* which = s_which[myc];
+  const double* s_mu = s_par, *s_lb = s_par + 2 * PIPE_KMAX, *s_ub = s_par + 3 * PIPE_KMAX;
+  double f0 = 0.0;
+  long long abs_iter = 0;
+  int nacc = 0, status = FMCMC_CHAIN_OK, thin_ctr = 0, have_mean = 0, nerr = 0;
+  unsigned int srow8 = 0, bitword = 0;
+  double* Scur = SigA;
+  double* Salt = SigB;
+  if (lane < k) { double t = A.theta0[(long long)cl * k + lane]; th0[lane] = t; th1[lane] = t; }
+  for (int e = lane; e < kf * LD; e += 64) {
+    const int a = e / LD, b = e % LD;
+    SigA[e] = A.fresh ? ((a == b) ? 1.0 * A.eps : 0.0) : ((b < kf) ? A.Sigma[((long long)cl * kf + a) * kf + b] : 0.0);
+    SigB[e] = 0.0;
+  }
+  if (!A.fresh) {
+    abs_iter = A.abs_iter[cl];
+    if (A.nerrors) nerr = A.nerrors[cl];
+    if (KIND == FMCMC_KERNEL_ADAPT) {
+      have_mean = A.have_mean[cl];
+      if (lane < kf) vmp[lane] = A.mean_prev[(long long)cl * kf + lane];
+    }
+  }
+  wave_sync();
+  const int jl = (lane < k) ? lane : 0;
+  const unsigned int sd_off = (unsigned int)((((long long)cl * k + jl) * A.S) * 8);
+  const unsigned int z_off = (unsigned int)((((long long)cl * nsteps) * kz + (lane < kz ? lane : 0)) * 8);
+  const unsigned int lp_off = (unsigned int)(((long long)cl * A.S) * 8);
+  const double* const lu_row = A.fed_logu + (long long)cl * nsteps;
+  auto ld_z = [&](int row) -> double {
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(A.fed_z) + (z_off + (unsigned int)row * (unsigned int)(kz * 8)));
+  };
+  double z_nx = (lane < kz && nsteps >= 2) ? ld_z(1) : 0.0;
+  double lu_nx = (nsteps >= 2) ? lu_row[1] : 0.0;
+  bool ram_gate = false;   // gate of the PENDING proposal (evaluated when it was made)
+  auto flush_bits = [&](int i) {
+    if (A.accept_bits && lane == 0) A.accept_bits[(long long)cl * ((nsteps + 31) >> 5) + ((i - 1) >> 5)] = bitword;
+    bitword = 0;
+  };
+
+  for (int v = 1; v <= nsteps; v++) {
+    while (lds_ld_u32(&s_done[myc]) < 8u * (unsigned)v) __builtin_amdgcn_s_sleep(1);
+    const double* src = s_tr + myc * (8 * PIPE_TRS) + lane;
+    const double v0 = src[0 * PIPE_TRS], v1 = src[1 * PIPE_TRS], v2 = src[2 * PIPE_TRS], v3 = src[3 * PIPE_TRS];
+    const double v4 = src[4 * PIPE_TRS], v5 = src[5 * PIPE_TRS], v6 = src[6 * PIPE_TRS], v7 = src[7 * PIPE_TRS];
+    const double tot = wave_xor_sum(((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7)));
+    const double f1 = finish_logpost(A, th1, tot);
+    bool keep_row = false;
+    if (v == 1) {
+      f0 = f1;
+      if (lane < kf) vrs[lane] = th0[which[lane]];
+      keep_row = true;
+    } else if (status == FMCMC_CHAIN_OK) {
+      const int i = v;
+      if (KIND == FMCMC_KERNEL_RAM) {   // adaptation with f(theta1) of the pending (un-reflected) proposal :129-152
+        if (ram_gate) {
+          double a_n = fmh_exp(f1 - f0);
+          if (fmh_isnan(a_n)) a_n = 0.0;
+          else if (a_n > 1.0) a_n = 1.0;
+          double eta = (double)kf * fmh_exp((-2.0 / 3.0) * fmh_log((double)i));
+          if (eta > 1.0) eta = 1.0;
+          double nrm2 = 0.0;
+          for (int b = 0; b < kf; b++) nrm2 = fmh_fma(vz[b], vz[b], nrm2);
+          double cp = (eta * (a_n - A.arate)) / nrm2;
+          if (cp != 0.0 && fmh_isfinite(cp)) {
+            const bool up = cp > 0.0;
+            const double scl = fmh_sqrt(fmh_abs(cp));
+            double w = (lane < kf) ? scl * vv[lane] : 0.0;
+            bool fail = false;
+            for (int j = 0; j < kf; j++) {
+              double ljj = Scur[j * LD + j];
+              double xj = shfl_d(w, j);
+              double r2 = up ? fmh_fma(xj, xj, ljj * ljj) : fmh_fma(-xj, xj, ljj * ljj);
+              if (!(r2 > 0.0) || !fmh_isfinite(r2)) { fail = true; break; }
+              double r = fmh_sqrt(r2);
+              double cc = r / ljj, ss = xj / ljj;
+              if (lane == j) {
+                Salt[j * LD + j] = r;
+              } else if (lane > j && lane < kf) {
+                double lij = Scur[lane * LD + j];
+                double ln = (up ? fmh_fma(ss, w, lij) : fmh_fma(-ss, w, lij)) / cc;
+                w = fmh_fma(-ss, ln, cc * w);
+                Salt[lane * LD + j] = ln;
+              }
+            }
+            wave_sync();
+            if (fail) nerr += 1;
+            else { double* t = Scur; Scur = Salt; Salt = t; }
+          }
+        }
+        abs_iter += 1;
+      }
+      if (fmh_isnan(f1)) status = FMCMC_CHAIN_NAN_LOGPOST;
+      const double ratio = f1 - f0;
+      if (status == FMCMC_CHAIN_OK && fmh_isnan(ratio)) status = FMCMC_CHAIN_NAN_RATIO;
+      if (status != FMCMC_CHAIN_OK) {
+        if (lane == 0) { A.status[cl] = status; A.status_step[cl] = i; }
+        if (lane < k) A.status_theta[(long long)cl * k + lane] = th1[lane];
+        flush_bits(i);
+      } else {
+        const double lu = lu_nx;
+        lu_nx = lu_row[v < nsteps ? v : nsteps - 1];
+        keep_row = true;
+        // row i of ans / draws / logpost (the proposal th1 is still the evaluated one here)
+        if (i > burnin) {
+          thin_ctr += 1;
+        }
+        const bool acc = lu < ratio;
+        const double dr = (lane < k) ? th1[lane] : 0.0;
+        if (acc) {
+          if (lane < k) th0[lane] = dr;
+          f0 = f1;
+          nacc += 1;
+          bitword |= (1u << ((i - 1) & 31));
+        }
+        wave_sync();
+        if (i > burnin && thin_ctr == thin) {
+          thin_ctr = 0;
+          if (lane < k) {
+            *reinterpret_cast<double*>(reinterpret_cast<char*>(A.samples) + (sd_off + srow8)) = th0[lane];
+            if (A.draws) *reinterpret_cast<double*>(reinterpret_cast<char*>(A.draws) + (sd_off + srow8)) = dr;
+          }
+          if (A.logpost && lane == 0) *reinterpret_cast<double*>(reinterpret_cast<char*>(A.logpost) + (lp_off + srow8)) = f1;
+          srow8 += 8;
+        }
+        if (KIND == FMCMC_KERNEL_ADAPT && lane < kf) vrs[lane] = vrs[lane] + th0[which[lane]];
+        if (((i - 1) & 31) == 31 || i == nsteps) flush_bits(i);
+      }
+    }
+    if (v == 1 && keep_row && 1 > burnin) {   // row 1 (R/mcmc.R:737-743)
+      thin_ctr += 1;
+      if (thin_ctr == thin) {
+        thin_ctr = 0;
+        if (lane < k) {
+          *reinterpret_cast<double*>(reinterpret_cast<char*>(A.samples) + (sd_off + srow8)) = th0[lane];
+          if (A.draws) *reinterpret_cast<double*>(reinterpret_cast<char*>(A.draws) + (sd_off + srow8)) = th1[lane];
+        }
+        if (A.logpost && lane == 0) *reinterpret_cast<double*>(reinterpret_cast<char*>(A.logpost) + (lp_off + srow8)) = f1;
+        srow8 += 8;
+      }
+    }
+    // ---- proposal of loop step i = v + 1
+    if (v < nsteps) {
+      if (status == FMCMC_CHAIN_OK) {
+        const int i = v + 1;
+        wave_sync();
+        if (lane < kz) vz[lane] = z_nx;
+        z_nx = (lane < kz) ? ld_z(v + 1 < nsteps ? v + 1 : nsteps - 1) : 0.0;
+        wave_sync();
+        if (KIND == FMCMC_KERNEL_ADAPT) {
+          if (A.until > (double)abs_iter && abs_iter > A.warmup && i > 2) {
+            const double t = (double)(abs_iter - 1);
+            double x = 0, mp = 0, mt = 0;
+            if (lane < kf) {
+              x = th0[which[lane]];
+              mp = have_mean ? vmp[lane] : (vrs[lane] / (double)(i - 1));
+              mt = (mp * t + x) / (t + 1);
+              vv[lane] = x; vmp[lane] = mp; vmt[lane] = mt;
+            }
+            wave_sync();
+            if (lane < kf) {
+              const double c1 = (t - 1) / t, c2 = 1.0 / t;
+              for (int b = 0; b < kf; b++) {
+                double ik = (b == lane) ? 1.0 * A.eps : 0.0;
+                double inner = t * (mp * vmp[b]) - (t + 1) * (mt * vmt[b]) + x * vv[b] + 1e-5 * ik;
+                SigA[lane * LD + b] = c1 * SigA[lane * LD + b] + c2 * inner;
+              }
+            }
+            wave_sync();
+            if (lane < kf) vmp[lane] = mt;
+            have_mean = 1;
+          }
+          abs_iter += 1;
+          bool notpd = false;
+          for (int j = 0; j < kf; j++) {
+            double sacc = 0.0;
+            if (lane >= j && lane < kf) {
+              sacc = SigA[lane * LD + j];
+              for (int b = 0; b < j; b++) sacc = fmh_fma(-SigB[lane * LD + b], SigB[j * LD + b], sacc);
+            }
+            double d = shfl_d(sacc, j);
+            if (!(d > 0.0) || !fmh_isfinite(d)) { notpd = true; break; }
+            double ljj = fmh_sqrt(d);
+            if (lane == j) SigB[j * LD + j] = ljj;
+            else if (lane > j && lane < kf) SigB[lane * LD + j] = sacc / ljj;
+            wave_sync();
+          }
+          if (notpd) {
+            status = FMCMC_CHAIN_NOT_PD;
+            if (lane == 0) { A.status[cl] = status; A.status_step[cl] = i; }
+            if (lane < k) A.status_theta[(long long)cl * k + lane] = th1[lane];
+          } else {
+            if (lane < k) th1[lane] = th0[lane];
+            wave_sync();
+            if (lane < kf) {
+              double sacc = 0.0;
+              for (int b = 0; b <= lane; b++) sacc = fmh_fma(SigB[lane * LD + b], vz[b], sacc);
+              const int j = which[lane];
+              th1[j] = reflect1(th0[j] + (s_mu[j] + sacc), s_lb[j], s_ub[j]);
+            }
+          }
+        } else {  // RAM P1 :123-126 (theta1 keeps its previous values in fixed coordinates)
+          if (lane < kf) {
+            double sacc = 0.0;
+            for (int b = 0; b <= lane; b++) sacc = fmh_fma(Scur[lane * LD + b], vz[b], sacc);
+            vv[lane] = sacc;
+            const int j = which[lane];
+            th1[j] = th0[j] + sacc;
+          }
+          ram_gate = (A.until > (double)abs_iter && abs_iter > A.warmup);
+        }
+        wave_sync();
+        if (lane < k) s_th1[myc * PIPE_KMAX + lane] = th1[lane];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_store(&s_ready[myc], (unsigned)(v + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+  // ---- write state back
+  wave_sync();
+  if (lane < k) A.theta0[(long long)cl * k + lane] = th0[lane];
+  if (lane == 0) {
+    A.f0[cl] = f0;
+    A.accept_count[cl] = nacc;
+    if (status == FMCMC_CHAIN_OK) { A.status[cl] = FMCMC_CHAIN_OK; A.status_step[cl] = 0; }
+    A.abs_iter[cl] = abs_iter;
+    if (A.nerrors) A.nerrors[cl] = nerr;
+    if (KIND == FMCMC_KERNEL_ADAPT) A.have_mean[cl] = have_mean;
+  }
+  const double* Sfin = (KIND == FMCMC_KERNEL_RAM) ? Scur : SigA;
+  for (int e = lane; e < kf * kf; e += 64) {
+    const int a = e / kf, b = e % kf;
+    A.Sigma[((long long)cl * kf + a) * kf + b] = Sfin[a * LD + b];
+  }
+  if (KIND == FMCMC_KERNEL_ADAPT && lane < kf) A.mean_prev[(long long)cl * kf + lane] = vmp[lane];
+}
+
 template <int P, int OPT, int KIND>
 __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
   constexpr int CW = 4;
@@ -1089,6 +1354,7 @@ __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
   unsigned* s_done = s_ready + CW;                         // [CW] partial arrivals (8 per version)
   double* s_tr = s_par + 4 * PIPE_KMAX + CW;       // [CW][8][PIPE_TRS] lane partials, transposed
   double* s_y = s_tr + CW * 8 * PIPE_TRS;          // [OPT/2][NT][2] this workgroup's copy of y
+  double* s_ad = s_y + OPT * NT;                   // KIND >= 3: [CW][SPEC_ADS] adaptive per-chain state
   const long long cg0 = (long long)blockIdx.x * CW;
   const int ncw = (int)((A.nchains - cg0 < CW) ? (A.nchains - cg0) : CW);
   const int nsteps = (int)A.nsteps, burnin = (int)A.burnin, thin = (int)A.thin;
@@ -1179,6 +1445,10 @@ __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
   const int myc = wave - SPEC_NCW;
   if (myc >= ncw) return;
   const int cl = __builtin_amdgcn_readfirstlane((int)cg0 + myc);
+  if constexpr (KIND == FMCMC_KERNEL_ADAPT || KIND == FMCMC_KERNEL_RAM) {
+    spec_owner_adaptive<KIND>(A, myc, cl, s_th1, s_par, s_ready, s_done, s_tr, s_ad + myc * SPEC_ADS);
+    return;
+  }
   const bool plane = (lane < k);
   const int jl = plane ? lane : 0;
   const bool fixed_l = A.fixed[jl] != 0;
@@ -1302,7 +1572,9 @@ __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
   }
 }
 
-size_t spec_lds_bytes(int opt) { return sizeof(double) * ((size_t)8 * PIPE_KMAX + 4 + 4 * 8 * PIPE_TRS + (size_t)opt * NT); }
+size_t spec_lds_bytes(int opt, bool adaptive) {
+  return sizeof(double) * ((size_t)8 * PIPE_KMAX + 4 + 4 * 8 * PIPE_TRS + (size_t)opt * NT + (adaptive ? 4 * SPEC_ADS : 0));
+}
 
 size_t pipe_lds_bytes(int opt) { return sizeof(double) * ((size_t)8 * PIPE_KMAX + 4 * 8 * PIPE_TRS + (size_t)opt * NT); }
 
@@ -1494,10 +1766,12 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcm
   }
   // software-pipelined fast path: normal kernels, joint scheme, k <= 16, linreg data in registers
   const char* nopipe = getenv("FMCMC_AMD_NO_PIPE");
+  const char* nospec0 = getenv("FMCMC_AMD_NO_SPEC");
   int pipe_opt = 0;
   if (!(force && force[0] == '1') && !(nopipe && nopipe[0] == '1') && m->family == FMCMC_FAM_GAUSSIAN_LINREG &&
-      (kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE) &&
-      kn->scheme == FMCMC_SCHEME_JOINT && kn->k <= PIPE_KMAX &&
+      (kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE ||
+       ((kn->kind == FMCMC_KERNEL_ADAPT || (kn->kind == FMCMC_KERNEL_RAM && !ram_bounded)) && !(nospec0 && nospec0[0] == '1'))) &&
+      (kn->scheme == FMCMC_SCHEME_JOINT || kn->kind >= FMCMC_KERNEL_ADAPT) && kn->k <= PIPE_KMAX &&
       (unsigned long long)run->nchains * kn->k * (unsigned long long)A.S * 8ull < (1ull << 32) &&
       (unsigned long long)run->nchains * (unsigned long long)run->nsteps * (unsigned long long)A.kz * 8ull < (1ull << 32)) {
     if (m->p == 3 && m->n > (long long)NT * 19 && m->n <= (long long)NT * 20) pipe_opt = 20;
@@ -1514,7 +1788,8 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcm
       if (e != hipSuccess) { set_err("hipMallocAsync(rng stream) failed: %s", hipGetErrorString(e)); return FMCMC_ERR_DEVICE; }
       hipLaunchKernelGGL(rng_fill_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream,
                          (unsigned long long)run->seed, (long long)run->step_base, (long long)run->chain_base,
-                         (long long)run->nchains, (long long)run->nsteps, A.kz, ws, ws + items);
+                         (long long)run->nchains, (long long)run->nsteps, A.kz,
+                         (kn->kind == FMCMC_KERNEL_RAM) ? kf : 0, ws, ws + items);
       A.fed_logu = ws;
       A.fed_z = ws + items;
       A.rng_mode = FMCMC_RNG_FED;
@@ -1529,7 +1804,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcm
     } while (0)
     const char* nospec = getenv("FMCMC_AMD_NO_SPEC");
     if (!(nospec && nospec[0] == '1')) {
-      const size_t slds = spec_lds_bytes(pipe_opt);
+      const size_t slds = spec_lds_bytes(pipe_opt, kn->kind >= FMCMC_KERNEL_ADAPT);
 #define LAUNCH_SPEC(PV, OV, KV)                                                                        \
       do {                                                                                             \
         if (slds > 48 * 1024)                                                                          \
@@ -1538,10 +1813,21 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcm
         if (e == hipSuccess)                                                                           \
           hipLaunchKernelGGL((mh_sweep_spec<PV, OV, KV>), dim3((unsigned)pblk), dim3(SPEC_NT), slds, stream, A); \
       } while (0)
-      if (pipe_opt == 20 && kn->kind == FMCMC_KERNEL_NORMAL) LAUNCH_SPEC(3, 20, 1);
-      else if (pipe_opt == 20) LAUNCH_SPEC(3, 20, 2);
-      else if (kn->kind == FMCMC_KERNEL_NORMAL) LAUNCH_SPEC(1, 2, 1);
-      else LAUNCH_SPEC(1, 2, 2);
+      if (pipe_opt == 20) {
+        switch (kn->kind) {
+          case FMCMC_KERNEL_NORMAL: LAUNCH_SPEC(3, 20, 1); break;
+          case FMCMC_KERNEL_NORMAL_REFLECTIVE: LAUNCH_SPEC(3, 20, 2); break;
+          case FMCMC_KERNEL_ADAPT: LAUNCH_SPEC(3, 20, 3); break;
+          default: LAUNCH_SPEC(3, 20, 4); break;
+        }
+      } else {
+        switch (kn->kind) {
+          case FMCMC_KERNEL_NORMAL: LAUNCH_SPEC(1, 2, 1); break;
+          case FMCMC_KERNEL_NORMAL_REFLECTIVE: LAUNCH_SPEC(1, 2, 2); break;
+          case FMCMC_KERNEL_ADAPT: LAUNCH_SPEC(1, 2, 3); break;
+          default: LAUNCH_SPEC(1, 2, 4); break;
+        }
+      }
 #undef LAUNCH_SPEC
     } else
     if (pipe_opt == 20 && kn->kind == FMCMC_KERNEL_NORMAL) LAUNCH_PIPE(3, 20, 1);
