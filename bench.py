@@ -119,10 +119,20 @@ def main():
                       np.full(K_PAR, -E.DBL_MAX), np.full(K_PAR, E.DBL_MAX), np.zeros(K_PAR, np.uint8), device=dev)
     init_d = torch.as_tensor(init).to(dev)
 
+    # the canonical Philox stream of a sweep is generated by its own small kernel into reusable HBM buffers,
+    # then the sweep consumes it (bit-identical to letting the library do both); two launches per step
+    logu_buf = torch.empty((chains, iters), dtype=torch.float64, device=dev)
+    z_buf = torch.empty((chains, iters, K_PAR), dtype=torch.float64, device=dev)
+    ev_mid = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    cur = {"s": None}
+
     def one_step():
         st = E.ChainState(init_d, K_PAR, device=dev)
+        E.rng_stream(st, gk, iters, seed=CHAIN_SEED, chain_base=chain_base, logu=logu_buf, z=z_buf)
+        if cur["s"] is not None:
+            ev_mid[cur["s"]].record()
         return E.sweep(gm, gk, st, iters, seed=CHAIN_SEED, chain_base=chain_base, want_logpost=True,
-                       want_draws=True, want_bits=False, check=False)
+                       want_draws=True, want_bits=False, check=False, fed_logu=logu_buf, fed_z=z_buf)
 
     for _ in range(args.warmup):
         out = one_step()
@@ -133,8 +143,9 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for s in range(args.steps):
-        ev[s][0].record()            # same stream the sweep kernel is launched on
-        out = one_step()
+        cur["s"] = s
+        ev[s][0].record()            # same stream the kernels are launched on
+        out = one_step()             # rng_fill_kernel | ev_mid | output allocation + mh_sweep kernel
         ev[s][1].record()
     torch.cuda.synchronize()
     if world > 1:
@@ -148,7 +159,8 @@ def main():
     assert int(out.status.abs().sum().item()) == 0, "a chain reported an error"
     # kernel duration: HIP events around the launch (the bracket also contains the output allocation
     # memset, < 1% of the sweep); rocprofv3 --kernel-trace --stats of the same command: profiles/
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    kern_ms = float(np.mean([ev_mid[s].elapsed_time(ev[s][1]) for s in range(args.steps)]))   # sweep kernel (+ its output memsets)
+    rng_ms = float(np.mean([ev[s][0].elapsed_time(ev_mid[s]) for s in range(args.steps)]))
     samples_per_step = chains * (iters - 1)
     value = world * samples_per_step * args.steps / elapsed
     acc = float(out.accept_count.double().mean().item()) / (iters - 1)
@@ -175,7 +187,7 @@ def main():
             "roofline": {"bound": "mfma", "pipe": "fp64 vector ALU (MI355X fp64 vector peak == fp64 matrix peak)",
                          "achieved": ach_tflops, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tflops / PEAK_FP64_TFLOPS, "traffic": traffic,
-                         "kernel": "mh_sweep", "kernel_ms": kern_ms,
+                         "kernel": "mh_sweep_spec<3,20,1>", "kernel_ms": kern_ms, "rng_fill_kernel_ms": rng_ms,
                          "flops_per_sample": flops_per_sample(),
                          "hbm": {"achieved_GBps": out_bytes / (kern_ms * 1e-3) / 1e9, "peak_GBps": PEAK_HBM_GBS,
                                  "algorithmic_bytes_per_launch": out_bytes}},

@@ -19,7 +19,7 @@ MAX_K = 64
 EXPORTS = ["fmcmc_abi_version", "fmcmc_last_error", "fmcmc_device_count", "fmcmc_kept_rows",
            "fmcmc_validate", "fmcmc_mcmc_run_dev", "fmcmc_mcmc_run_host", "fmcmc_gelman_partial_len",
            "fmcmc_gelman_work_len",
-           "fmcmc_gelman_partial_dev", "fmcmc_gelman_finish", "fmcmc_detmath_dev"]
+           "fmcmc_gelman_partial_dev", "fmcmc_gelman_finish", "fmcmc_detmath_dev", "fmcmc_rng_stream_dev"]
 
 
 class Model(C.Structure):
@@ -90,6 +90,9 @@ def lib():
                                                C.c_void_p, C.c_void_p]
         L.fmcmc_gelman_finish.restype = C.c_int
         L.fmcmc_gelman_finish.argtypes = [_dp, C.c_int32, C.c_int64, _dp, _dp]
+        L.fmcmc_rng_stream_dev.restype = C.c_int
+        L.fmcmc_rng_stream_dev.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
+                                           C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.fmcmc_detmath_dev.restype = C.c_int
         L.fmcmc_detmath_dev.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p]
         _lib = L

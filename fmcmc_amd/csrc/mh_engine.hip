@@ -1852,6 +1852,16 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcm
   return FMCMC_OK;
 }
 
+int fmcmc_rng_stream_dev(uint64_t seed, int64_t step_base, int64_t chain_base, int64_t nchains, int64_t nsteps,
+                         int32_t kz, int32_t student_df, double* logu, double* z, void* hip_stream) {
+  if (!logu || !z || nchains < 1 || nsteps < 1 || kz < 1) { set_err("fmcmc_rng_stream_dev: bad argument"); return FMCMC_ERR_ARG; }
+  const size_t items = (size_t)nchains * (size_t)nsteps;
+  hipLaunchKernelGGL(rng_fill_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream,
+                     (unsigned long long)seed, (long long)step_base, (long long)chain_base, (long long)nchains,
+                     (long long)nsteps, (int)kz, (int)student_df, logu, z);
+  return hipGetLastError() == hipSuccess ? FMCMC_OK : FMCMC_ERR_DEVICE;
+}
+
 int fmcmc_detmath_dev(int which, const double* x, double* out, int64_t n, uint64_t seed, void* hip_stream) {
   if (n <= 0) return FMCMC_OK;
   hipLaunchKernelGGL(detmath_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream,

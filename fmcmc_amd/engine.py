@@ -173,6 +173,29 @@ def sweep(model, kernel, state, nsteps, burnin=0, thin=1, seed=0, chain_base=0,
     return out
 
 
+def rng_stream(state, kernel, nsteps, seed=0, chain_base=0, logu=None, z=None, stream=None):
+    """Canonical Philox stream of the next sweep of `state` in HBM (fmcmc_rng_stream_dev); pass the returned
+    tensors as fed_logu / fed_z to sweep(): bit-identical to the in-library stream, buffers reusable."""
+    L = abi.lib()
+    dev = state.device
+    Cn = state.theta0.shape[0]
+    ordered = (kernel.scheme == abi.SCHEME_ORDERED and kernel.kind <= abi.KERNEL_NORMAL_REFLECTIVE)
+    kz = 1 if ordered else kernel.kf
+    if logu is None:
+        logu = torch.empty((Cn, nsteps), dtype=torch.float64, device=dev)
+    if z is None:
+        z = torch.empty((Cn, nsteps, kz), dtype=torch.float64, device=dev)
+    if stream is None:
+        stream = torch.cuda.current_stream(dev)
+    with torch.cuda.device(dev):
+        rc = L.fmcmc_rng_stream_dev(seed & 0xFFFFFFFFFFFFFFFF, state.step_base, chain_base, Cn, nsteps, kz,
+                                    kernel.kf if kernel.kind == abi.KERNEL_RAM else 0, logu.data_ptr(), z.data_ptr(),
+                                    C.c_void_p(stream.cuda_stream))
+    if rc != abi.OK:
+        raise RuntimeError("fmcmc_rng_stream_dev failed (%d): %s" % (rc, abi.last_error()))
+    return logu, z
+
+
 def raise_on_chain_error(out, chain_base=0):
     st = out.status.cpu().numpy()
     bad = np.nonzero(st)[0]

@@ -186,6 +186,14 @@ int fmcmc_gelman_partial_dev(const double* samples, int64_t nchains, int32_t k, 
 int fmcmc_gelman_finish(const double* partial, int32_t p, int64_t N, double* psrf,
                         double* mpsrf);
 
+/* Materialises the canonical Philox stream of a call in device memory, in the FED layout of fmcmc_run:
+ * logu[C][nsteps] (entry i-1 = log accept-uniform of loop step i), z[C][nsteps][kz] (N(0,1), or Student-t
+ * with student_df degrees of freedom when student_df > 0, the qfun of R/kernel_ram.R:68).  A sweep run with
+ * rng_mode = FMCMC_RNG_FED on these buffers is bit-identical to rng_mode = FMCMC_RNG_PHILOX; callers that
+ * launch many sweeps can reuse the buffers instead of letting the library allocate them per call. */
+int fmcmc_rng_stream_dev(uint64_t seed, int64_t step_base, int64_t chain_base, int64_t nchains, int64_t nsteps,
+                         int32_t kz, int32_t student_df, double* logu, double* z, void* hip_stream);
+
 /* Diagnostic: evaluate the canonical math / RNG primitives on the device, element-wise
  * (which: 0 log, 1 exp, 2 log1p, 3 qnorm, 4 log accept-u, 5 normal, 6 student-t(df=x), 7 sqrt,
  * 8 reciprocal). Used by tests to prove host/device bit-equality of include/fmh_*.h. */

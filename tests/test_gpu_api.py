@@ -226,3 +226,25 @@ def test_host_pointer_entry_point(E, O):
     r_bad = abi.Run(Cn, 10, 10, 1, 77, 0, 0, 0, 0, None, None)
     assert abi.lib().fmcmc_mcmc_run_host(C.byref(m), C.byref(kk), C.byref(r_bad), C.byref(st), C.byref(out), 0) == abi.ERR_ARG
     assert "-burnin- (10) cannot be >= than -nsteps- (10)." in abi.last_error()
+
+
+@pytest.mark.parametrize("kind", ["normal", "ram"])
+def test_rng_stream_entry_point_equals_in_library_stream(E, O, kind):
+    """fmcmc_rng_stream_dev + rng_mode FED is bit-identical to rng_mode PHILOX (what bench.py relies on)."""
+    import torch
+    from fmcmc_amd import _abi as abi
+    X, y = synth_linreg(10000, 3, 20260102)
+    init = np.array([0, 0, 0, 0, float(np.std(y))])[None, :] + 0.1 * np.random.default_rng(3).standard_normal((6, 5))
+    init[:, -1] = np.abs(init[:, -1])
+    ok = O.Kernel(O.K_NORMAL if kind == "normal" else O.K_RAM, 5, **(dict(scale=0.02) if kind == "normal" else {}))
+    gk = E.KernelSpec(ok.kind, 5, ok.mu, ok.scale, ok.lb, ok.ub, ok.fixed, warmup=ok.warmup, eps=ok.eps, arate=ok.arate)
+    gm = E.DeviceModel(abi.FAM_GAUSSIAN_LINREG, X, y)
+    st1, st2 = E.ChainState(init, 5), E.ChainState(init, 5)
+    a = E.sweep(gm, gk, st1, 120, seed=11, chain_base=40)
+    logu, z = E.rng_stream(st2, gk, 120, seed=11, chain_base=40)
+    b = E.sweep(gm, gk, st2, 120, seed=11, chain_base=40, fed_logu=logu, fed_z=z)
+    torch.cuda.synchronize()
+    assert np.array_equal(_bits(a.samples.cpu().numpy()), _bits(b.samples.cpu().numpy()))
+    assert np.array_equal(_bits(a.logpost.cpu().numpy()), _bits(b.logpost.cpu().numpy()))
+    ro = O.run(O.Model(O.FAM_LINREG, X, y), ok, init, nsteps=120, seed=11, chain_base=40)
+    assert np.array_equal(_bits(b.samples.cpu().numpy()), _bits(ro.samples_cks))
