@@ -1079,6 +1079,223 @@ __device__ __forceinline__ unsigned lds_ld_u32(const unsigned* p) {
   return v;
 }
 
+// ==============================================================================================
+// MFMA evaluation kernel for the headline shape: Gaussian linear regression with exactly 3 covariates.
+//
+// v_mfma_f64_4x4x4_4b_f64 on gfx950 (measured, tools/mfma64_exact.hip): k = lane / 16; inside a 16-lane group the
+// A operand sits at 4*blk + i, B at 4*blk + j, the result D at lane 16*i + 4*blk + j; and it is BITWISE the chain
+//     D = fma(a3, b3, fma(a2, b2, fma(a1, b1, fma(a0, b0, C)))).
+// With A = [x1, x2, x3, y], B = [b1, b2, b3, -1] and C = b0 this is exactly the canonical
+//     m = fma(x3, b3, fma(x2, b2, fma(x1, b1, b0)));   -r = fma(y, -1, m)
+// for 16 observations x 4 chains per instruction, and fma(D, D, acc) == fma(r, r, acc) bit for bit.
+// One MFMA replaces 16 x 4 x 4 = 256 VALU lane-FMAs + 64 subtractions with ONE issue slot, which lifts the
+// fp64 pipe out of the VALU issue limit (~6.2 ticks per instruction at 2 waves per SIMD).
+//
+// Mapping that keeps the canonical reduction: wave w owns canonical lanes 64w..64w+63; MFMA t = 4*s + g covers
+// slot s (observations i = lane + 512 s) of lanes 64w + 16g + o, o = 4*blk + i_row; result lane L holds chain
+// j = L % 4 of canonical lane 64w + 16g + 4*((L/4)%4) + L/16, accumulated in acc[g] in slot order; the four
+// accumulators are written to the same transposed partial tile the owners fold with the canonical tree.
+// All four chains of the workgroup are evaluated together, so this kernel is not chain-pipelined: a step is
+// evaluation | barrier | 4 owner phases in parallel (waves 0..3, priority raised) | barrier.
+// ==============================================================================================
+constexpr int MF_NMF = 80;   // MFMAs per wave per step: 20 slots x 4 lane groups
+
+template <int KIND>
+__global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
+  constexpr int CW = 4, OPT = 20;
+  extern __shared__ double smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int k = A.k, kz = A.kz;
+  double* s_th1 = smem;                            // [CW][PIPE_KMAX]
+  double* s_par = s_th1 + CW * PIPE_KMAX;          // [4][PIPE_KMAX]
+  double* s_tr = s_par + 4 * PIPE_KMAX;            // [CW][8][PIPE_TRS]
+  const long long cg0 = (long long)blockIdx.x * CW;
+  const int ncw = (int)((A.nchains - cg0 < CW) ? (A.nchains - cg0) : CW);
+  const int nsteps = (int)A.nsteps, burnin = (int)A.burnin, thin = (int)A.thin;
+  const int ic = A.intercept;
+
+  // ---- A operand: feature kf_ = lane / 16 of observation (64 w + 16 g + lane % 16) + 512 s, for t = 4 s + g
+  const int feat = lane >> 4, o16 = lane & 15;
+  double areg[MF_NMF];
+#pragma unroll
+  for (int t = 0; t < MF_NMF; t++) {
+    const int sl = t >> 2, g = t & 3;
+    const long long i = (long long)(64 * wave + 16 * g + o16) + (long long)NT * sl;
+    const bool valid = i < A.n;
+    areg[t] = valid ? (feat < 3 ? A.X[(long long)feat * A.n + i] : A.y[i]) : 0.0;
+  }
+  // result lane L: chain j = L % 4, canonical lane 64 w + 16 g + 4*((L/4)%4) + L/16
+  const int jch = lane & 3;
+  const int cl_in_g = 4 * ((lane >> 2) & 3) + (lane >> 4);
+  double wm[4];          // validity of the last slot per lane group (earlier slots are full: n > 512*19)
+  int trs[4];            // transposed tile slot of this lane's canonical lane, per group
+#pragma unroll
+  for (int g = 0; g < 4; g++) {
+    const int l = 64 * wave + 16 * g + cl_in_g;
+    wm[g] = ((long long)l + (long long)NT * (OPT - 1) < A.n) ? 1.0 : 0.0;
+    trs[g] = (l & 7) * PIPE_TRS + (l >> 3);
+  }
+  if (tid < k) {
+    s_par[0 * PIPE_KMAX + tid] = A.mu[tid];
+    s_par[1 * PIPE_KMAX + tid] = A.scale[tid];
+    s_par[2 * PIPE_KMAX + tid] = A.lb[tid];
+    s_par[3 * PIPE_KMAX + tid] = A.ub[tid];
+  }
+  if (tid < CW * PIPE_KMAX) {
+    const int c = tid / PIPE_KMAX, j = tid - c * PIPE_KMAX;
+    s_th1[tid] = (c < ncw && j < k) ? A.theta0[(cg0 + c) * k + j] : 0.0;
+  }
+
+  // ---- owner state (waves 0..3), as in mh_sweep_spec
+  const int myc = wave;
+  const bool owner = (myc < ncw);
+  const int cl = __builtin_amdgcn_readfirstlane((int)cg0 + (owner ? myc : 0));
+  const bool plane = owner && (lane < k);
+  const int jl = (lane < k) ? lane : 0;
+  const bool fixed_l = A.fixed[jl] != 0;
+  int zidx = 0;
+  for (int j = 0; j < jl; j++) zidx += A.fixed[j] ? 0 : 1;
+  double th0 = plane ? A.theta0[(long long)cl * k + lane] : 0.0;
+  double th1 = th0;
+  double f0 = 0.0;
+  int nacc = 0, status = FMCMC_CHAIN_OK, thin_ctr = 0;
+  unsigned int srow8 = 0, bitword = 0;
+  const unsigned int sd_off = (unsigned int)((((long long)cl * k + jl) * A.S) * 8);
+  const unsigned int z_off = (unsigned int)((((long long)cl * nsteps) * kz + zidx) * 8);
+  const unsigned int lp_off = (unsigned int)(((long long)cl * A.S) * 8);
+  const double* const lu_row = A.fed_logu + (long long)cl * nsteps;
+  const double dn = uniform_d((double)A.n);
+  auto ld_z = [&](int row) -> double {
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(A.fed_z) + (z_off + (unsigned int)row * (unsigned int)(kz * 8)));
+  };
+  double z_nx = (plane && !fixed_l && nsteps >= 2) ? ld_z(1) : 0.0;
+  double lu_nx = (owner && nsteps >= 2) ? lu_row[1] : 0.0;
+  auto logpost_of = [&](double tot, double sigma) -> double {
+    double f;
+    if (sigma < 0.0 || fmh_isnan(sigma)) {
+      f = fmh_nan();
+    } else if (sigma == 0.0) {
+      f = -fmh_inf();
+    } else {
+      double t1 = fmh_log(sigma) + FMH_K(FMH_LN_SQRT_2PI);
+      double q = (0.5 * tot) / (sigma * sigma);
+      f = -(dn * t1) - q;
+    }
+    if (A.guard && !fmh_isfinite(f)) f = -fmh_inf();
+    return f;
+  };
+  auto flush_bits = [&](int i) {
+    if (A.accept_bits && lane == 0)
+      A.accept_bits[(long long)cl * ((nsteps + 31) >> 5) + ((i - 1) >> 5)] = bitword;
+    bitword = 0;
+  };
+  lds_barrier();
+
+  const bool dbg = (A.debug & 8) != 0;
+  unsigned long long te = 0, tb1 = 0, to = 0, tb2 = 0;
+  for (int v = 1; v <= nsteps; v++) {
+    unsigned long long t_0 = dbg ? clk() : 0;
+    // ================= evaluation of version v of all 4 chains =================
+    {
+      const double* tj = s_th1 + jch * PIPE_KMAX;
+      const double bop = (feat < 3) ? tj[ic + feat] : -1.0;   // B[k][blk][j]
+      const double cop = ic ? tj[0] : 0.0;                      // C = intercept of chain j
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int t = 0; t < MF_NMF; t++) {
+        const double d = __builtin_amdgcn_mfma_f64_4x4x4f64(areg[t], bop, cop, 0, 0, 0);   // d = -r
+        if (t >= MF_NMF - 4) acc[t & 3] = fmh_fma(d * wm[t & 3], d, acc[t & 3]);
+        else acc[t & 3] = fmh_fma(d, d, acc[t & 3]);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; g++) s_tr[jch * (8 * PIPE_TRS) + trs[g]] = acc[g];
+    }
+    // (Measured: moving log(sigma) of the owners in front of, or right behind, their MFMAs makes the step SLOWER:
+    //  fp64 VALU work issued while the SIMD partner runs MFMAs slows those -- one fp64 datapath -- whereas in
+    //  the owner phase below that datapath is idle.)
+    unsigned long long t_1 = dbg ? clk() : 0;
+    lds_barrier();
+    unsigned long long t_2 = dbg ? clk() : 0;
+    // ================= owners: fold, decide, propose =================
+    if (owner) {
+      __builtin_amdgcn_s_setprio(3);
+      const double* src = s_tr + myc * (8 * PIPE_TRS) + lane;
+      const double v0 = src[0 * PIPE_TRS], v1 = src[1 * PIPE_TRS], v2 = src[2 * PIPE_TRS], v3 = src[3 * PIPE_TRS];
+      const double v4 = src[4 * PIPE_TRS], v5 = src[5 * PIPE_TRS], v6 = src[6 * PIPE_TRS], v7 = src[7 * PIPE_TRS];
+      const double tot = wave_xor_sum(((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7)));
+      const double sigma = readlane_d(th1, k - 1);
+      const double f1 = logpost_of(tot, sigma);
+      const double th1_eval = th1;
+      bool keep_row = false;
+      if (v == 1) {
+        f0 = uniform_d(f1);
+        keep_row = true;
+      } else if (status == FMCMC_CHAIN_OK) {
+        const double ratio = f1 - f0;
+        if (fmh_isnan(f1) || fmh_isnan(ratio)) {
+          status = fmh_isnan(f1) ? FMCMC_CHAIN_NAN_LOGPOST : FMCMC_CHAIN_NAN_RATIO;
+          if (lane == 0) { A.status[cl] = status; A.status_step[cl] = v; }
+          if (plane) A.status_theta[(long long)cl * k + lane] = th1;
+          flush_bits(v);
+        } else {
+          const double lu = lu_nx;
+          lu_nx = lu_row[v < nsteps ? v : nsteps - 1];
+          if (lu < ratio) {
+            th0 = th1;
+            f0 = uniform_d(f1);
+            nacc += 1;
+            bitword |= (1u << ((v - 1) & 31));
+          }
+          keep_row = true;
+        }
+      }
+      const double th0_row = th0;
+      if (v < nsteps && status == FMCMC_CHAIN_OK && plane) {
+        double t = th0;
+        if (!fixed_l) {
+          t = th0 + (s_par[0 * PIPE_KMAX + lane] + s_par[1 * PIPE_KMAX + lane] * z_nx);
+          if (KIND == FMCMC_KERNEL_NORMAL_REFLECTIVE) t = reflect1(t, s_par[2 * PIPE_KMAX + lane], s_par[3 * PIPE_KMAX + lane]);
+          z_nx = ld_z(v + 1 < nsteps ? v + 1 : nsteps - 1);
+        }
+        th1 = t;
+        s_th1[myc * PIPE_KMAX + lane] = t;
+      }
+      __builtin_amdgcn_s_setprio(0);
+      if (keep_row && v > burnin) {
+        thin_ctr += 1;
+        if (thin_ctr == thin) {
+          thin_ctr = 0;
+          if (plane) {
+            *reinterpret_cast<double*>(reinterpret_cast<char*>(A.samples) + (sd_off + srow8)) = th0_row;
+            if (A.draws) *reinterpret_cast<double*>(reinterpret_cast<char*>(A.draws) + (sd_off + srow8)) = th1_eval;
+          }
+          if (A.logpost && lane == 0) *reinterpret_cast<double*>(reinterpret_cast<char*>(A.logpost) + (lp_off + srow8)) = f1;
+          srow8 += 8;
+        }
+      }
+      if (status == FMCMC_CHAIN_OK && v >= 2 && (((v - 1) & 31) == 31 || v == nsteps)) flush_bits(v);
+    }
+    unsigned long long t_3 = dbg ? clk() : 0;
+    lds_barrier();
+    if (dbg) { unsigned long long t_4 = clk(); te += t_1 - t_0; tb1 += t_2 - t_1; to += t_3 - t_2; tb2 += t_4 - t_3; }
+  }
+  if (dbg && lane == 0 && A.logpost) {   // stamps leave through the logpost buffer in this diagnostic mode
+    double* d = A.logpost + (long long)A.nchains * A.S - 8 * ((long long)blockIdx.x * NW + wave + 1);
+    d[0] = (double)te; d[1] = (double)tb1; d[2] = (double)to; d[3] = (double)tb2; d[4] = (double)nsteps;
+  }
+  if (owner) {
+    if (plane) A.theta0[(long long)cl * k + lane] = th0;
+    if (lane == 0) {
+      A.f0[cl] = f0;
+      A.accept_count[cl] = nacc;
+      if (status == FMCMC_CHAIN_OK) { A.status[cl] = FMCMC_CHAIN_OK; A.status_step[cl] = 0; }
+    }
+  }
+}
+
+size_t mfma_lds_bytes() { return sizeof(double) * ((size_t)8 * PIPE_KMAX + 4 * 8 * PIPE_TRS); }
+
 constexpr int SPEC_ALD = PIPE_KMAX + 1;                       // row stride of the k x k matrices in LDS
 constexpr int SPEC_ADS = 7 * PIPE_KMAX + 2 * PIPE_KMAX * SPEC_ALD;  // doubles of adaptive state per chain
 
@@ -1803,6 +2020,14 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcm
         hipLaunchKernelGGL((mh_sweep_pipe<PV, OV, KV>), dim3((unsigned)pblk), dim3(NT), plds, stream, A); \
     } while (0)
     const char* nospec = getenv("FMCMC_AMD_NO_SPEC");
+    const char* usemf = getenv("FMCMC_AMD_MFMA");
+    if (!(usemf && usemf[0] == '0') && pipe_opt == 20 && kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE) {
+      const size_t mlds = mfma_lds_bytes();
+      if (kn->kind == FMCMC_KERNEL_NORMAL)
+        hipLaunchKernelGGL((mh_sweep_mfma<1>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A);
+      else
+        hipLaunchKernelGGL((mh_sweep_mfma<2>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A);
+    } else
     if (!(nospec && nospec[0] == '1')) {
       const size_t slds = spec_lds_bytes(pipe_opt, kn->kind >= FMCMC_KERNEL_ADAPT);
 #define LAUNCH_SPEC(PV, OV, KV)                                                                        \
