@@ -44,7 +44,8 @@ def make_workload(chains, chain_base):
 
 
 def flops_per_sample():
-    # E * n * (2(p-1)+3), p-1 = 3 covariates: 3 fma + 1 sub + 1 fma per observation
+    # E * n * (2(p-1)+3), p-1 = 3 covariates: 3 fma + 1 sub + 1 fma per observation (the MFMA path
+    # executes 4 fma + 1 fma = 10 flop per observation; the ALGORITHMIC 9 is what achieved/peak is computed from)
     return N_OBS * (2 * P_COV + 3)
 
 
@@ -184,10 +185,10 @@ def main():
                                    "nsteps=%d, outputs ans+logpost+draws" % (chains, K_PAR, N_OBS, SCALE, iters),
                        "chains_per_gpu": chains, "iters_per_step": iters, "accept_rate": acc,
                        "parallelism": "chains sharded, %d rank(s), no data-path collective" % world},
-            "roofline": {"bound": "mfma", "pipe": "fp64 vector ALU (MI355X fp64 vector peak == fp64 matrix peak)",
+            "roofline": {"bound": "mfma", "pipe": "fp64 MFMA (v_mfma_f64_4x4x4: x.beta - y) + fp64 VALU (r^2 accumulate); MI355X fp64 matrix peak == fp64 vector peak",
                          "achieved": ach_tflops, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tflops / PEAK_FP64_TFLOPS, "traffic": traffic,
-                         "kernel": "mh_sweep_spec<3,20,1>", "kernel_ms": kern_ms, "rng_fill_kernel_ms": rng_ms,
+                         "kernel": "mh_sweep_mfma<1>", "kernel_ms": kern_ms, "rng_fill_kernel_ms": rng_ms,
                          "flops_per_sample": flops_per_sample(),
                          "hbm": {"achieved_GBps": out_bytes / (kern_ms * 1e-3) / 1e9, "peak_GBps": PEAK_HBM_GBS,
                                  "algorithmic_bytes_per_launch": out_bytes}},

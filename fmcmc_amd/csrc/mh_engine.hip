@@ -1099,6 +1099,10 @@ __device__ __forceinline__ unsigned lds_ld_u32(const unsigned* p) {
 // evaluation | barrier | 4 owner phases in parallel (waves 0..3, priority raised) | barrier.
 // ==============================================================================================
 constexpr int MF_NMF = 80;   // MFMAs per wave per step: 20 slots x 4 lane groups
+// chain stride of the partial tiles: here one ds_write_b64 carries 4 chains x 16 canonical lanes; with the row stride
+// 66 the 16 lanes of a write group land on double-banks {0,8,1,9} + 2*(l&7), so a chain stride == 2 (mod 16) spreads the
+// four chains over all 16 double-banks (8*66 = 528 == 0 mod 16 made every write a 4-way conflict)
+constexpr int MF_TCS = 8 * PIPE_TRS + 2;
 
 template <int KIND>
 __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
@@ -1109,7 +1113,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
   const int k = A.k, kz = A.kz;
   double* s_th1 = smem;                            // [CW][PIPE_KMAX]
   double* s_par = s_th1 + CW * PIPE_KMAX;          // [4][PIPE_KMAX]
-  double* s_tr = s_par + 4 * PIPE_KMAX;            // [CW][8][PIPE_TRS]
+  double* s_tr = s_par + 4 * PIPE_KMAX;            // [CW][MF_TCS] transposed partial tiles, chain stride 530
   const long long cg0 = (long long)blockIdx.x * CW;
   const int ncw = (int)((A.nchains - cg0 < CW) ? (A.nchains - cg0) : CW);
   const int nsteps = (int)A.nsteps, burnin = (int)A.burnin, thin = (int)A.thin;
@@ -1209,7 +1213,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
         else acc[t & 3] = fmh_fma(d, d, acc[t & 3]);
       }
 #pragma unroll
-      for (int g = 0; g < 4; g++) s_tr[jch * (8 * PIPE_TRS) + trs[g]] = acc[g];
+      for (int g = 0; g < 4; g++) s_tr[jch * (MF_TCS) + trs[g]] = acc[g];
     }
     // (Measured: moving log(sigma) of the owners in front of, or right behind, their MFMAs makes the step SLOWER:
     //  fp64 VALU work issued while the SIMD partner runs MFMAs slows those -- one fp64 datapath -- whereas in
@@ -1220,7 +1224,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
     // ================= owners: fold, decide, propose =================
     if (owner) {
       __builtin_amdgcn_s_setprio(3);
-      const double* src = s_tr + myc * (8 * PIPE_TRS) + lane;
+      const double* src = s_tr + myc * (MF_TCS) + lane;
       const double v0 = src[0 * PIPE_TRS], v1 = src[1 * PIPE_TRS], v2 = src[2 * PIPE_TRS], v3 = src[3 * PIPE_TRS];
       const double v4 = src[4 * PIPE_TRS], v5 = src[5 * PIPE_TRS], v6 = src[6 * PIPE_TRS], v7 = src[7 * PIPE_TRS];
       const double tot = wave_xor_sum(((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7)));
@@ -1294,7 +1298,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
   }
 }
 
-size_t mfma_lds_bytes() { return sizeof(double) * ((size_t)8 * PIPE_KMAX + 4 * 8 * PIPE_TRS); }
+size_t mfma_lds_bytes() { return sizeof(double) * ((size_t)8 * PIPE_KMAX + 4 * MF_TCS); }
 
 constexpr int SPEC_ALD = PIPE_KMAX + 1;                       // row stride of the k x k matrices in LDS
 constexpr int SPEC_ADS = 7 * PIPE_KMAX + 2 * PIPE_KMAX * SPEC_ALD;  // doubles of adaptive state per chain
