@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfmcmc_amd.so")
+LIB_PATH = os.environ.get("FMCMC_AMD_LIB") or os.path.join(_HERE, "lib", "libfmcmc_amd.so")  # override: A/B builds
 
 _dp = C.POINTER(C.c_double)
 

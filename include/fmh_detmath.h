@@ -121,6 +121,19 @@ FMH_HD double fmh_log(double x) {
   return fmh_log_core_(f, k, 0.0);
 }
 
+/* fmh_log for a POSITIVE, FINITE, NORMAL argument (the caller checks): same bits as fmh_log(x), but
+ * straight-line code, so a scheduler can overlap it with independent work. */
+FMH_HD double fmh_log_pn(double x) {
+  uint64_t ux = fmh_d2u(x);
+  uint32_t hx = (uint32_t)(ux >> 32);
+  int k = (int)(hx >> 20) - 1023;
+  hx &= 0x000fffffu;
+  uint32_t i = (hx + 0x95f64u) & 0x100000u;
+  uint64_t um = ((uint64_t)(hx | (i ^ 0x3ff00000u)) << 32) | (ux & 0xffffffffull);
+  k += (int)(i >> 20);
+  return fmh_log_core_(fmh_u2d(um) - 1.0, k, 0.0);
+}
+
 FMH_HD double fmh_log1p(double x) {
   if (fmh_isnan(x)) return x;
   if (x < -1.0) return fmh_nan();
