@@ -1,7 +1,7 @@
 """Scratch timing of the headline config (not the contract bench)."""
-import sys, time
+import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from fmcmc_amd import engine as E, _abi as abi
 C, n, nsteps = int(sys.argv[1]) if len(sys.argv) > 1 else 1024, 10000, int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 rng = np.random.default_rng(20260102)
