@@ -1104,7 +1104,9 @@ constexpr int MF_NMF = 80;   // MFMAs per wave per step: 20 slots x 4 lane group
 // four chains over all 16 double-banks (8*66 = 528 == 0 mod 16 made every write a 4-way conflict)
 constexpr int MF_TCS = 8 * PIPE_TRS + 2;
 
-template <int KIND>
+// DBG is a TEMPLATE parameter on purpose: the MFMA loop is sensitive to every live register (fewer free VGPRs = fewer
+// MFMA results in flight before their dependent fma); stamp code that is merely disabled at run time cost 13 %.
+template <int KIND, bool DBG>
 __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
   constexpr int CW = 4, OPT = 20;
   extern __shared__ double smem[];
@@ -1196,7 +1198,9 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
   };
   lds_barrier();
 
-  const bool dbg = (A.debug & 8) != 0;
+  constexpr bool dbg = DBG;
+  bool st_keep = false;                      // row of the step just decided, stored after the barrier
+  double st_th0 = 0.0, st_th1 = 0.0, st_f1 = 0.0;
   unsigned long long te = 0, tb1 = 0, to = 0, tb2 = 0;
   for (int v = 1; v <= nsteps; v++) {
     unsigned long long t_0 = dbg ? clk() : 0;
@@ -1266,23 +1270,29 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
         s_th1[myc * PIPE_KMAX + lane] = t;
       }
       __builtin_amdgcn_s_setprio(0);
-      if (keep_row && v > burnin) {
+      st_keep = keep_row; st_th0 = th0_row; st_th1 = th1_eval; st_f1 = f1;
+    }
+    unsigned long long t_3 = dbg ? clk() : 0;
+    lds_barrier();
+    if (dbg) { unsigned long long t_4 = clk(); te += t_1 - t_0; tb1 += t_2 - t_1; to += t_3 - t_2; tb2 += t_4 - t_3; }
+    // Row stores and bookkeeping of step v happen AFTER the barrier that releases the next evaluation: the owner
+    // waves are the first of their SIMD to finish their MFMAs (~1400 ticks of slack), the stores ride in that slack
+    // instead of sitting in the exposed owner phase.
+    if (owner) {
+      if (st_keep && v > burnin) {
         thin_ctr += 1;
         if (thin_ctr == thin) {
           thin_ctr = 0;
           if (plane) {
-            *reinterpret_cast<double*>(reinterpret_cast<char*>(A.samples) + (sd_off + srow8)) = th0_row;
-            if (A.draws) *reinterpret_cast<double*>(reinterpret_cast<char*>(A.draws) + (sd_off + srow8)) = th1_eval;
+            *reinterpret_cast<double*>(reinterpret_cast<char*>(A.samples) + (sd_off + srow8)) = st_th0;
+            if (A.draws) *reinterpret_cast<double*>(reinterpret_cast<char*>(A.draws) + (sd_off + srow8)) = st_th1;
           }
-          if (A.logpost && lane == 0) *reinterpret_cast<double*>(reinterpret_cast<char*>(A.logpost) + (lp_off + srow8)) = f1;
+          if (A.logpost && lane == 0 && !dbg) *reinterpret_cast<double*>(reinterpret_cast<char*>(A.logpost) + (lp_off + srow8)) = st_f1;
           srow8 += 8;
         }
       }
       if (status == FMCMC_CHAIN_OK && v >= 2 && (((v - 1) & 31) == 31 || v == nsteps)) flush_bits(v);
     }
-    unsigned long long t_3 = dbg ? clk() : 0;
-    lds_barrier();
-    if (dbg) { unsigned long long t_4 = clk(); te += t_1 - t_0; tb1 += t_2 - t_1; to += t_3 - t_2; tb2 += t_4 - t_3; }
   }
   if (dbg && lane == 0 && A.logpost) {   // stamps leave through the logpost buffer in this diagnostic mode
     double* d = A.logpost + (long long)A.nchains * A.S - 8 * ((long long)blockIdx.x * NW + wave + 1);
@@ -2027,10 +2037,14 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcm
     const char* usemf = getenv("FMCMC_AMD_MFMA");
     if (!(usemf && usemf[0] == '0') && pipe_opt == 20 && kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE) {
       const size_t mlds = mfma_lds_bytes();
-      if (kn->kind == FMCMC_KERNEL_NORMAL)
-        hipLaunchKernelGGL((mh_sweep_mfma<1>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A);
-      else
-        hipLaunchKernelGGL((mh_sweep_mfma<2>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A);
+      if (A.debug & 8) {
+        if (kn->kind == FMCMC_KERNEL_NORMAL) hipLaunchKernelGGL((mh_sweep_mfma<1, true>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A);
+        else hipLaunchKernelGGL((mh_sweep_mfma<2, true>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A);
+      } else if (kn->kind == FMCMC_KERNEL_NORMAL) {
+        hipLaunchKernelGGL((mh_sweep_mfma<1, false>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A);
+      } else {
+        hipLaunchKernelGGL((mh_sweep_mfma<2, false>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A);
+      }
     } else
     if (!(nospec && nospec[0] == '1')) {
       const size_t slds = spec_lds_bytes(pipe_opt, kn->kind >= FMCMC_KERNEL_ADAPT);
