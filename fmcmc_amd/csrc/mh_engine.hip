@@ -1210,11 +1210,20 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
       const double bop = (feat < 3) ? tj[ic + feat] : -1.0;   // B[k][blk][j]
       const double cop = ic ? tj[0] : 0.0;                      // C = intercept of chain j
       double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      // batches of MB independent MFMAs followed by their MB dependent FMAs: the result latency of one MFMA is
+      // covered by issuing the next ones, and the batch shape (not the allocator's leftovers) bounds the live results
+      constexpr int MB = 8;
 #pragma unroll
-      for (int t = 0; t < MF_NMF; t++) {
-        const double d = __builtin_amdgcn_mfma_f64_4x4x4f64(areg[t], bop, cop, 0, 0, 0);   // d = -r
-        if (t >= MF_NMF - 4) acc[t & 3] = fmh_fma(d * wm[t & 3], d, acc[t & 3]);
-        else acc[t & 3] = fmh_fma(d, d, acc[t & 3]);
+      for (int t0 = 0; t0 < MF_NMF; t0 += MB) {
+        double d[MB];
+#pragma unroll
+        for (int u = 0; u < MB; u++) d[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(areg[t0 + u], bop, cop, 0, 0, 0);   // -r
+#pragma unroll
+        for (int u = 0; u < MB; u++) {
+          const int t = t0 + u;
+          if (t >= MF_NMF - 4) acc[t & 3] = fmh_fma(d[u] * wm[t & 3], d[u], acc[t & 3]);
+          else acc[t & 3] = fmh_fma(d[u], d[u], acc[t & 3]);
+        }
       }
 #pragma unroll
       for (int g = 0; g < 4; g++) s_tr[jch * (MF_TCS) + trs[g]] = acc[g];
