@@ -91,6 +91,13 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// Wavefront-level ordering of LDS traffic only.  wave_sync()'s acq_rel fence also orders GLOBAL memory, i.e. it
+// waits (vmcnt) for the owner's own row stores and prefetch loads at every one of the dozen sync points of an
+// adaptive proposal; the owners only ever exchange data with themselves through LDS.
+__device__ __forceinline__ void wave_sync_lds() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
 __device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also releases GLOBAL memory at
@@ -1366,7 +1373,7 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
       if (lane < kf) vmp[lane] = A.mean_prev[(long long)cl * kf + lane];
     }
   }
-  wave_sync();
+  wave_sync_lds();
   const int jl = (lane < k) ? lane : 0;
   const unsigned int sd_off = (unsigned int)((((long long)cl * k + jl) * A.S) * 8);
   const unsigned int z_off = (unsigned int)((((long long)cl * nsteps) * kz + (lane < kz ? lane : 0)) * 8);
@@ -1390,7 +1397,8 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
     const double v4 = src[4 * PIPE_TRS], v5 = src[5 * PIPE_TRS], v6 = src[6 * PIPE_TRS], v7 = src[7 * PIPE_TRS];
     const double tot = wave_xor_sum(((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7)));
     const double f1 = finish_logpost(A, th1, tot);
-    bool keep_row = false;
+    bool keep_row = false, st_row = false;
+    double st_th0 = 0.0, st_dr = 0.0;
     if (v == 1) {
       f0 = f1;
       if (lane < kf) vrs[lane] = th0[which[lane]];
@@ -1428,7 +1436,7 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
                 Salt[lane * LD + j] = ln;
               }
             }
-            wave_sync();
+            wave_sync_lds();
             if (fail) nerr += 1;
             else { double* t = Scur; Scur = Salt; Salt = t; }
           }
@@ -1458,15 +1466,12 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
           nacc += 1;
           bitword |= (1u << ((i - 1) & 31));
         }
-        wave_sync();
-        if (i > burnin && thin_ctr == thin) {
+        wave_sync_lds();
+        if (i > burnin && thin_ctr == thin) {   // stored after the proposal is published (below)
           thin_ctr = 0;
-          if (lane < k) {
-            *reinterpret_cast<double*>(reinterpret_cast<char*>(A.samples) + (sd_off + srow8)) = th0[lane];
-            if (A.draws) *reinterpret_cast<double*>(reinterpret_cast<char*>(A.draws) + (sd_off + srow8)) = dr;
-          }
-          if (A.logpost && lane == 0) *reinterpret_cast<double*>(reinterpret_cast<char*>(A.logpost) + (lp_off + srow8)) = f1;
-          srow8 += 8;
+          st_row = true;
+          st_th0 = (lane < k) ? th0[lane] : 0.0;
+          st_dr = dr;
         }
         if (KIND == FMCMC_KERNEL_ADAPT && lane < kf) vrs[lane] = vrs[lane] + th0[which[lane]];
         if (((i - 1) & 31) == 31 || i == nsteps) flush_bits(i);
@@ -1488,10 +1493,10 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
     if (v < nsteps) {
       if (status == FMCMC_CHAIN_OK) {
         const int i = v + 1;
-        wave_sync();
+        wave_sync_lds();
         if (lane < kz) vz[lane] = z_nx;
         z_nx = (lane < kz) ? ld_z(v + 1 < nsteps ? v + 1 : nsteps - 1) : 0.0;
-        wave_sync();
+        wave_sync_lds();
         if (KIND == FMCMC_KERNEL_ADAPT) {
           if (A.until > (double)abs_iter && abs_iter > A.warmup && i > 2) {
             const double t = (double)(abs_iter - 1);
@@ -1502,7 +1507,7 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
               mt = (mp * t + x) / (t + 1);
               vv[lane] = x; vmp[lane] = mp; vmt[lane] = mt;
             }
-            wave_sync();
+            wave_sync_lds();
             if (lane < kf) {
               const double c1 = (t - 1) / t, c2 = 1.0 / t;
               for (int b = 0; b < kf; b++) {
@@ -1511,7 +1516,7 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
                 SigA[lane * LD + b] = c1 * SigA[lane * LD + b] + c2 * inner;
               }
             }
-            wave_sync();
+            wave_sync_lds();
             if (lane < kf) vmp[lane] = mt;
             have_mean = 1;
           }
@@ -1528,7 +1533,7 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
             double ljj = fmh_sqrt(d);
             if (lane == j) SigB[j * LD + j] = ljj;
             else if (lane > j && lane < kf) SigB[lane * LD + j] = sacc / ljj;
-            wave_sync();
+            wave_sync_lds();
           }
           if (notpd) {
             status = FMCMC_CHAIN_NOT_PD;
@@ -1536,7 +1541,7 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
             if (lane < k) A.status_theta[(long long)cl * k + lane] = th1[lane];
           } else {
             if (lane < k) th1[lane] = th0[lane];
-            wave_sync();
+            wave_sync_lds();
             if (lane < kf) {
               double sacc = 0.0;
               for (int b = 0; b <= lane; b++) sacc = fmh_fma(SigB[lane * LD + b], vz[b], sacc);
@@ -1554,15 +1559,23 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
           }
           ram_gate = (A.until > (double)abs_iter && abs_iter > A.warmup);
         }
-        wave_sync();
+        wave_sync_lds();
         if (lane < k) s_th1[myc * PIPE_KMAX + lane] = th1[lane];
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (lane == 0) __hip_atomic_store(&s_ready[myc], (unsigned)(v + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+    if (st_row) {   // row v of ans / draws / logpost, off the compute waves' critical path
+      if (lane < k) {
+        *reinterpret_cast<double*>(reinterpret_cast<char*>(A.samples) + (sd_off + srow8)) = st_th0;
+        if (A.draws) *reinterpret_cast<double*>(reinterpret_cast<char*>(A.draws) + (sd_off + srow8)) = st_dr;
+      }
+      if (A.logpost && lane == 0) *reinterpret_cast<double*>(reinterpret_cast<char*>(A.logpost) + (lp_off + srow8)) = f1;
+      srow8 += 8;
+    }
   }
   // ---- write state back
-  wave_sync();
+  wave_sync_lds();
   if (lane < k) A.theta0[(long long)cl * k + lane] = th0[lane];
   if (lane == 0) {
     A.f0[cl] = f0;
@@ -1578,6 +1591,249 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
     A.Sigma[((long long)cl * kf + a) * kf + b] = Sfin[a * LD + b];
   }
   if (KIND == FMCMC_KERNEL_ADAPT && lane < kf) A.mean_prev[(long long)cl * kf + lane] = vmp[lane];
+}
+
+// Register-row variant of the adaptive owner for k <= SPEC_KA parameters, none fixed (C3, kernel_ram at k = 5):
+// lane a keeps ROW a of Sigma / S (and of the Cholesky factor) in VGPRs and other rows' entries arrive by v_readlane
+// (statically unrolled indices), so the Cholesky, the rank-1 update, the recursive covariance and the L z / S U
+// products run without a single LDS round trip or ds_bpermute.  Same operations in the same order per matrix
+// element as spec_owner_adaptive / the oracle, hence the same bits.
+constexpr int SPEC_KA = 8;
+
+template <int KIND>
+__device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int myc, int cl, double* s_th1, double* s_par,
+                                                        unsigned* s_ready, unsigned* s_done, double* s_tr) {
+  constexpr int KA = SPEC_KA;
+  const int lane = threadIdx.x & 63;
+  const int k = A.k, kf = A.k, kz = A.kz, nsteps = (int)A.nsteps, burnin = (int)A.burnin, thin = (int)A.thin;
+  const bool rl = lane < k;                 // row lane == parameter lane (no fixed parameters)
+  const int jl = rl ? lane : 0;
+  const double mu_l = A.mu[jl], lb_l = A.lb[jl], ub_l = A.ub[jl];
+  double Srow[KA], Lrow[KA];                // Sigma (adapt) or S (ram) row `lane`; Cholesky factor row (adapt)
+#pragma unroll
+  for (int b = 0; b < KA; b++) {
+    Lrow[b] = 0.0;
+    Srow[b] = (rl && b < kf) ? (A.fresh ? ((b == lane) ? 1.0 * A.eps : 0.0) : A.Sigma[((long long)cl * kf + lane) * kf + b]) : 0.0;
+  }
+  double th0 = rl ? A.theta0[(long long)cl * k + lane] : 0.0, th1 = th0;
+  double f0 = 0.0, mean_prev = 0.0, run_sum = 0.0, vv = 0.0, zcur = 0.0;
+  long long abs_iter = 0;
+  int nacc = 0, status = FMCMC_CHAIN_OK, thin_ctr = 0, have_mean = 0, nerr = 0;
+  unsigned int srow8 = 0, bitword = 0;
+  if (!A.fresh) {
+    abs_iter = A.abs_iter[cl];
+    if (A.nerrors) nerr = A.nerrors[cl];
+    if (KIND == FMCMC_KERNEL_ADAPT) {
+      have_mean = A.have_mean[cl];
+      if (rl) mean_prev = A.mean_prev[(long long)cl * kf + lane];
+    }
+  }
+  const unsigned int sd_off = (unsigned int)((((long long)cl * k + jl) * A.S) * 8);
+  const unsigned int z_off = (unsigned int)((((long long)cl * nsteps) * kz + jl) * 8);
+  const unsigned int lp_off = (unsigned int)(((long long)cl * A.S) * 8);
+  const double* const lu_row = A.fed_logu + (long long)cl * nsteps;
+  const double dn = uniform_d((double)A.n);
+  auto ld_z = [&](int row) -> double {
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(A.fed_z) + (z_off + (unsigned int)row * (unsigned int)(kz * 8)));
+  };
+  double z_nx = (rl && nsteps >= 2) ? ld_z(1) : 0.0;
+  double lu_nx = (nsteps >= 2) ? lu_row[1] : 0.0;
+  bool ram_gate = false;
+  auto flush_bits = [&](int i) {
+    if (A.accept_bits && lane == 0) A.accept_bits[(long long)cl * ((nsteps + 31) >> 5) + ((i - 1) >> 5)] = bitword;
+    bitword = 0;
+  };
+  auto logpost_of = [&](double tot, double sigma) -> double {   // Gaussian linreg closed form (same as the normal owners)
+    double f;
+    if (sigma < 0.0 || fmh_isnan(sigma)) f = fmh_nan();
+    else if (sigma == 0.0) f = -fmh_inf();
+    else {
+      double t1 = fmh_log(sigma) + FMH_K(FMH_LN_SQRT_2PI);
+      double q = (0.5 * tot) / (sigma * sigma);
+      f = -(dn * t1) - q;
+    }
+    if (A.guard && !fmh_isfinite(f)) f = -fmh_inf();
+    return f;
+  };
+
+  for (int v = 1; v <= nsteps; v++) {
+    while (lds_ld_u32(&s_done[myc]) < 8u * (unsigned)v) __builtin_amdgcn_s_sleep(1);
+    const double* src = s_tr + myc * (8 * PIPE_TRS) + lane;
+    const double v0 = src[0 * PIPE_TRS], v1 = src[1 * PIPE_TRS], v2 = src[2 * PIPE_TRS], v3 = src[3 * PIPE_TRS];
+    const double v4 = src[4 * PIPE_TRS], v5 = src[5 * PIPE_TRS], v6 = src[6 * PIPE_TRS], v7 = src[7 * PIPE_TRS];
+    const double tot = wave_xor_sum(((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7)));
+    const double f1 = logpost_of(tot, readlane_d(th1, k - 1));
+    bool st_row = false;
+    double st_th0 = 0.0;
+    const double st_dr = th1;
+    if (v == 1) {
+      f0 = f1;
+      run_sum = th0;
+      if (1 > burnin) { thin_ctr += 1; if (thin_ctr == thin) { thin_ctr = 0; st_row = true; st_th0 = th0; } }
+    } else if (status == FMCMC_CHAIN_OK) {
+      const int i = v;
+      if (KIND == FMCMC_KERNEL_RAM) {   // adaptation with f(theta1) of the pending proposal (R/kernel_ram.R:129-152)
+        if (ram_gate) {
+          double a_n = fmh_exp(f1 - f0);
+          if (fmh_isnan(a_n)) a_n = 0.0;
+          else if (a_n > 1.0) a_n = 1.0;
+          double eta = (double)kf * fmh_exp((-2.0 / 3.0) * fmh_log((double)i));
+          if (eta > 1.0) eta = 1.0;
+          double nrm2 = 0.0;
+#pragma unroll
+          for (int b = 0; b < KA; b++)
+            if (b < kf) { const double ub_ = readlane_d(zcur, b); nrm2 = fmh_fma(ub_, ub_, nrm2); }
+          const double cp = (eta * (a_n - A.arate)) / nrm2;
+          if (cp != 0.0 && fmh_isfinite(cp)) {
+            const bool up = cp > 0.0;
+            double w = rl ? fmh_sqrt(fmh_abs(cp)) * vv : 0.0;
+            double Snew[KA];
+#pragma unroll
+            for (int b = 0; b < KA; b++) Snew[b] = Srow[b];
+            bool fail = false;
+#pragma unroll
+            for (int j = 0; j < KA; j++) {
+              if (j < kf && !fail) {
+                const double ljj = readlane_d(Srow[j], j);
+                const double xj = readlane_d(w, j);
+                const double r2 = up ? fmh_fma(xj, xj, ljj * ljj) : fmh_fma(-xj, xj, ljj * ljj);
+                if (!(r2 > 0.0) || !fmh_isfinite(r2)) {
+                  fail = true;
+                } else {
+                  const double r = fmh_sqrt(r2);
+                  const double cc = r / ljj, ss = xj / ljj;
+                  if (lane == j) {
+                    Snew[j] = r;
+                  } else if (lane > j && rl) {
+                    const double ln = (up ? fmh_fma(ss, w, Srow[j]) : fmh_fma(-ss, w, Srow[j])) / cc;
+                    w = fmh_fma(-ss, ln, cc * w);
+                    Snew[j] = ln;
+                  }
+                }
+              }
+            }
+            if (fail) nerr += 1;
+            else {
+#pragma unroll
+              for (int b = 0; b < KA; b++) Srow[b] = Snew[b];
+            }
+          }
+        }
+        abs_iter += 1;
+      }
+      if (fmh_isnan(f1)) status = FMCMC_CHAIN_NAN_LOGPOST;
+      const double ratio = f1 - f0;
+      if (status == FMCMC_CHAIN_OK && fmh_isnan(ratio)) status = FMCMC_CHAIN_NAN_RATIO;
+      if (status != FMCMC_CHAIN_OK) {
+        if (lane == 0) { A.status[cl] = status; A.status_step[cl] = i; }
+        if (rl) A.status_theta[(long long)cl * k + lane] = th1;
+        flush_bits(i);
+      } else {
+        const double lu = lu_nx;
+        lu_nx = lu_row[v < nsteps ? v : nsteps - 1];
+        if (lu < ratio) {
+          th0 = th1;
+          f0 = f1;
+          nacc += 1;
+          bitword |= (1u << ((i - 1) & 31));
+        }
+        if (i > burnin) { thin_ctr += 1; if (thin_ctr == thin) { thin_ctr = 0; st_row = true; st_th0 = th0; } }
+        if (KIND == FMCMC_KERNEL_ADAPT) run_sum = run_sum + th0;
+        if (((i - 1) & 31) == 31 || i == nsteps) flush_bits(i);
+      }
+    }
+    // ---- proposal of loop step i = v + 1
+    if (v < nsteps) {
+      if (status == FMCMC_CHAIN_OK) {
+        const int i = v + 1;
+        zcur = z_nx;
+        z_nx = rl ? ld_z(v + 1 < nsteps ? v + 1 : nsteps - 1) : 0.0;
+        if (KIND == FMCMC_KERNEL_ADAPT) {
+          if (A.until > (double)abs_iter && abs_iter > A.warmup && i > 2) {   // R/kernel_adapt.R:118-166
+            const double t = (double)(abs_iter - 1);
+            const double x = th0;
+            const double mp = have_mean ? mean_prev : (run_sum / (double)(i - 1));
+            const double mt = (mp * t + x) / (t + 1);
+            const double c1 = (t - 1) / t, c2 = 1.0 / t;
+#pragma unroll
+            for (int b = 0; b < KA; b++) {
+              if (b < kf) {
+                const double mpb = readlane_d(mp, b), mtb = readlane_d(mt, b), xb = readlane_d(x, b);
+                const double ik = (b == lane) ? 1.0 * A.eps : 0.0;
+                const double inner = t * (mp * mpb) - (t + 1) * (mt * mtb) + x * xb + 1e-5 * ik;
+                Srow[b] = c1 * Srow[b] + c2 * inner;
+              }
+            }
+            mean_prev = mt;
+            have_mean = 1;
+          }
+          abs_iter += 1;
+          // left-looking Cholesky: column j, lane = row (twin of oracle chol_lower_canon)
+          bool notpd = false;
+#pragma unroll
+          for (int j = 0; j < KA; j++) {
+            if (j < kf && !notpd) {
+              double sacc = Srow[j];
+#pragma unroll
+              for (int b = 0; b < j; b++) sacc = fmh_fma(-Lrow[b], readlane_d(Lrow[b], j), sacc);
+              const double d = readlane_d(sacc, j);
+              if (!(d > 0.0) || !fmh_isfinite(d)) {
+                notpd = true;
+              } else {
+                const double ljj = fmh_sqrt(d);
+                if (lane == j) Lrow[j] = ljj;
+                else if (lane > j) Lrow[j] = sacc / ljj;
+              }
+            }
+          }
+          if (notpd) {
+            status = FMCMC_CHAIN_NOT_PD;
+            if (lane == 0) { A.status[cl] = status; A.status_step[cl] = i; }
+            if (rl) A.status_theta[(long long)cl * k + lane] = th1;
+          } else {
+            double sacc = 0.0;
+#pragma unroll
+            for (int b = 0; b < KA; b++)
+              if (b < kf) { const double zb = readlane_d(zcur, b); if (b <= lane) sacc = fmh_fma(Lrow[b], zb, sacc); }
+            th1 = reflect1(th0 + (mu_l + sacc), lb_l, ub_l);
+          }
+        } else {  // RAM P1 (R/kernel_ram.R:123-126)
+          double sacc = 0.0;
+#pragma unroll
+          for (int b = 0; b < KA; b++)
+            if (b < kf) { const double ub_ = readlane_d(zcur, b); if (b <= lane) sacc = fmh_fma(Srow[b], ub_, sacc); }
+          vv = sacc;
+          th1 = th0 + sacc;
+          ram_gate = (A.until > (double)abs_iter && abs_iter > A.warmup);
+        }
+        if (rl) s_th1[myc * PIPE_KMAX + lane] = th1;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_store(&s_ready[myc], (unsigned)(v + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if (st_row) {   // row v of ans / draws / logpost, off the compute waves' critical path
+      if (rl) {
+        *reinterpret_cast<double*>(reinterpret_cast<char*>(A.samples) + (sd_off + srow8)) = st_th0;
+        if (A.draws) *reinterpret_cast<double*>(reinterpret_cast<char*>(A.draws) + (sd_off + srow8)) = st_dr;
+      }
+      if (A.logpost && lane == 0) *reinterpret_cast<double*>(reinterpret_cast<char*>(A.logpost) + (lp_off + srow8)) = f1;
+      srow8 += 8;
+    }
+  }
+  // ---- write state back
+  if (rl) A.theta0[(long long)cl * k + lane] = th0;
+  if (lane == 0) {
+    A.f0[cl] = f0;
+    A.accept_count[cl] = nacc;
+    if (status == FMCMC_CHAIN_OK) { A.status[cl] = FMCMC_CHAIN_OK; A.status_step[cl] = 0; }
+    A.abs_iter[cl] = abs_iter;
+    if (A.nerrors) A.nerrors[cl] = nerr;
+    if (KIND == FMCMC_KERNEL_ADAPT) A.have_mean[cl] = have_mean;
+  }
+#pragma unroll
+  for (int b = 0; b < KA; b++)
+    if (rl && b < kf) A.Sigma[((long long)cl * kf + lane) * kf + b] = (b <= lane || KIND == FMCMC_KERNEL_ADAPT) ? Srow[b] : 0.0;
+  if (KIND == FMCMC_KERNEL_ADAPT && rl) A.mean_prev[(long long)cl * kf + lane] = mean_prev;
 }
 
 template <int P, int OPT, int KIND>
@@ -1686,7 +1942,12 @@ __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
   if (myc >= ncw) return;
   const int cl = __builtin_amdgcn_readfirstlane((int)cg0 + myc);
   if constexpr (KIND == FMCMC_KERNEL_ADAPT || KIND == FMCMC_KERNEL_RAM) {
-    spec_owner_adaptive<KIND>(A, myc, cl, s_th1, s_par, s_ready, s_done, s_tr, s_ad + myc * SPEC_ADS);
+    bool nofixed = true;
+    for (int j = 0; j < k; j++) nofixed = nofixed && (A.fixed[j] == 0);
+    if (k <= SPEC_KA && nofixed && !(A.debug & 16))
+      spec_owner_adaptive_reg<KIND>(A, myc, cl, s_th1, s_par, s_ready, s_done, s_tr);
+    else
+      spec_owner_adaptive<KIND>(A, myc, cl, s_th1, s_par, s_ready, s_done, s_tr, s_ad + myc * SPEC_ADS);
     return;
   }
   const bool plane = (lane < k);
