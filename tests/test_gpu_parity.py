@@ -232,3 +232,35 @@ def test_streamed_equals_resident(E, O, monkeypatch):
     monkeypatch.setenv("FMCMC_AMD_FORCE_STREAMED", "1")
     b, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=100, scale=0.02)
     assert _bits_equal(a.samples.cpu().numpy(), b.samples.cpu().numpy())
+
+
+# ---- the fp64 MFMA evaluation (default for 3 covariates, n in (9728, 10240], normal kernels)
+@pytest.mark.parametrize("n", [9729, 10000, 10239, 10240])
+def test_mfma_path_edge_sizes(E, O, n):
+    X, y = synth_linreg(n, 3, 7 * n)
+    init = jitter_init([0, 0, 0, 0, float(np.std(y))], 7, 21)
+    init[:, -1] = np.abs(init[:, -1])
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=90, burnin=7, thin=3, calls=2, scale=0.02)
+
+
+def test_mfma_path_no_intercept_fixed_and_reflective(E, O):
+    X, y = synth_linreg(10000, 3, 99)
+    init = jitter_init([2, -1, .5, 5.0], 5, 22)          # theta = (b1, b2, b3, sigma), no intercept
+    init[:, -1] = np.abs(init[:, -1])
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 4, init, nsteps=120, scale=0.02, intercept=False,
+             fixed=[False, True, False, False])
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL_REFLECTIVE, 4, init, nsteps=120, scale=0.5, intercept=False,
+             lb=[-3, -3, -3, 0.5], ub=[3, 3, 3, 6.0], guard=False)
+
+
+def test_mfma_equals_valu_kernels(E, O, monkeypatch):
+    """MFMA, wave-specialised VALU and streamed kernels: same bits (and == oracle inside run_both)."""
+    X, y = synth_linreg(10000, 3, 20260102)
+    init = jitter_init([0, 0, 0, 0, float(np.std(y))], 6, 23)
+    a, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=80, scale=0.02)
+    monkeypatch.setenv("FMCMC_AMD_MFMA", "0")
+    b, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=80, scale=0.02)
+    monkeypatch.setenv("FMCMC_AMD_NO_SPEC", "1")
+    c, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=80, scale=0.02)
+    assert _bits_equal(a.samples.cpu().numpy(), b.samples.cpu().numpy())
+    assert _bits_equal(a.samples.cpu().numpy(), c.samples.cpu().numpy())
