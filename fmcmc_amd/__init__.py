@@ -6,8 +6,10 @@ from .models import gaussian_linreg, logistic, iid_normal, LogPosterior
 from .mcmc import (MCMC, MCMC_without_conv_checker, MCMC_with_conv_checker, Mcmc, McmcList, check_initial,
                    append_chains, get_logpost, get_draws, get_elapsed, shard_bounds, DeviceChains)
 from .convergence import convergence_gelman
+from .recursive import cov_recursive, mean_recursive, reflect_on_boundaries
 
 __all__ = ["MCMC", "MCMC_without_conv_checker", "MCMC_with_conv_checker", "kernel_normal",
            "kernel_normal_reflective", "kernel_adapt", "kernel_am", "kernel_ram", "gaussian_linreg",
            "logistic", "iid_normal", "convergence_gelman", "Mcmc", "McmcList", "check_initial",
-           "append_chains", "get_logpost", "get_draws", "get_elapsed", "shard_bounds"]
+           "append_chains", "get_logpost", "get_draws", "get_elapsed", "shard_bounds", "cov_recursive", "mean_recursive",
+           "reflect_on_boundaries"]

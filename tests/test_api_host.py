@@ -120,3 +120,41 @@ def test_model_families_definitions():
     ref = np.sum(yb * (-np.log1p(np.exp(-eta))) + (1 - yb) * (-np.log1p(np.exp(eta)))) - np.sum(b ** 2) / 8
     assert abs(lg(b) - ref) < 1e-9 and lg.k == 3
     assert f.iid_normal(y).k == 2
+
+
+def test_recursive_helpers_match_reference_identities_and_oracle(O):
+    """test-kernel_adapt.R:32-55 (identity with colMeans / cov to 1e-10) + element-wise agreement with the oracle."""
+    rng = np.random.default_rng(2)
+    Xm = rng.standard_normal((30, 4))
+    mean, cov = Xm[:2].mean(0), np.cov(Xm[:2].T)
+    means = f.mean_recursive(Xm[2:], mean, 2)                      # matrix input: row-by-row recursion
+    covs = f.cov_recursive(Xm[2:], cov, mean, 2, Mean_t=means)
+    for i in range(28):
+        assert np.allclose(means[i], Xm[:i + 3].mean(0), atol=1e-10)
+        assert np.allclose(covs[i], np.cov(Xm[:i + 3].T), atol=1e-10)
+    # single-row step against the oracle's C restatement (same operation order)
+    x, mp, t = Xm[5], Xm[:5].mean(0), 5.0
+    mt = f.mean_recursive(x, mp, t)
+    mo = np.empty(4); O.lib().fmcmc_oracle_mean_recursive(O._p(np.ascontiguousarray(x)), O._p(np.ascontiguousarray(mp)), t, 4, O._p(mo))
+    assert np.array_equal(mt, mo)
+    c0 = np.cov(Xm[:5].T)
+    Ik = np.eye(4) * 1e-4
+    co = np.ascontiguousarray(c0.copy())
+    O.lib().fmcmc_oracle_cov_recursive(O._p(np.ascontiguousarray(x)), O._p(co), O._p(np.ascontiguousarray(mp)), O._p(mo), t, 1e-5, 1.0,
+                                       O._p(np.ascontiguousarray(Ik)), 4)
+    assert np.allclose(f.cov_recursive(x, c0, mp, t, Mean_t=mt, eps=1e-5, Ik=Ik), co, rtol=1e-14, atol=1e-16)
+
+
+def test_reflect_on_boundaries_matches_oracle(O):
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    lb, ub = np.array([-1.0, 0.0, 2.0, -5.0]), np.array([1.0, 0.5, 7.0, 5.0])
+    which = np.array([0, 2, 3])
+    for _ in range(200):
+        x = rng.uniform(-40, 40, 4)
+        got = f.reflect_on_boundaries(x, lb, ub, which)
+        ref = x.copy()
+        w32 = which.astype(np.int32)
+        O.lib().fmcmc_oracle_reflect(O._p(ref), O._p(lb), O._p(ub), w32.ctypes.data_as(C.POINTER(C.c_int32)), 3, O.MATH_R)
+        assert np.allclose(got, ref, atol=1e-12) and got[1] == x[1]
+        assert np.all(got[which] >= lb[which]) and np.all(got[which] <= ub[which])
