@@ -1086,6 +1086,12 @@ __device__ __forceinline__ unsigned lds_ld_u32(const unsigned* p) {
   return v;
 }
 
+__device__ __forceinline__ double lds_ld_f64(const double* p) {   // ordered after a preceding flag poll
+  double v;
+  asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(size_t)p) : "memory");
+  return v;
+}
+
 // ==============================================================================================
 // MFMA evaluation kernel for the headline shape: Gaussian linear regression with exactly 3 covariates.
 //
@@ -1247,9 +1253,31 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
       const double* src = s_tr + myc * (MF_TCS) + lane;
       const double v0 = src[0 * PIPE_TRS], v1 = src[1 * PIPE_TRS], v2 = src[2 * PIPE_TRS], v3 = src[3 * PIPE_TRS];
       const double v4 = src[4 * PIPE_TRS], v5 = src[5 * PIPE_TRS], v6 = src[6 * PIPE_TRS], v7 = src[7 * PIPE_TRS];
-      const double tot = wave_xor_sum(((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7)));
+      // increment of the NEXT proposal: consumes the variate fetched one step ago and refills the same register at once, so
+      // that load has a whole step to land and no vector-memory wait sits behind the decision below
+      double dz = 0.0;
+      if (plane && !fixed_l) {
+        dz = s_par[0 * PIPE_KMAX + lane] + s_par[1 * PIPE_KMAX + lane] * z_nx;
+        z_nx = ld_z(v + 1 < nsteps ? v + 1 : nsteps - 1);
+      }
+      // sigma-only part of the closed form first, as straight-line code in the block of the tile reads: its ~65 dependent
+      // instructions fill the LDS latency and the DPP stalls of the fold instead of queueing behind them
       const double sigma = readlane_d(th1, k - 1);
-      const double f1 = logpost_of(tot, sigma);
+      const unsigned sg_hi = (unsigned)(fmh_d2u(sigma) >> 32);
+      const bool sg_fast = (sg_hi - 0x00100000u) < 0x7fe00000u;          // positive, finite, normal
+      const double sg = sg_fast ? sigma : 1.0;
+      const double t1_fast = fmh_log_pn(sg) + FMH_K(FMH_LN_SQRT_2PI);   // same bits as fmh_log(sigma) on this range
+      double nt1_fast = dn * t1_fast;
+      double ss_fast = sg * sg;
+      asm volatile("" : "+v"(nt1_fast), "+v"(ss_fast));   // keep it HERE: the optimiser would sink it behind the fold
+      const double tot = wave_xor_sum(((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7)));
+      double f1;
+      if (sg_fast) {
+        f1 = -nt1_fast - (0.5 * tot) / ss_fast;
+        if (A.guard && !fmh_isfinite(f1)) f1 = -fmh_inf();
+      } else {
+        f1 = logpost_of(tot, sigma);
+      }
       const double th1_eval = th1;
       bool keep_row = false;
       if (v == 1) {
@@ -1263,9 +1291,9 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
           if (plane) A.status_theta[(long long)cl * k + lane] = th1;
           flush_bits(v);
         } else {
-          const double lu = lu_nx;
-          lu_nx = lu_row[v < nsteps ? v : nsteps - 1];
-          if (lu < ratio) {
+          const bool acc = lu_nx < ratio;
+          lu_nx = lu_row[v < nsteps ? v : nsteps - 1];   // refilled in place right behind its only use (same block)
+          if (acc) {
             th0 = th1;
             f0 = uniform_d(f1);
             nacc += 1;
@@ -1278,9 +1306,8 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
       if (v < nsteps && status == FMCMC_CHAIN_OK && plane) {
         double t = th0;
         if (!fixed_l) {
-          t = th0 + (s_par[0 * PIPE_KMAX + lane] + s_par[1 * PIPE_KMAX + lane] * z_nx);
+          t = th0 + dz;
           if (KIND == FMCMC_KERNEL_NORMAL_REFLECTIVE) t = reflect1(t, s_par[2 * PIPE_KMAX + lane], s_par[3 * PIPE_KMAX + lane]);
-          z_nx = ld_z(v + 1 < nsteps ? v + 1 : nsteps - 1);
         }
         th1 = t;
         s_th1[myc * PIPE_KMAX + lane] = t;
