@@ -1175,6 +1175,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
   const bool fixed_l = A.fixed[jl] != 0;
   int zidx = 0;
   for (int j = 0; j < jl; j++) zidx += A.fixed[j] ? 0 : 1;
+  if (zidx > kz - 1) zidx = kz > 0 ? kz - 1 : 0;   // lanes without a variate of their own read a valid neighbour (value unused)
   double th0 = plane ? A.theta0[(long long)cl * k + lane] : 0.0;
   double th1 = th0;
   double f0 = 0.0;
@@ -1188,8 +1189,10 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
   auto ld_z = [&](int row) -> double {
     return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(A.fed_z) + (z_off + (unsigned int)row * (unsigned int)(kz * 8)));
   };
-  double z_nx = (plane && !fixed_l && nsteps >= 2) ? ld_z(1) : 0.0;
-  double lu_nx = (owner && nsteps >= 2) ? lu_row[1] : 0.0;
+  // every lane of an owner wavefront keeps one variate and the log-uniform of the next step in flight (unconditional,
+  // clamped addresses: a conditional load costs a register copy behind the load, i.e. an exposed wait)
+  double z_nx = (owner && kz > 0) ? ld_z(nsteps >= 2 ? 1 : 0) : 0.0;
+  double lu_nx = owner ? lu_row[nsteps >= 2 ? 1 : 0] : 0.0;
   auto logpost_of = [&](double tot, double sigma) -> double {
     double f;
     if (sigma < 0.0 || fmh_isnan(sigma)) {
@@ -1214,7 +1217,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
   constexpr bool dbg = DBG;
   bool st_keep = false;                      // row of the step just decided, stored after the barrier
   double st_th0 = 0.0, st_th1 = 0.0, st_f1 = 0.0;
-  unsigned long long te = 0, tb1 = 0, to = 0, tb2 = 0;
+  unsigned long long te = 0, tb1 = 0, to = 0, tb2 = 0, tf = 0, tc = 0, td = 0;
   for (int v = 1; v <= nsteps; v++) {
     unsigned long long t_0 = dbg ? clk() : 0;
     // ================= evaluation of version v of all 4 chains =================
@@ -1255,11 +1258,14 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
       const double v4 = src[4 * PIPE_TRS], v5 = src[5 * PIPE_TRS], v6 = src[6 * PIPE_TRS], v7 = src[7 * PIPE_TRS];
       // increment of the NEXT proposal: consumes the variate fetched one step ago and refills the same register at once, so
       // that load has a whole step to land and no vector-memory wait sits behind the decision below
-      double dz = 0.0;
-      if (plane && !fixed_l) {
-        dz = s_par[0 * PIPE_KMAX + lane] + s_par[1 * PIPE_KMAX + lane] * z_nx;
-        z_nx = ld_z(v + 1 < nsteps ? v + 1 : nsteps - 1);
-      }
+      // The only vector-memory wait of the phase sits HERE, on loads issued one whole step ago; both registers are refilled
+      // at once, so nothing younger than an evaluation is ever waited for (a wait behind the decision would also cover the
+      // refill of the variate, an HBM miss every third step).
+      double lu = lu_nx, zc = z_nx;
+      asm volatile("" : "+v"(lu), "+v"(zc));
+      lu_nx = lu_row[v < nsteps ? v : nsteps - 1];
+      if (kz > 0) z_nx = ld_z(v + 1 < nsteps ? v + 1 : nsteps - 1);
+      const double dz = (plane && !fixed_l) ? s_par[0 * PIPE_KMAX + lane] + s_par[1 * PIPE_KMAX + lane] * zc : 0.0;
       // sigma-only part of the closed form first, as straight-line code in the block of the tile reads: its ~65 dependent
       // instructions fill the LDS latency and the DPP stalls of the fold instead of queueing behind them
       const double sigma = readlane_d(th1, k - 1);
@@ -1271,6 +1277,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
       double ss_fast = sg * sg;
       asm volatile("" : "+v"(nt1_fast), "+v"(ss_fast));   // keep it HERE: the optimiser would sink it behind the fold
       const double tot = wave_xor_sum(((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7)));
+      unsigned long long t_a = dbg ? clk() : 0;
       double f1;
       if (sg_fast) {
         f1 = -nt1_fast - (0.5 * tot) / ss_fast;
@@ -1278,6 +1285,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
       } else {
         f1 = logpost_of(tot, sigma);
       }
+      unsigned long long t_b = dbg ? clk() : 0;
       const double th1_eval = th1;
       bool keep_row = false;
       if (v == 1) {
@@ -1291,9 +1299,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
           if (plane) A.status_theta[(long long)cl * k + lane] = th1;
           flush_bits(v);
         } else {
-          const bool acc = lu_nx < ratio;
-          lu_nx = lu_row[v < nsteps ? v : nsteps - 1];   // refilled in place right behind its only use (same block)
-          if (acc) {
+          if (lu < ratio) {
             th0 = th1;
             f0 = uniform_d(f1);
             nacc += 1;
@@ -1302,6 +1308,8 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
           keep_row = true;
         }
       }
+      unsigned long long t_c = dbg ? clk() : 0;
+      if (dbg) { tf += t_a - t_2; tc += t_b - t_a; td += t_c - t_b; }
       const double th0_row = th0;
       if (v < nsteps && status == FMCMC_CHAIN_OK && plane) {
         double t = th0;
@@ -1339,7 +1347,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
   }
   if (dbg && lane == 0 && A.logpost) {   // stamps leave through the logpost buffer in this diagnostic mode
     double* d = A.logpost + (long long)A.nchains * A.S - 8 * ((long long)blockIdx.x * NW + wave + 1);
-    d[0] = (double)te; d[1] = (double)tb1; d[2] = (double)to; d[3] = (double)tb2; d[4] = (double)nsteps;
+    d[0] = (double)te; d[1] = (double)tb1; d[2] = (double)to; d[3] = (double)tb2; d[4] = (double)nsteps; d[5] = (double)tf; d[6] = (double)tc; d[7] = (double)td;
   }
   if (owner) {
     if (plane) A.theta0[(long long)cl * k + lane] = th0;

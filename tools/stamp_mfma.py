@@ -15,9 +15,9 @@ r = E.sweep(gm, gk, st, nsteps, want_draws=False, want_logpost=True, check=False
 torch.cuda.synchronize()
 flat = r.logpost.reshape(-1).cpu().numpy()
 nb = C // 4
-rows = np.array([[flat[flat.size - 8 * (b * 8 + w + 1): flat.size - 8 * (b * 8 + w + 1) + 5] for w in range(8)] for b in range(nb)])
-per = rows[:, :, :4] / rows[:, :, 4:5]
+rows = np.array([[flat[flat.size - 8 * (b * 8 + w + 1): flat.size - 8 * (b * 8 + w + 1) + 8] for w in range(8)] for b in range(nb)])
+per = rows[:, :, [0, 1, 2, 3, 5, 6, 7]] / rows[:, :, 4:5]
 med = np.median(per, axis=0)
-print("ticks per MH step, median over workgroups: eval(MFMA) | barrier wait | owner phase | barrier wait | total")
+print("ticks per MH step, median over workgroups: eval(MFMA) | barrier wait | owner phase | barrier wait | total || owner phase split: fold | closed form | decide (rest = propose)")
 for w in range(8):
-    print("wave %d: %7.0f %7.0f %7.0f %7.0f | %7.0f" % (w, *med[w], med[w].sum()))
+    print("wave %d: %7.0f %7.0f %7.0f %7.0f | %7.0f || %6.0f %6.0f %6.0f" % (w, *med[w][:4], med[w][:4].sum(), *med[w][4:]))
