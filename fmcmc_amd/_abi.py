@@ -9,8 +9,10 @@ LIB_PATH = os.environ.get("FMCMC_AMD_LIB") or os.path.join(_HERE, "lib", "libfmc
 _dp = C.POINTER(C.c_double)
 
 FAM_GAUSSIAN_LINREG, FAM_LOGISTIC, FAM_IID_NORMAL = 1, 2, 3
-KERNEL_NORMAL, KERNEL_NORMAL_REFLECTIVE, KERNEL_ADAPT, KERNEL_RAM = 1, 2, 3, 4
-SCHEME_JOINT, SCHEME_ORDERED = 0, 1
+KERNEL_NORMAL, KERNEL_NORMAL_REFLECTIVE, KERNEL_ADAPT, KERNEL_RAM, KERNEL_UNIF, KERNEL_UNIF_REFLECTIVE = 1, 2, 3, 4, 5, 6
+SIMPLE_KERNELS = (KERNEL_NORMAL, KERNEL_NORMAL_REFLECTIVE, KERNEL_UNIF, KERNEL_UNIF_REFLECTIVE)
+SCHEME_JOINT, SCHEME_ORDERED, SCHEME_RANDOM, SCHEME_EXPLICIT = 0, 1, 2, 3
+ABI_VERSION = 2
 RNG_PHILOX, RNG_FED = 0, 1
 OK, ERR_ARG, ERR_DEVICE, ERR_CHAIN, ERR_UNSUPPORTED = 0, 1, 2, 3, 4
 CHAIN_OK, CHAIN_NAN_LOGPOST, CHAIN_NAN_RATIO, CHAIN_NOT_PD = 0, 1, 2, 3
@@ -32,7 +34,9 @@ class Kernel(C.Structure):
     _fields_ = [("kind", C.c_int32), ("k", C.c_int32), ("mu", C.c_void_p), ("scale", C.c_void_p),
                 ("lb", C.c_void_p), ("ub", C.c_void_p), ("fixed", C.c_void_p), ("scheme", C.c_int32),
                 ("freq", C.c_int32), ("warmup", C.c_int32), ("bw", C.c_int32), ("until", C.c_double),
-                ("eps", C.c_double), ("arate", C.c_double), ("Sd", C.c_double)]
+                ("eps", C.c_double), ("arate", C.c_double), ("Sd", C.c_double),
+                ("scheme_seq", C.c_void_p), ("scheme_len", C.c_int32), ("reserved", C.c_int32),
+                ("constr", C.c_void_p)]
 
 
 class Run(C.Structure):
@@ -45,7 +49,8 @@ class Run(C.Structure):
 class State(C.Structure):
     _fields_ = [("theta0", C.c_void_p), ("f0", C.c_void_p), ("abs_iter", C.c_void_p),
                 ("Sigma", C.c_void_p), ("mean_prev", C.c_void_p), ("have_mean", C.c_void_p),
-                ("nerrors", C.c_void_p), ("fresh", C.c_int32), ("reserved", C.c_int32)]
+                ("nerrors", C.c_void_p), ("fresh", C.c_int32), ("reserved", C.c_int32),
+                ("scheme_cols", C.c_void_p)]
 
 
 class Out(C.Structure):
@@ -67,6 +72,9 @@ def lib():
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
         L = C.CDLL(LIB_PATH)
         L.fmcmc_abi_version.restype = C.c_int
+        if L.fmcmc_abi_version() != ABI_VERSION:
+            raise RuntimeError("%s has ABI version %d, this package binds version %d: rebuild with "
+                               "`python -m fmcmc_amd.build`." % (LIB_PATH, L.fmcmc_abi_version(), ABI_VERSION))
         L.fmcmc_last_error.restype = C.c_char_p
         L.fmcmc_device_count.restype = C.c_int
         L.fmcmc_kept_rows.restype = C.c_int64

@@ -55,6 +55,12 @@ struct SweepArgs {
   double prior_div;
   // kernel
   int kind, k, scheme, warmup;
+  int variate;               // 0: N(0,1) / Student-t by kind; 1: U(0,1) (uniform kernels)
+  int freq;                  // ram: adaptation frequency
+  int scheme_len;            // explicit scheme
+  const int* scheme_seq;     // [scheme_len] 0-based parameter indices (device)
+  const double* constr;      // ram: [kf][kf] mask or NULL (device)
+  int* scheme_cols;          // [C][nsteps] plan of scheme = "random": in (FED) / out (PHILOX), or NULL
   double until, eps, arate;
   const double* mu;
   const double* scale;
@@ -537,6 +543,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_kernel(const SweepArgs A0) {
           } else {
             if (A.rng_mode == FMCMC_RNG_FED) v = A.fed_z[(clc * A.nsteps + (ii - 1)) * kz + a];
             else if (A.kind == FMCMC_KERNEL_RAM) v = fmh_student_t(A.seed, st, cg, (unsigned int)a, (double)kf);
+            else if (A.variate == 1) v = fmh_unif(A.seed, st, cg, (unsigned int)a);
             else v = fmh_normal(A.seed, st, cg, (unsigned int)a);
             s_zt[(c * TB + t) * kz + a] = v;
           }
@@ -551,9 +558,27 @@ __global__ __launch_bounds__(NT) void mh_sweep_kernel(const SweepArgs A0) {
         if (lane < k) L.th1[lane] = L.th0[lane];
         wave_sync();
         const bool refl = (A.kind == FMCMC_KERNEL_NORMAL_REFLECTIVE);
-        const int nupd = (A.scheme == FMCMC_SCHEME_ORDERED) ? 1 : kf;
+        // plan_update_sequence (R/kernel.R:66-133): every scheme but "joint" updates ONE parameter per step
+        const bool single = (A.scheme != FMCMC_SCHEME_JOINT);
+        int col = 0;
+        if (A.scheme == FMCMC_SCHEME_ORDERED) {
+          col = s_which[ord];
+        } else if (A.scheme == FMCMC_SCHEME_EXPLICIT) {
+          col = A.scheme_seq[(i - 1) % A.scheme_len];
+        } else if (A.scheme == FMCMC_SCHEME_RANDOM) {
+          if (A.rng_mode == FMCMC_RNG_FED) {
+            col = A.scheme_cols[cl * A.nsteps + (i - 1)];
+          } else {
+            // sample(which(!fixed), nsteps, TRUE)[i]; a single free parameter at position j makes R sample from 1:j
+            const unsigned int npool = (kf == 1) ? (unsigned int)(s_which[0] + 1) : (unsigned int)kf;
+            const unsigned int idx = fmh_scheme_index(A.seed, (unsigned int)i, cgid, npool);
+            col = (kf == 1) ? (int)idx : s_which[idx];
+            if (A.scheme_cols && lane == 0) A.scheme_cols[cl * A.nsteps + (i - 1)] = col;
+          }
+        }
+        const int nupd = single ? 1 : kf;
         if (lane < nupd) {
-          int j = (A.scheme == FMCMC_SCHEME_ORDERED) ? s_which[ord] : s_which[lane];
+          int j = single ? col : s_which[lane];
           double z = zt[lane];
           double t = L.th0[j] + (s_mu[j] + s_scale[j] * z);
           if (refl) t = reflect1(t, s_lb[j], s_ub[j]);
@@ -622,7 +647,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_kernel(const SweepArgs A0) {
           int j = s_which[lane];
           L.th1[j] = L.th0[j] + s;
         }
-        ram_gate = (A.until > (double)abs_iter && abs_iter > A.warmup);
+        ram_gate = (A.until > (double)abs_iter && abs_iter > A.warmup && (i % A.freq) == 0);
       }
       if (status != FMCMC_CHAIN_OK) {  // raised inside the proposal (NOT_PD)
         if (lane == 0) { A.status[cl] = status; A.status_step[cl] = i; }
@@ -674,6 +699,11 @@ __global__ __launch_bounds__(NT) void mh_sweep_kernel(const SweepArgs A0) {
             } else {
               double* t = Scur; Scur = Salt; Salt = t;
             }
+          }
+          if (A.constr) {  // Sigma <<- constr[which., which.] * Sigma (R/kernel_ram.R:149-150)
+            if (lane < kf)
+              for (int b = 0; b < kf; b++) Scur[lane * LD + b] = A.constr[lane * kf + b] * Scur[lane * LD + b];
+            wave_sync();
           }
         }
         abs_iter += 1;
@@ -791,6 +821,10 @@ __global__ __launch_bounds__(256) void rng_fill_kernel(unsigned long long seed, 
   logu[item] = fmh_log_accept_u(seed, st, cg);
   if (student_df > 0) {  // kernel_ram: qfun = rt(k, k)
     for (int a = 0; a < kz; a++) z[item * kz + a] = fmh_student_t(seed, st, cg, (unsigned int)a, (double)student_df);
+    return;
+  }
+  if (student_df < 0) {  // uniform kernels: the unif_rand() behind runif (R/kernel_unif.R:74)
+    for (int a = 0; a < kz; a++) z[item * kz + a] = fmh_unif(seed, st, cg, (unsigned int)a);
     return;
   }
   for (int b = 0; 2 * b < kz; b++) {
@@ -1592,7 +1626,7 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
             const int j = which[lane];
             th1[j] = th0[j] + sacc;
           }
-          ram_gate = (A.until > (double)abs_iter && abs_iter > A.warmup);
+          ram_gate = (A.until > (double)abs_iter && abs_iter > A.warmup && ((v + 1) % A.freq) == 0);
         }
         wave_sync_lds();
         if (lane < k) s_th1[myc * PIPE_KMAX + lane] = th1[lane];
@@ -1839,7 +1873,7 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
             if (b < kf) { const double ub_ = readlane_d(zcur, b); if (b <= lane) sacc = fmh_fma(Srow[b], ub_, sacc); }
           vv = sacc;
           th1 = th0 + sacc;
-          ram_gate = (A.until > (double)abs_iter && abs_iter > A.warmup);
+          ram_gate = (A.until > (double)abs_iter && abs_iter > A.warmup && ((v + 1) % A.freq) == 0);
         }
         if (rl) s_th1[myc * PIPE_KMAX + lane] = th1;
       }
@@ -2172,6 +2206,14 @@ static int count_free(const fmcmc_kernel* kn, const uint8_t* fixed_host) {
 
 // Argument checks with the reference's own messages (R/mcmc.R:501-520, R/kernel.R:9,129-132,
 // R/kernel_normal.R:134-135). Pointers inside `kernel` must be HOST pointers here.
+static bool is_simple_kind(int kind) {
+  return kind == FMCMC_KERNEL_NORMAL || kind == FMCMC_KERNEL_NORMAL_REFLECTIVE || kind == FMCMC_KERNEL_UNIF ||
+         kind == FMCMC_KERNEL_UNIF_REFLECTIVE;
+}
+static int variates_per_step(const fmcmc_kernel* kn, int kf) {  // single-parameter schemes draw one variate per step
+  return (is_simple_kind(kn->kind) && kn->scheme != FMCMC_SCHEME_JOINT) ? 1 : kf;
+}
+
 int fmcmc_validate(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_run* run) {
   if (!m || !kn || !run) { set_err("null argument"); return FMCMC_ERR_ARG; }
   if (run->nchains < 1) { set_err("`nchains` must be an integer greater than 1."); return FMCMC_ERR_ARG; }
@@ -2200,8 +2242,13 @@ int fmcmc_validate(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_run
     return FMCMC_ERR_ARG;
   }
   if (m->n < 1) { set_err("the model needs at least one observation"); return FMCMC_ERR_ARG; }
-  if (kn->kind < FMCMC_KERNEL_NORMAL || kn->kind > FMCMC_KERNEL_RAM) {
+  if (kn->kind < FMCMC_KERNEL_NORMAL || kn->kind > FMCMC_KERNEL_UNIF_REFLECTIVE) {
     set_err("unknown kernel kind %d", kn->kind);
+    return FMCMC_ERR_ARG;
+  }
+  const bool simple = is_simple_kind(kn->kind);
+  if (simple && (kn->scheme < FMCMC_SCHEME_JOINT || kn->scheme > FMCMC_SCHEME_EXPLICIT)) {
+    set_err("-scheme- update must be either an integer sequence, 'joint', 'ordered', or 'random'.");
     return FMCMC_ERR_ARG;
   }
   if (kn->fixed && kn->lb && kn->ub) {
@@ -2211,14 +2258,35 @@ int fmcmc_validate(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_run
               "Check the value -fixed- in the kernel initialization.");
       return FMCMC_ERR_ARG;
     }
-    if (kn->kind != FMCMC_KERNEL_NORMAL)
+    if (kn->kind != FMCMC_KERNEL_NORMAL && kn->kind != FMCMC_KERNEL_UNIF)
       for (int j = 0; j < kn->k; j++)
         if (!(kn->ub[j] > kn->lb[j])) { set_err("-ub- cannot be <= than -lb-."); return FMCMC_ERR_ARG; }
+    if ((kn->kind == FMCMC_KERNEL_UNIF || kn->kind == FMCMC_KERNEL_UNIF_REFLECTIVE) && kn->scale)
+      for (int j = 0; j < kn->k; j++)   // scale = max. - min. (R/kernel_unif.R:55-56, :123-124)
+        if (!(kn->scale[j] > 0.0)) { set_err("-max.- cannot be <= than -min.-."); return FMCMC_ERR_ARG; }
+    if (simple && kn->scheme == FMCMC_SCHEME_EXPLICIT) {  // R/kernel.R:72-90
+      if (!kn->scheme_seq || kn->scheme_len != kf) {
+        set_err("When setting the update scheme, it should have the same length as the number of variables that will "
+                "not be fixed. Right now length(scheme) = %d while sum(!fixed) = %d.", kn->scheme_seq ? kn->scheme_len : 0, kf);
+        return FMCMC_ERR_ARG;
+      }
+      for (int j = 0; j < kn->k; j++) {
+        if (kn->fixed[j]) continue;
+        bool found = false;
+        for (int a = 0; a < kn->scheme_len; a++) found = found || (kn->scheme_seq[a] == j);
+        if (!found) {
+          set_err("One or more variables was not included in the ordering sequence. Only variables that are not fixed "
+                  "can be included in this list.");
+          return FMCMC_ERR_ARG;
+        }
+      }
+    }
   }
-  if ((kn->kind == FMCMC_KERNEL_ADAPT || kn->kind == FMCMC_KERNEL_RAM) && (kn->freq != 1 || kn->bw != 0)) {
-    set_err("device kernels support freq = 1 and bw = 0 only (got freq=%d, bw=%d)", kn->freq, kn->bw);
+  if (kn->kind == FMCMC_KERNEL_ADAPT && (kn->freq != 1 || kn->bw != 0)) {
+    set_err("device kernel_adapt supports freq = 1 and bw = 0 only (got freq=%d, bw=%d)", kn->freq, kn->bw);
     return FMCMC_ERR_UNSUPPORTED;
   }
+  if (kn->kind == FMCMC_KERNEL_RAM && kn->freq < 1) { set_err("-freq- must be >= 1."); return FMCMC_ERR_ARG; }
   if (kn->kind == FMCMC_KERNEL_ADAPT && kn->bw > 0 && kn->bw > kn->warmup) {
     set_err("The `warmup` parameter must be greater than `bw`.");
     return FMCMC_ERR_ARG;
@@ -2231,10 +2299,22 @@ int fmcmc_validate(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_run
 }
 
 // kernel->fixed etc. are DEVICE pointers here; kf and bounds info come via `kf`/`ram_bounded`.
-static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_run* run,
+static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const fmcmc_run* run,
                         fmcmc_state* st, fmcmc_out* out, int kf, int ram_bounded, hipStream_t stream) {
   SweepArgs A;
   memset(&A, 0, sizeof(A));
+  // the uniform kernels ARE the normal kernels with mu = min., scale = max. - min. and U(0,1) variates
+  fmcmc_kernel ke = *kn_in;
+  if (ke.kind == FMCMC_KERNEL_UNIF) { ke.kind = FMCMC_KERNEL_NORMAL; A.variate = 1; }
+  if (ke.kind == FMCMC_KERNEL_UNIF_REFLECTIVE) { ke.kind = FMCMC_KERNEL_NORMAL_REFLECTIVE; A.variate = 1; }
+  const fmcmc_kernel* kn = &ke;
+  if (kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE && kn->scheme == FMCMC_SCHEME_RANDOM && run->rng_mode == FMCMC_RNG_FED &&
+      !st->scheme_cols) {
+    set_err("rng_mode = FED with scheme = 'random' needs state->scheme_cols");
+    return FMCMC_ERR_ARG;
+  }
+  A.freq = kn->freq < 1 ? 1 : kn->freq; A.scheme_seq = kn->scheme_seq; A.scheme_len = kn->scheme_len;
+  A.constr = (kn->kind == FMCMC_KERNEL_RAM) ? kn->constr : nullptr; A.scheme_cols = st->scheme_cols;
   A.family = m->family; A.p = m->p; A.intercept = m->intercept ? 1 : 0; A.guard = m->guard ? 1 : 0;
   A.n = m->n; A.X = m->X; A.y = m->y; A.prior_div = m->prior_div;
   A.kind = kn->kind; A.k = kn->k; A.scheme = kn->scheme; A.warmup = kn->warmup;
@@ -2244,7 +2324,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcm
   A.S = fmcmc_kept_rows(run->nsteps, run->burnin, run->thin);
   A.chain_base = run->chain_base; A.step_base = run->step_base; A.seed = run->seed;
   A.rng_mode = run->rng_mode; A.fresh = st->fresh; A.ram_bounded = ram_bounded;
-  A.kz = (kn->scheme == FMCMC_SCHEME_ORDERED && kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE) ? 1 : kf;
+  A.kz = variates_per_step(kn, kf);
   A.fed_logu = run->fed_logu; A.fed_z = run->fed_z;
   { const char* dbg = getenv("FMCMC_AMD_DEBUG_MODE"); A.debug = dbg ? atoi(dbg) : 0; }  // timing ablations only
   A.theta0 = st->theta0; A.f0 = st->f0; A.abs_iter = (long long*)st->abs_iter; A.Sigma = st->Sigma;
@@ -2306,7 +2386,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcm
   int pipe_opt = 0;
   if (!(force && force[0] == '1') && !(nopipe && nopipe[0] == '1') && m->family == FMCMC_FAM_GAUSSIAN_LINREG &&
       (kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE ||
-       ((kn->kind == FMCMC_KERNEL_ADAPT || (kn->kind == FMCMC_KERNEL_RAM && !ram_bounded)) && !(nospec0 && nospec0[0] == '1'))) &&
+       ((kn->kind == FMCMC_KERNEL_ADAPT || (kn->kind == FMCMC_KERNEL_RAM && !ram_bounded && !kn->constr)) && !(nospec0 && nospec0[0] == '1'))) &&
       (kn->scheme == FMCMC_SCHEME_JOINT || kn->kind >= FMCMC_KERNEL_ADAPT) && kn->k <= PIPE_KMAX &&
       (unsigned long long)run->nchains * kn->k * (unsigned long long)A.S * 8ull < (1ull << 32) &&
       (unsigned long long)run->nchains * (unsigned long long)run->nsteps * (unsigned long long)A.kz * 8ull < (1ull << 32)) {
@@ -2325,7 +2405,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcm
       hipLaunchKernelGGL(rng_fill_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream,
                          (unsigned long long)run->seed, (long long)run->step_base, (long long)run->chain_base,
                          (long long)run->nchains, (long long)run->nsteps, A.kz,
-                         (kn->kind == FMCMC_KERNEL_RAM) ? kf : 0, ws, ws + items);
+                         (kn->kind == FMCMC_KERNEL_RAM) ? kf : (A.variate == 1 ? -1 : 0), ws, ws + items);
       A.fed_logu = ws;
       A.fed_z = ws + items;
       A.rng_mode = FMCMC_RNG_FED;
@@ -2434,6 +2514,19 @@ int fmcmc_mcmc_run_dev(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc
   }
   fmcmc_kernel kh = *kn;
   kh.fixed = fx; kh.lb = lb; kh.ub = ub;
+  double sc[MAXK];
+  int32_t seq[MAXK];
+  const bool unif = (kn->kind == FMCMC_KERNEL_UNIF || kn->kind == FMCMC_KERNEL_UNIF_REFLECTIVE);
+  const bool expl = (is_simple_kind(kn->kind) && kn->scheme == FMCMC_SCHEME_EXPLICIT && kn->scheme_seq &&
+                     kn->scheme_len >= 1 && kn->scheme_len <= MAXK);
+  if ((unif && hipMemcpyAsync(sc, kn->scale, kn->k * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess) ||
+      (expl && hipMemcpyAsync(seq, kn->scheme_seq, kn->scheme_len * sizeof(int32_t), hipMemcpyDeviceToHost, stream) != hipSuccess) ||
+      hipStreamSynchronize(stream) != hipSuccess) {
+    set_err("cannot read kernel parameters from device memory");
+    return FMCMC_ERR_DEVICE;
+  }
+  kh.scale = unif ? sc : nullptr;
+  kh.scheme_seq = expl ? seq : nullptr;
   int rc = fmcmc_validate(m, &kh, run);
   if (rc != FMCMC_OK) return rc;
   int kf = count_free(kn, fx);
@@ -2498,8 +2591,11 @@ int fmcmc_mcmc_run_host(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcm
   UP(dk.lb, kn->lb, sizeof(double) * k);
   UP(dk.ub, kn->ub, sizeof(double) * k);
   UP(dk.fixed, kn->fixed, (size_t)k);
+  if (kn->scheme_seq && kn->scheme_len > 0) UP(dk.scheme_seq, kn->scheme_seq, sizeof(int32_t) * (size_t)kn->scheme_len);
+  if (kn->constr && kn->kind == FMCMC_KERNEL_RAM) UP(dk.constr, kn->constr, sizeof(double) * (size_t)kf * kf);
+  if (st->scheme_cols) UP(ds.scheme_cols, st->scheme_cols, sizeof(int32_t) * (size_t)C * run->nsteps);
   if (run->rng_mode == FMCMC_RNG_FED) {
-    const int kz = (kn->scheme == FMCMC_SCHEME_ORDERED && kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE) ? 1 : kf;
+    const int kz = variates_per_step(kn, kf);
     UP(dr.fed_logu, run->fed_logu, sizeof(double) * (size_t)C * run->nsteps);
     UP(dr.fed_z, run->fed_z, sizeof(double) * (size_t)C * run->nsteps * kz);
   }
@@ -2536,6 +2632,8 @@ int fmcmc_mcmc_run_host(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcm
     DOWN(st->have_mean, ds.have_mean, sizeof(int32_t) * (size_t)C);
     if (st->nerrors) DOWN(st->nerrors, ds.nerrors, sizeof(int32_t) * (size_t)C);
   }
+  if (st->scheme_cols && run->rng_mode != FMCMC_RNG_FED && is_simple_kind(kn->kind) && kn->scheme == FMCMC_SCHEME_RANDOM)
+    DOWN(st->scheme_cols, ds.scheme_cols, sizeof(int32_t) * (size_t)C * run->nsteps);
   DOWN(out->samples, dout.samples, sizeof(double) * (size_t)C * k * S);
   if (out->logpost) DOWN(out->logpost, dout.logpost, sizeof(double) * (size_t)C * S);
   if (out->draws) DOWN(out->draws, dout.draws, sizeof(double) * (size_t)C * k * S);

@@ -71,7 +71,7 @@ class KernelSpec:
     """Expanded (recycled) kernel parameters on the device (fmcmc_kernel)."""
 
     def __init__(self, kind, k, mu, scale, lb, ub, fixed, scheme=abi.SCHEME_JOINT, freq=1, warmup=0,
-                 bw=0, until=float("inf"), eps=1e-4, arate=0.234, Sd=0.0, device=None):
+                 bw=0, until=float("inf"), eps=1e-4, arate=0.234, Sd=0.0, scheme_seq=None, constr=None, device=None):
         self.device = _dev(device)
         self.kind, self.k = int(kind), int(k)
         self.h_fixed = np.ascontiguousarray(np.asarray(fixed, dtype=np.uint8))
@@ -83,11 +83,23 @@ class KernelSpec:
         self.fixed = _t(self.h_fixed, torch.uint8, self.device)
         self.scheme, self.freq, self.warmup, self.bw = int(scheme), int(freq), int(warmup), int(bw)
         self.until, self.eps, self.arate, self.Sd = float(until), float(eps), float(arate), float(Sd)
+        # explicit update sequence: 0-based parameter indices (R/kernel.R:69-92); ram: constr[which., which.] mask
+        self.scheme_seq = None if scheme_seq is None else _t(np.asarray(scheme_seq, dtype=np.int32), torch.int32, self.device)
+        self.constr = None if constr is None else _t(np.asarray(constr, dtype=np.float64).reshape(self.kf, self.kf),
+                                                      torch.float64, self.device)
+
+    @property
+    def kz(self):
+        """proposal variates per step: one for the single-parameter schemes (R/kernel_normal.R:63)."""
+        return 1 if (self.kind in abi.SIMPLE_KERNELS and self.scheme != abi.SCHEME_JOINT) else self.kf
 
     def c(self):
         return abi.Kernel(self.kind, self.k, self.mu.data_ptr(), self.scale.data_ptr(), self.lb.data_ptr(),
                           self.ub.data_ptr(), self.fixed.data_ptr(), self.scheme, self.freq, self.warmup,
-                          self.bw, self.until, self.eps, self.arate, self.Sd)
+                          self.bw, self.until, self.eps, self.arate, self.Sd,
+                          self.scheme_seq.data_ptr() if self.scheme_seq is not None else None,
+                          int(self.scheme_seq.numel()) if self.scheme_seq is not None else 0, 0,
+                          self.constr.data_ptr() if self.constr is not None else None)
 
 
 class ChainState:
@@ -105,13 +117,20 @@ class ChainState:
         self.mean_prev = torch.zeros(Cn, kf, dtype=torch.float64, **z)
         self.have_mean = torch.zeros(Cn, dtype=torch.int32, **z)
         self.nerrors = torch.zeros(Cn, dtype=torch.int32, **z)
+        self.scheme_cols = None   # [C][nsteps] int32: plan of scheme = "random" (fmcmc_state.scheme_cols)
         self.fresh = 1
         self.step_base = 0
 
-    def c(self):
+    def c(self, nsteps=None):
+        cols = self.scheme_cols
+        if cols is not None and nsteps is not None and cols.shape[1] != nsteps:
+            if cols.shape[1] < nsteps:   # R: update_sequence[env$i, ] beyond the rows of the kernel's first call
+                raise IndexError("subscript out of bounds: the update plan of this kernel has %d rows" % cols.shape[1])
+            cols = cols[:, :nsteps].contiguous()
+        self._cols_keep = cols
         return abi.State(self.theta0.data_ptr(), self.f0.data_ptr(), self.abs_iter.data_ptr(),
                          self.Sigma.data_ptr(), self.mean_prev.data_ptr(), self.have_mean.data_ptr(),
-                         self.nerrors.data_ptr(), self.fresh, 0)
+                         self.nerrors.data_ptr(), self.fresh, 0, cols.data_ptr() if cols is not None else None)
 
 
 class SweepResult:
@@ -154,7 +173,11 @@ def sweep(model, kernel, state, nsteps, burnin=0, thin=1, seed=0, chain_base=0,
                    out.draws.data_ptr() if want_draws else None, out.accept_count.data_ptr(),
                    out.accept_bits.data_ptr() if want_bits else None, out.status.data_ptr(),
                    out.status_step.data_ptr(), out.status_theta.data_ptr())
-    cm, ck, cs = model.c(), kernel.c(), state.c()
+    if kernel.kind in abi.SIMPLE_KERNELS and kernel.scheme == abi.SCHEME_RANDOM and state.scheme_cols is None:
+        if rng_mode == abi.RNG_FED:
+            raise ValueError("rng_mode = FED with scheme = 'random' needs state.scheme_cols (the plan R drew)")
+        state.scheme_cols = torch.zeros((Cn, nsteps), dtype=torch.int32, device=dev)
+    cm, ck, cs = model.c(), kernel.c(), state.c(nsteps)
     if stream is None:
         stream = torch.cuda.current_stream(dev)
     with torch.cuda.device(dev):
@@ -179,8 +202,7 @@ def rng_stream(state, kernel, nsteps, seed=0, chain_base=0, logu=None, z=None, s
     L = abi.lib()
     dev = state.device
     Cn = state.theta0.shape[0]
-    ordered = (kernel.scheme == abi.SCHEME_ORDERED and kernel.kind <= abi.KERNEL_NORMAL_REFLECTIVE)
-    kz = 1 if ordered else kernel.kf
+    kz = kernel.kz
     if logu is None:
         logu = torch.empty((Cn, nsteps), dtype=torch.float64, device=dev)
     if z is None:
@@ -189,7 +211,9 @@ def rng_stream(state, kernel, nsteps, seed=0, chain_base=0, logu=None, z=None, s
         stream = torch.cuda.current_stream(dev)
     with torch.cuda.device(dev):
         rc = L.fmcmc_rng_stream_dev(seed & 0xFFFFFFFFFFFFFFFF, state.step_base, chain_base, Cn, nsteps, kz,
-                                    kernel.kf if kernel.kind == abi.KERNEL_RAM else 0, logu.data_ptr(), z.data_ptr(),
+                                    kernel.kf if kernel.kind == abi.KERNEL_RAM else
+                                    (-1 if kernel.kind in (abi.KERNEL_UNIF, abi.KERNEL_UNIF_REFLECTIVE) else 0),
+                                    logu.data_ptr(), z.data_ptr(),
                                     C.c_void_p(stream.cuda_stream))
     if rc != abi.OK:
         raise RuntimeError("fmcmc_rng_stream_dev failed (%d): %s" % (rc, abi.last_error()))

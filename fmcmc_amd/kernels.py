@@ -4,6 +4,8 @@
   kernel_normal_reflective R/kernel_normal.R:96-177
   kernel_adapt / kernel_am R/kernel_adapt.R:54-208
   kernel_ram               R/kernel_ram.R:65-181
+  kernel_unif / kernel_unif_reflective   R/kernel_unif.R:42-91, :96-170
+  plan_update_sequence     R/kernel.R:66-133 (scheme = "joint" | "ordered" | "random" | integer sequence)
   check_dimensions / process_bounds   R/kernel.R:3-41
 
 A kernel object is, as in fmcmc, a mutable environment: it is expanded ("initialised") on its
@@ -76,31 +78,55 @@ class fmcmc_kernel:
         if self.k is not None and self._k_total == k:
             return
         self._k_total = k
-        self.mu = check_dimensions(self.mu, k, "mu").astype(np.float64)
-        if self.kind in (abi.KERNEL_NORMAL, abi.KERNEL_NORMAL_REFLECTIVE):
-            self.scale = check_dimensions(self.scale, k, "scale").astype(np.float64)
+        unif = self.kind in (abi.KERNEL_UNIF, abi.KERNEL_UNIF_REFLECTIVE)
+        if unif:   # runif(k, min., max.) == min. + (max. - min.) * unif_rand(): mu := min., scale := max. - min.
+            self.min_ = check_dimensions(self.min_, k, "min.").astype(np.float64)
+            self.max_ = check_dimensions(self.max_, k, "max.").astype(np.float64)
+            self.mu, self.scale = self.min_, self.max_ - self.min_
         else:
-            self.scale = np.ones(k)
-        if self.kind != abi.KERNEL_NORMAL:
+            self.mu = check_dimensions(self.mu, k, "mu").astype(np.float64)
+            if self.kind in (abi.KERNEL_NORMAL, abi.KERNEL_NORMAL_REFLECTIVE):
+                self.scale = check_dimensions(self.scale, k, "scale").astype(np.float64)
+            else:
+                self.scale = np.ones(k)
+        if self.kind not in (abi.KERNEL_NORMAL, abi.KERNEL_UNIF):
             self.ub = process_bounds(check_dimensions(self.ub, k, "ub"), False)
             self.lb = process_bounds(check_dimensions(self.lb, k, "lb"), True)
         else:
             self.lb, self.ub = np.full(k, -DBL_MAX), np.full(k, DBL_MAX)
         self.fixed = check_dimensions(self.fixed, k, "fixed").astype(bool)
-        if self.kind != abi.KERNEL_NORMAL and np.any(self.ub <= self.lb):
+        if self.kind not in (abi.KERNEL_NORMAL, abi.KERNEL_UNIF) and np.any(self.ub <= self.lb):
             raise ValueError("-ub- cannot be <= than -lb-.")
+        if unif and np.any(self.max_ <= self.min_):
+            raise ValueError("-max.- cannot be <= than -min.-.")
         self.which_ = np.nonzero(~self.fixed)[0]
         kf = int(self.which_.size)
+        self._scheme_seq = None
+        if self.kind in abi.SIMPLE_KERNELS:
+            # plan_update_sequence (R/kernel.R:66-133); explicit sequences use R's 1-based parameter positions
+            if not isinstance(self.scheme, str) and np.size(self.scheme) > 1:
+                seq = np.asarray(self.scheme, dtype=np.int64).reshape(-1)
+                if seq.size != kf:
+                    raise ValueError("When setting the update scheme, it should have the same length as the number of "
+                                     "variables that will not be fixed. Right now length(scheme) = %d while "
+                                     "sum(!fixed) = %d." % (seq.size, kf))
+                missing = [int(w) + 1 for w in self.which_ if (w + 1) not in seq]
+                if missing:
+                    raise ValueError("One or more variables was not included in the ordering sequence. The full list "
+                                     "follows: %s. Only variables that are not fixed can be included in this list."
+                                     % ", ".join(map(str, missing)))
+                self._scheme_seq = (seq - 1).astype(np.int32)
+                self._scheme_id = abi.SCHEME_EXPLICIT
+            elif self.scheme in ("joint", "ordered", "random"):
+                self._scheme_id = {"joint": abi.SCHEME_JOINT, "ordered": abi.SCHEME_ORDERED,
+                                   "random": abi.SCHEME_RANDOM}[self.scheme]
+            else:
+                raise ValueError("-scheme- update must be either an integer sequence, 'joint', 'ordered', or 'random'.")
         if kf == 0:
             raise ValueError("The number of parameters to update, i.e. not fixed, cannot be zero. "
                              "Check the value -fixed- in the kernel initialization.")
-        if self.kind in (abi.KERNEL_NORMAL, abi.KERNEL_NORMAL_REFLECTIVE):
-            if self.scheme not in ("joint", "ordered"):
-                if self.scheme == "random" or not isinstance(self.scheme, str):
-                    raise NotImplementedError("scheme = 'random' / explicit sequences draw from R's RNG and are "
-                                              "not available on the device (SURVEY.md section 8(f) rank 3).")
-                raise ValueError("-scheme- update must be either an integer sequence, 'joint', 'ordered', or 'random'.")
-            self.k = kf if self.scheme == "joint" else 1  # k <<- sum(update_sequence[1,])
+        if self.kind in abi.SIMPLE_KERNELS:
+            self.k = kf if self._scheme_id == abi.SCHEME_JOINT else 1  # k <<- sum(update_sequence[1,])
         else:
             self.k = kf
         if self.kind == abi.KERNEL_ADAPT and self.Sd is None:
@@ -109,13 +135,17 @@ class fmcmc_kernel:
 
     def spec(self, device):
         from .engine import KernelSpec
-        sch = abi.SCHEME_ORDERED if getattr(self, "scheme", "joint") == "ordered" else abi.SCHEME_JOINT
+        sch = getattr(self, "_scheme_id", abi.SCHEME_JOINT) if self.kind in abi.SIMPLE_KERNELS else abi.SCHEME_JOINT
         until = getattr(self, "until", float("inf"))
+        constr = getattr(self, "constr", None)
+        if constr is not None:   # constr[which., , drop = FALSE][, which., drop = FALSE] (R/kernel_ram.R:150)
+            constr = np.asarray(constr, dtype=np.float64)[np.ix_(self.which_, self.which_)]
         return KernelSpec(self.kind, self._k_total, self.mu, self.scale, self.lb, self.ub,
                           self.fixed.astype(np.uint8), scheme=sch, freq=getattr(self, "freq", 1),
                           warmup=getattr(self, "warmup", 0), bw=getattr(self, "bw", 0), until=until,
                           eps=getattr(self, "eps", 1e-4), arate=getattr(self, "arate", 0.234),
-                          Sd=getattr(self, "Sd", 0.0) or 0.0, device=device)
+                          Sd=getattr(self, "Sd", 0.0) or 0.0, scheme_seq=getattr(self, "_scheme_seq", None),
+                          constr=constr, device=device)
 
     def state_for(self, initial, device):
         """Chain state for this call: the kernel's persistent part survives, theta0 := initial."""
@@ -155,7 +185,8 @@ class fmcmc_kernel:
         return int(a[0]) if a.size == 1 else a
 
     def __repr__(self):
-        names = {1: "kernel_normal", 2: "kernel_normal_reflective", 3: "kernel_adapt", 4: "kernel_ram"}
+        names = {1: "kernel_normal", 2: "kernel_normal_reflective", 3: "kernel_adapt", 4: "kernel_ram",
+                 5: "kernel_unif", 6: "kernel_unif_reflective"}
         return "<fmcmc_kernel %s k=%s>" % (names[self.kind], self.k)
 
 
@@ -166,6 +197,17 @@ def kernel_normal(mu=0.0, scale=1.0, fixed=False, scheme="joint"):
 def kernel_normal_reflective(mu=0.0, scale=1.0, lb=-DBL_MAX, ub=DBL_MAX, fixed=False, scheme="joint"):
     return fmcmc_kernel(abi.KERNEL_NORMAL_REFLECTIVE, mu=mu, scale=scale, lb=lb, ub=ub, fixed=fixed,
                         scheme=scheme)
+
+
+def kernel_unif(min_=-1.0, max_=1.0, fixed=False, scheme="joint"):
+    """R/kernel_unif.R:42-91 (`min.` / `max.` are spelled min_ / max_)."""
+    return fmcmc_kernel(abi.KERNEL_UNIF, min_=min_, max_=max_, mu=0.0, fixed=fixed, scheme=scheme)
+
+
+def kernel_unif_reflective(min_=-1.0, max_=1.0, lb=None, ub=None, fixed=False, scheme="joint"):
+    """R/kernel_unif.R:96-170; lb / ub default to min. / max. (:99-100)."""
+    return fmcmc_kernel(abi.KERNEL_UNIF_REFLECTIVE, min_=min_, max_=max_, mu=0.0, lb=min_ if lb is None else lb,
+                        ub=max_ if ub is None else ub, fixed=fixed, scheme=scheme)
 
 
 def kernel_adapt(mu=0.0, bw=0, lb=-DBL_MAX, ub=DBL_MAX, freq=1, warmup=500, Sigma=None, Sd=None,
@@ -184,10 +226,10 @@ kernel_am = kernel_adapt
 
 def kernel_ram(mu=0.0, eta=None, qfun=None, arate=0.234, freq=1, warmup=0, Sigma=None, eps=1e-4,
                lb=-DBL_MAX, ub=DBL_MAX, fixed=False, until=float("inf"), constr=None):
-    if eta is not None or qfun is not None or constr is not None:
-        raise NotImplementedError("user-supplied eta/qfun/constr are R closures; the device kernel implements the "
+    if eta is not None or qfun is not None:
+        raise NotImplementedError("user-supplied eta/qfun are R closures; the device kernel implements the "
                                   "defaults eta(i,k) = min(1, k i^(-2/3)) and qfun = rt(k, k) (R/kernel_ram.R:67-68).")
-    if freq != 1:
-        raise NotImplementedError("device kernel_ram supports freq = 1")
+    if int(freq) < 1:
+        raise ValueError("-freq- must be >= 1.")
     return fmcmc_kernel(abi.KERNEL_RAM, mu=mu, arate=arate, freq=int(freq), warmup=int(warmup), Sigma=Sigma,
-                        eps=eps, lb=lb, ub=ub, fixed=fixed, until=until)
+                        eps=eps, lb=lb, ub=ub, fixed=fixed, until=until, constr=constr)

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define FMCMC_ABI_VERSION 1
+#define FMCMC_ABI_VERSION 2
 #define FMCMC_MAX_K 64 /* parameters per chain supported by the device kernels */
 
 /* ---- log-posterior families: the `fun` argument of MCMC() (R/mcmc.R:327) ---------- */
@@ -67,26 +67,43 @@ enum {
   FMCMC_KERNEL_NORMAL = 1,            /* R/kernel_normal.R:26-82   */
   FMCMC_KERNEL_NORMAL_REFLECTIVE = 2, /* R/kernel_normal.R:96-177  */
   FMCMC_KERNEL_ADAPT = 3,             /* R/kernel_adapt.R:54-202   */
-  FMCMC_KERNEL_RAM = 4                /* R/kernel_ram.R:65-181     */
+  FMCMC_KERNEL_RAM = 4,               /* R/kernel_ram.R:65-181     */
+  /* theta1[w] = theta0[w] + runif(min.[w], max.[w]) (R/kernel_unif.R:42-91, :96-170): the same proposal code as
+   * the normal kernels with mu := min., scale := max. - min. and U(0,1) variates instead of N(0,1). */
+  FMCMC_KERNEL_UNIF = 5,
+  FMCMC_KERNEL_UNIF_REFLECTIVE = 6
 };
-enum { FMCMC_SCHEME_JOINT = 0, FMCMC_SCHEME_ORDERED = 1 }; /* R/kernel.R:94-104 */
+/* Update schemes of the normal / uniform kernels, plan_update_sequence (R/kernel.R:66-133).  Row i of the plan is used
+ * by loop step i (R/kernel_normal.R:67); the plan is built once per kernel object for the nsteps of its first call. */
+enum {
+  FMCMC_SCHEME_JOINT = 0,    /* all free parameters every step (:94-99) */
+  FMCMC_SCHEME_ORDERED = 1,  /* one parameter per step, which(!fixed)[(i-1) mod kf] (:101-104) */
+  FMCMC_SCHEME_RANDOM = 2,   /* one parameter per step, sample(which(!fixed), nsteps, TRUE)[i] (:106-113) */
+  FMCMC_SCHEME_EXPLICIT = 3  /* one parameter per step, scheme_seq[(i-1) mod scheme_len] (:69-92) */
+};
 
 typedef struct fmcmc_kernel {
   int32_t kind;         /* FMCMC_KERNEL_* */
   int32_t k;            /* number of parameters (length of theta) */
-  const double* mu;     /* [k] proposal mean (already recycled: R/kernel.R:3-17) */
-  const double* scale;  /* [k] proposal sd (normal kernels) */
+  const double* mu;     /* [k] proposal mean (already recycled: R/kernel.R:3-17); unif kernels: min. */
+  const double* scale;  /* [k] proposal sd (normal kernels); unif kernels: max. - min. */
   const double* lb;     /* [k] lower bounds, -DBL_MAX when unbounded (R/kernel.R:25-41) */
   const double* ub;     /* [k] upper bounds */
   const uint8_t* fixed; /* [k] 1 = parameter never updated */
-  int32_t scheme;       /* FMCMC_SCHEME_* (normal kernels) */
-  int32_t freq;         /* adapt/ram: adaptation frequency (only 1 supported on device) */
+  int32_t scheme;       /* FMCMC_SCHEME_* (normal / unif kernels) */
+  int32_t freq;         /* adapt/ram: adaptation frequency (adapt: only 1 supported on device) */
   int32_t warmup;       /* adapt/ram */
   int32_t bw;           /* adapt: window (only 0 supported on device) */
   double until;         /* adapt/ram: stop adapting when abs_iter >= until (Inf allowed) */
   double eps;           /* adapt/ram: initial Sigma = eps * I */
   double arate;         /* ram: target acceptance rate */
   double Sd;            /* adapt: scaling (unused on the recursive path, kept for write-back) */
+  const int32_t* scheme_seq; /* [scheme_len] FMCMC_SCHEME_EXPLICIT: 0-based parameter indices, a permutation of the
+                              * free parameters (R/kernel.R:72-90); NULL otherwise */
+  int32_t scheme_len;
+  int32_t reserved;
+  const double* constr; /* ram: [kf][kf] mask multiplied element-wise into the updated factor
+                         * (constr[which., which.], R/kernel_ram.R:149-150); NULL = none */
 } fmcmc_kernel;
 
 /* ---- one call of MCMC_without_conv_checker over all chains ------------------------ */
@@ -121,6 +138,11 @@ typedef struct fmcmc_state {
   int32_t* nerrors;    /* [C]     ram: failed factor updates (R/kernel_ram.R:143) */
   int32_t fresh;       /* 1: kernel state is uninitialised; the engine sets Sigma = eps*I etc. */
   int32_t reserved;
+  /* FMCMC_SCHEME_RANDOM: the plan of the kernel object, entry [c][i-1] = 0-based parameter updated by loop step i.
+   * PHILOX mode: a pure function of (seed, global chain, i) -- identical in every call, as the reference reuses
+   * the plan of the kernel's first call -- written here when non-NULL.  FED mode: read from here (the caller
+   * replays R's sample()).  [C][nsteps] int32, or NULL. */
+  int32_t* scheme_cols;
 } fmcmc_state;
 
 enum {
@@ -187,8 +209,9 @@ int fmcmc_gelman_finish(const double* partial, int32_t p, int64_t N, double* psr
                         double* mpsrf);
 
 /* Materialises the canonical Philox stream of a call in device memory, in the FED layout of fmcmc_run:
- * logu[C][nsteps] (entry i-1 = log accept-uniform of loop step i), z[C][nsteps][kz] (N(0,1), or Student-t
- * with student_df degrees of freedom when student_df > 0, the qfun of R/kernel_ram.R:68).  A sweep run with
+ * logu[C][nsteps] (entry i-1 = log accept-uniform of loop step i), z[C][nsteps][kz] (N(0,1); Student-t
+ * with student_df degrees of freedom when student_df > 0, the qfun of R/kernel_ram.R:68; U(0,1) of the uniform
+ * kernels when student_df == -1).  A sweep run with
  * rng_mode = FMCMC_RNG_FED on these buffers is bit-identical to rng_mode = FMCMC_RNG_PHILOX; callers that
  * launch many sweeps can reuse the buffers instead of letting the library allocate them per call. */
 int fmcmc_rng_stream_dev(uint64_t seed, int64_t step_base, int64_t chain_base, int64_t nchains, int64_t nsteps,

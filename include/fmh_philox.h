@@ -32,6 +32,8 @@
 #define FMH_STREAM_ACCEPT 0u   /* block 0: u0 = accept uniform */
 #define FMH_STREAM_NORMAL 1u   /* block j/2, lane j%2: N(0,1) for free parameter j */
 #define FMH_STREAM_GAMMA 2u    /* block = j*FMH_GAMMA_TRIES + attempt: (normal, uniform) pair */
+#define FMH_STREAM_UNIF 3u     /* block j/2, lane j%2: U(0,1) for free parameter j (uniform kernels) */
+#define FMH_STREAM_SCHEME 4u   /* block 0, word 0: update column of plan row `step` (scheme = "random") */
 #define FMH_GAMMA_TRIES 64u
 
 typedef struct { uint32_t v[4]; } fmh_u32x4;
@@ -88,6 +90,20 @@ FMH_HD double fmh_normal(uint64_t seed, uint32_t step, uint32_t chain, uint32_t 
   double u0, u1;
   fmh_uniform2(seed, step, chain, j >> 1, FMH_STREAM_NORMAL, &u0, &u1);
   return fmh_qnorm((j & 1u) ? u1 : u0);
+}
+
+/* j-th U(0,1) proposal variate of (step, chain): the canonical unif_rand() behind runif (R/kernel_unif.R:74). */
+FMH_HD double fmh_unif(uint64_t seed, uint32_t step, uint32_t chain, uint32_t j) {
+  double u0, u1;
+  fmh_uniform2(seed, step, chain, j >> 1, FMH_STREAM_UNIF, &u0, &u1);
+  return (j & 1u) ? u1 : u0;
+}
+
+/* Index in [0, npool) of plan row `row` (the LOCAL loop index i: the reference builds the plan once per kernel object
+ * and reuses its rows in every later call, R/kernel.R:106-113) of chain `chain`: multiply-shift of one 32-bit word. */
+FMH_HD uint32_t fmh_scheme_index(uint64_t seed, uint32_t row, uint32_t chain, uint32_t npool) {
+  fmh_u32x4 r = fmh_philox4x32_10(row, chain, 0u, FMH_STREAM_SCHEME, (uint32_t)seed, (uint32_t)(seed >> 32));
+  return (uint32_t)(((uint64_t)r.v[0] * (uint64_t)npool) >> 32);
 }
 
 /* j-th chi-square(df) variate of (step, chain), df >= 1 (not necessarily integer).

@@ -409,6 +409,7 @@ typedef struct {
   int nerrors;
   double run_sum[MAXK];        /* canonical: sum of ans rows 1..i-1 over free params */
   long double run_sum_ld[MAXK]; /* R mode */
+  const int32_t* cols;         /* scheme = "random": plan of this chain, entry i-1 = column of loop step i */
 } kstate;
 
 /* draw helpers ---------------------------------------------------------------------------- */
@@ -416,12 +417,22 @@ static double draw_normal(const ocfg* cfg, uint32_t step, uint32_t chain, uint32
   if (cfg->rng_mode == ORACLE_RNG_RMT) return r_norm_rand(cfg->g);
   return fmh_normal(cfg->seed, step, chain, j);
 }
+/* unif_rand() behind runif(k, min., max.) (R/kernel_unif.R:74; src/nmath/runif.c: a + (b - a) * u) */
+static double draw_unif(const ocfg* cfg, uint32_t step, uint32_t chain, uint32_t j) {
+  if (cfg->rng_mode == ORACLE_RNG_RMT) {
+    double u;
+    do { u = r_unif_rand(cfg->g); } while (u <= 0 || u >= 1);
+    return u;
+  }
+  return fmh_unif(cfg->seed, step, chain, j);
+}
 static double draw_t(const ocfg* cfg, uint32_t step, uint32_t chain, uint32_t j, double df) {
   if (cfg->rng_mode == ORACLE_RNG_RMT) return r_rt(cfg->g, df);
   return fmh_student_t(cfg->seed, step, chain, j, df);
 }
 
-/* kernel_normal / kernel_normal_reflective proposal (R/kernel_normal.R:65-72, :146-164) */
+/* kernel_normal / kernel_normal_reflective (R/kernel_normal.R:65-72, :146-164) and kernel_unif / kernel_unif_reflective
+ * (R/kernel_unif.R:70-76, :150-166; there mu = min., scale = max. - min. and the variate is unif_rand) */
 static void propose_normal(const ocfg* cfg, const fmcmc_kernel* kn, const kstate* ks, int64_t i,
                            uint32_t step, uint32_t chain, const double* theta0, double* theta1) {
   for (int a = 0; a < kn->k; a++) theta1[a] = theta0[a];
@@ -429,15 +440,21 @@ static void propose_normal(const ocfg* cfg, const fmcmc_kernel* kn, const kstate
   if (kn->scheme == FMCMC_SCHEME_ORDERED) {
     /* R/kernel.R:101-104: row r of the plan updates which(!fixed)[(r-1) mod kf] */
     upd[nupd++] = ks->which[(int)((i - 1) % ks->kf)];
+  } else if (kn->scheme == FMCMC_SCHEME_EXPLICIT) {
+    /* R/kernel.R:91-92: update_sequence[cbind(1:nsteps, scheme)] recycles scheme along the rows */
+    upd[nupd++] = kn->scheme_seq[(int)((i - 1) % kn->scheme_len)];
+  } else if (kn->scheme == FMCMC_SCHEME_RANDOM) {
+    upd[nupd++] = ks->cols[i - 1]; /* R/kernel.R:106-113 */
   } else {
     for (int a = 0; a < ks->kf; a++) upd[nupd++] = ks->which[a];
   }
+  const int unif = (kn->kind == FMCMC_KERNEL_UNIF || kn->kind == FMCMC_KERNEL_UNIF_REFLECTIVE);
   for (int a = 0; a < nupd; a++) {
     int j = upd[a];
-    double z = draw_normal(cfg, step, chain, (uint32_t)a);
+    double z = unif ? draw_unif(cfg, step, chain, (uint32_t)a) : draw_normal(cfg, step, chain, (uint32_t)a);
     theta1[j] = theta1[j] + (kn->mu[j] + kn->scale[j] * z);
   }
-  if (kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE)
+  if (kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE || kn->kind == FMCMC_KERNEL_UNIF_REFLECTIVE)
     for (int a = 0; a < nupd; a++) {
       int j = upd[a];
       theta1[j] = reflect1(theta1[j], kn->lb[j], kn->ub[j], cfg->math_mode);
@@ -592,6 +609,8 @@ static int propose_ram(const ocfg* cfg, const fmcmc_model* m, const fmcmc_kernel
         else memcpy(ks->Sigma, L, sizeof(double) * kf * kf);
       }
     }
+    if (kn->constr) /* Sigma <<- constr[which., which.] * Sigma :149-150 (element-wise) */
+      for (int a = 0; a < kf * kf; a++) ks->Sigma[a] = kn->constr[a] * ks->Sigma[a];
   }
   ks->abs_iter += 1;
   for (int a = 0; a < kf; a++) {
@@ -614,24 +633,33 @@ int fmcmc_oracle_run(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_r
   const int k = kn->k;
   if (k > MAXK || k < 1) return FMCMC_ERR_ARG;
   if (run->burnin >= run->nsteps || run->thin >= run->nsteps || run->thin < 1) return FMCMC_ERR_ARG;
-  if ((kn->kind == FMCMC_KERNEL_ADAPT || kn->kind == FMCMC_KERNEL_RAM) &&
-      (kn->freq != 1 || kn->bw != 0))
-    return FMCMC_ERR_UNSUPPORTED;
+  if (kn->kind == FMCMC_KERNEL_ADAPT && (kn->freq != 1 || kn->bw != 0)) return FMCMC_ERR_UNSUPPORTED;
+  if (kn->kind == FMCMC_KERNEL_RAM && kn->freq < 1) return FMCMC_ERR_ARG;
+  const int simple = (kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE ||
+                      kn->kind == FMCMC_KERNEL_UNIF || kn->kind == FMCMC_KERNEL_UNIF_REFLECTIVE);
+  if (simple && kn->scheme == FMCMC_SCHEME_EXPLICIT && (!kn->scheme_seq || kn->scheme_len < 1)) return FMCMC_ERR_ARG;
   ocfg cfg; cfg.rng_mode = rng_mode; cfg.math_mode = math_mode; cfg.g = g; cfg.seed = run->seed;
   const int64_t C = run->nchains, nsteps = run->nsteps;
   const int64_t S = fmcmc_oracle_kept_rows(nsteps, run->burnin, run->thin);
   const int64_t nwords = (nsteps + 31) / 32;
   int any_err = 0;
   double* logu = (double*)malloc(sizeof(double) * (size_t)(nsteps + 1));
+  int32_t* cols_buf = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nsteps + 1));
 
   kstate ks;
   ks.k = k; ks.kf = 0;
   for (int a = 0; a < k; a++)
     if (!kn->fixed[a]) ks.which[ks.kf++] = a;
   const int kf = ks.kf;
-  if (kf == 0) { free(logu); return FMCMC_ERR_ARG; }
+  if (kf == 0) { free(logu); free(cols_buf); return FMCMC_ERR_ARG; }
   for (int a = 0; a < k; a++)
-    if (kn->kind != FMCMC_KERNEL_NORMAL && !(kn->ub[a] > kn->lb[a])) { free(logu); return FMCMC_ERR_ARG; }
+    if (kn->kind != FMCMC_KERNEL_NORMAL && kn->kind != FMCMC_KERNEL_UNIF && !(kn->ub[a] > kn->lb[a])) {
+      free(logu); free(cols_buf); return FMCMC_ERR_ARG;
+    }
+  /* sample(which(!fixed), nsteps, TRUE): a length-one x >= 1 means sample(1:x) in R (R/kernel.R:110) */
+  int pool[MAXK], npool = 0;
+  if (kf == 1) for (int a = 0; a <= ks.which[0]; a++) pool[npool++] = a;
+  else for (int a = 0; a < kf; a++) pool[npool++] = ks.which[a];
 
   for (int64_t c = 0; c < C; c++) {
     const uint32_t chain = (uint32_t)(run->chain_base + c);
@@ -657,6 +685,22 @@ int fmcmc_oracle_run(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_r
     /* R <- log(runif(nsteps)) drawn up front (R/mcmc.R:726); R[1] is never used */
     if (rng_mode == ORACLE_RNG_RMT)
       for (int64_t i = 1; i <= nsteps; i++) logu[i] = log(r_unif_rand(g));
+
+    /* plan of scheme = "random": drawn when the kernel initialises, i.e. at the first proposal, behind R (R/kernel.R:106-113) */
+    ks.cols = NULL;
+    if (simple && kn->scheme == FMCMC_SCHEME_RANDOM) {
+      int32_t* io = st->scheme_cols ? st->scheme_cols + c * nsteps : NULL;
+      if (rng_mode == ORACLE_RNG_RMT && io && !st->fresh) {
+        ks.cols = io; /* the kernel object keeps its plan across calls */
+      } else {
+        for (int64_t i = 1; i <= nsteps; i++)
+          cols_buf[i - 1] = (rng_mode == ORACLE_RNG_RMT)
+                                ? pool[(int)r_unif_index(g, (double)npool)]
+                                : pool[fmh_scheme_index(cfg.seed, (uint32_t)i, chain, (uint32_t)npool)];
+        if (io) memcpy(io, cols_buf, sizeof(int32_t) * (size_t)nsteps);
+        ks.cols = cols_buf;
+      }
+    }
 
     double* ans = out->samples + c * k * S;
     double* drw = out->draws ? out->draws + c * k * S : NULL;
@@ -690,7 +734,7 @@ int fmcmc_oracle_run(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_r
     for (int64_t i = 2; i <= nsteps; i++) {
       const uint32_t step = (uint32_t)(run->step_base + i);
       int status = FMCMC_CHAIN_OK;
-      if (kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE)
+      if (simple)
         propose_normal(&cfg, kn, &ks, i, step, chain, theta0, theta1);
       else if (kn->kind == FMCMC_KERNEL_ADAPT)
         status = propose_adapt(&cfg, kn, &ks, i, step, chain, theta0, theta1);
@@ -737,6 +781,7 @@ int fmcmc_oracle_run(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_r
     }
   }
   free(logu);
+  free(cols_buf);
   return any_err ? FMCMC_ERR_CHAIN : FMCMC_OK;
 }
 
@@ -884,6 +929,12 @@ double fmcmc_oracle_canon_draw(int kind, uint64_t seed, uint32_t step, uint32_t 
                                double df) {
   if (kind == 0) return fmh_log_accept_u(seed, step, chain);
   if (kind == 1) return fmh_normal(seed, step, chain, j);
+  if (kind == 3) return fmh_unif(seed, step, chain, j);
+  if (kind == 4) return (double)fmh_scheme_index(seed, step, chain, j); /* j = pool size */
   return fmh_student_t(seed, step, chain, j, df);
+}
+/* test hook: sample.int(n, size, replace = TRUE) - 1 on the R stream */
+void fmcmc_oracle_r_sample_replace(r_rng* g, int n, int size, int32_t* out) {
+  for (int i = 0; i < size; i++) out[i] = (int32_t)r_unif_index(g, (double)n);
 }
 int fmcmc_oracle_cpu_has_fma(void) { return __builtin_cpu_supports("fma") ? 1 : 0; }

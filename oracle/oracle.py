@@ -23,8 +23,8 @@ RNG_PHILOX, RNG_RMT = 0, 1
 MATH_CANON, MATH_R = 0, 1
 
 FAM_LINREG, FAM_LOGISTIC, FAM_IID_NORMAL = 1, 2, 3
-K_NORMAL, K_NORMAL_REFLECTIVE, K_ADAPT, K_RAM = 1, 2, 3, 4
-SCHEME_JOINT, SCHEME_ORDERED = 0, 1
+K_NORMAL, K_NORMAL_REFLECTIVE, K_ADAPT, K_RAM, K_UNIF, K_UNIF_REFLECTIVE = 1, 2, 3, 4, 5, 6
+SCHEME_JOINT, SCHEME_ORDERED, SCHEME_RANDOM, SCHEME_EXPLICIT = 0, 1, 2, 3
 DBL_MAX = np.finfo(np.float64).max
 
 _dp = C.POINTER(C.c_double)
@@ -39,7 +39,9 @@ class CKernel(C.Structure):
     _fields_ = [("kind", C.c_int32), ("k", C.c_int32), ("mu", _dp), ("scale", _dp), ("lb", _dp),
                 ("ub", _dp), ("fixed", C.POINTER(C.c_uint8)), ("scheme", C.c_int32),
                 ("freq", C.c_int32), ("warmup", C.c_int32), ("bw", C.c_int32), ("until", C.c_double),
-                ("eps", C.c_double), ("arate", C.c_double), ("Sd", C.c_double)]
+                ("eps", C.c_double), ("arate", C.c_double), ("Sd", C.c_double),
+                ("scheme_seq", C.POINTER(C.c_int32)), ("scheme_len", C.c_int32), ("reserved", C.c_int32),
+                ("constr", _dp)]
 
 
 class CRun(C.Structure):
@@ -52,7 +54,8 @@ class CRun(C.Structure):
 class CState(C.Structure):
     _fields_ = [("theta0", _dp), ("f0", _dp), ("abs_iter", C.POINTER(C.c_int64)), ("Sigma", _dp),
                 ("mean_prev", _dp), ("have_mean", C.POINTER(C.c_int32)),
-                ("nerrors", C.POINTER(C.c_int32)), ("fresh", C.c_int32), ("reserved", C.c_int32)]
+                ("nerrors", C.POINTER(C.c_int32)), ("fresh", C.c_int32), ("reserved", C.c_int32),
+                ("scheme_cols", C.POINTER(C.c_int32))]
 
 
 class COut(C.Structure):
@@ -116,6 +119,7 @@ def lib():
         L.fmcmc_oracle_canon_draw.restype = C.c_double
         L.fmcmc_oracle_canon_draw.argtypes = [C.c_int, C.c_uint64, C.c_uint32, C.c_uint32,
                                               C.c_uint32, C.c_double]
+        L.fmcmc_oracle_r_sample_replace.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32)]
         L.fmcmc_oracle_cpu_has_fma.restype = C.c_int
         if not L.fmcmc_oracle_cpu_has_fma():
             raise RuntimeError("oracle needs a CPU with FMA (canonical math uses fma())")
@@ -162,6 +166,12 @@ class RRng:
         out = np.empty(n)
         lib().r_rnorm_vec(self._h, n, float(mean), float(sd), _p(out))
         return out
+
+    def sample_int(self, n, size):
+        """sample.int(n, size, replace = TRUE) (1-based, R >= 3.6 rejection sampling)."""
+        out = np.empty(size, dtype=np.int32)
+        lib().fmcmc_oracle_r_sample_replace(self._h, int(n), int(size), out.ctypes.data_as(C.POINTER(C.c_int32)))
+        return out + 1
 
     def rt(self, n, df):
         out = np.empty(n)
@@ -227,8 +237,16 @@ def _rec(x, k, name):
 class Kernel:
     def __init__(self, kind, k, mu=0.0, scale=1.0, lb=-DBL_MAX, ub=DBL_MAX, fixed=False,
                  scheme="joint", freq=1, warmup=None, bw=0, until=np.inf, eps=1e-4, arate=0.234,
-                 Sd=None):
+                 Sd=None, constr=None, min_=None, max_=None):
         self.kind, self.k = kind, k
+        if kind in (K_UNIF, K_UNIF_REFLECTIVE):   # R/kernel_unif.R: runif(k, min., max.) = min. + (max. - min.) * u
+            mn = _f64(_rec(-1.0 if min_ is None else min_, k, "min."))
+            mx = _f64(_rec(1.0 if max_ is None else max_, k, "max."))
+            if kind == K_UNIF_REFLECTIVE and np.isscalar(lb) and lb == -DBL_MAX and np.isscalar(ub) and ub == DBL_MAX:
+                lb, ub = mn, mx                       # defaults lb = min., ub = max. (R/kernel_unif.R:99-100)
+            if np.any(mx <= mn):
+                raise ValueError("-max.- cannot be <= than -min.-.")
+            mu, scale = mn, mx - mn
         self.mu = _f64(_rec(mu, k, "mu"))
         self.scale = _f64(_rec(scale, k, "scale"))
         lb = _f64(_rec(lb, k, "lb")).copy()
@@ -237,22 +255,39 @@ class Kernel:
         ub[np.isnan(ub)] = DBL_MAX
         self.lb, self.ub = lb, ub
         self.fixed = np.ascontiguousarray(_rec(fixed, k, "fixed").astype(np.uint8))
-        self.scheme = {"joint": SCHEME_JOINT, "ordered": SCHEME_ORDERED}[scheme]
+        self.scheme_seq = None
+        if not isinstance(scheme, str):               # explicit sequence of 1-based parameter positions (R/kernel.R:69-92)
+            seq = np.asarray(scheme, dtype=np.int64)
+            free = np.nonzero(self.fixed == 0)[0] + 1
+            if seq.size != free.size:
+                raise ValueError("When setting the update scheme, it should have the same length as the number of "
+                                 "variables that will not be fixed.")
+            if not np.all(np.isin(free, seq)):
+                raise ValueError("One or more variables was not included in the ordering sequence.")
+            self.scheme_seq = np.ascontiguousarray(seq - 1, dtype=np.int32)
+            self.scheme = SCHEME_EXPLICIT
+        else:
+            self.scheme = {"joint": SCHEME_JOINT, "ordered": SCHEME_ORDERED, "random": SCHEME_RANDOM}[scheme]
         self.freq, self.bw = int(freq), int(bw)
         if warmup is None:
             warmup = 500 if kind == K_ADAPT else 0
         self.warmup, self.until, self.eps, self.arate = int(warmup), float(until), float(eps), float(arate)
         self.kf = int((self.fixed == 0).sum())
         self.Sd = float(Sd) if Sd is not None else 5.76 / max(self.kf, 1)
-        if kind != K_NORMAL and np.any(self.ub <= self.lb):
+        if kind not in (K_NORMAL, K_UNIF) and np.any(self.ub <= self.lb):
             raise ValueError("-ub- cannot be <= than -lb-.")
+        free = np.nonzero(self.fixed == 0)[0]
+        self.constr = None if constr is None else _f64(np.asarray(constr, dtype=np.float64)[np.ix_(free, free)])
         if self.kf == 0:
             raise ValueError("The number of parameters to update, i.e. not fixed, cannot be zero.")
 
     def c(self):
         kk = CKernel(self.kind, self.k, _p(self.mu), _p(self.scale), _p(self.lb), _p(self.ub),
                      self.fixed.ctypes.data_as(C.POINTER(C.c_uint8)), self.scheme, self.freq,
-                     self.warmup, self.bw, self.until, self.eps, self.arate, self.Sd)
+                     self.warmup, self.bw, self.until, self.eps, self.arate, self.Sd,
+                     self.scheme_seq.ctypes.data_as(C.POINTER(C.c_int32)) if self.scheme_seq is not None else None,
+                     0 if self.scheme_seq is None else int(self.scheme_seq.size), 0,
+                     _p(self.constr) if self.constr is not None else None)
         return kk
 
 
@@ -268,6 +303,7 @@ class ChainState:
         self.mean_prev = np.zeros((Cn, kf))
         self.have_mean = np.zeros(Cn, dtype=np.int32)
         self.nerrors = np.zeros(Cn, dtype=np.int32)
+        self.scheme_cols = None   # [C][nsteps] int32 plan of scheme = "random" (set by run())
         self.fresh = 1
         self.step_base = 0
 
@@ -275,7 +311,8 @@ class ChainState:
         return CState(_p(self.theta0), _p(self.f0), self.abs_iter.ctypes.data_as(C.POINTER(C.c_int64)),
                       _p(self.Sigma), _p(self.mean_prev),
                       self.have_mean.ctypes.data_as(C.POINTER(C.c_int32)),
-                      self.nerrors.ctypes.data_as(C.POINTER(C.c_int32)), self.fresh, 0)
+                      self.nerrors.ctypes.data_as(C.POINTER(C.c_int32)), self.fresh, 0,
+                      self.scheme_cols.ctypes.data_as(C.POINTER(C.c_int32)) if self.scheme_cols is not None else None)
 
 
 def _as_initial(initial, nchains):
@@ -326,7 +363,17 @@ def run(model, kernel, initial=None, nsteps=1000, burnin=0, thin=1, seed=0, ncha
                status.ctypes.data_as(C.POINTER(C.c_int32)), sstep.ctypes.data_as(C.POINTER(C.c_int64)),
                _p(stheta))
     crun = CRun(Cn, nsteps, burnin, thin, seed, chain_base, state.step_base, 0, 0, None, None)
-    cm, ck, cs = model.c(), kernel.c(), state.c()
+    if kernel.scheme == SCHEME_RANDOM:
+        if state.scheme_cols is None:
+            state.scheme_cols = np.zeros((Cn, nsteps), dtype=np.int32)
+        elif state.scheme_cols.shape[1] < nsteps:
+            raise IndexError("subscript out of bounds")   # the plan has the rows of the kernel's first call only
+    cm, ck = model.c(), kernel.c()
+    full_plan = state.scheme_cols
+    if full_plan is not None and full_plan.shape[1] > nsteps:    # a shorter call (last bulk) reads the first rows of the plan
+        state.scheme_cols = np.ascontiguousarray(full_plan[:, :nsteps])
+    cs = state.c()
+    state.scheme_cols, cs._keep = full_plan, state.scheme_cols
     if rng_mode == RNG_RMT and rng is None:
         raise ValueError("RMT mode needs an RRng")
     rc = L.fmcmc_oracle_run(C.byref(cm), C.byref(ck), C.byref(crun), C.byref(cs), C.byref(out),

@@ -272,3 +272,22 @@ void r_rnorm_vec(r_rng* g, int64_t n, double mean, double sd, double* out) {
 void r_rt_vec(r_rng* g, int64_t n, double df, double* out) {
   for (int64_t i = 0; i < n; i++) out[i] = r_rt(g, df);
 }
+
+/* R_unif_index (src/main/RNG.c, sample.kind = "Rejection", the default since R 3.6.0): uniform integer in [0, dn)
+ * by rejection from the next power of two; rbits() consumes one unif_rand per 16 bits (and one even for 0 bits). */
+static double r_rbits(r_rng* g, int bits) {
+  int64_t v = 0;
+  for (int n = 0; n <= bits; n += 16) {
+    int v1 = (int)floor(r_unif_rand(g) * 65536);
+    v = 65536 * v + v1;
+  }
+  if (bits < 64) v &= (((int64_t)1 << bits) - 1);
+  return (double)v;
+}
+double r_unif_index(r_rng* g, double dn) {
+  if (dn <= 0) return 0.0;
+  int bits = (int)ceil(log2(dn));
+  double dv;
+  do { dv = r_rbits(g, bits); } while (dn <= dv);
+  return dv;
+}

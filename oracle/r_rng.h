@@ -16,6 +16,7 @@ double r_rgamma(r_rng* g, double a, double scale);
 double r_rchisq(r_rng* g, double df);
 double r_rt(r_rng* g, double df);
 double r_qnorm_std(double p);
+double r_unif_index(r_rng* g, double dn); /* sample.int(dn, 1) - 1, rejection sampling */
 void r_runif_vec(r_rng* g, int64_t n, double* out);
 void r_rnorm_vec(r_rng* g, int64_t n, double mean, double sd, double* out);
 void r_rt_vec(r_rng* g, int64_t n, double df, double* out);

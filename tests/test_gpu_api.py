@@ -248,3 +248,30 @@ def test_rng_stream_entry_point_equals_in_library_stream(E, O, kind):
     assert np.array_equal(_bits(a.logpost.cpu().numpy()), _bits(b.logpost.cpu().numpy()))
     ro = O.run(O.Model(O.FAM_LINREG, X, y), ok, init, nsteps=120, seed=11, chain_base=40)
     assert np.array_equal(_bits(b.samples.cpu().numpy()), _bits(ro.samples_cks))
+
+
+def test_mcmc_api_uniform_kernel_random_scheme_autostop(E, O, readme_data):
+    """kernel_unif_reflective + scheme = "random" through MCMC() with convergence_gelman: the update plan belongs to the
+    kernel object, so every bulk reuses it (R/kernel.R:106-113) -- chains, labels and R-hat history equal the oracle's."""
+    import fmcmc_amd as f
+    X, y = readme_data
+    init = np.tile([0, 0, O.r_sd(y)], (3, 1)) + 0.2 * np.random.default_rng(4).standard_normal((3, 3))
+    kw = dict(min_=-0.15, max_=0.15, lb=[-10, -10, 0.1], ub=10.0, scheme="random")
+    chk = f.convergence_gelman(100, threshold=1.10)
+    kern = f.kernel_unif_reflective(**kw)
+    ans = f.MCMC(init, f.gaussian_linreg(X, y), 3000, seed=5, nchains=3, kernel=kern, conv_checker=chk)
+    ro = O.mcmc_with_conv_checker(O.Model(O.FAM_LINREG, X, y), O.Kernel(O.K_UNIF_REFLECTIVE, 3, **kw), init, 3000, 3, 100,
+                                  threshold=1.10, seed=5)
+    assert [h[0] for h in chk.history] == [h[0] for h in ro.history] and len(ro.history) == 14
+    assert np.array_equal(_bits(ans.as_array()), _bits(ro.samples)) and list(ans.iters) == list(ro.iters)
+    assert np.array_equal(kern._state.scheme_cols.cpu().numpy()[:, 1:], ro.state.scheme_cols[:, 1:])
+    assert kern.k == 1 and repr(kern).startswith("<fmcmc_kernel kernel_unif_reflective")
+    # explicit sequence and kernel_ram(freq, constr) through the same front end
+    a2 = f.MCMC([0, 0, O.r_sd(y)], f.gaussian_linreg(X, y), 600, seed=2, kernel=f.kernel_normal(scale=0.05, scheme=[3, 1, 2]))
+    r2 = O.run(O.Model(O.FAM_LINREG, X, y), O.Kernel(O.K_NORMAL, 3, scale=0.05, scheme=[3, 1, 2]), [0, 0, O.r_sd(y)], nsteps=600, seed=2)
+    assert np.array_equal(_bits(a2.data), _bits(r2.samples[0]))
+    M = np.tril(np.ones((3, 3)))
+    M[2, 0] = 0.0
+    a3 = f.MCMC([0, 0, O.r_sd(y)], f.gaussian_linreg(X, y), 600, seed=2, kernel=f.kernel_ram(freq=2, constr=M))
+    r3 = O.run(O.Model(O.FAM_LINREG, X, y), O.Kernel(O.K_RAM, 3, freq=2, constr=M), [0, 0, O.r_sd(y)], nsteps=600, seed=2)
+    assert np.array_equal(_bits(a3.data), _bits(r3.samples[0]))

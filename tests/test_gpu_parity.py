@@ -35,7 +35,8 @@ def run_both(E, O, fam, X, y, kind, k, initial, nsteps, burnin=0, thin=1, seed=1
     ok = O.Kernel(kind, k, **kw)
     gm = E.DeviceModel(fam, X, y, intercept=intercept, guard=guard, prior_div=prior_div)
     gk = E.KernelSpec(kind, k, ok.mu, ok.scale, ok.lb, ok.ub, ok.fixed, scheme=ok.scheme, freq=ok.freq,
-                      warmup=ok.warmup, bw=ok.bw, until=ok.until, eps=ok.eps, arate=ok.arate, Sd=ok.Sd)
+                      warmup=ok.warmup, bw=ok.bw, until=ok.until, eps=ok.eps, arate=ok.arate, Sd=ok.Sd,
+                      scheme_seq=ok.scheme_seq, constr=ok.constr)
     initial = np.ascontiguousarray(initial, dtype=np.float64)
     ost = O.ChainState(initial, ok.kf)
     gst = E.ChainState(initial, ok.kf)
@@ -60,6 +61,8 @@ def run_both(E, O, fam, X, y, kind, k, initial, nsteps, burnin=0, thin=1, seed=1
             assert np.array_equal(gst.abs_iter.cpu().numpy(), ost.abs_iter)
             assert _bits_equal(gst.Sigma.cpu().numpy(), ost.Sigma), "Sigma"
             assert np.array_equal(gst.nerrors.cpu().numpy(), ost.nerrors)
+        if ok.scheme == O.SCHEME_RANDOM:
+            assert np.array_equal(gst.scheme_cols.cpu().numpy()[:, 1:nsteps], ost.scheme_cols[:, 1:nsteps]), "update plan"
         if kind == O.K_ADAPT:
             assert np.array_equal(gst.have_mean.cpu().numpy(), ost.have_mean)
             hm = ost.have_mean.astype(bool)
@@ -264,3 +267,97 @@ def test_mfma_equals_valu_kernels(E, O, monkeypatch):
     c, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=80, scale=0.02)
     assert _bits_equal(a.samples.cpu().numpy(), b.samples.cpu().numpy())
     assert _bits_equal(a.samples.cpu().numpy(), c.samples.cpu().numpy())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# uniform kernels, the remaining update schemes, kernel_ram freq / constr
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind_name,C,n,p", [("unif", 5, 777, 3), ("unif_reflective", 64, 2048, 3),
+                                              ("unif", 9, 10000, 3), ("unif_reflective", 6, 10000, 3),   # MFMA path
+                                              ("unif", 3, 1000, 1)])                                       # specialised path
+def test_uniform_kernels(E, O, kind_name, C, n, p):
+    """R/kernel_unif.R:42-170: all three code paths (streamed, MFMA, wave-specialised) draw the same U(0,1) stream."""
+    X, y = synth_linreg(n, p, 23 + n)
+    init = jitter_init([0.0] * (p + 1) + [float(np.std(y))], C, 6)
+    kind = O.K_UNIF if kind_name == "unif" else O.K_UNIF_REFLECTIVE
+    kw = dict(min_=-0.04, max_=0.05)
+    if kind == O.K_UNIF_REFLECTIVE:
+        kw.update(lb=[-10.0] * (p + 1) + [0.0], ub=[10.0] * (p + 1) + [float(np.std(y)) * 1.02])
+    rg, ro = run_both(E, O, O.FAM_LINREG, X, y, kind, p + 2, init, nsteps=260, calls=2, **kw)
+    inc = ro.draws_cks[:, :, 1:] - ro.samples_cks[:, :, :-1]
+    if kind == O.K_UNIF:
+        assert inc.min() >= -0.04 - 1e-12 and inc.max() <= 0.05 + 1e-12 and 0.05 < ro.accept_count.mean() / 259 < 0.999
+
+
+@pytest.mark.parametrize("scheme", ["ordered", "random", [3, 1, 4, 2, 5], "joint"])
+@pytest.mark.parametrize("kind_name", ["normal_reflective", "unif"])
+def test_update_schemes(E, O, scheme, kind_name):
+    """plan_update_sequence (R/kernel.R:66-133): one parameter per step for every scheme but "joint"; two calls, the
+    plan of scheme = "random" is the same in both (it belongs to the kernel object)."""
+    X, y = synth_linreg(1200, 3, 41)
+    init = jitter_init([0, 0, 0, 0, 4.0], 11, 2)
+    if kind_name == "unif":
+        kind, kw = O.K_UNIF, dict(min_=-0.1, max_=0.12)
+    else:
+        kind, kw = O.K_NORMAL_REFLECTIVE, dict(scale=0.06, lb=[-9, -9, -9, -9, 0.5], ub=9.0)
+    rg, ro = run_both(E, O, O.FAM_LINREG, X, y, kind, 5, init, nsteps=200, calls=2, chain_base=7, scheme=scheme, **kw)
+    moved = (ro.draws_cks[:, :, 1:] != ro.samples_cks[:, :, :-1]).sum(axis=1)      # parameters proposed per step
+    assert np.all(moved <= (5 if scheme == "joint" else 1))
+    if isinstance(scheme, list):   # step i updates scheme[(i - 1) mod 5]
+        for i in range(2, 40):
+            col = scheme[(i - 1) % 5] - 1
+            others = [j for j in range(5) if j != col]
+            assert np.all(ro.draws_cks[:, others, i - 1] == ro.samples_cks[:, others, i - 2])
+
+
+def test_update_schemes_with_fixed_parameters(E, O):
+    X, y = synth_linreg(900, 3, 5)
+    init = jitter_init([0, 0, 0, 0, 4.0], 4, 3)
+    fixed = [False, True, False, True, False]
+    for scheme in ("ordered", "random", [5, 1, 3]):
+        rg, ro = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=150, scale=0.05, fixed=fixed, scheme=scheme)
+        assert np.all(ro.samples_cks[:, [1, 3], :] == init[:, [1, 3], None])
+    # a single free parameter at position j: sample(j, nsteps, TRUE) draws from 1:j in R (R/kernel.R:110)
+    rg, ro = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=150, scale=0.05,
+                      fixed=[True, True, False, True, True], scheme="random")
+    assert set(np.unique(rg.samples.cpu().numpy()[0, 3])) == {init[0, 3]}            # positions > j never move
+
+
+def test_random_scheme_fed_replay_of_the_R_plan(E, O):
+    """FED mode: logu, z and the update plan all come from the restated R generator in R's own order; the GPU then equals
+    the oracle run on that R stream with canonical arithmetic, bit for bit."""
+    import torch
+    X, y = synth_linreg(600, 1, 8)
+    init = np.array([[0.0, 0.0, 2.0]] * 2)
+    om = O.Model(O.FAM_LINREG, X, y)
+    ok = O.Kernel(O.K_NORMAL, 3, scale=0.1, scheme="random")
+    ost = O.ChainState(init, 3)
+    ro = O.run(om, ok, nsteps=300, seed=0, state=ost, rng_mode=O.RNG_RMT, math_mode=O.MATH_CANON, rng=O.RRng(77))
+    g = O.RRng(77)                         # replay: per chain runif(nsteps), sample(), then one rnorm per step
+    logu, z, cols = np.zeros((2, 300)), np.zeros((2, 300, 1)), np.zeros((2, 300), dtype=np.int32)
+    for c in range(2):
+        logu[c] = np.log(g.runif(300))
+        cols[c] = g.sample_int(3, 300) - 1
+        z[c, 1:, 0] = g.rnorm(299)
+    assert np.array_equal(cols, ost.scheme_cols)
+    gm = E.DeviceModel(O.FAM_LINREG, X, y)
+    gk = E.KernelSpec(O.K_NORMAL, 3, ok.mu, ok.scale, ok.lb, ok.ub, ok.fixed, scheme=ok.scheme)
+    gst = E.ChainState(init, 3)
+    gst.scheme_cols = torch.as_tensor(cols).cuda()
+    rg = E.sweep(gm, gk, gst, 300, fed_logu=torch.as_tensor(logu).cuda(), fed_z=torch.as_tensor(z).cuda())
+    assert _bits_equal(rg.samples.cpu().numpy(), ro.samples_cks) and _bits_equal(rg.logpost.cpu().numpy(), ro.logpost)
+
+
+@pytest.mark.parametrize("C,n,p,freq,constr", [(6, 900, 3, 3, None), (5, 10000, 3, 2, None), (4, 900, 3, 1, "band"),
+                                                (3, 10000, 3, 4, "band")])
+def test_ram_freq_and_constr(E, O, C, n, p, freq, constr):
+    """R/kernel_ram.R:129 (`!(env$i %% freq)`) and :149-150 (constr mask), streamed and wave-specialised kernels."""
+    X, y = synth_linreg(n, p, 77)
+    k = p + 2
+    init = jitter_init([0.0] * (p + 1) + [float(np.std(y))], C, 9)
+    M = None
+    if constr == "band":
+        M = (np.abs(np.subtract.outer(np.arange(k), np.arange(k))) <= 1).astype(float)
+    rg, ro = run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, k, init, nsteps=220, calls=2, freq=freq, constr=M)
+    if M is not None:
+        assert np.all(ro.state.Sigma[:, M == 0] == 0) and np.any(ro.state.Sigma[:, 1, 0] != 0)

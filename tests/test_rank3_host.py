@@ -1,0 +1,222 @@
+"""CPU tests of the SURVEY section 8(f) rank-3 rows: uniform kernels (R/kernel_unif.R), the update schemes of
+plan_update_sequence (R/kernel.R:66-133) and kernel_ram's freq / constr (R/kernel_ram.R:129,149-150) -- oracle
+restatement, host-side constructors and C-ABI validation.  The GPU parity of the same features is in
+test_gpu_parity.py."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import synth_linreg
+
+
+@pytest.fixture(scope="module")
+def abi():
+    from fmcmc_amd import _abi, build
+    if build.needs_build():
+        build.build()
+    _abi.lib()
+    return _abi
+
+
+def test_r_sample_known_answers(O):
+    """sample.int(n, size, TRUE) under R >= 3.6 ("Rejection" sampling): outputs printed by R for these seeds."""
+    assert list(O.RRng(123).sample_int(10, 5)) == [3, 3, 10, 2, 6]
+    assert list(O.RRng(42).sample_int(10, 10)) == [1, 5, 1, 9, 10, 4, 2, 10, 1, 8]
+    assert list(O.RRng(1).sample_int(5, 10)) == [1, 4, 1, 2, 5, 3, 2, 3, 3, 1]
+    g = O.RRng(9)                                  # n = 1 still consumes one uniform per draw (rbits(0))
+    assert list(g.sample_int(1, 4)) == [1, 1, 1, 1] and g.count == 4
+
+
+def _iid(O, n=50, seed=3):
+    rng = np.random.default_rng(seed)
+    return O.Model(O.FAM_IID_NORMAL, None, rng.normal(1.0, 2.0, n))
+
+
+def test_unif_kernel_replays_R_draw_order(O):
+    """R/kernel_unif.R:70-76 inside R/mcmc.R:720-838: runif(nsteps) first, then k uniforms per step,
+    theta1 = theta0 + (min. + (max. - min.) * u)."""
+    m = _iid(O)
+    kn = O.Kernel(O.K_UNIF, 2, min_=[-0.3, -0.2], max_=[0.4, 0.1])
+    r = O.run(m, kn, initial=[1.0, 2.0], nsteps=60, rng_mode=O.RNG_RMT, math_mode=O.MATH_R, rng=O.RRng(5))
+    g = O.RRng(5)
+    logu = np.log(g.runif(60))
+    th0 = np.array([1.0, 2.0]); f0 = m.logpost(th0, O.MATH_R)
+    for i in range(2, 61):
+        u = g.runif(2)
+        th1 = th0 + (kn.mu + kn.scale * u)
+        assert np.array_equal(r.draws[0, i - 1], th1)
+        f1 = m.logpost(th1, O.MATH_R)
+        if logu[i - 1] < f1 - f0:
+            th0, f0 = th1, f1
+        assert np.array_equal(r.samples[0, i - 1], th0)
+
+
+def test_unif_kernels_reference_properties(O):
+    """inst/tinytest/test-kernel_unif.R: increments stay in [min., max.], fixed parameters never move, reflective
+    proposals stay inside [lb, ub], "ordered" alternates the free parameters."""
+    X, y = synth_linreg(300, 2, 1)
+    m = O.Model(O.FAM_LINREG, X, y)
+    lb, ub = -1.0, 0.5
+    kn = O.Kernel(O.K_UNIF, 4, min_=lb, max_=ub, fixed=[False, True, False, False])
+    r = O.run(m, kn, initial=[0, 0, 0, 3.0], nsteps=3000, seed=3)
+    inc = r.draws[0, 1:] - r.samples[0, :-1]
+    assert np.all(inc[:, 1] == 0) and np.all(inc[:, [0, 2, 3]] >= lb) and np.all(inc[:, [0, 2, 3]] <= ub)
+    assert abs(inc[:, [0, 2, 3]].mean() - (lb + ub) / 2) < 0.025
+    kr = O.Kernel(O.K_UNIF_REFLECTIVE, 4, min_=lb, max_=ub, lb=[-0.5, -0.5, -0.5, 2.5], ub=[0.25, 0.25, 0.25, 3.5])
+    r = O.run(m, kr, initial=[0, 0, 0, 3.0], nsteps=3000, seed=3)
+    assert np.all(r.draws[0, 1:] >= kr.lb) and np.all(r.draws[0, 1:] <= kr.ub)
+    ko = O.Kernel(O.K_UNIF, 4, min_=lb, max_=ub, fixed=[False, True, False, True], scheme="ordered")
+    r = O.run(m, ko, initial=[0, 0, 0, 3.0], nsteps=400, seed=3)
+    inc = r.draws[0, 1:] - r.samples[0, :-1]            # row i - 2 = loop step i: which(!fixed)[(i - 1) mod 2]
+    steps = np.arange(2, 401)
+    assert np.all(inc[(steps - 1) % 2 == 0][:, [1, 2, 3]] == 0) and np.all(inc[(steps - 1) % 2 == 1][:, [0, 1, 3]] == 0)
+    with pytest.raises(ValueError, match="-max.- cannot be <= than -min.-."):
+        O.Kernel(O.K_UNIF, 2, min_=1.0, max_=1.0)
+    kd = O.Kernel(O.K_UNIF_REFLECTIVE, 2, min_=-2.0, max_=3.0)   # lb / ub default to min. / max.
+    assert np.all(kd.lb == -2.0) and np.all(kd.ub == 3.0)
+
+
+def test_random_scheme_is_R_sample_and_belongs_to_the_kernel(O):
+    """R/kernel.R:106-113: sample(which(!fixed), nsteps, TRUE) drawn at the first proposal, reused by later calls."""
+    m = _iid(O)
+    kn = O.Kernel(O.K_NORMAL, 2, scale=0.3, scheme="random")
+    st = O.ChainState(np.array([[1.0, 2.0]] * 2), 2)
+    g = O.RRng(11)
+    r1 = O.run(m, kn, nsteps=50, state=st, rng_mode=O.RNG_RMT, math_mode=O.MATH_R, rng=g)
+    h = O.RRng(11)
+    for c in range(2):
+        h.runif(50)
+        assert np.array_equal(st.scheme_cols[c], h.sample_int(2, 50) - 1)
+        h.rnorm(49)
+    assert h.count == g.count
+    plan = st.scheme_cols.copy()
+    n0 = g.count
+    r2 = O.run(m, kn, nsteps=50, state=st, rng_mode=O.RNG_RMT, math_mode=O.MATH_R, rng=g)
+    assert np.array_equal(st.scheme_cols, plan) and g.count - n0 == 2 * (50 + 2 * 49)     # no second sample(); inversion rnorm takes two uniforms
+    for r in (r1, r2):
+        inc = r.draws[:, 1:] != r.samples[:, :-1]
+        assert np.array_equal(np.argmax(inc, axis=2), plan[:, 1:]) and np.all(inc.sum(axis=2) == 1)
+    O.run(m, kn, nsteps=30, state=st, rng_mode=O.RNG_RMT, math_mode=O.MATH_R, rng=g)         # shorter last bulk
+    with pytest.raises(IndexError, match="subscript out of bounds"):
+        O.run(m, kn, nsteps=51, state=st, rng_mode=O.RNG_RMT, math_mode=O.MATH_R, rng=g)
+
+
+def test_random_scheme_canonical_plan(O):
+    """PHILOX mode: column = pool[(word * npool) >> 32] of counter (row i, global chain, 0, SCHEME); the same in every
+    call and for every sharding; a single free parameter at position j samples 1:j like R does."""
+    m = _iid(O)
+    kn = O.Kernel(O.K_NORMAL_REFLECTIVE, 2, scale=0.3, lb=[-50, 0.1], ub=50, scheme="random")
+    st = O.ChainState(np.array([[1.0, 2.0]] * 3), 2)
+    O.run(m, kn, nsteps=40, seed=99, chain_base=5, state=st)
+    want = np.array([[O.lib().fmcmc_oracle_canon_draw(4, 99, i, 5 + c, 2, 0.0) for i in range(1, 41)] for c in range(3)])
+    assert np.array_equal(st.scheme_cols, want.astype(np.int32))
+    plan = st.scheme_cols.copy()
+    O.run(m, kn, nsteps=40, seed=99, chain_base=5, state=st)
+    assert np.array_equal(st.scheme_cols, plan)
+    st1 = O.ChainState(np.array([[1.0, 2.0]]), 2)
+    O.run(m, kn, nsteps=40, seed=99, chain_base=7, state=st1)
+    assert np.array_equal(st1.scheme_cols[0], plan[2])
+    k1 = O.Kernel(O.K_NORMAL, 2, scale=0.3, fixed=[True, False], scheme="random")
+    s1 = O.ChainState(np.array([[1.0, 2.0]]), 1)
+    O.run(m, k1, nsteps=200, seed=1, state=s1)
+    assert set(np.unique(s1.scheme_cols[0])) == {0, 1}            # sample(2, ...) == sample(1:2, ...)
+
+
+def test_explicit_scheme(O):
+    """R/kernel.R:69-92: scheme = c(2, 1, 3) recycled along the rows; validation texts."""
+    X, y = synth_linreg(200, 1, 2)
+    m = O.Model(O.FAM_LINREG, X, y)
+    kn = O.Kernel(O.K_NORMAL, 3, scale=0.1, scheme=[2, 1, 3])
+    r = O.run(m, kn, initial=[0, 0, 2.0], nsteps=100, seed=4)
+    inc = r.draws[0, 1:] != r.samples[0, :-1]
+    want = np.array([[2, 1, 3][(i - 1) % 3] - 1 for i in range(2, 101)])
+    assert np.array_equal(np.argmax(inc, axis=1), want) and np.all(inc.sum(axis=1) == 1)
+    with pytest.raises(ValueError, match="same length"):
+        O.Kernel(O.K_NORMAL, 3, scheme=[1, 2])
+    with pytest.raises(ValueError, match="not included in the ordering sequence"):
+        O.Kernel(O.K_NORMAL, 3, scheme=[1, 1, 2])
+
+
+def test_ram_freq_and_constr_oracle(O):
+    X, y = synth_linreg(300, 2, 6)
+    m = O.Model(O.FAM_LINREG, X, y)
+    init = np.array([[0, 0, 0, 3.0]])
+    base = O.run(m, O.Kernel(O.K_RAM, 4), initial=init, nsteps=120, seed=8)
+    ones = O.run(m, O.Kernel(O.K_RAM, 4, constr=np.ones((4, 4))), initial=init, nsteps=120, seed=8)
+    assert np.array_equal(base.samples, ones.samples) and np.array_equal(base.state.Sigma, ones.state.Sigma)
+    never = O.run(m, O.Kernel(O.K_RAM, 4, freq=1000), initial=init, nsteps=120, seed=8)    # i %% freq never 0
+    assert np.array_equal(never.state.Sigma[0], 1e-4 * np.eye(4)) and never.state.abs_iter[0] == 119
+    diag = O.run(m, O.Kernel(O.K_RAM, 4, constr=np.eye(4)), initial=init, nsteps=120, seed=8)
+    S = diag.state.Sigma[0]
+    assert np.all(S[~np.eye(4, dtype=bool)] == 0) and np.all(np.diag(S) > 0)
+    fx = O.run(m, O.Kernel(O.K_RAM, 4, fixed=[False, True, False, False], constr=np.eye(4)), initial=init, nsteps=60, seed=8)
+    assert fx.state.Sigma.shape == (1, 3, 3)                  # constr[which., which.]
+    for math, rng in ((O.MATH_R, O.RRng(2)),):                # R arithmetic: freq gates the same steps
+        r = O.run(m, O.Kernel(O.K_RAM, 4, freq=1000), initial=init, nsteps=50, rng_mode=O.RNG_RMT, math_mode=math, rng=rng)
+        assert np.array_equal(r.state.Sigma[0], 1e-4 * np.eye(4))
+
+
+def test_host_kernel_constructors(monkeypatch):
+    import fmcmc_amd as f
+    from fmcmc_amd import _abi as abi
+    k = f.kernel_unif(min_=[-1, -2, -3], max_=[1, 2, 4], fixed=[False, True, False], scheme="ordered")
+    k._init(3)
+    assert k.k == 1 and np.array_equal(k.mu, [-1, -2, -3]) and np.array_equal(k.scale, [2, 4, 7]) and k._scheme_id == abi.SCHEME_ORDERED
+    k = f.kernel_unif_reflective(min_=-1.0, max_=0.5)
+    k._init(2)
+    assert np.all(k.lb == -1.0) and np.all(k.ub == 0.5) and k.k == 2
+    with pytest.raises(ValueError, match="-max.- cannot be <= than -min.-."):
+        f.kernel_unif(min_=1.0, max_=0.0)._init(2)
+    with pytest.raises(ValueError, match="-ub- cannot be <= than -lb-."):
+        f.kernel_unif_reflective(lb=1.0, ub=1.0)._init(2)
+    k = f.kernel_normal(scheme=[2, 1, 3]); k._init(3)
+    assert k._scheme_id == abi.SCHEME_EXPLICIT and list(k._scheme_seq) == [1, 0, 2] and k.k == 1
+    k = f.kernel_normal(scheme="random"); k._init(3)
+    assert k._scheme_id == abi.SCHEME_RANDOM and k.k == 1
+    with pytest.raises(ValueError, match="same length"):
+        f.kernel_normal(scheme=[1, 2])._init(3)
+    with pytest.raises(ValueError, match="not included in the ordering sequence"):
+        f.kernel_normal(scheme=[1, 3], fixed=[False, False, True])._init(3)
+    with pytest.raises(ValueError, match="-scheme- update must be"):
+        f.kernel_normal(scheme="zigzag")._init(3)
+    assert f.kernel_ram(freq=3, constr=np.eye(2)).freq == 3
+    with pytest.raises(ValueError, match="freq"):
+        f.kernel_ram(freq=0)
+
+
+def test_abi_validation_of_the_new_rows(abi):
+    """fmcmc_validate (host pointers, no GPU): the reference's stop() texts for the new arguments."""
+    L = abi.lib()
+    y = np.zeros(10); X = np.zeros((1, 10))
+    m = abi.Model(abi.FAM_GAUSSIAN_LINREG, 1, 10, X.ctypes.data, y.ctypes.data, 1, 1, 0.0)
+    run = abi.Run(2, 100, 0, 1, 0, 0, 0, abi.RNG_PHILOX, 0, None, None)
+    mu, lb, ub = np.zeros(3), np.full(3, -1e300), np.full(3, 1e300)
+    fixed = np.zeros(3, dtype=np.uint8)
+
+    def kern(kind, scale, scheme=0, seq=None, freq=1):
+        sc = np.asarray(scale, dtype=np.float64)
+        sq = None if seq is None else np.asarray(seq, dtype=np.int32)
+        k = abi.Kernel(kind, 3, mu.ctypes.data, sc.ctypes.data, lb.ctypes.data, ub.ctypes.data, fixed.ctypes.data, scheme,
+                       freq, 0, 0, float("inf"), 1e-4, 0.234, 0.0, sq.ctypes.data if sq is not None else None,
+                       0 if sq is None else sq.size, 0, None)
+        k._keep = (sc, sq)
+        return k
+
+    def check(k, code, text=None):
+        rc = L.fmcmc_validate(C.byref(m), C.byref(k), C.byref(run))
+        assert rc == code, abi.last_error()
+        if text:
+            assert text in abi.last_error()
+
+    check(kern(abi.KERNEL_UNIF, [1, 1, 1]), abi.OK)
+    check(kern(abi.KERNEL_UNIF, [1, 0, 1]), abi.ERR_ARG, "-max.- cannot be <= than -min.-.")
+    check(kern(abi.KERNEL_UNIF_REFLECTIVE, [1, 1, 1], scheme=abi.SCHEME_RANDOM), abi.OK)
+    check(kern(abi.KERNEL_NORMAL, [1, 1, 1], scheme=7), abi.ERR_ARG, "-scheme- update must be")
+    check(kern(abi.KERNEL_NORMAL, [1, 1, 1], scheme=abi.SCHEME_EXPLICIT, seq=[2, 0, 1]), abi.OK)
+    check(kern(abi.KERNEL_NORMAL, [1, 1, 1], scheme=abi.SCHEME_EXPLICIT, seq=[2, 0]), abi.ERR_ARG, "same length")
+    check(kern(abi.KERNEL_NORMAL, [1, 1, 1], scheme=abi.SCHEME_EXPLICIT, seq=[2, 2, 1]), abi.ERR_ARG, "not included")
+    check(kern(abi.KERNEL_RAM, [1, 1, 1], freq=5), abi.OK)
+    check(kern(abi.KERNEL_RAM, [1, 1, 1], freq=0), abi.ERR_ARG, "freq")
+    check(kern(abi.KERNEL_ADAPT, [1, 1, 1], freq=2), abi.ERR_UNSUPPORTED)
+    check(kern(9, [1, 1, 1]), abi.ERR_ARG, "unknown kernel kind")
