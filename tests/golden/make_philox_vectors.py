@@ -22,6 +22,10 @@ def cases():
         "adapt_linreg": dict(kind="adapt", n=600, p=2, C=2, nsteps=160, seed=8, data_seed=103, warmup=40),
         "ram_linreg": dict(kind="ram", n=600, p=2, C=2, nsteps=120, seed=9, data_seed=104),
         "headline_shape": dict(kind="normal", n=10000, p=3, C=2, nsteps=40, seed=1215, data_seed=20260102, scale=0.02),
+        "unif_random_scheme": dict(kind="unif_reflective", n=500, p=2, C=3, nsteps=140, seed=21, data_seed=105, scheme="random"),
+        "normal_explicit_scheme": dict(kind="normal", n=500, p=2, C=2, nsteps=140, seed=22, data_seed=106, scale=0.08,
+                                       scheme=[4, 2, 1, 3]),
+        "ram_freq_constr": dict(kind="ram", n=500, p=2, C=2, nsteps=140, seed=23, data_seed=107, freq=3, constr="tridiag"),
     }
 
 
@@ -39,7 +43,13 @@ def make_inputs(spec):
 def kernel_kwargs(O, spec):
     k = spec["p"] + 2
     if spec["kind"] == "normal":
-        return O.K_NORMAL, dict(scale=spec["scale"])
+        return O.K_NORMAL, dict(scale=spec["scale"], scheme=spec.get("scheme", "joint"))
+    if spec["kind"] == "unif_reflective":
+        return O.K_UNIF_REFLECTIVE, dict(min_=-0.1, max_=0.15, lb=[-9.0] * (k - 1) + [0.2], ub=9.0,
+                                         scheme=spec.get("scheme", "joint"))
+    if spec["kind"] == "ram" and "constr" in spec:
+        M = (np.abs(np.subtract.outer(np.arange(k), np.arange(k))) <= 1).astype(float)
+        return O.K_RAM, dict(freq=spec["freq"], constr=M)
     if spec["kind"] == "reflective":
         return O.K_NORMAL_REFLECTIVE, dict(scale=spec["scale"], lb=[-5.0] * (k - 1) + [0.1], ub=[5.0] * k)
     if spec["kind"] == "adapt":

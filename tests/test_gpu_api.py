@@ -89,7 +89,8 @@ def test_committed_golden_vectors(E, O):
         X, y, init = make_inputs(spec)
         kind, kw = kernel_kwargs(O, spec)
         ok = O.Kernel(kind, spec["p"] + 2, **kw)
-        gk = E.KernelSpec(kind, ok.k, ok.mu, ok.scale, ok.lb, ok.ub, ok.fixed, warmup=ok.warmup, eps=ok.eps, arate=ok.arate)
+        gk = E.KernelSpec(kind, ok.k, ok.mu, ok.scale, ok.lb, ok.ub, ok.fixed, scheme=ok.scheme, freq=ok.freq, warmup=ok.warmup,
+                          eps=ok.eps, arate=ok.arate, scheme_seq=ok.scheme_seq, constr=ok.constr)
         st = E.ChainState(init, ok.kf)
         r = E.sweep(E.DeviceModel(abi.FAM_GAUSSIAN_LINREG, X, y), gk, st, spec["nsteps"], seed=spec["seed"])
         torch.cuda.synchronize()
