@@ -1153,9 +1153,17 @@ constexpr int MF_TCS = 8 * PIPE_TRS + 2;
 
 // DBG is a TEMPLATE parameter on purpose: the MFMA loop is sensitive to every live register (fewer free VGPRs = fewer
 // MFMA results in flight before their dependent fma); stamp code that is merely disabled at run time cost 13 %.
-template <int KIND, bool DBG>
+// Shapes: NG groups of K = 4 carry up to 4*NG - 1 covariates plus y (unused k-slots are zero: fma(0, 0, acc) == acc
+// exactly), the 80 operand registers of a lane hold 20 / NG observation slots, i.e. NG = 1: p <= 3, n <= 10240;
+// NG = 2: p <= 7, n <= 5120.  The number of observation slots NS = ceil(n / 512) is a TEMPLATE parameter: with a run-time
+// count every batch of MFMAs becomes a basic block, the scheduler can no longer overlap the FMAs of one batch with the
+// MFMAs of the next, and the step is 22 % slower (measured).  Only the last slot holds padding and pays for masks.
+template <int KIND, int NG, int NS, bool DBG>
 __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
-  constexpr int CW = 4, OPT = 20;
+  constexpr int CW = 4;
+  constexpr int MB = 8;             // (slot, lane group) pairs per batch = 2 observation slots
+  constexpr int TN = NS * 4;        // pairs held per lane and group (NG * TN <= MF_NMF registers)
+  static_assert(NG * TN <= MF_NMF, "operand registers");
   extern __shared__ double smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1170,24 +1178,33 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
 
   // ---- A operand: feature kf_ = lane / 16 of observation (64 w + 16 g + lane % 16) + 512 s, for t = 4 s + g
   const int feat = lane >> 4, o16 = lane & 15;
-  double areg[MF_NMF];
+  const int P = A.p;
+  double areg[NG][TN];
 #pragma unroll
-  for (int t = 0; t < MF_NMF; t++) {
-    const int sl = t >> 2, g = t & 3;
-    const long long i = (long long)(64 * wave + 16 * g + o16) + (long long)NT * sl;
-    const bool valid = i < A.n;
-    areg[t] = valid ? (feat < 3 ? A.X[(long long)feat * A.n + i] : A.y[i]) : 0.0;
+  for (int q = 0; q < NG; q++) {
+    const int f = 4 * q + feat;   // column of [x_1 .. x_P, y, 0 ..] this lane feeds as operand A of group q
+#pragma unroll
+    for (int t = 0; t < TN; t++) {
+      const int sl = t >> 2, g = t & 3;
+      const long long i = (long long)(64 * wave + 16 * g + o16) + (long long)NT * sl;
+      double a = 0.0;
+      if (i < A.n) {
+        if (f < P) a = A.X[(long long)f * A.n + i];
+        else if (f == P) a = A.y[i];
+      }
+      areg[q][t] = a;
+    }
   }
   // result lane L: chain j = L % 4, canonical lane 64 w + 16 g + 4*((L/4)%4) + L/16
   const int jch = lane & 3;
   const int cl_in_g = 4 * ((lane >> 2) & 3) + (lane >> 4);
-  double wm[4];          // validity of the last slot per lane group (earlier slots are full: n > 512*19)
+  unsigned vbits = 0;    // validity of this lane's 4 results in the LAST slot (all earlier slots are full)
   int trs[4];            // transposed tile slot of this lane's canonical lane, per group
 #pragma unroll
   for (int g = 0; g < 4; g++) {
     const int l = 64 * wave + 16 * g + cl_in_g;
-    wm[g] = ((long long)l + (long long)NT * (OPT - 1) < A.n) ? 1.0 : 0.0;
     trs[g] = (l & 7) * PIPE_TRS + (l >> 3);
+    if ((long long)l + (long long)NT * (NS - 1) < A.n) vbits |= 1u << g;
   }
   if (tid < k) {
     s_par[0 * PIPE_KMAX + tid] = A.mu[tid];
@@ -1257,22 +1274,41 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
     // ================= evaluation of version v of all 4 chains =================
     {
       const double* tj = s_th1 + jch * PIPE_KMAX;
-      const double bop = (feat < 3) ? tj[ic + feat] : -1.0;   // B[k][blk][j]
+      double bop[NG];                                            // B[k][blk][j] of group q
+#pragma unroll
+      for (int q = 0; q < NG; q++) {
+        const int f = 4 * q + feat;
+        bop[q] = (f < P) ? tj[ic + f] : (f == P ? -1.0 : 0.0);
+      }
       const double cop = ic ? tj[0] : 0.0;                      // C = intercept of chain j
       double acc[4] = {0.0, 0.0, 0.0, 0.0};
-      // batches of MB independent MFMAs followed by their MB dependent FMAs: the result latency of one MFMA is
+      // batches of MB independent MFMA chains followed by their MB dependent FMAs: the result latency of one MFMA is
       // covered by issuing the next ones, and the batch shape (not the allocator's leftovers) bounds the live results
-      constexpr int MB = 8;
 #pragma unroll
-      for (int t0 = 0; t0 < MF_NMF; t0 += MB) {
-        double d[MB];
+      for (int t0 = 0; t0 < TN; t0 += MB) {
+        {
+          constexpr int LAST = TN - 4;             // first pair of the last slot
+          const int nu = (TN - t0 < MB) ? TN - t0 : MB;
+          double d[MB];
+          // Only the last slot has padding.  A padded observation has A = 0 in every group, so its result is the C
+          // operand: feeding 0 instead of the intercept there makes -r == 0 exactly, and the accumulation below is the
+          // same straight-line code for every batch (masking the RESULTS put selects in front of the last FMAs).
 #pragma unroll
-        for (int u = 0; u < MB; u++) d[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(areg[t0 + u], bop, cop, 0, 0, 0);   // -r
+          for (int u = 0; u < MB; u++)
+            if (u < nu) {
+              const int t = t0 + u;
+              const double cm = (t >= LAST) ? (((vbits >> (t - LAST)) & 1u) ? cop : 0.0) : cop;
+              d[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(areg[0][t], bop[0], cm, 0, 0, 0);
+            }
 #pragma unroll
-        for (int u = 0; u < MB; u++) {
-          const int t = t0 + u;
-          if (t >= MF_NMF - 4) acc[t & 3] = fmh_fma(d[u] * wm[t & 3], d[u], acc[t & 3]);
-          else acc[t & 3] = fmh_fma(d[u], d[u], acc[t & 3]);
+          for (int q = 1; q < NG; q++)
+#pragma unroll
+            for (int u = 0; u < MB; u++)
+              if (u < nu) d[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(areg[q][t0 + u], bop[q], d[u], 0, 0, 0);
+          // d = -r of 16 observations x 4 chains per pair
+#pragma unroll
+          for (int u = 0; u < MB; u++)
+            if (u < nu) acc[u & 3] = fmh_fma(d[u], d[u], acc[u & 3]);
         }
       }
 #pragma unroll
@@ -2383,7 +2419,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
   // software-pipelined fast path: normal kernels, joint scheme, k <= 16, linreg data in registers
   const char* nopipe = getenv("FMCMC_AMD_NO_PIPE");
   const char* nospec0 = getenv("FMCMC_AMD_NO_SPEC");
-  int pipe_opt = 0;
+  int pipe_opt = 0, mfma_ng = 0;
   if (!(force && force[0] == '1') && !(nopipe && nopipe[0] == '1') && m->family == FMCMC_FAM_GAUSSIAN_LINREG &&
       (kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE ||
        ((kn->kind == FMCMC_KERNEL_ADAPT || (kn->kind == FMCMC_KERNEL_RAM && !ram_bounded && !kn->constr)) && !(nospec0 && nospec0[0] == '1'))) &&
@@ -2392,9 +2428,17 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
       (unsigned long long)run->nchains * (unsigned long long)run->nsteps * (unsigned long long)A.kz * 8ull < (1ull << 32)) {
     if (m->p == 3 && m->n > (long long)NT * 19 && m->n <= (long long)NT * 20) pipe_opt = 20;
     if (m->p == 1 && m->n > (long long)NT * 1 && m->n <= (long long)NT * 2) pipe_opt = 2;
+    // fp64-MFMA evaluation: general in n and p up to what 80 operand registers per lane hold (normal / uniform kernels)
+    const char* usemf0 = getenv("FMCMC_AMD_MFMA");
+    if (!(usemf0 && usemf0[0] == '0') && kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE && kn->scheme == FMCMC_SCHEME_JOINT) {
+      if (m->p <= 3 && m->n <= (long long)NT * 20) mfma_ng = 1;
+      else if (m->p <= 7 && m->n <= (long long)NT * 10) mfma_ng = 2;
+      // the wave-specialised VALU kernel overlaps owners and evaluation; at its small shape that beats the MFMAs
+      if (pipe_opt == 2 && !(nospec0 && nospec0[0] == '1')) mfma_ng = 0;
+    }
   }
-  if (pipe_opt) {
-    const size_t plds = pipe_lds_bytes(pipe_opt);
+  if (pipe_opt || mfma_ng) {
+    const size_t plds = pipe_opt ? pipe_lds_bytes(pipe_opt) : 0;
     const long long pblk = (run->nchains + 3) / 4;
     double* ws = nullptr;
     if (A.rng_mode == FMCMC_RNG_PHILOX) {
@@ -2419,17 +2463,91 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
         hipLaunchKernelGGL((mh_sweep_pipe<PV, OV, KV>), dim3((unsigned)pblk), dim3(NT), plds, stream, A); \
     } while (0)
     const char* nospec = getenv("FMCMC_AMD_NO_SPEC");
-    const char* usemf = getenv("FMCMC_AMD_MFMA");
-    if (!(usemf && usemf[0] == '0') && pipe_opt == 20 && kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE) {
+    if (mfma_ng) {
       const size_t mlds = mfma_lds_bytes();
-      if (A.debug & 8) {
-        if (kn->kind == FMCMC_KERNEL_NORMAL) hipLaunchKernelGGL((mh_sweep_mfma<1, true>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A);
-        else hipLaunchKernelGGL((mh_sweep_mfma<2, true>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A);
+      const int ns = (int)((m->n + NT - 1) / NT);   // observation slots of 512
+#define LAUNCH_MFMA(KV, GV, SV) hipLaunchKernelGGL((mh_sweep_mfma<KV, GV, SV, false>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A)
+      if ((A.debug & 8) && mfma_ng == 1 && ns == 20) {
+        if (kn->kind == FMCMC_KERNEL_NORMAL) hipLaunchKernelGGL((mh_sweep_mfma<1, 1, 20, true>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A);
+        else hipLaunchKernelGGL((mh_sweep_mfma<2, 1, 20, true>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A);
+      } else if (mfma_ng == 2 && kn->kind == FMCMC_KERNEL_NORMAL) {
+        switch (ns) {
+          case 1: LAUNCH_MFMA(1, 2, 1); break;
+          case 2: LAUNCH_MFMA(1, 2, 2); break;
+          case 3: LAUNCH_MFMA(1, 2, 3); break;
+          case 4: LAUNCH_MFMA(1, 2, 4); break;
+          case 5: LAUNCH_MFMA(1, 2, 5); break;
+          case 6: LAUNCH_MFMA(1, 2, 6); break;
+          case 7: LAUNCH_MFMA(1, 2, 7); break;
+          case 8: LAUNCH_MFMA(1, 2, 8); break;
+          case 9: LAUNCH_MFMA(1, 2, 9); break;
+          case 10: LAUNCH_MFMA(1, 2, 10); break;
+          default: break;
+        }
+      } else if (mfma_ng == 2) {
+        switch (ns) {
+          case 1: LAUNCH_MFMA(2, 2, 1); break;
+          case 2: LAUNCH_MFMA(2, 2, 2); break;
+          case 3: LAUNCH_MFMA(2, 2, 3); break;
+          case 4: LAUNCH_MFMA(2, 2, 4); break;
+          case 5: LAUNCH_MFMA(2, 2, 5); break;
+          case 6: LAUNCH_MFMA(2, 2, 6); break;
+          case 7: LAUNCH_MFMA(2, 2, 7); break;
+          case 8: LAUNCH_MFMA(2, 2, 8); break;
+          case 9: LAUNCH_MFMA(2, 2, 9); break;
+          case 10: LAUNCH_MFMA(2, 2, 10); break;
+          default: break;
+        }
       } else if (kn->kind == FMCMC_KERNEL_NORMAL) {
-        hipLaunchKernelGGL((mh_sweep_mfma<1, false>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A);
+        switch (ns) {
+          case 1: LAUNCH_MFMA(1, 1, 1); break;
+          case 2: LAUNCH_MFMA(1, 1, 2); break;
+          case 3: LAUNCH_MFMA(1, 1, 3); break;
+          case 4: LAUNCH_MFMA(1, 1, 4); break;
+          case 5: LAUNCH_MFMA(1, 1, 5); break;
+          case 6: LAUNCH_MFMA(1, 1, 6); break;
+          case 7: LAUNCH_MFMA(1, 1, 7); break;
+          case 8: LAUNCH_MFMA(1, 1, 8); break;
+          case 9: LAUNCH_MFMA(1, 1, 9); break;
+          case 10: LAUNCH_MFMA(1, 1, 10); break;
+          case 11: LAUNCH_MFMA(1, 1, 11); break;
+          case 12: LAUNCH_MFMA(1, 1, 12); break;
+          case 13: LAUNCH_MFMA(1, 1, 13); break;
+          case 14: LAUNCH_MFMA(1, 1, 14); break;
+          case 15: LAUNCH_MFMA(1, 1, 15); break;
+          case 16: LAUNCH_MFMA(1, 1, 16); break;
+          case 17: LAUNCH_MFMA(1, 1, 17); break;
+          case 18: LAUNCH_MFMA(1, 1, 18); break;
+          case 19: LAUNCH_MFMA(1, 1, 19); break;
+          case 20: LAUNCH_MFMA(1, 1, 20); break;
+          default: break;
+        }
       } else {
-        hipLaunchKernelGGL((mh_sweep_mfma<2, false>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A);
+        switch (ns) {
+          case 1: LAUNCH_MFMA(2, 1, 1); break;
+          case 2: LAUNCH_MFMA(2, 1, 2); break;
+          case 3: LAUNCH_MFMA(2, 1, 3); break;
+          case 4: LAUNCH_MFMA(2, 1, 4); break;
+          case 5: LAUNCH_MFMA(2, 1, 5); break;
+          case 6: LAUNCH_MFMA(2, 1, 6); break;
+          case 7: LAUNCH_MFMA(2, 1, 7); break;
+          case 8: LAUNCH_MFMA(2, 1, 8); break;
+          case 9: LAUNCH_MFMA(2, 1, 9); break;
+          case 10: LAUNCH_MFMA(2, 1, 10); break;
+          case 11: LAUNCH_MFMA(2, 1, 11); break;
+          case 12: LAUNCH_MFMA(2, 1, 12); break;
+          case 13: LAUNCH_MFMA(2, 1, 13); break;
+          case 14: LAUNCH_MFMA(2, 1, 14); break;
+          case 15: LAUNCH_MFMA(2, 1, 15); break;
+          case 16: LAUNCH_MFMA(2, 1, 16); break;
+          case 17: LAUNCH_MFMA(2, 1, 17); break;
+          case 18: LAUNCH_MFMA(2, 1, 18); break;
+          case 19: LAUNCH_MFMA(2, 1, 19); break;
+          case 20: LAUNCH_MFMA(2, 1, 20); break;
+          default: break;
+        }
       }
+#undef LAUNCH_MFMA
     } else
     if (!(nospec && nospec[0] == '1')) {
       const size_t slds = spec_lds_bytes(pipe_opt, kn->kind >= FMCMC_KERNEL_ADAPT);

@@ -361,3 +361,27 @@ def test_ram_freq_and_constr(E, O, C, n, p, freq, constr):
     rg, ro = run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, k, init, nsteps=220, calls=2, freq=freq, constr=M)
     if M is not None:
         assert np.all(ro.state.Sigma[:, M == 0] == 0) and np.any(ro.state.Sigma[:, 1, 0] != 0)
+
+
+@pytest.mark.parametrize("n,p", [(1, 0), (37, 1), (511, 2), (512, 3), (513, 3), (1025, 2), (3000, 0), (5000, 3), (8192, 3),
+                                 (9728, 3), (9729, 1), (10240, 2),                      # one group of K = 4: p <= 3
+                                 (700, 4), (2049, 5), (4096, 6), (5120, 7), (5119, 7)])  # two chained groups: p <= 7
+def test_mfma_path_is_general_in_n_and_p(E, O, n, p):
+    """mh_sweep_mfma with run-time n (batches of 2 observation slots, masks only in the last one) and run-time p (unused
+    k-slots of the 4x4x4 blocks are zero): same bits as the oracle for every shape the 80 operand registers can hold."""
+    X, y = synth_linreg(n, p, 1000 + n + p, beta=np.linspace(1.0, -1.0, p + 1))
+    C = 6
+    init = jitter_init([0.0] * (p + 1) + [float(np.std(y)) + 1.0], C, n)
+    run_both(E, O, O.FAM_LINREG, X if p else None, y, O.K_NORMAL, p + 2, init, nsteps=130, burnin=10, thin=3, calls=2, scale=0.05)
+
+
+def test_mfma_general_shapes_variants(E, O):
+    X, y = synth_linreg(6000, 2, 9)
+    init = jitter_init([0.0, 0.0, 4.0], 5, 3)
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL_REFLECTIVE, 3, init, nsteps=150, intercept=False, scale=0.04,
+             lb=[-3, -3, 0.5], ub=[3, 3, 6.0])
+    init = jitter_init([0.0, 0.0, 0.0, 4.0], 7, 4)
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_UNIF, 4, init, nsteps=150, min_=-0.03, max_=0.04, fixed=[False, True, False, False])
+    X5, y5 = synth_linreg(3000, 5, 10, beta=[1, 2, -1, 0.5, 0.25, -2])
+    init = jitter_init([0.0] * 6 + [4.0], 9, 5)
+    run_both(E, O, O.FAM_LINREG, X5, y5, O.K_NORMAL, 7, init, nsteps=150, guard=False, scale=0.03)
