@@ -1317,6 +1317,20 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
     // (Measured: moving log(sigma) of the owners in front of, or right behind, their MFMAs makes the step SLOWER:
     //  fp64 VALU work issued while the SIMD partner runs MFMAs slows those -- one fp64 datapath -- whereas in
     //  the owner phase below that datapath is idle.)
+    // sigma-only part of the closed form: the owner waves are the first of their SIMD to finish their MFMAs (the older
+    // wave wins the arbitration) and would wait ~1200 ticks at the barrier; its ~65 fp64 instructions run there, in the
+    // shadow of the partner wave's MFMAs, instead of in the exposed owner phase.  The results are wave-uniform (SGPRs).
+    double sigma = 0.0, nt1_fast = 0.0, ss_fast = 1.0;
+    bool sg_fast = false;
+    if (owner) {
+      sigma = readlane_d(th1, k - 1);
+      const unsigned sg_hi = (unsigned)(fmh_d2u(sigma) >> 32);
+      sg_fast = (sg_hi - 0x00100000u) < 0x7fe00000u;                     // positive, finite, normal
+      const double sg = sg_fast ? sigma : 1.0;
+      const double t1_fast = fmh_log_pn(sg) + FMH_K(FMH_LN_SQRT_2PI);   // same bits as fmh_log(sigma) on this range
+      nt1_fast = uniform_d(dn * t1_fast);
+      ss_fast = uniform_d(sg * sg);
+    }
     unsigned long long t_1 = dbg ? clk() : 0;
     lds_barrier();
     unsigned long long t_2 = dbg ? clk() : 0;
@@ -1336,16 +1350,6 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
       lu_nx = lu_row[v < nsteps ? v : nsteps - 1];
       if (kz > 0) z_nx = ld_z(v + 1 < nsteps ? v + 1 : nsteps - 1);
       const double dz = (plane && !fixed_l) ? s_par[0 * PIPE_KMAX + lane] + s_par[1 * PIPE_KMAX + lane] * zc : 0.0;
-      // sigma-only part of the closed form first, as straight-line code in the block of the tile reads: its ~65 dependent
-      // instructions fill the LDS latency and the DPP stalls of the fold instead of queueing behind them
-      const double sigma = readlane_d(th1, k - 1);
-      const unsigned sg_hi = (unsigned)(fmh_d2u(sigma) >> 32);
-      const bool sg_fast = (sg_hi - 0x00100000u) < 0x7fe00000u;          // positive, finite, normal
-      const double sg = sg_fast ? sigma : 1.0;
-      const double t1_fast = fmh_log_pn(sg) + FMH_K(FMH_LN_SQRT_2PI);   // same bits as fmh_log(sigma) on this range
-      double nt1_fast = dn * t1_fast;
-      double ss_fast = sg * sg;
-      asm volatile("" : "+v"(nt1_fast), "+v"(ss_fast));   // keep it HERE: the optimiser would sink it behind the fold
       const double tot = wave_xor_sum(((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7)));
       unsigned long long t_a = dbg ? clk() : 0;
       double f1;
