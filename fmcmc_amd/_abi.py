@@ -15,7 +15,7 @@ SCHEME_JOINT, SCHEME_ORDERED, SCHEME_RANDOM, SCHEME_EXPLICIT = 0, 1, 2, 3
 ABI_VERSION = 2
 RNG_PHILOX, RNG_FED = 0, 1
 OK, ERR_ARG, ERR_DEVICE, ERR_CHAIN, ERR_UNSUPPORTED = 0, 1, 2, 3, 4
-CHAIN_OK, CHAIN_NAN_LOGPOST, CHAIN_NAN_RATIO, CHAIN_NOT_PD = 0, 1, 2, 3
+CHAIN_OK, CHAIN_NAN_LOGPOST, CHAIN_NAN_RATIO, CHAIN_NOT_PD, CHAIN_BAD_WINDOW = 0, 1, 2, 3, 4
 MAX_K = 64
 
 EXPORTS = ["fmcmc_abi_version", "fmcmc_last_error", "fmcmc_device_count", "fmcmc_kept_rows",

@@ -61,6 +61,10 @@ struct SweepArgs {
   const int* scheme_seq;     // [scheme_len] 0-based parameter indices (device)
   const double* constr;      // ram: [kf][kf] mask or NULL (device)
   int* scheme_cols;          // [C][nsteps] plan of scheme = "random": in (FED) / out (PHILOX), or NULL
+  int bw;                    // adapt: window (0 = recursive)
+  int hist_rows;             // adapt with bw > 0 / freq > 1: rows of the ring below (max(freq, bw - 1)), else 0
+  double Sd;                 // adapt, bw > 0
+  double* hist;              // [C][hist_rows][kf] ring of the last rows of ans[, which.] (row r in slot r % hist_rows)
   double until, eps, arate;
   const double* mu;
   const double* scale;
@@ -514,6 +518,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_kernel(const SweepArgs A0) {
     f0 = finish_logpost(A, L.th1, total_of(myc));
     f1 = f0;
     if (lane < kf) L.vrs[lane] = L.th0[s_which[lane]];
+    if (A.hist_rows > 0 && lane < kf) A.hist[((long long)cl * A.hist_rows + (1 % A.hist_rows)) * kf + lane] = L.th0[s_which[lane]];
     store_row(1, f0);
   }
 
@@ -585,35 +590,76 @@ __global__ __launch_bounds__(NT) void mh_sweep_kernel(const SweepArgs A0) {
           L.th1[j] = t;
         }
       } else if (A.kind == FMCMC_KERNEL_ADAPT) {
-        // R/kernel_adapt.R:117-166 (bw = 0, freq = 1)
-        if (A.until > (double)abs_iter && abs_iter > A.warmup && i > 2) {
-          const double t = (double)(abs_iter - 1);
-          double x = 0, mp = 0, mt = 0;
-          if (lane < kf) {
-            x = L.th0[s_which[lane]];
-            mp = have_mean ? L.vmp[lane] : (L.vrs[lane] / (double)(i - 1));
-            mt = (mp * t + x) / (t + 1);
-            L.vv[lane] = x;
-            L.vmp[lane] = mp;
-            L.vmt[lane] = mt;
-          }
-          wave_sync();
-          if (lane < kf) {
-            const double c1 = (t - 1) / t, c2 = 1.0 / t;
-            for (int b = 0; b < kf; b++) {
-              double ik = (b == lane) ? 1.0 * A.eps : 0.0;
-              double inner = t * (mp * L.vmp[b]) - (t + 1) * (mt * L.vmt[b]) + x * L.vv[b] + 1e-5 * ik;
-              L.SigA[lane * LD + b] = c1 * L.SigA[lane * LD + b] + c2 * inner;
+        // R/kernel_adapt.R:117-166
+        if (A.until > (double)abs_iter && abs_iter > A.warmup && i > 2 && (i % A.freq) == 0) {
+          const int H = A.hist_rows;
+          double* ring = A.hist + (long long)cl * H * kf;
+          if (H > 0) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");   // the ring rows were stored by other lanes of this wave
+          if (A.bw > 0) {
+            // windowed AM: Sigma <<- Sd * (cov(ans[(i - bw + 1):(i - 1), which.]) + Ik) :120-125 (twin of the oracle's canonical cov)
+            const int N = A.bw - 1;
+            if (i - A.bw + 1 < 1 || N < 2) {
+              status = FMCMC_CHAIN_BAD_WINDOW;
+            } else {
+              double m = 0.0;
+              if (lane < kf) {
+                double sm = 0.0;
+                for (int r = i - A.bw + 1; r <= i - 1; r++) sm = sm + ring[(long long)(r % H) * kf + lane];
+                m = sm / (double)N;
+                for (int b = 0; b < kf; b++) L.SigA[lane * LD + b] = 0.0;
+              }
+              for (int r = i - A.bw + 1; r <= i - 1; r++) {
+                double d = 0.0;
+                if (lane < kf) {
+                  d = ring[(long long)(r % H) * kf + lane] - m;
+                  L.vv[lane] = d;
+                }
+                wave_sync();
+                if (lane < kf)
+                  for (int b = 0; b < kf; b++) L.SigA[lane * LD + b] = fmh_fma(d, L.vv[b], L.SigA[lane * LD + b]);
+                wave_sync();
+              }
+              if (lane < kf)
+                for (int b = 0; b < kf; b++) {
+                  const double ik = (b == lane) ? 1.0 * A.eps : 0.0;
+                  L.SigA[lane * LD + b] = A.Sd * (L.SigA[lane * LD + b] / (double)(N - 1) + ik);
+                }
+              wave_sync();
+            }
+          } else if (i - A.freq < 1) {
+            status = FMCMC_CHAIN_BAD_WINDOW;   // R: ans[0:(i-1), ] has fewer than freq rows, `[, , freq]` is out of bounds
+          } else {
+            // rows (i - freq):(i - 1) folded in one by one, t. = abs_iter - freq + (row - 1) (R/recursive.R:79-108,:129-136)
+            for (int jr = 0; jr < A.freq; jr++) {
+              const double t = (double)(abs_iter - A.freq + jr);
+              double x = 0, mp = 0, mt = 0;
+              if (lane < kf) {
+                x = (A.freq == 1) ? L.th0[s_which[lane]] : ring[(long long)((i - A.freq + jr) % H) * kf + lane];
+                mp = have_mean ? L.vmp[lane] : (L.vrs[lane] / (double)(i - 1));
+                mt = (mp * t + x) / (t + 1);
+                L.vv[lane] = x;
+                L.vmp[lane] = mp;
+                L.vmt[lane] = mt;
+              }
+              wave_sync();
+              if (lane < kf) {
+                const double c1 = (t - 1) / t, c2 = 1.0 / t;
+                for (int b = 0; b < kf; b++) {
+                  double ik = (b == lane) ? 1.0 * A.eps : 0.0;
+                  double inner = t * (mp * L.vmp[b]) - (t + 1) * (mt * L.vmt[b]) + x * L.vv[b] + 1e-5 * ik;
+                  L.SigA[lane * LD + b] = c1 * L.SigA[lane * LD + b] + c2 * inner;
+                }
+              }
+              wave_sync();
+              if (lane < kf) L.vmp[lane] = mt;
+              have_mean = 1;
             }
           }
-          wave_sync();
-          if (lane < kf) L.vmp[lane] = mt;
-          have_mean = 1;
         }
         abs_iter += 1;
         // left-looking Cholesky, lane = row (twin of oracle chol_lower_canon)
         bool notpd = false;
-        for (int j = 0; j < kf; j++) {
+        for (int j = 0; j < kf && status == FMCMC_CHAIN_OK; j++) {
           double s = 0.0;
           if (lane >= j && lane < kf) {
             s = L.SigA[lane * LD + j];
@@ -628,7 +674,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_kernel(const SweepArgs A0) {
         }
         if (notpd) {
           status = FMCMC_CHAIN_NOT_PD;
-        } else {
+        } else if (status == FMCMC_CHAIN_OK) {
           if (lane < k) L.th1[lane] = L.th0[lane];
           wave_sync();
           if (lane < kf) {
@@ -748,6 +794,8 @@ __global__ __launch_bounds__(NT) void mh_sweep_kernel(const SweepArgs A0) {
         wave_sync();
         store_row(i, f1);
         if (A.kind == FMCMC_KERNEL_ADAPT && lane < kf) L.vrs[lane] = L.vrs[lane] + L.th0[s_which[lane]];
+        if (A.hist_rows > 0 && lane < kf)   // row i of ans[, which.] for the windowed / strided adaptation
+          A.hist[((long long)cl * A.hist_rows + (i % A.hist_rows)) * kf + lane] = L.th0[s_which[lane]];
       }
     }
     if (owner && A.accept_bits && lane == 0 && (((i - 1) & 31) == 31 || i == nsteps)) {
@@ -2322,9 +2370,9 @@ int fmcmc_validate(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_run
       }
     }
   }
-  if (kn->kind == FMCMC_KERNEL_ADAPT && (kn->freq != 1 || kn->bw != 0)) {
-    set_err("device kernel_adapt supports freq = 1 and bw = 0 only (got freq=%d, bw=%d)", kn->freq, kn->bw);
-    return FMCMC_ERR_UNSUPPORTED;
+  if (kn->kind == FMCMC_KERNEL_ADAPT && (kn->freq < 1 || kn->bw < 0)) {
+    set_err("-freq- must be >= 1 and -bw- >= 0 (got freq=%d, bw=%d)", kn->freq, kn->bw);
+    return FMCMC_ERR_ARG;
   }
   if (kn->kind == FMCMC_KERNEL_RAM && kn->freq < 1) { set_err("-freq- must be >= 1."); return FMCMC_ERR_ARG; }
   if (kn->kind == FMCMC_KERNEL_ADAPT && kn->bw > 0 && kn->bw > kn->warmup) {
@@ -2352,6 +2400,13 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
       !st->scheme_cols) {
     set_err("rng_mode = FED with scheme = 'random' needs state->scheme_cols");
     return FMCMC_ERR_ARG;
+  }
+  A.bw = (kn->kind == FMCMC_KERNEL_ADAPT) ? kn->bw : 0; A.Sd = kn->Sd;
+  const bool adapt_hist = (kn->kind == FMCMC_KERNEL_ADAPT && (kn->bw > 0 || kn->freq > 1));
+  if (adapt_hist) {   // ring of the last rows of every chain (the reference reads them from env$ans)
+    A.hist_rows = (kn->bw - 1 > kn->freq) ? kn->bw - 1 : kn->freq;
+    hipError_t eh = hipMallocAsync((void**)&A.hist, sizeof(double) * (size_t)run->nchains * (size_t)A.hist_rows * (size_t)kf, stream);
+    if (eh != hipSuccess) { set_err("hipMallocAsync(adapt history) failed: %s", hipGetErrorString(eh)); return FMCMC_ERR_DEVICE; }
   }
   A.freq = kn->freq < 1 ? 1 : kn->freq; A.scheme_seq = kn->scheme_seq; A.scheme_len = kn->scheme_len;
   A.constr = (kn->kind == FMCMC_KERNEL_RAM) ? kn->constr : nullptr; A.scheme_cols = st->scheme_cols;
@@ -2426,7 +2481,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
   int pipe_opt = 0, mfma_ng = 0;
   if (!(force && force[0] == '1') && !(nopipe && nopipe[0] == '1') && m->family == FMCMC_FAM_GAUSSIAN_LINREG &&
       (kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE ||
-       ((kn->kind == FMCMC_KERNEL_ADAPT || (kn->kind == FMCMC_KERNEL_RAM && !ram_bounded && !kn->constr)) && !(nospec0 && nospec0[0] == '1'))) &&
+       (((kn->kind == FMCMC_KERNEL_ADAPT && !adapt_hist) || (kn->kind == FMCMC_KERNEL_RAM && !ram_bounded && !kn->constr)) && !(nospec0 && nospec0[0] == '1'))) &&
       (kn->scheme == FMCMC_SCHEME_JOINT || kn->kind >= FMCMC_KERNEL_ADAPT) && kn->k <= PIPE_KMAX &&
       (unsigned long long)run->nchains * kn->k * (unsigned long long)A.S * 8ull < (1ull << 32) &&
       (unsigned long long)run->nchains * (unsigned long long)run->nsteps * (unsigned long long)A.kz * 8ull < (1ull << 32)) {
@@ -2597,6 +2652,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
   }
 #undef LAUNCH_KIND
 #undef LAUNCH
+  if (A.hist) (void)hipFreeAsync(A.hist, stream);
   if (e == hipSuccess) e = hipGetLastError();
   if (e != hipSuccess) { set_err("HIP launch failed: %s", hipGetErrorString(e)); return FMCMC_ERR_DEVICE; }
   return FMCMC_OK;

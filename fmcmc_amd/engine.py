@@ -229,7 +229,9 @@ def raise_on_chain_error(out, chain_base=0):
         theta = out.status_theta[c].cpu().numpy()
         what = {abi.CHAIN_NAN_LOGPOST: "fun(par) is undefined (NaN).",
                 abi.CHAIN_NAN_RATIO: "fun(par) is undefined (f1 - f0 is NaN).",
-                abi.CHAIN_NOT_PD: "'Sigma' is not positive definite."}.get(int(st[c]), "chain error.")
+                abi.CHAIN_NOT_PD: "'Sigma' is not positive definite.",
+                abi.CHAIN_BAD_WINDOW: "subscript out of bounds: the rows kernel_adapt(bw / freq) adapts on reach before the "
+                                      "first row of this call."}.get(int(st[c]), "chain error.")
         raise RuntimeError(
             "%s Check either -fun- or the -lb- and -ub- parameters. This error ocurred during step i = %d "
             "(chain %d) and proposal parameters theta1 = %s" % (what, step, chain_base + c, np.array2string(theta, precision=4)))

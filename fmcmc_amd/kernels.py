@@ -214,9 +214,8 @@ def kernel_adapt(mu=0.0, bw=0, lb=-DBL_MAX, ub=DBL_MAX, freq=1, warmup=500, Sigm
                  eps=1e-4, fixed=False, until=float("inf")):
     if bw > 0 and bw > warmup:
         raise ValueError("The `warmup` parameter must be greater than `bw`.")
-    if bw != 0 or freq != 1:
-        raise NotImplementedError("device kernel_adapt supports bw = 0 and freq = 1 "
-                                  "(SURVEY.md section 8(f) rank 3 lists the windowed variant as next).")
+    if int(freq) < 1 or int(bw) < 0:
+        raise ValueError("-freq- must be >= 1 and -bw- >= 0.")
     return fmcmc_kernel(abi.KERNEL_ADAPT, mu=mu, bw=int(bw), lb=lb, ub=ub, freq=int(freq), warmup=int(warmup),
                         Sigma=Sigma, Sd=Sd, eps=eps, fixed=fixed, until=until)
 

@@ -91,13 +91,13 @@ typedef struct fmcmc_kernel {
   const double* ub;     /* [k] upper bounds */
   const uint8_t* fixed; /* [k] 1 = parameter never updated */
   int32_t scheme;       /* FMCMC_SCHEME_* (normal / unif kernels) */
-  int32_t freq;         /* adapt/ram: adaptation frequency (adapt: only 1 supported on device) */
+  int32_t freq;         /* adapt/ram: adaptation frequency (adapt every freq-th loop step, `!(env$i %% freq)`) */
   int32_t warmup;       /* adapt/ram */
-  int32_t bw;           /* adapt: window (only 0 supported on device) */
+  int32_t bw;           /* adapt: > 0 = windowed AM, Sigma = Sd * (cov(last bw - 1 rows) + eps * I) (R/kernel_adapt.R:123-125) */
   double until;         /* adapt/ram: stop adapting when abs_iter >= until (Inf allowed) */
   double eps;           /* adapt/ram: initial Sigma = eps * I */
   double arate;         /* ram: target acceptance rate */
-  double Sd;            /* adapt: scaling (unused on the recursive path, kept for write-back) */
+  double Sd;            /* adapt: scaling of the windowed variant (the recursive path does not apply it, as in R) */
   const int32_t* scheme_seq; /* [scheme_len] FMCMC_SCHEME_EXPLICIT: 0-based parameter indices, a permutation of the
                               * free parameters (R/kernel.R:72-90); NULL otherwise */
   int32_t scheme_len;
@@ -149,7 +149,10 @@ enum {
   FMCMC_CHAIN_OK = 0,
   FMCMC_CHAIN_NAN_LOGPOST = 1, /* fun(par) is undefined: R/mcmc.R:758-765 */
   FMCMC_CHAIN_NAN_RATIO = 2,   /* f1 - f0 is NaN (e.g. -Inf - -Inf): R's `if (NA)` error */
-  FMCMC_CHAIN_NOT_PD = 3       /* proposal covariance not positive definite (MASS::mvrnorm error) */
+  FMCMC_CHAIN_NOT_PD = 3,      /* proposal covariance not positive definite (MASS::mvrnorm error) */
+  /* kernel_adapt with bw > 0 or freq > 1: the rows ans[(i-bw+1):(i-1), ] / ans[(i-freq):(i-1), ] reach before the first row
+   * of this call (R: "subscript out of bounds" / mixed subscripts, R/kernel_adapt.R:119-125,139-156) */
+  FMCMC_CHAIN_BAD_WINDOW = 4
 };
 
 typedef struct fmcmc_out {

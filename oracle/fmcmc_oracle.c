@@ -410,6 +410,7 @@ typedef struct {
   double run_sum[MAXK];        /* canonical: sum of ans rows 1..i-1 over free params */
   long double run_sum_ld[MAXK]; /* R mode */
   const int32_t* cols;         /* scheme = "random": plan of this chain, entry i-1 = column of loop step i */
+  const double* hist;          /* adapt with bw > 0 / freq > 1: env$ans[, which.] of THIS call, row r at hist + (r-1)*kf */
 } kstate;
 
 /* draw helpers ---------------------------------------------------------------------------- */
@@ -462,27 +463,77 @@ static void propose_normal(const ocfg* cfg, const fmcmc_kernel* kn, const kstate
 }
 
 /* kernel_adapt proposal (R/kernel_adapt.R:117-180), bw = 0, freq = 1. Returns chain status. */
+/* stats::cov of N rows (src/library/stats/src/cov.c, cov_complete1, pearson): long-double column means refined by a
+ * second pass, then long-double sums of cross products over (N - 1). */
+static void r_cov(const double* X, int N, int k, double* out) {
+  long double xm[MAXK];
+  for (int a = 0; a < k; a++) {
+    long double s = 0.0L;
+    for (int t = 0; t < N; t++) s += X[t * k + a];
+    long double m = s / N;
+    s = 0.0L;
+    for (int t = 0; t < N; t++) s += (X[t * k + a] - m);
+    xm[a] = m + s / N;
+  }
+  for (int a = 0; a < k; a++)
+    for (int b = 0; b <= a; b++) {
+      long double s = 0.0L;
+      for (int t = 0; t < N; t++) s += (X[t * k + a] - xm[a]) * (X[t * k + b] - xm[b]);
+      out[a * k + b] = out[b * k + a] = (double)(s / (N - 1));
+    }
+}
+
 static int propose_adapt(const ocfg* cfg, const fmcmc_kernel* kn, kstate* ks, int64_t i,
                          uint32_t step, uint32_t chain, const double* theta0, double* theta1) {
   const int kf = ks->kf;
   if (kn->until > (double)ks->abs_iter && ks->abs_iter > kn->warmup && i > 2 &&
       (i % kn->freq) == 0) {
     double x[MAXK], mean_t[MAXK], Ik[MAXK * MAXK];
-    for (int a = 0; a < kf; a++) x[a] = theta0[ks->which[a]]; /* ans[i-1, which.] */
-    if (!ks->have_mean) { /* colMeans(ans[1:(i-1), which.]) :130-131 */
-      for (int a = 0; a < kf; a++)
-        ks->mean_prev[a] = (cfg->math_mode == ORACLE_MATH_R)
-                               ? (double)(ks->run_sum_ld[a] / (long double)(i - 1))
-                               : ks->run_sum[a] / (double)(i - 1);
-      ks->have_mean = 1;
-    }
-    double t = (double)(ks->abs_iter - kn->freq);
-    fmcmc_oracle_mean_recursive(x, ks->mean_prev, t, kf, mean_t);
     for (int a = 0; a < kf; a++)
       for (int b = 0; b < kf; b++) Ik[a * kf + b] = (a == b) ? 1.0 * kn->eps : 0.0;
-    /* eps = 1e-5 and Sd = 1 (the default of cov_recursive; kernel's Sd is NOT passed) :148-156 */
-    fmcmc_oracle_cov_recursive(x, ks->Sigma, ks->mean_prev, mean_t, t, 1e-5, 1.0, Ik, kf);
-    for (int a = 0; a < kf; a++) ks->mean_prev[a] = mean_t[a];
+    if (kn->bw > 0) {
+      /* Sigma <<- Sd * (cov(env$ans[(i - bw + 1):(i - 1), which.]) + Ik) :120-125 */
+      const int N = kn->bw - 1;
+      if (i - kn->bw + 1 < 1 || N < 2) { ks->abs_iter += 1; return FMCMC_CHAIN_BAD_WINDOW; }
+      const double* X = ks->hist + (i - kn->bw) * kf; /* row i - bw + 1 */
+      double cv[MAXK * MAXK];
+      if (cfg->math_mode == ORACLE_MATH_R) {
+        r_cov(X, N, kf, cv);
+      } else { /* canonical: plain sequential column sums, then fma-accumulated centred cross products */
+        double m[MAXK];
+        for (int a = 0; a < kf; a++) {
+          double sm = 0.0;
+          for (int t = 0; t < N; t++) sm = sm + X[t * kf + a];
+          m[a] = sm / (double)N;
+        }
+        for (int a = 0; a < kf; a++)
+          for (int b = 0; b < kf; b++) {
+            double acc = 0.0;
+            for (int t = 0; t < N; t++) acc = fmh_fma(X[t * kf + a] - m[a], X[t * kf + b] - m[b], acc);
+            cv[a * kf + b] = acc / (double)(N - 1);
+          }
+      }
+      for (int a = 0; a < kf * kf; a++) ks->Sigma[a] = kn->Sd * (cv[a] + Ik[a]);
+    } else {
+      if (i - kn->freq < 1) { ks->abs_iter += 1; return FMCMC_CHAIN_BAD_WINDOW; } /* ans[0:(i-1), ] has i - 1 < freq rows: `[, , freq]` fails */
+      if (!ks->have_mean) { /* colMeans(ans[1:(i-1), which.]) :130-131 */
+        for (int a = 0; a < kf; a++)
+          ks->mean_prev[a] = (cfg->math_mode == ORACLE_MATH_R)
+                                 ? (double)(ks->run_sum_ld[a] / (long double)(i - 1))
+                                 : ks->run_sum[a] / (double)(i - 1);
+        ks->have_mean = 1;
+      }
+      /* rows (i - freq):(i - 1) folded in one by one, t. = abs_iter - freq + (row - 1) (R/recursive.R:79-108,:129-136);
+       * eps = 1e-5 and Sd = 1 (the default of cov_recursive; the kernel's Sd is NOT passed) :139-156 */
+      for (int j = 0; j < kn->freq; j++) {
+        const double t = (double)(ks->abs_iter - kn->freq + j);
+        if (kn->freq == 1) for (int a = 0; a < kf; a++) x[a] = theta0[ks->which[a]]; /* ans[i-1, which.] */
+        else for (int a = 0; a < kf; a++) x[a] = ks->hist[(i - kn->freq + j - 1) * kf + a];
+        fmcmc_oracle_mean_recursive(x, ks->mean_prev, t, kf, mean_t);
+        fmcmc_oracle_cov_recursive(x, ks->Sigma, ks->mean_prev, mean_t, t, 1e-5, 1.0, Ik, kf);
+        for (int a = 0; a < kf; a++) ks->mean_prev[a] = mean_t[a];
+      }
+    }
   }
   ks->abs_iter += 1;
   double z[MAXK], delta[MAXK];
@@ -633,7 +684,7 @@ int fmcmc_oracle_run(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_r
   const int k = kn->k;
   if (k > MAXK || k < 1) return FMCMC_ERR_ARG;
   if (run->burnin >= run->nsteps || run->thin >= run->nsteps || run->thin < 1) return FMCMC_ERR_ARG;
-  if (kn->kind == FMCMC_KERNEL_ADAPT && (kn->freq != 1 || kn->bw != 0)) return FMCMC_ERR_UNSUPPORTED;
+  if (kn->kind == FMCMC_KERNEL_ADAPT && (kn->freq < 1 || kn->bw < 0 || (kn->bw > 0 && kn->bw > kn->warmup))) return FMCMC_ERR_ARG;
   if (kn->kind == FMCMC_KERNEL_RAM && kn->freq < 1) return FMCMC_ERR_ARG;
   const int simple = (kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE ||
                       kn->kind == FMCMC_KERNEL_UNIF || kn->kind == FMCMC_KERNEL_UNIF_REFLECTIVE);
@@ -645,16 +696,18 @@ int fmcmc_oracle_run(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_r
   int any_err = 0;
   double* logu = (double*)malloc(sizeof(double) * (size_t)(nsteps + 1));
   int32_t* cols_buf = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nsteps + 1));
+  const int need_hist = (kn->kind == FMCMC_KERNEL_ADAPT && (kn->bw > 0 || kn->freq > 1));
+  double* hist = need_hist ? (double*)malloc(sizeof(double) * (size_t)(nsteps + 1) * MAXK) : NULL;
 
   kstate ks;
   ks.k = k; ks.kf = 0;
   for (int a = 0; a < k; a++)
     if (!kn->fixed[a]) ks.which[ks.kf++] = a;
   const int kf = ks.kf;
-  if (kf == 0) { free(logu); free(cols_buf); return FMCMC_ERR_ARG; }
+  if (kf == 0) { free(logu); free(cols_buf); free(hist); return FMCMC_ERR_ARG; }
   for (int a = 0; a < k; a++)
     if (kn->kind != FMCMC_KERNEL_NORMAL && kn->kind != FMCMC_KERNEL_UNIF && !(kn->ub[a] > kn->lb[a])) {
-      free(logu); free(cols_buf); return FMCMC_ERR_ARG;
+      free(logu); free(cols_buf); free(hist); return FMCMC_ERR_ARG;
     }
   /* sample(which(!fixed), nsteps, TRUE): a length-one x >= 1 means sample(1:x) in R (R/kernel.R:110) */
   int pool[MAXK], npool = 0;
@@ -730,6 +783,8 @@ int fmcmc_oracle_run(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_r
     }                                                                                \
   } while (0)
     STORE_ROW(1, theta0, theta0, f0);
+    ks.hist = hist;
+    if (hist) for (int a = 0; a < kf; a++) hist[a] = theta0[ks.which[a]]; /* row 1 */
 
     for (int64_t i = 2; i <= nsteps; i++) {
       const uint32_t step = (uint32_t)(run->step_base + i);
@@ -761,6 +816,7 @@ int fmcmc_oracle_run(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_r
         if (bits) bits[(i - 1) >> 5] |= (1u << ((i - 1) & 31));
       }
       STORE_ROW(i, theta0, theta1, f1);
+      if (hist) for (int a = 0; a < kf; a++) hist[(i - 1) * kf + a] = theta0[ks.which[a]]; /* row i */
       for (int a = 0; a < kf; a++) {
         ks.run_sum[a] = ks.run_sum[a] + theta0[ks.which[a]];
         ks.run_sum_ld[a] += (long double)theta0[ks.which[a]];
@@ -782,6 +838,7 @@ int fmcmc_oracle_run(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_r
   }
   free(logu);
   free(cols_buf);
+  free(hist);
   return any_err ? FMCMC_ERR_CHAIN : FMCMC_OK;
 }
 

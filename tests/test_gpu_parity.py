@@ -385,3 +385,30 @@ def test_mfma_general_shapes_variants(E, O):
     X5, y5 = synth_linreg(3000, 5, 10, beta=[1, 2, -1, 0.5, 0.25, -2])
     init = jitter_init([0.0] * 6 + [4.0], 9, 5)
     run_both(E, O, O.FAM_LINREG, X5, y5, O.K_NORMAL, 7, init, nsteps=150, guard=False, scale=0.03)
+
+
+@pytest.mark.parametrize("C,n,p,bw,freq,warmup", [(5, 900, 3, 0, 3, 20), (4, 10000, 3, 0, 2, 30), (6, 700, 2, 25, 1, 40),
+                                                   (3, 10000, 3, 12, 1, 12), (4, 600, 1, 8, 5, 20)])
+def test_adapt_window_and_stride(E, O, C, n, p, bw, freq, warmup):
+    """kernel_adapt(bw > 0) / (freq > 1) (R/kernel_adapt.R:117-160): ring of the last rows per chain in HBM, same bits as
+    the oracle's canonical restatement; a second call on the warmed-up kernel raises the reference's subscript error as a
+    per-chain status when the rows it needs precede the call."""
+    X, y = synth_linreg(n, p, 55 + n)
+    k = p + 2
+    init = jitter_init([0.0] * (p + 1) + [float(np.std(y))], C, 2)
+    rg, ro = run_both(E, O, O.FAM_LINREG, X, y, O.K_ADAPT, k, init, nsteps=180, bw=bw, freq=freq, warmup=warmup, Sd=0.8)
+    assert np.all(ro.status == 0) and ro.accept_count.min() > 0
+    if bw > 0 or freq > 2:
+        om, ok = O.Model(O.FAM_LINREG, X, y), O.Kernel(O.K_ADAPT, k, bw=bw, freq=freq, warmup=warmup, Sd=0.8)
+        gm = E.DeviceModel(O.FAM_LINREG, X, y)
+        gk = E.KernelSpec(O.K_ADAPT, k, ok.mu, ok.scale, ok.lb, ok.ub, ok.fixed, freq=freq, warmup=warmup, bw=bw, Sd=0.8)
+        ost, gst = O.ChainState(init, ok.kf), E.ChainState(init, ok.kf)
+        for st, runner in ((ost, lambda: O.run(om, ok, nsteps=60, seed=3, state=ost)),
+                           (gst, lambda: E.sweep(gm, gk, gst, 60, seed=3, check=False))):
+            runner()
+        r2o = O.run(om, ok, nsteps=60, seed=3, state=ost)
+        r2g = E.sweep(gm, gk, gst, 60, seed=3, check=False)
+        assert np.all(r2o.status == 4) and np.array_equal(r2g.status.cpu().numpy(), r2o.status)
+        assert np.array_equal(r2g.status_step.cpu().numpy(), r2o.status_step)
+        with pytest.raises(RuntimeError, match="subscript out of bounds"):
+            E.raise_on_chain_error(r2g)

@@ -218,5 +218,46 @@ def test_abi_validation_of_the_new_rows(abi):
     check(kern(abi.KERNEL_NORMAL, [1, 1, 1], scheme=abi.SCHEME_EXPLICIT, seq=[2, 2, 1]), abi.ERR_ARG, "not included")
     check(kern(abi.KERNEL_RAM, [1, 1, 1], freq=5), abi.OK)
     check(kern(abi.KERNEL_RAM, [1, 1, 1], freq=0), abi.ERR_ARG, "freq")
-    check(kern(abi.KERNEL_ADAPT, [1, 1, 1], freq=2), abi.ERR_UNSUPPORTED)
+    check(kern(abi.KERNEL_ADAPT, [1, 1, 1], freq=2), abi.OK)
+    check(kern(abi.KERNEL_ADAPT, [1, 1, 1], freq=0), abi.ERR_ARG, "freq")
     check(kern(9, [1, 1, 1]), abi.ERR_ARG, "unknown kernel kind")
+
+
+def test_adapt_window_and_stride_oracle(O):
+    """kernel_adapt(bw > 0) and (freq > 1), R/kernel_adapt.R:117-160: the final Sigma recomputed offline from the chain with
+    numpy / the package's own cov_recursive (matrix input = R's row-by-row recursion)."""
+    import fmcmc_amd as f
+    X, y = synth_linreg(400, 1, 12)
+    m = O.Model(O.FAM_LINREG, X, y)
+    init = np.array([[0.0, 0.0, 4.0]])
+    for math, rng in ((O.MATH_CANON, None), (O.MATH_R, O.RRng(3))):
+        kw = dict(rng_mode=O.RNG_RMT, rng=rng) if rng else {}
+        # windowed: last step is a gated one (freq = 1), rows nsteps - bw + 1 .. nsteps - 1
+        kn = O.Kernel(O.K_ADAPT, 3, bw=20, warmup=30, Sd=0.7)
+        r = O.run(m, kn, initial=init, nsteps=120, seed=5, math_mode=math, **kw)
+        rows = r.samples[0, 120 - 20:119]                          # 0-based rows of ans[(i-bw+1):(i-1)] for i = 120
+        want = 0.7 * (np.cov(rows.T) + 1e-4 * np.eye(3))
+        assert rows.shape[0] == 19 and np.allclose(r.state.Sigma[0], want, rtol=1e-9, atol=1e-15)
+        # strided: every 4th step folds the 4 previous rows in, one by one
+        kn = O.Kernel(O.K_ADAPT, 3, freq=4, warmup=10)
+        r = O.run(m, kn, initial=init, nsteps=121, seed=5, math_mode=math, **kw)
+        S, mean = 1e-4 * np.eye(3), None
+        for i in range(2, 122):
+            abs_iter = i - 2
+            if abs_iter > 10 and i > 2 and i % 4 == 0:
+                if mean is None:
+                    mean = r.samples[0, :i - 1].mean(0)
+                Xt = r.samples[0, i - 4 - 1:i - 1]                  # rows (i-freq):(i-1)
+                means = f.mean_recursive(Xt, mean, abs_iter - 4)
+                S = f.cov_recursive(Xt, S, mean, abs_iter - 4, Mean_t=means, eps=1e-5, Ik=1e-4 * np.eye(3))[-1]
+                mean = means[-1]
+        assert np.allclose(r.state.Sigma[0], S, rtol=1e-9, atol=1e-18) and np.allclose(r.state.mean_prev[0], mean, rtol=1e-12)
+    # R fails when the window reaches before the first row of the call: continuation of a warmed-up windowed kernel
+    kn = O.Kernel(O.K_ADAPT, 3, bw=20, warmup=30)
+    st = O.ChainState(init, 3)
+    O.run(m, kn, nsteps=60, seed=1, state=st)
+    r = O.run(m, kn, nsteps=60, seed=1, state=st)
+    assert r.status[0] == 4 and r.status_step[0] == 3
+    with pytest.raises(ValueError, match="warmup"):
+        f.kernel_adapt(bw=40, warmup=30)
+    assert f.kernel_adapt(bw=10, freq=2).bw == 10
