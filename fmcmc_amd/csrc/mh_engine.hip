@@ -233,23 +233,66 @@ __device__ __forceinline__ void eval_partials(const SweepArgs& A, double* const*
 #pragma unroll
   for (int c = 0; c < CW; c++) acc[c] = 0.0;
   if (A.family == FMCMC_FAM_LOGISTIC) {
-    for (long long i = tid; i < n; i += NT) {
-      double eta[CW];
+    // The data comes from L2 (~1 us under load) and only two waves share a SIMD: a load-use chain per column made this
+    // loop latency-bound (6 dependent round trips per observation).  All columns of an observation are fetched as one
+    // batch, and the batch of the NEXT observation is in flight while exp / log1p of the current one run.
+    constexpr int JB = 8;
+    auto term_of = [&](double e, bool y1) -> double {
+      double s = y1 ? e : -e;
+      double a = (s < 0.0) ? s : -s;
+      double l1 = fmh_log1p_exp_nonpos(a);   // == fmh_log1p(fmh_exp(a)) bit for bit, straight-line on the common range
+      return (s < 0.0) ? (s - l1) : (-l1);
+    };
+    if (p <= JB) {
+      double xb[JB], yv = 0.0;
+      long long i = tid;
+      if (i < n) {
 #pragma unroll
-      for (int c = 0; c < CW; c++) eta[c] = ic ? th[c][0] : 0.0;
-      for (int j = 0; j < p; j++) {
-        double x = A.X[(long long)j * n + i];
-#pragma unroll
-        for (int c = 0; c < CW; c++) eta[c] = fmh_fma(x, th[c][ic + j], eta[c]);
+        for (int u = 0; u < JB; u++) xb[u] = (u < p) ? A.X[(long long)u * n + i] : 0.0;
+        yv = A.y[i];
       }
-      const bool y1 = (A.y[i] != 0.0);
+      for (; i < n; i += NT) {
+        double eta[CW];
 #pragma unroll
-      for (int c = 0; c < CW; c++) {
-        double s = y1 ? eta[c] : -eta[c];
-        double a = (s < 0.0) ? s : -s;
-        double l1 = fmh_log1p(fmh_exp(a));
-        double term = (s < 0.0) ? (s - l1) : (-l1);
-        acc[c] = acc[c] + term;
+        for (int c = 0; c < CW; c++) eta[c] = ic ? th[c][0] : 0.0;
+#pragma unroll
+        for (int u = 0; u < JB; u++)
+          if (u < p) {
+#pragma unroll
+            for (int c = 0; c < CW; c++) eta[c] = fmh_fma(xb[u], th[c][ic + u], eta[c]);
+          }
+        const bool y1 = (yv != 0.0);
+        const long long inx = (i + NT < n) ? i + NT : i;   // clamped: the last prefetch re-reads this observation
+#pragma unroll
+        for (int u = 0; u < JB; u++) xb[u] = (u < p) ? A.X[(long long)u * n + inx] : 0.0;
+        yv = A.y[inx];
+#pragma unroll
+        for (int c = 0; c < CW; c++) acc[c] = acc[c] + term_of(eta[c], y1);
+      }
+    } else {
+      for (long long i = tid; i < n; i += NT) {
+        double eta[CW];
+#pragma unroll
+        for (int c = 0; c < CW; c++) eta[c] = ic ? th[c][0] : 0.0;
+        const bool y1 = (A.y[i] != 0.0);
+        int j = 0;
+        for (; j + JB <= p; j += JB) {
+          double xb[JB];
+#pragma unroll
+          for (int u = 0; u < JB; u++) xb[u] = A.X[(long long)(j + u) * n + i];
+#pragma unroll
+          for (int u = 0; u < JB; u++) {
+#pragma unroll
+            for (int c = 0; c < CW; c++) eta[c] = fmh_fma(xb[u], th[c][ic + j + u], eta[c]);
+          }
+        }
+        for (; j < p; j++) {
+          double x = A.X[(long long)j * n + i];
+#pragma unroll
+          for (int c = 0; c < CW; c++) eta[c] = fmh_fma(x, th[c][ic + j], eta[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < CW; c++) acc[c] = acc[c] + term_of(eta[c], y1);
       }
     }
   } else {
@@ -2253,6 +2296,8 @@ __global__ void detmath_kernel(int which, const double* x, double* out, long lon
     case 6: r = fmh_student_t(seed, (unsigned)(i & 0xffff), (unsigned)(i >> 16), (unsigned)(i % 7), v); break;
     case 7: r = fmh_sqrt(v); break;
     case 8: r = 1.0 / v; break;
+    case 9: r = fmh_log1p_exp_nonpos(v); break;   // the fused softplus tail of the logistic family
+    case 10: r = fmh_unif(seed, (unsigned)(i & 0xffff), (unsigned)(i >> 16), (unsigned)(i % 7)); break;
     default: r = fmh_nan();
   }
   out[i] = r;

@@ -222,7 +222,7 @@ int fmcmc_rng_stream_dev(uint64_t seed, int64_t step_base, int64_t chain_base, i
 
 /* Diagnostic: evaluate the canonical math / RNG primitives on the device, element-wise
  * (which: 0 log, 1 exp, 2 log1p, 3 qnorm, 4 log accept-u, 5 normal, 6 student-t(df=x), 7 sqrt,
- * 8 reciprocal). Used by tests to prove host/device bit-equality of include/fmh_*.h. */
+ * 8 reciprocal, 9 fused log1p(exp(x)) for x <= 0, 10 uniform variate). Used by tests to prove host/device bit-equality of include/fmh_*.h. */
 int fmcmc_detmath_dev(int which, const double* x, double* out, int64_t n, uint64_t seed,
                       void* hip_stream);
 

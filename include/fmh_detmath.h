@@ -177,6 +177,43 @@ FMH_HD double fmh_exp(double x) {
   return y * fmh_u2d((uint64_t)(1023 + k) << 52);
 }
 
+/* log1p(exp(a)) for a <= 0 -- the softplus tail of the logistic log-likelihood.  BITWISE equal to fmh_log1p(fmh_exp(a)):
+ * on the common range -745.13 <= a <= -2^-28 it is the same arithmetic written as straight-line code (selects instead of the
+ * special-case branches, which cannot trigger there: exp(a) is in [0, 1), so 1 + exp(a) is a normal number in [1, 2)); any
+ * other argument (tiny |a|, underflow, NaN, a > 0) takes the general functions. */
+FMH_HD double fmh_log1p_exp_nonpos(double a) {
+  const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
+               P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06,
+               P5 = 4.13813679705723846039e-08;
+  if (!(a <= -3.7252902984619140625e-09) || a < -745.13321910194110842) return fmh_log1p(fmh_exp(a));
+  /* ---- e = fmh_exp(a), a < 0 */
+  double t0 = fmh_fma(a, FMH_K(FMH_INV_LN2), -0.5);
+  int k = (int)t0;
+  double dk = (double)k;
+  double hi = fmh_fma(-dk, FMH_K(FMH_LN2_HI), a);
+  double lo = dk * FMH_K(FMH_LN2_LO);
+  double r = hi - lo;
+  double t = r * r;
+  double c = r - t * fmh_fma(t, fmh_fma(t, fmh_fma(t, fmh_fma(t, FMH_K(P5), FMH_K(P4)), FMH_K(P3)), FMH_K(P2)), FMH_K(P1));
+  double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+  const int deep = (k < -1000);
+  y = deep ? y * fmh_u2d(0x0360000000000000ull) : y; /* 2^-969 */
+  k = deep ? k + 969 : k;
+  double e = y * fmh_u2d((uint64_t)(1023 + k) << 52);
+  /* ---- fmh_log1p(e), 0 <= e < 1 */
+  double u = 1.0 + e;
+  double cc = e - (u - 1.0); /* Fast2Sum error of the addition (|e| < 1) */
+  uint64_t ux = fmh_d2u(u);
+  uint32_t hx = (uint32_t)(ux >> 32);
+  int k2 = (int)(hx >> 20) - 1023;
+  hx &= 0x000fffffu;
+  uint32_t ih = (hx + 0x95f64u) & 0x100000u;
+  uint64_t um = ((uint64_t)(hx | (ih ^ 0x3ff00000u)) << 32) | (ux & 0xffffffffull);
+  k2 += (int)(ih >> 20);
+  double l = fmh_log_core_(fmh_u2d(um) - 1.0, k2, cc / u);
+  return (e < 5.551115123125783e-17) ? e : l; /* |x| < 2^-54: log1p(x) = x */
+}
+
 /* Standard normal quantile, Wichura AS 241 (PPND16). p in (0,1). */
 FMH_HD double fmh_qnorm(double p) {
   double q = p - 0.5;

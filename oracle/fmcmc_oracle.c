@@ -958,6 +958,8 @@ void fmcmc_oracle_detmath(int which, const double* x, double* out, int64_t n) {
       case 1: out[i] = fmh_exp(x[i]); break;
       case 2: out[i] = fmh_log1p(x[i]); break;
       case 3: out[i] = fmh_qnorm(x[i]); break;
+      case 9: out[i] = fmh_log1p(fmh_exp(x[i])); break;       /* the SPEC the fused device routine must equal */
+      case 11: out[i] = fmh_log1p_exp_nonpos(x[i]); break;    /* the fused routine itself, host build */
       default: out[i] = NAN;
     }
   }
@@ -977,6 +979,7 @@ void fmcmc_oracle_detmath_rng(int which, const double* x, double* out, int64_t n
       case 6: out[i] = fmh_student_t(seed, step, chain, j, x[i]); break;
       case 7: out[i] = fmh_sqrt(x[i]); break;
       case 8: out[i] = 1.0 / x[i]; break;
+      case 10: out[i] = fmh_unif(seed, step, chain, j); break;
       default: out[i] = NAN;
     }
   }

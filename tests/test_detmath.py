@@ -82,3 +82,20 @@ def test_canonical_draws_are_sane(O):
     # counter-based: same index -> same value, different chain -> different value
     assert L.fmcmc_oracle_canon_draw(1, 7, 10, 3, 0, 0.0) == L.fmcmc_oracle_canon_draw(1, 7, 10, 3, 0, 0.0)
     assert L.fmcmc_oracle_canon_draw(1, 7, 10, 3, 0, 0.0) != L.fmcmc_oracle_canon_draw(1, 7, 10, 4, 0, 0.0)
+
+
+def test_fused_log1p_exp_equals_the_composition(O):
+    """fmh_log1p_exp_nonpos (straight-line softplus tail used by the logistic device code) == fmh_log1p(fmh_exp(x)) bitwise
+    on 2M points of x <= 0 incl. the edges of its fast range; it is also within 2 ulp of libm's log1p(exp(x))."""
+    rng = np.random.default_rng(5)
+    x = np.concatenate([-np.exp(rng.uniform(-45, 6.7, 2_000_000)), -rng.uniform(0, 40, 500_000),
+                        [-0.0, 0.0, -745.2, -746.0, -3.7252902984619140625e-09, -3.7252902984619145e-09, -745.13321910194110842,
+                         -745.1332191019412, -700.0, -709.0, -1000 * np.log(2), np.nan, 2.0]])
+    x = np.ascontiguousarray(x)
+    a, b = np.empty_like(x), np.empty_like(x)
+    O.lib().fmcmc_oracle_detmath(9, O._p(x), O._p(a), x.size)
+    O.lib().fmcmc_oracle_detmath(11, O._p(x), O._p(b), x.size)
+    assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+    ok = np.isfinite(x) & (x <= 0) & (x > -700)
+    ref = np.log1p(np.exp(x[ok]))
+    assert np.max(np.abs(a[ok] - ref) / np.maximum(np.spacing(ref), 5e-324)) <= 2.0

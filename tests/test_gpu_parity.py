@@ -86,7 +86,11 @@ def test_detmath_device_equals_host(E, O):
              2: np.concatenate([rng.uniform(-0.999, 50, n // 2), rng.uniform(-1e-3, 1e-3, n // 2)]),
              3: np.concatenate([rng.uniform(0, 1, n // 2), np.exp(rng.uniform(-36, 0, n // 2))]),
              4: np.zeros(n), 5: np.zeros(n), 6: rng.integers(1, 60, n).astype(np.float64),
-             7: np.exp(rng.uniform(-700, 700, n)), 8: np.exp(rng.uniform(-700, 700, n))}
+             7: np.exp(rng.uniform(-700, 700, n)), 8: np.exp(rng.uniform(-700, 700, n)),
+             # fused log1p(exp(x)), x <= 0: bulk, the tiny-|x| and underflow edges, and a few out-of-contract points
+             9: np.concatenate([-np.exp(rng.uniform(-45, 6.7, n - 8)), [-0.0, 0.0, -745.2, -746.0, -3.7252902984619140625e-09,
+                                                                        -745.13321910194110842, np.nan, 1.5]]),
+             10: np.zeros(n)}
     for which, x in cases.items():
         x = np.ascontiguousarray(x)
         xd = torch.as_tensor(x).cuda()
@@ -95,7 +99,7 @@ def test_detmath_device_equals_host(E, O):
         assert rc == 0
         torch.cuda.synchronize()
         host = np.empty(n)
-        if which < 4:
+        if which < 4 or which == 9:
             O.lib().fmcmc_oracle_detmath(which, O._p(x), O._p(host), n)
         else:
             O.lib().fmcmc_oracle_detmath_rng(which, O._p(x), O._p(host), n, 99)
