@@ -299,6 +299,10 @@ __device__ __forceinline__ void eval_partials(const SweepArgs& A, double* const*
     // Memory-level parallelism: the data comes from L2 (latency ~1 us under load), so every thread keeps a
     // batch of JB independent column loads in flight before the FMAs that consume them; a dependent
     // load-use chain per (observation, column) left < 16 KB in flight per CU (10x below the L2 rate at k = 50).
+    // Measured (tools/bench_cw.py, k = 50, 512 chains): 2 chains per workgroup is the optimum (59 us per step; 1: 114,
+    // 4: 70, 8: 120), i.e. the loop is bound by load latency + FMA issue per CU (~65 GB/s per CU of the 154 GB/s L1 fill
+    // rate), not by aggregate L2 bandwidth; a second batch in flight (double-buffered xb) spills in this all-kinds kernel
+    // and is 12 % slower.
     constexpr int JB = 8;
     for (long long i = tid; i < n; i += NT) {
       double mu[CW];
@@ -2496,6 +2500,8 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
     cw = 4;
   } else {
     while (cw < NW && (long long)cw * ncu < run->nchains) cw <<= 1;
+    const char* cwenv = getenv("FMCMC_AMD_CW");   // diagnosis: chains per workgroup of the streamed kernel (1, 2, 4, 8)
+    if (cwenv && (cwenv[0] == '1' || cwenv[0] == '2' || cwenv[0] == '4' || cwenv[0] == '8')) cw = cwenv[0] - '0';
   }
   int tb = 32;
   while (tb > 1 && sweep_lds_bytes(kn->k, kf, kn->kind, cw, tb, A.kz, resident) > 60 * 1024) tb >>= 1;
