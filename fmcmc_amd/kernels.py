@@ -40,6 +40,41 @@ def process_bounds(bounds, is_lower=True):
     return b
 
 
+def plan_update_sequence(k, nsteps, fixed, scheme, rng=None):
+    """R/kernel.R:66-133: logical [nsteps x k] plan of which parameters each step updates.  Host utility (the device derives
+    the same plan on the fly); scheme = "random" draws with numpy here -- inside MCMC() the plan comes from the engine's
+    counter-based stream (or from R's sample() in a fed replay)."""
+    fixed = check_dimensions(fixed, k, "fixed").astype(bool)
+    free = np.nonzero(~fixed)[0]
+    plan = np.zeros((nsteps, k), dtype=bool)
+    rows = np.arange(nsteps)
+    if not isinstance(scheme, str) and np.size(scheme) > 1:
+        seq = np.asarray(scheme, dtype=np.int64).reshape(-1)
+        if seq.size != free.size:
+            raise ValueError("When setting the update scheme, it should have the same length as the number of variables that "
+                             "will not be fixed. Right now length(scheme) = %d while sum(!fixed) = %d." % (seq.size, free.size))
+        missing = [int(w) + 1 for w in free if (w + 1) not in seq]
+        if missing:
+            raise ValueError("One or more variables was not included in the ordering sequence. The full list follows: %s. "
+                             "Only variables that are not fixed can be included in this list." % ", ".join(map(str, missing)))
+        plan[rows, (seq - 1)[rows % seq.size]] = True
+    elif scheme == "joint":
+        plan[:, free] = True
+    elif scheme == "ordered":
+        if free.size:
+            plan[rows, free[rows % free.size]] = True
+    elif scheme == "random":
+        pool = np.arange(free[0] + 1) if free.size == 1 else free      # sample(x) with length-one x means 1:x in R
+        if free.size:
+            plan[rows, (rng or np.random.default_rng()).choice(pool, nsteps)] = True
+    else:
+        raise ValueError("-scheme- update must be either an integer sequence, 'joint', 'ordered', or 'random'.")
+    if nsteps and plan[0].sum() == 0:
+        raise ValueError("The number of parameters to update, i.e. not fixed, cannot be zero. "
+                         "Check the value -fixed- in the kernel initialization.")
+    return plan
+
+
 class _KernelView:
     """kernel[[i]] of an fmcmc_kernel_list: one chain's state."""
 

@@ -136,6 +136,7 @@ class _Output:
     def clear(self):
         self.logpost, self.draws, self.elapsed, self.nchains = None, None, None, 0
         self.accept_count, self.kernel = None, None
+        self.info = {}            # the call's arguments, R/mcmc.R:443-455 (get_nsteps(), get_seed(), ...)
 
 
 MCMC_OUTPUT = _Output()
@@ -159,6 +160,29 @@ def get_draws():
 
 def get_elapsed():
     return MCMC_OUTPUT.elapsed
+
+
+def get_(x):
+    """R/mcmc_info.R:301-315: an argument of the last MCMC() call (or logpost / draws / elapsed)."""
+    if x in ("logpost", "draws", "elapsed"):
+        return {"logpost": get_logpost, "draws": get_draws, "elapsed": get_elapsed}[x]()
+    if x not in MCMC_OUTPUT.info:
+        raise RuntimeError("-%s- not found in MCMC_OUTPUT." % x)
+    return MCMC_OUTPUT.info[x]
+
+
+def _getter(name):
+    def g():
+        return get_(name)
+    g.__name__ = "get_" + name
+    g.__doc__ = "R/mcmc_info.R:317-400: `%s` of the last MCMC() call." % name
+    return g
+
+
+get_initial, get_fun, get_nsteps, get_seed, get_nchains, get_burnin, get_thin, get_kernel, get_multicore, \
+    get_conv_checker, get_cl, get_progress, get_chain_id = (_getter(n) for n in (
+        "initial", "fun", "nsteps", "seed", "nchains", "burnin", "thin", "kernel", "multicore", "conv_checker", "cl",
+        "progress", "chain_id"))
 
 
 # ------------------------------------------------------------------------------ sharding (one process per GPU)
@@ -337,6 +361,9 @@ def MCMC(initial, fun, nsteps, *, seed=None, nchains=1, burnin=0, thin=1, kernel
         seed = _seed_counter[0]
     if kernel is None:
         kernel = kernel_normal()
+    MCMC_OUTPUT.info = dict(initial=initial, fun=fun, nsteps=nsteps, seed=seed, nchains=nchains, burnin=burnin, thin=thin,
+                            kernel=kernel, multicore=multicore, conv_checker=conv_checker, cl=cl, progress=progress,
+                            chain_id=chain_id)
     if conv_checker is not None:
         ans = MCMC_with_conv_checker(initial, fun, nsteps, nchains, burnin, thin, kernel, multicore, conv_checker,
                                      cl, progress, chain_id, seed=seed, device=device, _return_device=_return_device)

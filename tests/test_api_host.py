@@ -158,3 +158,21 @@ def test_reflect_on_boundaries_matches_oracle(O):
         O.lib().fmcmc_oracle_reflect(O._p(ref), O._p(lb), O._p(ub), w32.ctypes.data_as(C.POINTER(C.c_int32)), 3, O.MATH_R)
         assert np.allclose(got, ref, atol=1e-12) and got[1] == x[1]
         assert np.all(got[which] >= lb[which]) and np.all(got[which] <= ub[which])
+
+
+def test_plan_update_sequence_matches_the_reference_rules():
+    """R/kernel.R:66-133: row r (1-based) of "ordered" / explicit plans updates seq[(r - 1) mod len]."""
+    P = f.plan_update_sequence
+    assert P(3, 4, False, "joint").all() and not P(3, 4, [False, True, False], "joint")[:, 1].any()
+    o = P(3, 5, [False, True, False], "ordered")
+    assert [list(np.nonzero(r)[0]) for r in o] == [[0], [2], [0], [2], [0]]
+    e = P(3, 5, False, [2, 1, 3])
+    assert [int(np.nonzero(r)[0][0]) for r in e] == [1, 0, 2, 1, 0]
+    r = P(4, 200, [False, True, False, False], "random", rng=np.random.default_rng(1))
+    assert np.all(r.sum(axis=1) == 1) and not r[:, 1].any() and r[:, [0, 2, 3]].any(axis=0).all()
+    with pytest.raises(ValueError, match="cannot be zero"):
+        P(2, 3, True, "joint")
+    with pytest.raises(ValueError, match="same length"):
+        P(3, 3, False, [1, 2])
+    with pytest.raises(ValueError, match="-scheme- update must be"):
+        P(3, 3, False, "sideways")

@@ -276,3 +276,16 @@ def test_mcmc_api_uniform_kernel_random_scheme_autostop(E, O, readme_data):
     a3 = f.MCMC([0, 0, O.r_sd(y)], f.gaussian_linreg(X, y), 600, seed=2, kernel=f.kernel_ram(freq=2, constr=M))
     r3 = O.run(O.Model(O.FAM_LINREG, X, y), O.Kernel(O.K_RAM, 3, freq=2, constr=M), [0, 0, O.r_sd(y)], nsteps=600, seed=2)
     assert np.array_equal(_bits(a3.data), _bits(r3.samples[0]))
+
+
+def test_mcmc_output_accessors(E, O, readme_data):
+    """R/mcmc_info.R:301-400: get_*() return the arguments of the last MCMC() call."""
+    import fmcmc_amd as f
+    X, y = readme_data
+    kern = f.kernel_normal(scale=0.05)
+    f.MCMC([0, 0, 4.0], f.gaussian_linreg(X, y), 300, seed=9, kernel=kern, burnin=20, thin=2)
+    assert f.get_nsteps() == 300 and f.get_seed() == 9 and f.get_burnin() == 20 and f.get_thin() == 2 and f.get_nchains() == 1
+    assert f.get_kernel() is kern and f.get_("nsteps") == 300 and f.get_conv_checker() is None and f.get_elapsed() > 0
+    assert len(f.get_("logpost")) == 140
+    with pytest.raises(RuntimeError, match="not found in MCMC_OUTPUT"):
+        f.get_("userdata")
