@@ -1,7 +1,7 @@
 """fmcmc_amd: MI355X-native many-chain Metropolis-Hastings engine, a drop-in for the hot path of
 USCbiostats/fmcmc (MCMC(), kernel_*(), convergence_gelman()).  See DESIGN.md / INTEGRATION.md."""
 from .kernels import (kernel_normal, kernel_normal_reflective, kernel_adapt, kernel_am, kernel_ram, kernel_unif,
-                      kernel_unif_reflective, fmcmc_kernel, plan_update_sequence, check_dimensions, process_bounds)
+                      kernel_unif_reflective, kernel_nmirror, kernel_umirror, fmcmc_kernel, plan_update_sequence, check_dimensions, process_bounds)
 from .models import gaussian_linreg, logistic, iid_normal, LogPosterior
 from .mcmc import (MCMC, MCMC_without_conv_checker, MCMC_with_conv_checker, Mcmc, McmcList, check_initial,
                    append_chains, get_logpost, get_draws, get_elapsed, shard_bounds, DeviceChains, get_, get_initial,
@@ -12,7 +12,7 @@ from .recursive import cov_recursive, mean_recursive, reflect_on_boundaries
 
 __all__ = ["MCMC", "MCMC_without_conv_checker", "MCMC_with_conv_checker", "kernel_normal",
            "kernel_normal_reflective", "kernel_adapt", "kernel_am", "kernel_ram", "kernel_unif",
-           "kernel_unif_reflective", "gaussian_linreg",
+           "kernel_unif_reflective", "kernel_nmirror", "kernel_umirror", "gaussian_linreg",
            "logistic", "iid_normal", "convergence_gelman", "Mcmc", "McmcList", "check_initial",
            "append_chains", "get_logpost", "get_draws", "get_elapsed", "shard_bounds", "cov_recursive", "mean_recursive",
            "reflect_on_boundaries", "plan_update_sequence", "get_", "get_initial", "get_fun", "get_nsteps", "get_seed",

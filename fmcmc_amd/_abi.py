@@ -10,7 +10,9 @@ _dp = C.POINTER(C.c_double)
 
 FAM_GAUSSIAN_LINREG, FAM_LOGISTIC, FAM_IID_NORMAL = 1, 2, 3
 KERNEL_NORMAL, KERNEL_NORMAL_REFLECTIVE, KERNEL_ADAPT, KERNEL_RAM, KERNEL_UNIF, KERNEL_UNIF_REFLECTIVE = 1, 2, 3, 4, 5, 6
-SIMPLE_KERNELS = (KERNEL_NORMAL, KERNEL_NORMAL_REFLECTIVE, KERNEL_UNIF, KERNEL_UNIF_REFLECTIVE)
+KERNEL_NMIRROR, KERNEL_UMIRROR = 7, 8
+MIRROR_KERNELS = (KERNEL_NMIRROR, KERNEL_UMIRROR)
+SIMPLE_KERNELS = (KERNEL_NORMAL, KERNEL_NORMAL_REFLECTIVE, KERNEL_UNIF, KERNEL_UNIF_REFLECTIVE) + MIRROR_KERNELS
 SCHEME_JOINT, SCHEME_ORDERED, SCHEME_RANDOM, SCHEME_EXPLICIT = 0, 1, 2, 3
 ABI_VERSION = 2
 RNG_PHILOX, RNG_FED = 0, 1
@@ -35,7 +37,7 @@ class Kernel(C.Structure):
                 ("lb", C.c_void_p), ("ub", C.c_void_p), ("fixed", C.c_void_p), ("scheme", C.c_int32),
                 ("freq", C.c_int32), ("warmup", C.c_int32), ("bw", C.c_int32), ("until", C.c_double),
                 ("eps", C.c_double), ("arate", C.c_double), ("Sd", C.c_double),
-                ("scheme_seq", C.c_void_p), ("scheme_len", C.c_int32), ("reserved", C.c_int32),
+                ("scheme_seq", C.c_void_p), ("scheme_len", C.c_int32), ("nadapt", C.c_int32),
                 ("constr", C.c_void_p)]
 
 
@@ -50,7 +52,8 @@ class State(C.Structure):
     _fields_ = [("theta0", C.c_void_p), ("f0", C.c_void_p), ("abs_iter", C.c_void_p),
                 ("Sigma", C.c_void_p), ("mean_prev", C.c_void_p), ("have_mean", C.c_void_p),
                 ("nerrors", C.c_void_p), ("fresh", C.c_int32), ("reserved", C.c_int32),
-                ("scheme_cols", C.c_void_p)]
+                ("scheme_cols", C.c_void_p), ("mirror_mu", C.c_void_p), ("mirror_scale", C.c_void_p),
+                ("obs_arate", C.c_void_p)]
 
 
 class Out(C.Structure):

@@ -61,6 +61,10 @@ struct SweepArgs {
   const int* scheme_seq;     // [scheme_len] 0-based parameter indices (device)
   const double* constr;      // ram: [kf][kf] mask or NULL (device)
   int* scheme_cols;          // [C][nsteps] plan of scheme = "random": in (FED) / out (PHILOX), or NULL
+  int nadapt;                // mirror kernels: abs_iter of the one-off scale adaptation
+  double* mirror_mu;         // [C][k] in/out
+  double* mirror_scale;      // [C][k] in/out
+  double* obs_arate;         // [C] out (in when continuing)
   int bw;                    // adapt: window (0 = recursive)
   int hist_rows;             // adapt with bw > 0 / freq > 1: rows of the ring below (max(freq, bw - 1)), else 0
   double Sd;                 // adapt, bw > 0
@@ -194,12 +198,15 @@ struct ChainLds {
   double* SigA;  // [kf*LD]
   double* SigB;  // [kf*LD] adapt: Cholesky factor; ram: the other buffer of S
   double* sc;    // scalars: 0 f0, 1 f1
+  double* mmu;   // [k] mirror kernels: adapted mean
+  double* msc;   // [k] mirror kernels: adapted scale
 };
 
 __host__ __device__ inline int chain_lds_doubles(int k, int kf, int kind) {
   int LD = kf | 1;
   int mats = (kind == FMCMC_KERNEL_ADAPT || kind == FMCMC_KERNEL_RAM) ? 2 * kf * LD : 0;
-  return 2 * k + 5 * kf + mats + 4;
+  int mir = (kind == FMCMC_KERNEL_NMIRROR || kind == FMCMC_KERNEL_UMIRROR) ? 2 * k : 0;
+  return 2 * k + 5 * kf + mats + 4 + mir;
 }
 
 __device__ __forceinline__ ChainLds chain_lds(double* base, int k, int kf, int kind) {
@@ -216,6 +223,8 @@ __device__ __forceinline__ ChainLds chain_lds(double* base, int k, int kf, int k
   int mats = (kind == FMCMC_KERNEL_ADAPT || kind == FMCMC_KERNEL_RAM) ? kf * LD : 0;
   c.SigB = c.SigA + mats;
   c.sc = c.SigB + mats;
+  c.mmu = c.sc + 4;
+  c.msc = c.mmu + k;
   return c;
 }
 
@@ -503,6 +512,9 @@ __global__ __launch_bounds__(NT) void mh_sweep_kernel(const SweepArgs A0) {
   long long abs_iter = 0, nacc = 0;
   int have_mean = 0, nerr = 0, status = FMCMC_CHAIN_OK;
   unsigned int bitword = 0;
+  const bool mirror = (A.kind == FMCMC_KERNEL_NMIRROR || A.kind == FMCMC_KERNEL_UMIRROR);
+  double obs_arate = fmh_nan();   // mirror kernels
+  long long nzero = 0;            // rows 2..i-1 of this call equal to their predecessor (rowSums(diff(ans)^2) == 0)
   double* Scur = L.SigA;   // ram: current factor buffer
   double* Salt = L.SigB;
 
@@ -511,6 +523,13 @@ __global__ __launch_bounds__(NT) void mh_sweep_kernel(const SweepArgs A0) {
       double t = A.theta0[cl * k + lane];
       L.th0[lane] = t;
       L.th1[lane] = t;
+    }
+    if (mirror) {
+      if (lane < k) {
+        L.mmu[lane] = A.fresh ? A.mu[lane] : A.mirror_mu[cl * k + lane];
+        L.msc[lane] = A.fresh ? A.scale[lane] : A.mirror_scale[cl * k + lane];
+      }
+      if (!A.fresh) { abs_iter = A.abs_iter[cl]; obs_arate = A.obs_arate[cl]; }
     }
     if (adaptive) {
       if (A.fresh) {
@@ -636,6 +655,50 @@ __global__ __launch_bounds__(NT) void mh_sweep_kernel(const SweepArgs A0) {
           if (refl) t = reflect1(t, s_lb[j], s_ub[j]);
           L.th1[j] = t;
         }
+      } else if (mirror) {
+        // R/kernel_mirror.R:66-131 (nmirror), :203-262 (umirror); twin of the oracle's propose_mirror
+        if (abs_iter >= 1 && abs_iter <= A.warmup && lane < k)   // mu <<- mean_recursive(ans[i-1, ], mu, abs_iter)
+          L.mmu[lane] = (L.mmu[lane] * (double)abs_iter + L.th0[lane]) / ((double)abs_iter + 1);
+        if (abs_iter == A.nadapt) {   // the one-off scale adaptation (the closure reads its argument `nadapt`)
+          obs_arate = 1.0 - (double)nzero / (double)(i - 2);
+          const double num = fmh_tan_0_halfpi(1.5707963267948966 * obs_arate);
+          const double den = fmh_tan_0_halfpi(1.5707963267948966 * A.arate);
+          if (lane < k) L.msc[lane] = L.msc[lane] * num / den;
+        }
+        if (lane < k) L.th1[lane] = L.th0[lane];
+        wave_sync();
+        const bool single = (A.scheme != FMCMC_SCHEME_JOINT);
+        int col = 0;
+        if (A.scheme == FMCMC_SCHEME_ORDERED) {
+          col = s_which[ord];
+        } else if (A.scheme == FMCMC_SCHEME_EXPLICIT) {
+          col = A.scheme_seq[(i - 1) % A.scheme_len];
+        } else if (A.scheme == FMCMC_SCHEME_RANDOM) {
+          if (A.rng_mode == FMCMC_RNG_FED) {
+            col = A.scheme_cols[cl * A.nsteps + (i - 1)];
+          } else {
+            const unsigned int npool = (kf == 1) ? (unsigned int)(s_which[0] + 1) : (unsigned int)kf;
+            const unsigned int idx = fmh_scheme_index(A.seed, (unsigned int)i, cgid, npool);
+            col = (kf == 1) ? (int)idx : s_which[idx];
+            if (A.scheme_cols && lane == 0) A.scheme_cols[cl * A.nsteps + (i - 1)] = col;
+          }
+        }
+        const int nupd = single ? 1 : kf;
+        if (lane < nupd) {
+          const int j = single ? col : s_which[lane];
+          const double z = zt[lane];
+          double t;
+          if (A.kind == FMCMC_KERNEL_NMIRROR) {
+            t = (2.0 * L.mmu[j] - L.th0[j]) + L.msc[j] * z;
+          } else {   // runif(k, 2 mu - theta[which.] -+ sqrt3 scale): mu / scale of the a-th updated parameter are [a], as in R
+            const double sqrt3 = fmh_sqrt(3.0);
+            const double c = 2.0 * L.mmu[lane] - L.th0[j];
+            const double lo = c - sqrt3 * L.msc[lane], hi = c + sqrt3 * L.msc[lane];
+            t = lo + (hi - lo) * z;
+          }
+          L.th1[j] = reflect1(t, s_lb[j], s_ub[j]);
+        }
+        abs_iter += 1;
       } else if (A.kind == FMCMC_KERNEL_ADAPT) {
         // R/kernel_adapt.R:117-166
         if (A.until > (double)abs_iter && abs_iter > A.warmup && i > 2 && (i % A.freq) == 0) {
@@ -832,12 +895,20 @@ __global__ __launch_bounds__(NT) void mh_sweep_kernel(const SweepArgs A0) {
         if (lane < k) A.status_theta[cl * k + lane] = L.th1[lane];
       } else {
         const double lu = s_lu[myc * TB + tt];
+        bool moved = false;
         if (lu < ratio) {
+          if (mirror) {   // rowSums(diff(ans)^2) of the row about to be stored (sequential sum, as in the oracle)
+            double sq = 0.0;
+            for (int a = 0; a < k; a++) sq = sq + (L.th1[a] - L.th0[a]) * (L.th1[a] - L.th0[a]);
+            moved = (sq != 0.0);
+            wave_sync();
+          }
           if (lane < k) L.th0[lane] = L.th1[lane];
           f0 = f1;
           nacc += 1;
           bitword |= (1u << ((i - 1) & 31));
         }
+        if (mirror && !moved) nzero += 1;
         wave_sync();
         store_row(i, f1);
         if (A.kind == FMCMC_KERNEL_ADAPT && lane < kf) L.vrs[lane] = L.vrs[lane] + L.th0[s_which[lane]];
@@ -858,11 +929,16 @@ __global__ __launch_bounds__(NT) void mh_sweep_kernel(const SweepArgs A0) {
       A.f0[cl] = f0;
       A.accept_count[cl] = nacc;
       if (status == FMCMC_CHAIN_OK) { A.status[cl] = FMCMC_CHAIN_OK; A.status_step[cl] = 0; }
+      if (mirror) { A.abs_iter[cl] = abs_iter; A.obs_arate[cl] = obs_arate; }
       if (adaptive) {
         A.abs_iter[cl] = abs_iter;
         if (A.nerrors) A.nerrors[cl] = nerr;
         if (A.kind == FMCMC_KERNEL_ADAPT) A.have_mean[cl] = have_mean;
       }
+    }
+    if (mirror && lane < k) {
+      A.mirror_mu[cl * k + lane] = L.mmu[lane];
+      A.mirror_scale[cl * k + lane] = L.msc[lane];
     }
     if (adaptive) {
       wave_sync();
@@ -2302,6 +2378,7 @@ __global__ void detmath_kernel(int which, const double* x, double* out, long lon
     case 8: r = 1.0 / v; break;
     case 9: r = fmh_log1p_exp_nonpos(v); break;   // the fused softplus tail of the logistic family
     case 10: r = fmh_unif(seed, (unsigned)(i & 0xffff), (unsigned)(i >> 16), (unsigned)(i % 7)); break;
+    case 12: r = fmh_tan_0_halfpi(v); break;
     default: r = fmh_nan();
   }
   out[i] = r;
@@ -2345,7 +2422,7 @@ static int count_free(const fmcmc_kernel* kn, const uint8_t* fixed_host) {
 // R/kernel_normal.R:134-135). Pointers inside `kernel` must be HOST pointers here.
 static bool is_simple_kind(int kind) {
   return kind == FMCMC_KERNEL_NORMAL || kind == FMCMC_KERNEL_NORMAL_REFLECTIVE || kind == FMCMC_KERNEL_UNIF ||
-         kind == FMCMC_KERNEL_UNIF_REFLECTIVE;
+         kind == FMCMC_KERNEL_UNIF_REFLECTIVE || kind == FMCMC_KERNEL_NMIRROR || kind == FMCMC_KERNEL_UMIRROR;
 }
 static int variates_per_step(const fmcmc_kernel* kn, int kf) {  // single-parameter schemes draw one variate per step
   return (is_simple_kind(kn->kind) && kn->scheme != FMCMC_SCHEME_JOINT) ? 1 : kf;
@@ -2379,7 +2456,7 @@ int fmcmc_validate(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_run
     return FMCMC_ERR_ARG;
   }
   if (m->n < 1) { set_err("the model needs at least one observation"); return FMCMC_ERR_ARG; }
-  if (kn->kind < FMCMC_KERNEL_NORMAL || kn->kind > FMCMC_KERNEL_UNIF_REFLECTIVE) {
+  if (kn->kind < FMCMC_KERNEL_NORMAL || kn->kind > FMCMC_KERNEL_UMIRROR) {
     set_err("unknown kernel kind %d", kn->kind);
     return FMCMC_ERR_ARG;
   }
@@ -2444,8 +2521,15 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
   fmcmc_kernel ke = *kn_in;
   if (ke.kind == FMCMC_KERNEL_UNIF) { ke.kind = FMCMC_KERNEL_NORMAL; A.variate = 1; }
   if (ke.kind == FMCMC_KERNEL_UNIF_REFLECTIVE) { ke.kind = FMCMC_KERNEL_NORMAL_REFLECTIVE; A.variate = 1; }
+  if (ke.kind == FMCMC_KERNEL_UMIRROR) A.variate = 1;
+  const bool mirror = (ke.kind == FMCMC_KERNEL_NMIRROR || ke.kind == FMCMC_KERNEL_UMIRROR);
+  if (mirror && (!st->mirror_mu || !st->mirror_scale || !st->obs_arate || !st->abs_iter)) {
+    set_err("mirror kernels need state->mirror_mu, mirror_scale, obs_arate and abs_iter");
+    return FMCMC_ERR_ARG;
+  }
+  A.nadapt = kn_in->nadapt; A.mirror_mu = st->mirror_mu; A.mirror_scale = st->mirror_scale; A.obs_arate = st->obs_arate;
   const fmcmc_kernel* kn = &ke;
-  if (kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE && kn->scheme == FMCMC_SCHEME_RANDOM && run->rng_mode == FMCMC_RNG_FED &&
+  if ((kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE || mirror) && kn->scheme == FMCMC_SCHEME_RANDOM && run->rng_mode == FMCMC_RNG_FED &&
       !st->scheme_cols) {
     set_err("rng_mode = FED with scheme = 'random' needs state->scheme_cols");
     return FMCMC_ERR_ARG;
@@ -2485,7 +2569,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
   // register-resident variant: Gaussian linreg whose data fits the VGPR budget of 512 threads
   int res_p = -1, res_opt = 0;
   const char* force = getenv("FMCMC_AMD_FORCE_STREAMED");
-  if (!(force && force[0] == '1') && m->family == FMCMC_FAM_GAUSSIAN_LINREG) {
+  if (!(force && force[0] == '1') && m->family == FMCMC_FAM_GAUSSIAN_LINREG && !mirror) {
     static const int variants[][2] = {{1, 4}, {3, 20}};
     for (auto& v : variants)
       if (m->p == v[0] && m->n > (long long)NT * (v[1] - RES_MASKED) && m->n <= (long long)NT * v[1]) {
@@ -2786,6 +2870,7 @@ int fmcmc_mcmc_run_host(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcm
   const int64_t C = run->nchains, S = fmcmc_kept_rows(run->nsteps, run->burnin, run->thin);
   const int64_t nwords = (run->nsteps + 31) / 32;
   const bool adaptive = (kn->kind == FMCMC_KERNEL_ADAPT || kn->kind == FMCMC_KERNEL_RAM);
+  const bool mirror_h = (kn->kind == FMCMC_KERNEL_NMIRROR || kn->kind == FMCMC_KERNEL_UMIRROR);
   std::vector<void*> allocs;
   auto dalloc = [&](size_t bytes) -> void* {
     void* p = nullptr;
@@ -2830,6 +2915,17 @@ int fmcmc_mcmc_run_host(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcm
   }
   UP(ds.theta0, st->theta0, sizeof(double) * (size_t)C * k);
   UP(ds.f0, (double*)nullptr, sizeof(double) * (size_t)C);
+  if (mirror_h) {
+    if (!st->mirror_mu || !st->mirror_scale || !st->obs_arate || !st->abs_iter) {
+      set_err("mirror kernels need state->mirror_mu, mirror_scale, obs_arate and abs_iter");
+      rc = FMCMC_ERR_ARG;
+      goto done;
+    }
+    UP(ds.abs_iter, st->fresh ? nullptr : st->abs_iter, sizeof(int64_t) * (size_t)C);
+    UP(ds.mirror_mu, st->fresh ? nullptr : st->mirror_mu, sizeof(double) * (size_t)C * k);
+    UP(ds.mirror_scale, st->fresh ? nullptr : st->mirror_scale, sizeof(double) * (size_t)C * k);
+    UP(ds.obs_arate, st->fresh ? nullptr : st->obs_arate, sizeof(double) * (size_t)C);
+  }
   if (adaptive) {
     UP(ds.abs_iter, st->fresh ? nullptr : st->abs_iter, sizeof(int64_t) * (size_t)C);
     UP(ds.Sigma, st->fresh ? nullptr : st->Sigma, sizeof(double) * (size_t)C * kf * kf);
@@ -2854,6 +2950,12 @@ int fmcmc_mcmc_run_host(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcm
 #define DOWN(dst, src, bytes) HCHK(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, stream))
   DOWN(st->theta0, ds.theta0, sizeof(double) * (size_t)C * k);
   DOWN(st->f0, ds.f0, sizeof(double) * (size_t)C);
+  if (mirror_h) {
+    DOWN(st->abs_iter, ds.abs_iter, sizeof(int64_t) * (size_t)C);
+    DOWN(st->mirror_mu, ds.mirror_mu, sizeof(double) * (size_t)C * k);
+    DOWN(st->mirror_scale, ds.mirror_scale, sizeof(double) * (size_t)C * k);
+    DOWN(st->obs_arate, ds.obs_arate, sizeof(double) * (size_t)C);
+  }
   if (adaptive) {
     DOWN(st->abs_iter, ds.abs_iter, sizeof(int64_t) * (size_t)C);
     DOWN(st->Sigma, ds.Sigma, sizeof(double) * (size_t)C * kf * kf);

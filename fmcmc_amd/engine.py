@@ -71,7 +71,8 @@ class KernelSpec:
     """Expanded (recycled) kernel parameters on the device (fmcmc_kernel)."""
 
     def __init__(self, kind, k, mu, scale, lb, ub, fixed, scheme=abi.SCHEME_JOINT, freq=1, warmup=0,
-                 bw=0, until=float("inf"), eps=1e-4, arate=0.234, Sd=0.0, scheme_seq=None, constr=None, device=None):
+                 bw=0, until=float("inf"), eps=1e-4, arate=0.234, Sd=0.0, scheme_seq=None, constr=None, nadapt=4,
+                 device=None):
         self.device = _dev(device)
         self.kind, self.k = int(kind), int(k)
         self.h_fixed = np.ascontiguousarray(np.asarray(fixed, dtype=np.uint8))
@@ -83,6 +84,7 @@ class KernelSpec:
         self.fixed = _t(self.h_fixed, torch.uint8, self.device)
         self.scheme, self.freq, self.warmup, self.bw = int(scheme), int(freq), int(warmup), int(bw)
         self.until, self.eps, self.arate, self.Sd = float(until), float(eps), float(arate), float(Sd)
+        self.nadapt = int(nadapt)
         # explicit update sequence: 0-based parameter indices (R/kernel.R:69-92); ram: constr[which., which.] mask
         self.scheme_seq = None if scheme_seq is None else _t(np.asarray(scheme_seq, dtype=np.int32), torch.int32, self.device)
         self.constr = None if constr is None else _t(np.asarray(constr, dtype=np.float64).reshape(self.kf, self.kf),
@@ -98,7 +100,7 @@ class KernelSpec:
                           self.ub.data_ptr(), self.fixed.data_ptr(), self.scheme, self.freq, self.warmup,
                           self.bw, self.until, self.eps, self.arate, self.Sd,
                           self.scheme_seq.data_ptr() if self.scheme_seq is not None else None,
-                          int(self.scheme_seq.numel()) if self.scheme_seq is not None else 0, 0,
+                          int(self.scheme_seq.numel()) if self.scheme_seq is not None else 0, self.nadapt,
                           self.constr.data_ptr() if self.constr is not None else None)
 
 
@@ -118,6 +120,10 @@ class ChainState:
         self.have_mean = torch.zeros(Cn, dtype=torch.int32, **z)
         self.nerrors = torch.zeros(Cn, dtype=torch.int32, **z)
         self.scheme_cols = None   # [C][nsteps] int32: plan of scheme = "random" (fmcmc_state.scheme_cols)
+        k = self.theta0.shape[1]
+        self.mirror_mu = torch.zeros(Cn, k, dtype=torch.float64, **z)      # mirror kernels: adapted mean / scale
+        self.mirror_scale = torch.zeros(Cn, k, dtype=torch.float64, **z)
+        self.obs_arate = torch.full((Cn,), float("nan"), dtype=torch.float64, **z)
         self.fresh = 1
         self.step_base = 0
 
@@ -130,7 +136,8 @@ class ChainState:
         self._cols_keep = cols
         return abi.State(self.theta0.data_ptr(), self.f0.data_ptr(), self.abs_iter.data_ptr(),
                          self.Sigma.data_ptr(), self.mean_prev.data_ptr(), self.have_mean.data_ptr(),
-                         self.nerrors.data_ptr(), self.fresh, 0, cols.data_ptr() if cols is not None else None)
+                         self.nerrors.data_ptr(), self.fresh, 0, cols.data_ptr() if cols is not None else None,
+                         self.mirror_mu.data_ptr(), self.mirror_scale.data_ptr(), self.obs_arate.data_ptr())
 
 
 class SweepResult:
@@ -212,7 +219,7 @@ def rng_stream(state, kernel, nsteps, seed=0, chain_base=0, logu=None, z=None, s
     with torch.cuda.device(dev):
         rc = L.fmcmc_rng_stream_dev(seed & 0xFFFFFFFFFFFFFFFF, state.step_base, chain_base, Cn, nsteps, kz,
                                     kernel.kf if kernel.kind == abi.KERNEL_RAM else
-                                    (-1 if kernel.kind in (abi.KERNEL_UNIF, abi.KERNEL_UNIF_REFLECTIVE) else 0),
+                                    (-1 if kernel.kind in (abi.KERNEL_UNIF, abi.KERNEL_UNIF_REFLECTIVE, abi.KERNEL_UMIRROR) else 0),
                                     logu.data_ptr(), z.data_ptr(),
                                     C.c_void_p(stream.cuda_stream))
     if rc != abi.OK:

@@ -5,6 +5,7 @@
   kernel_adapt / kernel_am R/kernel_adapt.R:54-208
   kernel_ram               R/kernel_ram.R:65-181
   kernel_unif / kernel_unif_reflective   R/kernel_unif.R:42-91, :96-170
+  kernel_nmirror / kernel_umirror        R/kernel_mirror.R:3-138, :140-283
   plan_update_sequence     R/kernel.R:66-133 (scheme = "joint" | "ordered" | "random" | integer sequence)
   check_dimensions / process_bounds   R/kernel.R:3-41
 
@@ -94,6 +95,9 @@ class _KernelView:
             return st.mean_prev[i].cpu().numpy()
         if name == "nerrors":
             return int(st.nerrors[i].item()) if st is not None else 0
+        if p.kind in abi.MIRROR_KERNELS and st is not None and name in ("mu", "scale", "obs_arate"):
+            t = {"mu": st.mirror_mu, "scale": st.mirror_scale, "obs_arate": st.obs_arate}[name][i]
+            return t.cpu().numpy() if t.ndim else float(t.item())
         return getattr(p, name)
 
 
@@ -120,7 +124,7 @@ class fmcmc_kernel:
             self.mu, self.scale = self.min_, self.max_ - self.min_
         else:
             self.mu = check_dimensions(self.mu, k, "mu").astype(np.float64)
-            if self.kind in (abi.KERNEL_NORMAL, abi.KERNEL_NORMAL_REFLECTIVE):
+            if self.kind in (abi.KERNEL_NORMAL, abi.KERNEL_NORMAL_REFLECTIVE) + abi.MIRROR_KERNELS:
                 self.scale = check_dimensions(self.scale, k, "scale").astype(np.float64)
             else:
                 self.scale = np.ones(k)
@@ -180,7 +184,7 @@ class fmcmc_kernel:
                           warmup=getattr(self, "warmup", 0), bw=getattr(self, "bw", 0), until=until,
                           eps=getattr(self, "eps", 1e-4), arate=getattr(self, "arate", 0.234),
                           Sd=getattr(self, "Sd", 0.0) or 0.0, scheme_seq=getattr(self, "_scheme_seq", None),
-                          constr=constr, device=device)
+                          constr=constr, nadapt=getattr(self, "nadapt", 4), device=device)
 
     def state_for(self, initial, device):
         """Chain state for this call: the kernel's persistent part survives, theta0 := initial."""
@@ -221,7 +225,7 @@ class fmcmc_kernel:
 
     def __repr__(self):
         names = {1: "kernel_normal", 2: "kernel_normal_reflective", 3: "kernel_adapt", 4: "kernel_ram",
-                 5: "kernel_unif", 6: "kernel_unif_reflective"}
+                 5: "kernel_unif", 6: "kernel_unif_reflective", 7: "kernel_nmirror", 8: "kernel_umirror"}
         return "<fmcmc_kernel %s k=%s>" % (names[self.kind], self.k)
 
 
@@ -243,6 +247,19 @@ def kernel_unif_reflective(min_=-1.0, max_=1.0, lb=None, ub=None, fixed=False, s
     """R/kernel_unif.R:96-170; lb / ub default to min. / max. (:99-100)."""
     return fmcmc_kernel(abi.KERNEL_UNIF_REFLECTIVE, min_=min_, max_=max_, mu=0.0, lb=min_ if lb is None else lb,
                         ub=max_ if ub is None else ub, fixed=fixed, scheme=scheme)
+
+
+def kernel_nmirror(mu=0.0, scale=1.0, warmup=500, nadapt=4, arate=0.4, lb=-DBL_MAX, ub=DBL_MAX, fixed=False, scheme="joint"):
+    """R/kernel_mirror.R:3-138: theta1 ~ N(2 mu - theta0, scale^2), mu = running mean during warm-up, scale rescaled once at
+    abs_iter == nadapt by tan(pi/2 obs_arate) / tan(pi/2 arate)."""
+    return fmcmc_kernel(abi.KERNEL_NMIRROR, mu=mu, scale=scale, warmup=int(warmup), nadapt=int(nadapt), arate=arate, lb=lb, ub=ub,
+                        fixed=fixed, scheme=scheme)
+
+
+def kernel_umirror(mu=0.0, scale=1.0, warmup=500, nadapt=4, arate=0.4, lb=-DBL_MAX, ub=DBL_MAX, fixed=False, scheme="joint"):
+    """R/kernel_mirror.R:140-283: theta1 ~ U(2 mu - theta0 -+ sqrt(3) scale), same adaptation."""
+    return fmcmc_kernel(abi.KERNEL_UMIRROR, mu=mu, scale=scale, warmup=int(warmup), nadapt=int(nadapt), arate=arate, lb=lb, ub=ub,
+                        fixed=fixed, scheme=scheme)
 
 
 def kernel_adapt(mu=0.0, bw=0, lb=-DBL_MAX, ub=DBL_MAX, freq=1, warmup=500, Sigma=None, Sd=None,

@@ -71,7 +71,14 @@ enum {
   /* theta1[w] = theta0[w] + runif(min.[w], max.[w]) (R/kernel_unif.R:42-91, :96-170): the same proposal code as
    * the normal kernels with mu := min., scale := max. - min. and U(0,1) variates instead of N(0,1). */
   FMCMC_KERNEL_UNIF = 5,
-  FMCMC_KERNEL_UNIF_REFLECTIVE = 6
+  FMCMC_KERNEL_UNIF_REFLECTIVE = 6,
+  /* mirror kernels (R/kernel_mirror.R:3-138, :140-283): theta1[w] ~ N(2 mu[w] - theta0[w], scale[w]^2) resp.
+   * U(2 mu - theta0[w] -+ sqrt(3) scale); mu follows the running mean of the chain during warm-up and scale is rescaled
+   * once, when abs_iter == nadapt, by tan(pi/2 obs_arate) / tan(pi/2 arate).  (The closure reads its ARGUMENT nadapt,
+   * not the floor(seq(...)) vector stored next to it, so there is exactly one adaptation; the element-wise indexing of
+   * kernel_umirror -- mu[a], scale[a] of the a-th updated parameter -- is kept as it is in the reference.) */
+  FMCMC_KERNEL_NMIRROR = 7,
+  FMCMC_KERNEL_UMIRROR = 8
 };
 /* Update schemes of the normal / uniform kernels, plan_update_sequence (R/kernel.R:66-133).  Row i of the plan is used
  * by loop step i (R/kernel_normal.R:67); the plan is built once per kernel object for the nsteps of its first call. */
@@ -101,7 +108,7 @@ typedef struct fmcmc_kernel {
   const int32_t* scheme_seq; /* [scheme_len] FMCMC_SCHEME_EXPLICIT: 0-based parameter indices, a permutation of the
                               * free parameters (R/kernel.R:72-90); NULL otherwise */
   int32_t scheme_len;
-  int32_t reserved;
+  int32_t nadapt;       /* mirror kernels: abs_iter at which the scale is adapted (R/kernel_mirror.R:103,121) */
   const double* constr; /* ram: [kf][kf] mask multiplied element-wise into the updated factor
                          * (constr[which., which.], R/kernel_ram.R:149-150); NULL = none */
 } fmcmc_kernel;
@@ -143,6 +150,11 @@ typedef struct fmcmc_state {
    * the plan of the kernel's first call -- written here when non-NULL.  FED mode: read from here (the caller
    * replays R's sample()).  [C][nsteps] int32, or NULL. */
   int32_t* scheme_cols;
+  /* mirror kernels: the adapted mean and scale of every chain, [C][k] each, and the observed acceptance rate the one-off
+   * adaptation used, [C] (NaN before it happened); fresh == 1: initialised from kernel->mu / kernel->scale. */
+  double* mirror_mu;
+  double* mirror_scale;
+  double* obs_arate;
 } fmcmc_state;
 
 enum {

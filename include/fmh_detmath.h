@@ -214,6 +214,35 @@ FMH_HD double fmh_log1p_exp_nonpos(double a) {
   return (e < 5.551115123125783e-17) ? e : l; /* |x| < 2^-54: log1p(x) = x */
 }
 
+
+/* tan(x) for 0 <= x <= fl(pi/2): the only use is the one-off scale adaptation of the mirror kernels,
+ * scale * tan(pi/2 * obs_arate) / tan(pi/2 * arate) (R/kernel_mirror.R:121-127).  sin and cos of the argument reduced to
+ * [0, pi/4] by the standard minimax kernels (Sun fdlibm k_sin.c / k_cos.c coefficients, Horner with fma), then one division;
+ * above pi/4 the co-function identity tan(x) = cos(y) / sin(y), y = pi/2 - x with a two-term pi/2.  Accuracy ~1 ulp
+ * (tests/test_detmath.py); device bits == host bits like every routine in this header. */
+FMH_HD double fmh_sin_kernel_(double x) { /* |x| <= pi/4 */
+  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+               S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  double z = x * x;
+  double r = fmh_fma(z, fmh_fma(z, fmh_fma(z, fmh_fma(z, fmh_fma(z, FMH_K(S6), FMH_K(S5)), FMH_K(S4)), FMH_K(S3)), FMH_K(S2)), FMH_K(S1));
+  return fmh_fma(x * z, r, x);
+}
+FMH_HD double fmh_cos_kernel_(double x) { /* |x| <= pi/4 */
+  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+               C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+  double z = x * x;
+  double r = z * fmh_fma(z, fmh_fma(z, fmh_fma(z, fmh_fma(z, fmh_fma(z, FMH_K(C6), FMH_K(C5)), FMH_K(C4)), FMH_K(C3)), FMH_K(C2)), FMH_K(C1));
+  double hz = 0.5 * z;
+  double w = 1.0 - hz;
+  return w + (((1.0 - w) - hz) + z * r);
+}
+FMH_HD double fmh_tan_0_halfpi(double x) {
+  if (!(x >= 0.0) || x > 1.5707963267948966) return fmh_nan(); /* outside the contract (incl. NaN) */
+  if (x <= 0.78539816339744828) return fmh_sin_kernel_(x) / fmh_cos_kernel_(x);
+  double y = (1.57079632679489655800e+00 - x) + 6.12323399573676603587e-17; /* pi/2 = hi + lo */
+  return fmh_cos_kernel_(y) / fmh_sin_kernel_(y);
+}
+
 /* Standard normal quantile, Wichura AS 241 (PPND16). p in (0,1). */
 FMH_HD double fmh_qnorm(double p) {
   double q = p - 0.5;

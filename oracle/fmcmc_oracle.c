@@ -411,6 +411,9 @@ typedef struct {
   long double run_sum_ld[MAXK]; /* R mode */
   const int32_t* cols;         /* scheme = "random": plan of this chain, entry i-1 = column of loop step i */
   const double* hist;          /* adapt with bw > 0 / freq > 1: env$ans[, which.] of THIS call, row r at hist + (r-1)*kf */
+  double mmu[MAXK], msc[MAXK]; /* mirror kernels: adapted mean / scale (all k parameters) */
+  double obs_arate;
+  int64_t nzero;               /* rows r = 2..i-1 of this call with sum(diff(ans)[r-1, ]^2) == 0 */
 } kstate;
 
 /* draw helpers ---------------------------------------------------------------------------- */
@@ -452,7 +455,9 @@ static void propose_normal(const ocfg* cfg, const fmcmc_kernel* kn, const kstate
   const int unif = (kn->kind == FMCMC_KERNEL_UNIF || kn->kind == FMCMC_KERNEL_UNIF_REFLECTIVE);
   for (int a = 0; a < nupd; a++) {
     int j = upd[a];
-    double z = unif ? draw_unif(cfg, step, chain, (uint32_t)a) : draw_normal(cfg, step, chain, (uint32_t)a);
+    /* src/nmath/rnorm.c, runif.c: sd == 0 (a == b) returns the mean (a) WITHOUT consuming a variate */
+    const int skip = (cfg->rng_mode == ORACLE_RNG_RMT && kn->scale[j] == 0.0);
+    double z = skip ? 0.0 : (unif ? draw_unif(cfg, step, chain, (uint32_t)a) : draw_normal(cfg, step, chain, (uint32_t)a));
     theta1[j] = theta1[j] + (kn->mu[j] + kn->scale[j] * z);
   }
   if (kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE || kn->kind == FMCMC_KERNEL_UNIF_REFLECTIVE)
@@ -463,6 +468,59 @@ static void propose_normal(const ocfg* cfg, const fmcmc_kernel* kn, const kstate
 }
 
 /* kernel_adapt proposal (R/kernel_adapt.R:117-180), bw = 0, freq = 1. Returns chain status. */
+/* kernel_nmirror / kernel_umirror proposal (R/kernel_mirror.R:66-131, :203-262).  `i` is the loop index, ans[i-1, ] ==
+ * theta0; the plan column logic is the one of propose_normal. */
+static void propose_mirror(const ocfg* cfg, const fmcmc_kernel* kn, kstate* ks, int64_t i, uint32_t step,
+                           uint32_t chain, const double* theta0, double* theta1) {
+  const int k = kn->k;
+  const int64_t a_it = ks->abs_iter;
+  if (a_it >= 1 && a_it <= kn->warmup) /* mu <<- mean_recursive(ans[i-1, ], mu, abs_iter) :92-100 */
+    for (int a = 0; a < k; a++) ks->mmu[a] = (ks->mmu[a] * (double)a_it + theta0[a]) / ((double)a_it + 1);
+  if (a_it == kn->nadapt) {
+    /* obs_arate <<- 1 - mean(rowSums(diff(ans[1:(i-1), ])^2) == 0) :103-107 (mean of zero rows is NaN);
+     * scale <<- scale * tan(pi/2 obs_arate) / tan(pi/2 arate) :121-127 */
+    ks->obs_arate = 1.0 - (double)ks->nzero / (double)(i - 2);
+    double num, den;
+    if (cfg->math_mode == ORACLE_MATH_R) {
+      num = tan(M_PI / 2.0 * ks->obs_arate);
+      den = tan(M_PI / 2.0 * kn->arate);
+    } else {
+      num = fmh_tan_0_halfpi(1.5707963267948966 * ks->obs_arate);
+      den = fmh_tan_0_halfpi(1.5707963267948966 * kn->arate);
+    }
+    for (int a = 0; a < k; a++) ks->msc[a] = ks->msc[a] * num / den;
+  }
+  for (int a = 0; a < k; a++) theta1[a] = theta0[a];
+  int upd[MAXK], nupd = 0;
+  if (kn->scheme == FMCMC_SCHEME_ORDERED) upd[nupd++] = ks->which[(int)((i - 1) % ks->kf)];
+  else if (kn->scheme == FMCMC_SCHEME_EXPLICIT) upd[nupd++] = kn->scheme_seq[(int)((i - 1) % kn->scheme_len)];
+  else if (kn->scheme == FMCMC_SCHEME_RANDOM) upd[nupd++] = ks->cols[i - 1];
+  else for (int a = 0; a < ks->kf; a++) upd[nupd++] = ks->which[a];
+  const int rmt = (cfg->rng_mode == ORACLE_RNG_RMT);
+  for (int a = 0; a < nupd; a++) {
+    const int j = upd[a];
+    if (kn->kind == FMCMC_KERNEL_NMIRROR) {
+      /* rnorm(k, mean = 2 mu[which.] - theta0[which.], sd = scale[which.]) :113-117 */
+      const double mean = 2.0 * ks->mmu[j] - theta0[j], sd = ks->msc[j];
+      const double z = (rmt && sd == 0.0) ? 0.0 : draw_normal(cfg, step, chain, (uint32_t)a);
+      theta1[j] = mean + sd * z;
+    } else {
+      /* runif(k, min = 2 mu - theta1[which.] - sqrt3 scale, max = ... + sqrt3 scale) :246-250: mu and scale are NOT
+       * subset, so the a-th updated parameter reads mu[a], scale[a] (recycling rules of runif) */
+      const double sqrt3 = (cfg->math_mode == ORACLE_MATH_R) ? sqrt(3.0) : fmh_sqrt(3.0);
+      const double c = 2.0 * ks->mmu[a] - theta0[j];
+      const double lo = c - sqrt3 * ks->msc[a], hi = c + sqrt3 * ks->msc[a];
+      const double u = (rmt && lo == hi) ? 0.0 : draw_unif(cfg, step, chain, (uint32_t)a);
+      theta1[j] = lo + (hi - lo) * u;
+    }
+  }
+  ks->abs_iter += 1;
+  for (int a = 0; a < nupd; a++) {
+    const int j = upd[a];
+    theta1[j] = reflect1(theta1[j], kn->lb[j], kn->ub[j], cfg->math_mode);
+  }
+}
+
 /* stats::cov of N rows (src/library/stats/src/cov.c, cov_complete1, pearson): long-double column means refined by a
  * second pass, then long-double sums of cross products over (N - 1). */
 static void r_cov(const double* X, int N, int k, double* out) {
@@ -686,8 +744,9 @@ int fmcmc_oracle_run(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_r
   if (run->burnin >= run->nsteps || run->thin >= run->nsteps || run->thin < 1) return FMCMC_ERR_ARG;
   if (kn->kind == FMCMC_KERNEL_ADAPT && (kn->freq < 1 || kn->bw < 0 || (kn->bw > 0 && kn->bw > kn->warmup))) return FMCMC_ERR_ARG;
   if (kn->kind == FMCMC_KERNEL_RAM && kn->freq < 1) return FMCMC_ERR_ARG;
+  const int mirror = (kn->kind == FMCMC_KERNEL_NMIRROR || kn->kind == FMCMC_KERNEL_UMIRROR);
   const int simple = (kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE ||
-                      kn->kind == FMCMC_KERNEL_UNIF || kn->kind == FMCMC_KERNEL_UNIF_REFLECTIVE);
+                      kn->kind == FMCMC_KERNEL_UNIF || kn->kind == FMCMC_KERNEL_UNIF_REFLECTIVE || mirror);
   if (simple && kn->scheme == FMCMC_SCHEME_EXPLICIT && (!kn->scheme_seq || kn->scheme_len < 1)) return FMCMC_ERR_ARG;
   ocfg cfg; cfg.rng_mode = rng_mode; cfg.math_mode = math_mode; cfg.g = g; cfg.seed = run->seed;
   const int64_t C = run->nchains, nsteps = run->nsteps;
@@ -734,6 +793,17 @@ int fmcmc_oracle_run(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_r
     }
     double theta0[MAXK], theta1[MAXK];
     for (int a = 0; a < k; a++) theta0[a] = theta1[a] = st->theta0[c * k + a];
+    if (mirror) {
+      ks.nzero = 0;
+      if (st->fresh) {
+        for (int a = 0; a < k; a++) { ks.mmu[a] = kn->mu[a]; ks.msc[a] = kn->scale[a]; }
+        ks.obs_arate = NAN;
+      } else {
+        for (int a = 0; a < k; a++) { ks.mmu[a] = st->mirror_mu[c * k + a]; ks.msc[a] = st->mirror_scale[c * k + a]; }
+        ks.obs_arate = st->obs_arate[c];
+        ks.abs_iter = st->abs_iter[c];
+      }
+    }
 
     /* R <- log(runif(nsteps)) drawn up front (R/mcmc.R:726); R[1] is never used */
     if (rng_mode == ORACLE_RNG_RMT)
@@ -789,7 +859,9 @@ int fmcmc_oracle_run(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_r
     for (int64_t i = 2; i <= nsteps; i++) {
       const uint32_t step = (uint32_t)(run->step_base + i);
       int status = FMCMC_CHAIN_OK;
-      if (simple)
+      if (mirror)
+        propose_mirror(&cfg, kn, &ks, i, step, chain, theta0, theta1);
+      else if (simple)
         propose_normal(&cfg, kn, &ks, i, step, chain, theta0, theta1);
       else if (kn->kind == FMCMC_KERNEL_ADAPT)
         status = propose_adapt(&cfg, kn, &ks, i, step, chain, theta0, theta1);
@@ -809,13 +881,26 @@ int fmcmc_oracle_run(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_r
         break;
       }
       double lu = (rng_mode == ORACLE_RNG_RMT) ? logu[i] : fmh_log_accept_u(cfg.seed, step, chain);
+      int moved = 0;
       if (lu < ratio) { /* strict < :770 */
+        if (mirror) { /* rowSums(diff(ans)^2) of the row about to be stored */
+          if (math_mode == ORACLE_MATH_R) {
+            long double sq = 0.0L;
+            for (int a = 0; a < k; a++) sq += (long double)((theta1[a] - theta0[a]) * (theta1[a] - theta0[a]));
+            moved = (sq != 0.0L);
+          } else {
+            double sq = 0.0;
+            for (int a = 0; a < k; a++) sq = sq + (theta1[a] - theta0[a]) * (theta1[a] - theta0[a]);
+            moved = (sq != 0.0);
+          }
+        }
         for (int a = 0; a < k; a++) theta0[a] = theta1[a];
         f0 = f1;
         nacc++;
         if (bits) bits[(i - 1) >> 5] |= (1u << ((i - 1) & 31));
       }
       STORE_ROW(i, theta0, theta1, f1);
+      if (mirror && !moved) ks.nzero += 1;
       if (hist) for (int a = 0; a < kf; a++) hist[(i - 1) * kf + a] = theta0[ks.which[a]]; /* row i */
       for (int a = 0; a < kf; a++) {
         ks.run_sum[a] = ks.run_sum[a] + theta0[ks.which[a]];
@@ -826,6 +911,11 @@ int fmcmc_oracle_run(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_r
     /* write state back */
     for (int a = 0; a < k; a++) st->theta0[c * k + a] = theta0[a];
     st->f0[c] = f0;
+    if (mirror) {
+      for (int a = 0; a < k; a++) { st->mirror_mu[c * k + a] = ks.mmu[a]; st->mirror_scale[c * k + a] = ks.msc[a]; }
+      st->obs_arate[c] = ks.obs_arate;
+      st->abs_iter[c] = ks.abs_iter;
+    }
     if (kn->kind == FMCMC_KERNEL_ADAPT || kn->kind == FMCMC_KERNEL_RAM) {
       memcpy(st->Sigma + c * kf * kf, ks.Sigma, sizeof(double) * kf * kf);
       st->abs_iter[c] = ks.abs_iter;
@@ -960,6 +1050,7 @@ void fmcmc_oracle_detmath(int which, const double* x, double* out, int64_t n) {
       case 3: out[i] = fmh_qnorm(x[i]); break;
       case 9: out[i] = fmh_log1p(fmh_exp(x[i])); break;       /* the SPEC the fused device routine must equal */
       case 11: out[i] = fmh_log1p_exp_nonpos(x[i]); break;    /* the fused routine itself, host build */
+      case 12: out[i] = fmh_tan_0_halfpi(x[i]); break;
       default: out[i] = NAN;
     }
   }

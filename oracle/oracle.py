@@ -23,7 +23,7 @@ RNG_PHILOX, RNG_RMT = 0, 1
 MATH_CANON, MATH_R = 0, 1
 
 FAM_LINREG, FAM_LOGISTIC, FAM_IID_NORMAL = 1, 2, 3
-K_NORMAL, K_NORMAL_REFLECTIVE, K_ADAPT, K_RAM, K_UNIF, K_UNIF_REFLECTIVE = 1, 2, 3, 4, 5, 6
+K_NORMAL, K_NORMAL_REFLECTIVE, K_ADAPT, K_RAM, K_UNIF, K_UNIF_REFLECTIVE, K_NMIRROR, K_UMIRROR = 1, 2, 3, 4, 5, 6, 7, 8
 SCHEME_JOINT, SCHEME_ORDERED, SCHEME_RANDOM, SCHEME_EXPLICIT = 0, 1, 2, 3
 DBL_MAX = np.finfo(np.float64).max
 
@@ -40,7 +40,7 @@ class CKernel(C.Structure):
                 ("ub", _dp), ("fixed", C.POINTER(C.c_uint8)), ("scheme", C.c_int32),
                 ("freq", C.c_int32), ("warmup", C.c_int32), ("bw", C.c_int32), ("until", C.c_double),
                 ("eps", C.c_double), ("arate", C.c_double), ("Sd", C.c_double),
-                ("scheme_seq", C.POINTER(C.c_int32)), ("scheme_len", C.c_int32), ("reserved", C.c_int32),
+                ("scheme_seq", C.POINTER(C.c_int32)), ("scheme_len", C.c_int32), ("nadapt", C.c_int32),
                 ("constr", _dp)]
 
 
@@ -55,7 +55,7 @@ class CState(C.Structure):
     _fields_ = [("theta0", _dp), ("f0", _dp), ("abs_iter", C.POINTER(C.c_int64)), ("Sigma", _dp),
                 ("mean_prev", _dp), ("have_mean", C.POINTER(C.c_int32)),
                 ("nerrors", C.POINTER(C.c_int32)), ("fresh", C.c_int32), ("reserved", C.c_int32),
-                ("scheme_cols", C.POINTER(C.c_int32))]
+                ("scheme_cols", C.POINTER(C.c_int32)), ("mirror_mu", _dp), ("mirror_scale", _dp), ("obs_arate", _dp)]
 
 
 class COut(C.Structure):
@@ -237,7 +237,7 @@ def _rec(x, k, name):
 class Kernel:
     def __init__(self, kind, k, mu=0.0, scale=1.0, lb=-DBL_MAX, ub=DBL_MAX, fixed=False,
                  scheme="joint", freq=1, warmup=None, bw=0, until=np.inf, eps=1e-4, arate=0.234,
-                 Sd=None, constr=None, min_=None, max_=None):
+                 Sd=None, constr=None, min_=None, max_=None, nadapt=4):
         self.kind, self.k = kind, k
         if kind in (K_UNIF, K_UNIF_REFLECTIVE):   # R/kernel_unif.R: runif(k, min., max.) = min. + (max. - min.) * u
             mn = _f64(_rec(-1.0 if min_ is None else min_, k, "min."))
@@ -268,9 +268,11 @@ class Kernel:
             self.scheme = SCHEME_EXPLICIT
         else:
             self.scheme = {"joint": SCHEME_JOINT, "ordered": SCHEME_ORDERED, "random": SCHEME_RANDOM}[scheme]
-        self.freq, self.bw = int(freq), int(bw)
+        self.freq, self.bw, self.nadapt = int(freq), int(bw), int(nadapt)
         if warmup is None:
-            warmup = 500 if kind == K_ADAPT else 0
+            warmup = 500 if kind in (K_ADAPT, K_NMIRROR, K_UMIRROR) else 0
+        if kind in (K_NMIRROR, K_UMIRROR) and arate == 0.234:
+            arate = 0.4                                   # default of the mirror kernels (R/kernel_mirror.R:8)
         self.warmup, self.until, self.eps, self.arate = int(warmup), float(until), float(eps), float(arate)
         self.kf = int((self.fixed == 0).sum())
         self.Sd = float(Sd) if Sd is not None else 5.76 / max(self.kf, 1)
@@ -286,7 +288,7 @@ class Kernel:
                      self.fixed.ctypes.data_as(C.POINTER(C.c_uint8)), self.scheme, self.freq,
                      self.warmup, self.bw, self.until, self.eps, self.arate, self.Sd,
                      self.scheme_seq.ctypes.data_as(C.POINTER(C.c_int32)) if self.scheme_seq is not None else None,
-                     0 if self.scheme_seq is None else int(self.scheme_seq.size), 0,
+                     0 if self.scheme_seq is None else int(self.scheme_seq.size), self.nadapt,
                      _p(self.constr) if self.constr is not None else None)
         return kk
 
@@ -304,6 +306,8 @@ class ChainState:
         self.have_mean = np.zeros(Cn, dtype=np.int32)
         self.nerrors = np.zeros(Cn, dtype=np.int32)
         self.scheme_cols = None   # [C][nsteps] int32 plan of scheme = "random" (set by run())
+        self.mirror_mu, self.mirror_scale = np.zeros((Cn, k)), np.zeros((Cn, k))
+        self.obs_arate = np.full(Cn, np.nan)
         self.fresh = 1
         self.step_base = 0
 
@@ -312,7 +316,8 @@ class ChainState:
                       _p(self.Sigma), _p(self.mean_prev),
                       self.have_mean.ctypes.data_as(C.POINTER(C.c_int32)),
                       self.nerrors.ctypes.data_as(C.POINTER(C.c_int32)), self.fresh, 0,
-                      self.scheme_cols.ctypes.data_as(C.POINTER(C.c_int32)) if self.scheme_cols is not None else None)
+                      self.scheme_cols.ctypes.data_as(C.POINTER(C.c_int32)) if self.scheme_cols is not None else None,
+                      _p(self.mirror_mu), _p(self.mirror_scale), _p(self.obs_arate))
 
 
 def _as_initial(initial, nchains):

@@ -289,3 +289,18 @@ def test_mcmc_output_accessors(E, O, readme_data):
     assert len(f.get_("logpost")) == 140
     with pytest.raises(RuntimeError, match="not found in MCMC_OUTPUT"):
         f.get_("userdata")
+
+
+def test_mcmc_api_mirror_kernels(E, O, readme_data):
+    """kernel_nmirror / kernel_umirror through MCMC(): per-chain views of the adapted mean and scale like kernel[[i]]$mu in R."""
+    import fmcmc_amd as f
+    X, y = readme_data
+    init = np.tile([3.0, 2.0, 4.0], (3, 1)) + 0.05 * np.random.default_rng(1).standard_normal((3, 3))
+    for ctor, kind in ((f.kernel_nmirror, O.K_NMIRROR), (f.kernel_umirror, O.K_UMIRROR)):
+        kw = dict(mu=[3.0, 2.0, 4.0], scale=0.2, warmup=300, nadapt=5, lb=[-20, -20, 0.05], ub=20.0)
+        kern = ctor(**kw)
+        ans = f.MCMC(init, f.gaussian_linreg(X, y), 800, seed=17, nchains=3, kernel=kern)
+        ro = O.run(O.Model(O.FAM_LINREG, X, y), O.Kernel(kind, 3, **kw), init, nsteps=800, seed=17)
+        assert np.array_equal(_bits(ans.as_array()), _bits(ro.samples))
+        assert np.array_equal(_bits(kern[2].mu), _bits(ro.state.mirror_mu[1])) and kern[3].obs_arate == ro.state.obs_arate[2]
+        assert list(kern.abs_iter) == [799] * 3 and abs(ans.as_array()[:, 300:, 0].mean() - 3.1) < 0.6

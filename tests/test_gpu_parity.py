@@ -36,7 +36,7 @@ def run_both(E, O, fam, X, y, kind, k, initial, nsteps, burnin=0, thin=1, seed=1
     gm = E.DeviceModel(fam, X, y, intercept=intercept, guard=guard, prior_div=prior_div)
     gk = E.KernelSpec(kind, k, ok.mu, ok.scale, ok.lb, ok.ub, ok.fixed, scheme=ok.scheme, freq=ok.freq,
                       warmup=ok.warmup, bw=ok.bw, until=ok.until, eps=ok.eps, arate=ok.arate, Sd=ok.Sd,
-                      scheme_seq=ok.scheme_seq, constr=ok.constr)
+                      scheme_seq=ok.scheme_seq, constr=ok.constr, nadapt=ok.nadapt)
     initial = np.ascontiguousarray(initial, dtype=np.float64)
     ost = O.ChainState(initial, ok.kf)
     gst = E.ChainState(initial, ok.kf)
@@ -61,6 +61,11 @@ def run_both(E, O, fam, X, y, kind, k, initial, nsteps, burnin=0, thin=1, seed=1
             assert np.array_equal(gst.abs_iter.cpu().numpy(), ost.abs_iter)
             assert _bits_equal(gst.Sigma.cpu().numpy(), ost.Sigma), "Sigma"
             assert np.array_equal(gst.nerrors.cpu().numpy(), ost.nerrors)
+        if kind in (O.K_NMIRROR, O.K_UMIRROR):
+            assert np.array_equal(gst.abs_iter.cpu().numpy(), ost.abs_iter)
+            assert _bits_equal(gst.mirror_mu.cpu().numpy(), ost.mirror_mu), "mirror mu"
+            assert _bits_equal(gst.mirror_scale.cpu().numpy(), ost.mirror_scale), "mirror scale"
+            assert _bits_equal(gst.obs_arate.cpu().numpy(), ost.obs_arate), "obs_arate"
         if ok.scheme == O.SCHEME_RANDOM:
             assert np.array_equal(gst.scheme_cols.cpu().numpy()[:, 1:nsteps], ost.scheme_cols[:, 1:nsteps]), "update plan"
         if kind == O.K_ADAPT:
@@ -416,3 +421,22 @@ def test_adapt_window_and_stride(E, O, C, n, p, bw, freq, warmup):
         assert np.array_equal(r2g.status_step.cpu().numpy(), r2o.status_step)
         with pytest.raises(RuntimeError, match="subscript out of bounds"):
             E.raise_on_chain_error(r2g)
+
+
+@pytest.mark.parametrize("kind_name", ["nmirror", "umirror"])
+@pytest.mark.parametrize("C,n,p,scheme,fixed", [(5, 800, 2, "joint", False), (4, 10000, 3, "joint", False),
+                                                 (6, 600, 2, "ordered", [False, True, False, False]),
+                                                 (3, 900, 1, "random", False), (4, 1700, 1, "joint", [True, False, False])])
+def test_mirror_kernels(E, O, kind_name, C, n, p, scheme, fixed):
+    """R/kernel_mirror.R: running-mean mirror point, one-off tan() rescaling at abs_iter == nadapt, state carried into a
+    second call (mu, scale, abs_iter, obs_arate)."""
+    X, y = synth_linreg(n, p, 91 + n)
+    k = p + 2
+    base = [0.5] * (p + 1) + [float(np.std(y))]
+    init = jitter_init(base, C, 8)
+    kind = O.K_NMIRROR if kind_name == "nmirror" else O.K_UMIRROR
+    rg, ro = run_both(E, O, O.FAM_LINREG, X, y, kind, k, init, nsteps=160, calls=2, mu=base, scale=0.15, warmup=120, nadapt=6,
+                      lb=[-30.0] * (p + 1) + [0.05], ub=30.0, scheme=scheme, fixed=fixed)
+    q = ro.state.obs_arate
+    assert np.all(np.isfinite(q)) and np.allclose(q * 6, np.round(q * 6))          # multiples of 1 / nadapt
+    assert np.all(ro.state.abs_iter == 318)

@@ -261,3 +261,54 @@ def test_adapt_window_and_stride_oracle(O):
     with pytest.raises(ValueError, match="warmup"):
         f.kernel_adapt(bw=40, warmup=30)
     assert f.kernel_adapt(bw=10, freq=2).bw == 10
+
+
+@pytest.mark.parametrize("kind_name", ["nmirror", "umirror"])
+def test_mirror_kernels_replay_R_semantics(O, kind_name):
+    """R/kernel_mirror.R inside R/mcmc.R:720-838, restated independently in numpy on R's stream: mu <- running mean while
+    1 <= abs_iter <= warmup, scale rescaled once at abs_iter == nadapt (the closure's own argument), proposal
+    N(2 mu - theta0, scale) resp. U(2 mu - theta0 -+ sqrt(3) scale)."""
+    kind = O.K_NMIRROR if kind_name == "nmirror" else O.K_UMIRROR
+    rng = np.random.default_rng(3)
+    m = O.Model(O.FAM_IID_NORMAL, None, rng.normal(1.0, 2.0, 60))
+    kn = O.Kernel(kind, 2, mu=[1.0, 2.0], scale=[0.4, 0.3], warmup=30, nadapt=4, lb=[-20, 0.05], ub=20.0)
+    r = O.run(m, kn, initial=[1.0, 2.0], nsteps=80, rng_mode=O.RNG_RMT, math_mode=O.MATH_R, rng=O.RRng(6))
+    g = O.RRng(6)
+    logu = np.log(g.runif(80))
+    th0 = np.array([1.0, 2.0]); f0 = m.logpost(th0, O.MATH_R)
+    mu, scale, ans = np.array([1.0, 2.0]), np.array([0.4, 0.3]), [th0.copy()]
+    for i in range(2, 81):
+        a = i - 2
+        if 1 <= a <= 30:
+            mu = (mu * a + ans[-1]) / (a + 1)
+        if a == 4:
+            d = np.diff(np.array(ans), axis=0)
+            obs = 1.0 - np.mean((d ** 2).sum(axis=1) == 0.0)
+            scale = scale * np.tan(np.pi / 2.0 * obs) / np.tan(np.pi / 2.0 * 0.4)
+        if kind == O.K_NMIRROR:
+            th1 = (2 * mu - th0) + scale * g.rnorm(2)
+        else:
+            lo, hi = 2 * mu - th0 - np.sqrt(3.0) * scale, 2 * mu - th0 + np.sqrt(3.0) * scale
+            th1 = lo + (hi - lo) * g.runif(2)
+        ref = th1.copy()
+        w = np.array([0, 1], dtype=np.int32)
+        O.lib().fmcmc_oracle_reflect(O._p(ref), O._p(kn.lb), O._p(kn.ub), w.ctypes.data_as(C.POINTER(C.c_int32)), 2, O.MATH_R)
+        assert np.allclose(r.draws[0, i - 1], ref, rtol=1e-13, atol=1e-15), i
+        f1 = m.logpost(r.draws[0, i - 1], O.MATH_R)
+        if logu[i - 1] < f1 - f0:
+            th0, f0 = r.draws[0, i - 1].copy(), f1
+        ans.append(th0.copy())
+        assert np.array_equal(r.samples[0, i - 1], th0)
+    assert np.allclose(r.state.mirror_mu[0], mu, rtol=1e-13) and np.allclose(r.state.mirror_scale[0], scale, rtol=1e-13)
+    assert abs(r.state.obs_arate[0] - obs) < 1e-15 and r.state.abs_iter[0] == 79
+
+
+def test_mirror_kernels_sample_the_posterior(O):
+    """inst/tinytest/test-kernel_mirror.R checks posterior means; same here on the README-style regression."""
+    X, y = synth_linreg(500, 1, 4, beta=[3.0, 2.0])
+    m = O.Model(O.FAM_LINREG, X, y)
+    for kind in (O.K_NMIRROR, O.K_UMIRROR):
+        kn = O.Kernel(kind, 3, mu=[2.5, 1.5, 3.5], scale=0.3, warmup=1000, nadapt=5, lb=[-50, -50, 0.01], ub=50.0)
+        r = O.run(m, kn, initial=[[2.5, 1.5, 3.5]] * 2, nsteps=4000, seed=11)
+        post = r.samples[:, 1000:].mean(axis=(0, 1))
+        assert np.all(np.abs(post - [3.0, 2.0, 4.0]) < 0.5) and 0.05 < r.accept_count.mean() / 3999 < 0.95
