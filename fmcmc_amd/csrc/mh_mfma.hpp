@@ -1,0 +1,316 @@
+// mh_mfma.hpp -- mh_sweep_mfma<KIND, NG, NS, DBG>: the headline kernel, bit-exact fp64 MFMA evaluation.
+#pragma once
+
+namespace {
+
+// ==============================================================================================
+// MFMA evaluation kernel: Gaussian linear regression whose data fit the operand registers (p <= 3, n <= 10240 with one
+// group of K = 4; p <= 7, n <= 5120 with two chained groups).  Described below for p = 3.
+//
+// v_mfma_f64_4x4x4_4b_f64 on gfx950 (measured, tools/mfma64_exact.hip): k = lane / 16; inside a 16-lane group the
+// A operand sits at 4*blk + i, B at 4*blk + j, the result D at lane 16*i + 4*blk + j; and it is BITWISE the chain
+//     D = fma(a3, b3, fma(a2, b2, fma(a1, b1, fma(a0, b0, C)))).
+// With A = [x1, x2, x3, y], B = [b1, b2, b3, -1] and C = b0 this is exactly the canonical
+//     m = fma(x3, b3, fma(x2, b2, fma(x1, b1, b0)));   -r = fma(y, -1, m)
+// for 16 observations x 4 chains per instruction, and fma(D, D, acc) == fma(r, r, acc) bit for bit.
+// One MFMA replaces 16 x 4 x 4 = 256 VALU lane-FMAs + 64 subtractions with ONE issue slot, which lifts the
+// fp64 pipe out of the VALU issue limit (~6.2 ticks per instruction at 2 waves per SIMD).
+//
+// Mapping that keeps the canonical reduction: wave w owns canonical lanes 64w..64w+63; MFMA t = 4*s + g covers
+// slot s (observations i = lane + 512 s) of lanes 64w + 16g + o, o = 4*blk + i_row; result lane L holds chain
+// j = L % 4 of canonical lane 64w + 16g + 4*((L/4)%4) + L/16, accumulated in acc[g] in slot order; the four
+// accumulators are written to the same transposed partial tile the owners fold with the canonical tree.
+// All four chains of the workgroup are evaluated together, so this kernel is not chain-pipelined: a step is
+// evaluation | barrier | 4 owner phases in parallel (waves 0..3, priority raised) | barrier.
+// ==============================================================================================
+constexpr int MF_NMF = 80;   // MFMAs per wave per step: 20 slots x 4 lane groups
+// chain stride of the partial tiles: here one ds_write_b64 carries 4 chains x 16 canonical lanes; with the row stride
+// 66 the 16 lanes of a write group land on double-banks {0,8,1,9} + 2*(l&7), so a chain stride == 2 (mod 16) spreads the
+// four chains over all 16 double-banks (8*66 = 528 == 0 mod 16 made every write a 4-way conflict)
+constexpr int MF_TCS = 8 * PIPE_TRS + 2;
+
+// DBG is a TEMPLATE parameter on purpose: the MFMA loop is sensitive to every live register (fewer free VGPRs = fewer
+// MFMA results in flight before their dependent fma); stamp code that is merely disabled at run time cost 13 %.
+// Shapes: NG groups of K = 4 carry up to 4*NG - 1 covariates plus y (unused k-slots are zero: fma(0, 0, acc) == acc
+// exactly), the 80 operand registers of a lane hold 20 / NG observation slots, i.e. NG = 1: p <= 3, n <= 10240;
+// NG = 2: p <= 7, n <= 5120.  The number of observation slots NS = ceil(n / 512) is a TEMPLATE parameter: with a run-time
+// count every batch of MFMAs becomes a basic block, the scheduler can no longer overlap the FMAs of one batch with the
+// MFMAs of the next, and the step is 22 % slower (measured).  Only the last slot holds padding and pays for masks.
+template <int KIND, int NG, int NS, bool DBG>
+__global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
+  constexpr int CW = 4;
+  constexpr int MB = 8;             // (slot, lane group) pairs per batch = 2 observation slots
+  constexpr int TN = NS * 4;        // pairs held per lane and group (NG * TN <= MF_NMF registers)
+  static_assert(NG * TN <= MF_NMF, "operand registers");
+  extern __shared__ double smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int k = A.k, kz = A.kz;
+  double* s_th1 = smem;                            // [CW][PIPE_KMAX]
+  double* s_par = s_th1 + CW * PIPE_KMAX;          // [4][PIPE_KMAX]
+  double* s_tr = s_par + 4 * PIPE_KMAX;            // [CW][MF_TCS] transposed partial tiles, chain stride 530
+  const long long cg0 = (long long)blockIdx.x * CW;
+  const int ncw = (int)((A.nchains - cg0 < CW) ? (A.nchains - cg0) : CW);
+  const int nsteps = (int)A.nsteps, burnin = (int)A.burnin, thin = (int)A.thin;
+  const int ic = A.intercept;
+
+  // ---- A operand: feature kf_ = lane / 16 of observation (64 w + 16 g + lane % 16) + 512 s, for t = 4 s + g
+  const int feat = lane >> 4, o16 = lane & 15;
+  const int P = A.p;
+  double areg[NG][TN];
+#pragma unroll
+  for (int q = 0; q < NG; q++) {
+    const int f = 4 * q + feat;   // column of [x_1 .. x_P, y, 0 ..] this lane feeds as operand A of group q
+#pragma unroll
+    for (int t = 0; t < TN; t++) {
+      const int sl = t >> 2, g = t & 3;
+      const long long i = (long long)(64 * wave + 16 * g + o16) + (long long)NT * sl;
+      double a = 0.0;
+      if (i < A.n) {
+        if (f < P) a = A.X[(long long)f * A.n + i];
+        else if (f == P) a = A.y[i];
+      }
+      areg[q][t] = a;
+    }
+  }
+  // result lane L: chain j = L % 4, canonical lane 64 w + 16 g + 4*((L/4)%4) + L/16
+  const int jch = lane & 3;
+  const int cl_in_g = 4 * ((lane >> 2) & 3) + (lane >> 4);
+  unsigned vbits = 0;    // validity of this lane's 4 results in the LAST slot (all earlier slots are full)
+  int trs[4];            // transposed tile slot of this lane's canonical lane, per group
+#pragma unroll
+  for (int g = 0; g < 4; g++) {
+    const int l = 64 * wave + 16 * g + cl_in_g;
+    trs[g] = (l & 7) * PIPE_TRS + (l >> 3);
+    if ((long long)l + (long long)NT * (NS - 1) < A.n) vbits |= 1u << g;
+  }
+  if (tid < k) {
+    s_par[0 * PIPE_KMAX + tid] = A.mu[tid];
+    s_par[1 * PIPE_KMAX + tid] = A.scale[tid];
+    s_par[2 * PIPE_KMAX + tid] = A.lb[tid];
+    s_par[3 * PIPE_KMAX + tid] = A.ub[tid];
+  }
+  if (tid < CW * PIPE_KMAX) {
+    const int c = tid / PIPE_KMAX, j = tid - c * PIPE_KMAX;
+    s_th1[tid] = (c < ncw && j < k) ? A.theta0[(cg0 + c) * k + j] : 0.0;
+  }
+
+  // ---- owner state (waves 0..3), as in mh_sweep_spec
+  const int myc = wave;
+  const bool owner = (myc < ncw);
+  const int cl = __builtin_amdgcn_readfirstlane((int)cg0 + (owner ? myc : 0));
+  const bool plane = owner && (lane < k);
+  const int jl = (lane < k) ? lane : 0;
+  const bool fixed_l = A.fixed[jl] != 0;
+  int zidx = 0;
+  for (int j = 0; j < jl; j++) zidx += A.fixed[j] ? 0 : 1;
+  if (zidx > kz - 1) zidx = kz > 0 ? kz - 1 : 0;   // lanes without a variate of their own read a valid neighbour (value unused)
+  double th0 = plane ? A.theta0[(long long)cl * k + lane] : 0.0;
+  double th1 = th0;
+  double f0 = 0.0;
+  int nacc = 0, status = FMCMC_CHAIN_OK, thin_ctr = 0;
+  unsigned int srow8 = 0, bitword = 0;
+  const unsigned int sd_off = (unsigned int)((((long long)cl * k + jl) * A.S) * 8);
+  const unsigned int z_off = (unsigned int)((((long long)cl * nsteps) * kz + zidx) * 8);
+  const unsigned int lp_off = (unsigned int)(((long long)cl * A.S) * 8);
+  const double* const lu_row = A.fed_logu + (long long)cl * nsteps;
+  const double dn = uniform_d((double)A.n);
+  auto ld_z = [&](int row) -> double {
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(A.fed_z) + (z_off + (unsigned int)row * (unsigned int)(kz * 8)));
+  };
+  // every lane of an owner wavefront keeps one variate and the log-uniform of the next step in flight (unconditional,
+  // clamped addresses: a conditional load costs a register copy behind the load, i.e. an exposed wait)
+  double z_nx = (owner && kz > 0) ? ld_z(nsteps >= 2 ? 1 : 0) : 0.0;
+  double lu_nx = owner ? lu_row[nsteps >= 2 ? 1 : 0] : 0.0;
+  auto logpost_of = [&](double tot, double sigma) -> double {
+    double f;
+    if (sigma < 0.0 || fmh_isnan(sigma)) {
+      f = fmh_nan();
+    } else if (sigma == 0.0) {
+      f = -fmh_inf();
+    } else {
+      double t1 = fmh_log(sigma) + FMH_K(FMH_LN_SQRT_2PI);
+      double q = (0.5 * tot) / (sigma * sigma);
+      f = -(dn * t1) - q;
+    }
+    if (A.guard && !fmh_isfinite(f)) f = -fmh_inf();
+    return f;
+  };
+  auto flush_bits = [&](int i) {
+    if (A.accept_bits && lane == 0)
+      A.accept_bits[(long long)cl * ((nsteps + 31) >> 5) + ((i - 1) >> 5)] = bitword;
+    bitword = 0;
+  };
+  lds_barrier();
+
+  constexpr bool dbg = DBG;
+  bool st_keep = false;                      // row of the step just decided, stored after the barrier
+  double st_th0 = 0.0, st_th1 = 0.0, st_f1 = 0.0;
+  unsigned long long te = 0, tb1 = 0, to = 0, tb2 = 0, tf = 0, tc = 0, td = 0;
+  for (int v = 1; v <= nsteps; v++) {
+    unsigned long long t_0 = dbg ? clk() : 0;
+    // ================= evaluation of version v of all 4 chains =================
+    {
+      const double* tj = s_th1 + jch * PIPE_KMAX;
+      double bop[NG];                                            // B[k][blk][j] of group q
+#pragma unroll
+      for (int q = 0; q < NG; q++) {
+        const int f = 4 * q + feat;
+        bop[q] = (f < P) ? tj[ic + f] : (f == P ? -1.0 : 0.0);
+      }
+      const double cop = ic ? tj[0] : 0.0;                      // C = intercept of chain j
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      // batches of MB independent MFMA chains followed by their MB dependent FMAs: the result latency of one MFMA is
+      // covered by issuing the next ones, and the batch shape (not the allocator's leftovers) bounds the live results
+#pragma unroll
+      for (int t0 = 0; t0 < TN; t0 += MB) {
+        {
+          constexpr int LAST = TN - 4;             // first pair of the last slot
+          const int nu = (TN - t0 < MB) ? TN - t0 : MB;
+          double d[MB];
+          // Only the last slot has padding.  A padded observation has A = 0 in every group, so its result is the C
+          // operand: feeding 0 instead of the intercept there makes -r == 0 exactly, and the accumulation below is the
+          // same straight-line code for every batch (masking the RESULTS put selects in front of the last FMAs).
+#pragma unroll
+          for (int u = 0; u < MB; u++)
+            if (u < nu) {
+              const int t = t0 + u;
+              const double cm = (t >= LAST) ? (((vbits >> (t - LAST)) & 1u) ? cop : 0.0) : cop;
+              d[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(areg[0][t], bop[0], cm, 0, 0, 0);
+            }
+#pragma unroll
+          for (int q = 1; q < NG; q++)
+#pragma unroll
+            for (int u = 0; u < MB; u++)
+              if (u < nu) d[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(areg[q][t0 + u], bop[q], d[u], 0, 0, 0);
+          // d = -r of 16 observations x 4 chains per pair
+#pragma unroll
+          for (int u = 0; u < MB; u++)
+            if (u < nu) acc[u & 3] = fmh_fma(d[u], d[u], acc[u & 3]);
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 4; g++) s_tr[jch * (MF_TCS) + trs[g]] = acc[g];
+    }
+    // (Measured: moving log(sigma) of the owners in front of, or right behind, their MFMAs makes the step SLOWER:
+    //  fp64 VALU work issued while the SIMD partner runs MFMAs slows those -- one fp64 datapath -- whereas in
+    //  the owner phase below that datapath is idle.)
+    // sigma-only part of the closed form: the owner waves are the first of their SIMD to finish their MFMAs (the older
+    // wave wins the arbitration) and would wait ~1200 ticks at the barrier; its ~65 fp64 instructions run there, in the
+    // shadow of the partner wave's MFMAs, instead of in the exposed owner phase.  The results are wave-uniform (SGPRs).
+    double sigma = 0.0, nt1_fast = 0.0, ss_fast = 1.0;
+    bool sg_fast = false;
+    if (owner) {
+      sigma = readlane_d(th1, k - 1);
+      const unsigned sg_hi = (unsigned)(fmh_d2u(sigma) >> 32);
+      sg_fast = (sg_hi - 0x00100000u) < 0x7fe00000u;                     // positive, finite, normal
+      const double sg = sg_fast ? sigma : 1.0;
+      const double t1_fast = fmh_log_pn(sg) + FMH_K(FMH_LN_SQRT_2PI);   // same bits as fmh_log(sigma) on this range
+      nt1_fast = uniform_d(dn * t1_fast);
+      ss_fast = uniform_d(sg * sg);
+    }
+    unsigned long long t_1 = dbg ? clk() : 0;
+    lds_barrier();
+    unsigned long long t_2 = dbg ? clk() : 0;
+    // ================= owners: fold, decide, propose =================
+    if (owner) {
+      __builtin_amdgcn_s_setprio(3);
+      const double* src = s_tr + myc * (MF_TCS) + lane;
+      const double v0 = src[0 * PIPE_TRS], v1 = src[1 * PIPE_TRS], v2 = src[2 * PIPE_TRS], v3 = src[3 * PIPE_TRS];
+      const double v4 = src[4 * PIPE_TRS], v5 = src[5 * PIPE_TRS], v6 = src[6 * PIPE_TRS], v7 = src[7 * PIPE_TRS];
+      // increment of the NEXT proposal: consumes the variate fetched one step ago and refills the same register at once, so
+      // that load has a whole step to land and no vector-memory wait sits behind the decision below
+      // The only vector-memory wait of the phase sits HERE, on loads issued one whole step ago; both registers are refilled
+      // at once, so nothing younger than an evaluation is ever waited for (a wait behind the decision would also cover the
+      // refill of the variate, an HBM miss every third step).
+      double lu = lu_nx, zc = z_nx;
+      asm volatile("" : "+v"(lu), "+v"(zc));
+      lu_nx = lu_row[v < nsteps ? v : nsteps - 1];
+      if (kz > 0) z_nx = ld_z(v + 1 < nsteps ? v + 1 : nsteps - 1);
+      const double dz = (plane && !fixed_l) ? s_par[0 * PIPE_KMAX + lane] + s_par[1 * PIPE_KMAX + lane] * zc : 0.0;
+      const double tot = wave_xor_sum(((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7)));
+      unsigned long long t_a = dbg ? clk() : 0;
+      double f1;
+      if (sg_fast) {
+        f1 = -nt1_fast - (0.5 * tot) / ss_fast;
+        if (A.guard && !fmh_isfinite(f1)) f1 = -fmh_inf();
+      } else {
+        f1 = logpost_of(tot, sigma);
+      }
+      unsigned long long t_b = dbg ? clk() : 0;
+      const double th1_eval = th1;
+      bool keep_row = false;
+      if (v == 1) {
+        f0 = uniform_d(f1);
+        keep_row = true;
+      } else if (status == FMCMC_CHAIN_OK) {
+        const double ratio = f1 - f0;
+        if (fmh_isnan(f1) || fmh_isnan(ratio)) {
+          status = fmh_isnan(f1) ? FMCMC_CHAIN_NAN_LOGPOST : FMCMC_CHAIN_NAN_RATIO;
+          if (lane == 0) { A.status[cl] = status; A.status_step[cl] = v; }
+          if (plane) A.status_theta[(long long)cl * k + lane] = th1;
+          flush_bits(v);
+        } else {
+          if (lu < ratio) {
+            th0 = th1;
+            f0 = uniform_d(f1);
+            nacc += 1;
+            bitword |= (1u << ((v - 1) & 31));
+          }
+          keep_row = true;
+        }
+      }
+      unsigned long long t_c = dbg ? clk() : 0;
+      if (dbg) { tf += t_a - t_2; tc += t_b - t_a; td += t_c - t_b; }
+      const double th0_row = th0;
+      if (v < nsteps && status == FMCMC_CHAIN_OK && plane) {
+        double t = th0;
+        if (!fixed_l) {
+          t = th0 + dz;
+          if (KIND == FMCMC_KERNEL_NORMAL_REFLECTIVE) t = reflect1(t, s_par[2 * PIPE_KMAX + lane], s_par[3 * PIPE_KMAX + lane]);
+        }
+        th1 = t;
+        s_th1[myc * PIPE_KMAX + lane] = t;
+      }
+      __builtin_amdgcn_s_setprio(0);
+      st_keep = keep_row; st_th0 = th0_row; st_th1 = th1_eval; st_f1 = f1;
+    }
+    unsigned long long t_3 = dbg ? clk() : 0;
+    lds_barrier();
+    if (dbg) { unsigned long long t_4 = clk(); te += t_1 - t_0; tb1 += t_2 - t_1; to += t_3 - t_2; tb2 += t_4 - t_3; }
+    // Row stores and bookkeeping of step v happen AFTER the barrier that releases the next evaluation: the owner
+    // waves are the first of their SIMD to finish their MFMAs (~1400 ticks of slack), the stores ride in that slack
+    // instead of sitting in the exposed owner phase.
+    if (owner) {
+      if (st_keep && v > burnin) {
+        thin_ctr += 1;
+        if (thin_ctr == thin) {
+          thin_ctr = 0;
+          if (plane) {
+            *reinterpret_cast<double*>(reinterpret_cast<char*>(A.samples) + (sd_off + srow8)) = st_th0;
+            if (A.draws) *reinterpret_cast<double*>(reinterpret_cast<char*>(A.draws) + (sd_off + srow8)) = st_th1;
+          }
+          if (A.logpost && lane == 0 && !dbg) *reinterpret_cast<double*>(reinterpret_cast<char*>(A.logpost) + (lp_off + srow8)) = st_f1;
+          srow8 += 8;
+        }
+      }
+      if (status == FMCMC_CHAIN_OK && v >= 2 && (((v - 1) & 31) == 31 || v == nsteps)) flush_bits(v);
+    }
+  }
+  if (dbg && lane == 0 && A.logpost) {   // stamps leave through the logpost buffer in this diagnostic mode
+    double* d = A.logpost + (long long)A.nchains * A.S - 8 * ((long long)blockIdx.x * NW + wave + 1);
+    d[0] = (double)te; d[1] = (double)tb1; d[2] = (double)to; d[3] = (double)tb2; d[4] = (double)nsteps; d[5] = (double)tf; d[6] = (double)tc; d[7] = (double)td;
+  }
+  if (owner) {
+    if (plane) A.theta0[(long long)cl * k + lane] = th0;
+    if (lane == 0) {
+      A.f0[cl] = f0;
+      A.accept_count[cl] = nacc;
+      if (status == FMCMC_CHAIN_OK) { A.status[cl] = FMCMC_CHAIN_OK; A.status_step[cl] = 0; }
+    }
+  }
+}
+
+size_t mfma_lds_bytes() { return sizeof(double) * ((size_t)8 * PIPE_KMAX + 4 * MF_TCS); }
+
+}  // namespace

@@ -1,0 +1,793 @@
+// mh_spec.hpp -- mh_sweep_spec<P, OPT, KIND>: 8 compute + 4 owner wavefronts meeting on LDS sequence words; owner roles
+// for the normal kernels, kernel_adapt and kernel_ram (matrix rows in LDS or in registers).
+#pragma once
+
+namespace {
+
+// ==============================================================================================
+// Wave-specialised resident kernel (the headline path).
+//
+//   768 threads = 12 wavefronts per workgroup, 3 per SIMD:
+//     waves 0..7  COMPUTE: hold the x columns of their 64 canonical lanes in VGPRs (y in LDS) and do nothing
+//                 but evaluate: for version v, for chain c: wait ready[c] >= v, read theta1[c], 20 observations
+//                 x (3 fma + sub + fma), write the lane partial, arrive on done[c].
+//     waves 8..11 OWNERS (one per chain): wait done[c] == 8 v, fold the 512 partials (canonical tree), closed
+//                 form, accept, propose, prefetch, publish theta1[c] (ready[c] = v + 1), then store the row.
+//   No s_barrier in the steady state: producers/consumers meet on LDS sequence words, so an owner's
+//   latency-bound phase overlaps the evaluation of the OTHER three chains, and on every SIMD the owner's
+//   dependency stalls are filled by the two compute waves' independent FMAs (hardware multithreading instead
+//   of compiler interleaving).  Register budget: 12 waves -> 168 VGPRs; one chain per evaluation pass keeps the
+//   compute role at 120 (data) + ~30: 148 VGPRs, no scratch.
+//   FMCMC_AMD_DEBUG_MODE=8 stamps (s_memtime) flag-wait / work time per wave into the draws buffer.
+// ==============================================================================================
+constexpr int SPEC_NT = 768;
+constexpr int SPEC_NCW = 8;   // compute wavefronts
+
+__device__ __forceinline__ unsigned lds_ld_u32(const unsigned* p) {
+  unsigned v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(size_t)p) : "memory");
+  return v;
+}
+
+__device__ __forceinline__ double lds_ld_f64(const double* p) {   // ordered after a preceding flag poll
+  double v;
+  asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(size_t)p) : "memory");
+  return v;
+}
+
+
+
+constexpr int SPEC_ALD = PIPE_KMAX + 1;                       // row stride of the k x k matrices in LDS
+constexpr int SPEC_ADS = 7 * PIPE_KMAX + 2 * PIPE_KMAX * SPEC_ALD;  // doubles of adaptive state per chain
+
+// Owner role of the specialised kernel for kernel_adapt (R/kernel_adapt.R:117-180) and kernel_ram
+// (R/kernel_ram.R:123-158, unbounded parameters): same wave-collective arithmetic as mh_sweep_kernel (lanes = rows
+// of Sigma / S, twin of the oracle's propose_adapt / propose_ram), state in LDS, variates from the HBM stream.
+template <int KIND>
+__device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc, int cl, double* s_th1, double* s_par,
+                                                    unsigned* s_ready, unsigned* s_done, double* s_tr, double* ad) {
+  const int lane = threadIdx.x & 63;
+  const int k = A.k, kz = A.kz, nsteps = (int)A.nsteps, burnin = (int)A.burnin, thin = (int)A.thin;
+  constexpr int LD = SPEC_ALD;
+  double* th0 = ad;                    // [k]
+  double* th1 = th0 + PIPE_KMAX;       // [k]
+  double* vz = th1 + PIPE_KMAX;        // [kf] z / U of the pending proposal
+  double* vv = vz + PIPE_KMAX;         // [kf] S U, or x
+  double* vmp = vv + PIPE_KMAX;        // [kf] mean_prev
+  double* vmt = vmp + PIPE_KMAX;       // [kf] mean_t
+  double* vrs = vmt + PIPE_KMAX;       // [kf] running sum of ans rows
+  double* SigA = vrs + PIPE_KMAX;      // [kf][LD]
+  double* SigB = SigA + PIPE_KMAX * LD;
+  __shared__ int s_which[4][PIPE_KMAX];
+  int kf = 0;
+  for (int j = 0; j < k; j++)
+    if (!A.fixed[j]) { if (lane == 0) s_which[myc][kf] = j; kf++; }
+  const int* which = s_which[myc];
+  const double* s_mu = s_par, *s_lb = s_par + 2 * PIPE_KMAX, *s_ub = s_par + 3 * PIPE_KMAX;
+  double f0 = 0.0;
+  long long abs_iter = 0;
+  int nacc = 0, status = FMCMC_CHAIN_OK, thin_ctr = 0, have_mean = 0, nerr = 0;
+  unsigned int srow8 = 0, bitword = 0;
+  double* Scur = SigA;
+  double* Salt = SigB;
+  if (lane < k) { double t = A.theta0[(long long)cl * k + lane]; th0[lane] = t; th1[lane] = t; }
+  for (int e = lane; e < kf * LD; e += 64) {
+    const int a = e / LD, b = e % LD;
+    SigA[e] = A.fresh ? ((a == b) ? 1.0 * A.eps : 0.0) : ((b < kf) ? A.Sigma[((long long)cl * kf + a) * kf + b] : 0.0);
+    SigB[e] = 0.0;
+  }
+  if (!A.fresh) {
+    abs_iter = A.abs_iter[cl];
+    if (A.nerrors) nerr = A.nerrors[cl];
+    if (KIND == FMCMC_KERNEL_ADAPT) {
+      have_mean = A.have_mean[cl];
+      if (lane < kf) vmp[lane] = A.mean_prev[(long long)cl * kf + lane];
+    }
+  }
+  wave_sync_lds();
+  const int jl = (lane < k) ? lane : 0;
+  const unsigned int sd_off = (unsigned int)((((long long)cl * k + jl) * A.S) * 8);
+  const unsigned int z_off = (unsigned int)((((long long)cl * nsteps) * kz + (lane < kz ? lane : 0)) * 8);
+  const unsigned int lp_off = (unsigned int)(((long long)cl * A.S) * 8);
+  const double* const lu_row = A.fed_logu + (long long)cl * nsteps;
+  auto ld_z = [&](int row) -> double {
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(A.fed_z) + (z_off + (unsigned int)row * (unsigned int)(kz * 8)));
+  };
+  double z_nx = (lane < kz && nsteps >= 2) ? ld_z(1) : 0.0;
+  double lu_nx = (nsteps >= 2) ? lu_row[1] : 0.0;
+  bool ram_gate = false;   // gate of the PENDING proposal (evaluated when it was made)
+  auto flush_bits = [&](int i) {
+    if (A.accept_bits && lane == 0) A.accept_bits[(long long)cl * ((nsteps + 31) >> 5) + ((i - 1) >> 5)] = bitword;
+    bitword = 0;
+  };
+
+  for (int v = 1; v <= nsteps; v++) {
+    while (lds_ld_u32(&s_done[myc]) < 8u * (unsigned)v) __builtin_amdgcn_s_sleep(1);
+    const double* src = s_tr + myc * (8 * PIPE_TRS) + lane;
+    const double v0 = src[0 * PIPE_TRS], v1 = src[1 * PIPE_TRS], v2 = src[2 * PIPE_TRS], v3 = src[3 * PIPE_TRS];
+    const double v4 = src[4 * PIPE_TRS], v5 = src[5 * PIPE_TRS], v6 = src[6 * PIPE_TRS], v7 = src[7 * PIPE_TRS];
+    const double tot = wave_xor_sum(((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7)));
+    const double f1 = finish_logpost(A, th1, tot);
+    bool keep_row = false, st_row = false;
+    double st_th0 = 0.0, st_dr = 0.0;
+    if (v == 1) {
+      f0 = f1;
+      if (lane < kf) vrs[lane] = th0[which[lane]];
+      keep_row = true;
+    } else if (status == FMCMC_CHAIN_OK) {
+      const int i = v;
+      if (KIND == FMCMC_KERNEL_RAM) {   // adaptation with f(theta1) of the pending (un-reflected) proposal :129-152
+        if (ram_gate) {
+          double a_n = fmh_exp(f1 - f0);
+          if (fmh_isnan(a_n)) a_n = 0.0;
+          else if (a_n > 1.0) a_n = 1.0;
+          double eta = (double)kf * fmh_exp((-2.0 / 3.0) * fmh_log((double)i));
+          if (eta > 1.0) eta = 1.0;
+          double nrm2 = 0.0;
+          for (int b = 0; b < kf; b++) nrm2 = fmh_fma(vz[b], vz[b], nrm2);
+          double cp = (eta * (a_n - A.arate)) / nrm2;
+          if (cp != 0.0 && fmh_isfinite(cp)) {
+            const bool up = cp > 0.0;
+            const double scl = fmh_sqrt(fmh_abs(cp));
+            double w = (lane < kf) ? scl * vv[lane] : 0.0;
+            bool fail = false;
+            for (int j = 0; j < kf; j++) {
+              double ljj = Scur[j * LD + j];
+              double xj = shfl_d(w, j);
+              double r2 = up ? fmh_fma(xj, xj, ljj * ljj) : fmh_fma(-xj, xj, ljj * ljj);
+              if (!(r2 > 0.0) || !fmh_isfinite(r2)) { fail = true; break; }
+              double r = fmh_sqrt(r2);
+              double cc = r / ljj, ss = xj / ljj;
+              if (lane == j) {
+                Salt[j * LD + j] = r;
+              } else if (lane > j && lane < kf) {
+                double lij = Scur[lane * LD + j];
+                double ln = (up ? fmh_fma(ss, w, lij) : fmh_fma(-ss, w, lij)) / cc;
+                w = fmh_fma(-ss, ln, cc * w);
+                Salt[lane * LD + j] = ln;
+              }
+            }
+            wave_sync_lds();
+            if (fail) nerr += 1;
+            else { double* t = Scur; Scur = Salt; Salt = t; }
+          }
+        }
+        abs_iter += 1;
+      }
+      if (fmh_isnan(f1)) status = FMCMC_CHAIN_NAN_LOGPOST;
+      const double ratio = f1 - f0;
+      if (status == FMCMC_CHAIN_OK && fmh_isnan(ratio)) status = FMCMC_CHAIN_NAN_RATIO;
+      if (status != FMCMC_CHAIN_OK) {
+        if (lane == 0) { A.status[cl] = status; A.status_step[cl] = i; }
+        if (lane < k) A.status_theta[(long long)cl * k + lane] = th1[lane];
+        flush_bits(i);
+      } else {
+        const double lu = lu_nx;
+        lu_nx = lu_row[v < nsteps ? v : nsteps - 1];
+        keep_row = true;
+        // row i of ans / draws / logpost (the proposal th1 is still the evaluated one here)
+        if (i > burnin) {
+          thin_ctr += 1;
+        }
+        const bool acc = lu < ratio;
+        const double dr = (lane < k) ? th1[lane] : 0.0;
+        if (acc) {
+          if (lane < k) th0[lane] = dr;
+          f0 = f1;
+          nacc += 1;
+          bitword |= (1u << ((i - 1) & 31));
+        }
+        wave_sync_lds();
+        if (i > burnin && thin_ctr == thin) {   // stored after the proposal is published (below)
+          thin_ctr = 0;
+          st_row = true;
+          st_th0 = (lane < k) ? th0[lane] : 0.0;
+          st_dr = dr;
+        }
+        if (KIND == FMCMC_KERNEL_ADAPT && lane < kf) vrs[lane] = vrs[lane] + th0[which[lane]];
+        if (((i - 1) & 31) == 31 || i == nsteps) flush_bits(i);
+      }
+    }
+    if (v == 1 && keep_row && 1 > burnin) {   // row 1 (R/mcmc.R:737-743)
+      thin_ctr += 1;
+      if (thin_ctr == thin) {
+        thin_ctr = 0;
+        if (lane < k) {
+          *reinterpret_cast<double*>(reinterpret_cast<char*>(A.samples) + (sd_off + srow8)) = th0[lane];
+          if (A.draws) *reinterpret_cast<double*>(reinterpret_cast<char*>(A.draws) + (sd_off + srow8)) = th1[lane];
+        }
+        if (A.logpost && lane == 0) *reinterpret_cast<double*>(reinterpret_cast<char*>(A.logpost) + (lp_off + srow8)) = f1;
+        srow8 += 8;
+      }
+    }
+    // ---- proposal of loop step i = v + 1
+    if (v < nsteps) {
+      if (status == FMCMC_CHAIN_OK) {
+        const int i = v + 1;
+        wave_sync_lds();
+        if (lane < kz) vz[lane] = z_nx;
+        z_nx = (lane < kz) ? ld_z(v + 1 < nsteps ? v + 1 : nsteps - 1) : 0.0;
+        wave_sync_lds();
+        if (KIND == FMCMC_KERNEL_ADAPT) {
+          if (A.until > (double)abs_iter && abs_iter > A.warmup && i > 2) {
+            const double t = (double)(abs_iter - 1);
+            double x = 0, mp = 0, mt = 0;
+            if (lane < kf) {
+              x = th0[which[lane]];
+              mp = have_mean ? vmp[lane] : (vrs[lane] / (double)(i - 1));
+              mt = (mp * t + x) / (t + 1);
+              vv[lane] = x; vmp[lane] = mp; vmt[lane] = mt;
+            }
+            wave_sync_lds();
+            if (lane < kf) {
+              const double c1 = (t - 1) / t, c2 = 1.0 / t;
+              for (int b = 0; b < kf; b++) {
+                double ik = (b == lane) ? 1.0 * A.eps : 0.0;
+                double inner = t * (mp * vmp[b]) - (t + 1) * (mt * vmt[b]) + x * vv[b] + 1e-5 * ik;
+                SigA[lane * LD + b] = c1 * SigA[lane * LD + b] + c2 * inner;
+              }
+            }
+            wave_sync_lds();
+            if (lane < kf) vmp[lane] = mt;
+            have_mean = 1;
+          }
+          abs_iter += 1;
+          bool notpd = false;
+          for (int j = 0; j < kf; j++) {
+            double sacc = 0.0;
+            if (lane >= j && lane < kf) {
+              sacc = SigA[lane * LD + j];
+              for (int b = 0; b < j; b++) sacc = fmh_fma(-SigB[lane * LD + b], SigB[j * LD + b], sacc);
+            }
+            double d = shfl_d(sacc, j);
+            if (!(d > 0.0) || !fmh_isfinite(d)) { notpd = true; break; }
+            double ljj = fmh_sqrt(d);
+            if (lane == j) SigB[j * LD + j] = ljj;
+            else if (lane > j && lane < kf) SigB[lane * LD + j] = sacc / ljj;
+            wave_sync_lds();
+          }
+          if (notpd) {
+            status = FMCMC_CHAIN_NOT_PD;
+            if (lane == 0) { A.status[cl] = status; A.status_step[cl] = i; }
+            if (lane < k) A.status_theta[(long long)cl * k + lane] = th1[lane];
+          } else {
+            if (lane < k) th1[lane] = th0[lane];
+            wave_sync_lds();
+            if (lane < kf) {
+              double sacc = 0.0;
+              for (int b = 0; b <= lane; b++) sacc = fmh_fma(SigB[lane * LD + b], vz[b], sacc);
+              const int j = which[lane];
+              th1[j] = reflect1(th0[j] + (s_mu[j] + sacc), s_lb[j], s_ub[j]);
+            }
+          }
+        } else {  // RAM P1 :123-126 (theta1 keeps its previous values in fixed coordinates)
+          if (lane < kf) {
+            double sacc = 0.0;
+            for (int b = 0; b <= lane; b++) sacc = fmh_fma(Scur[lane * LD + b], vz[b], sacc);
+            vv[lane] = sacc;
+            const int j = which[lane];
+            th1[j] = th0[j] + sacc;
+          }
+          ram_gate = (A.until > (double)abs_iter && abs_iter > A.warmup && ((v + 1) % A.freq) == 0);
+        }
+        wave_sync_lds();
+        if (lane < k) s_th1[myc * PIPE_KMAX + lane] = th1[lane];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_store(&s_ready[myc], (unsigned)(v + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if (st_row) {   // row v of ans / draws / logpost, off the compute waves' critical path
+      if (lane < k) {
+        *reinterpret_cast<double*>(reinterpret_cast<char*>(A.samples) + (sd_off + srow8)) = st_th0;
+        if (A.draws) *reinterpret_cast<double*>(reinterpret_cast<char*>(A.draws) + (sd_off + srow8)) = st_dr;
+      }
+      if (A.logpost && lane == 0) *reinterpret_cast<double*>(reinterpret_cast<char*>(A.logpost) + (lp_off + srow8)) = f1;
+      srow8 += 8;
+    }
+  }
+  // ---- write state back
+  wave_sync_lds();
+  if (lane < k) A.theta0[(long long)cl * k + lane] = th0[lane];
+  if (lane == 0) {
+    A.f0[cl] = f0;
+    A.accept_count[cl] = nacc;
+    if (status == FMCMC_CHAIN_OK) { A.status[cl] = FMCMC_CHAIN_OK; A.status_step[cl] = 0; }
+    A.abs_iter[cl] = abs_iter;
+    if (A.nerrors) A.nerrors[cl] = nerr;
+    if (KIND == FMCMC_KERNEL_ADAPT) A.have_mean[cl] = have_mean;
+  }
+  const double* Sfin = (KIND == FMCMC_KERNEL_RAM) ? Scur : SigA;
+  for (int e = lane; e < kf * kf; e += 64) {
+    const int a = e / kf, b = e % kf;
+    A.Sigma[((long long)cl * kf + a) * kf + b] = Sfin[a * LD + b];
+  }
+  if (KIND == FMCMC_KERNEL_ADAPT && lane < kf) A.mean_prev[(long long)cl * kf + lane] = vmp[lane];
+}
+
+// Register-row variant of the adaptive owner for k <= SPEC_KA parameters, none fixed (C3, kernel_ram at k = 5):
+// lane a keeps ROW a of Sigma / S (and of the Cholesky factor) in VGPRs and other rows' entries arrive by v_readlane
+// (statically unrolled indices), so the Cholesky, the rank-1 update, the recursive covariance and the L z / S U
+// products run without a single LDS round trip or ds_bpermute.  Same operations in the same order per matrix
+// element as spec_owner_adaptive / the oracle, hence the same bits.
+constexpr int SPEC_KA = 8;
+
+template <int KIND>
+__device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int myc, int cl, double* s_th1, double* s_par,
+                                                        unsigned* s_ready, unsigned* s_done, double* s_tr) {
+  constexpr int KA = SPEC_KA;
+  const int lane = threadIdx.x & 63;
+  const int k = A.k, kf = A.k, kz = A.kz, nsteps = (int)A.nsteps, burnin = (int)A.burnin, thin = (int)A.thin;
+  const bool rl = lane < k;                 // row lane == parameter lane (no fixed parameters)
+  const int jl = rl ? lane : 0;
+  const double mu_l = A.mu[jl], lb_l = A.lb[jl], ub_l = A.ub[jl];
+  double Srow[KA], Lrow[KA];                // Sigma (adapt) or S (ram) row `lane`; Cholesky factor row (adapt)
+#pragma unroll
+  for (int b = 0; b < KA; b++) {
+    Lrow[b] = 0.0;
+    Srow[b] = (rl && b < kf) ? (A.fresh ? ((b == lane) ? 1.0 * A.eps : 0.0) : A.Sigma[((long long)cl * kf + lane) * kf + b]) : 0.0;
+  }
+  double th0 = rl ? A.theta0[(long long)cl * k + lane] : 0.0, th1 = th0;
+  double f0 = 0.0, mean_prev = 0.0, run_sum = 0.0, vv = 0.0, zcur = 0.0;
+  long long abs_iter = 0;
+  int nacc = 0, status = FMCMC_CHAIN_OK, thin_ctr = 0, have_mean = 0, nerr = 0;
+  unsigned int srow8 = 0, bitword = 0;
+  if (!A.fresh) {
+    abs_iter = A.abs_iter[cl];
+    if (A.nerrors) nerr = A.nerrors[cl];
+    if (KIND == FMCMC_KERNEL_ADAPT) {
+      have_mean = A.have_mean[cl];
+      if (rl) mean_prev = A.mean_prev[(long long)cl * kf + lane];
+    }
+  }
+  const unsigned int sd_off = (unsigned int)((((long long)cl * k + jl) * A.S) * 8);
+  const unsigned int z_off = (unsigned int)((((long long)cl * nsteps) * kz + jl) * 8);
+  const unsigned int lp_off = (unsigned int)(((long long)cl * A.S) * 8);
+  const double* const lu_row = A.fed_logu + (long long)cl * nsteps;
+  const double dn = uniform_d((double)A.n);
+  auto ld_z = [&](int row) -> double {
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(A.fed_z) + (z_off + (unsigned int)row * (unsigned int)(kz * 8)));
+  };
+  double z_nx = (rl && nsteps >= 2) ? ld_z(1) : 0.0;
+  double lu_nx = (nsteps >= 2) ? lu_row[1] : 0.0;
+  bool ram_gate = false;
+  auto flush_bits = [&](int i) {
+    if (A.accept_bits && lane == 0) A.accept_bits[(long long)cl * ((nsteps + 31) >> 5) + ((i - 1) >> 5)] = bitword;
+    bitword = 0;
+  };
+  auto logpost_of = [&](double tot, double sigma) -> double {   // Gaussian linreg closed form (same as the normal owners)
+    double f;
+    if (sigma < 0.0 || fmh_isnan(sigma)) f = fmh_nan();
+    else if (sigma == 0.0) f = -fmh_inf();
+    else {
+      double t1 = fmh_log(sigma) + FMH_K(FMH_LN_SQRT_2PI);
+      double q = (0.5 * tot) / (sigma * sigma);
+      f = -(dn * t1) - q;
+    }
+    if (A.guard && !fmh_isfinite(f)) f = -fmh_inf();
+    return f;
+  };
+
+  for (int v = 1; v <= nsteps; v++) {
+    while (lds_ld_u32(&s_done[myc]) < 8u * (unsigned)v) __builtin_amdgcn_s_sleep(1);
+    const double* src = s_tr + myc * (8 * PIPE_TRS) + lane;
+    const double v0 = src[0 * PIPE_TRS], v1 = src[1 * PIPE_TRS], v2 = src[2 * PIPE_TRS], v3 = src[3 * PIPE_TRS];
+    const double v4 = src[4 * PIPE_TRS], v5 = src[5 * PIPE_TRS], v6 = src[6 * PIPE_TRS], v7 = src[7 * PIPE_TRS];
+    const double tot = wave_xor_sum(((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7)));
+    const double f1 = logpost_of(tot, readlane_d(th1, k - 1));
+    bool st_row = false;
+    double st_th0 = 0.0;
+    const double st_dr = th1;
+    if (v == 1) {
+      f0 = f1;
+      run_sum = th0;
+      if (1 > burnin) { thin_ctr += 1; if (thin_ctr == thin) { thin_ctr = 0; st_row = true; st_th0 = th0; } }
+    } else if (status == FMCMC_CHAIN_OK) {
+      const int i = v;
+      if (KIND == FMCMC_KERNEL_RAM) {   // adaptation with f(theta1) of the pending proposal (R/kernel_ram.R:129-152)
+        if (ram_gate) {
+          double a_n = fmh_exp(f1 - f0);
+          if (fmh_isnan(a_n)) a_n = 0.0;
+          else if (a_n > 1.0) a_n = 1.0;
+          double eta = (double)kf * fmh_exp((-2.0 / 3.0) * fmh_log((double)i));
+          if (eta > 1.0) eta = 1.0;
+          double nrm2 = 0.0;
+#pragma unroll
+          for (int b = 0; b < KA; b++)
+            if (b < kf) { const double ub_ = readlane_d(zcur, b); nrm2 = fmh_fma(ub_, ub_, nrm2); }
+          const double cp = (eta * (a_n - A.arate)) / nrm2;
+          if (cp != 0.0 && fmh_isfinite(cp)) {
+            const bool up = cp > 0.0;
+            double w = rl ? fmh_sqrt(fmh_abs(cp)) * vv : 0.0;
+            double Snew[KA];
+#pragma unroll
+            for (int b = 0; b < KA; b++) Snew[b] = Srow[b];
+            bool fail = false;
+#pragma unroll
+            for (int j = 0; j < KA; j++) {
+              if (j < kf && !fail) {
+                const double ljj = readlane_d(Srow[j], j);
+                const double xj = readlane_d(w, j);
+                const double r2 = up ? fmh_fma(xj, xj, ljj * ljj) : fmh_fma(-xj, xj, ljj * ljj);
+                if (!(r2 > 0.0) || !fmh_isfinite(r2)) {
+                  fail = true;
+                } else {
+                  const double r = fmh_sqrt(r2);
+                  const double cc = r / ljj, ss = xj / ljj;
+                  if (lane == j) {
+                    Snew[j] = r;
+                  } else if (lane > j && rl) {
+                    const double ln = (up ? fmh_fma(ss, w, Srow[j]) : fmh_fma(-ss, w, Srow[j])) / cc;
+                    w = fmh_fma(-ss, ln, cc * w);
+                    Snew[j] = ln;
+                  }
+                }
+              }
+            }
+            if (fail) nerr += 1;
+            else {
+#pragma unroll
+              for (int b = 0; b < KA; b++) Srow[b] = Snew[b];
+            }
+          }
+        }
+        abs_iter += 1;
+      }
+      if (fmh_isnan(f1)) status = FMCMC_CHAIN_NAN_LOGPOST;
+      const double ratio = f1 - f0;
+      if (status == FMCMC_CHAIN_OK && fmh_isnan(ratio)) status = FMCMC_CHAIN_NAN_RATIO;
+      if (status != FMCMC_CHAIN_OK) {
+        if (lane == 0) { A.status[cl] = status; A.status_step[cl] = i; }
+        if (rl) A.status_theta[(long long)cl * k + lane] = th1;
+        flush_bits(i);
+      } else {
+        const double lu = lu_nx;
+        lu_nx = lu_row[v < nsteps ? v : nsteps - 1];
+        if (lu < ratio) {
+          th0 = th1;
+          f0 = f1;
+          nacc += 1;
+          bitword |= (1u << ((i - 1) & 31));
+        }
+        if (i > burnin) { thin_ctr += 1; if (thin_ctr == thin) { thin_ctr = 0; st_row = true; st_th0 = th0; } }
+        if (KIND == FMCMC_KERNEL_ADAPT) run_sum = run_sum + th0;
+        if (((i - 1) & 31) == 31 || i == nsteps) flush_bits(i);
+      }
+    }
+    // ---- proposal of loop step i = v + 1
+    if (v < nsteps) {
+      if (status == FMCMC_CHAIN_OK) {
+        const int i = v + 1;
+        zcur = z_nx;
+        z_nx = rl ? ld_z(v + 1 < nsteps ? v + 1 : nsteps - 1) : 0.0;
+        if (KIND == FMCMC_KERNEL_ADAPT) {
+          if (A.until > (double)abs_iter && abs_iter > A.warmup && i > 2) {   // R/kernel_adapt.R:118-166
+            const double t = (double)(abs_iter - 1);
+            const double x = th0;
+            const double mp = have_mean ? mean_prev : (run_sum / (double)(i - 1));
+            const double mt = (mp * t + x) / (t + 1);
+            const double c1 = (t - 1) / t, c2 = 1.0 / t;
+#pragma unroll
+            for (int b = 0; b < KA; b++) {
+              if (b < kf) {
+                const double mpb = readlane_d(mp, b), mtb = readlane_d(mt, b), xb = readlane_d(x, b);
+                const double ik = (b == lane) ? 1.0 * A.eps : 0.0;
+                const double inner = t * (mp * mpb) - (t + 1) * (mt * mtb) + x * xb + 1e-5 * ik;
+                Srow[b] = c1 * Srow[b] + c2 * inner;
+              }
+            }
+            mean_prev = mt;
+            have_mean = 1;
+          }
+          abs_iter += 1;
+          // left-looking Cholesky: column j, lane = row (twin of oracle chol_lower_canon)
+          bool notpd = false;
+#pragma unroll
+          for (int j = 0; j < KA; j++) {
+            if (j < kf && !notpd) {
+              double sacc = Srow[j];
+#pragma unroll
+              for (int b = 0; b < j; b++) sacc = fmh_fma(-Lrow[b], readlane_d(Lrow[b], j), sacc);
+              const double d = readlane_d(sacc, j);
+              if (!(d > 0.0) || !fmh_isfinite(d)) {
+                notpd = true;
+              } else {
+                const double ljj = fmh_sqrt(d);
+                if (lane == j) Lrow[j] = ljj;
+                else if (lane > j) Lrow[j] = sacc / ljj;
+              }
+            }
+          }
+          if (notpd) {
+            status = FMCMC_CHAIN_NOT_PD;
+            if (lane == 0) { A.status[cl] = status; A.status_step[cl] = i; }
+            if (rl) A.status_theta[(long long)cl * k + lane] = th1;
+          } else {
+            double sacc = 0.0;
+#pragma unroll
+            for (int b = 0; b < KA; b++)
+              if (b < kf) { const double zb = readlane_d(zcur, b); if (b <= lane) sacc = fmh_fma(Lrow[b], zb, sacc); }
+            th1 = reflect1(th0 + (mu_l + sacc), lb_l, ub_l);
+          }
+        } else {  // RAM P1 (R/kernel_ram.R:123-126)
+          double sacc = 0.0;
+#pragma unroll
+          for (int b = 0; b < KA; b++)
+            if (b < kf) { const double ub_ = readlane_d(zcur, b); if (b <= lane) sacc = fmh_fma(Srow[b], ub_, sacc); }
+          vv = sacc;
+          th1 = th0 + sacc;
+          ram_gate = (A.until > (double)abs_iter && abs_iter > A.warmup && ((v + 1) % A.freq) == 0);
+        }
+        if (rl) s_th1[myc * PIPE_KMAX + lane] = th1;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_store(&s_ready[myc], (unsigned)(v + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if (st_row) {   // row v of ans / draws / logpost, off the compute waves' critical path
+      if (rl) {
+        *reinterpret_cast<double*>(reinterpret_cast<char*>(A.samples) + (sd_off + srow8)) = st_th0;
+        if (A.draws) *reinterpret_cast<double*>(reinterpret_cast<char*>(A.draws) + (sd_off + srow8)) = st_dr;
+      }
+      if (A.logpost && lane == 0) *reinterpret_cast<double*>(reinterpret_cast<char*>(A.logpost) + (lp_off + srow8)) = f1;
+      srow8 += 8;
+    }
+  }
+  // ---- write state back
+  if (rl) A.theta0[(long long)cl * k + lane] = th0;
+  if (lane == 0) {
+    A.f0[cl] = f0;
+    A.accept_count[cl] = nacc;
+    if (status == FMCMC_CHAIN_OK) { A.status[cl] = FMCMC_CHAIN_OK; A.status_step[cl] = 0; }
+    A.abs_iter[cl] = abs_iter;
+    if (A.nerrors) A.nerrors[cl] = nerr;
+    if (KIND == FMCMC_KERNEL_ADAPT) A.have_mean[cl] = have_mean;
+  }
+#pragma unroll
+  for (int b = 0; b < KA; b++)
+    if (rl && b < kf) A.Sigma[((long long)cl * kf + lane) * kf + b] = (b <= lane || KIND == FMCMC_KERNEL_ADAPT) ? Srow[b] : 0.0;
+  if (KIND == FMCMC_KERNEL_ADAPT && rl) A.mean_prev[(long long)cl * kf + lane] = mean_prev;
+}
+
+template <int P, int OPT, int KIND>
+__global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
+  constexpr int CW = 4;
+  static_assert(OPT % 2 == 0, "OPT must be even (y is read back in pairs)");
+  extern __shared__ double smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int k = A.k, kz = A.kz;
+  double* s_th1 = smem;                            // [CW][PIPE_KMAX] proposals read by the evaluation
+  double* s_par = s_th1 + CW * PIPE_KMAX;          // [4][PIPE_KMAX]  mu, scale, lb, ub
+  unsigned* s_ready = (unsigned*)(s_par + 4 * PIPE_KMAX);  // [CW] version of theta1[c] that is published
+  unsigned* s_done = s_ready + CW;                         // [CW] partial arrivals (8 per version)
+  double* s_tr = s_par + 4 * PIPE_KMAX + CW;       // [CW][8][PIPE_TRS] lane partials, transposed
+  double* s_y = s_tr + CW * 8 * PIPE_TRS;          // [OPT/2][NT][2] this workgroup's copy of y
+  double* s_ad = s_y + OPT * NT;                   // KIND >= 3: [CW][SPEC_ADS] adaptive per-chain state
+  const long long cg0 = (long long)blockIdx.x * CW;
+  const int ncw = (int)((A.nchains - cg0 < CW) ? (A.nchains - cg0) : CW);
+  const int nsteps = (int)A.nsteps, burnin = (int)A.burnin, thin = (int)A.thin;
+  const int ic = A.intercept;
+  const bool dbg = (A.debug & 8) != 0;
+
+  // ---- cooperative set-up (all 12 waves): y -> LDS, kernel constants, initial theta1, flags
+  for (int e = tid; e < OPT * NT; e += SPEC_NT) {
+    const int s = e / NT, t = e - s * NT;
+    const long long i = (long long)t + (long long)NT * s;
+    s_y[((s >> 1) * NT + t) * 2 + (s & 1)] = (i < A.n) ? A.y[i] : 0.0;
+  }
+  if (tid < k) {
+    s_par[0 * PIPE_KMAX + tid] = A.mu[tid];
+    s_par[1 * PIPE_KMAX + tid] = A.scale[tid];
+    s_par[2 * PIPE_KMAX + tid] = A.lb[tid];
+    s_par[3 * PIPE_KMAX + tid] = A.ub[tid];
+  }
+  if (tid < CW * PIPE_KMAX) {
+    const int c = tid / PIPE_KMAX, j = tid - c * PIPE_KMAX;
+    s_th1[tid] = (c < ncw && j < k) ? A.theta0[(cg0 + c) * k + j] : 0.0;
+  }
+  if (tid < CW) { s_ready[tid] = 1u; s_done[tid] = 0u; }
+  __syncthreads();
+
+  if (wave < SPEC_NCW) {
+    // =========================== COMPUTE ROLE ===========================
+    double xr[OPT][P > 0 ? P : 1];
+    double wlast = 1.0;
+#pragma unroll
+    for (int s = 0; s < OPT; s++) {
+      const long long i = (long long)tid + (long long)NT * s;
+      const bool valid = i < A.n;
+#pragma unroll
+      for (int j = 0; j < P; j++) xr[s][j] = valid ? A.X[(long long)j * A.n + i] : 0.0;
+      if (s == OPT - 1) wlast = valid ? 1.0 : 0.0;
+    }
+    const int tr_slot = (tid & 7) * PIPE_TRS + (tid >> 3);
+    const double2* yp = reinterpret_cast<const double2*>(s_y) + tid;
+    unsigned long long tw = 0, te = 0;
+    for (int v = 1; v <= nsteps; v++) {
+      for (int c = 0; c < ncw; c++) {
+        unsigned long long t_a = dbg ? clk() : 0;
+        while (lds_ld_u32(&s_ready[c]) < (unsigned)v) __builtin_amdgcn_s_sleep(1);
+        unsigned long long t_b = dbg ? clk() : 0;
+        const double* t0 = s_th1 + c * PIPE_KMAX;
+        const double m00 = ic ? t0[0] : 0.0;
+        double b0[P > 0 ? P : 1];
+#pragma unroll
+        for (int j = 0; j < P; j++) b0[j] = t0[ic + j];
+        double a0 = 0.0;
+        // y pairs come from LDS three pairs (~30 FMAs) ahead of their use: LDS latency is ~130 cycles and only two
+        // compute waves share the SIMD, so a one-pair lookahead leaves the FMA pipe waiting on lgkmcnt
+        constexpr int YD = 3;
+        double2 yq[YD];
+#pragma unroll
+        for (int d = 0; d < YD; d++) yq[d] = yp[(d < OPT / 2 ? d : OPT / 2 - 1) * NT];
+#pragma unroll
+        for (int s2 = 0; s2 < OPT / 2; s2++) {
+          const double2 yy = yq[s2 % YD];
+          if (s2 + YD < OPT / 2) yq[s2 % YD] = yp[(s2 + YD) * NT];
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            const int s = 2 * s2 + h;
+            const double yv = h ? yy.y : yy.x;
+            double m0 = m00;
+#pragma unroll
+            for (int j = 0; j < P; j++) m0 = fmh_fma(xr[s][j], b0[j], m0);
+            const double r0 = yv - m0;
+            if (s == OPT - 1) a0 = fmh_fma(r0 * wlast, r0, a0);
+            else a0 = fmh_fma(r0, r0, a0);
+          }
+        }
+        s_tr[c * (8 * PIPE_TRS) + tr_slot] = a0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // partials landed before the arrival is visible
+        if (lane == 0) __hip_atomic_fetch_add(&s_done[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (dbg) { unsigned long long t_c = clk(); tw += t_b - t_a; te += t_c - t_b; }
+      }
+    }
+    if (dbg && lane == 0 && A.draws) {
+      double* d = A.draws + ((long long)blockIdx.x * 12 + wave) * 4;
+      d[0] = (double)tw; d[1] = (double)te; d[2] = 0.0; d[3] = (double)nsteps;
+    }
+    return;
+  }
+
+  // =========================== OWNER ROLE ===========================
+  const int myc = wave - SPEC_NCW;
+  if (myc >= ncw) return;
+  const int cl = __builtin_amdgcn_readfirstlane((int)cg0 + myc);
+  if constexpr (KIND == FMCMC_KERNEL_ADAPT || KIND == FMCMC_KERNEL_RAM) {
+    bool nofixed = true;
+    for (int j = 0; j < k; j++) nofixed = nofixed && (A.fixed[j] == 0);
+    if (k <= SPEC_KA && nofixed && !(A.debug & 16))
+      spec_owner_adaptive_reg<KIND>(A, myc, cl, s_th1, s_par, s_ready, s_done, s_tr);
+    else
+      spec_owner_adaptive<KIND>(A, myc, cl, s_th1, s_par, s_ready, s_done, s_tr, s_ad + myc * SPEC_ADS);
+    return;
+  }
+  const bool plane = (lane < k);
+  const int jl = plane ? lane : 0;
+  const bool fixed_l = A.fixed[jl] != 0;
+  int zidx = 0;
+  for (int j = 0; j < jl; j++) zidx += A.fixed[j] ? 0 : 1;
+  double th0 = plane ? A.theta0[(long long)cl * k + lane] : 0.0;
+  double th1 = th0;
+  double f0 = 0.0;
+  int nacc = 0, status = FMCMC_CHAIN_OK, thin_ctr = 0;
+  unsigned int srow8 = 0, bitword = 0;
+  const unsigned int sd_off = (unsigned int)((((long long)cl * k + jl) * A.S) * 8);
+  const unsigned int z_off = (unsigned int)((((long long)cl * nsteps) * kz + zidx) * 8);
+  const unsigned int lp_off = (unsigned int)(((long long)cl * A.S) * 8);
+  const double* const lu_row = A.fed_logu + (long long)cl * nsteps;
+  const double dn = uniform_d((double)A.n);
+  auto ld_z = [&](int row) -> double {
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(A.fed_z) + (z_off + (unsigned int)row * (unsigned int)(kz * 8)));
+  };
+  double z_nx = (plane && !fixed_l && nsteps >= 2) ? ld_z(1) : 0.0;   // variates of the NEXT proposal / decision
+  double lu_nx = (nsteps >= 2) ? lu_row[1] : 0.0;
+
+  auto logpost_of = [&](double tot, double sigma) -> double {
+    double f;
+    if (sigma < 0.0 || fmh_isnan(sigma)) {
+      f = fmh_nan();
+    } else if (sigma == 0.0) {
+      f = -fmh_inf();
+    } else {
+      double t1 = fmh_log(sigma) + FMH_K(FMH_LN_SQRT_2PI);
+      double q = (0.5 * tot) / (sigma * sigma);
+      f = -(dn * t1) - q;
+    }
+    if (A.guard && !fmh_isfinite(f)) f = -fmh_inf();
+    return f;
+  };
+  auto flush_bits = [&](int i) {
+    if (A.accept_bits && lane == 0)
+      A.accept_bits[(long long)cl * ((nsteps + 31) >> 5) + ((i - 1) >> 5)] = bitword;
+    bitword = 0;
+  };
+
+  unsigned long long tw = 0, tp = 0, tst = 0;
+  for (int v = 1; v <= nsteps; v++) {
+    // ---- wait for the 8 compute waves' partials of version v
+    unsigned long long t_a = dbg ? clk() : 0;
+    while (lds_ld_u32(&s_done[myc]) < 8u * (unsigned)v) __builtin_amdgcn_s_sleep(1);
+    unsigned long long t_b = dbg ? clk() : 0;
+    const double* src = s_tr + myc * (8 * PIPE_TRS) + lane;  // this lane folds canonical lanes 8*lane .. 8*lane+7
+    const double v0 = src[0 * PIPE_TRS], v1 = src[1 * PIPE_TRS], v2 = src[2 * PIPE_TRS], v3 = src[3 * PIPE_TRS];
+    const double v4 = src[4 * PIPE_TRS], v5 = src[5 * PIPE_TRS], v6 = src[6 * PIPE_TRS], v7 = src[7 * PIPE_TRS];
+    const double tot = wave_xor_sum(((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7)));
+    const double sigma = readlane_d(th1, k - 1);
+    const double f1 = logpost_of(tot, sigma);
+    const double th1_eval = th1;
+    bool keep_row = false;
+    if (v == 1) {                       // row 1: f0 = f(initial)
+      f0 = uniform_d(f1);
+      keep_row = true;
+    } else if (status == FMCMC_CHAIN_OK) {
+      const double ratio = f1 - f0;
+      if (fmh_isnan(f1) || fmh_isnan(ratio)) {
+        status = fmh_isnan(f1) ? FMCMC_CHAIN_NAN_LOGPOST : FMCMC_CHAIN_NAN_RATIO;
+        if (lane == 0) { A.status[cl] = status; A.status_step[cl] = v; }
+        if (plane) A.status_theta[(long long)cl * k + lane] = th1;
+        flush_bits(v);
+      } else {
+        const double lu = lu_nx;
+        lu_nx = lu_row[v < nsteps ? v : nsteps - 1];   // log u of step v + 1 (clamped), consumed a step later
+        if (lu < ratio) {
+          th0 = th1;
+          f0 = uniform_d(f1);
+          nacc += 1;
+          bitword |= (1u << ((v - 1) & 31));
+        }
+        keep_row = true;
+      }
+    }
+    const double th0_row = th0;
+    // ---- proposal of step v + 1, published for the compute waves
+    if (v < nsteps) {
+      if (status == FMCMC_CHAIN_OK && plane) {
+        double t = th0;
+        if (!fixed_l) {
+          t = th0 + (s_par[0 * PIPE_KMAX + lane] + s_par[1 * PIPE_KMAX + lane] * z_nx);
+          if (KIND == FMCMC_KERNEL_NORMAL_REFLECTIVE) t = reflect1(t, s_par[2 * PIPE_KMAX + lane], s_par[3 * PIPE_KMAX + lane]);
+          z_nx = ld_z(v + 1 < nsteps ? v + 1 : nsteps - 1);   // row of step v + 2 (clamped), awaited a step later
+        }
+        th1 = t;
+        s_th1[myc * PIPE_KMAX + lane] = t;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_store(&s_ready[myc], (unsigned)(v + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    unsigned long long t_c = dbg ? clk() : 0;
+    // ---- stores last (off the compute waves' critical path)
+    if (keep_row && v > burnin && !(dbg && A.draws)) {
+      thin_ctr += 1;
+      if (thin_ctr == thin) {
+        thin_ctr = 0;
+        if (plane) {
+          *reinterpret_cast<double*>(reinterpret_cast<char*>(A.samples) + (sd_off + srow8)) = th0_row;
+          if (A.draws) *reinterpret_cast<double*>(reinterpret_cast<char*>(A.draws) + (sd_off + srow8)) = th1_eval;
+        }
+        if (A.logpost && lane == 0) *reinterpret_cast<double*>(reinterpret_cast<char*>(A.logpost) + (lp_off + srow8)) = f1;
+        srow8 += 8;
+      }
+    }
+    if (status == FMCMC_CHAIN_OK && v >= 2 && (((v - 1) & 31) == 31 || v == nsteps)) flush_bits(v);
+    if (dbg) { unsigned long long t_d = clk(); tw += t_b - t_a; tp += t_c - t_b; tst += t_d - t_c; }
+  }
+  if (dbg && lane == 0 && A.draws) {
+    double* d = A.draws + ((long long)blockIdx.x * 12 + wave) * 4;
+    d[0] = (double)tw; d[1] = (double)tp; d[2] = (double)tst; d[3] = (double)nsteps;
+  }
+  // ---- write state back
+  if (plane) A.theta0[(long long)cl * k + lane] = th0;
+  if (lane == 0) {
+    A.f0[cl] = f0;
+    A.accept_count[cl] = nacc;
+    if (status == FMCMC_CHAIN_OK) { A.status[cl] = FMCMC_CHAIN_OK; A.status_step[cl] = 0; }
+  }
+}
+
+size_t spec_lds_bytes(int opt, bool adaptive) {
+  return sizeof(double) * ((size_t)8 * PIPE_KMAX + 4 + 4 * 8 * PIPE_TRS + (size_t)opt * NT + (adaptive ? 4 * SPEC_ADS : 0));
+}
+
+size_t pipe_lds_bytes(int opt) { return sizeof(double) * ((size_t)8 * PIPE_KMAX + 4 * 8 * PIPE_TRS + (size_t)opt * NT); }
+
+}  // namespace

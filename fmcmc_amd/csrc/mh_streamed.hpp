@@ -1,0 +1,582 @@
+// mh_streamed.hpp -- mh_sweep_kernel<CW, P, OPT, KIND>: the general kernel (every family, kernel, scheme and k <= 64; data
+// streamed from L2 or, for two shapes, resident in VGPRs) with in-kernel Philox tiles.
+#pragma once
+
+namespace {
+
+// ---- the sweep kernel ----------------------------------------------------------------------
+// P < 0 : streamed evaluation (any family, any n, p: data re-read from L2 every step)
+// P >= 0: register-resident Gaussian linear regression with P covariates: each thread keeps its
+//         OPT observations (x[P], y) in VGPRs for the whole sweep; n in (512*(OPT-4), 512*OPT].
+constexpr int RES_MASKED = 4;  // trailing observation slots that carry a validity mask
+
+// KIND > 0 compiles exactly one proposal kernel in (resident variants); KIND == 0 keeps all four
+// behind the runtime A.kind (streamed variants).
+template <int CW, int P, int OPT, int KIND>
+__global__ __launch_bounds__(NT) void mh_sweep_kernel(const SweepArgs A0) {
+  constexpr bool RESIDENT = (P >= 0);
+  SweepArgs A = A0;
+  if constexpr (KIND > 0) A.kind = KIND;
+  extern __shared__ double smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int k = A.k;
+  const int TB = A.tb, kz = A.kz;
+  // ---- shared layout: kernel parameters, which[], partials, RNG tile, then CW chain blocks
+  double* s_mu = smem;
+  double* s_scale = s_mu + k;
+  double* s_lb = s_scale + k;
+  double* s_ub = s_lb + k;
+  int* s_which = (int*)(s_ub + k);          // [k] ints (k/2+1 doubles)
+  double* s_part = s_ub + k + (k / 2 + 1);  // [NW*CW]
+  int* s_flag = (int*)(s_part + NW * CW);   // [2] ints
+  double* s_zt = s_part + NW * CW + 1;      // [CW][TB][kz] proposal variates of the tile
+  double* s_lu = s_zt + CW * TB * kz;       // [CW][TB]     log accept uniforms of the tile
+  double* s_tr = s_lu + CW * TB;            // RESIDENT: [CW][NT] lane partials
+  double* s_chains = s_tr + (RESIDENT ? CW * NT : 0);
+
+  __shared__ int s_kf;
+  if (tid == 0) {
+    int kf = 0;
+    for (int j = 0; j < k; j++)
+      if (!A.fixed[j]) s_which[kf++] = j;
+    s_kf = kf;
+    s_flag[0] = 0;
+  }
+  if (tid < k) {
+    s_mu[tid] = A.mu[tid];
+    s_scale[tid] = A.scale[tid];
+    s_lb[tid] = A.lb[tid];
+    s_ub[tid] = A.ub[tid];
+  }
+  __syncthreads();
+  const int kf = s_kf;
+  const int LD = kf | 1;
+  const int CHS = chain_lds_doubles(k, kf, A.kind);
+  const long long cg0 = (long long)blockIdx.x * CW;  // first local chain of this workgroup
+  const int ncw = (int)((A.nchains - cg0 < CW) ? (A.nchains - cg0) : CW);
+  const bool adaptive = (A.kind == FMCMC_KERNEL_ADAPT || A.kind == FMCMC_KERNEL_RAM);
+
+  // owner wavefront of chain c is wave c (CW <= NW)
+  const int myc = wave;                 // chain slot owned by this wavefront
+  const bool owner = (myc < ncw);
+  const long long cl = cg0 + myc;       // local chain index
+  const unsigned int cgid = (unsigned int)(A.chain_base + cl);
+  ChainLds L = chain_lds(s_chains + (owner ? myc : 0) * CHS, k, kf, A.kind);
+
+  double* thp[CW];
+#pragma unroll
+  for (int c = 0; c < CW; c++) thp[c] = s_chains + (c < ncw ? c : 0) * CHS + k;  // th1 of chain c
+
+  // ---- RESIDENT: this thread's observations live in registers for the whole sweep
+  constexpr int PR = RESIDENT ? (P > 0 ? P : 1) : 1;
+  constexpr int OR = RESIDENT ? OPT : 1;
+  double xr[OR][PR];
+  double yr[OR];
+  double wm[RES_MASKED];
+  if constexpr (RESIDENT) {
+#pragma unroll
+    for (int s = 0; s < OPT; s++) {
+      const long long i = (long long)tid + (long long)NT * s;
+      const bool valid = i < A.n;
+      yr[s] = valid ? A.y[i] : 0.0;
+#pragma unroll
+      for (int j = 0; j < P; j++) xr[s][j] = valid ? A.X[(long long)j * A.n + i] : 0.0;
+      if (s >= OPT - RES_MASKED) wm[s - (OPT - RES_MASKED)] = valid ? 1.0 : 0.0;
+    }
+  }
+
+  // collective evaluation of f(theta1) for all chains of the workgroup; on return s_part holds
+  // what finish needs (streamed: 8 wave partials per chain; resident: 2 half totals per chain)
+  auto evaluate = [&]() {
+    if constexpr (RESIDENT) {
+      double m0[CW], bb[CW][PR], acc[CW];
+#pragma unroll
+      for (int c = 0; c < CW; c++) {
+        m0[c] = A.intercept ? thp[c][0] : 0.0;
+#pragma unroll
+        for (int j = 0; j < P; j++) bb[c][j] = thp[c][A.intercept + j];
+        acc[c] = 0.0;
+      }
+#pragma unroll
+      for (int s = 0; s < OPT; s++) {
+#pragma unroll
+        for (int c = 0; c < CW; c++) {
+          double m = m0[c];
+#pragma unroll
+          for (int j = 0; j < P; j++) m = fmh_fma(xr[s][j], bb[c][j], m);
+          double r = yr[s] - m;
+          if (s >= OPT - RES_MASKED) acc[c] = fmh_fma(r * wm[s - (OPT - RES_MASKED)], r, acc[c]);
+          else acc[c] = fmh_fma(r, r, acc[c]);
+        }
+      }
+      // canonical tree through LDS: lane partials -> [chain][lane]; wave (c, h) folds 256 lanes
+#pragma unroll
+      for (int c = 0; c < CW; c++) s_tr[c * NT + tid] = acc[c];
+      __syncthreads();
+      for (int job = wave; job < 2 * CW; job += NW) {
+        const int c = job % CW, h = job / CW;
+        const double* src = s_tr + c * NT + 256 * h + 4 * lane;
+        double v = (src[0] + src[1]) + (src[2] + src[3]);      // levels 1, 2
+        v = wave_xor_sum(v);                                   // levels 4..128
+        if (lane == 0) s_part[h * CW + c] = v;
+      }
+    } else {
+      eval_partials<CW>(A, thp, s_part);
+    }
+  };
+  auto total_of = [&](int c) -> double {
+    if constexpr (RESIDENT) {
+      return s_part[0 * CW + c] + s_part[1 * CW + c];           // level 256
+    } else {
+      double w0 = s_part[0 * CW + c], w1 = s_part[1 * CW + c], w2 = s_part[2 * CW + c], w3 = s_part[3 * CW + c];
+      double w4 = s_part[4 * CW + c], w5 = s_part[5 * CW + c], w6 = s_part[6 * CW + c], w7 = s_part[7 * CW + c];
+      return ((w0 + w1) + (w2 + w3)) + ((w4 + w5) + (w6 + w7));  // levels 64, 128, 256
+    }
+  };
+
+  // ---- per-chain registers of the owner wavefront (uniform across its lanes)
+  double f0 = 0.0, f1 = 0.0;
+  long long abs_iter = 0, nacc = 0;
+  int have_mean = 0, nerr = 0, status = FMCMC_CHAIN_OK;
+  unsigned int bitword = 0;
+  const bool mirror = (A.kind == FMCMC_KERNEL_NMIRROR || A.kind == FMCMC_KERNEL_UMIRROR);
+  double obs_arate = fmh_nan();   // mirror kernels
+  long long nzero = 0;            // rows 2..i-1 of this call equal to their predecessor (rowSums(diff(ans)^2) == 0)
+  double* Scur = L.SigA;   // ram: current factor buffer
+  double* Salt = L.SigB;
+
+  if (owner) {
+    if (lane < k) {
+      double t = A.theta0[cl * k + lane];
+      L.th0[lane] = t;
+      L.th1[lane] = t;
+    }
+    if (mirror) {
+      if (lane < k) {
+        L.mmu[lane] = A.fresh ? A.mu[lane] : A.mirror_mu[cl * k + lane];
+        L.msc[lane] = A.fresh ? A.scale[lane] : A.mirror_scale[cl * k + lane];
+      }
+      if (!A.fresh) { abs_iter = A.abs_iter[cl]; obs_arate = A.obs_arate[cl]; }
+    }
+    if (adaptive) {
+      if (A.fresh) {
+        for (int e = lane; e < kf * LD; e += 64) {
+          int a = e / LD, b = e % LD;
+          L.SigA[e] = (a == b) ? 1.0 * A.eps : 0.0;
+          L.SigB[e] = 0.0;
+        }
+      } else {
+        for (int e = lane; e < kf * LD; e += 64) {
+          int a = e / LD, b = e % LD;
+          L.SigA[e] = (b < kf) ? A.Sigma[(cl * kf + a) * kf + b] : 0.0;
+          L.SigB[e] = 0.0;
+        }
+        abs_iter = A.abs_iter[cl];
+        if (A.nerrors) nerr = A.nerrors[cl];
+        if (A.kind == FMCMC_KERNEL_ADAPT) {
+          have_mean = A.have_mean[cl];
+          if (lane < kf) L.vmp[lane] = A.mean_prev[cl * kf + lane];
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- row 1: f0 = f(initial)
+  evaluate();
+  __syncthreads();
+  const long long S = A.S;
+  // row bookkeeping without integer division: `thin_ctr` counts rows since the last kept one
+  const int nsteps = (int)A.nsteps, burnin = (int)A.burnin, thin = (int)A.thin;
+  int thin_ctr = 0;       // (r - burnin) mod thin for r > burnin
+  long long srow = 0;     // next kept-row index
+  double* const out_s = A.samples + (cl * k + (lane < k ? lane : 0)) * S;
+  double* const out_d = A.draws ? A.draws + (cl * k + (lane < k ? lane : 0)) * S : nullptr;
+  double* const out_l = A.logpost ? A.logpost + cl * S : nullptr;
+  auto store_row = [&](int r, double lpv) {
+    if (r > burnin) {
+      thin_ctr += 1;
+      if (thin_ctr == thin) {
+        thin_ctr = 0;
+        if (lane < k) {
+          out_s[srow] = L.th0[lane];
+          if (out_d) out_d[srow] = L.th1[lane];
+        }
+        if (out_l && lane == 0) out_l[srow] = lpv;
+        srow += 1;
+      }
+    }
+  };
+  if (owner) {
+    f0 = finish_logpost(A, L.th1, total_of(myc));
+    f1 = f0;
+    if (lane < kf) L.vrs[lane] = L.th0[s_which[lane]];
+    if (A.hist_rows > 0 && lane < kf) A.hist[((long long)cl * A.hist_rows + (1 % A.hist_rows)) * kf + lane] = L.th0[s_which[lane]];
+    store_row(1, f0);
+  }
+
+  // ---- main loop
+  int tt = -1;         // position inside the RNG tile
+  int ord = 0;         // ordered scheme: (i - 1) mod kf
+  for (int i = 2; i <= nsteps; i++) {
+    tt = (tt + 1 == TB) ? 0 : tt + 1;
+    ord = (ord + 1 == kf) ? 0 : ord + 1;
+    bool ram_gate = false;
+    // ================= RNG tile: all 512 threads draw the variates of the next TB steps ===========
+    if (tt == 0) {
+      __syncthreads();  // owners are done with the previous tile (and with s_part)
+      const int per_c = TB * (kz + 1);
+      for (int idx = tid; idx < CW * per_c; idx += NT) {
+        const int c = idx / per_c, rem = idx - c * per_c;
+        const int t = rem / (kz + 1), a = rem - t * (kz + 1);
+        const long long ii = (long long)i + t;
+        if (c < ncw && ii <= A.nsteps) {
+          const long long clc = cg0 + c;
+          const unsigned int cg = (unsigned int)(A.chain_base + clc);
+          const unsigned int st = (unsigned int)(A.step_base + ii);
+          double v;
+          if (a == kz) {
+            v = (A.rng_mode == FMCMC_RNG_FED) ? A.fed_logu[clc * A.nsteps + (ii - 1)] : fmh_log_accept_u(A.seed, st, cg);
+            s_lu[c * TB + t] = v;
+          } else {
+            if (A.rng_mode == FMCMC_RNG_FED) v = A.fed_z[(clc * A.nsteps + (ii - 1)) * kz + a];
+            else if (A.kind == FMCMC_KERNEL_RAM) v = fmh_student_t(A.seed, st, cg, (unsigned int)a, (double)kf);
+            else if (A.variate == 1) v = fmh_unif(A.seed, st, cg, (unsigned int)a);
+            else v = fmh_normal(A.seed, st, cg, (unsigned int)a);
+            s_zt[(c * TB + t) * kz + a] = v;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    const double* zt = s_zt + ((owner ? myc : 0) * TB + tt) * kz;
+    // ================= scalar phase A: proposal =================
+    if (owner && status == FMCMC_CHAIN_OK) {
+      if (A.kind == FMCMC_KERNEL_NORMAL || A.kind == FMCMC_KERNEL_NORMAL_REFLECTIVE) {
+        if (lane < k) L.th1[lane] = L.th0[lane];
+        wave_sync();
+        const bool refl = (A.kind == FMCMC_KERNEL_NORMAL_REFLECTIVE);
+        // plan_update_sequence (R/kernel.R:66-133): every scheme but "joint" updates ONE parameter per step
+        const bool single = (A.scheme != FMCMC_SCHEME_JOINT);
+        int col = 0;
+        if (A.scheme == FMCMC_SCHEME_ORDERED) {
+          col = s_which[ord];
+        } else if (A.scheme == FMCMC_SCHEME_EXPLICIT) {
+          col = A.scheme_seq[(i - 1) % A.scheme_len];
+        } else if (A.scheme == FMCMC_SCHEME_RANDOM) {
+          if (A.rng_mode == FMCMC_RNG_FED) {
+            col = A.scheme_cols[cl * A.nsteps + (i - 1)];
+          } else {
+            // sample(which(!fixed), nsteps, TRUE)[i]; a single free parameter at position j makes R sample from 1:j
+            const unsigned int npool = (kf == 1) ? (unsigned int)(s_which[0] + 1) : (unsigned int)kf;
+            const unsigned int idx = fmh_scheme_index(A.seed, (unsigned int)i, cgid, npool);
+            col = (kf == 1) ? (int)idx : s_which[idx];
+            if (A.scheme_cols && lane == 0) A.scheme_cols[cl * A.nsteps + (i - 1)] = col;
+          }
+        }
+        const int nupd = single ? 1 : kf;
+        if (lane < nupd) {
+          int j = single ? col : s_which[lane];
+          double z = zt[lane];
+          double t = L.th0[j] + (s_mu[j] + s_scale[j] * z);
+          if (refl) t = reflect1(t, s_lb[j], s_ub[j]);
+          L.th1[j] = t;
+        }
+      } else if (mirror) {
+        // R/kernel_mirror.R:66-131 (nmirror), :203-262 (umirror); twin of the oracle's propose_mirror
+        if (abs_iter >= 1 && abs_iter <= A.warmup && lane < k)   // mu <<- mean_recursive(ans[i-1, ], mu, abs_iter)
+          L.mmu[lane] = (L.mmu[lane] * (double)abs_iter + L.th0[lane]) / ((double)abs_iter + 1);
+        if (abs_iter == A.nadapt) {   // the one-off scale adaptation (the closure reads its argument `nadapt`)
+          obs_arate = 1.0 - (double)nzero / (double)(i - 2);
+          const double num = fmh_tan_0_halfpi(1.5707963267948966 * obs_arate);
+          const double den = fmh_tan_0_halfpi(1.5707963267948966 * A.arate);
+          if (lane < k) L.msc[lane] = L.msc[lane] * num / den;
+        }
+        if (lane < k) L.th1[lane] = L.th0[lane];
+        wave_sync();
+        const bool single = (A.scheme != FMCMC_SCHEME_JOINT);
+        int col = 0;
+        if (A.scheme == FMCMC_SCHEME_ORDERED) {
+          col = s_which[ord];
+        } else if (A.scheme == FMCMC_SCHEME_EXPLICIT) {
+          col = A.scheme_seq[(i - 1) % A.scheme_len];
+        } else if (A.scheme == FMCMC_SCHEME_RANDOM) {
+          if (A.rng_mode == FMCMC_RNG_FED) {
+            col = A.scheme_cols[cl * A.nsteps + (i - 1)];
+          } else {
+            const unsigned int npool = (kf == 1) ? (unsigned int)(s_which[0] + 1) : (unsigned int)kf;
+            const unsigned int idx = fmh_scheme_index(A.seed, (unsigned int)i, cgid, npool);
+            col = (kf == 1) ? (int)idx : s_which[idx];
+            if (A.scheme_cols && lane == 0) A.scheme_cols[cl * A.nsteps + (i - 1)] = col;
+          }
+        }
+        const int nupd = single ? 1 : kf;
+        if (lane < nupd) {
+          const int j = single ? col : s_which[lane];
+          const double z = zt[lane];
+          double t;
+          if (A.kind == FMCMC_KERNEL_NMIRROR) {
+            t = (2.0 * L.mmu[j] - L.th0[j]) + L.msc[j] * z;
+          } else {   // runif(k, 2 mu - theta[which.] -+ sqrt3 scale): mu / scale of the a-th updated parameter are [a], as in R
+            const double sqrt3 = fmh_sqrt(3.0);
+            const double c = 2.0 * L.mmu[lane] - L.th0[j];
+            const double lo = c - sqrt3 * L.msc[lane], hi = c + sqrt3 * L.msc[lane];
+            t = lo + (hi - lo) * z;
+          }
+          L.th1[j] = reflect1(t, s_lb[j], s_ub[j]);
+        }
+        abs_iter += 1;
+      } else if (A.kind == FMCMC_KERNEL_ADAPT) {
+        // R/kernel_adapt.R:117-166
+        if (A.until > (double)abs_iter && abs_iter > A.warmup && i > 2 && (i % A.freq) == 0) {
+          const int H = A.hist_rows;
+          double* ring = A.hist + (long long)cl * H * kf;
+          if (H > 0) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");   // the ring rows were stored by other lanes of this wave
+          if (A.bw > 0) {
+            // windowed AM: Sigma <<- Sd * (cov(ans[(i - bw + 1):(i - 1), which.]) + Ik) :120-125 (twin of the oracle's canonical cov)
+            const int N = A.bw - 1;
+            if (i - A.bw + 1 < 1 || N < 2) {
+              status = FMCMC_CHAIN_BAD_WINDOW;
+            } else {
+              double m = 0.0;
+              if (lane < kf) {
+                double sm = 0.0;
+                for (int r = i - A.bw + 1; r <= i - 1; r++) sm = sm + ring[(long long)(r % H) * kf + lane];
+                m = sm / (double)N;
+                for (int b = 0; b < kf; b++) L.SigA[lane * LD + b] = 0.0;
+              }
+              for (int r = i - A.bw + 1; r <= i - 1; r++) {
+                double d = 0.0;
+                if (lane < kf) {
+                  d = ring[(long long)(r % H) * kf + lane] - m;
+                  L.vv[lane] = d;
+                }
+                wave_sync();
+                if (lane < kf)
+                  for (int b = 0; b < kf; b++) L.SigA[lane * LD + b] = fmh_fma(d, L.vv[b], L.SigA[lane * LD + b]);
+                wave_sync();
+              }
+              if (lane < kf)
+                for (int b = 0; b < kf; b++) {
+                  const double ik = (b == lane) ? 1.0 * A.eps : 0.0;
+                  L.SigA[lane * LD + b] = A.Sd * (L.SigA[lane * LD + b] / (double)(N - 1) + ik);
+                }
+              wave_sync();
+            }
+          } else if (i - A.freq < 1) {
+            status = FMCMC_CHAIN_BAD_WINDOW;   // R: ans[0:(i-1), ] has fewer than freq rows, `[, , freq]` is out of bounds
+          } else {
+            // rows (i - freq):(i - 1) folded in one by one, t. = abs_iter - freq + (row - 1) (R/recursive.R:79-108,:129-136)
+            for (int jr = 0; jr < A.freq; jr++) {
+              const double t = (double)(abs_iter - A.freq + jr);
+              double x = 0, mp = 0, mt = 0;
+              if (lane < kf) {
+                x = (A.freq == 1) ? L.th0[s_which[lane]] : ring[(long long)((i - A.freq + jr) % H) * kf + lane];
+                mp = have_mean ? L.vmp[lane] : (L.vrs[lane] / (double)(i - 1));
+                mt = (mp * t + x) / (t + 1);
+                L.vv[lane] = x;
+                L.vmp[lane] = mp;
+                L.vmt[lane] = mt;
+              }
+              wave_sync();
+              if (lane < kf) {
+                const double c1 = (t - 1) / t, c2 = 1.0 / t;
+                for (int b = 0; b < kf; b++) {
+                  double ik = (b == lane) ? 1.0 * A.eps : 0.0;
+                  double inner = t * (mp * L.vmp[b]) - (t + 1) * (mt * L.vmt[b]) + x * L.vv[b] + 1e-5 * ik;
+                  L.SigA[lane * LD + b] = c1 * L.SigA[lane * LD + b] + c2 * inner;
+                }
+              }
+              wave_sync();
+              if (lane < kf) L.vmp[lane] = mt;
+              have_mean = 1;
+            }
+          }
+        }
+        abs_iter += 1;
+        // left-looking Cholesky, lane = row (twin of oracle chol_lower_canon)
+        bool notpd = false;
+        for (int j = 0; j < kf && status == FMCMC_CHAIN_OK; j++) {
+          double s = 0.0;
+          if (lane >= j && lane < kf) {
+            s = L.SigA[lane * LD + j];
+            for (int b = 0; b < j; b++) s = fmh_fma(-L.SigB[lane * LD + b], L.SigB[j * LD + b], s);
+          }
+          double d = shfl_d(s, j);
+          if (!(d > 0.0) || !fmh_isfinite(d)) { notpd = true; break; }
+          double ljj = fmh_sqrt(d);
+          if (lane == j) L.SigB[j * LD + j] = ljj;
+          else if (lane > j && lane < kf) L.SigB[lane * LD + j] = s / ljj;
+          wave_sync();
+        }
+        if (notpd) {
+          status = FMCMC_CHAIN_NOT_PD;
+        } else if (status == FMCMC_CHAIN_OK) {
+          if (lane < k) L.th1[lane] = L.th0[lane];
+          wave_sync();
+          if (lane < kf) {
+            double s = 0.0;
+            for (int b = 0; b <= lane; b++) s = fmh_fma(L.SigB[lane * LD + b], zt[b], s);
+            int j = s_which[lane];
+            double t = L.th0[j] + (s_mu[j] + s);
+            L.th1[j] = reflect1(t, s_lb[j], s_ub[j]);
+          }
+        }
+      } else {  // RAM, R/kernel_ram.R:123-126
+        if (lane < kf) {
+          double s = 0.0;
+          for (int b = 0; b <= lane; b++) s = fmh_fma(Scur[lane * LD + b], zt[b], s);
+          L.vv[lane] = s;
+          int j = s_which[lane];
+          L.th1[j] = L.th0[j] + s;
+        }
+        ram_gate = (A.until > (double)abs_iter && abs_iter > A.warmup && (i % A.freq) == 0);
+      }
+      if (status != FMCMC_CHAIN_OK) {  // raised inside the proposal (NOT_PD)
+        if (lane == 0) { A.status[cl] = status; A.status_step[cl] = i; }
+        if (lane < k) A.status_theta[cl * k + lane] = L.th1[lane];
+      }
+    }
+    __syncthreads();
+    // ================= collective evaluation of f(theta1) =================
+    evaluate();
+    __syncthreads();
+    // ================= scalar phase B: RAM adaptation (needs f(theta1) un-reflected) =================
+    if (A.kind == FMCMC_KERNEL_RAM) {
+      bool changed = false;
+      if (owner && status == FMCMC_CHAIN_OK) {
+        if (ram_gate) {
+          double f1u = finish_logpost(A, L.th1, total_of(myc));
+          double a_n = fmh_exp(f1u - f0);
+          if (fmh_isnan(a_n)) a_n = 0.0;
+          else if (a_n > 1.0) a_n = 1.0;
+          double eta = (double)kf * fmh_exp((-2.0 / 3.0) * fmh_log((double)i));
+          if (eta > 1.0) eta = 1.0;
+          double nrm2 = 0.0;
+          for (int b = 0; b < kf; b++) nrm2 = fmh_fma(zt[b], zt[b], nrm2);
+          double cp = (eta * (a_n - A.arate)) / nrm2;
+          if (cp != 0.0 && fmh_isfinite(cp)) {
+            const bool up = cp > 0.0;
+            const double scl = fmh_sqrt(fmh_abs(cp));
+            double w = (lane < kf) ? scl * L.vv[lane] : 0.0;
+            bool fail = false;
+            for (int j = 0; j < kf; j++) {
+              double ljj = Scur[j * LD + j];
+              double xj = shfl_d(w, j);
+              double r2 = up ? fmh_fma(xj, xj, ljj * ljj) : fmh_fma(-xj, xj, ljj * ljj);
+              if (!(r2 > 0.0) || !fmh_isfinite(r2)) { fail = true; break; }
+              double r = fmh_sqrt(r2);
+              double cc = r / ljj, ss = xj / ljj;
+              if (lane == j) {
+                Salt[j * LD + j] = r;
+              } else if (lane > j && lane < kf) {
+                double lij = Scur[lane * LD + j];
+                double ln = (up ? fmh_fma(ss, w, lij) : fmh_fma(-ss, w, lij)) / cc;
+                w = fmh_fma(-ss, ln, cc * w);
+                Salt[lane * LD + j] = ln;
+              }
+            }
+            wave_sync();
+            if (fail) {
+              nerr += 1;
+            } else {
+              double* t = Scur; Scur = Salt; Salt = t;
+            }
+          }
+          if (A.constr) {  // Sigma <<- constr[which., which.] * Sigma (R/kernel_ram.R:149-150)
+            if (lane < kf)
+              for (int b = 0; b < kf; b++) Scur[lane * LD + b] = A.constr[lane * kf + b] * Scur[lane * LD + b];
+            wave_sync();
+          }
+        }
+        abs_iter += 1;
+        if (A.ram_bounded) {
+          if (lane < kf) {
+            int j = s_which[lane];
+            double t0 = L.th1[j];
+            double t1 = reflect1(t0, s_lb[j], s_ub[j]);
+            if (!(t1 == t0)) { L.th1[j] = t1; changed = true; }
+          }
+          if (__any(changed)) s_flag[0] = 1;
+        }
+      }
+      if (A.ram_bounded) {  // uniform over the workgroup (launch-time constant)
+        __syncthreads();
+        const bool again = (s_flag[0] != 0);
+        __syncthreads();
+        if (again) {
+          if (tid == 0) s_flag[0] = 0;
+          evaluate();
+          __syncthreads();
+        }
+      }
+    }
+    // ================= scalar phase C: accept / store (R/mcmc.R:754-778) =================
+    if (owner && status == FMCMC_CHAIN_OK) {
+      f1 = finish_logpost(A, L.th1, total_of(myc));
+      if (fmh_isnan(f1)) status = FMCMC_CHAIN_NAN_LOGPOST;
+      const double ratio = f1 - f0;
+      if (status == FMCMC_CHAIN_OK && fmh_isnan(ratio)) status = FMCMC_CHAIN_NAN_RATIO;
+      if (status != FMCMC_CHAIN_OK) {
+        if (lane == 0) { A.status[cl] = status; A.status_step[cl] = i; }
+        if (lane < k) A.status_theta[cl * k + lane] = L.th1[lane];
+      } else {
+        const double lu = s_lu[myc * TB + tt];
+        bool moved = false;
+        if (lu < ratio) {
+          if (mirror) {   // rowSums(diff(ans)^2) of the row about to be stored (sequential sum, as in the oracle)
+            double sq = 0.0;
+            for (int a = 0; a < k; a++) sq = sq + (L.th1[a] - L.th0[a]) * (L.th1[a] - L.th0[a]);
+            moved = (sq != 0.0);
+            wave_sync();
+          }
+          if (lane < k) L.th0[lane] = L.th1[lane];
+          f0 = f1;
+          nacc += 1;
+          bitword |= (1u << ((i - 1) & 31));
+        }
+        if (mirror && !moved) nzero += 1;
+        wave_sync();
+        store_row(i, f1);
+        if (A.kind == FMCMC_KERNEL_ADAPT && lane < kf) L.vrs[lane] = L.vrs[lane] + L.th0[s_which[lane]];
+        if (A.hist_rows > 0 && lane < kf)   // row i of ans[, which.] for the windowed / strided adaptation
+          A.hist[((long long)cl * A.hist_rows + (i % A.hist_rows)) * kf + lane] = L.th0[s_which[lane]];
+      }
+    }
+    if (owner && A.accept_bits && lane == 0 && (((i - 1) & 31) == 31 || i == nsteps)) {
+      A.accept_bits[cl * (long long)((nsteps + 31) >> 5) + ((i - 1) >> 5)] = bitword;
+      bitword = 0;
+    }
+  }
+
+  // ---- write state back
+  if (owner) {
+    if (lane < k) A.theta0[cl * k + lane] = L.th0[lane];
+    if (lane == 0) {
+      A.f0[cl] = f0;
+      A.accept_count[cl] = nacc;
+      if (status == FMCMC_CHAIN_OK) { A.status[cl] = FMCMC_CHAIN_OK; A.status_step[cl] = 0; }
+      if (mirror) { A.abs_iter[cl] = abs_iter; A.obs_arate[cl] = obs_arate; }
+      if (adaptive) {
+        A.abs_iter[cl] = abs_iter;
+        if (A.nerrors) A.nerrors[cl] = nerr;
+        if (A.kind == FMCMC_KERNEL_ADAPT) A.have_mean[cl] = have_mean;
+      }
+    }
+    if (mirror && lane < k) {
+      A.mirror_mu[cl * k + lane] = L.mmu[lane];
+      A.mirror_scale[cl * k + lane] = L.msc[lane];
+    }
+    if (adaptive) {
+      wave_sync();
+      const double* Sfin = (A.kind == FMCMC_KERNEL_RAM) ? Scur : L.SigA;
+      for (int e = lane; e < kf * kf; e += 64) {
+        int a = e / kf, b = e % kf;
+        A.Sigma[(cl * kf + a) * kf + b] = Sfin[a * LD + b];
+      }
+      if (A.kind == FMCMC_KERNEL_ADAPT && lane < kf) A.mean_prev[cl * kf + lane] = L.vmp[lane];
+    }
+  }
+}
+
+}  // namespace
