@@ -176,3 +176,61 @@ def test_plan_update_sequence_matches_the_reference_rules():
         P(3, 3, False, [1, 2])
     with pytest.raises(ValueError, match="-scheme- update must be"):
         P(3, 3, False, "sideways")
+
+
+def _ar1(phi, n, seed):
+    rng = np.random.default_rng(seed)
+    e = rng.standard_normal(n)
+    y = np.zeros(n)
+    for t in range(1, n):
+        y[t] = phi * y[t - 1] + e[t]
+    return y
+
+
+def test_spectrum0_ar_and_yule_walker():
+    """coda::spectrum0.ar = var.pred / (1 - sum(ar))^2 of stats::ar(aic = TRUE); Levinson-Durbin == the Toeplitz solve."""
+    from fmcmc_amd.convergence import _ar_yw, _pcramer
+    y = _ar1(0.6, 40000, 1)
+    s0, order = f.spectrum0_ar(y)
+    assert order >= 1 and abs(s0 - 1 / 0.4 ** 2) / 6.25 < 0.12
+    ar, vp, order = _ar_yw(y)
+    n = y.size
+    x = y - y.mean()
+    r = np.array([np.dot(x[:n - l], x[l:]) / n for l in range(order + 1)])
+    T = np.array([[r[abs(i - j)] for j in range(order)] for i in range(order)])
+    assert np.allclose(ar, np.linalg.solve(T, r[1:]), atol=1e-10)
+    assert np.isclose(vp, (r[0] - ar @ r[1:]) * n / (n - (order + 1)), rtol=1e-10)
+    assert f.spectrum0_ar(np.full(50, 3.0)) == (0.0, 0) and f.spectrum0_ar(2.0 + 0.5 * np.arange(50.0)) == (0.0, 0)
+    # Cramer-von Mises distribution: published 5 % and 1 % critical values 0.461 and 0.743
+    assert abs(_pcramer(0.461) - 0.95) < 2e-3 and abs(_pcramer(0.743) - 0.99) < 2e-3
+
+
+def test_geweke_and_heidel_checkers():
+    """R/convergence.R:248-344 on host chains: stationary chains pass, drifting ones do not; error texts."""
+    n = 4000
+    it = np.arange(1, n + 1)
+    stat = np.stack([5 + _ar1(0.5, n, 2), -3 + _ar1(0.2, n, 3)], axis=1)
+    drift = stat + np.linspace(0, 6, n)[:, None]
+    z = f.geweke_diag(stat, it)
+    assert z.shape == (2,) and np.all(np.abs(z) < 3.5) and np.all(np.abs(f.geweke_diag(drift, it)) > 5)
+    gw = f.convergence_geweke(200)
+    assert gw(f.Mcmc(stat, start=1, end=n, thin=1)) is True and "avg Geweke's Z" in gw.msg and len(gw.history) == 1
+    # the reference compares 1 - p-value with the threshold (R/convergence.R:283-288), so a drifting chain (|z| large) passes
+    # -- kept as it is; a non-finite z (both windows constant) does not
+    assert gw(f.Mcmc(drift, start=1, end=n, thin=1)) is True
+    step = (np.arange(n) >= n // 3).astype(float)[:, None]
+    assert not np.isfinite(f.geweke_diag(step, it)[0]) and gw(f.Mcmc(step, start=1, end=n, thin=1)) is False
+    h = f.heidel_diag(stat, it)
+    assert h.shape == (2, 6) and np.all(h[:, 0] == 1) and np.all(h[:, 3] == 1) and np.allclose(h[:, 4], stat.mean(0), atol=0.2)
+    hd = f.convergence_heildel(500)
+    assert hd(f.Mcmc(stat, start=1, end=n, thin=1)) is True and "Heidel's Avg. pval" in hd.msg
+    assert hd(f.Mcmc(np.cumsum(stat, axis=0), start=1, end=n, thin=1)) is False          # random walk: not stationary
+    two = f.McmcList([f.Mcmc(stat, start=1, end=n, thin=1)] * 2)
+    with pytest.raises(ValueError, match="only available with runs of a single chain"):
+        gw(two)
+    with pytest.raises(ValueError, match="only available with runs of a single chain"):
+        hd(two)
+    with pytest.warns(UserWarning, match="failed to be computed"):
+        assert gw(f.Mcmc(np.ones((1, 1)), start=1, end=1, thin=1)) is False
+    thinned = f.geweke_diag(stat[::10], it[::10])      # window() works on iteration labels, not row numbers
+    assert thinned.shape == (2,) and np.all(np.isfinite(thinned))

@@ -304,3 +304,32 @@ def test_mcmc_api_mirror_kernels(E, O, readme_data):
         assert np.array_equal(_bits(ans.as_array()), _bits(ro.samples))
         assert np.array_equal(_bits(kern[2].mu), _bits(ro.state.mirror_mu[1])) and kern[3].obs_arate == ro.state.obs_arate[2]
         assert list(kern.abs_iter) == [799] * 3 and abs(ans.as_array()[:, 300:, 0].mean() - 3.1) < 0.6
+
+
+def test_single_chain_checkers_in_mcmc(E, O):
+    """vignettes/workflow-with-fmcmc.Rmd:95-106 (logistic model, convergence_geweke(200)) and
+    inst/tinytest/test-convergence.R (convergence_auto picks Geweke for one chain, Gelman for several; Heidelberger)."""
+    import fmcmc_amd as f
+    rng = np.random.default_rng(7)
+    n = 500
+    X = rng.standard_normal((n, 2))
+    yb = (rng.uniform(size=n) < 1 / (1 + np.exp(-(0.5 + X @ [1.0, -1.0])))).astype(float)
+    fun = f.logistic(X, yb, intercept=True, prior_div=8.0)
+    gw = f.convergence_geweke(200)
+    out = f.MCMC([0.0, 0.0, 0.0], fun, 3000, seed=42, kernel=f.kernel_normal(scale=0.2), conv_checker=gw)
+    assert isinstance(out, f.Mcmc) and out.niter % 200 == 0 and len(gw.history) == out.niter // 200 and "Geweke" in gw.msg
+    # the GPU chain and the checker's verdicts equal a host replay on the oracle's chain
+    ro = O.run(O.Model(O.FAM_LOGISTIC, X, yb, prior_div=8.0), O.Kernel(O.K_NORMAL, 3, scale=0.2), [0.0, 0.0, 0.0], nsteps=200, seed=42)
+    assert np.array_equal(_bits(out.data[:200]), _bits(ro.samples[0]))
+    z_host = f.geweke_diag(out.data[:200], np.arange(1, 201))
+    assert np.allclose(gw.history[0][1], z_host, rtol=1e-12, equal_nan=True)
+    au = f.convergence_auto(300)
+    o1 = f.MCMC([0.0, 0.0, 0.0], fun, 1500, seed=1, kernel=f.kernel_normal(scale=0.2), conv_checker=au)
+    assert isinstance(o1, f.Mcmc) and "Geweke" in au.msg
+    o2 = f.MCMC(np.zeros((3, 3)), fun, 1500, seed=1, nchains=3, kernel=f.kernel_normal(scale=0.2), conv_checker=au)
+    assert isinstance(o2, f.McmcList) and "Gelman" in au.msg
+    hd = f.convergence_heildel(500)
+    o3 = f.MCMC([0.0, 0.0, 0.0], fun, 2000, seed=3, kernel=f.kernel_normal(scale=0.2), conv_checker=hd)
+    assert len(hd.history) >= 1 and hd.history[0][1].shape == (3, 6)
+    with pytest.raises(ValueError, match="single chain"):
+        f.MCMC(np.zeros((2, 3)), fun, 2000, seed=3, nchains=2, kernel=f.kernel_normal(scale=0.2), conv_checker=hd)
