@@ -333,3 +333,48 @@ def test_single_chain_checkers_in_mcmc(E, O):
     assert len(hd.history) >= 1 and hd.history[0][1].shape == (3, 6)
     with pytest.raises(ValueError, match="single chain"):
         f.MCMC(np.zeros((2, 3)), fun, 2000, seed=3, nchains=2, kernel=f.kernel_normal(scale=0.2), conv_checker=hd)
+
+
+def test_host_pointer_entry_point_new_rows(E, O):
+    """fmcmc_mcmc_run_host stages the ABI-v2 fields too: explicit / random schemes, uniform and mirror kernels,
+    kernel_ram(freq, constr), kernel_adapt(bw)."""
+    from fmcmc_amd import _abi as abi
+    X, y = synth_linreg(1300, 2, 6)
+    Cn, k, nsteps = 4, 4, 200
+    init = np.ascontiguousarray(np.array([0.5, 0.5, 0.5, 4.0])[None, :] + 0.1 * np.random.default_rng(1).standard_normal((Cn, k)))
+    band = (np.abs(np.subtract.outer(np.arange(k), np.arange(k))) <= 1).astype(float)
+    cases = [(O.K_UNIF, dict(min_=-0.1, max_=0.1, scheme=[2, 4, 1, 3])),
+             (O.K_NORMAL_REFLECTIVE, dict(scale=0.05, lb=[-9, -9, -9, 0.1], ub=9.0, scheme="random")),
+             (O.K_UMIRROR, dict(mu=[0.5, 0.5, 0.5, 4.0], scale=0.1, warmup=100, nadapt=5, lb=[-9, -9, -9, 0.1], ub=9.0)),
+             (O.K_RAM, dict(freq=2, constr=band)),
+             (O.K_ADAPT, dict(bw=15, warmup=20, Sd=0.6))]
+    P = lambda a: a.ctypes.data if a is not None else None
+    for kind, okw in cases:
+        ok = O.Kernel(kind, k, **okw)
+        ost = O.ChainState(init, ok.kf)
+        ro = O.run(O.Model(O.FAM_LINREG, X, y), ok, nsteps=nsteps, seed=5, state=ost)
+        Xc = np.ascontiguousarray(X.T); yc = np.ascontiguousarray(y)
+        th = init.copy(); f0 = np.zeros(Cn); abs_iter = np.zeros(Cn, np.int64)
+        Sig = np.zeros((Cn, k, k)); mp = np.zeros((Cn, k)); hm = np.zeros(Cn, np.int32); ne = np.zeros(Cn, np.int32)
+        cols = np.zeros((Cn, nsteps), np.int32); mmu = np.zeros((Cn, k)); msc = np.zeros((Cn, k)); oar = np.full(Cn, np.nan)
+        samples = np.empty((Cn, k, nsteps)); lp = np.empty((Cn, nsteps)); dr = np.empty((Cn, k, nsteps))
+        acc = np.zeros(Cn, np.int64); bits = np.zeros((Cn, (nsteps + 31) // 32), np.uint32)
+        status = np.zeros(Cn, np.int32); sstep = np.zeros(Cn, np.int64); stheta = np.zeros((Cn, k))
+        m = abi.Model(abi.FAM_GAUSSIAN_LINREG, 2, 1300, P(Xc), P(yc), 1, 1, 0.0)
+        kk = abi.Kernel(kind, k, P(ok.mu), P(ok.scale), P(ok.lb), P(ok.ub), P(ok.fixed), ok.scheme, ok.freq, ok.warmup, ok.bw,
+                        ok.until, ok.eps, ok.arate, ok.Sd, P(ok.scheme_seq), 0 if ok.scheme_seq is None else ok.scheme_seq.size,
+                        ok.nadapt, P(ok.constr))
+        r = abi.Run(Cn, nsteps, 0, 1, 5, 0, 0, 0, 0, None, None)
+        st = abi.State(P(th), P(f0), P(abs_iter), P(Sig), P(mp), P(hm), P(ne), 1, 0, P(cols), P(mmu), P(msc), P(oar))
+        out = abi.Out(P(samples), P(lp), P(dr), P(acc), P(bits), P(status), P(sstep), P(stheta))
+        rc = abi.lib().fmcmc_mcmc_run_host(C.byref(m), C.byref(kk), C.byref(r), C.byref(st), C.byref(out), 0)
+        assert rc == 0, abi.last_error()
+        assert np.array_equal(_bits(samples), _bits(ro.samples_cks)), kind
+        assert np.array_equal(_bits(dr), _bits(ro.draws_cks)) and np.array_equal(bits, ro.accept_bits)
+        if ok.scheme == O.SCHEME_RANDOM:
+            assert np.array_equal(cols[:, 1:], ost.scheme_cols[:, 1:])
+        if kind == O.K_UMIRROR:
+            assert np.array_equal(_bits(mmu), _bits(ost.mirror_mu)) and np.array_equal(_bits(msc), _bits(ost.mirror_scale))
+            assert np.array_equal(_bits(oar), _bits(ost.obs_arate)) and np.array_equal(abs_iter, ost.abs_iter)
+        if kind in (O.K_RAM, O.K_ADAPT):
+            assert np.array_equal(_bits(Sig), _bits(ost.Sigma))
