@@ -1,7 +1,8 @@
 // mh_engine.hip — gfx950 (MI355X) many-chain Metropolis-Hastings engine: the C-ABI (include/fmcmc_amd.h), validation,
 // kernel selection and launches.  The device code lives in the headers included below (one translation unit):
 //   mh_common.hpp  shared device helpers      mh_streamed.hpp  general kernel (all families / kernels / schemes)
-//   mh_pipe.hpp    RNG stream + pipelined VALU kernel   mh_mfma.hpp  fp64-MFMA kernel (headline)   mh_spec.hpp  wave-specialised kernel
+//   mh_pipe.hpp    RNG stream + pipelined VALU kernel   mh_mfma.hpp  fp64-MFMA kernel, owner waves (headline)
+//   mh_mfma_rep.hpp  fp64-MFMA kernel, replicated chain state   mh_spec.hpp  wave-specialised kernel
 //
 // Replaces, for ALL chains of a call at once, the per-chain loop of the reference
 //   R/mcmc.R:720-838 (loop, accept, burn-in/thin)  x  R/kernel_normal.R / R/kernel_adapt.R /
@@ -38,6 +39,7 @@
 #include "mh_streamed.hpp"
 #include "mh_pipe.hpp"
 #include "mh_mfma.hpp"
+#include "mh_mfma_rep.hpp"
 #include "mh_spec.hpp"
 
 namespace {
@@ -341,90 +343,44 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
     } while (0)
     const char* nospec = getenv("FMCMC_AMD_NO_SPEC");
     if (mfma_ng) {
-      const size_t mlds = mfma_lds_bytes();
+      // Two MFMA kernels with identical results.  mh_sweep_mfmar (chain state replicated in every wave, one barrier per
+      // step) is 2-10 % faster for the non-reflective kernels up to n = 8192 (same-box A/B, tools/bench_shapes_ab.py);
+      // mh_sweep_mfma (owner waves) is as fast or faster for n > 8192 and for the reflective kernels, whose reflection
+      // would run in all eight waves.  FMCMC_AMD_MFMA_OWNERS=1 / =0 forces one of them wherever it is compiled in.
       const int ns = (int)((m->n + NT - 1) / NT);   // observation slots of 512
-#define LAUNCH_MFMA(KV, GV, SV) hipLaunchKernelGGL((mh_sweep_mfma<KV, GV, SV, false>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A)
-      if ((A.debug & 8) && mfma_ng == 1 && ns == 20) {
-        if (kn->kind == FMCMC_KERNEL_NORMAL) hipLaunchKernelGGL((mh_sweep_mfma<1, 1, 20, true>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A);
+      const int kv = (kn->kind == FMCMC_KERNEL_NORMAL) ? 1 : 2;
+      const char* own0 = getenv("FMCMC_AMD_MFMA_OWNERS");
+      bool owners = !(kv == 1 && ns <= 16);
+      if (own0 && own0[0] == '0' && kv == 1) owners = false;
+      if (own0 && own0[0] == '1' && (kv == 2 || ns > 16)) owners = true;
+      const size_t mlds = owners ? mfma_lds_bytes() : mfmar_lds_bytes();
+      const bool dbgk = (A.debug & 8) != 0 && mfma_ng == 1 && ns == 20;
+#define MF_CASE(KN, KV, GV, SV) case SV: hipLaunchKernelGGL((KN<KV, GV, SV, false>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A); break;
+#define MF_CASES10(KN, KV, GV) MF_CASE(KN, KV, GV, 1) MF_CASE(KN, KV, GV, 2) MF_CASE(KN, KV, GV, 3) MF_CASE(KN, KV, GV, 4) MF_CASE(KN, KV, GV, 5) \
+                               MF_CASE(KN, KV, GV, 6) MF_CASE(KN, KV, GV, 7) MF_CASE(KN, KV, GV, 8) MF_CASE(KN, KV, GV, 9) MF_CASE(KN, KV, GV, 10)
+#define MF_CASES16(KN, KV, GV) MF_CASES10(KN, KV, GV) MF_CASE(KN, KV, GV, 11) MF_CASE(KN, KV, GV, 12) MF_CASE(KN, KV, GV, 13) \
+                               MF_CASE(KN, KV, GV, 14) MF_CASE(KN, KV, GV, 15) MF_CASE(KN, KV, GV, 16)
+#define MF_CASES17(KN, KV, GV) MF_CASE(KN, KV, GV, 17) MF_CASE(KN, KV, GV, 18) MF_CASE(KN, KV, GV, 19) MF_CASE(KN, KV, GV, 20)
+      if (dbgk && owners) {
+        if (kv == 1) hipLaunchKernelGGL((mh_sweep_mfma<1, 1, 20, true>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A);
         else hipLaunchKernelGGL((mh_sweep_mfma<2, 1, 20, true>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A);
-      } else if (mfma_ng == 2 && kn->kind == FMCMC_KERNEL_NORMAL) {
-        switch (ns) {
-          case 1: LAUNCH_MFMA(1, 2, 1); break;
-          case 2: LAUNCH_MFMA(1, 2, 2); break;
-          case 3: LAUNCH_MFMA(1, 2, 3); break;
-          case 4: LAUNCH_MFMA(1, 2, 4); break;
-          case 5: LAUNCH_MFMA(1, 2, 5); break;
-          case 6: LAUNCH_MFMA(1, 2, 6); break;
-          case 7: LAUNCH_MFMA(1, 2, 7); break;
-          case 8: LAUNCH_MFMA(1, 2, 8); break;
-          case 9: LAUNCH_MFMA(1, 2, 9); break;
-          case 10: LAUNCH_MFMA(1, 2, 10); break;
-          default: break;
-        }
+      } else if (dbgk) {
+        hipLaunchKernelGGL((mh_sweep_mfmar<1, 1, 20, true>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A);
+      } else if (!owners && mfma_ng == 2) {
+        switch (ns) { MF_CASES10(mh_sweep_mfmar, 1, 2) default: break; }
+      } else if (!owners) {
+        switch (ns) { MF_CASES16(mh_sweep_mfmar, 1, 1) MF_CASES17(mh_sweep_mfmar, 1, 1) default: break; }
+      } else if (kv == 1) {   // owners, non-reflective: n > 8192 only (and p <= 3, or the shape would not be here)
+        switch (ns) { MF_CASES17(mh_sweep_mfma, 1, 1) default: break; }
       } else if (mfma_ng == 2) {
-        switch (ns) {
-          case 1: LAUNCH_MFMA(2, 2, 1); break;
-          case 2: LAUNCH_MFMA(2, 2, 2); break;
-          case 3: LAUNCH_MFMA(2, 2, 3); break;
-          case 4: LAUNCH_MFMA(2, 2, 4); break;
-          case 5: LAUNCH_MFMA(2, 2, 5); break;
-          case 6: LAUNCH_MFMA(2, 2, 6); break;
-          case 7: LAUNCH_MFMA(2, 2, 7); break;
-          case 8: LAUNCH_MFMA(2, 2, 8); break;
-          case 9: LAUNCH_MFMA(2, 2, 9); break;
-          case 10: LAUNCH_MFMA(2, 2, 10); break;
-          default: break;
-        }
-      } else if (kn->kind == FMCMC_KERNEL_NORMAL) {
-        switch (ns) {
-          case 1: LAUNCH_MFMA(1, 1, 1); break;
-          case 2: LAUNCH_MFMA(1, 1, 2); break;
-          case 3: LAUNCH_MFMA(1, 1, 3); break;
-          case 4: LAUNCH_MFMA(1, 1, 4); break;
-          case 5: LAUNCH_MFMA(1, 1, 5); break;
-          case 6: LAUNCH_MFMA(1, 1, 6); break;
-          case 7: LAUNCH_MFMA(1, 1, 7); break;
-          case 8: LAUNCH_MFMA(1, 1, 8); break;
-          case 9: LAUNCH_MFMA(1, 1, 9); break;
-          case 10: LAUNCH_MFMA(1, 1, 10); break;
-          case 11: LAUNCH_MFMA(1, 1, 11); break;
-          case 12: LAUNCH_MFMA(1, 1, 12); break;
-          case 13: LAUNCH_MFMA(1, 1, 13); break;
-          case 14: LAUNCH_MFMA(1, 1, 14); break;
-          case 15: LAUNCH_MFMA(1, 1, 15); break;
-          case 16: LAUNCH_MFMA(1, 1, 16); break;
-          case 17: LAUNCH_MFMA(1, 1, 17); break;
-          case 18: LAUNCH_MFMA(1, 1, 18); break;
-          case 19: LAUNCH_MFMA(1, 1, 19); break;
-          case 20: LAUNCH_MFMA(1, 1, 20); break;
-          default: break;
-        }
+        switch (ns) { MF_CASES10(mh_sweep_mfma, 2, 2) default: break; }
       } else {
-        switch (ns) {
-          case 1: LAUNCH_MFMA(2, 1, 1); break;
-          case 2: LAUNCH_MFMA(2, 1, 2); break;
-          case 3: LAUNCH_MFMA(2, 1, 3); break;
-          case 4: LAUNCH_MFMA(2, 1, 4); break;
-          case 5: LAUNCH_MFMA(2, 1, 5); break;
-          case 6: LAUNCH_MFMA(2, 1, 6); break;
-          case 7: LAUNCH_MFMA(2, 1, 7); break;
-          case 8: LAUNCH_MFMA(2, 1, 8); break;
-          case 9: LAUNCH_MFMA(2, 1, 9); break;
-          case 10: LAUNCH_MFMA(2, 1, 10); break;
-          case 11: LAUNCH_MFMA(2, 1, 11); break;
-          case 12: LAUNCH_MFMA(2, 1, 12); break;
-          case 13: LAUNCH_MFMA(2, 1, 13); break;
-          case 14: LAUNCH_MFMA(2, 1, 14); break;
-          case 15: LAUNCH_MFMA(2, 1, 15); break;
-          case 16: LAUNCH_MFMA(2, 1, 16); break;
-          case 17: LAUNCH_MFMA(2, 1, 17); break;
-          case 18: LAUNCH_MFMA(2, 1, 18); break;
-          case 19: LAUNCH_MFMA(2, 1, 19); break;
-          case 20: LAUNCH_MFMA(2, 1, 20); break;
-          default: break;
-        }
+        switch (ns) { MF_CASES16(mh_sweep_mfma, 2, 1) MF_CASES17(mh_sweep_mfma, 2, 1) default: break; }
       }
-#undef LAUNCH_MFMA
+#undef MF_CASES17
+#undef MF_CASES16
+#undef MF_CASES10
+#undef MF_CASE
     } else
     if (!(nospec && nospec[0] == '1')) {
       const size_t slds = spec_lds_bytes(pipe_opt, kn->kind >= FMCMC_KERNEL_ADAPT);

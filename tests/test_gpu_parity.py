@@ -278,6 +278,30 @@ def test_mfma_equals_valu_kernels(E, O, monkeypatch):
     assert _bits_equal(a.samples.cpu().numpy(), c.samples.cpu().numpy())
 
 
+@pytest.mark.parametrize("n", [10000, 9000, 600])
+def test_mfma_replicated_equals_owner_kernel(E, O, monkeypatch, n):
+    """The two MFMA kernels (owner waves / chain state replicated in every wave, hoisted division, one barrier) give the
+    same bits as the oracle and as each other wherever both are compiled in (n > 8192), incl. thinning, continuation,
+    a fixed parameter, the uniform kernel and a chain that fails with a NaN (general path of the replicated kernel)."""
+    X, y = synth_linreg(n, 3, 31 + n)
+    init = jitter_init([0, 0, 0, 0, float(np.std(y))], 7, 24)
+    init[:, -1] = np.abs(init[:, -1])
+    bad = init.copy()
+    bad[:, -1] = 0.03                                     # sigma steps below zero within a few proposals of scale 1
+    out = {}
+    for force in ("1", "0"):
+        monkeypatch.setenv("FMCMC_AMD_MFMA_OWNERS", force)
+        a, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=150, burnin=11, thin=4, calls=2, scale=0.02)
+        b, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=90, scale=0.03, fixed=[False, False, True, False, False])
+        c, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_UNIF, 5, init, nsteps=90, min_=-0.03, max_=0.04)
+        d, ro = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, bad, nsteps=60, guard=False, scale=1.0)
+        assert (ro.status == 1).any()
+        out[force] = [r.samples.cpu().numpy() for r in (a, b, c)] + [d.status.cpu().numpy()]
+    for u, w in zip(out["1"][:3], out["0"][:3]):
+        assert _bits_equal(u, w)
+    assert np.array_equal(out["1"][3], out["0"][3])
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # SURVEY section 8(f) rank 3: uniform kernels, the remaining update schemes, kernel_ram freq / constr
 # ---------------------------------------------------------------------------------------------------------------------
