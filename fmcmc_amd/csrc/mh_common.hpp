@@ -85,6 +85,11 @@ __device__ __forceinline__ void wave_sync_lds() {
   __builtin_amdgcn_wave_barrier();
 }
 __device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ double sgpr_d(double v) {  // pin a wave-uniform double into an SGPR pair
+  unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also releases GLOBAL memory at
 // workgroup scope, i.e. s_waitcnt vmcnt(0): every wave would sit at every barrier until its sample /
@@ -130,6 +135,24 @@ __device__ __forceinline__ double wave_xor_sum(double v) {
     v = a + b;              // xor 32
   }
   return v;
+}
+
+// Split fp64 division.  The compiler expands a / b into v_div_scale x2, v_rcp_f64, two Newton steps on the reciprocal,
+// q0 = a r, e = fma(-b, q0, a), v_div_fmas (= fma(e, r, q0)), v_div_fixup.  With both operands positive, normal and
+// inside 2^-300 .. 2^300 the scale / fix-up instructions are identities, so r = div_recip(b) -- which depends on the
+// denominator only and can be computed early -- followed by div_finish(a, b, r) is bit for bit a / b: three dependent
+// instructions instead of twelve where the numerator arrives late.
+__device__ __forceinline__ bool mfr_div_safe(double x) {
+  return ((unsigned)(fmh_d2u(x) >> 32) - (723u << 20)) < (601u << 20);
+}
+__device__ __forceinline__ double div_recip(double b) {
+  const double r0 = __builtin_amdgcn_rcp(b);
+  const double r1 = fmh_fma(r0, fmh_fma(-b, r0, 1.0), r0);
+  return fmh_fma(r1, fmh_fma(-b, r1, 1.0), r1);
+}
+__device__ __forceinline__ double div_finish(double a, double b, double r) {
+  const double q0 = a * r;
+  return fmh_fma(fmh_fma(-b, q0, a), r, q0);
 }
 
 // canonical reflect (twin of oracle reflect1, MATH_CANON branch; R/kernel.R:450-493)
@@ -200,31 +223,164 @@ __device__ __forceinline__ ChainLds chain_lds(double* base, int k, int kf, int k
   return c;
 }
 
+// ---- chain-vectorised twin of fmh_log1p_exp_nonpos (include/fmh_detmath.h): the same operations in the same order for
+// every element, so the same bits -- but each constant is materialised ONCE per observation instead of once per chain
+// (FMH_K costs two scalar moves per use), the CW dependent chains interleave, and the out-of-range test is one branch
+// per observation.  Called once per observation, the scalar routine made the logistic loop ~1100 instructions per
+// observation and four chains, at the ~6 cycles per instruction one wave issues.
+template <int CW>
+__device__ __forceinline__ void softplus_nonpos_vec(const double (&a)[CW], double (&out)[CW]) {
+  const double* tab = fmh_sp_tab_();
+  bool slow = false;
+  double r[CW], sc[CW], q[CW];
+#pragma unroll
+  for (int c = 0; c < CW; c++) slow = slow || !(a[c] <= FMH_SP_AMAX) || a[c] < FMH_SP_AMIN;
+  {
+    const double inv_ln2 = FMH_K(FMH_INV_LN2), ln2_hi = FMH_K(FMH_LN2_HI), ln2_lo = FMH_K(FMH_LN2_LO);
+#pragma unroll
+    for (int c = 0; c < CW; c++) {
+      const double t0 = fmh_fma(a[c], inv_ln2, -0.5);
+      const int k = (int)t0;
+      const double dk = (double)k;
+      r[c] = fmh_fma(-dk, ln2_hi, a[c]) - dk * ln2_lo;
+      sc[c] = fmh_u2d((uint64_t)(1023 + k) << 52);
+    }
+  }
+  {
+    const double e13 = FMH_K(FMH_SP_E13), e12 = FMH_K(FMH_SP_E12);
+#pragma unroll
+    for (int c = 0; c < CW; c++) q[c] = fmh_fma(r[c], e13, e12);
+  }
+#define SP_STEP(arr, x, K) { const double kk = FMH_K(K); _Pragma("unroll") for (int c = 0; c < CW; c++) arr[c] = fmh_fma(x[c], arr[c], kk); }
+  SP_STEP(q, r, FMH_SP_E11) SP_STEP(q, r, FMH_SP_E10) SP_STEP(q, r, FMH_SP_E9) SP_STEP(q, r, FMH_SP_E8) SP_STEP(q, r, FMH_SP_E7)
+  SP_STEP(q, r, FMH_SP_E6) SP_STEP(q, r, FMH_SP_E5) SP_STEP(q, r, FMH_SP_E4) SP_STEP(q, r, FMH_SP_E3) SP_STEP(q, r, FMH_SP_E2)
+  double u[CW], cc[CW], invc[CW], rr[CW], p[CW];
+  unsigned int T[CW];   // index of the table row
+#pragma unroll
+  for (int c = 0; c < CW; c++) {
+    const double w = fmh_fma(r[c] * r[c], q[c], r[c]);
+    const double er = 1.0 + w;
+    const double el = w - (er - 1.0);
+    const double e = er * sc[c];
+    u[c] = 1.0 + e;
+    cc[c] = fmh_fma(el, sc[c], e - (u[c] - 1.0));
+    T[c] = 3u * ((uint32_t)(fmh_d2u(u[c]) >> 45) & 127u);
+    invc[c] = tab[T[c]];
+    rr[c] = fmh_fma(u[c], invc[c], -1.0);
+  }
+  {
+    const double l8 = FMH_K(FMH_SP_L8), l7 = FMH_K(FMH_SP_L7);
+#pragma unroll
+    for (int c = 0; c < CW; c++) p[c] = fmh_fma(rr[c], l8, l7);
+  }
+  SP_STEP(p, rr, FMH_SP_L6) SP_STEP(p, rr, FMH_SP_L5) SP_STEP(p, rr, FMH_SP_L4) SP_STEP(p, rr, FMH_SP_L3) SP_STEP(p, rr, FMH_SP_L2)
+#undef SP_STEP
+#pragma unroll
+  for (int c = 0; c < CW; c++) {
+    const double s = fmh_fma(rr[c] * rr[c], p[c], fmh_fma(cc[c], invc[c], tab[T[c] + 2]));
+    out[c] = tab[T[c] + 1] + (rr[c] + s);
+  }
+  if (__builtin_expect(slow, 0)) {   // |eta| < 2^-28, eta beyond +-700, NaN: the general functions, as in the scalar routine
+#pragma unroll
+    for (int c = 0; c < CW; c++) out[c] = fmh_log1p_exp_nonpos(a[c]);
+  }
+}
+
 // ---- workgroup-collective log-posterior partial sums (streamed variant) ------------------
 // Every thread accumulates its canonical lane for all CW chains, then the wavefront butterfly
 // (levels 1..32) runs and lane 0 of each wavefront publishes its partial to s_part[w][c].
-template <int CW>
+// FAM > 0 compiles one family in (leaner kernels for the logistic model), FAM == 0 keeps all behind A.family.
+template <int CW, int FAM = 0>
 __device__ __forceinline__ void eval_partials(const SweepArgs& A, double* const* th /*[CW] -> theta in LDS*/,
                                               double* s_part) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long long n = A.n;
-  const int p = (A.family == FMCMC_FAM_IID_NORMAL) ? 0 : A.p;
-  const int ic = (A.family == FMCMC_FAM_IID_NORMAL) ? 1 : A.intercept;
+  const int family = FAM ? FAM : A.family;
+  const int p = (family == FMCMC_FAM_IID_NORMAL) ? 0 : A.p;
+  const int ic = (family == FMCMC_FAM_IID_NORMAL) ? 1 : A.intercept;
   double acc[CW];
 #pragma unroll
   for (int c = 0; c < CW; c++) acc[c] = 0.0;
-  if (A.family == FMCMC_FAM_LOGISTIC) {
+  if (family == FMCMC_FAM_LOGISTIC) {
     // The data comes from L2 (~1 us under load) and only two waves share a SIMD: a load-use chain per column made this
     // loop latency-bound (6 dependent round trips per observation).  All columns of an observation are fetched as one
     // batch, and the batch of the NEXT observation is in flight while exp / log1p of the current one run.
     constexpr int JB = 8;
-    auto term_of = [&](double e, bool y1) -> double {
-      double s = y1 ? e : -e;
-      double a = (s < 0.0) ? s : -s;
-      double l1 = fmh_log1p_exp_nonpos(a);   // == fmh_log1p(fmh_exp(a)) bit for bit, straight-line on the common range
-      return (s < 0.0) ? (s - l1) : (-l1);
+    // log-likelihood terms of one observation for all CW chains: logq(eta) == logp(-eta), softplus tail on -|eta|
+    auto add_terms = [&](const double (&eta)[CW], bool y1) {
+      double sg[CW], ab[CW], l1[CW];
+#pragma unroll
+      for (int c = 0; c < CW; c++) {
+        sg[c] = y1 ? eta[c] : -eta[c];
+        ab[c] = (sg[c] < 0.0) ? sg[c] : -sg[c];
+      }
+#ifndef FMCMC_SP_GROUP
+#define FMCMC_SP_GROUP 4
+#endif
+      constexpr int G = (CW < FMCMC_SP_GROUP) ? CW : FMCMC_SP_GROUP;   // chains per softplus batch (register pressure vs constant re-use)
+#pragma unroll
+      for (int g0 = 0; g0 < CW; g0 += G) {
+        double ag[G], lg[G];
+#pragma unroll
+        for (int c = 0; c < G; c++) ag[c] = ab[g0 + c];
+        softplus_nonpos_vec<G>(ag, lg);
+#pragma unroll
+        for (int c = 0; c < G; c++) l1[g0 + c] = lg[c];
+      }
+#pragma unroll
+      for (int c = 0; c < CW; c++) acc[c] = acc[c] + ((sg[c] < 0.0) ? (sg[c] - l1[c]) : (-l1[c]));
     };
-    if (p <= JB) {
+    // P known at compile time (P <= 8): straight-line loop body -- with a run-time p every `if (u < p)` was a basic
+    // block of its own (6 scalar branches per observation, each with its LDS / memory wait in front) -- and the CW x
+    // (P + 1) coefficients sit in SGPRs for the whole evaluation instead of being re-read from LDS per observation.
+    auto fixed_p = [&](auto PC) {
+      constexpr int PL = decltype(PC)::value;
+      double b0[CW], bs[CW][PL > 0 ? PL : 1];
+#pragma unroll
+      for (int c = 0; c < CW; c++) {
+        b0[c] = ic ? sgpr_d(th[c][0]) : 0.0;
+#pragma unroll
+        for (int u = 0; u < PL; u++) bs[c][u] = sgpr_d(th[c][ic + u]);
+      }
+      double xb[PL > 0 ? PL : 1], yv = 0.0;
+      long long i = tid;
+      if (i < n) {
+#pragma unroll
+        for (int u = 0; u < PL; u++) xb[u] = A.X[(long long)u * n + i];
+        yv = A.y[i];
+      }
+      for (; i < n; i += NT) {
+        double eta[CW];
+#pragma unroll
+        for (int c = 0; c < CW; c++) eta[c] = b0[c];
+#pragma unroll
+        for (int u = 0; u < PL; u++) {
+#pragma unroll
+          for (int c = 0; c < CW; c++) eta[c] = fmh_fma(xb[u], bs[c][u], eta[c]);
+        }
+        const bool y1 = (yv != 0.0);
+        const long long inx = (i + NT < n) ? i + NT : i;   // clamped: the last prefetch re-reads this observation
+#pragma unroll
+        for (int u = 0; u < PL; u++) xb[u] = A.X[(long long)u * n + inx];
+        yv = A.y[inx];
+        add_terms(eta, y1);
+      }
+    };
+    // (the logistic-only instantiations of the kernel carry these loop bodies; CW (P + 1) <= 28 coefficients fit the SGPRs)
+    constexpr int PMAX = (FAM == FMCMC_FAM_LOGISTIC) ? (28 / CW - 1 > 8 ? 8 : 28 / CW - 1) : -1;
+    if (p <= PMAX) {
+      switch (p) {
+        case 0: fixed_p(std::integral_constant<int, 0>()); break;
+        case 1: fixed_p(std::integral_constant<int, (PMAX >= 1 ? 1 : 0)>()); break;
+        case 2: fixed_p(std::integral_constant<int, (PMAX >= 2 ? 2 : 0)>()); break;
+        case 3: fixed_p(std::integral_constant<int, (PMAX >= 3 ? 3 : 0)>()); break;
+        case 4: fixed_p(std::integral_constant<int, (PMAX >= 4 ? 4 : 0)>()); break;
+        case 5: fixed_p(std::integral_constant<int, (PMAX >= 5 ? 5 : 0)>()); break;
+        case 6: fixed_p(std::integral_constant<int, (PMAX >= 6 ? 6 : 0)>()); break;
+        case 7: fixed_p(std::integral_constant<int, (PMAX >= 7 ? 7 : 0)>()); break;
+        default: fixed_p(std::integral_constant<int, (PMAX >= 8 ? 8 : 0)>()); break;
+      }
+    } else if (p <= JB) {
       double xb[JB], yv = 0.0;
       long long i = tid;
       if (i < n) {
@@ -247,8 +403,7 @@ __device__ __forceinline__ void eval_partials(const SweepArgs& A, double* const*
 #pragma unroll
         for (int u = 0; u < JB; u++) xb[u] = (u < p) ? A.X[(long long)u * n + inx] : 0.0;
         yv = A.y[inx];
-#pragma unroll
-        for (int c = 0; c < CW; c++) acc[c] = acc[c] + term_of(eta[c], y1);
+        add_terms(eta, y1);
       }
     } else {
       for (long long i = tid; i < n; i += NT) {
@@ -272,8 +427,7 @@ __device__ __forceinline__ void eval_partials(const SweepArgs& A, double* const*
 #pragma unroll
           for (int c = 0; c < CW; c++) eta[c] = fmh_fma(x, th[c][ic + j], eta[c]);
         }
-#pragma unroll
-        for (int c = 0; c < CW; c++) acc[c] = acc[c] + term_of(eta[c], y1);
+        add_terms(eta, y1);
       }
     }
   } else {
@@ -321,9 +475,11 @@ __device__ __forceinline__ void eval_partials(const SweepArgs& A, double* const*
 }
 
 // closed form of the family given the canonical total `tot`. Uniform over the wave.
+template <int FAM = 0>
 __device__ __forceinline__ double finish_logpost(const SweepArgs& A, const double* th, double tot) {
   double f;
-  if (A.family == FMCMC_FAM_LOGISTIC) {
+  const int family = FAM ? FAM : A.family;
+  if (family == FMCMC_FAM_LOGISTIC) {
     f = tot;
     if (A.prior_div != 0.0) {
       double ss = 0.0;
@@ -332,8 +488,8 @@ __device__ __forceinline__ double finish_logpost(const SweepArgs& A, const doubl
       f = f - ss / A.prior_div;
     }
   } else {
-    const int pp = (A.family == FMCMC_FAM_IID_NORMAL) ? 0 : A.p;
-    const int ic = (A.family == FMCMC_FAM_IID_NORMAL) ? 1 : A.intercept;
+    const int pp = (family == FMCMC_FAM_IID_NORMAL) ? 0 : A.p;
+    const int ic = (family == FMCMC_FAM_IID_NORMAL) ? 1 : A.intercept;
     const double sigma = th[ic + pp];
     if (sigma < 0.0 || fmh_isnan(sigma)) {
       f = fmh_nan();

@@ -30,6 +30,7 @@
 #include <math.h>
 #include <float.h>
 #include <vector>
+#include <type_traits>
 
 #include "../../include/fmcmc_amd.h"
 #include "../../include/fmh_detmath.h"
@@ -418,6 +419,26 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
   } else
   if (resident && res_p == 1) { LAUNCH_KIND(4, 1, 4); }
   else if (resident && res_p == 3) { LAUNCH_KIND(4, 3, 20); }
+  else if (m->family == FMCMC_FAM_LOGISTIC && cw <= 4 && m->p <= 28 / cw - 1 &&
+           (kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE)) {
+    // logistic-only instantiations: the number of covariates is a compile-time constant of the evaluation loop and the
+    // coefficients of the CW chains live in SGPRs (mh_common.hpp); with the division-free softplus 2x the general kernel
+#define LAUNCH_LOGIT(CWV, KV)                                                                                          \
+    do {                                                                                                               \
+      if (lds > 48 * 1024)                                                                                             \
+        e = hipFuncSetAttribute((const void*)mh_sweep_kernel<CWV, -1, 0, KV, FMCMC_FAM_LOGISTIC>,                      \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
+      if (e == hipSuccess)                                                                                             \
+        hipLaunchKernelGGL((mh_sweep_kernel<CWV, -1, 0, KV, FMCMC_FAM_LOGISTIC>), dim3((unsigned)nblk), dim3(NT), lds, stream, A); \
+    } while (0)
+    const bool refl = kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE;
+    switch (cw) {
+      case 1: if (refl) LAUNCH_LOGIT(1, 2); else LAUNCH_LOGIT(1, 1); break;
+      case 2: if (refl) LAUNCH_LOGIT(2, 2); else LAUNCH_LOGIT(2, 1); break;
+      default: if (refl) LAUNCH_LOGIT(4, 2); else LAUNCH_LOGIT(4, 1); break;
+    }
+#undef LAUNCH_LOGIT
+  }
   else switch (cw) {
     case 1: LAUNCH(1, -1, 0, 0); break;
     case 2: LAUNCH(2, -1, 0, 0); break;

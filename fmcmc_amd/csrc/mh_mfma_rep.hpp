@@ -71,11 +71,6 @@ __device__ __forceinline__ double mfma_wave_fold(double a0, double a1, double a2
   return u;
 }
 
-// both operands of a division inside 2^-300 .. 2^300 (positive, normal): no scaling or fix-up in the hardware sequence
-__device__ __forceinline__ bool mfr_div_safe(double x) {
-  return ((unsigned)(fmh_d2u(x) >> 32) - (723u << 20)) < (601u << 20);
-}
-
 // Timing ablations for tools/exp_mfmar.hip (never set in the product build; they change the results):
 //   1 no row stores   2 no sigma-only publisher   4 no in-wave fold   8 no cross-wave butterfly   16 no general path
 //   32 no MFMAs       64 no decision (always reject)
@@ -300,9 +295,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfmar(const SweepArgs A) {
       const double t1_fast = fmh_log_pn(sg) + FMH_K(FMH_LN_SQRT_2PI);   // same bits as fmh_log(sigma) on this range
       const double ss = sg * sg;
       const bool okf = sg_fast && mfr_div_safe(ss) && v > 1 && status == FMCMC_CHAIN_OK;
-      const double r0 = __builtin_amdgcn_rcp(ss);
-      const double r1 = fmh_fma(r0, fmh_fma(-ss, r0, 1.0), r0);
-      const double r2 = fmh_fma(r1, fmh_fma(-ss, r1, 1.0), r1);
+      const double r2 = div_recip(ss);
       if (lane == wave) {
         double* cf = s_cf + (par * 4 + lane) * 6;
         cf[0] = okf ? dn * t1_fast : fmh_nan();

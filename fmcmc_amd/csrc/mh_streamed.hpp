@@ -12,8 +12,10 @@ constexpr int RES_MASKED = 4;  // trailing observation slots that carry a validi
 
 // KIND > 0 compiles exactly one proposal kernel in (resident variants); KIND == 0 keeps all four
 // behind the runtime A.kind (streamed variants).
-template <int CW, int P, int OPT, int KIND>
-__global__ __launch_bounds__(NT) void mh_sweep_kernel(const SweepArgs A0) {
+// FAM > 0 compiles one model family in, MINB is the number of workgroups per CU the register allocation must allow
+// (the logistic model is bound by fp64 instruction issue: with 128 VGPRs two workgroups share a CU, 4 waves per SIMD).
+template <int CW, int P, int OPT, int KIND, int FAM = 0, int MINB = 1>
+__global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) {
   constexpr bool RESIDENT = (P >= 0);
   SweepArgs A = A0;
   if constexpr (KIND > 0) A.kind = KIND;
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_kernel(const SweepArgs A0) {
         if (lane == 0) s_part[h * CW + c] = v;
       }
     } else {
-      eval_partials<CW>(A, thp, s_part);
+      eval_partials<CW, FAM>(A, thp, s_part);
     }
   };
   auto total_of = [&](int c) -> double {
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_kernel(const SweepArgs A0) {
     }
   };
   if (owner) {
-    f0 = finish_logpost(A, L.th1, total_of(myc));
+    f0 = finish_logpost<FAM>(A, L.th1, total_of(myc));
     f1 = f0;
     if (lane < kf) L.vrs[lane] = L.th0[s_which[lane]];
     if (A.hist_rows > 0 && lane < kf) A.hist[((long long)cl * A.hist_rows + (1 % A.hist_rows)) * kf + lane] = L.th0[s_which[lane]];
@@ -446,7 +448,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_kernel(const SweepArgs A0) {
       bool changed = false;
       if (owner && status == FMCMC_CHAIN_OK) {
         if (ram_gate) {
-          double f1u = finish_logpost(A, L.th1, total_of(myc));
+          double f1u = finish_logpost<FAM>(A, L.th1, total_of(myc));
           double a_n = fmh_exp(f1u - f0);
           if (fmh_isnan(a_n)) a_n = 0.0;
           else if (a_n > 1.0) a_n = 1.0;
@@ -513,7 +515,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_kernel(const SweepArgs A0) {
     }
     // ================= scalar phase C: accept / store (R/mcmc.R:754-778) =================
     if (owner && status == FMCMC_CHAIN_OK) {
-      f1 = finish_logpost(A, L.th1, total_of(myc));
+      f1 = finish_logpost<FAM>(A, L.th1, total_of(myc));
       if (fmh_isnan(f1)) status = FMCMC_CHAIN_NAN_LOGPOST;
       const double ratio = f1 - f0;
       if (status == FMCMC_CHAIN_OK && fmh_isnan(ratio)) status = FMCMC_CHAIN_NAN_RATIO;

