@@ -188,7 +188,7 @@ def main():
             "roofline": {"bound": "mfma", "pipe": "fp64 MFMA (v_mfma_f64_4x4x4: x.beta - y) + fp64 VALU (r^2 accumulate); MI355X fp64 matrix peak == fp64 vector peak",
                          "achieved": ach_tflops, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tflops / PEAK_FP64_TFLOPS, "traffic": traffic,
-                         "kernel": "mh_sweep_mfma<1>", "kernel_ms": kern_ms, "rng_fill_kernel_ms": rng_ms,
+                         "kernel": "mh_sweep_mfma<1,1,20,false>", "kernel_ms": kern_ms, "rng_fill_kernel_ms": rng_ms,
                          "flops_per_sample": flops_per_sample(),
                          "hbm": {"achieved_GBps": out_bytes / (kern_ms * 1e-3) / 1e9, "peak_GBps": PEAK_HBM_GBS,
                                  "algorithmic_bytes_per_launch": out_bytes}},

@@ -438,7 +438,67 @@ __device__ __forceinline__ void eval_partials(const SweepArgs& A, double* const*
     // 4: 70, 8: 120), i.e. the loop is bound by load latency + FMA issue per CU (~65 GB/s per CU of the 154 GB/s L1 fill
     // rate), not by aggregate L2 bandwidth; a second batch in flight (double-buffered xb) spills in this all-kinds kernel
     // and is 12 % slower.
+    // Wide models (p >= 16, e.g. config C4: k = 50): every thread works on OB of its observations at once, so that every
+    // coefficient read from LDS feeds OB observations and OB x 8 column loads are in flight per thread.  Same arithmetic
+    // per observation, and the lane still accumulates its observations in index order.  Measured (tools/bench_c4.py):
+    // OB = 2 is worth 2 %, OB = 4 spills and is slower; the time per step does not depend on the number of active CUs
+    // (59 us from 8 to 256 workgroups), i.e. the evaluation is NOT bound by aggregate L2 bandwidth but by what one
+    // workgroup of 8 waves keeps in flight -- a leaner kernel with a software-pipelined column loop is the next step.
     constexpr int JB = 8;
+#ifndef FMCMC_OBS_BLOCK
+#define FMCMC_OBS_BLOCK 2
+#endif
+    // (only the one-family, one-kernel instantiations have the registers for it; 4 chains x 4 observations never fit)
+    constexpr int OB = (CW <= 2 && FAM == FMCMC_FAM_GAUSSIAN_LINREG) ? FMCMC_OBS_BLOCK : 1;
+    if (OB > 1 && p >= 2 * JB) {
+      for (long long i0 = tid; i0 < n; i0 += (long long)NT * OB) {
+        long long ii[OB];
+        double mu[OB][CW];
+#pragma unroll
+        for (int o = 0; o < OB; o++) {
+          const long long i = i0 + (long long)NT * o;
+          ii[o] = (i < n) ? i : i0;            // clamped: a padded slot re-reads observation i0 and is discarded below
+#pragma unroll
+          for (int c = 0; c < CW; c++) mu[o][c] = ic ? th[c][0] : 0.0;
+        }
+        int j = 0;
+        for (; j + JB <= p; j += JB) {
+          double xb[OB][JB];
+#pragma unroll
+          for (int u = 0; u < JB; u++) {
+#pragma unroll
+            for (int o = 0; o < OB; o++) xb[o][u] = A.X[(long long)(j + u) * n + ii[o]];
+          }
+#pragma unroll
+          for (int u = 0; u < JB; u++) {
+#pragma unroll
+            for (int c = 0; c < CW; c++) {
+              const double b = th[c][ic + j + u];
+#pragma unroll
+              for (int o = 0; o < OB; o++) mu[o][c] = fmh_fma(xb[o][u], b, mu[o][c]);
+            }
+          }
+        }
+        for (; j < p; j++) {
+#pragma unroll
+          for (int c = 0; c < CW; c++) {
+            const double b = th[c][ic + j];
+#pragma unroll
+            for (int o = 0; o < OB; o++) mu[o][c] = fmh_fma(A.X[(long long)j * n + ii[o]], b, mu[o][c]);
+          }
+        }
+#pragma unroll
+        for (int o = 0; o < OB; o++) {
+          const double yv = A.y[ii[o]];
+          const bool valid = (i0 + (long long)NT * o) < n;
+#pragma unroll
+          for (int c = 0; c < CW; c++) {
+            const double r = valid ? yv - mu[o][c] : 0.0;       // fma(0, 0, acc) == acc exactly
+            acc[c] = fmh_fma(r, r, acc[c]);
+          }
+        }
+      }
+    } else
     for (long long i = tid; i < n; i += NT) {
       double mu[CW];
 #pragma unroll

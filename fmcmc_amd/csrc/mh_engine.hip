@@ -439,6 +439,23 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
     }
 #undef LAUNCH_LOGIT
   }
+  else if (m->family == FMCMC_FAM_GAUSSIAN_LINREG && m->p >= 16 && cw <= 2 &&
+           (kn->kind == FMCMC_KERNEL_RAM || kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE)) {
+    // wide linear models (config C4: k = 50): one family and one proposal kernel compiled in, which leaves the streamed
+    // evaluation the registers for 4 observations x 8 columns in flight per thread (mh_common.hpp)
+#define LAUNCH_WIDE(CWV, KV)                                                                                           \
+    do {                                                                                                               \
+      if (lds > 48 * 1024)                                                                                             \
+        e = hipFuncSetAttribute((const void*)mh_sweep_kernel<CWV, -1, 0, KV, FMCMC_FAM_GAUSSIAN_LINREG>,               \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
+      if (e == hipSuccess)                                                                                             \
+        hipLaunchKernelGGL((mh_sweep_kernel<CWV, -1, 0, KV, FMCMC_FAM_GAUSSIAN_LINREG>), dim3((unsigned)nblk), dim3(NT), lds, stream, A); \
+    } while (0)
+    const int kv = kn->kind;   // 1, 2 or 4
+    if (cw == 1) { if (kv == 1) LAUNCH_WIDE(1, 1); else if (kv == 2) LAUNCH_WIDE(1, 2); else LAUNCH_WIDE(1, 4); }
+    else { if (kv == 1) LAUNCH_WIDE(2, 1); else if (kv == 2) LAUNCH_WIDE(2, 2); else LAUNCH_WIDE(2, 4); }
+#undef LAUNCH_WIDE
+  }
   else switch (cw) {
     case 1: LAUNCH(1, -1, 0, 0); break;
     case 2: LAUNCH(2, -1, 0, 0); break;
