@@ -440,10 +440,10 @@ __device__ __forceinline__ void eval_partials(const SweepArgs& A, double* const*
     // and is 12 % slower.
     // Wide models (p >= 16, e.g. config C4: k = 50): every thread works on OB of its observations at once, so that every
     // coefficient read from LDS feeds OB observations and OB x 8 column loads are in flight per thread.  Same arithmetic
-    // per observation, and the lane still accumulates its observations in index order.  Measured (tools/bench_c4.py):
-    // OB = 2 is worth 2 %, OB = 4 spills and is slower; the time per step does not depend on the number of active CUs
-    // (59 us from 8 to 256 workgroups), i.e. the evaluation is NOT bound by aggregate L2 bandwidth but by what one
-    // workgroup of 8 waves keeps in flight -- a leaner kernel with a software-pipelined column loop is the next step.
+    // per observation, and the lane still accumulates its observations in index order.  Worth 2 % only, and no other
+    // form of this loop is faster (column batches outside / observations inside with the coefficients in SGPRs and 40
+    // buffer loads in flight per thread: same time): at k = 50 a CU reads X at 65-67 GB/s, the rate at which one CU
+    // gets data out of its XCD's L2 (MI355X_MICROARCH.md: 66-73 GB/s per CU) -- DESIGN.md, C4.
     constexpr int JB = 8;
 #ifndef FMCMC_OBS_BLOCK
 #define FMCMC_OBS_BLOCK 2
