@@ -311,12 +311,16 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
 // element as spec_owner_adaptive / the oracle, hence the same bits.
 constexpr int SPEC_KA = 8;
 
-template <int KIND>
+// KX > 0: the number of parameters is the compile-time constant KX (the statically unrolled loops then carry no `b < kf`
+// predicates and no dead iterations: at k = 5 the owner loop was 1800 instructions per step with KA = 8, and an owner
+// wave issues one instruction per ~6.5 cycles: the chain-step rate of C3 IS this instruction count); KX == 0: k <= 8.
+template <int KIND, int KX>
 __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int myc, int cl, double* s_th1, double* s_par,
                                                         unsigned* s_ready, unsigned* s_done, double* s_tr) {
-  constexpr int KA = SPEC_KA;
+  constexpr int KA = KX > 0 ? KX : SPEC_KA;
   const int lane = threadIdx.x & 63;
-  const int k = A.k, kf = A.k, kz = A.kz, nsteps = (int)A.nsteps, burnin = (int)A.burnin, thin = (int)A.thin;
+  const int k = KX > 0 ? KX : A.k, kf = k, kz = KX > 0 ? KX : A.kz;
+  const int nsteps = (int)A.nsteps, burnin = (int)A.burnin, thin = (int)A.thin;
   const bool rl = lane < k;                 // row lane == parameter lane (no fixed parameters)
   const int jl = rl ? lane : 0;
   const double mu_l = A.mu[jl], lb_l = A.lb[jl], ub_l = A.ub[jl];
@@ -413,13 +417,10 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
                 } else {
                   const double r = fmh_sqrt(r2);
                   const double cc = r / ljj, ss = xj / ljj;
-                  if (lane == j) {
-                    Snew[j] = r;
-                  } else if (lane > j && rl) {
-                    const double ln = (up ? fmh_fma(ss, w, Srow[j]) : fmh_fma(-ss, w, Srow[j])) / cc;
-                    w = fmh_fma(-ss, ln, cc * w);
-                    Snew[j] = ln;
-                  }
+                  const double ln = (up ? fmh_fma(ss, w, Srow[j]) : fmh_fma(-ss, w, Srow[j])) / cc;
+                  const bool below = lane > j && rl;
+                  w = below ? fmh_fma(-ss, ln, cc * w) : w;
+                  Snew[j] = (lane == j) ? r : (below ? ln : Snew[j]);
                 }
               }
             }
@@ -491,9 +492,11 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
               if (!(d > 0.0) || !fmh_isfinite(d)) {
                 notpd = true;
               } else {
+                // selects, not exec-mask regions: every `if (lane ...)` costs three scalar instructions and a branch, and
+                // the owner's rate is its instruction count (rows above j keep their 0)
                 const double ljj = fmh_sqrt(d);
-                if (lane == j) Lrow[j] = ljj;
-                else if (lane > j) Lrow[j] = sacc / ljj;
+                const double qj = sacc / ljj;
+                Lrow[j] = (lane == j) ? ljj : ((lane > j) ? qj : Lrow[j]);
               }
             }
           }
@@ -504,15 +507,15 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
           } else {
             double sacc = 0.0;
 #pragma unroll
-            for (int b = 0; b < KA; b++)
-              if (b < kf) { const double zb = readlane_d(zcur, b); if (b <= lane) sacc = fmh_fma(Lrow[b], zb, sacc); }
+            for (int b = 0; b < KA; b++)   // (row `lane` of the factor is 0 beyond its diagonal and sacc starts at +0: the terms
+              if (b < kf) { const double zb = readlane_d(zcur, b); sacc = fmh_fma(Lrow[b], zb, sacc); }   // b > lane add +-0 exactly)
             th1 = reflect1(th0 + (mu_l + sacc), lb_l, ub_l);
           }
         } else {  // RAM P1 (R/kernel_ram.R:123-126)
           double sacc = 0.0;
 #pragma unroll
           for (int b = 0; b < KA; b++)
-            if (b < kf) { const double ub_ = readlane_d(zcur, b); if (b <= lane) sacc = fmh_fma(Srow[b], ub_, sacc); }
+            if (b < kf) { const double ub_ = readlane_d(zcur, b); sacc = fmh_fma(Srow[b], ub_, sacc); }   // (S is lower triangular: +-0 beyond the diagonal)
           vv = sacc;
           th1 = th0 + sacc;
           ram_gate = (A.until > (double)abs_iter && abs_iter > A.warmup && ((v + 1) % A.freq) == 0);
@@ -655,8 +658,12 @@ __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
   if constexpr (KIND == FMCMC_KERNEL_ADAPT || KIND == FMCMC_KERNEL_RAM) {
     bool nofixed = true;
     for (int j = 0; j < k; j++) nofixed = nofixed && (A.fixed[j] == 0);
-    if (k <= SPEC_KA && nofixed && !(A.debug & 16))
-      spec_owner_adaptive_reg<KIND>(A, myc, cl, s_th1, s_par, s_ready, s_done, s_tr);
+    if (k == P + 2 && nofixed && A.kz == k && !(A.debug & 16))        // intercept + P covariates + sigma (C3: k = 5)
+      spec_owner_adaptive_reg<KIND, P + 2>(A, myc, cl, s_th1, s_par, s_ready, s_done, s_tr);
+    else if (k == P + 1 && nofixed && A.kz == k && !(A.debug & 16))   // no intercept
+      spec_owner_adaptive_reg<KIND, P + 1>(A, myc, cl, s_th1, s_par, s_ready, s_done, s_tr);
+    else if (k <= SPEC_KA && nofixed && !(A.debug & 16))
+      spec_owner_adaptive_reg<KIND, 0>(A, myc, cl, s_th1, s_par, s_ready, s_done, s_tr);
     else
       spec_owner_adaptive<KIND>(A, myc, cl, s_th1, s_par, s_ready, s_done, s_tr, s_ad + myc * SPEC_ADS);
     return;
