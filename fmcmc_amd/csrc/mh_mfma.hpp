@@ -120,6 +120,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
   };
   // every lane of an owner wavefront keeps one variate and the log-uniform of the next step in flight (unconditional,
   // clamped addresses: a conditional load costs a register copy behind the load, i.e. an exposed wait)
+  const double mu_l = A.mu[jl], sc_l = A.scale[jl];
   double z_nx = (owner && kz > 0) ? ld_z(nsteps >= 2 ? 1 : 0) : 0.0;
   double lu_nx = owner ? lu_row[nsteps >= 2 ? 1 : 0] : 0.0;
   auto logpost_of = [&](double tot, double sigma) -> double {
@@ -198,8 +199,8 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
     // sigma-only part of the closed form: the owner waves are the first of their SIMD to finish their MFMAs (the older
     // wave wins the arbitration) and would wait ~1200 ticks at the barrier; its ~65 fp64 instructions run there, in the
     // shadow of the partner wave's MFMAs, instead of in the exposed owner phase.  The results are wave-uniform (SGPRs).
-    double sigma = 0.0, nt1_fast = 0.0, ss_fast = 1.0;
-    bool sg_fast = false;
+    double sigma = 0.0, nt1_fast = 0.0, ss_fast = 1.0, rs_fast = 1.0;
+    bool sg_fast = false, ok_fast = false;
     if (owner) {
       sigma = readlane_d(th1, k - 1);
       const unsigned sg_hi = (unsigned)(fmh_d2u(sigma) >> 32);
@@ -208,6 +209,9 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
       const double t1_fast = fmh_log_pn(sg) + FMH_K(FMH_LN_SQRT_2PI);   // same bits as fmh_log(sigma) on this range
       nt1_fast = uniform_d(dn * t1_fast);
       ss_fast = uniform_d(sg * sg);
+      // denominator half of (0.5 tot) / sigma^2 (mh_common.hpp: div_recip / div_finish), in the same slack
+      ok_fast = sg_fast && mfr_div_safe(ss_fast);
+      rs_fast = uniform_d(div_recip(ok_fast ? ss_fast : 1.0));
     }
     unsigned long long t_1 = dbg ? clk() : 0;
     lds_barrier();
@@ -227,51 +231,68 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
       asm volatile("" : "+v"(lu), "+v"(zc));
       lu_nx = lu_row[v < nsteps ? v : nsteps - 1];
       if (kz > 0) z_nx = ld_z(v + 1 < nsteps ? v + 1 : nsteps - 1);
-      const double dz = (plane && !fixed_l) ? s_par[0 * PIPE_KMAX + lane] + s_par[1 * PIPE_KMAX + lane] * zc : 0.0;
+      const double dz = mu_l + sc_l * zc;   // (unused by fixed / idle lanes; mu and scale live in registers: no LDS read, no exec region)
       const double tot = wave_xor_sum(((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7)));
       unsigned long long t_a = dbg ? clk() : 0;
-      double f1;
-      if (sg_fast) {
-        f1 = -nt1_fast - (0.5 * tot) / ss_fast;
-        if (A.guard && !fmh_isfinite(f1)) f1 = -fmh_inf();
-      } else {
-        f1 = logpost_of(tot, sigma);
-      }
+      // The owner phase is exposed, and a wave issues one instruction per ~6.5 cycles whatever their dependences: the
+      // common case is straight-line (three instructions finish the division, one compare, selects, no guard: -inf needs
+      // none and a NaN ends in the ratio), everything else sits behind ONE wave-level branch and redoes the closed form
+      // with the general code.
+      const double h = 0.5 * tot;
+      double f1 = -nt1_fast - div_finish(h, ss_fast, rs_fast);
       unsigned long long t_b = dbg ? clk() : 0;
       const double th1_eval = th1;
-      bool keep_row = false;
-      if (v == 1) {
-        f0 = uniform_d(f1);
-        keep_row = true;
-      } else if (status == FMCMC_CHAIN_OK) {
-        const double ratio = f1 - f0;
-        if (fmh_isnan(f1) || fmh_isnan(ratio)) {
-          status = fmh_isnan(f1) ? FMCMC_CHAIN_NAN_LOGPOST : FMCMC_CHAIN_NAN_RATIO;
-          if (lane == 0) { A.status[cl] = status; A.status_step[cl] = v; }
-          if (plane) A.status_theta[(long long)cl * k + lane] = th1;
-          flush_bits(v);
-        } else {
-          if (lu < ratio) {
-            th0 = th1;
-            f0 = uniform_d(f1);
-            nacc += 1;
-            bitword |= (1u << ((v - 1) & 31));
-          }
-          keep_row = true;
+      bool keep_row = true, acc = false;
+      const double ratio_f = f1 - f0;
+      const bool rare = (v == 1) || (status != FMCMC_CHAIN_OK) || !ok_fast || !mfr_div_safe(h) || fmh_isnan(ratio_f);
+      auto propose = [&](bool frozen) {   // next proposal (a failed chain keeps its theta1; behind the last step it goes nowhere)
+        double t = th0 + dz;
+        if (KIND == FMCMC_KERNEL_NORMAL_REFLECTIVE) {
+          if (plane && !fixed_l) t = reflect1(t, s_par[2 * PIPE_KMAX + lane], s_par[3 * PIPE_KMAX + lane]);
         }
+        t = fixed_l ? th0 : t;
+        th1 = frozen ? th1 : t;
+        if (plane) s_th1[myc * PIPE_KMAX + lane] = th1;
+      };
+      double th0_row;
+      if (__builtin_expect(!__any(rare), 1)) {
+        acc = lu < ratio_f;
+        th0 = acc ? th1 : th0;
+        f0 = acc ? f1 : f0;
+        th0_row = th0;
+        propose(false);
+      } else {
+        keep_row = false;
+        if (sg_fast) {
+          f1 = -nt1_fast - h / ss_fast;
+          if (A.guard && !fmh_isfinite(f1)) f1 = -fmh_inf();
+        } else {
+          f1 = logpost_of(tot, sigma);
+        }
+        if (v == 1) {
+          f0 = f1;
+          keep_row = true;
+        } else if (status == FMCMC_CHAIN_OK) {
+          const double ratio = f1 - f0;
+          if (fmh_isnan(f1) || fmh_isnan(ratio)) {
+            status = fmh_isnan(f1) ? FMCMC_CHAIN_NAN_LOGPOST : FMCMC_CHAIN_NAN_RATIO;
+            if (lane == 0) { A.status[cl] = status; A.status_step[cl] = v; }
+            if (plane) A.status_theta[(long long)cl * k + lane] = th1;
+            flush_bits(v);
+          } else {
+            acc = lu < ratio;
+            keep_row = true;
+          }
+        }
+        th0 = acc ? th1 : th0;
+        f0 = acc ? f1 : f0;
+        th0_row = th0;
+        propose(status != FMCMC_CHAIN_OK);
       }
+      nacc += acc ? 1 : 0;
+      bitword |= (acc ? 1u : 0u) << ((v - 1) & 31);
       unsigned long long t_c = dbg ? clk() : 0;
       if (dbg) { tf += t_a - t_2; tc += t_b - t_a; td += t_c - t_b; }
-      const double th0_row = th0;
-      if (v < nsteps && status == FMCMC_CHAIN_OK && plane) {
-        double t = th0;
-        if (!fixed_l) {
-          t = th0 + dz;
-          if (KIND == FMCMC_KERNEL_NORMAL_REFLECTIVE) t = reflect1(t, s_par[2 * PIPE_KMAX + lane], s_par[3 * PIPE_KMAX + lane]);
-        }
-        th1 = t;
-        s_th1[myc * PIPE_KMAX + lane] = t;
-      }
       __builtin_amdgcn_s_setprio(0);
       st_keep = keep_row; st_th0 = th0_row; st_th1 = th1_eval; st_f1 = f1;
     }
