@@ -344,16 +344,15 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
     } while (0)
     const char* nospec = getenv("FMCMC_AMD_NO_SPEC");
     if (mfma_ng) {
-      // Two MFMA kernels with identical results.  mh_sweep_mfmar (chain state replicated in every wave, one barrier per
-      // step) is 2-10 % faster for the non-reflective kernels up to n = 8192 (same-box A/B, tools/bench_shapes_ab.py);
-      // mh_sweep_mfma (owner waves) is as fast or faster for n > 8192 and for the reflective kernels, whose reflection
-      // would run in all eight waves.  FMCMC_AMD_MFMA_OWNERS=1 / =0 forces one of them wherever it is compiled in.
+      // Two MFMA kernels with identical results.  mh_sweep_mfma (owner waves) is the product path for every shape;
+      // mh_sweep_mfmar (chain state replicated in every wave, one barrier per step) was 2-10 % ahead below n = 8192
+      // until the owner phase of mh_sweep_mfma went through the same instruction diet, and is 1-7 % behind since
+      // (tools/bench_shapes_ab.py).  It stays compiled in for n > 8192, p <= 3, non-reflective kernels as the A/B
+      // partner (FMCMC_AMD_MFMA_OWNERS=0, tools/exp_mfmar.hip) and as a second implementation the parity tests compare.
       const int ns = (int)((m->n + NT - 1) / NT);   // observation slots of 512
       const int kv = (kn->kind == FMCMC_KERNEL_NORMAL) ? 1 : 2;
       const char* own0 = getenv("FMCMC_AMD_MFMA_OWNERS");
-      bool owners = !(kv == 1 && ns <= 16);
-      if (own0 && own0[0] == '0' && kv == 1) owners = false;
-      if (own0 && own0[0] == '1' && (kv == 2 || ns > 16)) owners = true;
+      const bool owners = !(own0 && own0[0] == '0' && kv == 1 && mfma_ng == 1 && ns > 16);
       const size_t mlds = owners ? mfma_lds_bytes() : mfmar_lds_bytes();
       const bool dbgk = (A.debug & 8) != 0 && mfma_ng == 1 && ns == 20;
 #define MF_CASE(KN, KV, GV, SV) case SV: hipLaunchKernelGGL((KN<KV, GV, SV, false>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A); break;
@@ -367,14 +366,14 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
         else hipLaunchKernelGGL((mh_sweep_mfma<2, 1, 20, true>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A);
       } else if (dbgk) {
         hipLaunchKernelGGL((mh_sweep_mfmar<1, 1, 20, true>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A);
-      } else if (!owners && mfma_ng == 2) {
-        switch (ns) { MF_CASES10(mh_sweep_mfmar, 1, 2) default: break; }
       } else if (!owners) {
-        switch (ns) { MF_CASES16(mh_sweep_mfmar, 1, 1) MF_CASES17(mh_sweep_mfmar, 1, 1) default: break; }
-      } else if (kv == 1) {   // owners, non-reflective: n > 8192 only (and p <= 3, or the shape would not be here)
-        switch (ns) { MF_CASES17(mh_sweep_mfma, 1, 1) default: break; }
+        switch (ns) { MF_CASES17(mh_sweep_mfmar, 1, 1) default: break; }
+      } else if (mfma_ng == 2 && kv == 1) {
+        switch (ns) { MF_CASES10(mh_sweep_mfma, 1, 2) default: break; }
       } else if (mfma_ng == 2) {
         switch (ns) { MF_CASES10(mh_sweep_mfma, 2, 2) default: break; }
+      } else if (kv == 1) {
+        switch (ns) { MF_CASES16(mh_sweep_mfma, 1, 1) MF_CASES17(mh_sweep_mfma, 1, 1) default: break; }
       } else {
         switch (ns) { MF_CASES16(mh_sweep_mfma, 2, 1) MF_CASES17(mh_sweep_mfma, 2, 1) default: break; }
       }

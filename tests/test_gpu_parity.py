@@ -280,9 +280,10 @@ def test_mfma_equals_valu_kernels(E, O, monkeypatch):
 
 @pytest.mark.parametrize("n", [10000, 9000, 600])
 def test_mfma_replicated_equals_owner_kernel(E, O, monkeypatch, n):
-    """The two MFMA kernels (owner waves / chain state replicated in every wave, hoisted division, one barrier) give the
-    same bits as the oracle and as each other wherever both are compiled in (n > 8192), incl. thinning, continuation,
-    a fixed parameter, the uniform kernel and a chain that fails with a NaN (general path of the replicated kernel)."""
+    """The two MFMA kernels (owner waves = the product path / chain state replicated in every wave, one barrier) give the
+    same bits as the oracle and as each other wherever both are compiled in (n > 8192; below that the switch is a no-op),
+    incl. thinning, continuation, a fixed parameter, the uniform kernel and a chain that fails with a NaN (the rare-path
+    branch of either kernel)."""
     X, y = synth_linreg(n, 3, 31 + n)
     init = jitter_init([0, 0, 0, 0, float(np.std(y))], 7, 24)
     init[:, -1] = np.abs(init[:, -1])
