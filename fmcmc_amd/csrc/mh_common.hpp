@@ -85,6 +85,12 @@ __device__ __forceinline__ void wave_sync_lds() {
   __builtin_amdgcn_wave_barrier();
 }
 __device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ double readlane_d(double v, int src) {   // lane `src` (wave-uniform index) of v, as a scalar
+  unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  unsigned lo = __builtin_amdgcn_readlane((unsigned)u, src), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), src);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double uniform_d(double v);
 __device__ __forceinline__ double sgpr_d(double v) {  // pin a wave-uniform double into an SGPR pair
   unsigned long long u = (unsigned long long)__double_as_longlong(v);
   unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
@@ -136,6 +142,8 @@ __device__ __forceinline__ double wave_xor_sum(double v) {
   }
   return v;
 }
+
+__device__ __forceinline__ double uniform_d(double v) { return sgpr_d(v); }
 
 // Split fp64 division.  The compiler expands a / b into v_div_scale x2, v_rcp_f64, two Newton steps on the reciprocal,
 // q0 = a r, e = fma(-b, q0, a), v_div_fmas (= fma(e, r, q0)), v_div_fixup.  With both operands positive, normal and

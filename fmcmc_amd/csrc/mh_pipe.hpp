@@ -63,17 +63,6 @@ __device__ __forceinline__ unsigned long long clk() {  // diagnostic stamp (debu
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
   return t;
 }
-__device__ __forceinline__ double uniform_d(double v) {  // pin a wave-uniform double into SGPRs
-  unsigned long long u = (unsigned long long)__double_as_longlong(v);
-  unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
-  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-__device__ __forceinline__ double readlane_d(double v, int src) {
-  unsigned long long u = (unsigned long long)__double_as_longlong(v);
-  unsigned lo = __builtin_amdgcn_readlane((unsigned)u, src), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), src);
-  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-
 // Register budget (512 threads -> 256 VGPRs): the x columns live in VGPRs (2*P*OPT = 120 at P=3,
 // OPT=20), y lives in LDS (OPT*512*8 B = 80 KB, read back as b128 pairs), owner-only constants and
 // addresses are kept in LDS / recomputed, so the steady-state loop runs without scratch traffic.

@@ -462,21 +462,26 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
             const double scl = fmh_sqrt(fmh_abs(cp));
             double w = (lane < kf) ? scl * L.vv[lane] : 0.0;
             bool fail = false;
+            // One column per iteration, sequential in w.  What an iteration waits for is kept off its path: the column's
+            // entries come from LDS one iteration ahead, x_j is a v_readlane (not a ds_bpermute round trip), the row
+            // update is selects plus one store region (the old form: three LDS round trips and two exec regions per
+            // column, 25 us of the 85 us step at k = 50).
+            const int myrow = (lane < kf) ? lane : 0;
+            double lij_nx = Scur[myrow * LD], ljj_nx = Scur[0];
             for (int j = 0; j < kf; j++) {
-              double ljj = Scur[j * LD + j];
-              double xj = shfl_d(w, j);
+              const double ljj = ljj_nx, lij = lij_nx;
+              const int jn = (j + 1 < kf) ? j + 1 : j;
+              lij_nx = Scur[myrow * LD + jn];
+              ljj_nx = Scur[jn * LD + jn];
+              const double xj = readlane_d(w, j);
               double r2 = up ? fmh_fma(xj, xj, ljj * ljj) : fmh_fma(-xj, xj, ljj * ljj);
               if (!(r2 > 0.0) || !fmh_isfinite(r2)) { fail = true; break; }
               double r = fmh_sqrt(r2);
               double cc = r / ljj, ss = xj / ljj;
-              if (lane == j) {
-                Salt[j * LD + j] = r;
-              } else if (lane > j && lane < kf) {
-                double lij = Scur[lane * LD + j];
-                double ln = (up ? fmh_fma(ss, w, lij) : fmh_fma(-ss, w, lij)) / cc;
-                w = fmh_fma(-ss, ln, cc * w);
-                Salt[lane * LD + j] = ln;
-              }
+              const double ln = (up ? fmh_fma(ss, w, lij) : fmh_fma(-ss, w, lij)) / cc;
+              const bool below = lane > j && lane < kf;
+              w = below ? fmh_fma(-ss, ln, cc * w) : w;
+              if (lane >= j && lane < kf) Salt[lane * LD + j] = (lane == j) ? r : ln;
             }
             wave_sync();
             if (fail) {
