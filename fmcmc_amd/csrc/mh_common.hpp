@@ -238,7 +238,10 @@ __device__ __forceinline__ ChainLds chain_lds(double* base, int k, int kf, int k
 // observation and four chains, at the ~6 cycles per instruction one wave issues.
 template <int CW>
 __device__ __forceinline__ void softplus_nonpos_vec(const double (&a)[CW], double (&out)[CW]) {
-  const double* tab = fmh_sp_tab_();
+  // (the table is a constant in global memory; through the generic pointer the loads were FLAT loads with 64-bit index
+  //  arithmetic -- as a global pointer they are global_load with a scalar base and a 32-bit lane offset)
+  typedef const double __attribute__((address_space(1))) * gptr_t;
+  const gptr_t tab = (gptr_t)(unsigned long long)fmh_sp_tab_();
   bool slow = false;
   double r[CW], sc[CW], q[CW];
 #pragma unroll
@@ -350,14 +353,22 @@ __device__ __forceinline__ void eval_partials(const SweepArgs& A, double* const*
 #pragma unroll
         for (int u = 0; u < PL; u++) bs[c][u] = sgpr_d(th[c][ic + u]);
       }
-      double xb[PL > 0 ? PL : 1], yv = 0.0;
-      long long i = tid;
-      if (i < n) {
+      // global (not generic) pointers, scalar column bases and a 32-bit lane index: one global_load per value with no
+      // 64-bit address arithmetic (through the by-value copy of the arguments the loads were FLAT loads)
+      typedef const double __attribute__((address_space(1))) * gptr_t;
+      gptr_t colp[PL > 0 ? PL : 1];
 #pragma unroll
-        for (int u = 0; u < PL; u++) xb[u] = A.X[(long long)u * n + i];
-        yv = A.y[i];
+      for (int u = 0; u < PL; u++) colp[u] = (gptr_t)(unsigned long long)(A.X + (long long)u * n);
+      const gptr_t yp = (gptr_t)(unsigned long long)A.y;
+      const unsigned int nn = (unsigned int)n;
+      double xb[PL > 0 ? PL : 1], yv = 0.0;
+      unsigned int i = (unsigned int)tid;
+      if (i < nn) {
+#pragma unroll
+        for (int u = 0; u < PL; u++) xb[u] = colp[u][i];
+        yv = yp[i];
       }
-      for (; i < n; i += NT) {
+      for (; i < nn; i += NT) {
         double eta[CW];
 #pragma unroll
         for (int c = 0; c < CW; c++) eta[c] = b0[c];
@@ -367,16 +378,16 @@ __device__ __forceinline__ void eval_partials(const SweepArgs& A, double* const*
           for (int c = 0; c < CW; c++) eta[c] = fmh_fma(xb[u], bs[c][u], eta[c]);
         }
         const bool y1 = (yv != 0.0);
-        const long long inx = (i + NT < n) ? i + NT : i;   // clamped: the last prefetch re-reads this observation
+        const unsigned int inx = (i + NT < nn) ? i + NT : i;   // clamped: the last prefetch re-reads this observation
 #pragma unroll
-        for (int u = 0; u < PL; u++) xb[u] = A.X[(long long)u * n + inx];
-        yv = A.y[inx];
+        for (int u = 0; u < PL; u++) xb[u] = colp[u][inx];
+        yv = yp[inx];
         add_terms(eta, y1);
       }
     };
     // (the logistic-only instantiations of the kernel carry these loop bodies; CW (P + 1) <= 28 coefficients fit the SGPRs)
     constexpr int PMAX = (FAM == FMCMC_FAM_LOGISTIC) ? (28 / CW - 1 > 8 ? 8 : 28 / CW - 1) : -1;
-    if (p <= PMAX) {
+    if (p <= PMAX && n < (1ll << 28)) {
       switch (p) {
         case 0: fixed_p(std::integral_constant<int, 0>()); break;
         case 1: fixed_p(std::integral_constant<int, (PMAX >= 1 ? 1 : 0)>()); break;
