@@ -465,3 +465,64 @@ def test_mirror_kernels(E, O, kind_name, C, n, p, scheme, fixed):
     q = ro.state.obs_arate
     assert np.all(np.isfinite(q)) and np.allclose(q * 6, np.round(q * 6))          # multiples of 1 / nadapt
     assert np.all(ro.state.abs_iter == 318)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# One-family instantiations of the streamed kernel: logistic (compile-time number of covariates, coefficients in SGPRs,
+# chain-vectorised softplus), wide linear models (observation blocking), and the adaptive owners with a compile-time k
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cw", ["1", "2", "4"])
+@pytest.mark.parametrize("p,intercept", [(0, True), (1, True), (3, False), (5, True), (6, True), (8, True), (9, True)])
+def test_logistic_specialised_loops(E, O, monkeypatch, cw, p, intercept):
+    """Every compile-time-p loop body of the logistic instantiations (p <= 28 / CW - 1 coefficients in SGPRs, beyond
+    that the run-time loop), for 1, 2 and 4 chains per workgroup, normal and reflective kernels, ragged n, a chain count
+    that is not a multiple of CW, plus large |eta| (both softplus tails)."""
+    monkeypatch.setenv("FMCMC_AMD_CW", cw)
+    rng = np.random.default_rng(100 + 10 * p + int(cw))
+    n = 1500 + 37 * p
+    X = rng.standard_normal((n, p)) * (3.0 if p == 5 else 1.0)        # p = 5: |eta| up to ~40
+    k = p + (1 if intercept else 0)
+    beta = rng.uniform(-1.5, 1.5, k)
+    eta = (beta[0] if intercept else 0.0) + (X @ beta[(1 if intercept else 0):] if p else 0.0)
+    y = (rng.uniform(size=n) < 1 / (1 + np.exp(-eta))).astype(np.float64)
+    C = 2 * int(cw) + 1
+    init = jitter_init(beta, C, 40 + p)
+    run_both(E, O, O.FAM_LOGISTIC, X if p else None, y, O.K_NORMAL, k, init, nsteps=70, burnin=5, thin=2, calls=2,
+             prior_div=8.0, scale=0.04, intercept=intercept)
+    run_both(E, O, O.FAM_LOGISTIC, X if p else None, y, O.K_NORMAL_REFLECTIVE, k, init, nsteps=50, prior_div=0.0,
+             scale=0.3, lb=-2.0, ub=2.0, intercept=intercept)
+
+
+@pytest.mark.parametrize("cw", ["1", "2"])
+@pytest.mark.parametrize("n,p", [(1023, 16), (2500, 21), (1024 * 3 + 1, 33)])
+def test_wide_linreg_instantiations(E, O, monkeypatch, cw, n, p):
+    """Wide linear models (p >= 16) run one-family / one-kernel instantiations with two observations per thread: odd
+    observation counts (padded second slot), column remainders (p % 8), normal / reflective / RAM kernels."""
+    monkeypatch.setenv("FMCMC_AMD_CW", cw)
+    X, y = synth_linreg(n, p, 7000 + n + p, beta=np.linspace(1.0, -1.0, p + 1))
+    C = 2 * int(cw) + 1
+    init = jitter_init(list(np.linspace(1.0, -1.0, p + 1)) + [4.0], C, n + p)
+    init[:, -1] = np.abs(init[:, -1])
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, p + 2, init, nsteps=60, burnin=3, thin=2, calls=2, scale=0.01)
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL_REFLECTIVE, p + 2, init, nsteps=40, scale=0.2, lb=-3.0, ub=6.0)
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, p + 2, init, nsteps=60, calls=2)
+
+
+@pytest.mark.parametrize("kind_name", ["adapt", "ram"])
+@pytest.mark.parametrize("n,p,intercept,fixed", [(10000, 3, True, None), (10000, 3, False, None), (1000, 1, True, None),
+                                                 (1000, 1, False, None), (10000, 3, True, [False, True, False, False, False])])
+def test_adaptive_owner_variants(E, O, kind_name, n, p, intercept, fixed):
+    """Register-row adaptive owners of mh_sweep_spec: k = P + 2 and k = P + 1 as compile-time constants, and the generic
+    k <= 8 / LDS versions (a fixed parameter), with continuation of the adapted state."""
+    X, y = synth_linreg(n, p, 300 + n + p)
+    k = p + 1 + (1 if intercept else 0)
+    base = ([0.0] if intercept else []) + [0.0] * p + [float(np.std(y))]
+    init = jitter_init(base, 6, 50 + k)
+    init[:, -1] = np.abs(init[:, -1])
+    kw = dict(intercept=intercept)
+    if fixed is not None:
+        kw["fixed"] = fixed
+    if kind_name == "adapt":
+        run_both(E, O, O.FAM_LINREG, X, y, O.K_ADAPT, k, init, nsteps=140, calls=2, warmup=30, **kw)
+    else:
+        run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, k, init, nsteps=120, calls=2, **kw)
