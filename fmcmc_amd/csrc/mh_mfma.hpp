@@ -206,7 +206,11 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
       const unsigned sg_hi = (unsigned)(fmh_d2u(sigma) >> 32);
       sg_fast = (sg_hi - 0x00100000u) < 0x7fe00000u;                     // positive, finite, normal
       const double sg = sg_fast ? sigma : 1.0;
+#ifdef MFO_NOLOG   /* timing ablation (tools/exp_mfmar.hip): what the logarithm in the owners' MFMA slack costs */
+      const double t1_fast = sg + FMH_K(FMH_LN_SQRT_2PI);
+#else
       const double t1_fast = fmh_log_pn(sg) + FMH_K(FMH_LN_SQRT_2PI);   // same bits as fmh_log(sigma) on this range
+#endif
       nt1_fast = uniform_d(dn * t1_fast);
       ss_fast = uniform_d(sg * sg);
       // denominator half of (0.5 tot) / sigma^2 (mh_common.hpp: div_recip / div_finish), in the same slack
