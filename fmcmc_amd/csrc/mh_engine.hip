@@ -313,8 +313,9 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
     if (!(usemf0 && usemf0[0] == '0') && kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE && kn->scheme == FMCMC_SCHEME_JOINT) {
       if (m->p <= 3 && m->n <= (long long)NT * 20) mfma_ng = 1;
       else if (m->p <= 7 && m->n <= (long long)NT * 10) mfma_ng = 2;
-      // the wave-specialised VALU kernel overlaps owners and evaluation; at its small shape that beats the MFMAs
-      if (pipe_opt == 2 && !(nospec0 && nospec0[0] == '1')) mfma_ng = 0;
+      // (the wave-specialised VALU kernel, which overlaps owners and evaluation, used to win at its small shape
+      //  (p = 1, n ~ 1000); since the instruction diet of the owner phase the MFMA kernel is 1.2-1.35x ahead there too:
+      //  tools/bench_small.py.  FMCMC_AMD_MFMA=0 still selects it.)
     }
   }
   if (pipe_opt || mfma_ng) {

@@ -526,3 +526,18 @@ def test_adaptive_owner_variants(E, O, kind_name, n, p, intercept, fixed):
         run_both(E, O, O.FAM_LINREG, X, y, O.K_ADAPT, k, init, nsteps=140, calls=2, warmup=30, **kw)
     else:
         run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, k, init, nsteps=120, calls=2, **kw)
+
+
+def test_small_shape_mfma_equals_wave_specialised_kernel(E, O, monkeypatch):
+    """README-size data (p = 1, n ~ 1000): the MFMA kernel (default) and the wave-specialised VALU kernel it replaced there
+    (FMCMC_AMD_MFMA=0) give the oracle's bits, normal and reflective kernels."""
+    X, y = synth_linreg(1000, 1, 4242)
+    init = jitter_init([0.0, 0.0, float(np.std(y))], 7, 77)
+    init[:, -1] = np.abs(init[:, -1])
+    out = []
+    for mf in ("1", "0"):
+        monkeypatch.setenv("FMCMC_AMD_MFMA", mf)
+        a, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 3, init, nsteps=200, burnin=10, thin=3, calls=2, scale=0.05)
+        b, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL_REFLECTIVE, 3, init, nsteps=150, scale=0.5, lb=[-4, -4, 0.5], ub=[6, 6, 8.0])
+        out.append((a.samples.cpu().numpy(), b.samples.cpu().numpy()))
+    assert _bits_equal(out[0][0], out[1][0]) and _bits_equal(out[0][1], out[1][1])
