@@ -49,7 +49,7 @@ def flops_per_sample():
     return N_OBS * (2 * P_COV + 3)
 
 
-def cpu_baseline(seconds_budget=15.0):
+def cpu_baseline(seconds_budget=24.0):
     """The oracle (PHILOX/canonical mode = same outputs as the GPU) timed on the host cores, on a
     bounded sample of the SAME workload: `m` chains x 10,000 iterations per host thread."""
     from concurrent.futures import ThreadPoolExecutor
