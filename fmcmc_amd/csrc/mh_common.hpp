@@ -236,47 +236,63 @@ __device__ __forceinline__ ChainLds chain_lds(double* base, int k, int kf, int k
 // (FMH_K costs two scalar moves per use), the CW dependent chains interleave, and the out-of-range test is one branch
 // per observation.  Called once per observation, the scalar routine made the logistic loop ~1100 instructions per
 // observation and four chains, at the ~6 cycles per instruction one wave issues.
+// Tables of the softplus staged in LDS (the logistic-only kernel instantiations): a lookup from global memory is a
+// 64-address gather, ~64 cycles of the texture addresser each (16 per observation made the loop 31 % slower than the
+// arithmetic they replaced); from LDS it is one ds_read_b128.  Layout: 128 rows {invc, logc_hi, logc_lo, -} then 128 rows
+// {2^(j/128) hi, lo}.
+constexpr int SP_LDS_DOUBLES = 128 * 4 + 128 * 2;
+__device__ __forceinline__ void softplus_stage_tables(double* s_tab) {
+  const double* lt = fmh_sp_tab_();
+  const double* xt = fmh_sp_exp_tab_();
+  for (int i = threadIdx.x; i < 128 * 4; i += blockDim.x) s_tab[i] = ((i & 3) < 3) ? lt[3 * (i >> 2) + (i & 3)] : 0.0;
+  for (int i = threadIdx.x; i < 128 * 2; i += blockDim.x) s_tab[128 * 4 + i] = xt[i];
+}
+
 template <int CW>
-__device__ __forceinline__ void softplus_nonpos_vec(const double (&a)[CW], double (&out)[CW]) {
-  // (the table is a constant in global memory; through the generic pointer the loads were FLAT loads with 64-bit index
-  //  arithmetic -- as a global pointer they are global_load with a scalar base and a 32-bit lane offset)
+__device__ __forceinline__ void softplus_nonpos_vec(const double (&a)[CW], double (&out)[CW], const double* s_tab) {
+  // (without LDS tables -- the all-family kernels -- the tables are read as global memory: scalar base + 32-bit lane offset)
   typedef const double __attribute__((address_space(1))) * gptr_t;
-  const gptr_t tab = (gptr_t)(unsigned long long)fmh_sp_tab_();
+  const gptr_t gtab = (gptr_t)(unsigned long long)fmh_sp_tab_();
+  const gptr_t gxtab = (gptr_t)(unsigned long long)fmh_sp_exp_tab_();
   bool slow = false;
-  double r[CW], sc[CW], q[CW];
+  double r[CW], sc[CW], q[CW], xh[CW], xl[CW];
 #pragma unroll
   for (int c = 0; c < CW; c++) slow = slow || !(a[c] <= FMH_SP_AMAX) || a[c] < FMH_SP_AMIN;
   {
-    const double inv_ln2 = FMH_K(FMH_INV_LN2), ln2_hi = FMH_K(FMH_LN2_HI), ln2_lo = FMH_K(FMH_LN2_LO);
+    const double n_inv_ln2 = FMH_K(FMH_SP_N_INV_LN2), shift = FMH_K(FMH_SP_SHIFT);
+    const double ln2_hi = FMH_K(FMH_SP_LN2_N_HI), ln2_lo = FMH_K(FMH_SP_LN2_N_LO);
 #pragma unroll
     for (int c = 0; c < CW; c++) {
-      const double t0 = fmh_fma(a[c], inv_ln2, -0.5);
-      const int k = (int)t0;
-      const double dk = (double)k;
-      r[c] = fmh_fma(-dk, ln2_hi, a[c]) - dk * ln2_lo;
-      sc[c] = fmh_u2d((uint64_t)(1023 + k) << 52);
+      const double t = fmh_fma(a[c], n_inv_ln2, shift);
+      const double kd = t - shift;
+      const int32_t ki = (int32_t)(uint32_t)fmh_d2u(t);
+      r[c] = fmh_fma(-kd, ln2_lo, fmh_fma(-kd, ln2_hi, a[c]));
+      const unsigned int xi = 2u * (unsigned int)(ki & 127);
+      if (s_tab) { xh[c] = s_tab[128 * 4 + xi]; xl[c] = s_tab[128 * 4 + xi + 1]; }
+      else { xh[c] = gxtab[xi]; xl[c] = gxtab[xi + 1]; }
+      sc[c] = fmh_u2d((uint64_t)(1023 + (ki >> 7)) << 52);
     }
   }
   {
-    const double e13 = FMH_K(FMH_SP_E13), e12 = FMH_K(FMH_SP_E12);
+    const double e5 = FMH_K(FMH_SP_E5), e4 = FMH_K(FMH_SP_E4);
 #pragma unroll
-    for (int c = 0; c < CW; c++) q[c] = fmh_fma(r[c], e13, e12);
+    for (int c = 0; c < CW; c++) q[c] = fmh_fma(r[c], e5, e4);
   }
 #define SP_STEP(arr, x, K) { const double kk = FMH_K(K); _Pragma("unroll") for (int c = 0; c < CW; c++) arr[c] = fmh_fma(x[c], arr[c], kk); }
-  SP_STEP(q, r, FMH_SP_E11) SP_STEP(q, r, FMH_SP_E10) SP_STEP(q, r, FMH_SP_E9) SP_STEP(q, r, FMH_SP_E8) SP_STEP(q, r, FMH_SP_E7)
-  SP_STEP(q, r, FMH_SP_E6) SP_STEP(q, r, FMH_SP_E5) SP_STEP(q, r, FMH_SP_E4) SP_STEP(q, r, FMH_SP_E3) SP_STEP(q, r, FMH_SP_E2)
-  double u[CW], cc[CW], invc[CW], rr[CW], p[CW];
-  unsigned int T[CW];   // index of the table row
+  SP_STEP(q, r, FMH_SP_E3) SP_STEP(q, r, FMH_SP_E2)
+  double u[CW], cc[CW], invc[CW], lch[CW], lcl[CW], rr[CW], p[CW];
 #pragma unroll
   for (int c = 0; c < CW; c++) {
-    const double w = fmh_fma(r[c] * r[c], q[c], r[c]);
-    const double er = 1.0 + w;
-    const double el = w - (er - 1.0);
+    const double pm1 = fmh_fma(r[c] * r[c], q[c], r[c]);
+    const double w = fmh_fma(xh[c], pm1, xl[c]);
+    const double er = xh[c] + w;
+    const double el = w - (er - xh[c]);
     const double e = er * sc[c];
     u[c] = 1.0 + e;
     cc[c] = fmh_fma(el, sc[c], e - (u[c] - 1.0));
-    T[c] = 3u * ((uint32_t)(fmh_d2u(u[c]) >> 45) & 127u);
-    invc[c] = tab[T[c]];
+    const unsigned int ti = (uint32_t)(fmh_d2u(u[c]) >> 45) & 127u;
+    if (s_tab) { invc[c] = s_tab[4 * ti]; lch[c] = s_tab[4 * ti + 1]; lcl[c] = s_tab[4 * ti + 2]; }
+    else { invc[c] = gtab[3 * ti]; lch[c] = gtab[3 * ti + 1]; lcl[c] = gtab[3 * ti + 2]; }
     rr[c] = fmh_fma(u[c], invc[c], -1.0);
   }
   {
@@ -288,8 +304,8 @@ __device__ __forceinline__ void softplus_nonpos_vec(const double (&a)[CW], doubl
 #undef SP_STEP
 #pragma unroll
   for (int c = 0; c < CW; c++) {
-    const double s = fmh_fma(rr[c] * rr[c], p[c], fmh_fma(cc[c], invc[c], tab[T[c] + 2]));
-    out[c] = tab[T[c] + 1] + (rr[c] + s);
+    const double s = fmh_fma(rr[c] * rr[c], p[c], fmh_fma(cc[c], invc[c], lcl[c]));
+    out[c] = lch[c] + (rr[c] + s);
   }
   if (__builtin_expect(slow, 0)) {   // |eta| < 2^-28, eta beyond +-700, NaN: the general functions, as in the scalar routine
 #pragma unroll
@@ -303,7 +319,7 @@ __device__ __forceinline__ void softplus_nonpos_vec(const double (&a)[CW], doubl
 // FAM > 0 compiles one family in (leaner kernels for the logistic model), FAM == 0 keeps all behind A.family.
 template <int CW, int FAM = 0>
 __device__ __forceinline__ void eval_partials(const SweepArgs& A, double* const* th /*[CW] -> theta in LDS*/,
-                                              double* s_part) {
+                                              double* s_part, const double* s_sptab = nullptr /* softplus tables in LDS */) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long long n = A.n;
   const int family = FAM ? FAM : A.family;
@@ -334,7 +350,7 @@ __device__ __forceinline__ void eval_partials(const SweepArgs& A, double* const*
         double ag[G], lg[G];
 #pragma unroll
         for (int c = 0; c < G; c++) ag[c] = ab[g0 + c];
-        softplus_nonpos_vec<G>(ag, lg);
+        softplus_nonpos_vec<G>(ag, lg, s_sptab);
 #pragma unroll
         for (int c = 0; c < G; c++) l1[g0 + c] = lg[c];
       }

@@ -432,6 +432,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
         hipLaunchKernelGGL((mh_sweep_kernel<CWV, -1, 0, KV, FMCMC_FAM_LOGISTIC>), dim3((unsigned)nblk), dim3(NT), lds, stream, A); \
     } while (0)
     const bool refl = kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE;
+    lds += sizeof(double) * (SP_LDS_DOUBLES + 1);   // the softplus tables staged behind the chain blocks
     switch (cw) {
       case 1: if (refl) LAUNCH_LOGIT(1, 2); else LAUNCH_LOGIT(1, 1); break;
       case 2: if (refl) LAUNCH_LOGIT(2, 2); else LAUNCH_LOGIT(2, 1); break;

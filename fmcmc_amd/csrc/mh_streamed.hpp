@@ -34,7 +34,7 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
   double* s_zt = s_part + NW * CW + 1;      // [CW][TB][kz] proposal variates of the tile
   double* s_lu = s_zt + CW * TB * kz;       // [CW][TB]     log accept uniforms of the tile
   double* s_tr = s_lu + CW * TB;            // RESIDENT: [CW][NT] lane partials
-  double* s_chains = s_tr + (RESIDENT ? CW * NT : 0);
+  double* s_chains = s_tr + (RESIDENT ? CW * NT : 0);   // [CW][CHS], then (logistic-only instantiations) the softplus tables
 
   __shared__ int s_kf;
   if (tid == 0) {
@@ -54,6 +54,12 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
   const int kf = s_kf;
   const int LD = kf | 1;
   const int CHS = chain_lds_doubles(k, kf, A.kind);
+  const double* s_sptab = nullptr;
+  if constexpr (FAM == FMCMC_FAM_LOGISTIC) {
+    double* tabs = s_chains + CW * CHS + ((CW * CHS) & 1);    // 16-byte aligned rows
+    softplus_stage_tables(tabs);
+    s_sptab = tabs;
+  }
   const long long cg0 = (long long)blockIdx.x * CW;  // first local chain of this workgroup
   const int ncw = (int)((A.nchains - cg0 < CW) ? (A.nchains - cg0) : CW);
   const bool adaptive = (A.kind == FMCMC_KERNEL_ADAPT || A.kind == FMCMC_KERNEL_RAM);
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
         if (lane == 0) s_part[h * CW + c] = v;
       }
     } else {
-      eval_partials<CW, FAM>(A, thp, s_part);
+      eval_partials<CW, FAM>(A, thp, s_part, s_sptab);
     }
   };
   auto total_of = [&](int c) -> double {

@@ -72,7 +72,7 @@ int main(int argc, char** argv) {
   A.status = dstat; A.status_step = dss; A.status_theta = dst_th;
   const int kf = k;
   const size_t ldsd = 4 * (size_t)k + (k / 2 + 1) + (size_t)NW * CWV + 1 + (size_t)CWV * A.tb * (kz + 1) + (size_t)CWV * chain_lds_doubles(k, kf, A.kind);
-  const size_t lds = ldsd * 8;
+  const size_t lds = (ldsd + (FAMV == 2 ? SP_LDS_DOUBLES + 1 : 0)) * 8;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   float tot = 0;
   for (int r = 0; r < reps + 1; r++) {
