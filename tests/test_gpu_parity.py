@@ -541,3 +541,21 @@ def test_small_shape_mfma_equals_wave_specialised_kernel(E, O, monkeypatch):
         b, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL_REFLECTIVE, 3, init, nsteps=150, scale=0.5, lb=[-4, -4, 0.5], ub=[6, 6, 8.0])
         out.append((a.samples.cpu().numpy(), b.samples.cpu().numpy()))
     assert _bits_equal(out[0][0], out[1][0]) and _bits_equal(out[0][1], out[1][1])
+
+
+@pytest.mark.parametrize("kind_name", ["adapt", "ram", "normal_ordered"])
+def test_logistic_on_the_general_kernel(E, O, kind_name):
+    """Logistic model with the kernels that stay on the all-family streamed kernel (adaptive kernels, single-parameter
+    schemes): its softplus reads the tables from global memory instead of LDS -- same bits as the oracle."""
+    rng = np.random.default_rng(77)
+    n, p = 1300, 3
+    X = rng.standard_normal((n, p))
+    beta = np.array([-0.5, 1.0, -1.0, 0.5])
+    y = (rng.uniform(size=n) < 1 / (1 + np.exp(-(beta[0] + X @ beta[1:])))).astype(np.float64)
+    init = jitter_init(beta, 5, 9)
+    if kind_name == "adapt":
+        run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_ADAPT, 4, init, nsteps=120, calls=2, warmup=30, prior_div=8.0)
+    elif kind_name == "ram":
+        run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_RAM, 4, init, nsteps=120, calls=2, prior_div=8.0)
+    else:
+        run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_NORMAL, 4, init, nsteps=150, prior_div=8.0, scale=0.1, scheme="ordered")
