@@ -5,18 +5,36 @@
 // Launched cooperatively (all workgroups co-resident) and with a bounded spin (gives up and reports instead of hanging).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#ifndef BAR_VARIANT
+#define BAR_VARIANT 1
+#endif
+// grp: 8 arrival counters (128 B apart), top: arrival counter of the groups, rel: 8 release words (128 B apart, variant 1)
 __device__ __forceinline__ bool grid_barrier(unsigned* grp, unsigned* top, unsigned epoch, unsigned ngroups, unsigned gsize) {
   __syncthreads();
   bool ok = true;
   if (threadIdx.x == 0) {
     const unsigned g = blockIdx.x % ngroups;
-    const unsigned old = __hip_atomic_fetch_add(&grp[g * 32], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);   // 128-B apart
-    if (old + 1 == epoch * gsize) __hip_atomic_fetch_add(top, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned spins = 0;
-    while (__hip_atomic_load(top, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < epoch * ngroups) {
-      __builtin_amdgcn_s_sleep(2);
-      if (++spins > 4000000u) { ok = false; break; }      // ~ a second: give up instead of hanging the GPU
+    unsigned* rel = top + 32;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const unsigned old = __hip_atomic_fetch_add(&grp[g * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1 == epoch * gsize) {
+      const unsigned t = __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (BAR_VARIANT == 1 && t + 1 == epoch * ngroups)       // last group in: release everybody through 8 separate lines
+        for (unsigned q = 0; q < ngroups; q++) __hip_atomic_store(&rel[q * 32], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    unsigned spins = 0;
+    if (BAR_VARIANT == 1) {
+      while (__hip_atomic_load(&rel[g * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > 8000000u) { ok = false; break; }
+      }
+    } else {
+      while (__hip_atomic_load(top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch * ngroups) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > 8000000u) { ok = false; break; }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
   return ok;
@@ -36,10 +54,10 @@ __global__ __launch_bounds__(512) void k(double* buf, unsigned* grp, unsigned* t
 }
 int main() {
   double* buf; unsigned *grp, *top; int* err;
-  hipMalloc(&buf, 8 * 4096); hipMalloc(&grp, 4 * 32 * 8); hipMalloc(&top, 128); hipMalloc(&err, 4);
+  hipMalloc(&buf, 8 * 4096); hipMalloc(&grp, 4 * 32 * 8); hipMalloc(&top, 128 * 10); hipMalloc(&err, 4);
   for (int blocks : {64, 128, 256}) {
     for (int iters : {200, 2000}) {
-      hipMemset(buf, 0, 8 * 4096); hipMemset(grp, 0, 4 * 32 * 8); hipMemset(top, 0, 128); hipMemset(err, 0, 4);
+      hipMemset(buf, 0, 8 * 4096); hipMemset(grp, 0, 4 * 32 * 8); hipMemset(top, 0, 128 * 10); hipMemset(err, 0, 4);
       void* args[] = {&buf, &grp, &top, &iters, &err};
       hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
       hipEventRecord(e0, 0);
