@@ -17,10 +17,10 @@ SCHEME_JOINT, SCHEME_ORDERED, SCHEME_RANDOM, SCHEME_EXPLICIT = 0, 1, 2, 3
 ABI_VERSION = 2
 RNG_PHILOX, RNG_FED = 0, 1
 OK, ERR_ARG, ERR_DEVICE, ERR_CHAIN, ERR_UNSUPPORTED = 0, 1, 2, 3, 4
-CHAIN_OK, CHAIN_NAN_LOGPOST, CHAIN_NAN_RATIO, CHAIN_NOT_PD, CHAIN_BAD_WINDOW = 0, 1, 2, 3, 4
+CHAIN_OK, CHAIN_NAN_LOGPOST, CHAIN_NAN_RATIO, CHAIN_NOT_PD, CHAIN_BAD_WINDOW, CHAIN_SYNC_TIMEOUT = 0, 1, 2, 3, 4, 5
 MAX_K = 64
 
-EXPORTS = ["fmcmc_abi_version", "fmcmc_last_error", "fmcmc_device_count", "fmcmc_kept_rows",
+EXPORTS = ["fmcmc_abi_version", "fmcmc_last_error", "fmcmc_last_kernel", "fmcmc_device_count", "fmcmc_kept_rows",
            "fmcmc_validate", "fmcmc_mcmc_run_dev", "fmcmc_mcmc_run_host", "fmcmc_gelman_partial_len",
            "fmcmc_gelman_work_len",
            "fmcmc_gelman_partial_dev", "fmcmc_gelman_finish", "fmcmc_detmath_dev", "fmcmc_rng_stream_dev"]
@@ -79,6 +79,7 @@ def lib():
             raise RuntimeError("%s has ABI version %d, this package binds version %d: rebuild with "
                                "`python -m fmcmc_amd.build`." % (LIB_PATH, L.fmcmc_abi_version(), ABI_VERSION))
         L.fmcmc_last_error.restype = C.c_char_p
+        L.fmcmc_last_kernel.restype = C.c_char_p
         L.fmcmc_device_count.restype = C.c_int
         L.fmcmc_kept_rows.restype = C.c_int64
         L.fmcmc_kept_rows.argtypes = [C.c_int64, C.c_int64, C.c_int64]
@@ -112,3 +113,8 @@ def lib():
 
 def last_error():
     return lib().fmcmc_last_error().decode("utf-8", "replace")
+
+
+def last_kernel():
+    """Kernel variant chosen by this thread's last sweep (diagnostic; results never depend on it)."""
+    return lib().fmcmc_last_kernel().decode("utf-8", "replace")

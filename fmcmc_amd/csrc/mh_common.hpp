@@ -61,6 +61,14 @@ struct SweepArgs {
   double* mean_prev;
   int* have_mean;
   int* nerrors;
+  // observation-sharded evaluation (wide linear models, cooperative launch; 0 = off)
+  int shard;                 // canonical lanes per workgroup (512 / number of workgroups: 2 or 4)
+  int sh_nslots;             // observations per canonical lane, ceil(n / 512); shard * sh_nslots <= SH_MAXO
+  const double* sh_xs;       // [G][p][SH_MAXO] the workgroup's observations, column by column, slot-major (0 beyond n)
+  const double* sh_ys;       // [G][SH_MAXO]
+  double* sh_th;             // [k][nchains] proposals of all chains
+  double* sh_part;           // [512][nchains] lane partials of all chains
+  unsigned* sh_bar;          // barrier words, zeroed per launch (shard_barrier)
   // out
   double* samples;
   double* logpost;
@@ -313,13 +321,155 @@ __device__ __forceinline__ void softplus_nonpos_vec(const double (&a)[CW], doubl
   }
 }
 
+// ---- observation-sharded evaluation of wide linear models (config C4) ---------------------------------------------
+// With chains sharded over the CUs every CU streams all of X from L2 once per step, at the rate one CU gets out of its
+// XCD's L2 (65-67 GB/s: 59 us per step at k = 50 -- the roofline of that design).  Here the OBSERVATIONS are sharded
+// instead: workgroup b of G owns the canonical lanes b LPW .. b LPW + LPW - 1 (LPW = 512 / G) for ALL chains, i.e. a
+// constant slice of LPW x nslots observations that it reads as scalar operands from a compact copy (15 KB at k = 50,
+// stays in the scalar cache), and per step only the coefficients of all chains (k x nchains doubles) cross the chip.
+// A step's evaluation is: every workgroup publishes the proposals of its own chains -> grid barrier -> thread = chain:
+// the canonical fma chain over the columns for each observation of the slice, r^2 accumulated per lane in slot order ->
+// lane partials of all chains to memory -> grid barrier -> thread = canonical lane again: it picks up its partial of
+// the workgroup's own chains and the usual tree follows.  Same arithmetic, same order, same bits.
+constexpr int SH_PAD = 32;             // row padding (doubles) of the exchange tables: a 4 KB row stride put every row
+                                       // of a workgroup's strided accesses on the same L2 channel
+constexpr int SH_MAXO = 40;            // observations of a slice held in registers by a thread; the slice (p x 40 doubles)
+                                       // must stay in the 16 KB scalar cache: with 48 x 48 doubles (18 KB) every pass missed
+// Grid barrier: 8 arrival counters + a top counter + 8 release words on separate cache lines, one lane per workgroup,
+// relaxed agent-scope polling (5.3 us at 256 workgroups, tools/grid_barrier_custom.hip; cooperative_groups' grid.sync()
+// takes 27 us).  NO agent-scope fence: its acquire half (buffer_inv sc1) drops the slice from the caches and the scalar
+// loop then runs 3x slower (tools/scalar_slice_probe.hip: 11.8 -> 32.6 us per step), its release half writes back the
+// whole L2.  Instead everything that crosses workgroups (coefficients, lane partials) is moved with agent-scope atomic
+// loads and stores (sc1: write-through / L2-coherent per location), every thread drains its own stores (s_waitcnt
+// vmcnt(0)) before the workgroup arrives, and workgroup-scope fences keep the compiler from moving accesses across.
+// Cooperative launch guarantees co-residency; the spin is bounded anyway.
+// (global address space on purpose: through a generic pointer these are FLAT instructions -- 64-bit VGPR addresses for
+// every load in flight, and lgkmcnt shared with the scalar loads of the slice)
+typedef double __attribute__((address_space(1))) * sh_gptr_t;
+__device__ __forceinline__ void sh_store(double* p, double v) {
+  __hip_atomic_store((sh_gptr_t)(unsigned long long)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double sh_load(const double* p) {
+  return __hip_atomic_load((sh_gptr_t)(unsigned long long)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool shard_barrier(unsigned* bar, unsigned epoch) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0);           // this thread's sc1 stores have been acknowledged
+  __syncthreads();
+  bool ok = true;
+  if (threadIdx.x == 0) {
+    const unsigned ngroups = 8, gsize = gridDim.x / 8, g = blockIdx.x % ngroups;
+    unsigned* top = bar + 8 * 32;
+    unsigned* rel = bar + 9 * 32;
+    const unsigned old = __hip_atomic_fetch_add(&bar[g * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1 == epoch * gsize) {
+      const unsigned t = __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t + 1 == epoch * ngroups)
+        for (unsigned q = 0; q < ngroups; q++) __hip_atomic_store(&rel[q * 32], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    unsigned spins = 0;
+    while (__hip_atomic_load(&rel[g * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > 20000000u) { ok = false; break; }
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  return ok;
+}
+
+// lane partials acc[c] of canonical lane `tid` for the CW chains of this workgroup, via the sharded evaluation
+template <int CW, int LPW>
+__device__ __forceinline__ bool eval_sharded(const SweepArgs& A, double* const* th, double (&acc)[CW], unsigned& epoch) {
+  const int tid = threadIdx.x;
+  const int NC = (int)A.nchains, NCP = NC + SH_PAD, p = A.p, ic = A.intercept, nb = ic + p;
+  const long long cg0 = (long long)blockIdx.x * CW;
+  const int ncw = (int)((A.nchains - cg0 < CW) ? (A.nchains - cg0) : CW);
+  // 1. publish the coefficients of this workgroup's chains, [coefficient][chain]
+  for (int idx = tid; idx < CW * nb; idx += NT) {
+    const int c = idx / nb, j = idx - c * nb;
+    if (c < ncw) sh_store(&A.sh_th[(long long)j * NCP + cg0 + c], th[c][j]);
+  }
+  bool ok = (A.debug & 32) ? true : shard_barrier(A.sh_bar, ++epoch);   // (debug bits 32 / 64 / 128: timing ablations)
+  // 2. thread = chain: the slice's observations for that chain
+  const double* thg = A.sh_th;
+  // constant address space + uniform address = SCALAR loads (s_load_dwordx16: 8 observations per instruction); through
+  // the generic pointer they were 48 broadcast vector loads per column and the evaluation took 96 us instead of ~15
+  typedef const double __attribute__((address_space(4))) * cptr_t;
+  const cptr_t xs = (cptr_t)(unsigned long long)(A.sh_xs + (long long)blockIdx.x * p * SH_MAXO);
+  const cptr_t ys = (cptr_t)(unsigned long long)(A.sh_ys + (long long)blockIdx.x * SH_MAXO);
+  const int nslots = A.sh_nslots;
+  for (int cb = 0; cb < NC; cb += NT) {
+    const int chain = cb + tid;
+    const unsigned int chc = (unsigned int)(chain < NC ? chain : 0);
+    double mu[SH_MAXO];
+    const double b0 = ic ? sh_load(thg + chc) : 0.0;
+#pragma unroll
+    for (int o = 0; o < SH_MAXO; o++) mu[o] = b0;
+    // coefficients in blocks of 8, THREE blocks in flight: they were written by other XCDs a barrier ago, every load is
+    // an L2 miss of 1-3 us and a block's 320 FMAs cover ~1 us; one block ahead stalled on every block (36 us for the
+    // columns instead of 12), all of them at once (6 blocks + tail) spilled 300 registers
+    constexpr int JB8 = 8, RING = 3;
+    const int pe = (A.debug & 64) ? 1 : p;
+    double tb[RING][JB8];
+    // (column index clamped instead of a guard per load: 32 guarded loads compiled to 32 branches, each reloading the
+    // kernel arguments through spilled SGPRs)
+#define SH_LOAD_BLOCK(q, j0)                                                                                   \
+    _Pragma("unroll") for (int u = 0; u < JB8; u++) {                                                          \
+      const int jj = ((j0) + u < pe) ? (j0) + u : pe - 1;                                                      \
+      tb[q][u] = sh_load(thg + ((unsigned int)((ic + jj) * NCP) + chc));                                       \
+    }
+#pragma unroll
+    for (int q = 0; q < RING; q++) { SH_LOAD_BLOCK(q, q * JB8) }
+    for (int jb = 0; jb < pe; jb += RING * JB8) {
+#pragma unroll
+      for (int q = 0; q < RING; q++) {
+        const int j0 = jb + q * JB8;
+        if (j0 < pe) {
+#pragma unroll
+          for (int u = 0; u < JB8; u++) {
+            if (j0 + u < pe) {               // uniform
+              const cptr_t xc = xs + (j0 + u) * SH_MAXO;
+#pragma unroll
+              for (int o = 0; o < SH_MAXO; o++) mu[o] = fmh_fma(xc[o], tb[q][u], mu[o]);
+            }
+          }
+          if (j0 + RING * JB8 < pe) { SH_LOAD_BLOCK(q, j0 + RING * JB8) }
+        }
+      }
+    }
+#undef SH_LOAD_BLOCK
+    double al[LPW];
+#pragma unroll
+    for (int q = 0; q < LPW; q++) al[q] = 0.0;
+#pragma unroll
+    for (int o = 0; o < SH_MAXO; o++) {          // o = slot * LPW + lane-in-slice: slot order per lane
+      const int sl = o / LPW, q = o % LPW;
+      const bool valid = sl < nslots && ((long long)(blockIdx.x * LPW + q) + (long long)NT * sl) < A.n;   // uniform
+      const double r = valid ? ys[o] - mu[o] : 0.0;                      // fma(0, 0, acc) == acc exactly
+      al[q] = fmh_fma(r, r, al[q]);
+    }
+    if (chain < NC) {
+#pragma unroll
+      for (int q = 0; q < LPW; q++) sh_store(&A.sh_part[(long long)chain * (NT + SH_PAD) + blockIdx.x * LPW + q], al[q]);
+    }
+  }
+  if (!(A.debug & 32)) ok = shard_barrier(A.sh_bar, ++epoch) && ok;
+  // 3. thread = canonical lane: its partial of this workgroup's chains
+#pragma unroll
+  for (int c = 0; c < CW; c++)
+    acc[c] = (c < ncw && !(A.debug & 128)) ? sh_load(A.sh_part + ((unsigned int)(cg0 + c) * (unsigned int)(NT + SH_PAD) + (unsigned int)tid)) : 1.0;
+  return ok;
+}
+
 // ---- workgroup-collective log-posterior partial sums (streamed variant) ------------------
 // Every thread accumulates its canonical lane for all CW chains, then the wavefront butterfly
 // (levels 1..32) runs and lane 0 of each wavefront publishes its partial to s_part[w][c].
 // FAM > 0 compiles one family in (leaner kernels for the logistic model), FAM == 0 keeps all behind A.family.
-template <int CW, int FAM = 0>
+template <int CW, int FAM = 0, int SHL = 0 /* > 0: observation-sharded evaluation, SHL canonical lanes per workgroup */>
 __device__ __forceinline__ void eval_partials(const SweepArgs& A, double* const* th /*[CW] -> theta in LDS*/,
-                                              double* s_part, const double* s_sptab = nullptr /* softplus tables in LDS */) {
+                                              double* s_part, const double* s_sptab = nullptr /* softplus tables in LDS */,
+                                              unsigned* sh_epoch = nullptr /* barrier epoch of the sharded evaluation */) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long long n = A.n;
   const int family = FAM ? FAM : A.family;
@@ -465,6 +615,9 @@ __device__ __forceinline__ void eval_partials(const SweepArgs& A, double* const*
         add_terms(eta, y1);
       }
     }
+  } else if constexpr (FAM == FMCMC_FAM_GAUSSIAN_LINREG && CW <= 2 && SHL > 0) {
+    const bool ok = eval_sharded<CW, SHL>(A, th, acc, *sh_epoch);
+    if (!ok && tid == 0) A.status[(long long)blockIdx.x * CW] = FMCMC_CHAIN_SYNC_TIMEOUT;
   } else {
     // Memory-level parallelism: the data comes from L2 (latency ~1 us under load), so every thread keeps a
     // batch of JB independent column loads in flight before the FMAs that consume them; a dependent

@@ -70,6 +70,21 @@ __global__ void detmath_kernel(int which, const double* x, double* out, long lon
   out[i] = r;
 }
 
+// compact per-workgroup slices of X and y for the observation-sharded evaluation (mh_common.hpp, eval_sharded):
+// xs[(b p + j) SH_MAXO + o], ys[b SH_MAXO + o] with o = slot * LPW + q <-> observation b LPW + q + 512 slot (0 beyond n)
+__global__ void shard_build_slices(const double* X, const double* y, long long n, int p, int lpw, int nslots,
+                                   double* xs, double* ys) {
+  const int b = blockIdx.x;
+  for (int idx = threadIdx.x; idx < (p + 1) * SH_MAXO; idx += blockDim.x) {
+    const int j = idx / SH_MAXO, o = idx - j * SH_MAXO;
+    const int sl = o / lpw, q = o - sl * lpw;
+    const long long i = (long long)b * lpw + q + (long long)NT * sl;
+    const bool valid = sl < nslots && i < n;
+    if (j < p) xs[((long long)b * p + j) * SH_MAXO + o] = valid ? X[(long long)j * n + i] : 0.0;
+    else ys[(long long)b * SH_MAXO + o] = valid ? y[i] : 0.0;
+  }
+}
+
 size_t sweep_lds_bytes(int k, int kf, int kind, int CW, int tb, int kz, bool resident) {
   size_t d = 4 * (size_t)k + (k / 2 + 1) + (size_t)NW * CW + 1 + (size_t)CW * tb * (kz + 1) +
              (resident ? (size_t)CW * NT : 0) + (size_t)CW * chain_lds_doubles(k, kf, kind);
@@ -85,6 +100,8 @@ extern "C" {
 
 int fmcmc_abi_version(void) { return FMCMC_ABI_VERSION; }
 const char* fmcmc_last_error(void) { return g_err; }
+static thread_local const char* g_kernel = "";
+const char* fmcmc_last_kernel(void) { return g_kernel; }
 
 int fmcmc_device_count(void) {
   int n = 0;
@@ -344,6 +361,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
         hipLaunchKernelGGL((mh_sweep_pipe<PV, OV, KV>), dim3((unsigned)pblk), dim3(NT), plds, stream, A); \
     } while (0)
     const char* nospec = getenv("FMCMC_AMD_NO_SPEC");
+    g_kernel = mfma_ng ? "mfma" : (!(nospec && nospec[0] == '1')) ? "spec" : "pipe";
     if (mfma_ng) {
       // Two MFMA kernels with identical results.  mh_sweep_mfma (owner waves) is the product path for every shape;
       // mh_sweep_mfmar (chain state replicated in every wave, one barrier per step) was 2-10 % ahead below n = 8192
@@ -355,6 +373,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
       const char* own0 = getenv("FMCMC_AMD_MFMA_OWNERS");
       const bool owners = !(own0 && own0[0] == '0' && kv == 1 && mfma_ng == 1 && ns > 16);
       const size_t mlds = owners ? mfma_lds_bytes() : mfmar_lds_bytes();
+      if (!owners) g_kernel = "mfma-replicated";
       const bool dbgk = (A.debug & 8) != 0 && mfma_ng == 1 && ns == 20;
 #define MF_CASE(KN, KV, GV, SV) case SV: hipLaunchKernelGGL((KN<KV, GV, SV, false>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A); break;
 #define MF_CASES10(KN, KV, GV) MF_CASE(KN, KV, GV, 1) MF_CASE(KN, KV, GV, 2) MF_CASE(KN, KV, GV, 3) MF_CASE(KN, KV, GV, 4) MF_CASE(KN, KV, GV, 5) \
@@ -417,12 +436,13 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
 #undef LAUNCH_PIPE
     if (ws) (void)hipFreeAsync(ws, stream);
   } else
-  if (resident && res_p == 1) { LAUNCH_KIND(4, 1, 4); }
-  else if (resident && res_p == 3) { LAUNCH_KIND(4, 3, 20); }
+  if (resident && res_p == 1) { g_kernel = "resident"; LAUNCH_KIND(4, 1, 4); }
+  else if (resident && res_p == 3) { g_kernel = "resident"; LAUNCH_KIND(4, 3, 20); }
   else if (m->family == FMCMC_FAM_LOGISTIC && cw <= 4 && m->p <= 28 / cw - 1 &&
            (kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE)) {
     // logistic-only instantiations: the number of covariates is a compile-time constant of the evaluation loop and the
     // coefficients of the CW chains live in SGPRs (mh_common.hpp); with the division-free softplus 2x the general kernel
+    g_kernel = "streamed-logistic";
 #define LAUNCH_LOGIT(CWV, KV)                                                                                          \
     do {                                                                                                               \
       if (lds > 48 * 1024)                                                                                             \
@@ -453,16 +473,62 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
         hipLaunchKernelGGL((mh_sweep_kernel<CWV, -1, 0, KV, FMCMC_FAM_GAUSSIAN_LINREG>), dim3((unsigned)nblk), dim3(NT), lds, stream, A); \
     } while (0)
     const int kv = kn->kind;   // 1, 2 or 4
+    // Observation-sharded evaluation (mh_common.hpp, eval_sharded): the workgroups must split the 512 canonical lanes
+    // evenly (128 or 256 workgroups), be co-resident (cooperative launch) and hold their slice in SH_MAXO registers.
+    const char* shenv = getenv("FMCMC_AMD_SHARD");
+    const int nslots = (int)((m->n + NT - 1) / NT);
+    const int lpw = (nblk == 128 || nblk == 256) ? (int)(NT / nblk) : 0;
+    bool shard = !(shenv && shenv[0] == '0') && lpw > 0 && !(kv == FMCMC_KERNEL_RAM && ram_bounded) && lpw * nslots <= SH_MAXO && nblk <= ncu &&
+                 (size_t)m->p * SH_MAXO * sizeof(double) <= 15872 &&   /* the slice has to stay in the scalar cache */
+                 (long long)m->p * SH_MAXO * nblk < (1ll << 28) && (long long)(m->p + 1) * (run->nchains + SH_PAD) < (1ll << 31) &&
+                 (long long)(NT + SH_PAD) * run->nchains < (1ll << 31);
+    // the sharded evaluation is its own instantiation (OPT = lanes per workgroup): sharing one with the streamed loop
+    // cost 200-300 spilled registers in BOTH paths
+    const void* kfn = nullptr;
+#define SHK(CWV, LV) ((kv == 1) ? (const void*)mh_sweep_kernel<CWV, -1, LV, 1, FMCMC_FAM_GAUSSIAN_LINREG>   \
+                    : (kv == 2) ? (const void*)mh_sweep_kernel<CWV, -1, LV, 2, FMCMC_FAM_GAUSSIAN_LINREG> \
+                                : (const void*)mh_sweep_kernel<CWV, -1, LV, 4, FMCMC_FAM_GAUSSIAN_LINREG>)
+    if (shard) kfn = (cw == 1) ? (lpw == 2 ? SHK(1, 2) : SHK(1, 4)) : (lpw == 2 ? SHK(2, 2) : SHK(2, 4));
+#undef SHK
+    if (A.debug & 256) fprintf(stderr, "fmcmc_amd: wide path nblk=%lld lpw=%d nslots=%d p=%d bounded=%d shard=%d\n", nblk, lpw, nslots, m->p, (int)ram_bounded, (int)shard);
+    double* shw = nullptr;
+    g_kernel = shard ? "streamed-wide-sharded" : "streamed-wide";
+    if (shard) {
+      int coop = 0, perCU = 0;
+      (void)hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev);
+      if (lds > 48 * 1024) e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess || !coop ||
+          hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kfn, NT, lds) != hipSuccess || (long long)perCU * ncu < nblk) {
+        if (A.debug & 256) fprintf(stderr, "fmcmc_amd: sharded evaluation not launched: err=%d coop=%d perCU=%d lds=%zu\n", (int)e, coop, perCU, lds);
+        shard = false;
+        g_kernel = "streamed-wide";
+      }
+      e = hipSuccess;
+    }
+    if (shard) {
+      const size_t nxs = (size_t)nblk * m->p * SH_MAXO, nys = (size_t)nblk * SH_MAXO, nth = (size_t)kn->k * (run->nchains + SH_PAD),
+                   npt = (size_t)(NT + SH_PAD) * run->nchains, nbar = 32 * 20 / 2;   // (barrier words counted in doubles)
+      e = hipMallocAsync((void**)&shw, sizeof(double) * (nxs + nys + nth + npt + nbar), stream);
+      if (e != hipSuccess) { set_err("hipMallocAsync(sharded evaluation) failed: %s", hipGetErrorString(e)); return FMCMC_ERR_DEVICE; }
+      double* xs = shw; double* ys = xs + nxs; double* thw = ys + nys; double* ptw = thw + nth;
+      unsigned* bar = (unsigned*)(ptw + npt);
+      (void)hipMemsetAsync(bar, 0, sizeof(double) * nbar, stream);
+      hipLaunchKernelGGL(shard_build_slices, dim3((unsigned)nblk), dim3(256), 0, stream, m->X, m->y, (long long)m->n, m->p, lpw, nslots, xs, ys);
+      A.shard = lpw; A.sh_nslots = nslots; A.sh_xs = xs; A.sh_ys = ys; A.sh_th = thw; A.sh_part = ptw; A.sh_bar = bar;
+      void* kargs[] = {(void*)&A};
+      e = hipLaunchCooperativeKernel(kfn, dim3((unsigned)nblk), dim3(NT), kargs, (unsigned int)lds, stream);
+      (void)hipFreeAsync(shw, stream);
+    } else
     if (cw == 1) { if (kv == 1) LAUNCH_WIDE(1, 1); else if (kv == 2) LAUNCH_WIDE(1, 2); else LAUNCH_WIDE(1, 4); }
     else { if (kv == 1) LAUNCH_WIDE(2, 1); else if (kv == 2) LAUNCH_WIDE(2, 2); else LAUNCH_WIDE(2, 4); }
 #undef LAUNCH_WIDE
   }
-  else switch (cw) {
+  else { g_kernel = "streamed"; switch (cw) {
     case 1: LAUNCH(1, -1, 0, 0); break;
     case 2: LAUNCH(2, -1, 0, 0); break;
     case 4: LAUNCH(4, -1, 0, 0); break;
     default: LAUNCH(8, -1, 0, 0); break;
-  }
+  } }
 #undef LAUNCH_KIND
 #undef LAUNCH
   if (A.hist) (void)hipFreeAsync(A.hist, stream);

@@ -93,6 +93,7 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
     }
   }
 
+  unsigned sh_epoch = 0;   // grid-barrier epoch of the observation-sharded evaluation (uniform over the grid)
   // collective evaluation of f(theta1) for all chains of the workgroup; on return s_part holds
   // what finish needs (streamed: 8 wave partials per chain; resident: 2 half totals per chain)
   auto evaluate = [&]() {
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
         if (lane == 0) s_part[h * CW + c] = v;
       }
     } else {
-      eval_partials<CW, FAM>(A, thp, s_part, s_sptab);
+      eval_partials<CW, FAM, (P < 0 ? OPT : 0)>(A, thp, s_part, s_sptab, &sh_epoch);
     }
   };
   auto total_of = [&](int c) -> double {

@@ -164,7 +164,8 @@ enum {
   FMCMC_CHAIN_NOT_PD = 3,      /* proposal covariance not positive definite (MASS::mvrnorm error) */
   /* kernel_adapt with bw > 0 or freq > 1: the rows ans[(i-bw+1):(i-1), ] / ans[(i-freq):(i-1), ] reach before the first row
    * of this call (R: "subscript out of bounds" / mixed subscripts, R/kernel_adapt.R:119-125,139-156) */
-  FMCMC_CHAIN_BAD_WINDOW = 4
+  FMCMC_CHAIN_BAD_WINDOW = 4,
+  FMCMC_CHAIN_SYNC_TIMEOUT = 5 /* engine-internal: a grid-wide hand-over of the observation-sharded evaluation timed out */
 };
 
 typedef struct fmcmc_out {
@@ -189,6 +190,9 @@ enum {
 
 int fmcmc_abi_version(void);
 const char* fmcmc_last_error(void);
+/* Diagnostic: which kernel variant the calling thread's last fmcmc_mcmc_run_* chose ("mfma", "spec", "resident",
+ * "streamed", "streamed-logistic", "streamed-wide", "streamed-wide-sharded", ...).  Results never depend on it. */
+const char* fmcmc_last_kernel(void);
 int fmcmc_device_count(void);
 int64_t fmcmc_kept_rows(int64_t nsteps, int64_t burnin, int64_t thin);
 

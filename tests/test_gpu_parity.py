@@ -559,3 +559,57 @@ def test_logistic_on_the_general_kernel(E, O, kind_name):
         run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_RAM, 4, init, nsteps=120, calls=2, prior_div=8.0)
     else:
         run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_NORMAL, 4, init, nsteps=150, prior_div=8.0, scale=0.1, scheme="ordered")
+
+
+@pytest.mark.parametrize("chains,cw,n,p,intercept", [
+    (256, "1", 10000, 16, True),      # 256 workgroups x 2 canonical lanes, 20 slots: the full slice of 40 observations
+    (128, "1", 4099, 21, True),       # 128 workgroups x 4 lanes, ragged last slot
+    (512, "2", 1023, 33, True),       # two chains per workgroup, n < 2 x 512
+    (255, "2", 2500, 49, False),      # last workgroup holds one chain; widest slice (49 columns); no intercept
+])
+def test_observation_sharded_evaluation(E, O, monkeypatch, chains, cw, n, p, intercept):
+    """Wide linear models whose workgroups split the 512 canonical lanes evenly evaluate observation-sharded
+    (eval_sharded, cooperative launch, two grid barriers per step): the oracle's bits for the normal, reflective and RAM
+    kernels, continued over two calls, and the same bits as the chain-sharded kernel (FMCMC_AMD_SHARD=0)."""
+    from fmcmc_amd import _abi as abi
+    monkeypatch.setenv("FMCMC_AMD_CW", cw)
+    nb = p + (1 if intercept else 0)
+    X, y = synth_linreg(n, p, 9100 + n + p, beta=np.linspace(1.0, -1.0, p + 1))
+    init = jitter_init(list(np.linspace(1.0, -1.0, p + 1))[(0 if intercept else 1):] + [4.0], chains, n + p)
+    init[:, -1] = np.abs(init[:, -1])
+    kw = dict(intercept=intercept)
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, nb + 1, init, nsteps=24, burnin=2, thin=2, calls=2, scale=0.01, **kw)
+    assert abi.last_kernel() == "streamed-wide-sharded"
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL_REFLECTIVE, nb + 1, init, nsteps=16, scale=0.2, lb=-3.0, ub=6.0, **kw)
+    assert abi.last_kernel() == "streamed-wide-sharded"
+    a, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, nb + 1, init, nsteps=24, calls=2, **kw)
+    assert abi.last_kernel() == "streamed-wide-sharded"
+    monkeypatch.setenv("FMCMC_AMD_SHARD", "0")
+    b, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, nb + 1, init, nsteps=24, calls=2, **kw)
+    assert abi.last_kernel() == "streamed-wide"
+    assert _bits_equal(a.samples.cpu().numpy(), b.samples.cpu().numpy())
+
+
+def test_observation_sharded_long_run_equals_chain_sharded(E, monkeypatch):
+    """Config C4's shape (512 chains, n = 10,000, k = 50, kernel_ram), 400 steps: 800 grid barriers without a stale read --
+    the sharded and the chain-sharded kernels return identical bits for every output."""
+    import torch
+    from fmcmc_amd import _abi as abi
+    n, p, chains = 10000, 48, 512
+    X, y = synth_linreg(n, p, 515, beta=np.linspace(1.0, -1.0, p + 1))
+    init = jitter_init(list(np.linspace(1.0, -1.0, p + 1)) + [4.0], chains, 99)
+    init[:, -1] = np.abs(init[:, -1])
+    k = p + 2
+    gm = E.DeviceModel(abi.FAM_GAUSSIAN_LINREG, X, y)
+    outs = []
+    for sh in ("1", "0"):
+        monkeypatch.setenv("FMCMC_AMD_SHARD", sh)
+        gk = E.KernelSpec(abi.KERNEL_RAM, k, np.zeros(k), np.ones(k), np.full(k, -E.DBL_MAX), np.full(k, E.DBL_MAX),
+                          np.zeros(k, np.uint8))
+        st = E.ChainState(init, k)
+        r = E.sweep(gm, gk, st, 400, seed=77, check=True)
+        torch.cuda.synchronize()
+        assert abi.last_kernel() == ("streamed-wide-sharded" if sh == "1" else "streamed-wide")
+        outs.append([t.cpu().numpy() for t in (r.samples, r.logpost, r.draws, r.accept_count, st.Sigma, st.theta0)])
+    for u, v in zip(*outs):
+        assert _bits_equal(u, v) if u.dtype == np.float64 else np.array_equal(u, v)
