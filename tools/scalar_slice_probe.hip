@@ -4,6 +4,7 @@
 // x 40 observations, thread = chain.  Reports the time per "step".
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 constexpr int NOBS = 40, NCOL = 49;
 __global__ __launch_bounds__(512) void k(const double* __restrict__ Xs, const double* __restrict__ TH, double* out, int steps, int nchains) {
   const double* xs = Xs + (long long)blockIdx.x * NOBS * NCOL;      // this workgroup's slice, [col][obs]
@@ -31,7 +32,16 @@ int main() {
   const int G = 256, C = 512, steps = 200;
   double *Xs, *TH, *out;
   hipMalloc(&Xs, (size_t)G * NOBS * NCOL * 8); hipMalloc(&TH, (size_t)2 * NCOL * C * 8); hipMalloc(&out, (size_t)G * 512 * 8);
-  hipMemset(Xs, 0, (size_t)G * NOBS * NCOL * 8); hipMemset(TH, 0, (size_t)2 * NCOL * C * 8);
+  {  // real-looking operands (all-zero data ran the same loop at the same speed: no data-dependent clock effect)
+    size_t nx = (size_t)G * NOBS * NCOL, nt = (size_t)2 * NCOL * C;
+    double* h = (double*)malloc((nx > nt ? nx : nt) * 8);
+    unsigned long long r = 88172645463325252ull;
+    for (size_t i = 0; i < nx; i++) { r ^= r << 13; r ^= r >> 7; r ^= r << 17; h[i] = (double)(r >> 11) * (1.0 / 9007199254740992.0) - 0.5; }
+    hipMemcpy(Xs, h, nx * 8, hipMemcpyHostToDevice);
+    for (size_t i = 0; i < nt; i++) { r ^= r << 13; r ^= r >> 7; r ^= r << 17; h[i] = (double)(r >> 11) * (1.0 / 9007199254740992.0) - 0.5; }
+    hipMemcpy(TH, h, nt * 8, hipMemcpyHostToDevice);
+    free(h);
+  }
   for (int blocks : {8, 64, 256}) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 2; rep++) {
