@@ -378,27 +378,39 @@ __device__ __forceinline__ bool shard_barrier(unsigned* bar, unsigned epoch) {
   return ok;
 }
 
-// lane partials acc[c] of canonical lane `tid` for the CW chains of this workgroup, via the sharded evaluation
-template <int CW, int LPW>
-__device__ __forceinline__ bool eval_sharded(const SweepArgs& A, double* const* th, double (&acc)[CW], unsigned& epoch) {
+// Step 2 of the sharded evaluation -- thread = chain: the slice's observations for that chain -- is a REAL function, not
+// inlined into the sweep kernel: inlined, its 40 accumulators + the coefficient ring competed with everything the sweep
+// keeps live across an evaluation, the instantiation sat at 256 VGPRs with 18-66 of them spilled, and the column loop
+// ran at half the speed of the same loop alone (tools/scalar_slice_probe.hip).  Arguments arrive in VGPRs (the calling
+// convention knows no uniform arguments), so everything uniform goes through v_readfirstlane first: without that the
+// slice pointer is "divergent" and x comes through 40 vector loads per column instead of five scalar loads.
+struct ShardCols {
+  const double* xs;      // this workgroup's slice [p][SH_MAXO]
+  const double* ys;      // [SH_MAXO]
+  const double* th;      // [k][NC + SH_PAD] proposals of all chains
+  double* part;          // [NC][NT + SH_PAD] lane partials
+  long long n;
+  int NC, p, ic, nslots, lane0, debug;
+};
+__device__ __forceinline__ int rfl_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned long long rfl_u64(unsigned long long v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+template <int LPW>
+__device__ __attribute__((noinline)) void shard_columns(ShardCols c) {
   const int tid = threadIdx.x;
-  const int NC = (int)A.nchains, NCP = NC + SH_PAD, p = A.p, ic = A.intercept, nb = ic + p;
-  const long long cg0 = (long long)blockIdx.x * CW;
-  const int ncw = (int)((A.nchains - cg0 < CW) ? (A.nchains - cg0) : CW);
-  // 1. publish the coefficients of this workgroup's chains, [coefficient][chain]
-  for (int idx = tid; idx < CW * nb; idx += NT) {
-    const int c = idx / nb, j = idx - c * nb;
-    if (c < ncw) sh_store(&A.sh_th[(long long)j * NCP + cg0 + c], th[c][j]);
-  }
-  bool ok = (A.debug & 32) ? true : shard_barrier(A.sh_bar, ++epoch);   // (debug bits 32 / 64 / 128: timing ablations)
-  // 2. thread = chain: the slice's observations for that chain
-  const double* thg = A.sh_th;
+  const int NC = rfl_i(c.NC), NCP = NC + SH_PAD, p = rfl_i(c.p), ic = rfl_i(c.ic), nslots = rfl_i(c.nslots);
+  const int lane0 = rfl_i(c.lane0), debug = rfl_i(c.debug);
+  const long long n = (long long)rfl_u64((unsigned long long)c.n);
   // constant address space + uniform address = SCALAR loads (s_load_dwordx16: 8 observations per instruction); through
   // the generic pointer they were 48 broadcast vector loads per column and the evaluation took 96 us instead of ~15
   typedef const double __attribute__((address_space(4))) * cptr_t;
-  const cptr_t xs = (cptr_t)(unsigned long long)(A.sh_xs + (long long)blockIdx.x * p * SH_MAXO);
-  const cptr_t ys = (cptr_t)(unsigned long long)(A.sh_ys + (long long)blockIdx.x * SH_MAXO);
-  const int nslots = A.sh_nslots;
+  const cptr_t xs = (cptr_t)rfl_u64((unsigned long long)c.xs);
+  const cptr_t ys = (cptr_t)rfl_u64((unsigned long long)c.ys);
+  const double* thg = (const double*)rfl_u64((unsigned long long)c.th);
+  double* part = (double*)rfl_u64((unsigned long long)c.part);
   for (int cb = 0; cb < NC; cb += NT) {
     const int chain = cb + tid;
     const unsigned int chc = (unsigned int)(chain < NC ? chain : 0);
@@ -410,10 +422,9 @@ __device__ __forceinline__ bool eval_sharded(const SweepArgs& A, double* const* 
     // an L2 miss of 1-3 us and a block's 320 FMAs cover ~1 us; one block ahead stalled on every block (36 us for the
     // columns instead of 12), all of them at once (6 blocks + tail) spilled 300 registers
     constexpr int JB8 = 8, RING = 3;
-    const int pe = (A.debug & 64) ? 1 : p;
+    const int pe = (debug & 64) ? 1 : p;
     double tb[RING][JB8];
-    // (column index clamped instead of a guard per load: 32 guarded loads compiled to 32 branches, each reloading the
-    // kernel arguments through spilled SGPRs)
+    // (column index clamped instead of a guard per load: 32 guarded loads compiled to 32 branches)
 #define SH_LOAD_BLOCK(q, j0)                                                                                   \
     _Pragma("unroll") for (int u = 0; u < JB8; u++) {                                                          \
       const int jj = ((j0) + u < pe) ? (j0) + u : pe - 1;                                                      \
@@ -428,8 +439,8 @@ __device__ __forceinline__ bool eval_sharded(const SweepArgs& A, double* const* 
         if (j0 < pe) {
 #pragma unroll
           for (int u = 0; u < JB8; u++) {
-            if (j0 + u < pe) {               // uniform
-              const cptr_t xc = xs + (j0 + u) * SH_MAXO;
+            if (j0 + u < pe) {               // uniform (and on purpose: without a guard between the columns the
+              const cptr_t xc = xs + (j0 + u) * SH_MAXO;   // scheduler hoists scalar loads until 700 B per lane spill)
 #pragma unroll
               for (int o = 0; o < SH_MAXO; o++) mu[o] = fmh_fma(xc[o], tb[q][u], mu[o]);
             }
@@ -445,15 +456,37 @@ __device__ __forceinline__ bool eval_sharded(const SweepArgs& A, double* const* 
 #pragma unroll
     for (int o = 0; o < SH_MAXO; o++) {          // o = slot * LPW + lane-in-slice: slot order per lane
       const int sl = o / LPW, q = o % LPW;
-      const bool valid = sl < nslots && ((long long)(blockIdx.x * LPW + q) + (long long)NT * sl) < A.n;   // uniform
+      const bool valid = sl < nslots && ((long long)(lane0 + q) + (long long)NT * sl) < n;   // uniform
       const double r = valid ? ys[o] - mu[o] : 0.0;                      // fma(0, 0, acc) == acc exactly
       al[q] = fmh_fma(r, r, al[q]);
     }
     if (chain < NC) {
 #pragma unroll
-      for (int q = 0; q < LPW; q++) sh_store(&A.sh_part[(long long)chain * (NT + SH_PAD) + blockIdx.x * LPW + q], al[q]);
+      for (int q = 0; q < LPW; q++) sh_store(&part[(long long)chain * (NT + SH_PAD) + lane0 + q], al[q]);
     }
   }
+}
+
+// lane partials acc[c] of canonical lane `tid` for the CW chains of this workgroup, via the sharded evaluation
+template <int CW, int LPW>
+__device__ __forceinline__ bool eval_sharded(const SweepArgs& A, double* const* th, double (&acc)[CW], unsigned& epoch) {
+  const int tid = threadIdx.x;
+  const int NC = (int)A.nchains, NCP = NC + SH_PAD, p = A.p, ic = A.intercept, nb = ic + p;
+  const long long cg0 = (long long)blockIdx.x * CW;
+  const int ncw = (int)((A.nchains - cg0 < CW) ? (A.nchains - cg0) : CW);
+  // 1. publish the coefficients of this workgroup's chains, [coefficient][chain]
+  for (int idx = tid; idx < CW * nb; idx += NT) {
+    const int c = idx / nb, j = idx - c * nb;
+    if (c < ncw) sh_store(&A.sh_th[(long long)j * NCP + cg0 + c], th[c][j]);
+  }
+  bool ok = (A.debug & 32) ? true : shard_barrier(A.sh_bar, ++epoch);   // (debug bits 32 / 64 / 128: timing ablations)
+  // 2. thread = chain: the slice's observations for that chain
+  ShardCols sc;
+  sc.xs = A.sh_xs + (long long)blockIdx.x * p * SH_MAXO;
+  sc.ys = A.sh_ys + (long long)blockIdx.x * SH_MAXO;
+  sc.th = A.sh_th; sc.part = A.sh_part; sc.n = A.n; sc.NC = NC; sc.p = p; sc.ic = ic; sc.nslots = A.sh_nslots;
+  sc.lane0 = (int)blockIdx.x * LPW; sc.debug = A.debug;
+  shard_columns<LPW>(sc);
   if (!(A.debug & 32)) ok = shard_barrier(A.sh_bar, ++epoch) && ok;
   // 3. thread = canonical lane: its partial of this workgroup's chains
 #pragma unroll
