@@ -373,7 +373,7 @@ __device__ __forceinline__ bool shard_barrier(unsigned* bar, unsigned epoch) {
       if (++spins > 20000000u) { ok = false; break; }
     }
   }
-  __syncthreads();
+  ok = !__syncthreads_or(ok ? 0 : 1);      // the verdict of thread 0, for every thread of the workgroup
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   return ok;
 }
@@ -479,7 +479,11 @@ __device__ __forceinline__ bool eval_sharded(const SweepArgs& A, double* const* 
     const int c = idx / nb, j = idx - c * nb;
     if (c < ncw) sh_store(&A.sh_th[(long long)j * NCP + cg0 + c], th[c][j]);
   }
-  bool ok = (A.debug & 32) ? true : shard_barrier(A.sh_bar, ++epoch);   // (debug bits 32 / 64 / 128: timing ablations)
+  // (debug bits 32 / 64 / 128: timing ablations.  A hand-over that timed out is not waited for again: bit 31 of the
+  //  epoch marks the sweep as lost, its remaining steps run through without barriers and the host raises.)
+  constexpr unsigned LOST = 0x80000000u;
+  bool ok = true;
+  if (!(A.debug & 32) && !(epoch & LOST)) { ok = shard_barrier(A.sh_bar, ++epoch); if (!ok) epoch |= LOST; }
   // 2. thread = chain: the slice's observations for that chain
   ShardCols sc;
   sc.xs = A.sh_xs + (long long)blockIdx.x * p * SH_MAXO;
@@ -487,7 +491,8 @@ __device__ __forceinline__ bool eval_sharded(const SweepArgs& A, double* const* 
   sc.th = A.sh_th; sc.part = A.sh_part; sc.n = A.n; sc.NC = NC; sc.p = p; sc.ic = ic; sc.nslots = A.sh_nslots;
   sc.lane0 = (int)blockIdx.x * LPW; sc.debug = A.debug;
   shard_columns<LPW>(sc);
-  if (!(A.debug & 32)) ok = shard_barrier(A.sh_bar, ++epoch) && ok;
+  if (!(A.debug & 32) && !(epoch & LOST)) { ok = shard_barrier(A.sh_bar, ++epoch); if (!ok) epoch |= LOST; }
+  ok = !(epoch & LOST);
   // 3. thread = canonical lane: its partial of this workgroup's chains
 #pragma unroll
   for (int c = 0; c < CW; c++)
