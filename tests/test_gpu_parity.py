@@ -571,19 +571,22 @@ def test_observation_sharded_evaluation(E, O, monkeypatch, chains, cw, n, p, int
     """Wide linear models whose workgroups split the 512 canonical lanes evenly evaluate observation-sharded
     (eval_sharded, cooperative launch, two grid barriers per step): the oracle's bits for the normal, reflective and RAM
     kernels, continued over two calls, and the same bits as the chain-sharded kernel (FMCMC_AMD_SHARD=0)."""
+    import torch
     from fmcmc_amd import _abi as abi
     monkeypatch.setenv("FMCMC_AMD_CW", cw)
     nb = p + (1 if intercept else 0)
+    groups = -(-chains // int(cw))       # co-residency needs one CU per workgroup (a partitioned GPU falls back)
+    sharded = "streamed-wide-sharded" if torch.cuda.get_device_properties(0).multi_processor_count >= groups else "streamed-wide"
     X, y = synth_linreg(n, p, 9100 + n + p, beta=np.linspace(1.0, -1.0, p + 1))
     init = jitter_init(list(np.linspace(1.0, -1.0, p + 1))[(0 if intercept else 1):] + [4.0], chains, n + p)
     init[:, -1] = np.abs(init[:, -1])
     kw = dict(intercept=intercept)
     run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, nb + 1, init, nsteps=24, burnin=2, thin=2, calls=2, scale=0.01, **kw)
-    assert abi.last_kernel() == "streamed-wide-sharded"
+    assert abi.last_kernel() == sharded
     run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL_REFLECTIVE, nb + 1, init, nsteps=16, scale=0.2, lb=-3.0, ub=6.0, **kw)
-    assert abi.last_kernel() == "streamed-wide-sharded"
+    assert abi.last_kernel() == sharded
     a, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, nb + 1, init, nsteps=24, calls=2, **kw)
-    assert abi.last_kernel() == "streamed-wide-sharded"
+    assert abi.last_kernel() == sharded
     monkeypatch.setenv("FMCMC_AMD_SHARD", "0")
     b, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, nb + 1, init, nsteps=24, calls=2, **kw)
     assert abi.last_kernel() == "streamed-wide"
@@ -609,7 +612,100 @@ def test_observation_sharded_long_run_equals_chain_sharded(E, monkeypatch):
         st = E.ChainState(init, k)
         r = E.sweep(gm, gk, st, 400, seed=77, check=True)
         torch.cuda.synchronize()
-        assert abi.last_kernel() == ("streamed-wide-sharded" if sh == "1" else "streamed-wide")
+        if torch.cuda.get_device_properties(0).multi_processor_count >= 256:
+            assert abi.last_kernel() == ("streamed-wide-sharded" if sh == "1" else "streamed-wide")
         outs.append([t.cpu().numpy() for t in (r.samples, r.logpost, r.draws, r.accept_count, st.Sigma, st.theta0)])
     for u, v in zip(*outs):
         assert _bits_equal(u, v) if u.dtype == np.float64 else np.array_equal(u, v)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Randomised sweep over the dispatcher: shapes, chain counts and options drawn from a fixed seed, so that combinations
+# nobody wrote a dedicated test for (a kernel variant x a ragged shape x a fixed mask x thinning x a continued call)
+# still have to give the oracle's bits.  Every case is sized so that the scalar oracle needs well under a second.
+# ---------------------------------------------------------------------------------------------------------------------
+def _random_case(seed):
+    rng = np.random.default_rng(900000 + seed)
+    fam = rng.choice(["linreg", "linreg", "linreg", "logistic", "iid"])
+    n = int(rng.choice([1, 7, 511, 512, 513, 1000, 1024, 2049, 5000, 9999, 10240, 10241]))
+    p = int(rng.choice([1, 1, 2, 3, 3, 4, 7, 8, 15, 16, 17, 24, 31]))
+    intercept = bool(rng.integers(0, 2))
+    chains = int(rng.choice([1, 3, 4, 5, 8, 31, 64, 128, 129, 256]))
+    if fam == "iid":
+        p, intercept = 0, True
+    if fam == "logistic":
+        p = min(p, 9)
+    kind = str(rng.choice(["normal", "reflective", "adapt", "ram", "unif", "unif_reflective", "nmirror", "umirror"]))
+    if fam == "linreg":
+        k = p + int(intercept) + 1
+    elif fam == "logistic":
+        k = p + int(intercept)
+    else:
+        k = 2
+    # keep the oracle's work bounded: chains x n x max(p, 1) x steps <= ~1.5e8 multiply-adds
+    nsteps = int(max(6, min(90, 1.5e8 / (chains * n * max(p, 1) * 2))))
+    burnin = int(rng.integers(0, max(1, nsteps // 3)))
+    thin = int(rng.choice([1, 1, 2, 3]))
+    if burnin + thin > nsteps - 1:
+        burnin, thin = 0, 1
+    fixed = np.zeros(k, bool)
+    if k > 2 and rng.random() < 0.35:
+        fixed[rng.choice(k - 1, size=int(rng.integers(1, max(2, (k - 1) // 2))), replace=False)] = True
+    scheme = "joint"
+    if kind in ("normal", "reflective", "unif", "unif_reflective", "nmirror", "umirror") and rng.random() < 0.3:
+        scheme = str(rng.choice(["ordered", "random"]))
+    return dict(fam=fam, n=n, p=p, intercept=intercept, chains=chains, kind=kind, k=k, nsteps=nsteps, burnin=burnin,
+                thin=thin, fixed=fixed, scheme=scheme, calls=int(rng.integers(1, 3)), seed=int(rng.integers(1, 10**6)),
+                chain_base=int(rng.choice([0, 0, 5, 1000])))
+
+
+@pytest.mark.parametrize("case", range(160))
+def test_randomised_dispatch_cases(E, O, case):
+    c = _random_case(case)
+    rng = np.random.default_rng(17 + case)
+    n, p, k = c["n"], c["p"], c["k"]
+    if c["fam"] == "linreg":
+        beta = rng.uniform(-1.5, 1.5, p + 1)
+        X = rng.standard_normal((n, p))
+        y = (beta[0] if c["intercept"] else 0.0) + X @ beta[1:] + 2.0 * rng.standard_normal(n)
+        base = list(beta[(0 if c["intercept"] else 1):]) + [2.0]
+        fam, kw = O.FAM_LINREG, dict(intercept=c["intercept"])
+        lb = [-40.0] * (k - 1) + [0.05]
+    elif c["fam"] == "logistic":
+        beta = rng.uniform(-1.0, 1.0, p + 1)
+        X = rng.standard_normal((n, p))
+        eta = (beta[0] if c["intercept"] else 0.0) + X @ beta[1:]
+        y = (rng.uniform(size=n) < 1 / (1 + np.exp(-eta))).astype(np.float64)
+        base = list(beta[(0 if c["intercept"] else 1):])
+        fam, kw = O.FAM_LOGISTIC, dict(intercept=c["intercept"], prior_div=8.0)
+        lb = [-6.0] * k
+    else:
+        X, y = None, 1.5 + 2.0 * rng.standard_normal(n)
+        base = [1.0, 2.0]
+        fam, kw = O.FAM_IID_NORMAL, {}
+        lb = [-40.0, 0.05]
+    init = jitter_init(base, c["chains"], 3 + case)
+    if c["fam"] != "logistic":
+        init[:, -1] = np.abs(init[:, -1]) + 0.1
+    kind = {"normal": O.K_NORMAL, "reflective": O.K_NORMAL_REFLECTIVE, "adapt": O.K_ADAPT, "ram": O.K_RAM,
+            "unif": O.K_UNIF, "unif_reflective": O.K_UNIF_REFLECTIVE, "nmirror": O.K_NMIRROR,
+            "umirror": O.K_UMIRROR}[c["kind"]]
+    opts = dict(fixed=c["fixed"], scheme=c["scheme"])
+    if c["kind"] in ("normal", "reflective"):
+        opts["scale"] = 0.03
+    if c["kind"] in ("unif", "unif_reflective"):
+        opts.update(min_=-0.04, max_=0.05)
+    if c["kind"] in ("reflective", "unif_reflective") or (c["kind"] in ("adapt", "ram") and case % 2):
+        opts.update(lb=lb, ub=40.0)
+    if c["kind"] == "adapt":
+        opts["warmup"] = 5
+        if case % 3 == 0:
+            opts["freq"] = 2
+        if case % 5 == 0:
+            opts["until"] = c["nsteps"] // 2
+    if c["kind"] == "ram" and case % 3 == 0:
+        opts.update(warmup=3, freq=2)
+    if c["kind"] in ("nmirror", "umirror"):
+        opts.update(mu=base, scale=0.1, warmup=c["nsteps"] // 2, nadapt=4, lb=lb, ub=40.0)
+    run_both(E, O, fam, X, y, kind, k, init, nsteps=c["nsteps"], burnin=c["burnin"], thin=c["thin"], seed=c["seed"],
+             chain_base=c["chain_base"], calls=c["calls"], **kw, **opts)
