@@ -709,3 +709,42 @@ def test_randomised_dispatch_cases(E, O, case):
         opts.update(mu=base, scale=0.1, warmup=c["nsteps"] // 2, nadapt=4, lb=lb, ub=40.0)
     run_both(E, O, fam, X, y, kind, k, init, nsteps=c["nsteps"], burnin=c["burnin"], thin=c["thin"], seed=c["seed"],
              chain_base=c["chain_base"], calls=c["calls"], **kw, **opts)
+
+
+def test_randomised_sharded_shapes(E, O):
+    """Random wide models around the eligibility limits of the observation-sharded evaluation (128 / 256 workgroups, slices
+    of <= 40 observations and <= 49 columns): whichever kernel the dispatcher picks, the oracle's bits; most of them
+    must actually have run sharded."""
+    import torch
+    from fmcmc_amd import _abi as abi
+    picked = []
+    for case in range(18):
+        rng = np.random.default_rng(4200 + case)
+        chains = int(rng.choice([128, 255, 256, 257, 511, 512]))
+        p = int(rng.integers(16, 50))
+        lanes = 2 if chains > 256 or chains in (255, 256) else 4       # (257 chains: 2 per workgroup -> 129 workgroups, not sharded)
+        nmax = 512 * (40 // lanes)
+        n = int(rng.choice([nmax, nmax - 1, nmax + 1, nmax // 2 + 3, 777, 512, 513]))
+        intercept = bool(rng.integers(0, 2))
+        k = p + int(intercept) + 1
+        kind = [O.K_NORMAL, O.K_NORMAL_REFLECTIVE, O.K_RAM][case % 3]
+        nsteps = int(max(5, min(40, 2.0e8 / (chains * n * p * 2))))
+        beta = rng.uniform(-1.0, 1.0, p + 1)
+        X = rng.standard_normal((n, p))
+        y = (beta[0] if intercept else 0.0) + X @ beta[1:] + 2.0 * rng.standard_normal(n)
+        init = jitter_init(list(beta[(0 if intercept else 1):]) + [2.0], chains, case)
+        init[:, -1] = np.abs(init[:, -1]) + 0.1
+        fixed = np.zeros(k, bool)
+        if case % 4 == 1:
+            fixed[rng.choice(k - 1, size=3, replace=False)] = True
+        opts = dict(fixed=fixed, intercept=intercept)
+        if kind == O.K_NORMAL:
+            opts["scale"] = 0.01
+        if kind == O.K_NORMAL_REFLECTIVE:
+            opts.update(scale=0.05, lb=[-3.0] * (k - 1) + [0.05], ub=6.0)
+        run_both(E, O, O.FAM_LINREG, X, y, kind, k, init, nsteps=nsteps, burnin=case % 3, thin=1 + case % 2, seed=100 + case,
+                 chain_base=17 * case, calls=1 + case % 2, **opts)
+        picked.append(abi.last_kernel())
+    assert all(name.startswith("streamed-wide") for name in picked), picked
+    if torch.cuda.get_device_properties(0).multi_processor_count >= 256:
+        assert sum(name == "streamed-wide-sharded" for name in picked) >= 9, picked
