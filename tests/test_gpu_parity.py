@@ -748,3 +748,31 @@ def test_randomised_sharded_shapes(E, O):
     assert all(name.startswith("streamed-wide") for name in picked), picked
     if torch.cuda.get_device_properties(0).multi_processor_count >= 256:
         assert sum(name == "streamed-wide-sharded" for name in picked) >= 9, picked
+
+
+def test_sharded_evaluation_with_failing_chains(E, O):
+    """Chains that raise "fun(par) is undefined" (sigma < 0 without the guard) inside an observation-sharded sweep: they
+    stop, their workgroups keep taking part in every grid-wide hand-over, the other chains are unaffected (oracle's bits,
+    status, step and theta of the failure), for kernel_normal and kernel_ram."""
+    import torch
+    from fmcmc_amd import _abi as abi
+    n, p, chains = 3000, 20, 256
+    rng = np.random.default_rng(77)
+    beta = rng.uniform(-1.0, 1.0, p + 1)
+    X = rng.standard_normal((n, p))
+    y = beta[0] + X @ beta[1:] + 2.0 * rng.standard_normal(n)
+    init = jitter_init(list(beta) + [2.0], chains, 5)
+    init[:, -1] = np.abs(init[:, -1]) + 0.1
+    init[::7, -1] = 0.004                       # every 7th chain: sigma steps below zero within a few proposals
+    scale = np.full(p + 2, 0.001); scale[-1] = 0.05
+    rg, ro = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, p + 2, init, nsteps=40, guard=False, scale=scale)
+    if torch.cuda.get_device_properties(0).multi_processor_count >= 256:
+        assert abi.last_kernel() == "streamed-wide-sharded"
+    assert (ro.status == 1).sum() >= 10 and (ro.status == 0).sum() >= 200
+    assert np.array_equal(rg.status_step.cpu().numpy(), ro.status_step)
+    with pytest.raises(RuntimeError, match="undefined"):
+        E.raise_on_chain_error(rg)
+    init[::7, -1] = 2e-5
+    rg, ro = run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, p + 2, init, nsteps=30, guard=False)
+    assert (ro.status != 0).any() and (ro.status == 0).any()
+    assert np.array_equal(rg.status_step.cpu().numpy(), ro.status_step)
