@@ -776,3 +776,111 @@ def test_sharded_evaluation_with_failing_chains(E, O):
     rg, ro = run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, p + 2, init, nsteps=30, guard=False)
     assert (ro.status != 0).any() and (ro.status == 0).any()
     assert np.array_equal(rg.status_step.cpu().numpy(), ro.status_step)
+
+
+def test_full_size_headline_properties(E, monkeypatch):
+    """BASELINE configs[1] at its full size (1024 chains x 10,000 iterations, n = 10,000, k = 5; the oracle would need
+    minutes), through properties that do not depend on the size: (a) two shards of 512 chains with their chain_base give
+    the bits of the single launch; (b) every row is the proposal if its accept bit is set and the previous row otherwise
+    (R/mcmc.R:770-778), row 1 is the initial state; (c) accept_count is the population count of the accept bits;
+    (d) the headline (MFMA) kernel and the wave-specialised VALU kernel agree bit for bit on all outputs."""
+    import torch
+    from fmcmc_amd import _abi as abi
+    import bench
+    chains, iters, k = 1024, 10000, 5
+    X, y, init = bench.make_workload(chains, 0)
+    gm = E.DeviceModel(abi.FAM_GAUSSIAN_LINREG, X, y)
+    gk = E.KernelSpec(abi.KERNEL_NORMAL, k, np.zeros(k), np.full(k, bench.SCALE), np.full(k, -E.DBL_MAX),
+                      np.full(k, E.DBL_MAX), np.zeros(k, np.uint8))
+
+    def launch(lo, hi):
+        st = E.ChainState(init[lo:hi], k)
+        r = E.sweep(gm, gk, st, iters, seed=bench.CHAIN_SEED, chain_base=lo, check=True)
+        torch.cuda.synchronize()
+        return r, st
+
+    full, st_full = launch(0, chains)
+    assert abi.last_kernel() == "mfma"
+    # (a) sharding
+    for lo, hi in ((0, 512), (512, 1024)):
+        part, st_part = launch(lo, hi)
+        for name in ("samples", "logpost", "draws", "accept_count", "accept_bits"):
+            assert torch.equal(getattr(part, name), getattr(full, name)[lo:hi]), name
+        assert torch.equal(st_part.theta0, st_full.theta0[lo:hi])
+        del part
+    # (b) structure of the chain
+    bits = full.accept_bits.view(torch.int32)                                  # [C][ceil(nsteps / 32)], bit r <-> row r
+    r_idx = torch.arange(iters, device=bits.device)
+    acc = ((bits[:, (r_idx >> 5)] >> (r_idx & 31)) & 1).bool()                 # [C][iters]
+    assert not bool(acc[:, 0].any())
+    s64, d64 = full.samples.view(torch.int64), full.draws.view(torch.int64)   # [C][k][S], compared as bit patterns
+    assert torch.equal(s64[:, :, 0], torch.as_tensor(init, device=bits.device).view(torch.int64))
+    expect = torch.where(acc[:, None, 1:], d64[:, :, 1:], s64[:, :, :-1])
+    assert torch.equal(s64[:, :, 1:], expect)
+    # (c) counts
+    assert torch.equal(acc.sum(dim=1), full.accept_count.to(acc.sum(dim=1).dtype))
+    rate = float(full.accept_count.double().mean().item()) / (iters - 1)
+    assert 0.45 < rate < 0.65                                                  # the config's frozen scale: ~0.56
+    # (d) a second implementation of the same sweep
+    monkeypatch.setenv("FMCMC_AMD_MFMA", "0")
+    other, _ = launch(0, chains)
+    assert abi.last_kernel() == "spec"
+    for name in ("samples", "logpost", "draws", "accept_count", "accept_bits"):
+        assert torch.equal(getattr(other, name), getattr(full, name)), name
+
+
+def test_full_size_logistic_and_wide_properties(E, monkeypatch):
+    """BASELINE configs C5 (1024 chains per GPU, logistic n = 100,000, k = 6, kernel_normal_reflective, thin 10) and C4
+    (512 chains per GPU, n = 10,000, k = 50, kernel_ram) at their per-GPU sizes, through size-independent properties:
+    shards with their chain_base give the bits of the single launch, a thinned run is every thin-th row of the unthinned
+    one, every sample respects the reflective bounds."""
+    import torch
+    from fmcmc_amd import _abi as abi
+    big = E.DBL_MAX
+    # ---- C5
+    rng = np.random.default_rng(20260105)
+    n5, C5, k5, steps5 = 100000, 1024, 6, 600
+    X5 = rng.standard_normal((n5, 5)); b5 = np.array([-1, .5, -.5, .25, -.25, 1.0])
+    y5 = (rng.uniform(size=n5) < 1 / (1 + np.exp(-(b5[0] + X5 @ b5[1:])))).astype(np.float64)
+    init5 = b5[None, :] + 0.01 * rng.standard_normal((C5, k5))
+    gm = E.DeviceModel(abi.FAM_LOGISTIC, X5, y5, intercept=True, guard=False, prior_div=8.0)
+    o = np.ones(k5)
+    gk = E.KernelSpec(abi.KERNEL_NORMAL_REFLECTIVE, k5, 0 * o, 0.01 * o, -5 * o, 5 * o, np.zeros(k5, np.uint8))
+
+    def run5(lo, hi, thin, nsteps=steps5, state=None):
+        st = state if state is not None else E.ChainState(init5[lo:hi], k5)
+        r = E.sweep(gm, gk, st, nsteps, thin=thin, seed=1215, chain_base=lo, check=True)
+        torch.cuda.synchronize()
+        return r, st
+
+    full, _ = run5(0, C5, 10)
+    assert abi.last_kernel() == "streamed-logistic"
+    assert full.samples.shape[-1] == steps5 // 10
+    assert bool((full.samples.abs() <= 5.0).all())
+    part, _ = run5(256, 768, 10)
+    assert torch.equal(part.samples, full.samples[256:768]) and torch.equal(part.logpost, full.logpost[256:768])
+    dense, _ = run5(0, 256, 1)
+    assert torch.equal(dense.samples[:, :, 9::10], full.samples[:256])        # kept rows: 10, 20, ... (R/mcmc.R:786-813)
+    assert torch.equal(dense.logpost[:, 9::10], full.logpost[:256])
+    # ---- C4
+    rng = np.random.default_rng(20260104)
+    n4, C4, k4, steps4 = 10000, 512, 50, 240
+    X4 = rng.standard_normal((n4, k4 - 2)); b4 = rng.standard_normal(k4 - 1)
+    y4 = b4[0] + X4 @ b4[1:] + 2 * rng.standard_normal(n4)
+    init4 = np.concatenate([b4, [2.0]])[None, :] + 0.01 * rng.standard_normal((C4, k4)); init4[:, -1] = np.abs(init4[:, -1])
+    gm4 = E.DeviceModel(abi.FAM_GAUSSIAN_LINREG, X4, y4)
+    o = np.ones(k4)
+    gk4 = E.KernelSpec(abi.KERNEL_RAM, k4, 0 * o, o, -big * o, big * o, np.zeros(k4, np.uint8))
+    st1 = E.ChainState(init4, k4)
+    one = E.sweep(gm4, gk4, st1, steps4, seed=7, check=True)
+    torch.cuda.synchronize()
+    # (a continued kernel_ram sweep is NOT the single sweep: eta = k i^(-2/3) uses the loop index of the call, as
+    #  R/kernel_ram.R does with env$i -- so C4's size-independent property is sharding: 256 of the chains on their own,
+    #  which is also a different instantiation, one chain per workgroup instead of two)
+    for lo, hi in ((0, 256), (256, 512)):
+        st2 = E.ChainState(init4[lo:hi], k4)
+        part = E.sweep(gm4, gk4, st2, steps4, seed=7, chain_base=lo, check=True)
+        torch.cuda.synchronize()
+        assert torch.equal(part.samples, one.samples[lo:hi]) and torch.equal(part.logpost, one.logpost[lo:hi])
+        assert torch.equal(part.accept_count, one.accept_count[lo:hi])
+        assert torch.equal(st2.Sigma, st1.Sigma[lo:hi]) and torch.equal(st2.abs_iter, st1.abs_iter[lo:hi])
