@@ -2,6 +2,7 @@
 PHILOX/canonical mode on the same seeded inputs: samples, proposals, log-posteriors, accept
 bitmap and the persistent kernel state.  All tests here need a real MI355X."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -659,7 +660,7 @@ def _random_case(seed):
                 chain_base=int(rng.choice([0, 0, 5, 1000])))
 
 
-@pytest.mark.parametrize("case", range(160))
+@pytest.mark.parametrize("case", range(int(os.environ.get("FMCMC_TEST_RANDOM_CASES", "160"))))   # soak: 3000 passed
 def test_randomised_dispatch_cases(E, O, case):
     c = _random_case(case)
     rng = np.random.default_rng(17 + case)
