@@ -885,3 +885,79 @@ def test_full_size_logistic_and_wide_properties(E, monkeypatch):
         assert torch.equal(part.samples, one.samples[lo:hi]) and torch.equal(part.logpost, one.logpost[lo:hi])
         assert torch.equal(part.accept_count, one.accept_count[lo:hi])
         assert torch.equal(st2.Sigma, st1.Sigma[lo:hi]) and torch.equal(st2.abs_iter, st1.abs_iter[lo:hi])
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("FMCMC_TEST_RANDOM_CASES2", "80"))))   # soak: 2000 passed
+def test_randomised_option_cases(E, O, case):
+    """Second randomised sweep, over the options the first one leaves at their defaults: unguarded log-posteriors,
+    flat / Gaussian priors, non-zero proposal means, explicit update sequences, kernel_ram's constr mask and target rate,
+    kernel_adapt's window / stride / until / eps / Sd, wide models up to k = 64, two or three consecutive calls."""
+    rng = np.random.default_rng(5150000 + case)
+    fam = str(rng.choice(["linreg", "linreg", "logistic"]))
+    n = int(rng.choice([3, 64, 500, 777, 1024, 1500, 4097, 10000]))
+    p = int(rng.choice([1, 2, 3, 5, 6, 9, 12, 20, 33, 47, 62])) if fam == "linreg" else int(rng.choice([1, 2, 4, 6, 8, 11]))
+    intercept = bool(rng.integers(0, 2))
+    chains = int(rng.choice([1, 2, 4, 6, 17, 128, 256]))
+    k = p + int(intercept) + (1 if fam == "linreg" else 0)
+    if k > 64:
+        p -= k - 64; k = 64
+    kind_name = str(rng.choice(["normal", "reflective", "adapt", "ram", "unif"]))
+    nsteps = int(max(8, min(70, 1.2e8 / (chains * n * p * 2))))
+    calls = int(rng.integers(1, 4))
+    beta = rng.uniform(-1.0, 1.0, p + 1)
+    X = rng.standard_normal((n, p))
+    if fam == "linreg":
+        y = (beta[0] if intercept else 0.0) + X @ beta[1:] + 1.5 * rng.standard_normal(n)
+        base = list(beta[(0 if intercept else 1):]) + [1.5]
+        famc, kw = O.FAM_LINREG, dict(intercept=intercept, guard=bool(rng.integers(0, 2)))
+        lb = [-30.0] * (k - 1) + [0.2]
+    else:
+        eta = (beta[0] if intercept else 0.0) + X @ beta[1:]
+        y = (rng.uniform(size=n) < 1 / (1 + np.exp(-eta))).astype(np.float64)
+        base = list(beta[(0 if intercept else 1):])
+        famc, kw = O.FAM_LOGISTIC, dict(intercept=intercept, prior_div=float(rng.choice([0.0, 8.0, 2.5])))
+        lb = [-5.0] * k
+    init = jitter_init(base, chains, 11 + case)
+    if fam == "linreg":
+        init[:, -1] = np.abs(init[:, -1]) + 0.3
+    fixed = np.zeros(k, bool)
+    if k > 3 and rng.random() < 0.4:
+        fixed[rng.choice(k - 1, size=int(rng.integers(1, 3)), replace=False)] = True
+    free = np.nonzero(~fixed)[0]
+    opts = dict(fixed=fixed)
+    if kind_name in ("normal", "reflective"):
+        kind = O.K_NORMAL if kind_name == "normal" else O.K_NORMAL_REFLECTIVE
+        opts.update(scale=rng.uniform(0.002, 0.02, k), mu=rng.uniform(-0.002, 0.002, k))
+        r = rng.random()
+        if r < 0.25:
+            opts["scheme"] = list(rng.permutation(free) + 1)          # explicit sequence, 1-based as in R
+        elif r < 0.4:
+            opts["scheme"] = "random"
+        if kind_name == "reflective":
+            opts.update(lb=lb, ub=30.0 if fam == "linreg" else 5.0)
+    elif kind_name == "unif":
+        kind = O.K_UNIF_REFLECTIVE if case % 2 else O.K_UNIF
+        opts.update(min_=-0.01, max_=0.012)
+        if case % 2:
+            opts.update(lb=lb, ub=30.0 if fam == "linreg" else 5.0)
+    elif kind_name == "adapt":
+        kind = O.K_ADAPT
+        warm = int(rng.integers(2, 12))
+        opts.update(warmup=warm, eps=float(rng.choice([1e-4, 1e-6])), freq=int(rng.choice([1, 1, 2, 3])))
+        if rng.random() < 0.3:
+            opts.update(bw=int(rng.integers(3, 8)), Sd=0.7)
+            opts["warmup"] = max(warm, opts["bw"])                  # kernel_adapt stops when bw > warmup
+        if rng.random() < 0.3:
+            opts["until"] = float(nsteps // 2)
+        if rng.random() < 0.4:
+            opts.update(lb=lb, ub=30.0 if fam == "linreg" else 5.0)
+    else:
+        kind = O.K_RAM
+        opts.update(arate=float(rng.choice([0.234, 0.4])), warmup=int(rng.choice([0, 0, 4])), freq=int(rng.choice([1, 1, 2])))
+        if rng.random() < 0.3:
+            M = (np.abs(np.subtract.outer(np.arange(k), np.arange(k))) <= 2).astype(float)
+            opts["constr"] = M
+        if rng.random() < 0.3:
+            opts.update(lb=lb, ub=30.0 if fam == "linreg" else 5.0)
+    run_both(E, O, famc, X, y, kind, k, init, nsteps=nsteps, burnin=int(rng.integers(0, 3)), thin=int(rng.choice([1, 1, 2])),
+             seed=int(rng.integers(1, 10**6)), chain_base=int(rng.choice([0, 3, 4096])), calls=calls, **kw, **opts)
