@@ -481,7 +481,8 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
     bool shard = !(shenv && shenv[0] == '0') && lpw > 0 && !(kv == FMCMC_KERNEL_RAM && ram_bounded) && lpw * nslots <= SH_MAXO && nblk <= ncu &&
                  (size_t)m->p * SH_MAXO * sizeof(double) <= 15872 &&   /* the slice has to stay in the scalar cache */
                  (long long)m->p * SH_MAXO * nblk < (1ll << 28) && (long long)(m->p + 1) * (run->nchains + SH_PAD) < (1ll << 31) &&
-                 (long long)(NT + SH_PAD) * run->nchains < (1ll << 31);
+                 (long long)(NT + SH_PAD) * run->nchains < (1ll << 31) &&
+                 run->nsteps < 30000000;   /* barrier epochs (2 per step) x workgroups per group stay below 2^32 */
     // the sharded evaluation is its own instantiation (OPT = lanes per workgroup): sharing one with the streamed loop
     // cost 200-300 spilled registers in BOTH paths
     const void* kfn = nullptr;
