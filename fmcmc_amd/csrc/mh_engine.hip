@@ -519,6 +519,15 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
       void* kargs[] = {(void*)&A};
       e = hipLaunchCooperativeKernel(kfn, dim3((unsigned)nblk), dim3(NT), kargs, (unsigned int)lds, stream);
       (void)hipFreeAsync(shw, stream);
+      if (e != hipSuccess) {   // the runtime refused the cooperative launch after all: nothing ran, take the chain-sharded kernel
+        (void)hipGetLastError();
+        e = hipSuccess;
+        shard = false;
+        g_kernel = "streamed-wide";
+        A.shard = 0; A.sh_xs = nullptr; A.sh_ys = nullptr; A.sh_th = nullptr; A.sh_part = nullptr; A.sh_bar = nullptr;
+      }
+    }
+    if (shard) {
     } else
     if (cw == 1) { if (kv == 1) LAUNCH_WIDE(1, 1); else if (kv == 2) LAUNCH_WIDE(1, 2); else LAUNCH_WIDE(1, 4); }
     else { if (kv == 1) LAUNCH_WIDE(2, 1); else if (kv == 2) LAUNCH_WIDE(2, 2); else LAUNCH_WIDE(2, 4); }
