@@ -398,7 +398,8 @@ __device__ __forceinline__ unsigned long long rfl_u64(unsigned long long v) {
   const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
   return ((unsigned long long)hi << 32) | lo;
 }
-template <int LPW>
+// MAXO: observations of the slice that are actually walked (the first MAXO of its SH_MAXO slots; 20 when n <= 512 x 20 / LPW)
+template <int LPW, int MAXO>
 __device__ __attribute__((noinline)) void shard_columns(ShardCols c) {
   const int tid = threadIdx.x;
   const int NC = rfl_i(c.NC), NCP = NC + SH_PAD, p = rfl_i(c.p), ic = rfl_i(c.ic), nslots = rfl_i(c.nslots);
@@ -414,10 +415,10 @@ __device__ __attribute__((noinline)) void shard_columns(ShardCols c) {
   for (int cb = 0; cb < NC; cb += NT) {
     const int chain = cb + tid;
     const unsigned int chc = (unsigned int)(chain < NC ? chain : 0);
-    double mu[SH_MAXO];
+    double mu[MAXO];
     const double b0 = ic ? sh_load(thg + chc) : 0.0;
 #pragma unroll
-    for (int o = 0; o < SH_MAXO; o++) mu[o] = b0;
+    for (int o = 0; o < MAXO; o++) mu[o] = b0;
     // coefficients in blocks of 8, THREE blocks in flight: they were written by other XCDs a barrier ago, every load is
     // an L2 miss of 1-3 us and a block's 320 FMAs cover ~1 us; one block ahead stalled on every block (36 us for the
     // columns instead of 12), all of them at once (6 blocks + tail) spilled 300 registers
@@ -442,7 +443,7 @@ __device__ __attribute__((noinline)) void shard_columns(ShardCols c) {
             if (j0 + u < pe) {               // uniform (and on purpose: without a guard between the columns the
               const cptr_t xc = xs + (j0 + u) * SH_MAXO;   // scheduler hoists scalar loads until 700 B per lane spill)
 #pragma unroll
-              for (int o = 0; o < SH_MAXO; o++) mu[o] = fmh_fma(xc[o], tb[q][u], mu[o]);
+              for (int o = 0; o < MAXO; o++) mu[o] = fmh_fma(xc[o], tb[q][u], mu[o]);
             }
           }
           if (j0 + RING * JB8 < pe) { SH_LOAD_BLOCK(q, j0 + RING * JB8) }
@@ -454,7 +455,7 @@ __device__ __attribute__((noinline)) void shard_columns(ShardCols c) {
 #pragma unroll
     for (int q = 0; q < LPW; q++) al[q] = 0.0;
 #pragma unroll
-    for (int o = 0; o < SH_MAXO; o++) {          // o = slot * LPW + lane-in-slice: slot order per lane
+    for (int o = 0; o < MAXO; o++) {             // o = slot * LPW + lane-in-slice: slot order per lane
       const int sl = o / LPW, q = o % LPW;
       const bool valid = sl < nslots && ((long long)(lane0 + q) + (long long)NT * sl) < n;   // uniform
       const double r = valid ? ys[o] - mu[o] : 0.0;                      // fma(0, 0, acc) == acc exactly
@@ -490,7 +491,8 @@ __device__ __forceinline__ bool eval_sharded(const SweepArgs& A, double* const* 
   sc.ys = A.sh_ys + (long long)blockIdx.x * SH_MAXO;
   sc.th = A.sh_th; sc.part = A.sh_part; sc.n = A.n; sc.NC = NC; sc.p = p; sc.ic = ic; sc.nslots = A.sh_nslots;
   sc.lane0 = (int)blockIdx.x * LPW; sc.debug = A.debug;
-  shard_columns<LPW>(sc);
+  if (A.sh_nslots * LPW <= SH_MAXO / 2) shard_columns<LPW, SH_MAXO / 2>(sc);   // half-empty slices: half the FMAs
+  else shard_columns<LPW, SH_MAXO>(sc);
   if (!(A.debug & 32) && !(epoch & LOST)) { ok = shard_barrier(A.sh_bar, ++epoch); if (!ok) epoch |= LOST; }
   ok = !(epoch & LOST);
   // 3. thread = canonical lane: its partial of this workgroup's chains

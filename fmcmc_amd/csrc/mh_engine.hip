@@ -483,6 +483,16 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
                  (long long)m->p * SH_MAXO * nblk < (1ll << 28) && (long long)(m->p + 1) * (run->nchains + SH_PAD) < (1ll << 31) &&
                  (long long)(NT + SH_PAD) * run->nchains < (1ll << 31) &&
                  run->nsteps < 30000000;   /* barrier epochs (2 per step) x workgroups per group stay below 2^32 */
+    if (shard && !(shenv && shenv[0] == '1')) {
+      // Worth it?  Measured at k = 50 (us per step): the chain-sharded evaluation costs ~4 + X bytes / 65 GB/s (the per-CU L2
+      // rate), the sharded one ~14 of hand-overs and fixed work + 0.0085 per column and walked observation slot (+ ~6 of
+      // barrier imbalance under kernel_ram): n = 2500 loses (23.9 vs 19.1), n = 5000 wins (24.3 vs 30.1), C4 wins 2x.
+      // FMCMC_AMD_SHARD=1 forces the sharded kernel for every eligible shape (tests), =0 disables it.
+      const int walked = (lpw * nslots <= SH_MAXO / 2) ? SH_MAXO / 2 : SH_MAXO;
+      const double est_chain = 4.0 + (double)m->n * (double)m->p * 8.0 / 65000.0;
+      const double est_shard = 14.0 + 0.0085 * (double)m->p * (double)walked + (kv == FMCMC_KERNEL_RAM ? 6.0 : 0.0);
+      shard = est_shard < est_chain;
+    }
     // the sharded evaluation is its own instantiation (OPT = lanes per workgroup): sharing one with the streamed loop
     // cost 200-300 spilled registers in BOTH paths
     const void* kfn = nullptr;

@@ -575,6 +575,7 @@ def test_observation_sharded_evaluation(E, O, monkeypatch, chains, cw, n, p, int
     import torch
     from fmcmc_amd import _abi as abi
     monkeypatch.setenv("FMCMC_AMD_CW", cw)
+    monkeypatch.setenv("FMCMC_AMD_SHARD", "1")      # every eligible shape, also where the cost model prefers chain-sharded
     nb = p + (1 if intercept else 0)
     groups = -(-chains // int(cw))       # co-residency needs one CU per workgroup (a partitioned GPU falls back)
     sharded = "streamed-wide-sharded" if torch.cuda.get_device_properties(0).multi_processor_count >= groups else "streamed-wide"
@@ -712,12 +713,13 @@ def test_randomised_dispatch_cases(E, O, case):
              chain_base=c["chain_base"], calls=c["calls"], **kw, **opts)
 
 
-def test_randomised_sharded_shapes(E, O):
+def test_randomised_sharded_shapes(E, O, monkeypatch):
     """Random wide models around the eligibility limits of the observation-sharded evaluation (128 / 256 workgroups, slices
     of <= 40 observations and <= 49 columns): whichever kernel the dispatcher picks, the oracle's bits; most of them
     must actually have run sharded."""
     import torch
     from fmcmc_amd import _abi as abi
+    monkeypatch.setenv("FMCMC_AMD_SHARD", "1")      # every eligible shape, also where the cost model prefers chain-sharded
     picked = []
     for case in range(18):
         rng = np.random.default_rng(4200 + case)
@@ -751,12 +753,13 @@ def test_randomised_sharded_shapes(E, O):
         assert sum(name == "streamed-wide-sharded" for name in picked) >= 9, picked
 
 
-def test_sharded_evaluation_with_failing_chains(E, O):
+def test_sharded_evaluation_with_failing_chains(E, O, monkeypatch):
     """Chains that raise "fun(par) is undefined" (sigma < 0 without the guard) inside an observation-sharded sweep: they
     stop, their workgroups keep taking part in every grid-wide hand-over, the other chains are unaffected (oracle's bits,
     status, step and theta of the failure), for kernel_normal and kernel_ram."""
     import torch
     from fmcmc_amd import _abi as abi
+    monkeypatch.setenv("FMCMC_AMD_SHARD", "1")
     n, p, chains = 3000, 20, 256
     rng = np.random.default_rng(77)
     beta = rng.uniform(-1.0, 1.0, p + 1)
