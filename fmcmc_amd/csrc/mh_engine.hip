@@ -215,6 +215,54 @@ int fmcmc_validate(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_run
   return FMCMC_OK;
 }
 
+// The same sweep for the chains [off, off + cnt) of a call: every per-chain array advanced, RNG ids continued.
+static SweepArgs chain_window(const SweepArgs& A, long long off, long long cnt, int kf) {
+  SweepArgs W = A;
+  const long long k = A.k, S = A.S, ns = A.nsteps, words = (A.nsteps + 31) >> 5;
+  W.nchains = cnt; W.chain_base = A.chain_base + off;
+#define ADV(f, stride) if (W.f) W.f += off * (stride)
+  ADV(scheme_cols, ns); ADV(mirror_mu, k); ADV(mirror_scale, k); ADV(obs_arate, 1);
+  ADV(hist, (long long)A.hist_rows * kf);
+  ADV(fed_logu, ns); ADV(fed_z, ns * A.kz);
+  ADV(theta0, k); ADV(f0, 1); ADV(abs_iter, 1); ADV(Sigma, (long long)kf * kf); ADV(mean_prev, kf); ADV(have_mean, 1); ADV(nerrors, 1);
+  ADV(samples, k * S); ADV(logpost, S); ADV(draws, k * S); ADV(accept_count, 1); ADV(accept_bits, words);
+  ADV(status, 1); ADV(status_step, 1); ADV(status_theta, k);
+#undef ADV
+  return W;
+}
+
+// Observation-sharded evaluation (mh_common.hpp, eval_sharded): `nb` workgroups per launch must split the 512 canonical
+// lanes evenly (128 or 256 of them), be co-resident (cooperative launch) and hold their slice in SH_MAXO registers.
+// Returns the canonical lanes per workgroup (2 or 4), or 0 when the shape is not eligible or the cost model prefers the
+// chain-sharded kernel.  Cost model (us per step, fitted at k = 50): chain-sharded ~4 + X bytes / 65 GB/s (the per-CU L2
+// rate); sharded ~14 of hand-overs and fixed work + 0.0085 per column and walked observation slot (+ ~6 of barrier
+// imbalance under kernel_ram): n = 2500 loses (23.9 vs 19.1), n = 5000 wins (24.3 vs 30.1), C4 wins 2x.
+// FMCMC_AMD_SHARD=1 forces the sharded kernel for every eligible shape (tests), =0 disables it.
+static int wide_sharded_lanes(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_run* run, int ram_bounded, int ncu, long long nb) {
+  const char* shenv = getenv("FMCMC_AMD_SHARD");
+  if (shenv && shenv[0] == '0') return 0;
+  if (m->family != FMCMC_FAM_GAUSSIAN_LINREG || m->p < 16) return 0;
+  if (kn->kind != FMCMC_KERNEL_RAM && kn->kind != FMCMC_KERNEL_NORMAL && kn->kind != FMCMC_KERNEL_NORMAL_REFLECTIVE) return 0;
+  const int nslots = (int)((m->n + NT - 1) / NT);
+  const int lpw = (nb == 128 || nb == 256) ? (int)(NT / nb) : 0;
+  const long long per_launch = nb * 2;   // (upper bound of the chains of one launch: at most two per workgroup)
+  const bool ok = lpw > 0 && !(kn->kind == FMCMC_KERNEL_RAM && ram_bounded) && lpw * nslots <= SH_MAXO && nb <= ncu &&
+                  (size_t)m->p * SH_MAXO * sizeof(double) <= 15872 &&   /* the slice has to stay in the scalar cache */
+                  (long long)m->p * SH_MAXO * nb < (1ll << 28) && (long long)(m->p + 1) * (per_launch + SH_PAD) < (1ll << 31) &&
+                  run->nsteps < 30000000;   /* barrier epochs (2 per step) x workgroups per group stay below 2^32 */
+  if (!ok) return 0;
+  if (!(shenv && shenv[0] == '1')) {
+    const int walked = (lpw * nslots <= SH_MAXO / 2) ? SH_MAXO / 2 : SH_MAXO;
+    const double est_chain = 4.0 + (double)m->n * (double)m->p * 8.0 / 65000.0;
+    const double est_shard = 14.0 + 0.0085 * (double)m->p * (double)walked + (kn->kind == FMCMC_KERNEL_RAM ? 6.0 : 0.0);
+    if (!(est_shard < est_chain)) return 0;
+  }
+  return lpw;
+}
+static bool wide_sharded_pays(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_run* run, int ram_bounded, int ncu, long long nb) {
+  return wide_sharded_lanes(m, kn, run, ram_bounded, ncu, nb) > 0;
+}
+
 // kernel->fixed etc. are DEVICE pointers here; kf and bounds info come via `kf`/`ram_bounded`.
 static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const fmcmc_run* run,
                         fmcmc_state* st, fmcmc_out* out, int kf, int ram_bounded, hipStream_t stream) {
@@ -289,6 +337,11 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
     while (cw < NW && (long long)cw * ncu < run->nchains) cw <<= 1;
     const char* cwenv = getenv("FMCMC_AMD_CW");   // diagnosis: chains per workgroup of the streamed kernel (1, 2, 4, 8)
     if (cwenv && (cwenv[0] == '1' || cwenv[0] == '2' || cwenv[0] == '4' || cwenv[0] == '8')) cw = cwenv[0] - '0';
+    // wide linear models with more than two chains per CU: two chains per workgroup, so that the sweep can run as
+    // consecutive observation-sharded launches of 2 x CUs chains each (below) when that pays off
+    // (measured at k = 50, n = 10k: 1024 chains 63.8 us per step instead of 71.6 with four chains per workgroup; at 2048
+    //  chains the general kernel with eight chains per workgroup is level, 123 vs 128, and keeps the sweep)
+    else if (cw == 4 && wide_sharded_pays(m, kn, run, ram_bounded, ncu, (long long)ncu) && run->nchains % (2LL * ncu) == 0) cw = 2;
   }
   int tb = 32;
   while (tb > 1 && sweep_lds_bytes(kn->k, kf, kn->kind, cw, tb, A.kz, resident) > 60 * 1024) tb >>= 1;
@@ -473,26 +526,13 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
         hipLaunchKernelGGL((mh_sweep_kernel<CWV, -1, 0, KV, FMCMC_FAM_GAUSSIAN_LINREG>), dim3((unsigned)nblk), dim3(NT), lds, stream, A); \
     } while (0)
     const int kv = kn->kind;   // 1, 2 or 4
-    // Observation-sharded evaluation (mh_common.hpp, eval_sharded): the workgroups must split the 512 canonical lanes
-    // evenly (128 or 256 workgroups), be co-resident (cooperative launch) and hold their slice in SH_MAXO registers.
-    const char* shenv = getenv("FMCMC_AMD_SHARD");
+    // Observation-sharded evaluation: one cooperative launch when the call has 128 or 256 workgroups, consecutive launches
+    // of 256 workgroups when it has a multiple of that (more than 512 chains per GPU at two chains per workgroup)
     const int nslots = (int)((m->n + NT - 1) / NT);
-    const int lpw = (nblk == 128 || nblk == 256) ? (int)(NT / nblk) : 0;
-    bool shard = !(shenv && shenv[0] == '0') && lpw > 0 && !(kv == FMCMC_KERNEL_RAM && ram_bounded) && lpw * nslots <= SH_MAXO && nblk <= ncu &&
-                 (size_t)m->p * SH_MAXO * sizeof(double) <= 15872 &&   /* the slice has to stay in the scalar cache */
-                 (long long)m->p * SH_MAXO * nblk < (1ll << 28) && (long long)(m->p + 1) * (run->nchains + SH_PAD) < (1ll << 31) &&
-                 (long long)(NT + SH_PAD) * run->nchains < (1ll << 31) &&
-                 run->nsteps < 30000000;   /* barrier epochs (2 per step) x workgroups per group stay below 2^32 */
-    if (shard && !(shenv && shenv[0] == '1')) {
-      // Worth it?  Measured at k = 50 (us per step): the chain-sharded evaluation costs ~4 + X bytes / 65 GB/s (the per-CU L2
-      // rate), the sharded one ~14 of hand-overs and fixed work + 0.0085 per column and walked observation slot (+ ~6 of
-      // barrier imbalance under kernel_ram): n = 2500 loses (23.9 vs 19.1), n = 5000 wins (24.3 vs 30.1), C4 wins 2x.
-      // FMCMC_AMD_SHARD=1 forces the sharded kernel for every eligible shape (tests), =0 disables it.
-      const int walked = (lpw * nslots <= SH_MAXO / 2) ? SH_MAXO / 2 : SH_MAXO;
-      const double est_chain = 4.0 + (double)m->n * (double)m->p * 8.0 / 65000.0;
-      const double est_shard = 14.0 + 0.0085 * (double)m->p * (double)walked + (kv == FMCMC_KERNEL_RAM ? 6.0 : 0.0);
-      shard = est_shard < est_chain;
-    }
+    const long long nb_launch = (nblk > 256 && nblk % 256 == 0) ? 256 : nblk;
+    const long long ch_launch = (nb_launch == nblk) ? (long long)run->nchains : nb_launch * cw;
+    const int lpw = wide_sharded_lanes(m, kn, run, ram_bounded, ncu, nb_launch);
+    bool shard = lpw > 0;
     // the sharded evaluation is its own instantiation (OPT = lanes per workgroup): sharing one with the streamed loop
     // cost 200-300 spilled registers in BOTH paths
     const void* kfn = nullptr;
@@ -509,7 +549,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
       (void)hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev);
       if (lds > 48 * 1024) e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess || !coop ||
-          hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kfn, NT, lds) != hipSuccess || (long long)perCU * ncu < nblk) {
+          hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kfn, NT, lds) != hipSuccess || (long long)perCU * ncu < nb_launch) {
         if (A.debug & 256) fprintf(stderr, "fmcmc_amd: sharded evaluation not launched: err=%d coop=%d perCU=%d lds=%zu\n", (int)e, coop, perCU, lds);
         shard = false;
         g_kernel = "streamed-wide";
@@ -517,20 +557,24 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
       e = hipSuccess;
     }
     if (shard) {
-      const size_t nxs = (size_t)nblk * m->p * SH_MAXO, nys = (size_t)nblk * SH_MAXO, nth = (size_t)kn->k * (run->nchains + SH_PAD),
-                   npt = (size_t)(NT + SH_PAD) * run->nchains, nbar = 32 * 20 / 2;   // (barrier words counted in doubles)
+      const size_t nxs = (size_t)nb_launch * m->p * SH_MAXO, nys = (size_t)nb_launch * SH_MAXO, nth = (size_t)kn->k * (ch_launch + SH_PAD),
+                   npt = (size_t)(NT + SH_PAD) * ch_launch, nbar = 32 * 20 / 2;   // (barrier words counted in doubles)
       e = hipMallocAsync((void**)&shw, sizeof(double) * (nxs + nys + nth + npt + nbar), stream);
       if (e != hipSuccess) { set_err("hipMallocAsync(sharded evaluation) failed: %s", hipGetErrorString(e)); return FMCMC_ERR_DEVICE; }
       double* xs = shw; double* ys = xs + nxs; double* thw = ys + nys; double* ptw = thw + nth;
       unsigned* bar = (unsigned*)(ptw + npt);
-      (void)hipMemsetAsync(bar, 0, sizeof(double) * nbar, stream);
-      hipLaunchKernelGGL(shard_build_slices, dim3((unsigned)nblk), dim3(256), 0, stream, m->X, m->y, (long long)m->n, m->p, lpw, nslots, xs, ys);
+      hipLaunchKernelGGL(shard_build_slices, dim3((unsigned)nb_launch), dim3(256), 0, stream, m->X, m->y, (long long)m->n, m->p, lpw, nslots, xs, ys);
       A.shard = lpw; A.sh_nslots = nslots; A.sh_xs = xs; A.sh_ys = ys; A.sh_th = thw; A.sh_part = ptw; A.sh_bar = bar;
-      void* kargs[] = {(void*)&A};
-      e = hipLaunchCooperativeKernel(kfn, dim3((unsigned)nblk), dim3(NT), kargs, (unsigned int)lds, stream);
+      long long done = 0;
+      for (; done < run->nchains && e == hipSuccess; done += ch_launch) {   // (the slices and tables serve every launch)
+        SweepArgs W = chain_window(A, done, (run->nchains - done < ch_launch) ? run->nchains - done : ch_launch, kf);
+        (void)hipMemsetAsync(bar, 0, sizeof(double) * nbar, stream);
+        void* kargs[] = {(void*)&W};
+        e = hipLaunchCooperativeKernel(kfn, dim3((unsigned)nb_launch), dim3(NT), kargs, (unsigned int)lds, stream);
+      }
       (void)hipFreeAsync(shw, stream);
-      if (e != hipSuccess) {   // the runtime refused the cooperative launch after all: nothing ran, take the chain-sharded kernel
-        (void)hipGetLastError();
+      if (e != hipSuccess && done <= ch_launch) {   // the runtime refused the first cooperative launch after all: nothing ran,
+        (void)hipGetLastError();                    // take the chain-sharded kernel
         e = hipSuccess;
         shard = false;
         g_kernel = "streamed-wide";

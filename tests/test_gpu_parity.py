@@ -964,3 +964,29 @@ def test_randomised_option_cases(E, O, case):
             opts.update(lb=lb, ub=30.0 if fam == "linreg" else 5.0)
     run_both(E, O, famc, X, y, kind, k, init, nsteps=nsteps, burnin=int(rng.integers(0, 3)), thin=int(rng.choice([1, 1, 2])),
              seed=int(rng.integers(1, 10**6)), chain_base=int(rng.choice([0, 3, 4096])), calls=calls, **kw, **opts)
+
+
+@pytest.mark.parametrize("kind_name", ["normal", "ram"])
+def test_sharded_evaluation_in_consecutive_launches(E, O, monkeypatch, kind_name):
+    """More than 512 chains per GPU on a wide model: the sweep runs as consecutive cooperative launches of 512 chains
+    (chain windows of one call: every per-chain array advanced, RNG ids continued) -- the oracle's bits for all 1024
+    chains, continued over two calls, and the bits of the chain-sharded kernel."""
+    import torch
+    from fmcmc_amd import _abi as abi
+    monkeypatch.setenv("FMCMC_AMD_SHARD", "1")
+    n, p, chains = 1500, 18, 1024
+    rng = np.random.default_rng(31)
+    beta = rng.uniform(-1.0, 1.0, p + 1)
+    X = rng.standard_normal((n, p))
+    y = beta[0] + X @ beta[1:] + 2.0 * rng.standard_normal(n)
+    init = jitter_init(list(beta) + [2.0], chains, 6)
+    init[:, -1] = np.abs(init[:, -1]) + 0.1
+    kind = O.K_NORMAL if kind_name == "normal" else O.K_RAM
+    opts = dict(scale=0.01, fixed=[False] * 3 + [True] + [False] * (p - 2)) if kind_name == "normal" else {}
+    a, _ = run_both(E, O, O.FAM_LINREG, X, y, kind, p + 2, init, nsteps=16, burnin=1, thin=2, calls=2, chain_base=40, **opts)
+    if torch.cuda.get_device_properties(0).multi_processor_count >= 256:
+        assert abi.last_kernel() == "streamed-wide-sharded"
+    monkeypatch.setenv("FMCMC_AMD_SHARD", "0")
+    b, _ = run_both(E, O, O.FAM_LINREG, X, y, kind, p + 2, init, nsteps=16, burnin=1, thin=2, calls=2, chain_base=40, **opts)
+    assert abi.last_kernel() in ("streamed-wide", "streamed")
+    assert _bits_equal(a.samples.cpu().numpy(), b.samples.cpu().numpy())
