@@ -657,7 +657,8 @@ __device__ __forceinline__ void eval_partials(const SweepArgs& A, double* const*
     }
   } else if constexpr (FAM == FMCMC_FAM_GAUSSIAN_LINREG && CW <= 2 && SHL > 0) {
     const bool ok = eval_sharded<CW, SHL>(A, th, acc, *sh_epoch);
-    if (!ok && tid == 0) A.status[(long long)blockIdx.x * CW] = FMCMC_CHAIN_SYNC_TIMEOUT;
+    if (!ok && tid == 0 && (long long)blockIdx.x * CW < A.nchains)      // (a workgroup without chains has no status slot)
+      A.status[(long long)blockIdx.x * CW] = FMCMC_CHAIN_SYNC_TIMEOUT;
   } else {
     // Memory-level parallelism: the data comes from L2 (latency ~1 us under load), so every thread keeps a
     // batch of JB independent column loads in flight before the FMAs that consume them; a dependent

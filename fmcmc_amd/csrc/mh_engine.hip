@@ -341,7 +341,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
     // consecutive observation-sharded launches of 2 x CUs chains each (below) when that pays off
     // (measured at k = 50, n = 10k: 1024 chains 63.8 us per step instead of 71.6 with four chains per workgroup; at 2048
     //  chains the general kernel with eight chains per workgroup is level, 123 vs 128, and keeps the sweep)
-    else if (cw == 4 && wide_sharded_pays(m, kn, run, ram_bounded, ncu, (long long)ncu) && run->nchains % (2LL * ncu) == 0) cw = 2;
+    else if (cw == 4 && wide_sharded_pays(m, kn, run, ram_bounded, ncu, (long long)ncu)) cw = 2;
   }
   int tb = 32;
   while (tb > 1 && sweep_lds_bytes(kn->k, kf, kn->kind, cw, tb, A.kz, resident) > 60 * 1024) tb >>= 1;
@@ -529,8 +529,10 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
     // Observation-sharded evaluation: one cooperative launch when the call has 128 or 256 workgroups, consecutive launches
     // of 256 workgroups when it has a multiple of that (more than 512 chains per GPU at two chains per workgroup)
     const int nslots = (int)((m->n + NT - 1) / NT);
-    const long long nb_launch = (nblk > 256 && nblk % 256 == 0) ? 256 : nblk;
-    const long long ch_launch = (nb_launch == nblk) ? (long long)run->nchains : nb_launch * cw;
+    // (a launch may hold workgroups WITHOUT chains -- they own canonical lanes like the others -- so any chain count works:
+    //  up to 512 chains run as one launch of 256 workgroups, exactly 128 workgroups keep 4 lanes each when n allows)
+    const long long nb_launch = (nblk == 128 && 4 * nslots <= SH_MAXO) ? 128 : 256;
+    const long long ch_launch = (nblk > nb_launch) ? nb_launch * cw : (long long)run->nchains;
     const int lpw = wide_sharded_lanes(m, kn, run, ram_bounded, ncu, nb_launch);
     bool shard = lpw > 0;
     // the sharded evaluation is its own instantiation (OPT = lanes per workgroup): sharing one with the streamed loop

@@ -567,6 +567,8 @@ def test_logistic_on_the_general_kernel(E, O, kind_name):
     (128, "1", 4099, 21, True),       # 128 workgroups x 4 lanes, ragged last slot
     (512, "2", 1023, 33, True),       # two chains per workgroup, n < 2 x 512
     (255, "2", 2500, 49, False),      # last workgroup holds one chain; widest slice (49 columns); no intercept
+    (300, "2", 7000, 17, True),       # 150 workgroups with chains + 106 without: every chain count is eligible
+    (77, "1", 10240, 23, True),       # 77 of 256 workgroups hold a chain
 ])
 def test_observation_sharded_evaluation(E, O, monkeypatch, chains, cw, n, p, intercept):
     """Wide linear models whose workgroups split the 512 canonical lanes evenly evaluate observation-sharded
@@ -577,8 +579,8 @@ def test_observation_sharded_evaluation(E, O, monkeypatch, chains, cw, n, p, int
     monkeypatch.setenv("FMCMC_AMD_CW", cw)
     monkeypatch.setenv("FMCMC_AMD_SHARD", "1")      # every eligible shape, also where the cost model prefers chain-sharded
     nb = p + (1 if intercept else 0)
-    groups = -(-chains // int(cw))       # co-residency needs one CU per workgroup (a partitioned GPU falls back)
-    sharded = "streamed-wide-sharded" if torch.cuda.get_device_properties(0).multi_processor_count >= groups else "streamed-wide"
+    # co-residency needs one CU per workgroup of the launch (256, or exactly 128): a partitioned GPU falls back
+    sharded = "streamed-wide-sharded" if torch.cuda.get_device_properties(0).multi_processor_count >= 256 else "streamed-wide"
     X, y = synth_linreg(n, p, 9100 + n + p, beta=np.linspace(1.0, -1.0, p + 1))
     init = jitter_init(list(np.linspace(1.0, -1.0, p + 1))[(0 if intercept else 1):] + [4.0], chains, n + p)
     init[:, -1] = np.abs(init[:, -1])
@@ -723,9 +725,9 @@ def test_randomised_sharded_shapes(E, O, monkeypatch):
     picked = []
     for case in range(18):
         rng = np.random.default_rng(4200 + case)
-        chains = int(rng.choice([128, 255, 256, 257, 511, 512]))
+        chains = int(rng.choice([128, 200, 255, 256, 257, 300, 511, 512, 700]))
         p = int(rng.integers(16, 50))
-        lanes = 2 if chains > 256 or chains in (255, 256) else 4       # (257 chains: 2 per workgroup -> 129 workgroups, not sharded)
+        lanes = 4 if chains == 128 else 2
         nmax = 512 * (40 // lanes)
         n = int(rng.choice([nmax, nmax - 1, nmax + 1, nmax // 2 + 3, 777, 512, 513]))
         intercept = bool(rng.integers(0, 2))
@@ -750,7 +752,7 @@ def test_randomised_sharded_shapes(E, O, monkeypatch):
         picked.append(abi.last_kernel())
     assert all(name.startswith("streamed-wide") for name in picked), picked
     if torch.cuda.get_device_properties(0).multi_processor_count >= 256:
-        assert sum(name == "streamed-wide-sharded" for name in picked) >= 9, picked
+        assert sum(name == "streamed-wide-sharded" for name in picked) >= 12, picked
 
 
 def test_sharded_evaluation_with_failing_chains(E, O, monkeypatch):
