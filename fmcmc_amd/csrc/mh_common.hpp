@@ -63,10 +63,9 @@ struct SweepArgs {
   int* nerrors;
   // observation-sharded evaluation (wide linear models, cooperative launch; 0 = off)
   int shard;                 // canonical lanes per workgroup (512 / number of workgroups: 2 or 4)
-  int sh_nslots;             // observations per canonical lane, ceil(n / 512)
-  int sh_npass;              // slices of SH_MAXO observations per workgroup: ceil(shard * sh_nslots / SH_MAXO), <= SH_MAXPASS
-  const double* sh_xs;       // [G][npass][p][SH_MAXO] the workgroup's observations, column by column, slot-major (0 beyond n)
-  const double* sh_ys;       // [G][npass][SH_MAXO]
+  int sh_nslots;             // observations per canonical lane, ceil(n / 512); shard * sh_nslots <= SH_MAXO
+  const double* sh_xs;       // [G][p][SH_MAXO] the workgroup's observations, column by column, slot-major (0 beyond n)
+  const double* sh_ys;       // [G][SH_MAXO]
   double* sh_th;             // [k][nchains] proposals of all chains
   double* sh_part;           // [512][nchains] lane partials of all chains
   unsigned* sh_bar;          // barrier words, zeroed per launch (shard_barrier)
@@ -334,7 +333,6 @@ __device__ __forceinline__ void softplus_nonpos_vec(const double (&a)[CW], doubl
 // the workgroup's own chains and the usual tree follows.  Same arithmetic, same order, same bits.
 constexpr int SH_PAD = 32;             // row padding (doubles) of the exchange tables: a 4 KB row stride put every row
                                        // of a workgroup's strided accesses on the same L2 channel
-constexpr int SH_MAXPASS = 8;          // n <= 8 x 10240: a workgroup walks up to 8 slices per step (beyond one they miss the scalar cache)
 constexpr int SH_MAXO = 40;            // observations of a slice held in registers by a thread; the slice (p x 40 doubles)
                                        // must stay in the 16 KB scalar cache: with 48 x 48 doubles (18 KB) every pass missed
 // Grid barrier: 8 arrival counters + a top counter + 8 release words on separate cache lines, one lane per workgroup,
@@ -392,7 +390,7 @@ struct ShardCols {
   const double* th;      // [k][NC + SH_PAD] proposals of all chains
   double* part;          // [NC][NT + SH_PAD] lane partials
   long long n;
-  int NC, p, ic, nslots, lane0, debug, npass;
+  int NC, p, ic, nslots, lane0, debug;
 };
 __device__ __forceinline__ int rfl_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ unsigned long long rfl_u64(unsigned long long v) {
@@ -405,69 +403,63 @@ template <int LPW, int MAXO>
 __device__ __attribute__((noinline)) void shard_columns(ShardCols c) {
   const int tid = threadIdx.x;
   const int NC = rfl_i(c.NC), NCP = NC + SH_PAD, p = rfl_i(c.p), ic = rfl_i(c.ic), nslots = rfl_i(c.nslots);
-  const int lane0 = rfl_i(c.lane0), debug = rfl_i(c.debug), npass = rfl_i(c.npass);
+  const int lane0 = rfl_i(c.lane0), debug = rfl_i(c.debug);
   const long long n = (long long)rfl_u64((unsigned long long)c.n);
   // constant address space + uniform address = SCALAR loads (s_load_dwordx16: 8 observations per instruction); through
   // the generic pointer they were 48 broadcast vector loads per column and the evaluation took 96 us instead of ~15
   typedef const double __attribute__((address_space(4))) * cptr_t;
-  const cptr_t xs0 = (cptr_t)rfl_u64((unsigned long long)c.xs);
-  const cptr_t ys0 = (cptr_t)rfl_u64((unsigned long long)c.ys);
+  const cptr_t xs = (cptr_t)rfl_u64((unsigned long long)c.xs);
+  const cptr_t ys = (cptr_t)rfl_u64((unsigned long long)c.ys);
   const double* thg = (const double*)rfl_u64((unsigned long long)c.th);
   double* part = (double*)rfl_u64((unsigned long long)c.part);
   for (int cb = 0; cb < NC; cb += NT) {
     const int chain = cb + tid;
     const unsigned int chc = (unsigned int)(chain < NC ? chain : 0);
+    double mu[MAXO];
+    const double b0 = ic ? sh_load(thg + chc) : 0.0;
+#pragma unroll
+    for (int o = 0; o < MAXO; o++) mu[o] = b0;
+    // coefficients in blocks of 8, THREE blocks in flight: they were written by other XCDs a barrier ago, every load is
+    // an L2 miss of 1-3 us and a block's 320 FMAs cover ~1 us; one block ahead stalled on every block (36 us for the
+    // columns instead of 12), all of them at once (6 blocks + tail) spilled 300 registers
+    constexpr int JB8 = 8, RING = 3;
+    const int pe = (debug & 64) ? 1 : p;
+    double tb[RING][JB8];
+    // (column index clamped instead of a guard per load: 32 guarded loads compiled to 32 branches)
+#define SH_LOAD_BLOCK(q, j0)                                                                                   \
+    _Pragma("unroll") for (int u = 0; u < JB8; u++) {                                                          \
+      const int jj = ((j0) + u < pe) ? (j0) + u : pe - 1;                                                      \
+      tb[q][u] = sh_load(thg + ((unsigned int)((ic + jj) * NCP) + chc));                                       \
+    }
+#pragma unroll
+    for (int q = 0; q < RING; q++) { SH_LOAD_BLOCK(q, q * JB8) }
+    for (int jb = 0; jb < pe; jb += RING * JB8) {
+#pragma unroll
+      for (int q = 0; q < RING; q++) {
+        const int j0 = jb + q * JB8;
+        if (j0 < pe) {
+#pragma unroll
+          for (int u = 0; u < JB8; u++) {
+            if (j0 + u < pe) {               // uniform (and on purpose: without a guard between the columns the
+              const cptr_t xc = xs + (j0 + u) * SH_MAXO;   // scheduler hoists scalar loads until 700 B per lane spill)
+#pragma unroll
+              for (int o = 0; o < MAXO; o++) mu[o] = fmh_fma(xc[o], tb[q][u], mu[o]);
+            }
+          }
+          if (j0 + RING * JB8 < pe) { SH_LOAD_BLOCK(q, j0 + RING * JB8) }
+        }
+      }
+    }
+#undef SH_LOAD_BLOCK
     double al[LPW];
 #pragma unroll
     for (int q = 0; q < LPW; q++) al[q] = 0.0;
-    // n > 10240: the workgroup's observations come as several slices of SH_MAXO, walked one after the other (every pass
-    // fetches the coefficients again); the slices continue the slot order, so the lane partials simply carry over
-    for (int ps = 0; ps < npass; ps++) {
-      const cptr_t xs = xs0 + ps * p * SH_MAXO;
-      const cptr_t ys = ys0 + ps * SH_MAXO;
-      double mu[MAXO];
-      const double b0 = ic ? sh_load(thg + chc) : 0.0;
 #pragma unroll
-      for (int o = 0; o < MAXO; o++) mu[o] = b0;
-      // coefficients in blocks of 8, THREE blocks in flight: they were written by other XCDs a barrier ago, every load is
-      // an L2 miss of 1-3 us and a block's 320 FMAs cover ~1 us; one block ahead stalled on every block (36 us for the
-      // columns instead of 12), all of them at once (6 blocks + tail) spilled 300 registers
-      constexpr int JB8 = 8, RING = 3;
-      const int pe = (debug & 64) ? 1 : p;
-      double tb[RING][JB8];
-      // (column index clamped instead of a guard per load: 32 guarded loads compiled to 32 branches)
-#define SH_LOAD_BLOCK(q, j0)                                                                                   \
-      _Pragma("unroll") for (int u = 0; u < JB8; u++) {                                                          \
-        const int jj = ((j0) + u < pe) ? (j0) + u : pe - 1;                                                      \
-        tb[q][u] = sh_load(thg + ((unsigned int)((ic + jj) * NCP) + chc));                                       \
-      }
-#pragma unroll
-      for (int q = 0; q < RING; q++) { SH_LOAD_BLOCK(q, q * JB8) }
-      for (int jb = 0; jb < pe; jb += RING * JB8) {
-#pragma unroll
-        for (int q = 0; q < RING; q++) {
-          const int j0 = jb + q * JB8;
-          if (j0 < pe) {
-#pragma unroll
-            for (int u = 0; u < JB8; u++) {
-              if (j0 + u < pe) {               // uniform (and on purpose: without a guard between the columns the
-                const cptr_t xc = xs + (j0 + u) * SH_MAXO;   // scheduler hoists scalar loads until 700 B per lane spill)
-#pragma unroll
-                for (int o = 0; o < MAXO; o++) mu[o] = fmh_fma(xc[o], tb[q][u], mu[o]);
-              }
-            }
-            if (j0 + RING * JB8 < pe) { SH_LOAD_BLOCK(q, j0 + RING * JB8) }
-          }
-        }
-      }
-#undef SH_LOAD_BLOCK
-#pragma unroll
-      for (int o = 0; o < MAXO; o++) {             // ps * SH_MAXO + o = slot * LPW + lane-in-slice: slot order per lane
-        const int sl = ps * (SH_MAXO / LPW) + o / LPW, q = o % LPW;
-        const bool valid = sl < nslots && ((long long)(lane0 + q) + (long long)NT * sl) < n;   // uniform
-        const double r = valid ? ys[o] - mu[o] : 0.0;                      // fma(0, 0, acc) == acc exactly
-        al[q] = fmh_fma(r, r, al[q]);
-      }
+    for (int o = 0; o < MAXO; o++) {             // o = slot * LPW + lane-in-slice: slot order per lane
+      const int sl = o / LPW, q = o % LPW;
+      const bool valid = sl < nslots && ((long long)(lane0 + q) + (long long)NT * sl) < n;   // uniform
+      const double r = valid ? ys[o] - mu[o] : 0.0;                      // fma(0, 0, acc) == acc exactly
+      al[q] = fmh_fma(r, r, al[q]);
     }
     if (chain < NC) {
 #pragma unroll
@@ -495,9 +487,8 @@ __device__ __forceinline__ bool eval_sharded(const SweepArgs& A, double* const* 
   if (!(A.debug & 32) && !(epoch & LOST)) { ok = shard_barrier(A.sh_bar, ++epoch); if (!ok) epoch |= LOST; }
   // 2. thread = chain: the slice's observations for that chain
   ShardCols sc;
-  sc.xs = A.sh_xs + (long long)blockIdx.x * A.sh_npass * p * SH_MAXO;
-  sc.ys = A.sh_ys + (long long)blockIdx.x * A.sh_npass * SH_MAXO;
-  sc.npass = A.sh_npass;
+  sc.xs = A.sh_xs + (long long)blockIdx.x * p * SH_MAXO;
+  sc.ys = A.sh_ys + (long long)blockIdx.x * SH_MAXO;
   sc.th = A.sh_th; sc.part = A.sh_part; sc.n = A.n; sc.NC = NC; sc.p = p; sc.ic = ic; sc.nslots = A.sh_nslots;
   sc.lane0 = (int)blockIdx.x * LPW; sc.debug = A.debug;
   if (A.sh_nslots * LPW <= SH_MAXO / 2) shard_columns<LPW, SH_MAXO / 2>(sc);   // half-empty slices: half the FMAs

@@ -71,20 +71,17 @@ __global__ void detmath_kernel(int which, const double* x, double* out, long lon
 }
 
 // compact per-workgroup slices of X and y for the observation-sharded evaluation (mh_common.hpp, eval_sharded):
-// xs[((b npass + ps) p + j) SH_MAXO + o], ys[(b npass + ps) SH_MAXO + o] with ps SH_MAXO + o = slot * LPW + q <->
-// observation b LPW + q + 512 slot (0 beyond n)
-__global__ void shard_build_slices(const double* X, const double* y, long long n, int p, int lpw, int nslots, int npass,
+// xs[(b p + j) SH_MAXO + o], ys[b SH_MAXO + o] with o = slot * LPW + q <-> observation b LPW + q + 512 slot (0 beyond n)
+__global__ void shard_build_slices(const double* X, const double* y, long long n, int p, int lpw, int nslots,
                                    double* xs, double* ys) {
   const int b = blockIdx.x;
-  for (int idx = threadIdx.x; idx < npass * (p + 1) * SH_MAXO; idx += blockDim.x) {
-    const int ps = idx / ((p + 1) * SH_MAXO), rem = idx - ps * (p + 1) * SH_MAXO;
-    const int j = rem / SH_MAXO, o = rem - j * SH_MAXO;
-    const int og = ps * SH_MAXO + o;
-    const int sl = og / lpw, q = og - sl * lpw;
+  for (int idx = threadIdx.x; idx < (p + 1) * SH_MAXO; idx += blockDim.x) {
+    const int j = idx / SH_MAXO, o = idx - j * SH_MAXO;
+    const int sl = o / lpw, q = o - sl * lpw;
     const long long i = (long long)b * lpw + q + (long long)NT * sl;
     const bool valid = sl < nslots && i < n;
-    if (j < p) xs[(((long long)b * npass + ps) * p + j) * SH_MAXO + o] = valid ? X[(long long)j * n + i] : 0.0;
-    else ys[((long long)b * npass + ps) * SH_MAXO + o] = valid ? y[i] : 0.0;
+    if (j < p) xs[((long long)b * p + j) * SH_MAXO + o] = valid ? X[(long long)j * n + i] : 0.0;
+    else ys[(long long)b * SH_MAXO + o] = valid ? y[i] : 0.0;
   }
 }
 
@@ -249,18 +246,15 @@ static int wide_sharded_lanes(const fmcmc_model* m, const fmcmc_kernel* kn, cons
   const int nslots = (int)((m->n + NT - 1) / NT);
   const int lpw = (nb == 128 || nb == 256) ? (int)(NT / nb) : 0;
   const long long per_launch = nb * 2;   // (upper bound of the chains of one launch: at most two per workgroup)
-  const int npass = lpw > 0 ? (lpw * nslots + SH_MAXO - 1) / SH_MAXO : 1;
-  const bool ok = lpw > 0 && !(kn->kind == FMCMC_KERNEL_RAM && ram_bounded) && npass <= SH_MAXPASS && nb <= ncu &&
-                  (size_t)m->p * SH_MAXO * sizeof(double) <= 15872 &&   /* ONE slice has to stay in the scalar cache */
-                  (long long)m->p * SH_MAXO * nb * npass < (1ll << 28) && (long long)(m->p + 1) * (per_launch + SH_PAD) < (1ll << 31) &&
+  const bool ok = lpw > 0 && !(kn->kind == FMCMC_KERNEL_RAM && ram_bounded) && lpw * nslots <= SH_MAXO && nb <= ncu &&
+                  (size_t)m->p * SH_MAXO * sizeof(double) <= 15872 &&   /* the slice has to stay in the scalar cache */
+                  (long long)m->p * SH_MAXO * nb < (1ll << 28) && (long long)(m->p + 1) * (per_launch + SH_PAD) < (1ll << 31) &&
                   run->nsteps < 30000000;   /* barrier epochs (2 per step) x workgroups per group stay below 2^32 */
   if (!ok) return 0;
   if (!(shenv && shenv[0] == '1')) {
-    // (several slices per workgroup do not stay in the scalar cache: 2.1x per walked slot -- n = 20,000 / 50,000 at k = 50:
-    //  84 / 218 us per step, chain-sharded 115 / 278)
-    const double walked = (npass > 1) ? 2.1 * npass * SH_MAXO : ((lpw * nslots <= SH_MAXO / 2) ? SH_MAXO / 2 : SH_MAXO);
+    const int walked = (lpw * nslots <= SH_MAXO / 2) ? SH_MAXO / 2 : SH_MAXO;
     const double est_chain = 4.0 + (double)m->n * (double)m->p * 8.0 / 65000.0;
-    const double est_shard = 14.0 + 0.0085 * (double)m->p * walked + (kn->kind == FMCMC_KERNEL_RAM ? 6.0 : 0.0);
+    const double est_shard = 14.0 + 0.0085 * (double)m->p * (double)walked + (kn->kind == FMCMC_KERNEL_RAM ? 6.0 : 0.0);
     if (!(est_shard < est_chain)) return 0;
   }
   return lpw;
@@ -538,7 +532,6 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
     // (a launch may hold workgroups WITHOUT chains -- they own canonical lanes like the others -- so any chain count works:
     //  up to 512 chains run as one launch of 256 workgroups, exactly 128 workgroups keep 4 lanes each when n allows)
     const long long nb_launch = (nblk == 128 && 4 * nslots <= SH_MAXO) ? 128 : 256;
-    const int npass = (int)(((NT / nb_launch) * nslots + SH_MAXO - 1) / SH_MAXO);
     const long long ch_launch = (nblk > nb_launch) ? nb_launch * cw : (long long)run->nchains;
     const int lpw = wide_sharded_lanes(m, kn, run, ram_bounded, ncu, nb_launch);
     bool shard = lpw > 0;
@@ -566,14 +559,14 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
       e = hipSuccess;
     }
     if (shard) {
-      const size_t nxs = (size_t)nb_launch * npass * m->p * SH_MAXO, nys = (size_t)nb_launch * npass * SH_MAXO, nth = (size_t)kn->k * (ch_launch + SH_PAD),
+      const size_t nxs = (size_t)nb_launch * m->p * SH_MAXO, nys = (size_t)nb_launch * SH_MAXO, nth = (size_t)kn->k * (ch_launch + SH_PAD),
                    npt = (size_t)(NT + SH_PAD) * ch_launch, nbar = 32 * 20 / 2;   // (barrier words counted in doubles)
       e = hipMallocAsync((void**)&shw, sizeof(double) * (nxs + nys + nth + npt + nbar), stream);
       if (e != hipSuccess) { set_err("hipMallocAsync(sharded evaluation) failed: %s", hipGetErrorString(e)); return FMCMC_ERR_DEVICE; }
       double* xs = shw; double* ys = xs + nxs; double* thw = ys + nys; double* ptw = thw + nth;
       unsigned* bar = (unsigned*)(ptw + npt);
-      hipLaunchKernelGGL(shard_build_slices, dim3((unsigned)nb_launch), dim3(256), 0, stream, m->X, m->y, (long long)m->n, m->p, lpw, nslots, npass, xs, ys);
-      A.shard = lpw; A.sh_nslots = nslots; A.sh_npass = npass; A.sh_xs = xs; A.sh_ys = ys; A.sh_th = thw; A.sh_part = ptw; A.sh_bar = bar;
+      hipLaunchKernelGGL(shard_build_slices, dim3((unsigned)nb_launch), dim3(256), 0, stream, m->X, m->y, (long long)m->n, m->p, lpw, nslots, xs, ys);
+      A.shard = lpw; A.sh_nslots = nslots; A.sh_xs = xs; A.sh_ys = ys; A.sh_th = thw; A.sh_part = ptw; A.sh_bar = bar;
       long long done = 0;
       for (; done < run->nchains && e == hipSuccess; done += ch_launch) {   // (the slices and tables serve every launch)
         SweepArgs W = chain_window(A, done, (run->nchains - done < ch_launch) ? run->nchains - done : ch_launch, kf);
