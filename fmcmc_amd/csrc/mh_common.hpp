@@ -392,6 +392,9 @@ struct ShardCols {
   long long n;
   int NC, p, ic, nslots, lane0, debug;
 };
+// 16 dwords, and it has to stay there: one more field -- even an unused one -- and the C4 step went from 33 to 41 us
+// (the argument no longer travels in registers)
+static_assert(sizeof(ShardCols) == 64, "ShardCols must stay at 16 dwords");
 __device__ __forceinline__ int rfl_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ unsigned long long rfl_u64(unsigned long long v) {
   const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
