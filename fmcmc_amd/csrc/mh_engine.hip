@@ -246,15 +246,18 @@ static int wide_sharded_lanes(const fmcmc_model* m, const fmcmc_kernel* kn, cons
   const int nslots = (int)((m->n + NT - 1) / NT);
   const int lpw = (nb == 128 || nb == 256) ? (int)(NT / nb) : 0;
   const long long per_launch = nb * 2;   // (upper bound of the chains of one launch: at most two per workgroup)
-  const bool ok = lpw > 0 && !(kn->kind == FMCMC_KERNEL_RAM && ram_bounded) && lpw * nslots <= SH_MAXO && nb <= ncu &&
-                  (size_t)m->p * SH_MAXO * sizeof(double) <= 15872 &&   /* the slice has to stay in the scalar cache */
+  // A slice of more than 49 columns (15.5 KB) no longer stays in the scalar cache: 2.1x per walked slot, still ahead for the
+  // normal kernels (k = 64, n = 10k: 57 us per step against 78); kernel_ram stays chain-sharded there, its owner phase
+  // dominates at that width and runs slower in the sharded instantiation (121 against 108).
+  const bool cached = (size_t)m->p * SH_MAXO * sizeof(double) <= 15872;
+  const bool ok = lpw > 0 && !(kn->kind == FMCMC_KERNEL_RAM && (ram_bounded || !cached)) && lpw * nslots <= SH_MAXO && nb <= ncu &&
                   (long long)m->p * SH_MAXO * nb < (1ll << 28) && (long long)(m->p + 1) * (per_launch + SH_PAD) < (1ll << 31) &&
                   run->nsteps < 30000000;   /* barrier epochs (2 per step) x workgroups per group stay below 2^32 */
   if (!ok) return 0;
   if (!(shenv && shenv[0] == '1')) {
-    const int walked = (lpw * nslots <= SH_MAXO / 2) ? SH_MAXO / 2 : SH_MAXO;
+    const double walked = (cached ? 1.0 : 2.1) * ((lpw * nslots <= SH_MAXO / 2) ? SH_MAXO / 2 : SH_MAXO);
     const double est_chain = 4.0 + (double)m->n * (double)m->p * 8.0 / 65000.0;
-    const double est_shard = 14.0 + 0.0085 * (double)m->p * (double)walked + (kn->kind == FMCMC_KERNEL_RAM ? 6.0 : 0.0);
+    const double est_shard = 14.0 + 0.0085 * (double)m->p * walked + (kn->kind == FMCMC_KERNEL_RAM ? 6.0 : 0.0);
     if (!(est_shard < est_chain)) return 0;
   }
   return lpw;
