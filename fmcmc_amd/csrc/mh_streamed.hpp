@@ -14,6 +14,39 @@ constexpr int RES_MASKED = 4;  // trailing observation slots that carry a validi
 // behind the runtime A.kind (streamed variants).
 // FAM > 0 compiles one model family in, MINB is the number of workgroups per CU the register allocation must allow
 // (the logistic model is bound by fp64 instruction issue: with 128 VGPRs two workgroups share a CU, 4 waves per SIMD).
+// kernel_ram's rank-1 update of the lower factor (twin of the oracle's chol_rank1_canon): Salt <- chol(Scur Scur' +- w w'),
+// lane = row, one column per iteration, sequential in w.  What an iteration waits for is kept off its path: the column's
+// entries come from LDS one iteration ahead, x_j is a v_readlane (not a ds_bpermute round trip), the row update is selects
+// plus one store region (the old form: three LDS round trips and two exec regions per column, 25 us of the 85 us step at
+// k = 50).  A REAL function on purpose: inlined into the sweep kernels the loop shares their register allocation, and the
+// instantiations that sit at 256 VGPRs spill inside it.  Returns true when the update fails (r^2 <= 0 or not finite;
+// R/kernel_ram.R:143).
+typedef __attribute__((address_space(3))) double* lds_dptr_t;
+__device__ __attribute__((noinline)) bool ram_rank1_update(lds_dptr_t Scur, lds_dptr_t Salt, int LD_, int kf_, double w, int up_) {
+  const int lane = threadIdx.x & 63;
+  const int LD = __builtin_amdgcn_readfirstlane(LD_), kf = __builtin_amdgcn_readfirstlane(kf_);
+  const bool up = __builtin_amdgcn_readfirstlane(up_) != 0;
+  bool fail = false;
+  const int myrow = (lane < kf) ? lane : 0;
+  double lij_nx = Scur[myrow * LD], ljj_nx = Scur[0];
+  for (int j = 0; j < kf; j++) {
+    const double ljj = ljj_nx, lij = lij_nx;
+    const int jn = (j + 1 < kf) ? j + 1 : j;
+    lij_nx = Scur[myrow * LD + jn];
+    ljj_nx = Scur[jn * LD + jn];
+    const double xj = readlane_d(w, j);
+    double r2 = up ? fmh_fma(xj, xj, ljj * ljj) : fmh_fma(-xj, xj, ljj * ljj);
+    if (!(r2 > 0.0) || !fmh_isfinite(r2)) { fail = true; break; }
+    double r = fmh_sqrt(r2);
+    double cc = r / ljj, ss = xj / ljj;
+    const double ln = (up ? fmh_fma(ss, w, lij) : fmh_fma(-ss, w, lij)) / cc;
+    const bool below = lane > j && lane < kf;
+    w = below ? fmh_fma(-ss, ln, cc * w) : w;
+    if (lane >= j && lane < kf) Salt[lane * LD + j] = (lane == j) ? r : ln;
+  }
+  return fail;
+}
+
 template <int CW, int P, int OPT, int KIND, int FAM = 0, int MINB = 1>
 __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) {
   constexpr bool RESIDENT = (P >= 0);
@@ -468,28 +501,7 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
             const bool up = cp > 0.0;
             const double scl = fmh_sqrt(fmh_abs(cp));
             double w = (lane < kf) ? scl * L.vv[lane] : 0.0;
-            bool fail = false;
-            // One column per iteration, sequential in w.  What an iteration waits for is kept off its path: the column's
-            // entries come from LDS one iteration ahead, x_j is a v_readlane (not a ds_bpermute round trip), the row
-            // update is selects plus one store region (the old form: three LDS round trips and two exec regions per
-            // column, 25 us of the 85 us step at k = 50).
-            const int myrow = (lane < kf) ? lane : 0;
-            double lij_nx = Scur[myrow * LD], ljj_nx = Scur[0];
-            for (int j = 0; j < kf; j++) {
-              const double ljj = ljj_nx, lij = lij_nx;
-              const int jn = (j + 1 < kf) ? j + 1 : j;
-              lij_nx = Scur[myrow * LD + jn];
-              ljj_nx = Scur[jn * LD + jn];
-              const double xj = readlane_d(w, j);
-              double r2 = up ? fmh_fma(xj, xj, ljj * ljj) : fmh_fma(-xj, xj, ljj * ljj);
-              if (!(r2 > 0.0) || !fmh_isfinite(r2)) { fail = true; break; }
-              double r = fmh_sqrt(r2);
-              double cc = r / ljj, ss = xj / ljj;
-              const double ln = (up ? fmh_fma(ss, w, lij) : fmh_fma(-ss, w, lij)) / cc;
-              const bool below = lane > j && lane < kf;
-              w = below ? fmh_fma(-ss, ln, cc * w) : w;
-              if (lane >= j && lane < kf) Salt[lane * LD + j] = (lane == j) ? r : ln;
-            }
+            const bool fail = ram_rank1_update((lds_dptr_t)Scur, (lds_dptr_t)Salt, LD, kf, w, up ? 1 : 0);
             wave_sync();
             if (fail) {
               nerr += 1;
