@@ -153,6 +153,40 @@ __device__ __forceinline__ double wave_xor_sum(double v) {
 
 __device__ __forceinline__ double uniform_d(double v) { return sgpr_d(v); }
 
+// ---- kernel_ram: update of the lower factor in product form (twin of the oracle's scan_sq_canon / ram_factor_update_canon;
+// R/kernel_ram.R:136-146).  S (I + cp z z') S' = (S T)(S T)' with T = chol(I + sg p p') known in closed form (Gill, Golub,
+// Murray & Saunders 1974): beta_0 = sg, beta_{j+1} = beta_j + p_j^2, T_jj = d_j = sqrt(beta_{j+1} / beta_j), T_ij = p_i p_j /
+// (beta_j d_j).  So S'_ij = S_ij d_j + G_ij kappa_j, G_ij = sum_{m = j+1..i} S_im z_m, kappa_j = |cp| z_j / (beta_j d_j): the
+// square root and the two divisions of a column are independent of every other column (lane = column: one of each per
+// update instead of one dependent sqrt + two divisions PER COLUMN), and a row is two fma per element with G as its only
+// carried value.  The sequential rank-1 update this replaces was 17.7 us of the 62 us C4 step (k = 50).
+// Inclusive Hillis-Steele scan of q over the lanes, offsets 1, 2, 4, ...; lanes without a partner add +0 (q >= 0).
+__device__ __forceinline__ double lane_scan_row16(double q) {   // k <= 16: inside one DPP row, row_shr with zero fill
+  q = q + dpp_d<0x111>(q);
+  q = q + dpp_d<0x112>(q);
+  q = q + dpp_d<0x114>(q);
+  q = q + dpp_d<0x118>(q);
+  return q;
+}
+__device__ __forceinline__ double lane_scan_wave(double q) {    // k <= 64
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1) {
+    const double t = __shfl_up(q, s, 64);
+    q = q + ((lane >= s) ? t : 0.0);
+  }
+  return q;
+}
+// lane j: d_j and kappa_j from cp, Pj = sum_{b<j} z_b^2, Pj1 = Pj + z_j^2; false when the column is unusable
+__device__ __forceinline__ bool ram_coef(double cp, double Pj, double Pj1, double zj, double& d, double& kap) {
+  const double acp = fmh_abs(cp), sg = (cp > 0.0) ? 1.0 : -1.0;
+  const double b0 = fmh_fma(acp, Pj, sg), b1 = fmh_fma(acp, Pj1, sg);
+  const double rho = b1 / b0;
+  d = fmh_sqrt(rho);
+  kap = (acp * zj) / (b0 * d);
+  return (rho > 0.0) && fmh_isfinite(rho) && fmh_isfinite(kap);
+}
+
 // Split fp64 division.  The compiler expands a / b into v_div_scale x2, v_rcp_f64, two Newton steps on the reciprocal,
 // q0 = a r, e = fma(-b, q0, a), v_div_fmas (= fma(e, r, q0)), v_div_fixup.  With both operands positive, normal and
 // inside 2^-300 .. 2^300 the scale / fix-up instructions are identities, so r = div_recip(b) -- which depends on the
@@ -207,7 +241,7 @@ struct ChainLds {
   double* vmt;   // [kf] mean_t
   double* vrs;   // [kf] running sum of ans rows (adapt)
   double* SigA;  // [kf*LD]
-  double* SigB;  // [kf*LD] adapt: Cholesky factor; ram: the other buffer of S
+  double* SigB;  // [kf*LD] adapt: Cholesky factor (ram: not allocated)
   double* sc;    // scalars: 0 f0, 1 f1
   double* mmu;   // [k] mirror kernels: adapted mean
   double* msc;   // [k] mirror kernels: adapted scale
@@ -215,7 +249,7 @@ struct ChainLds {
 
 __host__ __device__ inline int chain_lds_doubles(int k, int kf, int kind) {
   int LD = kf | 1;
-  int mats = (kind == FMCMC_KERNEL_ADAPT || kind == FMCMC_KERNEL_RAM) ? 2 * kf * LD : 0;
+  int mats = (kind == FMCMC_KERNEL_ADAPT) ? 2 * kf * LD : (kind == FMCMC_KERNEL_RAM) ? kf * LD : 0;   // (ram: S is updated in place)
   int mir = (kind == FMCMC_KERNEL_NMIRROR || kind == FMCMC_KERNEL_UMIRROR) ? 2 * k : 0;
   return 2 * k + 5 * kf + mats + 4 + mir;
 }
@@ -233,7 +267,7 @@ __device__ __forceinline__ ChainLds chain_lds(double* base, int k, int kf, int k
   c.SigA = c.vrs + kf;
   int mats = (kind == FMCMC_KERNEL_ADAPT || kind == FMCMC_KERNEL_RAM) ? kf * LD : 0;
   c.SigB = c.SigA + mats;
-  c.sc = c.SigB + mats;
+  c.sc = c.SigB + ((kind == FMCMC_KERNEL_ADAPT) ? mats : 0);
   c.mmu = c.sc + 4;
   c.msc = c.mmu + k;
   return c;

@@ -68,12 +68,11 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
   long long abs_iter = 0;
   int nacc = 0, status = FMCMC_CHAIN_OK, thin_ctr = 0, have_mean = 0, nerr = 0;
   unsigned int srow8 = 0, bitword = 0;
-  double* Scur = SigA;
-  double* Salt = SigB;
+  double* const Scur = SigA;
   if (lane < k) { double t = A.theta0[(long long)cl * k + lane]; th0[lane] = t; th1[lane] = t; }
   for (int e = lane; e < kf * LD; e += 64) {
-    const int a = e / LD, b = e % LD;
-    SigA[e] = A.fresh ? ((a == b) ? 1.0 * A.eps : 0.0) : ((b < kf) ? A.Sigma[((long long)cl * kf + a) * kf + b] : 0.0);
+    const int a = e / LD, b = e % LD;   // (ram: S is a LOWER factor, anything above its diagonal is not part of it)
+    SigA[e] = A.fresh ? ((a == b) ? 1.0 * A.eps : 0.0) : ((b < kf && (b <= a || KIND == FMCMC_KERNEL_ADAPT)) ? A.Sigma[((long long)cl * kf + a) * kf + b] : 0.0);
     SigB[e] = 0.0;
   }
   if (!A.fresh) {
@@ -123,33 +122,29 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
           else if (a_n > 1.0) a_n = 1.0;
           double eta = (double)kf * fmh_exp((-2.0 / 3.0) * fmh_log((double)i));
           if (eta > 1.0) eta = 1.0;
-          double nrm2 = 0.0;
-          for (int b = 0; b < kf; b++) nrm2 = fmh_fma(vz[b], vz[b], nrm2);
+          // S <- S T in place (mh_common.hpp, ram_coef; twin of the oracle's ram_factor_update_canon)
+          const double zl = (lane < kf) ? vz[lane] : 0.0;
+          const double Pj1 = lane_scan_row16(zl * zl);
+          const double Pj = dpp_d<0x111>(Pj1);                 // row_shr:1, lane 0 reads 0
+          const double nrm2 = readlane_d(Pj1, kf - 1);
           double cp = (eta * (a_n - A.arate)) / nrm2;
           if (cp != 0.0 && fmh_isfinite(cp)) {
-            const bool up = cp > 0.0;
-            const double scl = fmh_sqrt(fmh_abs(cp));
-            double w = (lane < kf) ? scl * vv[lane] : 0.0;
-            bool fail = false;
-            for (int j = 0; j < kf; j++) {
-              double ljj = Scur[j * LD + j];
-              double xj = shfl_d(w, j);
-              double r2 = up ? fmh_fma(xj, xj, ljj * ljj) : fmh_fma(-xj, xj, ljj * ljj);
-              if (!(r2 > 0.0) || !fmh_isfinite(r2)) { fail = true; break; }
-              double r = fmh_sqrt(r2);
-              double cc = r / ljj, ss = xj / ljj;
-              if (lane == j) {
-                Salt[j * LD + j] = r;
-              } else if (lane > j && lane < kf) {
-                double lij = Scur[lane * LD + j];
-                double ln = (up ? fmh_fma(ss, w, lij) : fmh_fma(-ss, w, lij)) / cc;
-                w = fmh_fma(-ss, ln, cc * w);
-                Salt[lane * LD + j] = ln;
+            double dl, kl;
+            const bool okl = ram_coef(cp, Pj, Pj1, zl, dl, kl);
+            if (__any(lane < kf && !okl)) {
+              nerr += 1;
+            } else {
+              double* row = Scur + ((lane < kf) ? lane : 0) * LD;
+              double G = 0.0;
+              for (int j = kf - 1; j >= 0; j--) {
+                const double dj = readlane_d(dl, j), kj = readlane_d(kl, j), zj = readlane_d(zl, j);
+                const double sij = row[j];
+                const double nw = fmh_fma(G, kj, sij * dj);
+                G = fmh_fma(sij, zj, G);
+                if (lane < kf) row[j] = nw;
               }
+              wave_sync_lds();
             }
-            wave_sync_lds();
-            if (fail) nerr += 1;
-            else { double* t = Scur; Scur = Salt; Salt = t; }
           }
         }
         abs_iter += 1;
@@ -264,7 +259,6 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
           if (lane < kf) {
             double sacc = 0.0;
             for (int b = 0; b <= lane; b++) sacc = fmh_fma(Scur[lane * LD + b], vz[b], sacc);
-            vv[lane] = sacc;
             const int j = which[lane];
             th1[j] = th0[j] + sacc;
           }
@@ -328,10 +322,11 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
 #pragma unroll
   for (int b = 0; b < KA; b++) {
     Lrow[b] = 0.0;
-    Srow[b] = (rl && b < kf) ? (A.fresh ? ((b == lane) ? 1.0 * A.eps : 0.0) : A.Sigma[((long long)cl * kf + lane) * kf + b]) : 0.0;
+    Srow[b] = (rl && b < kf) ? (A.fresh ? ((b == lane) ? 1.0 * A.eps : 0.0)
+                                        : ((b <= lane || KIND == FMCMC_KERNEL_ADAPT) ? A.Sigma[((long long)cl * kf + lane) * kf + b] : 0.0)) : 0.0;
   }
   double th0 = rl ? A.theta0[(long long)cl * k + lane] : 0.0, th1 = th0;
-  double f0 = 0.0, mean_prev = 0.0, run_sum = 0.0, vv = 0.0, zcur = 0.0;
+  double f0 = 0.0, mean_prev = 0.0, run_sum = 0.0, zcur = 0.0;
   long long abs_iter = 0;
   int nacc = 0, status = FMCMC_CHAIN_OK, thin_ctr = 0, have_mean = 0, nerr = 0;
   unsigned int srow8 = 0, bitword = 0;
@@ -394,40 +389,28 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
           else if (a_n > 1.0) a_n = 1.0;
           double eta = (double)kf * fmh_exp((-2.0 / 3.0) * fmh_log((double)i));
           if (eta > 1.0) eta = 1.0;
-          double nrm2 = 0.0;
-#pragma unroll
-          for (int b = 0; b < KA; b++)
-            if (b < kf) { const double ub_ = readlane_d(zcur, b); nrm2 = fmh_fma(ub_, ub_, nrm2); }
+          // S <- S T (mh_common.hpp, ram_coef): square root and divisions once per update, lane = column; then row `lane`
+          // in registers, two fma per element, column values by v_readlane
+          const double Pj1 = lane_scan_row16(zcur * zcur);     // (zcur is 0 beyond the parameters)
+          const double Pj = dpp_d<0x111>(Pj1);                 // row_shr:1, lane 0 reads 0
+          const double nrm2 = readlane_d(Pj1, kf - 1);
           const double cp = (eta * (a_n - A.arate)) / nrm2;
           if (cp != 0.0 && fmh_isfinite(cp)) {
-            const bool up = cp > 0.0;
-            double w = rl ? fmh_sqrt(fmh_abs(cp)) * vv : 0.0;
-            double Snew[KA];
+            double dl, kl;
+            const bool okl = ram_coef(cp, Pj, Pj1, zcur, dl, kl);
+            if (__any(rl && !okl)) {
+              nerr += 1;
+            } else {
+              double G = 0.0;
 #pragma unroll
-            for (int b = 0; b < KA; b++) Snew[b] = Srow[b];
-            bool fail = false;
-#pragma unroll
-            for (int j = 0; j < KA; j++) {
-              if (j < kf && !fail) {
-                const double ljj = readlane_d(Srow[j], j);
-                const double xj = readlane_d(w, j);
-                const double r2 = up ? fmh_fma(xj, xj, ljj * ljj) : fmh_fma(-xj, xj, ljj * ljj);
-                if (!(r2 > 0.0) || !fmh_isfinite(r2)) {
-                  fail = true;
-                } else {
-                  const double r = fmh_sqrt(r2);
-                  const double cc = r / ljj, ss = xj / ljj;
-                  const double ln = (up ? fmh_fma(ss, w, Srow[j]) : fmh_fma(-ss, w, Srow[j])) / cc;
-                  const bool below = lane > j && rl;
-                  w = below ? fmh_fma(-ss, ln, cc * w) : w;
-                  Snew[j] = (lane == j) ? r : (below ? ln : Snew[j]);
+              for (int j = KA - 1; j >= 0; j--) {
+                if (j < kf) {
+                  const double dj = readlane_d(dl, j), kj = readlane_d(kl, j), zj = readlane_d(zcur, j);
+                  const double sij = Srow[j];
+                  Srow[j] = fmh_fma(G, kj, sij * dj);
+                  G = fmh_fma(sij, zj, G);
                 }
               }
-            }
-            if (fail) nerr += 1;
-            else {
-#pragma unroll
-              for (int b = 0; b < KA; b++) Srow[b] = Snew[b];
             }
           }
         }
@@ -516,7 +499,6 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
 #pragma unroll
           for (int b = 0; b < KA; b++)
             if (b < kf) { const double ub_ = readlane_d(zcur, b); sacc = fmh_fma(Srow[b], ub_, sacc); }   // (S is lower triangular: +-0 beyond the diagonal)
-          vv = sacc;
           th1 = th0 + sacc;
           ram_gate = (A.until > (double)abs_iter && abs_iter > A.warmup && ((v + 1) % A.freq) == 0);
         }

@@ -14,37 +14,26 @@ constexpr int RES_MASKED = 4;  // trailing observation slots that carry a validi
 // behind the runtime A.kind (streamed variants).
 // FAM > 0 compiles one model family in, MINB is the number of workgroups per CU the register allocation must allow
 // (the logistic model is bound by fp64 instruction issue: with 128 VGPRs two workgroups share a CU, 4 waves per SIMD).
-// kernel_ram's rank-1 update of the lower factor (twin of the oracle's chol_rank1_canon): Salt <- chol(Scur Scur' +- w w'),
-// lane = row, one column per iteration, sequential in w.  What an iteration waits for is kept off its path: the column's
-// entries come from LDS one iteration ahead, x_j is a v_readlane (not a ds_bpermute round trip), the row update is selects
-// plus one store region (the old form: three LDS round trips and two exec regions per column, 25 us of the 85 us step at
-// k = 50).  A REAL function on purpose: inlined into the sweep kernels the loop shares their register allocation, and the
-// instantiations that sit at 256 VGPRs spill inside it.  Returns true when the update fails (r^2 <= 0 or not finite;
-// R/kernel_ram.R:143).
+// kernel_ram's factor update S <- S T (mh_common.hpp, ram_coef): the rows, lane = row, in place.  d / kap / z hold d_j, kappa_j
+// and z_j in lane j (valid: every lane < kf passed ram_coef).  Per column one LDS read and write, three broadcasts by
+// v_readlane, one mul and two fma; the upper triangle is +0 and stays +0 (fma(+0, kappa, +0 d) = +0), so nothing is
+// predicated.  A REAL function on purpose: inlined into the sweep kernels the loop shares their register allocation, and
+// the instantiations that sit at 256 VGPRs spill inside it.
 typedef __attribute__((address_space(3))) double* lds_dptr_t;
-__device__ __attribute__((noinline)) bool ram_rank1_update(lds_dptr_t Scur, lds_dptr_t Salt, int LD_, int kf_, double w, int up_) {
+__device__ __attribute__((noinline)) void ram_factor_rows(lds_dptr_t S, int LD_, int kf_, double d, double kap, double z) {
   const int lane = threadIdx.x & 63;
   const int LD = __builtin_amdgcn_readfirstlane(LD_), kf = __builtin_amdgcn_readfirstlane(kf_);
-  const bool up = __builtin_amdgcn_readfirstlane(up_) != 0;
-  bool fail = false;
-  const int myrow = (lane < kf) ? lane : 0;
-  double lij_nx = Scur[myrow * LD], ljj_nx = Scur[0];
-  for (int j = 0; j < kf; j++) {
-    const double ljj = ljj_nx, lij = lij_nx;
-    const int jn = (j + 1 < kf) ? j + 1 : j;
-    lij_nx = Scur[myrow * LD + jn];
-    ljj_nx = Scur[jn * LD + jn];
-    const double xj = readlane_d(w, j);
-    double r2 = up ? fmh_fma(xj, xj, ljj * ljj) : fmh_fma(-xj, xj, ljj * ljj);
-    if (!(r2 > 0.0) || !fmh_isfinite(r2)) { fail = true; break; }
-    double r = fmh_sqrt(r2);
-    double cc = r / ljj, ss = xj / ljj;
-    const double ln = (up ? fmh_fma(ss, w, lij) : fmh_fma(-ss, w, lij)) / cc;
-    const bool below = lane > j && lane < kf;
-    w = below ? fmh_fma(-ss, ln, cc * w) : w;
-    if (lane >= j && lane < kf) Salt[lane * LD + j] = (lane == j) ? r : ln;
+  const lds_dptr_t row = S + ((lane < kf) ? lane : 0) * LD;
+  double G = 0.0;
+  double s_nx = row[kf - 1];
+  for (int j = kf - 1; j >= 0; j--) {
+    const double sij = s_nx;
+    s_nx = row[j > 0 ? j - 1 : 0];
+    const double dj = readlane_d(d, j), kj = readlane_d(kap, j), zj = readlane_d(z, j);
+    const double nw = fmh_fma(G, kj, sij * dj);
+    G = fmh_fma(sij, zj, G);
+    if (lane < kf) row[j] = nw;
   }
-  return fail;
 }
 
 template <int CW, int P, int OPT, int KIND, int FAM = 0, int MINB = 1>
@@ -184,8 +173,7 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
   const bool mirror = (A.kind == FMCMC_KERNEL_NMIRROR || A.kind == FMCMC_KERNEL_UMIRROR);
   double obs_arate = fmh_nan();   // mirror kernels
   long long nzero = 0;            // rows 2..i-1 of this call equal to their predecessor (rowSums(diff(ans)^2) == 0)
-  double* Scur = L.SigA;   // ram: current factor buffer
-  double* Salt = L.SigB;
+  double* const Scur = L.SigA;   // ram: the factor S
 
   if (owner) {
     if (lane < k) {
@@ -205,13 +193,14 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
         for (int e = lane; e < kf * LD; e += 64) {
           int a = e / LD, b = e % LD;
           L.SigA[e] = (a == b) ? 1.0 * A.eps : 0.0;
-          L.SigB[e] = 0.0;
+          if (A.kind == FMCMC_KERNEL_ADAPT) L.SigB[e] = 0.0;
         }
       } else {
         for (int e = lane; e < kf * LD; e += 64) {
           int a = e / LD, b = e % LD;
-          L.SigA[e] = (b < kf) ? A.Sigma[(cl * kf + a) * kf + b] : 0.0;
-          L.SigB[e] = 0.0;
+          // (ram: S is a LOWER factor; whatever the caller left above the diagonal is not part of it)
+          L.SigA[e] = (b < kf && (b <= a || A.kind == FMCMC_KERNEL_ADAPT)) ? A.Sigma[(cl * kf + a) * kf + b] : 0.0;
+          if (A.kind == FMCMC_KERNEL_ADAPT) L.SigB[e] = 0.0;
         }
         abs_iter = A.abs_iter[cl];
         if (A.nerrors) nerr = A.nerrors[cl];
@@ -468,7 +457,6 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
         if (lane < kf) {
           double s = 0.0;
           for (int b = 0; b <= lane; b++) s = fmh_fma(Scur[lane * LD + b], zt[b], s);
-          L.vv[lane] = s;
           int j = s_which[lane];
           L.th1[j] = L.th0[j] + s;
         }
@@ -494,19 +482,20 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
           else if (a_n > 1.0) a_n = 1.0;
           double eta = (double)kf * fmh_exp((-2.0 / 3.0) * fmh_log((double)i));
           if (eta > 1.0) eta = 1.0;
-          double nrm2 = 0.0;
-          for (int b = 0; b < kf; b++) nrm2 = fmh_fma(zt[b], zt[b], nrm2);
+          const double zl = (lane < kf) ? zt[lane] : 0.0;
+          const double Pj1 = lane_scan_wave(zl * zl);              // sum_{b <= lane} z_b^2
+          double Pj = __shfl_up(Pj1, 1, 64);
+          Pj = (lane == 0) ? 0.0 : Pj;
+          const double nrm2 = readlane_d(Pj1, kf - 1);
           double cp = (eta * (a_n - A.arate)) / nrm2;
           if (cp != 0.0 && fmh_isfinite(cp)) {
-            const bool up = cp > 0.0;
-            const double scl = fmh_sqrt(fmh_abs(cp));
-            double w = (lane < kf) ? scl * L.vv[lane] : 0.0;
-            const bool fail = ram_rank1_update((lds_dptr_t)Scur, (lds_dptr_t)Salt, LD, kf, w, up ? 1 : 0);
-            wave_sync();
-            if (fail) {
+            double dl, kl;
+            const bool okl = ram_coef(cp, Pj, Pj1, zl, dl, kl);
+            if (__any(lane < kf && !okl)) {
               nerr += 1;
             } else {
-              double* t = Scur; Scur = Salt; Salt = t;
+              ram_factor_rows((lds_dptr_t)Scur, LD, kf, dl, kl, zl);
+              wave_sync();
             }
           }
           if (A.constr) {  // Sigma <<- constr[which., which.] * Sigma (R/kernel_ram.R:149-150)

@@ -624,20 +624,48 @@ static int propose_adapt(const ocfg* cfg, const fmcmc_kernel* kn, kstate* ks, in
   return FMCMC_CHAIN_OK;
 }
 
-/* canonical rank-1 update/downdate of a lower factor: L L^T + sgn * w w^T. 0 ok, 1 failed. */
-static int chol_rank1_canon(double* L, double* w, int k, int sgn) {
+/* Canonical update of kernel_ram's lower factor (R/kernel_ram.R:136-146), in PRODUCT form:
+ *     S (I + cp z z^T) S^T = (S T)(S T)^T,   T = chol(I + sg p p^T),  p = sqrt|cp| z,  sg = sign(cp).
+ * The Cholesky factor of identity + rank one is known in closed form (Gill, Golub, Murray & Saunders 1974, "Methods
+ * for modifying matrix factorizations", method C1): with beta_0 = sg, beta_{j+1} = beta_j + p_j^2,
+ *     T_jj = d_j = sqrt(beta_{j+1} / beta_j),     T_ij = p_i p_j / (beta_j d_j)   (i > j),
+ * hence S'_ij = S_ij d_j + G_ij kappa_j with G_ij = sum_{m = j+1..i} S_im z_m and kappa_j = |cp| z_j / (beta_j d_j).
+ * Nothing sequential is left but two fma chains (the prefix sums of z^2, which also give |z|^2, and G along a row):
+ * the square roots and divisions are independent per column.  |cp| |z|^2 = eta |a_n - arate| < 1, so for a downdate
+ * every beta_j stays in [-1, -0.23]: the update cannot fail for finite input (the reference's chol() + nearPD path,
+ * R/kernel_ram.R:141-146, is never needed); non-finite input is reported as failure and leaves S untouched.
+ * Pz[j] = sum_{b<j} z_b^2 from scan_sq_canon below (Pz[k] = |z|^2), cp = eta (a_n - arate) / |z|^2.  0 ok, 1 failed. */
+/* Prefix sums of z^2 in the canonical order: q_j = z_j z_j, then a Hillis-Steele scan over the index with offsets
+ * 1, 2, 4, ... (every element adds the element `s` places below it, all at once) -- the order a 64-lane wavefront
+ * computes in log2(k) steps.  Pz[0] = 0, Pz[j + 1] = q_0 + ... + q_j. */
+static void scan_sq_canon(const double* z, int k, double* Pz) {
+  double q[MAXK], t[MAXK];
+  for (int j = 0; j < k; j++) q[j] = z[j] * z[j];
+  for (int s = 1; s < k; s <<= 1) {
+    for (int j = 0; j < k; j++) t[j] = (j >= s) ? q[j] + q[j - s] : q[j];
+    for (int j = 0; j < k; j++) q[j] = t[j];
+  }
+  Pz[0] = 0.0;
+  for (int j = 0; j < k; j++) Pz[j + 1] = q[j];
+}
+
+static int ram_factor_update_canon(double* L, const double* z, const double* Pz, double cp, int k) {
+  const double acp = fmh_abs(cp), sg = (cp > 0.0) ? 1.0 : -1.0;
+  double d[MAXK], kap[MAXK];
   for (int j = 0; j < k; j++) {
-    double ljj = L[j * k + j], xj = w[j];
-    double r2 = (sgn > 0) ? fmh_fma(xj, xj, ljj * ljj) : fmh_fma(-xj, xj, ljj * ljj);
-    if (!(r2 > 0.0) || !fmh_isfinite(r2)) return 1;
-    double r = fmh_sqrt(r2);
-    double c = r / ljj, s = xj / ljj;
-    L[j * k + j] = r;
-    for (int i = j + 1; i < k; i++) {
-      double lij = L[i * k + j];
-      double ln = ((sgn > 0) ? fmh_fma(s, w[i], lij) : fmh_fma(-s, w[i], lij)) / c;
-      w[i] = fmh_fma(-s, ln, c * w[i]);
-      L[i * k + j] = ln;
+    const double b0 = fmh_fma(acp, Pz[j], sg), b1 = fmh_fma(acp, Pz[j + 1], sg);
+    const double rho = b1 / b0;
+    if (!(rho > 0.0) || !fmh_isfinite(rho)) return 1;
+    d[j] = fmh_sqrt(rho);
+    kap[j] = (acp * z[j]) / (b0 * d[j]);
+    if (!fmh_isfinite(kap[j])) return 1;
+  }
+  for (int i = 0; i < k; i++) {
+    double G = 0.0;
+    for (int j = i; j >= 0; j--) {
+      const double sij = L[i * k + j];
+      L[i * k + j] = fmh_fma(G, kap[j], sij * d[j]);
+      G = fmh_fma(sij, z[j], G);
     }
   }
   return 0;
@@ -706,15 +734,13 @@ static int propose_ram(const ocfg* cfg, const fmcmc_model* m, const fmcmc_kernel
       else if (a_n > 1.0) a_n = 1.0;
       eta = (double)kf * fmh_exp((-2.0 / 3.0) * fmh_log((double)i));
       if (eta > 1.0) eta = 1.0;
-      double nrm2 = 0.0;
-      for (int a = 0; a < kf; a++) nrm2 = fmh_fma(U[a], U[a], nrm2);
-      double cp = (eta * (a_n - kn->arate)) / nrm2;
+      double Pz[MAXK + 1];
+      scan_sq_canon(U, kf, Pz);
+      double cp = (eta * (a_n - kn->arate)) / Pz[kf];
       if (cp != 0.0 && fmh_isfinite(cp)) {
-        double L[MAXK * MAXK], w[MAXK];
+        double L[MAXK * MAXK];
         memcpy(L, ks->Sigma, sizeof(double) * kf * kf);
-        double sc = fmh_sqrt(fmh_abs(cp));
-        for (int a = 0; a < kf; a++) w[a] = sc * v[a];
-        if (chol_rank1_canon(L, w, kf, cp > 0.0 ? 1 : -1)) ks->nerrors += 1;
+        if (ram_factor_update_canon(L, U, Pz, cp, kf)) ks->nerrors += 1;
         else memcpy(ks->Sigma, L, sizeof(double) * kf * kf);
       }
     }
