@@ -69,6 +69,8 @@ struct SweepArgs {
   double* sh_th;             // [k][nchains] proposals of all chains
   double* sh_part;           // [512][nchains] lane partials of all chains
   unsigned* sh_bar;          // barrier words, zeroed per launch (shard_barrier)
+  const double* sh_mfma;     // [G][sh_mblk] the slices once more, in fp64-MFMA operand layout (shard_columns_mfma), or NULL
+  int sh_mblk, sh_nmt;       // doubles per workgroup block; M-tiles of 16 observations per slice (1..3)
   // out
   double* samples;
   double* logpost;
@@ -505,9 +507,119 @@ __device__ __attribute__((noinline)) void shard_columns(ShardCols c) {
   }
 }
 
+// ---- step 2 on the matrix cores: mu[observation][chain] = b0 + X_slice . B as v_mfma_f64_16x16x4 tiles -------------------
+// One tile = 16 observations (M) x 16 chains (N) x 4 columns (K).  The instruction is BITWISE
+// fma(a3, b3, fma(a2, b2, fma(a1, b1, fma(a0, b0, C)))) per output (tools/mfma64_16x16_exact.hip), so K-blocks chained
+// through C in ascending column order ARE the canonical fma chain of an observation: same bits as shard_columns, the
+// streamed kernels and the oracle.  Operand layout (lane l): A[i = l % 16][kk = l / 16], B[kk = l / 16][j = l % 16],
+// D register r = row 4 r + l / 16, column l % 16 (probed).  So a lane GROUP g = l / 16 ends up with 4 rows per M-tile for chain
+// l % 16, and the slice is laid out (shard_build_mfma, mh_engine.hip) so that those rows are CONSECUTIVE SLOTS of one
+// canonical lane: group g works for canonical lane q = g / H of the slice (H = 4 / LPW groups per lane), its value
+// t = 4 mt + r (M-tile mt, register r) is slot spg h + t, h = g % H, spg = ceil(nslots / H) <= 10.  The r^2 chain of a
+// canonical lane therefore runs inside a lane in slot order; with H = 2 the second half continues from the partner
+// group's value (lane ^ 16).  Rows / columns beyond the data are 0 in A and masked out of the chain.
+// LDS block per workgroup (doubles), staged once per launch: [0, 32) validity bits (u32 per lane, bit t), [32, 32 + 12 x 64)
+// y in D layout [t][lane], then the A tiles [mt][kb][lane].
+constexpr int SHM_T = 12;                       // D values per lane and N-tile (3 M-tiles x 4 registers)
+constexpr int SHM_HDR = 32 + SHM_T * 64;        // doubles in front of the A tiles
+constexpr int SHM_KBMAX = 16;                   // K-blocks of 4 columns: p <= 64
+typedef double d4_t __attribute__((ext_vector_type(4)));
+struct ShardMfma {
+  const double* th;      // [k][NC + SH_PAD] proposals of all chains
+  double* part;          // [NC][NT + SH_PAD] lane partials
+  unsigned lds;          // LDS address of the block
+  int NC, p, ic, lane0, debug;
+};
+static_assert(sizeof(ShardMfma) <= 64, "ShardMfma must travel in registers (16 dwords)");
+template <int LPW, int NMT>
+__device__ __attribute__((noinline)) void shard_columns_mfma(ShardMfma c) {
+  const int lane = threadIdx.x & 63, wave = rfl_i((int)(threadIdx.x >> 6));
+  const int NC = rfl_i(c.NC), NCP = NC + SH_PAD, p = rfl_i(c.p), ic = rfl_i(c.ic), lane0 = rfl_i(c.lane0);
+  const int KB = (p + 3) >> 2;
+  const double* thg = (const double*)rfl_u64((unsigned long long)c.th);
+  double* part = (double*)rfl_u64((unsigned long long)c.part);
+  typedef __attribute__((address_space(3))) const double* ldsc_t;
+  typedef __attribute__((address_space(3))) const unsigned* ldsu_t;
+  const unsigned lbase = (unsigned)rfl_i((int)c.lds);
+  const ldsc_t blk = (ldsc_t)(unsigned long long)lbase;
+  const unsigned vmask = ((ldsu_t)(unsigned long long)lbase)[lane];
+  double ya[SHM_T];
+#pragma unroll
+  for (int t = 0; t < 4 * NMT; t++) ya[t] = blk[32 + 64 * t + lane];
+  const ldsc_t xa = blk + SHM_HDR + lane;       // tile (mt, kb) at xa[(mt KB + kb) 64]
+  const int kk = lane >> 4, j = lane & 15;
+  const int ntiles = (NC + 15) >> 4;
+  // B operand of N-tile T: coefficient column 4 kb + kk of chain 16 T + j; C operand: its intercept.  Written by other
+  // XCDs a barrier ago: every load is a miss of 1-3 us, so the next tile's are in flight under this tile's MFMAs.
+  double Bc[SHM_KBMAX], Bn[SHM_KBMAX], c0c = 0.0, c0n = 0.0;
+#define SHM_LOAD_B(T_, B_, c0_)                                                                          \
+  {                                                                                                      \
+    const int ch_ = 16 * (T_) + j;                                                                       \
+    const unsigned int chc_ = (unsigned int)(ch_ < NC ? ch_ : NC - 1);                                   \
+    c0_ = ic ? sh_load(thg + chc_) : 0.0;                                                                \
+    _Pragma("unroll") for (int kb = 0; kb < SHM_KBMAX; kb++) {                                           \
+      if (kb < KB) {                                                                                     \
+        const int col_ = 4 * kb + kk;                                                                    \
+        B_[kb] = sh_load(thg + ((unsigned int)((ic + (col_ < p ? col_ : p - 1)) * NCP) + chc_));         \
+      }                                                                                                  \
+    }                                                                                                    \
+  }
+#pragma unroll
+  for (int kb = 0; kb < SHM_KBMAX; kb++) { Bc[kb] = 0.0; Bn[kb] = 0.0; }
+  int T = wave;                                  // N-tiles round robin over the waves
+  if (T < ntiles) SHM_LOAD_B(T, Bc, c0c)
+  for (; T < ntiles; T += NW) {
+    if (T + NW < ntiles) SHM_LOAD_B(T + NW, Bn, c0n)
+    d4_t acc[NMT];
+#pragma unroll
+    for (int mt = 0; mt < NMT; mt++) acc[mt] = (d4_t){c0c, c0c, c0c, c0c};
+    double a_cur[NMT], a_nxt[NMT];
+#pragma unroll
+    for (int mt = 0; mt < NMT; mt++) a_cur[mt] = xa[(mt * KB) * 64];
+#pragma unroll
+    for (int kb = 0; kb < SHM_KBMAX; kb++) {
+      if (kb < KB) {
+        const int kn = (kb + 1 < KB) ? kb + 1 : kb;
+#pragma unroll
+        for (int mt = 0; mt < NMT; mt++) a_nxt[mt] = xa[(mt * KB + kn) * 64];
+        const double b = (4 * kb + kk < p) ? Bc[kb] : 0.0;    // (a padded column must not turn an infinite coefficient into NaN)
+#pragma unroll
+        for (int mt = 0; mt < NMT; mt++) acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[mt], b, acc[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < NMT; mt++) a_cur[mt] = a_nxt[mt];
+      }
+    }
+    double rr[4 * NMT];
+#pragma unroll
+    for (int t = 0; t < 4 * NMT; t++) rr[t] = ((vmask >> t) & 1u) ? ya[t] - acc[t >> 2][t & 3] : 0.0;   // fma(0, 0, a) == a exactly
+    double a = 0.0;
+#pragma unroll
+    for (int t = 0; t < 4 * NMT; t++) a = fmh_fma(rr[t], rr[t], a);
+    const int chain = 16 * T + j;
+    if constexpr (LPW == 2) {
+      double a2 = __shfl_xor(a, 16, 64);          // groups 1 and 3 continue where groups 0 and 2 stopped
+#pragma unroll
+      for (int t = 0; t < 4 * NMT; t++) a2 = fmh_fma(rr[t], rr[t], a2);
+      const double a_hi = __shfl_xor(a2, 32, 64); // canonical lane 1 of the slice (group 3) next to lane 0 (group 1)
+      if (kk == 1 && chain < NC) {
+        double* dst = &part[(long long)chain * (NT + SH_PAD) + lane0];
+        sh_store(dst, a2);
+        sh_store(dst + 1, a_hi);
+      }
+    } else {
+      if (chain < NC) sh_store(&part[(long long)chain * (NT + SH_PAD) + lane0 + kk], a);
+    }
+#pragma unroll
+    for (int kb = 0; kb < SHM_KBMAX; kb++) Bc[kb] = Bn[kb];
+    c0c = c0n;
+  }
+#undef SHM_LOAD_B
+}
+
 // lane partials acc[c] of canonical lane `tid` for the CW chains of this workgroup, via the sharded evaluation
 template <int CW, int LPW>
-__device__ __forceinline__ bool eval_sharded(const SweepArgs& A, double* const* th, double (&acc)[CW], unsigned& epoch) {
+__device__ __forceinline__ bool eval_sharded(const SweepArgs& A, double* const* th, double (&acc)[CW], unsigned& epoch,
+                                             const double* s_mblk /* LDS block of the MFMA form, or NULL */) {
   const int tid = threadIdx.x;
   const int NC = (int)A.nchains, NCP = NC + SH_PAD, p = A.p, ic = A.intercept, nb = ic + p;
   const long long cg0 = (long long)blockIdx.x * CW;
@@ -528,6 +640,14 @@ __device__ __forceinline__ bool eval_sharded(const SweepArgs& A, double* const* 
   sc.ys = A.sh_ys + (long long)blockIdx.x * SH_MAXO;
   sc.th = A.sh_th; sc.part = A.sh_part; sc.n = A.n; sc.NC = NC; sc.p = p; sc.ic = ic; sc.nslots = A.sh_nslots;
   sc.lane0 = (int)blockIdx.x * LPW; sc.debug = A.debug;
+  if (s_mblk) {
+    ShardMfma sm;
+    sm.th = A.sh_th; sm.part = A.sh_part; sm.NC = NC; sm.p = p; sm.ic = ic; sm.lane0 = (int)blockIdx.x * LPW; sm.debug = A.debug;
+    sm.lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const double*)s_mblk;
+    if (A.sh_nmt == 1) shard_columns_mfma<LPW, 1>(sm);
+    else if (A.sh_nmt == 2) shard_columns_mfma<LPW, 2>(sm);
+    else shard_columns_mfma<LPW, 3>(sm);
+  } else
   if (A.sh_nslots * LPW <= SH_MAXO / 2) shard_columns<LPW, SH_MAXO / 2>(sc);   // half-empty slices: half the FMAs
   else shard_columns<LPW, SH_MAXO>(sc);
   if (!(A.debug & 32) && !(epoch & LOST)) { ok = shard_barrier(A.sh_bar, ++epoch); if (!ok) epoch |= LOST; }
@@ -545,7 +665,7 @@ __device__ __forceinline__ bool eval_sharded(const SweepArgs& A, double* const* 
 // FAM > 0 compiles one family in (leaner kernels for the logistic model), FAM == 0 keeps all behind A.family.
 template <int CW, int FAM = 0, int SHL = 0 /* > 0: observation-sharded evaluation, SHL canonical lanes per workgroup */>
 __device__ __forceinline__ void eval_partials(const SweepArgs& A, double* const* th /*[CW] -> theta in LDS*/,
-                                              double* s_part, const double* s_sptab = nullptr /* softplus tables in LDS */,
+                                              double* s_part, const double* s_sptab = nullptr /* LDS: softplus tables (logistic) / MFMA slice block (sharded linreg) */,
                                               unsigned* sh_epoch = nullptr /* barrier epoch of the sharded evaluation */) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long long n = A.n;
@@ -693,7 +813,7 @@ __device__ __forceinline__ void eval_partials(const SweepArgs& A, double* const*
       }
     }
   } else if constexpr (FAM == FMCMC_FAM_GAUSSIAN_LINREG && CW <= 2 && SHL > 0) {
-    const bool ok = eval_sharded<CW, SHL>(A, th, acc, *sh_epoch);
+    const bool ok = eval_sharded<CW, SHL>(A, th, acc, *sh_epoch, s_sptab);
     if (!ok && tid == 0 && (long long)blockIdx.x * CW < A.nchains)      // (a workgroup without chains has no status slot)
       A.status[(long long)blockIdx.x * CW] = FMCMC_CHAIN_SYNC_TIMEOUT;
   } else {

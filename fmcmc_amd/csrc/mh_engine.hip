@@ -85,6 +85,44 @@ __global__ void shard_build_slices(const double* X, const double* y, long long n
   }
 }
 
+// the same slices in fp64-MFMA operand layout (mh_common.hpp, shard_columns_mfma): per workgroup a block of
+// SHM_HDR + nmt KB 64 doubles = validity bits | y in D layout | A tiles [mt][kb][lane]
+__global__ void shard_build_mfma(const double* X, const double* y, long long n, int p, int lpw, int nslots, int nmt,
+                                 double* out, int blk_doubles) {
+  const int b = blockIdx.x, KB = (p + 3) >> 2, H = 4 / lpw, spg = (nslots + H - 1) / H;
+  double* o = out + (long long)b * blk_doubles;
+  auto obs_of = [&](int g, int t) -> long long {   // observation at D position (lane group g, value t), -1: none
+    const int q = g / H, h = g % H;
+    if (t >= spg) return -1;
+    const int slot = spg * h + t;
+    if (slot >= nslots) return -1;
+    const long long i = (long long)b * lpw + q + (long long)NT * slot;
+    return i < n ? i : -1;
+  };
+  for (int idx = threadIdx.x; idx < blk_doubles; idx += blockDim.x) {
+    if (idx < 32) {
+      unsigned w[2];
+      for (int e = 0; e < 2; e++) {
+        const int g = (2 * idx + e) >> 4;
+        unsigned m = 0;
+        for (int t = 0; t < SHM_T; t++) if (obs_of(g, t) >= 0) m |= 1u << t;
+        w[e] = m;
+      }
+      ((unsigned*)o)[2 * idx] = w[0];
+      ((unsigned*)o)[2 * idx + 1] = w[1];
+    } else if (idx < SHM_HDR) {
+      const int t = (idx - 32) >> 6, lane = (idx - 32) & 63;
+      const long long i = obs_of(lane >> 4, t);
+      o[idx] = i >= 0 ? y[i] : 0.0;
+    } else {
+      const int e = idx - SHM_HDR, lane = e & 63, kb = (e >> 6) % KB, mt = (e >> 6) / KB;
+      const int row = lane & 15, kk = lane >> 4, col = 4 * kb + kk;
+      const long long i = obs_of(row & 3, 4 * mt + (row >> 2));   // D register r of lane group g is row 4 r + g of the tile
+      o[idx] = (i >= 0 && col < p && mt < nmt) ? X[(long long)col * n + i] : 0.0;
+    }
+  }
+}
+
 size_t sweep_lds_bytes(int k, int kf, int kind, int CW, int tb, int kz, bool resident) {
   size_t d = 4 * (size_t)k + (k / 2 + 1) + (size_t)NW * CW + 1 + (size_t)CW * tb * (kz + 1) +
              (resident ? (size_t)CW * NT : 0) + (size_t)CW * chain_lds_doubles(k, kf, kind);
@@ -238,6 +276,10 @@ static SweepArgs chain_window(const SweepArgs& A, long long off, long long cnt, 
 // rate); sharded ~14 of hand-overs and fixed work + 0.0085 per column and walked observation slot (+ ~6 of barrier
 // imbalance under kernel_ram): n = 2500 loses (23.9 vs 19.1), n = 5000 wins (24.3 vs 30.1), C4 wins 2x.
 // FMCMC_AMD_SHARD=1 forces the sharded kernel for every eligible shape (tests), =0 disables it.
+static bool shard_mfma_enabled() {   // FMCMC_AMD_SHARD_MFMA=0: the VALU form of the slice product (A/B partner)
+  const char* e = getenv("FMCMC_AMD_SHARD_MFMA");
+  return !(e && e[0] == '0');
+}
 static int wide_sharded_lanes(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_run* run, int ram_bounded, int ncu, long long nb) {
   const char* shenv = getenv("FMCMC_AMD_SHARD");
   if (shenv && shenv[0] == '0') return 0;
@@ -249,7 +291,7 @@ static int wide_sharded_lanes(const fmcmc_model* m, const fmcmc_kernel* kn, cons
   // A slice of more than 49 columns (15.5 KB) no longer stays in the scalar cache: 2.1x per walked slot, still ahead for the
   // normal kernels (k = 64, n = 10k: 57 us per step against 78); kernel_ram stays chain-sharded there, its owner phase
   // dominates at that width and runs slower in the sharded instantiation (121 against 108).
-  const bool cached = (size_t)m->p * SH_MAXO * sizeof(double) <= 15872;
+  const bool cached = shard_mfma_enabled() || (size_t)m->p * SH_MAXO * sizeof(double) <= 15872;   // (the MFMA form keeps the slice in LDS)
   const bool ok = lpw > 0 && !(kn->kind == FMCMC_KERNEL_RAM && (ram_bounded || !cached)) && lpw * nslots <= SH_MAXO && nb <= ncu &&
                   (long long)m->p * SH_MAXO * nb < (1ll << 28) && (long long)(m->p + 1) * (per_launch + SH_PAD) < (1ll << 31) &&
                   run->nsteps < 30000000;   /* barrier epochs (2 per step) x workgroups per group stay below 2^32 */
@@ -549,6 +591,13 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
     if (A.debug & 256) fprintf(stderr, "fmcmc_amd: wide path nblk=%lld lpw=%d nslots=%d p=%d bounded=%d shard=%d\n", nblk, lpw, nslots, m->p, (int)ram_bounded, (int)shard);
     double* shw = nullptr;
     g_kernel = shard ? "streamed-wide-sharded" : "streamed-wide";
+    // the slice product on the matrix cores (shard_columns_mfma): the slice lives in LDS behind the chain blocks
+    const int mf_spg = shard ? (nslots + 4 / lpw - 1) / (4 / lpw) : 0, nmt = (mf_spg + 3) / 4;
+    const int mblk = SHM_HDR + nmt * ((m->p + 3) / 4) * 64;
+    bool mfma_form = shard && shard_mfma_enabled() && m->p <= 4 * SHM_KBMAX && mf_spg <= SHM_T &&
+                     lds + sizeof(double) * (size_t)(mblk + 1) <= 160 * 1024;
+    if (mfma_form) lds += sizeof(double) * (size_t)(mblk + 1);
+    if (shard) g_kernel = mfma_form ? "streamed-wide-sharded-mfma" : "streamed-wide-sharded";
     if (shard) {
       int coop = 0, perCU = 0;
       (void)hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev);
@@ -558,18 +607,27 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
         if (A.debug & 256) fprintf(stderr, "fmcmc_amd: sharded evaluation not launched: err=%d coop=%d perCU=%d lds=%zu\n", (int)e, coop, perCU, lds);
         shard = false;
         g_kernel = "streamed-wide";
+        if (mfma_form) lds -= sizeof(double) * (size_t)(mblk + 1);
       }
       e = hipSuccess;
     }
     if (shard) {
-      const size_t nxs = (size_t)nb_launch * m->p * SH_MAXO, nys = (size_t)nb_launch * SH_MAXO, nth = (size_t)kn->k * (ch_launch + SH_PAD),
+      const size_t nxs = mfma_form ? 0 : (size_t)nb_launch * m->p * SH_MAXO, nys = mfma_form ? 0 : (size_t)nb_launch * SH_MAXO, nth = (size_t)kn->k * (ch_launch + SH_PAD),
                    npt = (size_t)(NT + SH_PAD) * ch_launch, nbar = 32 * 20 / 2;   // (barrier words counted in doubles)
-      e = hipMallocAsync((void**)&shw, sizeof(double) * (nxs + nys + nth + npt + nbar), stream);
+      const size_t nmf = mfma_form ? (size_t)nb_launch * mblk : 0;
+      e = hipMallocAsync((void**)&shw, sizeof(double) * (nxs + nys + nth + npt + nbar + nmf), stream);
       if (e != hipSuccess) { set_err("hipMallocAsync(sharded evaluation) failed: %s", hipGetErrorString(e)); return FMCMC_ERR_DEVICE; }
       double* xs = shw; double* ys = xs + nxs; double* thw = ys + nys; double* ptw = thw + nth;
       unsigned* bar = (unsigned*)(ptw + npt);
-      hipLaunchKernelGGL(shard_build_slices, dim3((unsigned)nb_launch), dim3(256), 0, stream, m->X, m->y, (long long)m->n, m->p, lpw, nslots, xs, ys);
+      if (!mfma_form)
+        hipLaunchKernelGGL(shard_build_slices, dim3((unsigned)nb_launch), dim3(256), 0, stream, m->X, m->y, (long long)m->n, m->p, lpw, nslots, xs, ys);
       A.shard = lpw; A.sh_nslots = nslots; A.sh_xs = xs; A.sh_ys = ys; A.sh_th = thw; A.sh_part = ptw; A.sh_bar = bar;
+      if (mfma_form) {
+        double* mf = ptw + npt + nbar;
+        hipLaunchKernelGGL(shard_build_mfma, dim3((unsigned)nb_launch), dim3(256), 0, stream, m->X, m->y, (long long)m->n, m->p, lpw, nslots,
+                           nmt, mf, mblk);
+        A.sh_mfma = mf; A.sh_mblk = mblk; A.sh_nmt = nmt;
+      }
       long long done = 0;
       for (; done < run->nchains && e == hipSuccess; done += ch_launch) {   // (the slices and tables serve every launch)
         SweepArgs W = chain_window(A, done, (run->nchains - done < ch_launch) ? run->nchains - done : ch_launch, kf);
@@ -584,6 +642,8 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
         shard = false;
         g_kernel = "streamed-wide";
         A.shard = 0; A.sh_xs = nullptr; A.sh_ys = nullptr; A.sh_th = nullptr; A.sh_part = nullptr; A.sh_bar = nullptr;
+        A.sh_mfma = nullptr; A.sh_mblk = 0; A.sh_nmt = 0;
+        if (mfma_form) lds -= sizeof(double) * (size_t)(mblk + 1);
       }
     }
     if (shard) {

@@ -82,6 +82,14 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
     softplus_stage_tables(tabs);
     s_sptab = tabs;
   }
+  if constexpr (FAM == FMCMC_FAM_GAUSSIAN_LINREG && P < 0 && OPT > 0) {
+    if (A.sh_mfma) {   // observation-sharded evaluation on the matrix cores: this workgroup's slice in operand layout
+      double* blk = s_chains + CW * CHS + ((CW * CHS) & 1);
+      const double* src = A.sh_mfma + (long long)blockIdx.x * A.sh_mblk;
+      for (int i = tid; i < A.sh_mblk; i += NT) blk[i] = src[i];
+      s_sptab = blk;
+    }
+  }
   const long long cg0 = (long long)blockIdx.x * CW;  // first local chain of this workgroup
   const int ncw = (int)((A.nchains - cg0 < CW) ? (A.nchains - cg0) : CW);
   const bool adaptive = (A.kind == FMCMC_KERNEL_ADAPT || A.kind == FMCMC_KERNEL_RAM);

@@ -581,7 +581,7 @@ def test_observation_sharded_evaluation(E, O, monkeypatch, chains, cw, n, p, int
     monkeypatch.setenv("FMCMC_AMD_SHARD", "1")      # every eligible shape, also where the cost model prefers chain-sharded
     nb = p + (1 if intercept else 0)
     # co-residency needs one CU per workgroup of the launch (256, or exactly 128): a partitioned GPU falls back
-    sharded = "streamed-wide-sharded" if torch.cuda.get_device_properties(0).multi_processor_count >= 256 else "streamed-wide"
+    sharded = "streamed-wide-sharded-mfma" if torch.cuda.get_device_properties(0).multi_processor_count >= 256 else "streamed-wide"
     X, y = synth_linreg(n, p, 9100 + n + p, beta=np.linspace(1.0, -1.0, p + 1))
     init = jitter_init(list(np.linspace(1.0, -1.0, p + 1))[(0 if intercept else 1):] + [4.0], chains, n + p)
     init[:, -1] = np.abs(init[:, -1])
@@ -591,7 +591,7 @@ def test_observation_sharded_evaluation(E, O, monkeypatch, chains, cw, n, p, int
     run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL_REFLECTIVE, nb + 1, init, nsteps=16, scale=0.2, lb=-3.0, ub=6.0, **kw)
     assert abi.last_kernel() == sharded
     a, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, nb + 1, init, nsteps=24, calls=2, **kw)
-    assert abi.last_kernel() == (sharded if p <= 49 else "streamed-wide")     # kernel_ram beyond 49 columns stays chain-sharded
+    assert abi.last_kernel() == sharded
     monkeypatch.setenv("FMCMC_AMD_SHARD", "0")
     b, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, nb + 1, init, nsteps=24, calls=2, **kw)
     assert abi.last_kernel() == "streamed-wide"
@@ -618,7 +618,7 @@ def test_observation_sharded_long_run_equals_chain_sharded(E, monkeypatch):
         r = E.sweep(gm, gk, st, 400, seed=77, check=True)
         torch.cuda.synchronize()
         if torch.cuda.get_device_properties(0).multi_processor_count >= 256:
-            assert abi.last_kernel() == ("streamed-wide-sharded" if sh == "1" else "streamed-wide")
+            assert abi.last_kernel() == ("streamed-wide-sharded-mfma" if sh == "1" else "streamed-wide")
         outs.append([t.cpu().numpy() for t in (r.samples, r.logpost, r.draws, r.accept_count, st.Sigma, st.theta0)])
     for u, v in zip(*outs):
         assert _bits_equal(u, v) if u.dtype == np.float64 else np.array_equal(u, v)
@@ -753,7 +753,7 @@ def test_randomised_sharded_shapes(E, O, monkeypatch):
         picked.append(abi.last_kernel())
     assert all(name.startswith("streamed-wide") for name in picked), picked
     if torch.cuda.get_device_properties(0).multi_processor_count >= 256:
-        assert sum(name == "streamed-wide-sharded" for name in picked) >= 12, picked
+        assert sum(name == "streamed-wide-sharded-mfma" for name in picked) >= 12, picked
 
 
 def test_sharded_evaluation_with_failing_chains(E, O, monkeypatch):
@@ -774,7 +774,7 @@ def test_sharded_evaluation_with_failing_chains(E, O, monkeypatch):
     scale = np.full(p + 2, 0.001); scale[-1] = 0.05
     rg, ro = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, p + 2, init, nsteps=40, guard=False, scale=scale)
     if torch.cuda.get_device_properties(0).multi_processor_count >= 256:
-        assert abi.last_kernel() == "streamed-wide-sharded"
+        assert abi.last_kernel() == "streamed-wide-sharded-mfma"
     assert (ro.status == 1).sum() >= 10 and (ro.status == 0).sum() >= 200
     assert np.array_equal(rg.status_step.cpu().numpy(), ro.status_step)
     with pytest.raises(RuntimeError, match="undefined"):
@@ -988,7 +988,7 @@ def test_sharded_evaluation_in_consecutive_launches(E, O, monkeypatch, kind_name
     opts = dict(scale=0.01, fixed=[False] * 3 + [True] + [False] * (p - 2)) if kind_name == "normal" else {}
     a, _ = run_both(E, O, O.FAM_LINREG, X, y, kind, p + 2, init, nsteps=16, burnin=1, thin=2, calls=2, chain_base=40, **opts)
     if torch.cuda.get_device_properties(0).multi_processor_count >= 256:
-        assert abi.last_kernel() == "streamed-wide-sharded"
+        assert abi.last_kernel() == "streamed-wide-sharded-mfma"
     monkeypatch.setenv("FMCMC_AMD_SHARD", "0")
     b, _ = run_both(E, O, O.FAM_LINREG, X, y, kind, p + 2, init, nsteps=16, burnin=1, thin=2, calls=2, chain_base=40, **opts)
     assert abi.last_kernel() in ("streamed-wide", "streamed")
