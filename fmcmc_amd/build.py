@@ -20,16 +20,19 @@ def needs_build():
     return any(os.path.exists(f) and os.path.getmtime(f) > t for f in SRC + DEPS)
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
-        return OUT
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+def build(force=False, verbose=False, extra_flags=(), out=None):
+    """extra_flags / out: diagnostic variants next to the product library (e.g. -DFMCMC_STAMP -> lib/libfmcmc_amd_stamp.so,
+    loaded through FMCMC_AMD_LIB by tools/stamp_wide.py)."""
+    out = out or OUT
+    if not force and not extra_flags and not needs_build():
+        return out
+    os.makedirs(os.path.dirname(out), exist_ok=True)
     src = [s for s in SRC if os.path.exists(s)]
-    cmd = [HIPCC] + FLAGS + src + ["-o", OUT]
+    cmd = [HIPCC] + FLAGS + list(extra_flags) + src + ["-o", out]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":

@@ -155,6 +155,20 @@ __device__ __forceinline__ double wave_xor_sum(double v) {
 
 __device__ __forceinline__ double uniform_d(double v) { return sgpr_d(v); }
 
+// Diagnostic build only (-DFMCMC_STAMP, tools/stamp_wide.py): s_memtime shares of the phases of a step, wave 0 of every
+// workgroup, written over status_theta at the end of the sweep.  Compiled out of the product library.
+struct Stamps { unsigned long long acc[16]; unsigned long long prev; };
+#ifdef FMCMC_STAMP
+__device__ __forceinline__ unsigned long long stamp_clk() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  return t;
+}
+#define FMH_STAMP(S, i) do { if ((S) && (threadIdx.x >> 6) == 0) { const unsigned long long t_ = stamp_clk(); (S)->acc[i] += t_ - (S)->prev; (S)->prev = t_; } } while (0)
+#else
+#define FMH_STAMP(S, i) do { } while (0)
+#endif
+
 // ---- kernel_ram: update of the lower factor in product form (twin of the oracle's scan_sq_canon / ram_factor_update_canon;
 // R/kernel_ram.R:136-146).  S (I + cp z z') S' = (S T)(S T)' with T = chol(I + sg p p') known in closed form (Gill, Golub,
 // Murray & Saunders 1974): beta_0 = sg, beta_{j+1} = beta_j + p_j^2, T_jj = d_j = sqrt(beta_{j+1} / beta_j), T_ij = p_i p_j /
@@ -243,7 +257,7 @@ struct ChainLds {
   double* vmt;   // [kf] mean_t
   double* vrs;   // [kf] running sum of ans rows (adapt)
   double* SigA;  // [kf*LD]
-  double* SigB;  // [kf*LD] adapt: Cholesky factor (ram: not allocated)
+  double* SigB;  // [kf*LD] adapt: Cholesky factor; ram: G, the partial sums of the proposal's S U chains
   double* sc;    // scalars: 0 f0, 1 f1
   double* mmu;   // [k] mirror kernels: adapted mean
   double* msc;   // [k] mirror kernels: adapted scale
@@ -251,7 +265,7 @@ struct ChainLds {
 
 __host__ __device__ inline int chain_lds_doubles(int k, int kf, int kind) {
   int LD = kf | 1;
-  int mats = (kind == FMCMC_KERNEL_ADAPT) ? 2 * kf * LD : (kind == FMCMC_KERNEL_RAM) ? kf * LD : 0;   // (ram: S is updated in place)
+  int mats = (kind == FMCMC_KERNEL_ADAPT || kind == FMCMC_KERNEL_RAM) ? 2 * kf * LD : 0;   // (ram: S, updated in place, and G)
   int mir = (kind == FMCMC_KERNEL_NMIRROR || kind == FMCMC_KERNEL_UMIRROR) ? 2 * k : 0;
   return 2 * k + 5 * kf + mats + 4 + mir;
 }
@@ -269,7 +283,7 @@ __device__ __forceinline__ ChainLds chain_lds(double* base, int k, int kf, int k
   c.SigA = c.vrs + kf;
   int mats = (kind == FMCMC_KERNEL_ADAPT || kind == FMCMC_KERNEL_RAM) ? kf * LD : 0;
   c.SigB = c.SigA + mats;
-  c.sc = c.SigB + ((kind == FMCMC_KERNEL_ADAPT) ? mats : 0);
+  c.sc = c.SigB + mats;
   c.mmu = c.sc + 4;
   c.msc = c.mmu + k;
   return c;
@@ -619,7 +633,7 @@ __device__ __attribute__((noinline)) void shard_columns_mfma(ShardMfma c) {
 // lane partials acc[c] of canonical lane `tid` for the CW chains of this workgroup, via the sharded evaluation
 template <int CW, int LPW>
 __device__ __forceinline__ bool eval_sharded(const SweepArgs& A, double* const* th, double (&acc)[CW], unsigned& epoch,
-                                             const double* s_mblk /* LDS block of the MFMA form, or NULL */) {
+                                             const double* s_mblk /* LDS block of the MFMA form, or NULL */, Stamps* stp = nullptr) {
   const int tid = threadIdx.x;
   const int NC = (int)A.nchains, NCP = NC + SH_PAD, p = A.p, ic = A.intercept, nb = ic + p;
   const long long cg0 = (long long)blockIdx.x * CW;
@@ -633,7 +647,9 @@ __device__ __forceinline__ bool eval_sharded(const SweepArgs& A, double* const* 
   //  epoch marks the sweep as lost, its remaining steps run through without barriers and the host raises.)
   constexpr unsigned LOST = 0x80000000u;
   bool ok = true;
+  FMH_STAMP(stp, 3);
   if (!(A.debug & 32) && !(epoch & LOST)) { ok = shard_barrier(A.sh_bar, ++epoch); if (!ok) epoch |= LOST; }
+  FMH_STAMP(stp, 4);
   // 2. thread = chain: the slice's observations for that chain
   ShardCols sc;
   sc.xs = A.sh_xs + (long long)blockIdx.x * p * SH_MAXO;
@@ -650,7 +666,9 @@ __device__ __forceinline__ bool eval_sharded(const SweepArgs& A, double* const* 
   } else
   if (A.sh_nslots * LPW <= SH_MAXO / 2) shard_columns<LPW, SH_MAXO / 2>(sc);   // half-empty slices: half the FMAs
   else shard_columns<LPW, SH_MAXO>(sc);
+  FMH_STAMP(stp, 5);
   if (!(A.debug & 32) && !(epoch & LOST)) { ok = shard_barrier(A.sh_bar, ++epoch); if (!ok) epoch |= LOST; }
+  FMH_STAMP(stp, 6);
   ok = !(epoch & LOST);
   // 3. thread = canonical lane: its partial of this workgroup's chains
 #pragma unroll
@@ -666,7 +684,7 @@ __device__ __forceinline__ bool eval_sharded(const SweepArgs& A, double* const* 
 template <int CW, int FAM = 0, int SHL = 0 /* > 0: observation-sharded evaluation, SHL canonical lanes per workgroup */>
 __device__ __forceinline__ void eval_partials(const SweepArgs& A, double* const* th /*[CW] -> theta in LDS*/,
                                               double* s_part, const double* s_sptab = nullptr /* LDS: softplus tables (logistic) / MFMA slice block (sharded linreg) */,
-                                              unsigned* sh_epoch = nullptr /* barrier epoch of the sharded evaluation */) {
+                                              unsigned* sh_epoch = nullptr /* barrier epoch of the sharded evaluation */, Stamps* stp = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long long n = A.n;
   const int family = FAM ? FAM : A.family;
@@ -813,7 +831,7 @@ __device__ __forceinline__ void eval_partials(const SweepArgs& A, double* const*
       }
     }
   } else if constexpr (FAM == FMCMC_FAM_GAUSSIAN_LINREG && CW <= 2 && SHL > 0) {
-    const bool ok = eval_sharded<CW, SHL>(A, th, acc, *sh_epoch, s_sptab);
+    const bool ok = eval_sharded<CW, SHL>(A, th, acc, *sh_epoch, s_sptab, stp);
     if (!ok && tid == 0 && (long long)blockIdx.x * CW < A.nchains)      // (a workgroup without chains has no status slot)
       A.status[(long long)blockIdx.x * CW] = FMCMC_CHAIN_SYNC_TIMEOUT;
   } else {

@@ -135,13 +135,12 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
               nerr += 1;
             } else {
               double* row = Scur + ((lane < kf) ? lane : 0) * LD;
-              double G = 0.0;
-              for (int j = kf - 1; j >= 0; j--) {
-                const double dj = readlane_d(dl, j), kj = readlane_d(kl, j), zj = readlane_d(zl, j);
+              const double* grow = SigB + ((lane < kf) ? lane : 0) * LD;   // G_ij, kept by the proposal
+              for (int j = 0; j < kf; j++) {
+                const double dj = readlane_d(dl, j), kj = readlane_d(kl, j);
                 const double sij = row[j];
-                const double nw = fmh_fma(G, kj, sij * dj);
-                G = fmh_fma(sij, zj, G);
-                if (lane < kf) row[j] = nw;
+                const double nw = fmh_fma(grow[j], kj, sij * dj);
+                if (lane >= j && lane < kf) row[j] = nw;
               }
               wave_sync_lds();
             }
@@ -258,7 +257,10 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
         } else {  // RAM P1 :123-126 (theta1 keeps its previous values in fixed coordinates)
           if (lane < kf) {
             double sacc = 0.0;
-            for (int b = 0; b <= lane; b++) sacc = fmh_fma(Scur[lane * LD + b], vz[b], sacc);
+            for (int b = lane; b >= 0; b--) {   // from the diagonal down to column 0, keeping the partial sums G_ib
+              SigB[lane * LD + b] = sacc;
+              sacc = fmh_fma(Scur[lane * LD + b], vz[b], sacc);
+            }
             const int j = which[lane];
             th1[j] = th0[j] + sacc;
           }
@@ -319,6 +321,7 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
   const int jl = rl ? lane : 0;
   const double mu_l = A.mu[jl], lb_l = A.lb[jl], ub_l = A.ub[jl];
   double Srow[KA], Lrow[KA];                // Sigma (adapt) or S (ram) row `lane`; Cholesky factor row (adapt)
+  double (&Grow)[KA] = Lrow;                // ram: G_ib, the partial sums of the proposal's (S z)_lane chain
 #pragma unroll
   for (int b = 0; b < KA; b++) {
     Lrow[b] = 0.0;
@@ -401,14 +404,11 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
             if (__any(rl && !okl)) {
               nerr += 1;
             } else {
-              double G = 0.0;
 #pragma unroll
-              for (int j = KA - 1; j >= 0; j--) {
+              for (int j = 0; j < KA; j++) {
                 if (j < kf) {
-                  const double dj = readlane_d(dl, j), kj = readlane_d(kl, j), zj = readlane_d(zcur, j);
-                  const double sij = Srow[j];
-                  Srow[j] = fmh_fma(G, kj, sij * dj);
-                  G = fmh_fma(sij, zj, G);
+                  const double dj = readlane_d(dl, j), kj = readlane_d(kl, j);
+                  Srow[j] = fmh_fma(Grow[j], kj, Srow[j] * dj);    // (G_ij kept by the proposal; +0 above the diagonal stays +0)
                 }
               }
             }
@@ -497,8 +497,8 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
         } else {  // RAM P1 (R/kernel_ram.R:123-126)
           double sacc = 0.0;
 #pragma unroll
-          for (int b = 0; b < KA; b++)
-            if (b < kf) { const double ub_ = readlane_d(zcur, b); sacc = fmh_fma(Srow[b], ub_, sacc); }   // (S is lower triangular: +-0 beyond the diagonal)
+          for (int b = KA - 1; b >= 0; b--)   // last column first; the partial sums are the G_ib of the factor update
+            if (b < kf) { const double ub_ = readlane_d(zcur, b); Grow[b] = sacc; sacc = fmh_fma(Srow[b], ub_, sacc); }   // (+0 above the diagonal adds +0)
           th1 = th0 + sacc;
           ram_gate = (A.until > (double)abs_iter && abs_iter > A.warmup && ((v + 1) % A.freq) == 0);
         }

@@ -14,25 +14,76 @@ constexpr int RES_MASKED = 4;  // trailing observation slots that carry a validi
 // behind the runtime A.kind (streamed variants).
 // FAM > 0 compiles one model family in, MINB is the number of workgroups per CU the register allocation must allow
 // (the logistic model is bound by fp64 instruction issue: with 128 VGPRs two workgroups share a CU, 4 waves per SIMD).
-// kernel_ram's factor update S <- S T (mh_common.hpp, ram_coef): the rows, lane = row, in place.  d / kap / z hold d_j, kappa_j
-// and z_j in lane j (valid: every lane < kf passed ram_coef).  Per column one LDS read and write, three broadcasts by
-// v_readlane, one mul and two fma; the upper triangle is +0 and stays +0 (fma(+0, kappa, +0 d) = +0), so nothing is
-// predicated.  A REAL function on purpose: inlined into the sweep kernels the loop shares their register allocation, and
-// the instantiations that sit at 256 VGPRs spill inside it.
+// kernel_ram on the owner wave, lane = row of the lower factor S (LDS, row stride LD, +0 above the diagonal).
+// ram_propose_rows: (S z)_i as an fma chain from the last column down to column 0 (the entries above the diagonal add +0
+// exactly), keeping every partial sum G_ij = sum_{m = j+1..i} S_im z_m: they are what the factor update needs, which then
+// is one mul + fma per element with nothing carried (ram_update_rows; d_j, kappa_j in dk[0..kf), dk[kf..2 kf), from
+// ram_coef).  REAL functions on purpose: inlined into the sweep kernels the loops share their register allocation, and the
+// instantiations that sit at 256 VGPRs spill inside them.
 typedef __attribute__((address_space(3))) double* lds_dptr_t;
-__device__ __attribute__((noinline)) void ram_factor_rows(lds_dptr_t S, int LD_, int kf_, double d, double kap, double z) {
+// (both loops: ONE exec region around everything, loads unconditional and a group of four columns ahead of the arithmetic --
+//  with a predicate per store the compiler sank the loads into a branch per column: one LDS round trip per column, 4 us
+//  per update at k = 50)
+__device__ __attribute__((noinline)) double ram_propose_rows(lds_dptr_t S, lds_dptr_t G, lds_dptr_t z, int LD_, int kf_) {
   const int lane = threadIdx.x & 63;
   const int LD = __builtin_amdgcn_readfirstlane(LD_), kf = __builtin_amdgcn_readfirstlane(kf_);
-  const lds_dptr_t row = S + ((lane < kf) ? lane : 0) * LD;
-  double G = 0.0;
-  double s_nx = row[kf - 1];
-  for (int j = kf - 1; j >= 0; j--) {
-    const double sij = s_nx;
-    s_nx = row[j > 0 ? j - 1 : 0];
-    const double dj = readlane_d(d, j), kj = readlane_d(kap, j), zj = readlane_d(z, j);
-    const double nw = fmh_fma(G, kj, sij * dj);
-    G = fmh_fma(sij, zj, G);
-    if (lane < kf) row[j] = nw;
+  double s = 0.0;
+  if (lane < kf) {
+    const lds_dptr_t row = S + lane * LD, grow = G + lane * LD;
+    int j = kf - 1;
+    double sc[4], zc[4];
+    if (j >= 3) {
+#pragma unroll
+      for (int u = 0; u < 4; u++) { sc[u] = row[j - u]; zc[u] = z[j - u]; }
+    }
+    for (; j >= 3; j -= 4) {
+      const int jn = (j - 4 >= 3) ? j - 4 : j;       // the next group (the last round re-reads its own: unused)
+      double sn[4], zn[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { sn[u] = row[jn - u]; zn[u] = z[jn - u]; }
+      const double g0 = s, g1 = fmh_fma(sc[0], zc[0], g0), g2 = fmh_fma(sc[1], zc[1], g1), g3 = fmh_fma(sc[2], zc[2], g2);
+      s = fmh_fma(sc[3], zc[3], g3);
+      grow[j] = g0; grow[j - 1] = g1; grow[j - 2] = g2; grow[j - 3] = g3;
+#pragma unroll
+      for (int u = 0; u < 4; u++) { sc[u] = sn[u]; zc[u] = zn[u]; }
+    }
+    for (; j >= 0; j--) {
+      const double sij = row[j];
+      grow[j] = s;
+      s = fmh_fma(sij, z[j], s);
+    }
+  }
+  return s;
+}
+__device__ __attribute__((noinline)) void ram_update_rows(lds_dptr_t S, lds_dptr_t G, lds_dptr_t dk, int LD_, int kf_) {
+  const int lane = threadIdx.x & 63;
+  const int LD = __builtin_amdgcn_readfirstlane(LD_), kf = __builtin_amdgcn_readfirstlane(kf_);
+  if (lane < kf) {
+    const lds_dptr_t row = S + lane * LD, grow = G + lane * LD, kap = dk + kf;
+    const int nq = kf & ~3;
+    double sc[4], gc[4], dc[4], kc[4];
+    if (nq > 0) {
+#pragma unroll
+      for (int u = 0; u < 4; u++) { sc[u] = row[u]; gc[u] = grow[u]; dc[u] = dk[u]; kc[u] = kap[u]; }
+    }
+    int j = 0;
+    for (; j < nq; j += 4) {
+      const int jn = (j + 4 < nq) ? j + 4 : j;
+      double sn[4], gn[4], dn[4], kn[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { sn[u] = row[jn + u]; gn[u] = grow[jn + u]; dn[u] = dk[jn + u]; kn[u] = kap[jn + u]; }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const double nw = fmh_fma(gc[u], kc[u], sc[u] * dc[u]);
+        row[j + u] = (lane >= j + u) ? nw : sc[u];        // (above the diagonal: the +0 it holds)
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) { sc[u] = sn[u]; gc[u] = gn[u]; dc[u] = dn[u]; kc[u] = kn[u]; }
+    }
+    for (; j < kf; j++) {
+      const double sij = row[j], nw = fmh_fma(grow[j], kap[j], sij * dk[j]);
+      row[j] = (lane >= j) ? nw : sij;
+    }
   }
 }
 
@@ -124,6 +175,13 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
   }
 
   unsigned sh_epoch = 0;   // grid-barrier epoch of the observation-sharded evaluation (uniform over the grid)
+#ifdef FMCMC_STAMP
+  Stamps stamps; for (int q = 0; q < 16; q++) stamps.acc[q] = 0;
+  stamps.prev = 0;
+  Stamps* const stp = &stamps;
+#else
+  Stamps* const stp = nullptr;
+#endif
   // collective evaluation of f(theta1) for all chains of the workgroup; on return s_part holds
   // what finish needs (streamed: 8 wave partials per chain; resident: 2 half totals per chain)
   auto evaluate = [&]() {
@@ -160,7 +218,7 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
         if (lane == 0) s_part[h * CW + c] = v;
       }
     } else {
-      eval_partials<CW, FAM, (P < 0 ? OPT : 0)>(A, thp, s_part, s_sptab, &sh_epoch);
+      eval_partials<CW, FAM, (P < 0 ? OPT : 0)>(A, thp, s_part, s_sptab, &sh_epoch, stp);
     }
   };
   auto total_of = [&](int c) -> double {
@@ -254,46 +312,60 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
     store_row(1, f0);
   }
 
+  // variate `a` (a == kz: the log accept uniform) of loop step ii for chain slot c, into slot t of the tile
+  auto draw_variate = [&](int c, int t, int a, long long ii) {
+    if (c < ncw && ii <= A.nsteps) {
+      const long long clc = cg0 + c;
+      const unsigned int cg = (unsigned int)(A.chain_base + clc);
+      const unsigned int st = (unsigned int)(A.step_base + ii);
+      double v;
+      if (a == kz) {
+        v = (A.rng_mode == FMCMC_RNG_FED) ? A.fed_logu[clc * A.nsteps + (ii - 1)] : fmh_log_accept_u(A.seed, st, cg);
+        s_lu[c * TB + t] = v;
+      } else {
+        if (A.rng_mode == FMCMC_RNG_FED) v = A.fed_z[(clc * A.nsteps + (ii - 1)) * kz + a];
+        else if (A.kind == FMCMC_KERNEL_RAM) v = fmh_student_t(A.seed, st, cg, (unsigned int)a, (double)kf);
+        else if (A.variate == 1) v = fmh_unif(A.seed, st, cg, (unsigned int)a);
+        else v = fmh_normal(A.seed, st, cg, (unsigned int)a);
+        s_zt[(c * TB + t) * kz + a] = v;
+      }
+    }
+  };
+  const bool ring = (CW <= NW - 4) && TB >= 4;
+
   // ---- main loop
   int tt = -1;         // position inside the RNG tile
   int ord = 0;         // ordered scheme: (i - 1) mod kf
+#ifdef FMCMC_STAMP
+  for (int q = 0; q < 16; q++) stamps.acc[q] = 0;
+  stamps.prev = stamp_clk();
+#endif
   for (int i = 2; i <= nsteps; i++) {
     tt = (tt + 1 == TB) ? 0 : tt + 1;
     ord = (ord + 1 == kf) ? 0 : ord + 1;
     bool ram_gate = false;
-    // ================= RNG tile: all 512 threads draw the variates of the next TB steps ===========
-    if (tt == 0) {
+    // ================= RNG: the variates of a step sit in slot (step - 2) mod TB of the LDS tile =================
+    // Tile mode: every TB steps all 512 threads draw the next TB steps.  Ring mode (workgroups with at least four waves
+    // that own no chain): the first tile as above, then the NON-owner waves refill one slot per step while the owners are
+    // busy with the scalar phases (after the evaluation of step i: the slot of step i - 1, for step i - 1 + TB) -- the
+    // Student-t variates of a wide kernel_ram sweep cost 1.3 us per step when everybody stops for them.
+    if (tt == 0 && (!ring || i == 2)) {
       __syncthreads();  // owners are done with the previous tile (and with s_part)
       const int per_c = TB * (kz + 1);
       for (int idx = tid; idx < CW * per_c; idx += NT) {
         const int c = idx / per_c, rem = idx - c * per_c;
         const int t = rem / (kz + 1), a = rem - t * (kz + 1);
-        const long long ii = (long long)i + t;
-        if (c < ncw && ii <= A.nsteps) {
-          const long long clc = cg0 + c;
-          const unsigned int cg = (unsigned int)(A.chain_base + clc);
-          const unsigned int st = (unsigned int)(A.step_base + ii);
-          double v;
-          if (a == kz) {
-            v = (A.rng_mode == FMCMC_RNG_FED) ? A.fed_logu[clc * A.nsteps + (ii - 1)] : fmh_log_accept_u(A.seed, st, cg);
-            s_lu[c * TB + t] = v;
-          } else {
-            if (A.rng_mode == FMCMC_RNG_FED) v = A.fed_z[(clc * A.nsteps + (ii - 1)) * kz + a];
-            else if (A.kind == FMCMC_KERNEL_RAM) v = fmh_student_t(A.seed, st, cg, (unsigned int)a, (double)kf);
-            else if (A.variate == 1) v = fmh_unif(A.seed, st, cg, (unsigned int)a);
-            else v = fmh_normal(A.seed, st, cg, (unsigned int)a);
-            s_zt[(c * TB + t) * kz + a] = v;
-          }
-        }
+        draw_variate(c, t, a, (long long)i + t);
       }
       __syncthreads();
     }
     const double* zt = s_zt + ((owner ? myc : 0) * TB + tt) * kz;
+    FMH_STAMP(stp, 0);
     // ================= scalar phase A: proposal =================
     if (owner && status == FMCMC_CHAIN_OK) {
       if (A.kind == FMCMC_KERNEL_NORMAL || A.kind == FMCMC_KERNEL_NORMAL_REFLECTIVE) {
         if (lane < k) L.th1[lane] = L.th0[lane];
-        wave_sync();
+        wave_sync_lds();
         const bool refl = (A.kind == FMCMC_KERNEL_NORMAL_REFLECTIVE);
         // plan_update_sequence (R/kernel.R:66-133): every scheme but "joint" updates ONE parameter per step
         const bool single = (A.scheme != FMCMC_SCHEME_JOINT);
@@ -332,7 +404,7 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
           if (lane < k) L.msc[lane] = L.msc[lane] * num / den;
         }
         if (lane < k) L.th1[lane] = L.th0[lane];
-        wave_sync();
+        wave_sync_lds();
         const bool single = (A.scheme != FMCMC_SCHEME_JOINT);
         int col = 0;
         if (A.scheme == FMCMC_SCHEME_ORDERED) {
@@ -390,17 +462,17 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
                   d = ring[(long long)(r % H) * kf + lane] - m;
                   L.vv[lane] = d;
                 }
-                wave_sync();
+                wave_sync_lds();
                 if (lane < kf)
                   for (int b = 0; b < kf; b++) L.SigA[lane * LD + b] = fmh_fma(d, L.vv[b], L.SigA[lane * LD + b]);
-                wave_sync();
+                wave_sync_lds();
               }
               if (lane < kf)
                 for (int b = 0; b < kf; b++) {
                   const double ik = (b == lane) ? 1.0 * A.eps : 0.0;
                   L.SigA[lane * LD + b] = A.Sd * (L.SigA[lane * LD + b] / (double)(N - 1) + ik);
                 }
-              wave_sync();
+              wave_sync_lds();
             }
           } else if (i - A.freq < 1) {
             status = FMCMC_CHAIN_BAD_WINDOW;   // R: ans[0:(i-1), ] has fewer than freq rows, `[, , freq]` is out of bounds
@@ -417,7 +489,7 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
                 L.vmp[lane] = mp;
                 L.vmt[lane] = mt;
               }
-              wave_sync();
+              wave_sync_lds();
               if (lane < kf) {
                 const double c1 = (t - 1) / t, c2 = 1.0 / t;
                 for (int b = 0; b < kf; b++) {
@@ -426,7 +498,7 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
                   L.SigA[lane * LD + b] = c1 * L.SigA[lane * LD + b] + c2 * inner;
                 }
               }
-              wave_sync();
+              wave_sync_lds();
               if (lane < kf) L.vmp[lane] = mt;
               have_mean = 1;
             }
@@ -446,13 +518,13 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
           double ljj = fmh_sqrt(d);
           if (lane == j) L.SigB[j * LD + j] = ljj;
           else if (lane > j && lane < kf) L.SigB[lane * LD + j] = s / ljj;
-          wave_sync();
+          wave_sync_lds();
         }
         if (notpd) {
           status = FMCMC_CHAIN_NOT_PD;
         } else if (status == FMCMC_CHAIN_OK) {
           if (lane < k) L.th1[lane] = L.th0[lane];
-          wave_sync();
+          wave_sync_lds();
           if (lane < kf) {
             double s = 0.0;
             for (int b = 0; b <= lane; b++) s = fmh_fma(L.SigB[lane * LD + b], zt[b], s);
@@ -462,11 +534,12 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
           }
         }
       } else {  // RAM, R/kernel_ram.R:123-126
-        if (lane < kf) {
-          double s = 0.0;
-          for (int b = 0; b <= lane; b++) s = fmh_fma(Scur[lane * LD + b], zt[b], s);
-          int j = s_which[lane];
-          L.th1[j] = L.th0[j] + s;
+        {
+          const double s = ram_propose_rows((lds_dptr_t)Scur, (lds_dptr_t)L.SigB, (lds_dptr_t)zt, LD, kf);
+          if (lane < kf) {
+            const int j = s_which[lane];
+            L.th1[j] = L.th0[j] + s;
+          }
         }
         ram_gate = (A.until > (double)abs_iter && abs_iter > A.warmup && (i % A.freq) == 0);
       }
@@ -475,41 +548,60 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
         if (lane < k) A.status_theta[cl * k + lane] = L.th1[lane];
       }
     }
+    FMH_STAMP(stp, 1);
     __syncthreads();
+    FMH_STAMP(stp, 2);
     // ================= collective evaluation of f(theta1) =================
     evaluate();
+    FMH_STAMP(stp, 7);
     __syncthreads();
+    FMH_STAMP(stp, 8);
+    if (ring && wave >= CW && i >= 3) {   // (the owners last read the slot of step i - 1 before this barrier)
+      const int t = (tt == 0) ? TB - 1 : tt - 1;
+      for (int idx = tid - CW * 64; idx < CW * (kz + 1); idx += (NW - CW) * 64)
+        draw_variate(idx / (kz + 1), t, idx % (kz + 1), (long long)i - 1 + TB);
+    }
     // ================= scalar phase B: RAM adaptation (needs f(theta1) un-reflected) =================
+    double f1_pre = 0.0;      // f(theta1) when phase B has it already (unbounded kernel_ram: the proposal is final)
+    bool have_f1 = false;
     if (A.kind == FMCMC_KERNEL_RAM) {
       bool changed = false;
       if (owner && status == FMCMC_CHAIN_OK) {
         if (ram_gate) {
           double f1u = finish_logpost<FAM>(A, L.th1, total_of(myc));
+          f1_pre = f1u;
+          have_f1 = !A.ram_bounded;
           double a_n = fmh_exp(f1u - f0);
           if (fmh_isnan(a_n)) a_n = 0.0;
           else if (a_n > 1.0) a_n = 1.0;
           double eta = (double)kf * fmh_exp((-2.0 / 3.0) * fmh_log((double)i));
           if (eta > 1.0) eta = 1.0;
+          FMH_STAMP(stp, 11);
           const double zl = (lane < kf) ? zt[lane] : 0.0;
           const double Pj1 = lane_scan_wave(zl * zl);              // sum_{b <= lane} z_b^2
           double Pj = __shfl_up(Pj1, 1, 64);
           Pj = (lane == 0) ? 0.0 : Pj;
           const double nrm2 = readlane_d(Pj1, kf - 1);
           double cp = (eta * (a_n - A.arate)) / nrm2;
+          FMH_STAMP(stp, 12);
           if (cp != 0.0 && fmh_isfinite(cp)) {
             double dl, kl;
             const bool okl = ram_coef(cp, Pj, Pj1, zl, dl, kl);
             if (__any(lane < kf && !okl)) {
               nerr += 1;
             } else {
-              ram_factor_rows((lds_dptr_t)Scur, LD, kf, dl, kl, zl);
-              wave_sync();
+              FMH_STAMP(stp, 13);
+              if (lane < kf) { L.vmp[lane] = dl; L.vmt[lane] = kl; }    // (vmt == vmp + kf: d_j | kappa_j)
+              wave_sync_lds();
+              ram_update_rows((lds_dptr_t)Scur, (lds_dptr_t)L.SigB, (lds_dptr_t)L.vmp, LD, kf);
+              wave_sync_lds();
+              FMH_STAMP(stp, 14);
             }
           }
           if (A.constr) {  // Sigma <<- constr[which., which.] * Sigma (R/kernel_ram.R:149-150)
             if (lane < kf)
               for (int b = 0; b < kf; b++) Scur[lane * LD + b] = A.constr[lane * kf + b] * Scur[lane * LD + b];
-            wave_sync();
+            wave_sync_lds();
           }
         }
         abs_iter += 1;
@@ -534,9 +626,11 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
         }
       }
     }
+    FMH_STAMP(stp, 9);
     // ================= scalar phase C: accept / store (R/mcmc.R:754-778) =================
     if (owner && status == FMCMC_CHAIN_OK) {
-      f1 = finish_logpost<FAM>(A, L.th1, total_of(myc));
+      f1 = have_f1 ? f1_pre : finish_logpost<FAM>(A, L.th1, total_of(myc));
+      FMH_STAMP(stp, 15);
       if (fmh_isnan(f1)) status = FMCMC_CHAIN_NAN_LOGPOST;
       const double ratio = f1 - f0;
       if (status == FMCMC_CHAIN_OK && fmh_isnan(ratio)) status = FMCMC_CHAIN_NAN_RATIO;
@@ -551,7 +645,7 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
             double sq = 0.0;
             for (int a = 0; a < k; a++) sq = sq + (L.th1[a] - L.th0[a]) * (L.th1[a] - L.th0[a]);
             moved = (sq != 0.0);
-            wave_sync();
+            wave_sync_lds();
           }
           if (lane < k) L.th0[lane] = L.th1[lane];
           f0 = f1;
@@ -559,7 +653,7 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
           bitword |= (1u << ((i - 1) & 31));
         }
         if (mirror && !moved) nzero += 1;
-        wave_sync();
+        wave_sync_lds();
         store_row(i, f1);
         if (A.kind == FMCMC_KERNEL_ADAPT && lane < kf) L.vrs[lane] = L.vrs[lane] + L.th0[s_which[lane]];
         if (A.hist_rows > 0 && lane < kf)   // row i of ans[, which.] for the windowed / strided adaptation
@@ -570,7 +664,11 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
       A.accept_bits[cl * (long long)((nsteps + 31) >> 5) + ((i - 1) >> 5)] = bitword;
       bitword = 0;
     }
+    FMH_STAMP(stp, 10);
   }
+#ifdef FMCMC_STAMP
+  if (wave == 0 && owner && lane < 16 && k >= 16) A.status_theta[cl * k + lane] = (double)stamps.acc[lane];
+#endif
 
   // ---- write state back
   if (owner) {
@@ -591,7 +689,7 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
       A.mirror_scale[cl * k + lane] = L.msc[lane];
     }
     if (adaptive) {
-      wave_sync();
+      wave_sync_lds();
       const double* Sfin = (A.kind == FMCMC_KERNEL_RAM) ? Scur : L.SigA;
       for (int e = lane; e < kf * kf; e += 64) {
         int a = e / kf, b = e % kf;

@@ -685,9 +685,11 @@ static int propose_ram(const ocfg* cfg, const fmcmc_model* m, const fmcmc_kernel
       v[a] = s;
     }
   } else {
+    /* (S U)_a as an fma chain from the diagonal DOWN to column 0: its partial sums are the G_ab of the factor update
+     * (ram_factor_update_canon), so an implementation can keep them and update S element by element */
     for (int a = 0; a < kf; a++) {
       double s = 0.0;
-      for (int b = 0; b <= a; b++) s = fmh_fma(ks->Sigma[a * kf + b], U[b], s);
+      for (int b = a; b >= 0; b--) s = fmh_fma(ks->Sigma[a * kf + b], U[b], s);
       v[a] = s;
     }
   }
