@@ -14,7 +14,7 @@ KERNEL_NMIRROR, KERNEL_UMIRROR = 7, 8
 MIRROR_KERNELS = (KERNEL_NMIRROR, KERNEL_UMIRROR)
 SIMPLE_KERNELS = (KERNEL_NORMAL, KERNEL_NORMAL_REFLECTIVE, KERNEL_UNIF, KERNEL_UNIF_REFLECTIVE) + MIRROR_KERNELS
 SCHEME_JOINT, SCHEME_ORDERED, SCHEME_RANDOM, SCHEME_EXPLICIT = 0, 1, 2, 3
-ABI_VERSION = 2
+ABI_VERSION = 3
 RNG_PHILOX, RNG_FED = 0, 1
 OK, ERR_ARG, ERR_DEVICE, ERR_CHAIN, ERR_UNSUPPORTED = 0, 1, 2, 3, 4
 CHAIN_OK, CHAIN_NAN_LOGPOST, CHAIN_NAN_RATIO, CHAIN_NOT_PD, CHAIN_BAD_WINDOW, CHAIN_SYNC_TIMEOUT = 0, 1, 2, 3, 4, 5
@@ -38,7 +38,8 @@ class Kernel(C.Structure):
                 ("freq", C.c_int32), ("warmup", C.c_int32), ("bw", C.c_int32), ("until", C.c_double),
                 ("eps", C.c_double), ("arate", C.c_double), ("Sd", C.c_double),
                 ("scheme_seq", C.c_void_p), ("scheme_len", C.c_int32), ("nadapt", C.c_int32),
-                ("constr", C.c_void_p)]
+                ("constr", C.c_void_p), ("h_fixed", C.c_void_p), ("h_lb", C.c_void_p), ("h_ub", C.c_void_p),
+                ("h_scale", C.c_void_p), ("h_scheme_seq", C.c_void_p)]
 
 
 class Run(C.Structure):
@@ -59,7 +60,7 @@ class State(C.Structure):
 class Out(C.Structure):
     _fields_ = [("samples", C.c_void_p), ("logpost", C.c_void_p), ("draws", C.c_void_p),
                 ("accept_count", C.c_void_p), ("accept_bits", C.c_void_p), ("status", C.c_void_p),
-                ("status_step", C.c_void_p), ("status_theta", C.c_void_p)]
+                ("status_step", C.c_void_p), ("status_theta", C.c_void_p), ("ld_rows", C.c_int64)]
 
 
 _lib = None

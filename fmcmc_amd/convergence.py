@@ -41,8 +41,9 @@ class convergence_gelman:
         import torch
         import torch.distributed as dist
         L = abi.lib()
-        samples = chains.samples
+        samples = chains.samples             # view of the filled rows; the buffer's row stride is its capacity
         Cn, k, S = samples.shape
+        stride = chains.capacity
         dev = samples.device
         p = int(len(cols))
         distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
@@ -65,7 +66,7 @@ class convergence_gelman:
         if Cn > 0:
             work = torch.empty(int(L.fmcmc_gelman_work_len(Cn, p)), dtype=torch.float64, device=dev)
             with torch.cuda.device(dev):
-                rc = L.fmcmc_gelman_partial_dev(samples.data_ptr(), Cn, k, S, row0, N, cols_d.data_ptr(), p,
+                rc = L.fmcmc_gelman_partial_dev(samples.data_ptr(), Cn, k, stride, row0, N, cols_d.data_ptr(), p,
                                                 center.data_ptr(), work.data_ptr(), partial.data_ptr(),
                                                 C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
             if rc != abi.OK:

@@ -49,6 +49,7 @@ struct SweepArgs {
   const uint8_t* fixed;
   // run
   long long nchains, nsteps, burnin, thin, S, chain_base, step_base;
+  long long ldS;             // row stride of the samples / draws columns and of logpost (>= S: fmcmc_out.ld_rows)
   unsigned long long seed;
   int rng_mode, fresh, ram_bounded, kz, tb, debug;
   const double* fed_logu;

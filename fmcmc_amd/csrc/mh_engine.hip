@@ -256,7 +256,7 @@ int fmcmc_validate(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_run
 // The same sweep for the chains [off, off + cnt) of a call: every per-chain array advanced, RNG ids continued.
 static SweepArgs chain_window(const SweepArgs& A, long long off, long long cnt, int kf) {
   SweepArgs W = A;
-  const long long k = A.k, S = A.S, ns = A.nsteps, words = (A.nsteps + 31) >> 5;
+  const long long k = A.k, S = A.ldS, ns = A.nsteps, words = (A.nsteps + 31) >> 5;
   W.nchains = cnt; W.chain_base = A.chain_base + off;
 #define ADV(f, stride) if (W.f) W.f += off * (stride)
   ADV(scheme_cols, ns); ADV(mirror_mu, k); ADV(mirror_scale, k); ADV(obs_arate, 1);
@@ -308,11 +308,19 @@ static bool wide_sharded_pays(const fmcmc_model* m, const fmcmc_kernel* kn, cons
   return wide_sharded_lanes(m, kn, run, ram_bounded, ncu, nb) > 0;
 }
 
+// stream-ordered scratch that is released on EVERY way out of launch_sweep
+struct AsyncScratch {
+  void* p = nullptr;
+  hipStream_t s = nullptr;
+  ~AsyncScratch() { if (p) (void)hipFreeAsync(p, s); }
+};
+
 // kernel->fixed etc. are DEVICE pointers here; kf and bounds info come via `kf`/`ram_bounded`.
 static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const fmcmc_run* run,
                         fmcmc_state* st, fmcmc_out* out, int kf, int ram_bounded, hipStream_t stream) {
   SweepArgs A;
   memset(&A, 0, sizeof(A));
+  AsyncScratch hist_guard, ws_guard, shw_guard;
   // the uniform kernels ARE the normal kernels with mu = min., scale = max. - min. and U(0,1) variates
   fmcmc_kernel ke = *kn_in;
   if (ke.kind == FMCMC_KERNEL_UNIF) { ke.kind = FMCMC_KERNEL_NORMAL; A.variate = 1; }
@@ -336,6 +344,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
     A.hist_rows = (kn->bw - 1 > kn->freq) ? kn->bw - 1 : kn->freq;
     hipError_t eh = hipMallocAsync((void**)&A.hist, sizeof(double) * (size_t)run->nchains * (size_t)A.hist_rows * (size_t)kf, stream);
     if (eh != hipSuccess) { set_err("hipMallocAsync(adapt history) failed: %s", hipGetErrorString(eh)); return FMCMC_ERR_DEVICE; }
+    hist_guard.p = A.hist; hist_guard.s = stream;
   }
   A.freq = kn->freq < 1 ? 1 : kn->freq; A.scheme_seq = kn->scheme_seq; A.scheme_len = kn->scheme_len;
   A.constr = (kn->kind == FMCMC_KERNEL_RAM) ? kn->constr : nullptr; A.scheme_cols = st->scheme_cols;
@@ -346,6 +355,8 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
   A.mu = kn->mu; A.scale = kn->scale; A.lb = kn->lb; A.ub = kn->ub; A.fixed = kn->fixed;
   A.nchains = run->nchains; A.nsteps = run->nsteps; A.burnin = run->burnin; A.thin = run->thin;
   A.S = fmcmc_kept_rows(run->nsteps, run->burnin, run->thin);
+  A.ldS = out->ld_rows > 0 ? out->ld_rows : A.S;
+  if (A.ldS < A.S) { set_err("fmcmc_out.ld_rows (%lld) is smaller than the %lld kept rows of this call", (long long)out->ld_rows, (long long)A.S); return FMCMC_ERR_ARG; }
   A.chain_base = run->chain_base; A.step_base = run->step_base; A.seed = run->seed;
   A.rng_mode = run->rng_mode; A.fresh = st->fresh; A.ram_bounded = ram_bounded;
   A.kz = variates_per_step(kn, kf);
@@ -419,7 +430,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
       (kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE ||
        (((kn->kind == FMCMC_KERNEL_ADAPT && !adapt_hist) || (kn->kind == FMCMC_KERNEL_RAM && !ram_bounded && !kn->constr)) && !(nospec0 && nospec0[0] == '1'))) &&
       (kn->scheme == FMCMC_SCHEME_JOINT || kn->kind >= FMCMC_KERNEL_ADAPT) && kn->k <= PIPE_KMAX &&
-      (unsigned long long)run->nchains * kn->k * (unsigned long long)A.S * 8ull < (1ull << 32) &&
+      (unsigned long long)run->nchains * kn->k * (unsigned long long)A.ldS * 8ull < (1ull << 32) &&
       (unsigned long long)run->nchains * (unsigned long long)run->nsteps * (unsigned long long)A.kz * 8ull < (1ull << 32)) {
     if (m->p == 3 && m->n > (long long)NT * 19 && m->n <= (long long)NT * 20) pipe_opt = 20;
     if (m->p == 1 && m->n > (long long)NT * 1 && m->n <= (long long)NT * 2) pipe_opt = 2;
@@ -442,6 +453,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
       const size_t items = (size_t)run->nchains * (size_t)run->nsteps;
       e = hipMallocAsync((void**)&ws, sizeof(double) * items * (size_t)(A.kz + 1), stream);
       if (e != hipSuccess) { set_err("hipMallocAsync(rng stream) failed: %s", hipGetErrorString(e)); return FMCMC_ERR_DEVICE; }
+      ws_guard.p = ws; ws_guard.s = stream;
       hipLaunchKernelGGL(rng_fill_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream,
                          (unsigned long long)run->seed, (long long)run->step_base, (long long)run->chain_base,
                          (long long)run->nchains, (long long)run->nsteps, A.kz,
@@ -532,7 +544,6 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
     else if (kn->kind == FMCMC_KERNEL_NORMAL) LAUNCH_PIPE(1, 2, 1);
     else LAUNCH_PIPE(1, 2, 2);
 #undef LAUNCH_PIPE
-    if (ws) (void)hipFreeAsync(ws, stream);
   } else
   if (resident && res_p == 1) { g_kernel = "resident"; LAUNCH_KIND(4, 1, 4); }
   else if (resident && res_p == 3) { g_kernel = "resident"; LAUNCH_KIND(4, 3, 20); }
@@ -617,6 +628,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
       const size_t nmf = mfma_form ? (size_t)nb_launch * mblk : 0;
       e = hipMallocAsync((void**)&shw, sizeof(double) * (nxs + nys + nth + npt + nbar + nmf), stream);
       if (e != hipSuccess) { set_err("hipMallocAsync(sharded evaluation) failed: %s", hipGetErrorString(e)); return FMCMC_ERR_DEVICE; }
+      shw_guard.p = shw; shw_guard.s = stream;
       double* xs = shw; double* ys = xs + nxs; double* thw = ys + nys; double* ptw = thw + nth;
       unsigned* bar = (unsigned*)(ptw + npt);
       if (!mfma_form)
@@ -635,7 +647,6 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
         void* kargs[] = {(void*)&W};
         e = hipLaunchCooperativeKernel(kfn, dim3((unsigned)nb_launch), dim3(NT), kargs, (unsigned int)lds, stream);
       }
-      (void)hipFreeAsync(shw, stream);
       if (e != hipSuccess && done <= ch_launch) {   // the runtime refused the first cooperative launch after all: nothing ran,
         (void)hipGetLastError();                    // take the chain-sharded kernel
         e = hipSuccess;
@@ -660,7 +671,6 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
   } }
 #undef LAUNCH_KIND
 #undef LAUNCH
-  if (A.hist) (void)hipFreeAsync(A.hist, stream);
   if (e == hipSuccess) e = hipGetLastError();
   if (e != hipSuccess) { set_err("HIP launch failed: %s", hipGetErrorString(e)); return FMCMC_ERR_DEVICE; }
   return FMCMC_OK;
@@ -686,31 +696,35 @@ int fmcmc_detmath_dev(int which, const double* x, double* out, int64_t n, uint64
 int fmcmc_mcmc_run_dev(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_run* run,
                        fmcmc_state* st, fmcmc_out* out, void* hip_stream) {
   if (!m || !kn || !run || !st || !out) { set_err("null argument"); return FMCMC_ERR_ARG; }
-  // `fixed`, `lb`, `ub` live on the device: fetch the few bytes the launch geometry needs.
+  // `fixed`, `lb`, `ub` (and scale / scheme_seq where they are checked) live on the device.  A caller that passes their
+  // host copies (fmcmc_kernel.h_*) gets a call that only enqueues work; otherwise the few bytes are read back here, which
+  // synchronises the stream.
   uint8_t fx[MAXK];
-  double lb[MAXK], ub[MAXK];
+  double lb[MAXK], ub[MAXK], sc[MAXK];
+  int32_t seq[MAXK];
   if (kn->k < 1 || kn->k > MAXK) { set_err("k=%d outside [1,%d]", kn->k, MAXK); return FMCMC_ERR_UNSUPPORTED; }
   hipStream_t stream = (hipStream_t)hip_stream;
-  if (hipMemcpyAsync(fx, kn->fixed, kn->k, hipMemcpyDeviceToHost, stream) != hipSuccess ||
-      hipMemcpyAsync(lb, kn->lb, kn->k * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess ||
-      hipMemcpyAsync(ub, kn->ub, kn->k * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess ||
-      hipStreamSynchronize(stream) != hipSuccess) {
+  const bool unif = (kn->kind == FMCMC_KERNEL_UNIF || kn->kind == FMCMC_KERNEL_UNIF_REFLECTIVE);
+  const bool expl = (is_simple_kind(kn->kind) && kn->scheme == FMCMC_SCHEME_EXPLICIT && kn->scheme_seq &&
+                     kn->scheme_len >= 1 && kn->scheme_len <= MAXK);
+  const bool mirrored = kn->h_fixed && kn->h_lb && kn->h_ub && (!unif || kn->h_scale) && (!expl || kn->h_scheme_seq);
+  if (mirrored) {
+    memcpy(fx, kn->h_fixed, (size_t)kn->k);
+    memcpy(lb, kn->h_lb, sizeof(double) * (size_t)kn->k);
+    memcpy(ub, kn->h_ub, sizeof(double) * (size_t)kn->k);
+    if (unif) memcpy(sc, kn->h_scale, sizeof(double) * (size_t)kn->k);
+    if (expl) memcpy(seq, kn->h_scheme_seq, sizeof(int32_t) * (size_t)kn->scheme_len);
+  } else if (hipMemcpyAsync(fx, kn->fixed, kn->k, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+             hipMemcpyAsync(lb, kn->lb, kn->k * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+             hipMemcpyAsync(ub, kn->ub, kn->k * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+             (unif && hipMemcpyAsync(sc, kn->scale, kn->k * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess) ||
+             (expl && hipMemcpyAsync(seq, kn->scheme_seq, kn->scheme_len * sizeof(int32_t), hipMemcpyDeviceToHost, stream) != hipSuccess) ||
+             hipStreamSynchronize(stream) != hipSuccess) {
     set_err("cannot read kernel parameters from device memory");
     return FMCMC_ERR_DEVICE;
   }
   fmcmc_kernel kh = *kn;
   kh.fixed = fx; kh.lb = lb; kh.ub = ub;
-  double sc[MAXK];
-  int32_t seq[MAXK];
-  const bool unif = (kn->kind == FMCMC_KERNEL_UNIF || kn->kind == FMCMC_KERNEL_UNIF_REFLECTIVE);
-  const bool expl = (is_simple_kind(kn->kind) && kn->scheme == FMCMC_SCHEME_EXPLICIT && kn->scheme_seq &&
-                     kn->scheme_len >= 1 && kn->scheme_len <= MAXK);
-  if ((unif && hipMemcpyAsync(sc, kn->scale, kn->k * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess) ||
-      (expl && hipMemcpyAsync(seq, kn->scheme_seq, kn->scheme_len * sizeof(int32_t), hipMemcpyDeviceToHost, stream) != hipSuccess) ||
-      hipStreamSynchronize(stream) != hipSuccess) {
-    set_err("cannot read kernel parameters from device memory");
-    return FMCMC_ERR_DEVICE;
-  }
   kh.scale = unif ? sc : nullptr;
   kh.scheme_seq = expl ? seq : nullptr;
   int rc = fmcmc_validate(m, &kh, run);
@@ -758,6 +772,8 @@ int fmcmc_mcmc_run_host(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcm
   fmcmc_state ds = *st;
   fmcmc_out dout = *out;
   hipStream_t stream = nullptr;
+  if (out->ld_rows != 0 && out->ld_rows != S) { set_err("fmcmc_out.ld_rows is honoured by fmcmc_mcmc_run_dev only (host buffers are dense)"); return FMCMC_ERR_ARG; }
+  dout.ld_rows = 0;
   int bounded = 0;
   for (int j = 0; j < k; j++)
     if (!kn->fixed[j] && (kn->lb[j] > -DBL_MAX || kn->ub[j] < DBL_MAX)) bounded = 1;
@@ -851,10 +867,19 @@ int fmcmc_mcmc_run_host(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcm
   st->fresh = 0;
   for (int64_t c = 0; c < C; c++)
     if (out->status[c] != FMCMC_CHAIN_OK) {
-      // message of R/mcmc.R:759-765
-      set_err("fun(par) is undefined (chain %lld, status %d). Check either -fun- or the -lb- and -ub- "
+      // NaN log-posterior: the message of R/mcmc.R:759-765; the engine's own conditions by name
+      const char* what = "fun(par) is undefined.";
+      switch (out->status[c]) {
+        case FMCMC_CHAIN_NAN_LOGPOST: what = "fun(par) is undefined (NaN)."; break;
+        case FMCMC_CHAIN_NAN_RATIO: what = "fun(par) is undefined (f1 - f0 is NaN)."; break;
+        case FMCMC_CHAIN_NOT_PD: what = "'Sigma' is not positive definite."; break;
+        case FMCMC_CHAIN_BAD_WINDOW: what = "subscript out of bounds: the rows kernel_adapt(bw / freq) adapts on reach before the first row of this call."; break;
+        case FMCMC_CHAIN_SYNC_TIMEOUT: what = "a grid-wide hand-over of the observation-sharded evaluation timed out; the results of this call are invalid (FMCMC_AMD_SHARD=0 selects the chain-sharded kernel)."; break;
+        default: break;
+      }
+      set_err("%s (chain %lld, status %d). Check either -fun- or the -lb- and -ub- "
               "parameters. This error ocurred during step i = %lld",
-              (long long)(run->chain_base + c), out->status[c], (long long)out->status_step[c]);
+              what, (long long)(run->chain_base + c), out->status[c], (long long)out->status_step[c]);
       rc = FMCMC_ERR_CHAIN;
       break;
     }

@@ -110,9 +110,9 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
   double f0 = 0.0;
   int nacc = 0, status = FMCMC_CHAIN_OK, thin_ctr = 0;
   unsigned int srow8 = 0, bitword = 0;
-  const unsigned int sd_off = (unsigned int)((((long long)cl * k + jl) * A.S) * 8);
+  const unsigned int sd_off = (unsigned int)((((long long)cl * k + jl) * A.ldS) * 8);
   const unsigned int z_off = (unsigned int)((((long long)cl * nsteps) * kz + zidx) * 8);
-  const unsigned int lp_off = (unsigned int)(((long long)cl * A.S) * 8);
+  const unsigned int lp_off = (unsigned int)(((long long)cl * A.ldS) * 8);
   const double* const lu_row = A.fed_logu + (long long)cl * nsteps;
   const double dn = uniform_d((double)A.n);
   auto ld_z = [&](int row) -> double {

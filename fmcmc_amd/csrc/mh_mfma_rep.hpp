@@ -166,7 +166,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfmar(const SweepArgs A) {
     for (int j = 0; j < pj; j++) zi += A.fixed[j] ? 0 : 1;
     // a slot that is not updated adds entry 63 of the tile, a constant -0.0: x + (-0.0) == x bit for bit for every x
     zix[s] = fx ? 63 : jch * (kz + 1) + 1 + zi;           // the slot's increment in the staged tile
-    sdoff[s] = (unsigned int)((((long long)cl * k + pj) * A.S) * 8);
+    sdoff[s] = (unsigned int)((((long long)cl * k + pj) * A.ldS) * 8);
     th0[s] = (pi >= 0) ? A.theta0[(long long)cl * k + pj] : cst;
     if (!cvalid && pi >= 0) th0[s] = 0.0;
     th1[s] = th0[s];
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfmar(const SweepArgs A) {
   double f0 = 0.0;
   int nacc = 0, status = FMCMC_CHAIN_OK, thin_ctr = 0;
   unsigned int srow8 = 0, bitword = 0;
-  const unsigned int lp_off = (unsigned int)(((long long)cl * A.S) * 8);
+  const unsigned int lp_off = (unsigned int)(((long long)cl * A.ldS) * 8);
   const double dn = (double)A.n;
   // ---- random stream: ONE wave fetches the log-uniform and the kz variates of all four chains, one step ahead, with a
   // single load (lane = chain * (kz + 1) + item), turns the variates into the increments mu + scale z of "their"

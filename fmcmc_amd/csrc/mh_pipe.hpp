@@ -129,9 +129,9 @@ __global__ __launch_bounds__(NT) void mh_sweep_pipe(const SweepArgs A) {
   unsigned int srow8 = 0;  // byte offset of the next kept row inside a column
   unsigned int bitword = 0;
   // 32-bit byte offsets off the SGPR base pointers (the dispatcher guarantees every array < 4 GiB)
-  const unsigned int sd_off = (unsigned int)((((long long)cl * k + jl) * A.S) * 8);       // samples / draws column
+  const unsigned int sd_off = (unsigned int)((((long long)cl * k + jl) * A.ldS) * 8);       // samples / draws column
   const unsigned int z_off = (unsigned int)((((long long)cl * nsteps) * kz + zidx) * 8);  // this lane's z column
-  const unsigned int lp_off = (unsigned int)(((long long)cl * A.S) * 8);
+  const unsigned int lp_off = (unsigned int)(((long long)cl * A.ldS) * 8);
   const double* const lu_row = A.fed_logu + (long long)cl * nsteps;                        // scalar address
   const double dn = uniform_d((double)A.n);
   double z_nx = 0.0, lu_nx = 0.0;  // variates of the NEXT proposal / decision (prefetched)

@@ -85,9 +85,9 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
   }
   wave_sync_lds();
   const int jl = (lane < k) ? lane : 0;
-  const unsigned int sd_off = (unsigned int)((((long long)cl * k + jl) * A.S) * 8);
+  const unsigned int sd_off = (unsigned int)((((long long)cl * k + jl) * A.ldS) * 8);
   const unsigned int z_off = (unsigned int)((((long long)cl * nsteps) * kz + (lane < kz ? lane : 0)) * 8);
-  const unsigned int lp_off = (unsigned int)(((long long)cl * A.S) * 8);
+  const unsigned int lp_off = (unsigned int)(((long long)cl * A.ldS) * 8);
   const double* const lu_row = A.fed_logu + (long long)cl * nsteps;
   auto ld_z = [&](int row) -> double {
     return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(A.fed_z) + (z_off + (unsigned int)row * (unsigned int)(kz * 8)));
@@ -341,9 +341,9 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
       if (rl) mean_prev = A.mean_prev[(long long)cl * kf + lane];
     }
   }
-  const unsigned int sd_off = (unsigned int)((((long long)cl * k + jl) * A.S) * 8);
+  const unsigned int sd_off = (unsigned int)((((long long)cl * k + jl) * A.ldS) * 8);
   const unsigned int z_off = (unsigned int)((((long long)cl * nsteps) * kz + jl) * 8);
-  const unsigned int lp_off = (unsigned int)(((long long)cl * A.S) * 8);
+  const unsigned int lp_off = (unsigned int)(((long long)cl * A.ldS) * 8);
   const double* const lu_row = A.fed_logu + (long long)cl * nsteps;
   const double dn = uniform_d((double)A.n);
   auto ld_z = [&](int row) -> double {
@@ -660,9 +660,9 @@ __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
   double f0 = 0.0;
   int nacc = 0, status = FMCMC_CHAIN_OK, thin_ctr = 0;
   unsigned int srow8 = 0, bitword = 0;
-  const unsigned int sd_off = (unsigned int)((((long long)cl * k + jl) * A.S) * 8);
+  const unsigned int sd_off = (unsigned int)((((long long)cl * k + jl) * A.ldS) * 8);
   const unsigned int z_off = (unsigned int)((((long long)cl * nsteps) * kz + zidx) * 8);
-  const unsigned int lp_off = (unsigned int)(((long long)cl * A.S) * 8);
+  const unsigned int lp_off = (unsigned int)(((long long)cl * A.ldS) * 8);
   const double* const lu_row = A.fed_logu + (long long)cl * nsteps;
   const double dn = uniform_d((double)A.n);
   auto ld_z = [&](int row) -> double {

@@ -287,9 +287,9 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
   const int nsteps = (int)A.nsteps, burnin = (int)A.burnin, thin = (int)A.thin;
   int thin_ctr = 0;       // (r - burnin) mod thin for r > burnin
   long long srow = 0;     // next kept-row index
-  double* const out_s = A.samples + (cl * k + (lane < k ? lane : 0)) * S;
-  double* const out_d = A.draws ? A.draws + (cl * k + (lane < k ? lane : 0)) * S : nullptr;
-  double* const out_l = A.logpost ? A.logpost + cl * S : nullptr;
+  double* const out_s = A.samples + (cl * k + (lane < k ? lane : 0)) * A.ldS;
+  double* const out_d = A.draws ? A.draws + (cl * k + (lane < k ? lane : 0)) * A.ldS : nullptr;
+  double* const out_l = A.logpost ? A.logpost + cl * A.ldS : nullptr;
   auto store_row = [&](int r, double lpv) {
     if (r > burnin) {
       thin_ctr += 1;

@@ -77,6 +77,12 @@ class KernelSpec:
         self.kind, self.k = int(kind), int(k)
         self.h_fixed = np.ascontiguousarray(np.asarray(fixed, dtype=np.uint8))
         self.kf = int((self.h_fixed == 0).sum())
+        # host mirrors of what fmcmc_mcmc_run_dev checks and sizes its launch with (fmcmc_kernel.h_*): with them the
+        # entry point only enqueues work
+        self.h_lb = np.ascontiguousarray(np.asarray(lb, dtype=np.float64))
+        self.h_ub = np.ascontiguousarray(np.asarray(ub, dtype=np.float64))
+        self.h_scale = np.ascontiguousarray(np.asarray(scale, dtype=np.float64))
+        self.h_seq = None if scheme_seq is None else np.ascontiguousarray(np.asarray(scheme_seq, dtype=np.int32))
         self.mu = _t(mu, torch.float64, self.device)
         self.scale = _t(scale, torch.float64, self.device)
         self.lb = _t(lb, torch.float64, self.device)
@@ -101,7 +107,9 @@ class KernelSpec:
                           self.bw, self.until, self.eps, self.arate, self.Sd,
                           self.scheme_seq.data_ptr() if self.scheme_seq is not None else None,
                           int(self.scheme_seq.numel()) if self.scheme_seq is not None else 0, self.nadapt,
-                          self.constr.data_ptr() if self.constr is not None else None)
+                          self.constr.data_ptr() if self.constr is not None else None,
+                          self.h_fixed.ctypes.data, self.h_lb.ctypes.data, self.h_ub.ctypes.data, self.h_scale.ctypes.data,
+                          self.h_seq.ctypes.data if self.h_seq is not None else None)
 
 
 class ChainState:
@@ -150,8 +158,12 @@ def kept_rows(nsteps, burnin, thin):
 
 def sweep(model, kernel, state, nsteps, burnin=0, thin=1, seed=0, chain_base=0,
           want_logpost=True, want_draws=True, want_bits=True, fed_logu=None, fed_z=None,
-          stream=None, check=True):
+          stream=None, check=True, into=None, row0=0):
     """Enqueue one sweep (all local chains, nsteps iterations) and return the output tensors.
+
+    into = (samples [C][k][cap], logpost [C][cap] or None, draws [C][k][cap] or None), row0: write the kept rows of this
+    call at rows row0.. of a preallocated history (fmcmc_out.ld_rows = cap) instead of allocating; the result then holds
+    views of those rows.
 
     Raises ValueError for argument errors (messages mirror the reference's stop() texts) and
     RuntimeError for chain errors ("fun(par) is undefined", R/mcmc.R:758-765)."""
@@ -164,9 +176,20 @@ def sweep(model, kernel, state, nsteps, burnin=0, thin=1, seed=0, chain_base=0,
     nwords = (nsteps + 31) // 32
     out = SweepResult()
     f64 = dict(dtype=torch.float64, device=dev)
-    out.samples = torch.full((Cn, k, max(S, 0)), float("nan"), **f64)
-    out.logpost = torch.empty((Cn, S), **f64) if want_logpost else None
-    out.draws = torch.empty((Cn, k, S), **f64) if want_draws else None
+    ld = 0
+    if into is not None:
+        hs, hl, hd = into
+        ld = int(hs.shape[2])
+        if row0 + S > ld or hs.shape[0] != Cn or hs.shape[1] != k or not hs.is_contiguous():
+            raise ValueError("sweep(into=...): the history holds %s rows, this call writes rows %d..%d" % (ld, row0, row0 + S))
+        want_logpost, want_draws = hl is not None, hd is not None
+        out.samples = hs[:, :, row0:row0 + S]
+        out.logpost = hl[:, row0:row0 + S] if want_logpost else None
+        out.draws = hd[:, :, row0:row0 + S] if want_draws else None
+    else:
+        out.samples = torch.full((Cn, k, max(S, 0)), float("nan"), **f64)
+        out.logpost = torch.empty((Cn, S), **f64) if want_logpost else None
+        out.draws = torch.empty((Cn, k, S), **f64) if want_draws else None
     out.accept_count = torch.zeros(Cn, dtype=torch.int64, device=dev)
     out.accept_bits = torch.zeros((Cn, nwords), dtype=torch.int32, device=dev) if want_bits else None
     out.status = torch.zeros(Cn, dtype=torch.int32, device=dev)
@@ -176,10 +199,11 @@ def sweep(model, kernel, state, nsteps, burnin=0, thin=1, seed=0, chain_base=0,
     crun = abi.Run(Cn, nsteps, burnin, thin, seed & 0xFFFFFFFFFFFFFFFF, chain_base, state.step_base,
                    rng_mode, 0, fed_logu.data_ptr() if fed_logu is not None else None,
                    fed_z.data_ptr() if fed_z is not None else None)
+    # (a view's data_ptr() is the address of its first element: row row0 of chain 0, parameter 0)
     cout = abi.Out(out.samples.data_ptr(), out.logpost.data_ptr() if want_logpost else None,
                    out.draws.data_ptr() if want_draws else None, out.accept_count.data_ptr(),
                    out.accept_bits.data_ptr() if want_bits else None, out.status.data_ptr(),
-                   out.status_step.data_ptr(), out.status_theta.data_ptr())
+                   out.status_step.data_ptr(), out.status_theta.data_ptr(), ld)
     if kernel.kind in abi.SIMPLE_KERNELS and kernel.scheme == abi.SCHEME_RANDOM and state.scheme_cols is None:
         if rng_mode == abi.RNG_FED:
             raise ValueError("rng_mode = FED with scheme = 'random' needs state.scheme_cols (the plan R drew)")

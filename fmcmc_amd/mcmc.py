@@ -200,12 +200,41 @@ def _dist():
 
 # ------------------------------------------------------------------------------ device-side result of one call
 class DeviceChains:
-    """Samples of the local chains, resident in HBM: samples [C][k][S] (+ logpost, draws)."""
+    """Samples of the local chains, resident in HBM: samples [C][k][S] (+ logpost, draws).
 
-    def __init__(self, samples, logpost, draws, iters, thin, names, chain_base, nchains_total):
-        self.samples, self.logpost, self.draws = samples, logpost, draws
+    With `capacity` rows allocated up front (MCMC_with_conv_checker: the kept rows of all bulks, R/mcmc.R:926-947) the
+    buffers are [C][k][capacity] and `nrows` of them are filled; samples / logpost / draws are views of the filled part
+    (their row stride stays `capacity`, which is what fmcmc_gelman_partial_dev takes as S)."""
+
+    def __init__(self, samples, logpost, draws, iters, thin, names, chain_base, nchains_total, nrows=None):
+        self._samples, self._logpost, self._draws = samples, logpost, draws
+        self.nrows = int(samples.shape[-1]) if nrows is None else int(nrows)
         self.iters, self.thin, self.names = np.asarray(iters), thin, names
         self.chain_base, self.nchains_total = chain_base, nchains_total
+
+    samples = property(lambda self: self._samples[:, :, :self.nrows])
+    logpost = property(lambda self: None if self._logpost is None else self._logpost[:, :self.nrows])
+    draws = property(lambda self: None if self._draws is None else self._draws[:, :, :self.nrows])
+    capacity = property(lambda self: int(self._samples.shape[-1]))
+
+    @classmethod
+    def allocate(cls, nchains_local, k, capacity, thin, names, chain_base, nchains_total, device, want_logpost=True,
+                 want_draws=True):
+        import torch
+        f64 = dict(dtype=torch.float64, device=device)
+        return cls(torch.full((nchains_local, k, capacity), float("nan"), **f64),
+                   torch.empty((nchains_local, capacity), **f64) if want_logpost else None,
+                   torch.empty((nchains_local, k, capacity), **f64) if want_draws else None,
+                   np.zeros(0, dtype=np.int64), thin, names, chain_base, nchains_total, nrows=0)
+
+    def extend(self, iters_of_call):
+        """The rows of one more call were written behind the filled part (engine.sweep(into=...)): labels continue
+        (R/append_chains.R:113-142)."""
+        it = np.asarray(iters_of_call)
+        if it.size:
+            self.iters = it if self.iters.size == 0 else np.concatenate(
+                [self.iters, it - it[0] + self.iters[-1] + self.thin])
+            self.nrows += int(it.size)
 
     def append(self, other):
         import torch
@@ -237,15 +266,43 @@ def _validate_common(nsteps, nchains, burnin, thin, multicore):
 
 
 def _run_call(initial_local, fun, nsteps, burnin, thin, kernel, seed, chain_base, nchains_total, names,
-              device, want_logpost=True, want_draws=True):
-    """One MCMC_without_conv_checker over the local chains -> DeviceChains."""
+              device, want_logpost=True, want_draws=True, history=None, fed=None):
+    """One MCMC_without_conv_checker over the local chains -> DeviceChains (history: append the rows to it instead)."""
+    import torch
     gm = fun.device_model(device)
     kernel._init(initial_local.shape[1])
     if kernel._spec is None or kernel._spec.device != gm.device:
         kernel._spec = kernel.spec(gm.device)
+    if initial_local.shape[0] == 0:
+        # a rank without chains (nchains < number of ranks): nothing to launch, but it still takes part in the checker's
+        # all-reduce with an empty partial
+        if history is not None:
+            history.extend(burnin + thin * np.arange(1, engine.kept_rows(nsteps, burnin, thin) + 1))
+            return history
+        k, S = initial_local.shape[1], max(engine.kept_rows(nsteps, burnin, thin), 0)
+        f64 = dict(dtype=torch.float64, device=gm.device)
+        dc = DeviceChains(torch.empty((0, k, S), **f64), torch.empty((0, S), **f64) if want_logpost else None,
+                          torch.empty((0, k, S), **f64) if want_draws else None,
+                          burnin + thin * np.arange(1, S + 1), thin, names, chain_base, nchains_total)
+        dc.accept_count = torch.zeros(0, dtype=torch.int64, device=gm.device)
+        return dc
     st = kernel.state_for(initial_local, gm.device)
+    fkw = {}
+    if fed is not None:
+        # FMCMC_RNG_FED: the caller supplies the variates of this call in the order the reference draws them (per chain:
+        # log(runif(nsteps)), then the kernel's draws step by step, chains one after the other: R/mcmc.R:643-673,726)
+        logu, z = fed(initial_local.shape[0], nsteps, kernel._spec.kz, kernel)
+        fkw = dict(fed_logu=torch.as_tensor(np.ascontiguousarray(logu, dtype=np.float64)).to(gm.device),
+                   fed_z=torch.as_tensor(np.ascontiguousarray(z, dtype=np.float64)).to(gm.device))
+    if history is not None:
+        out = engine.sweep(gm, kernel._spec, st, nsteps, burnin=burnin, thin=thin, seed=seed, chain_base=chain_base,
+                           want_bits=False, into=(history._samples, history._logpost, history._draws), row0=history.nrows,
+                           **fkw)
+        history.extend(out.iters)
+        history.accept_count = out.accept_count
+        return history
     out = engine.sweep(gm, kernel._spec, st, nsteps, burnin=burnin, thin=thin, seed=seed, chain_base=chain_base,
-                       want_logpost=want_logpost, want_draws=want_draws, want_bits=False)
+                       want_logpost=want_logpost, want_draws=want_draws, want_bits=False, **fkw)
     dc = DeviceChains(out.samples, out.logpost, out.draws, out.iters, thin, names, chain_base, nchains_total)
     dc.accept_count = out.accept_count
     return dc
@@ -253,7 +310,7 @@ def _run_call(initial_local, fun, nsteps, burnin, thin, kernel, seed, chain_base
 
 def MCMC_without_conv_checker(initial, fun, nsteps, nchains=1, burnin=0, thin=1, kernel=None, multicore=False,
                               conv_checker=None, cl=None, progress=False, chain_id=1, seed=0, device=None,
-                              _return_device=False):
+                              _return_device=False, keep_logpost=True, keep_draws=True, fed=None):
     """R/mcmc.R:485-838 for all chains at once."""
     if kernel is None:
         kernel = kernel_normal()
@@ -268,7 +325,8 @@ def MCMC_without_conv_checker(initial, fun, nsteps, nchains=1, burnin=0, thin=1,
         raise ValueError("Incorrect length of -initial-: the model has %d parameters, got %d." % (fun.k, init.shape[1]))
     dist, rank, world = _dist()
     lo, hi = shard_bounds(nchains, world, rank)
-    dc = _run_call(init[lo:hi], fun, nsteps, burnin, thin, kernel, seed, lo, nchains, names, device)
+    dc = _run_call(init[lo:hi], fun, nsteps, burnin, thin, kernel, seed, lo, nchains, names, device,
+                   want_logpost=keep_logpost, want_draws=keep_draws, fed=fed)
     _store_output(dc, kernel)
     return dc if _return_device else dc.to_host()
 
@@ -283,7 +341,8 @@ def _store_output(dc, kernel):
 
 
 def MCMC_with_conv_checker(initial, fun, nsteps, nchains, burnin, thin, kernel, multicore, conv_checker, cl=None,
-                           progress=False, chain_id=1, seed=0, device=None, _return_device=False, verbose=True):
+                           progress=False, chain_id=1, seed=0, device=None, _return_device=False, verbose=True,
+                           keep_logpost=True, keep_draws=True, fed=None):
     """R/mcmc.R:841-1019: run in bulks of `freq`, restart every chain from its last row, stop when the
     checker says so."""
     if conv_checker is None:
@@ -308,16 +367,22 @@ def MCMC_with_conv_checker(initial, fun, nsteps, nchains, burnin, thin, kernel, 
     lo, hi = shard_bounds(nchains, world, rank)
     init_local = init[lo:hi]
     conv_checker.flush()
-    ans = None
     converged = False
     free = None
+    # the history of all bulks, allocated once: every bulk's kept rows are written behind the previous ones by the sweep
+    # itself (fmcmc_out.ld_rows) -- no per-bulk concatenation of a history that reaches GBs at config C4
+    capacity = sum(engine.kept_rows(nb, burnin if bi == 0 else 0, thin) for bi, nb in enumerate(bulks))
+    gdev = fun.device_model(device).device
+    ans = DeviceChains.allocate(hi - lo, init.shape[1], capacity, thin, names, lo, nchains, gdev,
+                                want_logpost=keep_logpost, want_draws=keep_draws)
     for bi, nb in enumerate(bulks):
         if bi > 0:
             burnin = 0
-            init_local = kernel._state.theta0  # last row of each chain (R/mcmc.R:908-911)
+            # initial <- ans[niter(ans), ]: the last KEPT row of every chain (R/mcmc.R:908-911), which with thin > 1 is not
+            # the last row the loop visited
+            init_local = ans._samples[:, :, ans.nrows - 1]
         _validate_common(nb, nchains, burnin, thin, multicore)
-        tmp = _run_call(init_local, fun, nb, burnin, thin, kernel, seed, lo, nchains, names, device)
-        ans = tmp if ans is None else ans.append(tmp)
+        _run_call(init_local, fun, nb, burnin, thin, kernel, seed, lo, nchains, names, device, history=ans, fed=fed)
         if free is None:
             free = np.nonzero(~kernel.fixed)[0]
         converged = conv_checker.check_device(ans, free)
@@ -341,12 +406,17 @@ _seed_counter = [int(time.time_ns()) & 0xFFFFFFFF]
 
 
 def MCMC(initial, fun, nsteps, *, seed=None, nchains=1, burnin=0, thin=1, kernel=None, multicore=False,
-         conv_checker=None, cl=None, progress=False, chain_id=1, device=None, _return_device=False):
+         conv_checker=None, cl=None, progress=False, chain_id=1, device=None, _return_device=False,
+         keep_logpost=True, keep_draws=True, fed=None):
     """Drop-in for fmcmc::MCMC (R/mcmc.R:325-340).
 
     initial: vector, [nchains x k] matrix, or a previous result (Mcmc: its last `nchains` rows,
     R/mcmc.R:344-378; McmcList: each chain's last row, :382-422).  fun: gaussian_linreg / logistic /
-    iid_normal object.  seed: Philox key (None: a fresh one per call)."""
+    iid_normal object.  seed: Philox key (None: a fresh one per call; with torch.distributed every rank uses rank 0's).
+    keep_logpost / keep_draws = False: do not record MCMC_OUTPUT's logpost / draws (R always does, R/mcmc.R:822-823; at
+    config C4 the draws alone are 2 GB per GPU).  fed: callable (nchains, nsteps, kz, kernel) -> (logu [C][nsteps],
+    z [C][nsteps][kz]) supplying the variates of every call instead of the Philox stream (fmcmc_run.rng_mode = FED; one
+    process only): fed R's own Mersenne-Twister stream the engine retraces fmcmc's printed outputs."""
     MCMC_OUTPUT.clear()
     t0 = time.time()
     if isinstance(initial, Mcmc):
@@ -358,7 +428,15 @@ def MCMC(initial, fun, nsteps, *, seed=None, nchains=1, burnin=0, thin=1, kernel
             raise ValueError("The parameter `nchains` must equal the number of chains passed by `initial`.")
     if seed is None:
         _seed_counter[0] = (_seed_counter[0] * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
-        seed = _seed_counter[0]
+        seed = _seed_counter[0] & 0x7FFFFFFFFFFFFFFF
+        dist, rank, world = _dist()
+        if dist is not None:
+            # the RNG is keyed by (seed, GLOBAL chain id): every rank must use the same key or sharding would change the chains
+            import torch
+            dev = fun.device_model(device).device if isinstance(fun, LogPosterior) else "cpu"
+            t = torch.tensor([seed], dtype=torch.int64, device=dev)
+            dist.broadcast(t, src=0)
+            seed = int(t.item())
     if kernel is None:
         kernel = kernel_normal()
     MCMC_OUTPUT.info = dict(initial=initial, fun=fun, nsteps=nsteps, seed=seed, nchains=nchains, burnin=burnin, thin=thin,
@@ -366,9 +444,11 @@ def MCMC(initial, fun, nsteps, *, seed=None, nchains=1, burnin=0, thin=1, kernel
                             chain_id=chain_id)
     if conv_checker is not None:
         ans = MCMC_with_conv_checker(initial, fun, nsteps, nchains, burnin, thin, kernel, multicore, conv_checker,
-                                     cl, progress, chain_id, seed=seed, device=device, _return_device=_return_device)
+                                     cl, progress, chain_id, seed=seed, device=device, _return_device=_return_device,
+                                     keep_logpost=keep_logpost, keep_draws=keep_draws, fed=fed)
     else:
         ans = MCMC_without_conv_checker(initial, fun, nsteps, nchains, burnin, thin, kernel, multicore, None, cl,
-                                        progress, chain_id, seed=seed, device=device, _return_device=_return_device)
+                                        progress, chain_id, seed=seed, device=device, _return_device=_return_device,
+                                        keep_logpost=keep_logpost, keep_draws=keep_draws, fed=fed)
     MCMC_OUTPUT.elapsed = time.time() - t0
     return ans

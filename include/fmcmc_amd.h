@@ -13,7 +13,8 @@
  * Two pointer domains, same structs:
  *   *_host entry points: every pointer is HOST memory; the library stages to/from HBM.
  *   *_dev  entry points: every pointer is DEVICE memory (hipMalloc / a torch tensor's
- *                        data_ptr); the call only enqueues work on `stream`.
+ *                        data_ptr); the call only enqueues work on `stream` when the kernel's
+ *                        host mirrors (fmcmc_kernel.h_*) are set, else it reads a few bytes back first.
  *
  * Layouts (chosen so that one chain's block is exactly an R column-major matrix):
  *   X        [p][n]       column-major n x p design matrix (no intercept column)
@@ -35,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FMCMC_ABI_VERSION 2
+#define FMCMC_ABI_VERSION 3
 #define FMCMC_MAX_K 64 /* parameters per chain supported by the device kernels */
 
 /* ---- log-posterior families: the `fun` argument of MCMC() (R/mcmc.R:327) ---------- */
@@ -111,6 +112,14 @@ typedef struct fmcmc_kernel {
   int32_t nadapt;       /* mirror kernels: abs_iter at which the scale is adapted (R/kernel_mirror.R:103,121) */
   const double* constr; /* ram: [kf][kf] mask multiplied element-wise into the updated factor
                          * (constr[which., which.], R/kernel_ram.R:149-150); NULL = none */
+  /* v3, fmcmc_mcmc_run_dev only: HOST copies of the device arrays above that the launch geometry and the argument checks
+   * need (fixed, lb, ub; scale for the uniform kernels; scheme_seq).  With all of them set the entry point only enqueues
+   * work; with NULLs it reads the few bytes back from the device and synchronises the stream first. */
+  const uint8_t* h_fixed;
+  const double* h_lb;
+  const double* h_ub;
+  const double* h_scale;
+  const int32_t* h_scheme_seq;
 } fmcmc_kernel;
 
 /* ---- one call of MCMC_without_conv_checker over all chains ------------------------ */
@@ -177,6 +186,9 @@ typedef struct fmcmc_out {
   int32_t* status;        /* [C] FMCMC_CHAIN_* */
   int64_t* status_step;   /* [C] loop index i at which status was raised */
   double* status_theta;   /* [C][k] theta1 at that step */
+  int64_t ld_rows;        /* v3, fmcmc_mcmc_run_dev only: row stride of samples / draws columns and of logpost rows; 0 = S.
+                           * With ld_rows > S the kept rows of consecutive calls (the bulks of MCMC_with_conv_checker,
+                           * R/mcmc.R:926-947) land in ONE preallocated [C][k][ld_rows] history: pass samples + rows so far. */
 } fmcmc_out;
 
 /* Return codes */

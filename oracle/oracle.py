@@ -41,7 +41,8 @@ class CKernel(C.Structure):
                 ("freq", C.c_int32), ("warmup", C.c_int32), ("bw", C.c_int32), ("until", C.c_double),
                 ("eps", C.c_double), ("arate", C.c_double), ("Sd", C.c_double),
                 ("scheme_seq", C.POINTER(C.c_int32)), ("scheme_len", C.c_int32), ("nadapt", C.c_int32),
-                ("constr", _dp)]
+                ("constr", _dp), ("h_fixed", C.c_void_p), ("h_lb", C.c_void_p), ("h_ub", C.c_void_p),
+                ("h_scale", C.c_void_p), ("h_scheme_seq", C.c_void_p)]   # (v3 host mirrors: device entry only)
 
 
 class CRun(C.Structure):
@@ -62,7 +63,7 @@ class COut(C.Structure):
     _fields_ = [("samples", _dp), ("logpost", _dp), ("draws", _dp),
                 ("accept_count", C.POINTER(C.c_int64)), ("accept_bits", C.POINTER(C.c_uint32)),
                 ("status", C.POINTER(C.c_int32)), ("status_step", C.POINTER(C.c_int64)),
-                ("status_theta", _dp)]
+                ("status_theta", _dp), ("ld_rows", C.c_int64)]   # (ld_rows: device entry only, the oracle's rows are dense)
 
 
 def build(force=False):
@@ -470,6 +471,9 @@ def mcmc_with_conv_checker(model, kernel, initial, nsteps, nchains, freq, thresh
         r = run(model, kernel, nsteps=nb, burnin=burnin if bi == 0 else 0, thin=thin, seed=seed,
                 rng_mode=rng_mode, math_mode=math_mode, rng=rng, state=state)
         parts.append(r.samples)
+        # initial <- ans[niter(ans), ]: the next bulk starts from the last KEPT row (R/mcmc.R:908-911); with thin > 1 that
+        # is not the last row the loop visited
+        state.theta0[:] = r.samples[:, -1, :]
         if iters is None:
             iters = r.iters.copy()
         else:  # append_chains.mcmc labels (R/append_chains.R:113-121)

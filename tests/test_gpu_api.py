@@ -378,3 +378,158 @@ def test_host_pointer_entry_point_new_rows(E, O):
             assert np.array_equal(_bits(oar), _bits(ost.obs_arate)) and np.array_equal(abs_iter, ost.abs_iter)
         if kind in (O.K_RAM, O.K_ADAPT):
             assert np.array_equal(_bits(Sig), _bits(ost.Sigma))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# R's own stream through the drop-in API: MCMC(..., fed = <R's draws>) on the device retraces what fmcmc prints
+# ---------------------------------------------------------------------------------------------------------------------
+class RStream:
+    """The variates of one MCMC_without_conv_checker call in the order R draws them: chains one after the other from ONE
+    Mersenne-Twister stream (serial fan-out, R/mcmc.R:643-673); per chain log(runif(nsteps)) first (R/mcmc.R:726), then the
+    kernel's draws of loop steps 2..nsteps (rnorm(k'), R/kernel_normal.R:71; rt(k, k), R/kernel_ram.R:68)."""
+
+    def __init__(self, O, seed):
+        self.g = O.RRng(seed)
+
+    def __call__(self, nchains, nsteps, kz, kernel):
+        from fmcmc_amd import _abi as abi
+        logu, z = np.zeros((nchains, nsteps)), np.zeros((nchains, nsteps, kz))
+        for c in range(nchains):
+            logu[c] = np.log(self.g.runif(nsteps))
+            for i in range(1, nsteps):
+                z[c, i] = self.g.rt(kz, float(kz)) if kernel.kind == abi.KERNEL_RAM else self.g.rnorm(kz)
+        return logu, z
+
+
+@pytest.mark.filterwarnings("ignore:While using multiple chains")
+def test_fed_replay_G2_G3_autostop_through_MCMC(E, O, readme_data):
+    """README.md:301-339 and :370-412: two chains sharing one R stream, convergence_gelman(200): the 13 printed R-hat values
+    and the stop after 2600 steps, from the device."""
+    import fmcmc_amd as f
+    X, y = readme_data
+    init = [0, 0, O.r_sd(y)]
+    chk = f.convergence_gelman(200)
+    ans = f.MCMC(init, f.gaussian_linreg(X, y), 5000, nchains=2, kernel=f.kernel_normal(scale=.05), conv_checker=chk,
+                 fed=RStream(O, 1215))
+    assert [round(h[1], 4) for h in chk.history] == G["G2"]["rhat"]
+    assert [h[0] for h in chk.history] == list(range(200, 2601, 200))
+    assert ans.niter == G["G2"]["final_steps"] and ans.nchain == 2
+    chk = f.convergence_gelman(200)
+    kr = f.kernel_normal_reflective(scale=.05, ub=5.0, lb=[-5.0, 0.0, 0.0])
+    ans = f.MCMC(init, f.gaussian_linreg(X, y, guard=False), 5000, nchains=2, kernel=kr, conv_checker=chk,
+                 fed=RStream(O, 1215))
+    assert [round(h[1], 4) for h in chk.history] == G["G3"]["rhat"]
+    assert ans.niter == G["G3"]["final_steps"]
+    a = ans.as_array()
+    assert a[:, :, 0].min() >= -5 and a.max() <= 5 and a[:, :, 1:].min() >= 0
+
+
+def test_fed_replay_G5_ith_step_examples_through_MCMC(E, O):
+    """R/mcmc_info.R:467-543 (seed 22): the states / proposals fmcmc's roxygen examples print at steps 500..2000 and the
+    running maxima of the log-posterior, from the device (sigma is the fixed second parameter)."""
+    import fmcmc_amd as f
+    g = O.RRng(23133)
+    x = g.rnorm(200)
+    y = x * 2 + g.rnorm(200)
+    fun = f.gaussian_linreg(x, y, intercept=False, guard=False)
+    ans = f.MCMC([0.0, 1.0], fun, 2000, kernel=f.kernel_normal(fixed=[False, True]), fed=RStream(O, 22))
+    draws = f.get_draws()
+    for i, (t0, t1) in G["G5"]["ith_step"].items():
+        i = int(i)
+        assert sig(ans.data[i - 2, 0], 7) == t0       # theta0 seen inside f at step i = ans[i-1]
+        assert sig(draws[i - 1, 0], 7) == t1          # theta1 = proposal of step i
+    f.MCMC([0.0, 1.0], fun, 1000, kernel=f.kernel_normal(fixed=[False, True]), fed=RStream(O, 22))
+    lp = f.get_logpost()
+    got = [(sig(lp[i], 7), i + 1) for i in range(1, 1000) if lp[i] > lp[:i].max()]
+    assert got == [tuple(v) for v in G["G5"]["new_max"]]
+
+
+def test_readme_session_through_MCMC_on_R_stream(E, O, readme_data):
+    """The README's whole session (README.md:156-269) through the drop-in API on ONE R stream, as R runs it: MCMC() with the
+    default kernel (G1), continued with kernel_normal(scale = .05), then kernel_ram() (G4: 1761 / 4999 accepted) and
+    kernel_adapt() (G6).  G6 is a statistical target by nature (MASS::mvrnorm maps z through LAPACK eigenvectors, the engine
+    through a Cholesky factor: same law, other trajectory): within 0.025 of the printed 0.5365, like the oracle."""
+    import fmcmc_amd as f
+    X, y = readme_data
+    fun = f.gaussian_linreg(X, y)
+    rs = RStream(O, 1215)
+    acc = lambda a: float(np.mean(np.any(np.diff(a.data, axis=0) != 0, axis=1)))     # 1 - coda::rejectionRate
+    a1 = f.MCMC([0, 0, O.r_sd(y)], fun, 5000, fed=rs)
+    assert [sig(v, 4) for v in a1.data.mean(0)] == G["G1"]["mean"]
+    a2 = f.MCMC(a1, fun, 5000, kernel=f.kernel_normal(scale=.05), fed=rs)
+    assert round(acc(a2) * 4999) == 3641
+    a3 = f.MCMC(a2, fun, 5000, kernel=f.kernel_ram(), fed=rs)
+    assert sig(acc(a3), 7) == G["G4"]["ram_accept_rate"]
+    a4 = f.MCMC(a2, fun, 5000, kernel=f.kernel_adapt(), fed=rs)
+    assert abs(acc(a4) - G["G6"]["adapt_accept_rate"]) < 0.025, acc(a4)
+
+
+def test_kernel_adapt_acceptance_on_the_philox_stream(E, O, readme_data):
+    """G6 again, on the engine's own stream: over six seeds the rate spreads with sd ~ 0.012 around 0.56 (the adaptation
+    makes it trajectory dependent: the reference's restatement itself gives 0.522-0.556 under different eigenvector
+    conventions); the printed 0.5365 must be a plausible member of that spread."""
+    from fmcmc_amd import _abi as abi
+    X, y = readme_data
+    gm = E.DeviceModel(abi.FAM_GAUSSIAN_LINREG, X, y)
+    big = E.DBL_MAX
+    start = [3.1551402264840505, 1.8035961818024204, 4.0637777462858455]   # last row of the README's second run
+    gk = E.KernelSpec(abi.KERNEL_ADAPT, 3, np.zeros(3), np.ones(3), np.full(3, -big), np.full(3, big), np.zeros(3, np.uint8),
+                      warmup=500, eps=1e-4)
+    rates = []
+    for seed in (1, 2, 3, 4, 5, 6):
+        st = E.ChainState(np.asarray(start)[None, :], 3)
+        r = E.sweep(gm, gk, st, 5000, seed=seed)
+        rates.append(int(r.accept_count[0]) / 4999)
+    rates = np.array(rates)
+    assert abs(rates.mean() - G["G6"]["adapt_accept_rate"]) < 0.04 and rates.min() > 0.50 and rates.max() < 0.62, rates
+    assert abs(G["G6"]["adapt_accept_rate"] - rates.mean()) < 3.5 * max(rates.std(ddof=1), 0.008), rates
+
+
+def test_autostop_with_thinning_restarts_from_the_last_kept_row(E, O, readme_data):
+    """R/mcmc.R:908-911: every later bulk starts from ans[niter(ans), ], the last KEPT row -- with thin = 3 and bulks of 200
+    that is not the last row the loop visited.  Same bulks, history, labels and bits as the oracle's restatement."""
+    import fmcmc_amd as f
+    X, y = readme_data
+    init = np.tile([0, 0, O.r_sd(y)], (4, 1)) + 0.3 * np.random.default_rng(3).standard_normal((4, 3))
+    chk = f.convergence_gelman(200, threshold=1.02)
+    ans = f.MCMC(init, f.gaussian_linreg(X, y), 3000, seed=5, nchains=4, burnin=50, thin=3, kernel=f.kernel_normal(scale=0.05),
+                 conv_checker=chk)
+    ro = O.mcmc_with_conv_checker(O.Model(O.FAM_LINREG, X, y), O.Kernel(O.K_NORMAL, 3, scale=0.05), init, 3000, 4, 200,
+                                  threshold=1.02, burnin=50, thin=3, seed=5)
+    assert len(ro.history) >= 3 and len(chk.history) == len(ro.history)      # (the checker labels a check by the last kept
+    assert np.allclose([h[1] for h in chk.history], [h[1] for h in ro.history], rtol=1e-8)   # iteration, the oracle by steps run)
+    assert np.array_equal(_bits(ans.as_array()), _bits(ro.samples))
+    assert list(ans.iters) == list(ro.iters)
+    assert len(f.get_logpost()) == 4 and f.get_logpost()[0].shape[0] == ans.niter
+
+
+def test_preallocated_history_equals_separate_calls(E, O):
+    """fmcmc_out.ld_rows: two calls writing behind each other into one [C][k][capacity] history give the bits of two
+    separately allocated calls (every kernel family of the dispatcher that the shapes below reach)."""
+    import torch
+    from fmcmc_amd import _abi as abi
+    big = E.DBL_MAX
+    for (n, p, kind, chains) in ((10000, 3, abi.KERNEL_NORMAL, 8), (10000, 3, abi.KERNEL_ADAPT, 8), (700, 2, abi.KERNEL_RAM, 5),
+                                 (900, 20, abi.KERNEL_RAM, 6), (3000, 5, abi.KERNEL_NORMAL_REFLECTIVE, 4)):
+        X, y = synth_linreg(n, p, 40 + p, beta=np.linspace(1.0, -1.0, p + 1))
+        k = p + 2
+        init = np.concatenate([np.linspace(1.0, -1.0, p + 1), [4.0]])[None, :] + 0.01 * np.random.default_rng(p).standard_normal((chains, k))
+        gm = E.DeviceModel(abi.FAM_GAUSSIAN_LINREG, X, y)
+        refl = kind == abi.KERNEL_NORMAL_REFLECTIVE
+        gk = E.KernelSpec(kind, k, np.zeros(k), np.full(k, 0.01), np.full(k, -6.0 if refl else -big), np.full(k, 6.0 if refl else big),
+                          np.zeros(k, np.uint8), warmup=20)
+        sa, sb = E.ChainState(init, k), E.ChainState(init, k)
+        a1 = E.sweep(gm, gk, sa, 60, burnin=5, thin=2, seed=9)
+        a2 = E.sweep(gm, gk, sa, 41, thin=2, seed=9)
+        cap = a1.samples.shape[2] + a2.samples.shape[2] + 3
+        f64 = dict(dtype=torch.float64, device="cuda")
+        hs, hl, hd = torch.full((chains, k, cap), -7.0, **f64), torch.full((chains, cap), -7.0, **f64), torch.full((chains, k, cap), -7.0, **f64)
+        b1 = E.sweep(gm, gk, sb, 60, burnin=5, thin=2, seed=9, into=(hs, hl, hd), row0=0)
+        b2 = E.sweep(gm, gk, sb, 41, thin=2, seed=9, into=(hs, hl, hd), row0=b1.samples.shape[2])
+        torch.cuda.synchronize()
+        n1, n2 = a1.samples.shape[2], a2.samples.shape[2]
+        assert np.array_equal(_bits(hs[:, :, :n1].cpu().numpy()), _bits(a1.samples.cpu().numpy())), (kind, abi.last_kernel())
+        assert np.array_equal(_bits(hs[:, :, n1:n1 + n2].cpu().numpy()), _bits(a2.samples.cpu().numpy()))
+        assert np.array_equal(_bits(hl[:, n1:n1 + n2].cpu().numpy()), _bits(a2.logpost.cpu().numpy()))
+        assert np.array_equal(_bits(hd[:, :, :n1].cpu().numpy()), _bits(a1.draws.cpu().numpy()))
+        assert (hs[:, :, n1 + n2:] == -7.0).all() and (hl[:, n1 + n2:] == -7.0).all()     # nothing written behind the rows

@@ -1,0 +1,106 @@
+"""The N > 1 path of the PRODUCT on hardware: MCMC() with torch.distributed initialised -- shard_bounds, global chain ids,
+DeviceChains.nchains_total, the seed broadcast, convergence_gelman.check_device's two all-reduces -- run by two fresh
+processes on the one GPU of the box (gloo moves the CUDA tensors of the all-reduce through the host; on a multi-GPU node the
+same code runs one rank per GPU over RCCL).  Replaces, for all chains, the PSOCK fan-out of R/mcmc.R:536-641 and the
+checker loop of R/mcmc.R:841-1019."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def _run_ranks(tmp_path, case, world=2):
+    port = 29600 + (os.getpid() * 7 + abs(hash(case))) % 1500
+    outs = [str(tmp_path / ("%s_rank%d.npz" % (case, r))) for r in range(world)]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "rank_worker.py"), str(r), str(world), str(port),
+                               outs[r], case], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=420)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o)
+    for p, o in zip(procs, logs):
+        assert p.returncode == 0, o[-3000:]
+    return [np.load(o) for o in outs]
+
+
+@pytest.fixture(scope="module")
+def setup():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import fmcmc_amd as f
+    from conftest import synth_linreg
+    X, y = synth_linreg(1200, 2, 77)
+    return f, f.gaussian_linreg(X, y)
+
+
+def test_two_ranks_autostop_equals_the_unsharded_run(setup, tmp_path):
+    f, fun = setup
+    nch = 6
+    init = np.array([0, 0, 0, 4.0])[None, :] + 0.2 * np.random.default_rng(1).standard_normal((nch, 4))
+    chk = f.convergence_gelman(200, threshold=1.03)
+    full = f.MCMC(init, fun, 4000, seed=5, nchains=nch, kernel=f.kernel_normal(scale=0.05), conv_checker=chk)
+    assert len(chk.history) >= 3                                     # several bulks, several all-reduces
+    r = _run_ranks(tmp_path, "gelman")
+    assert [int(x["chain_base"]) for x in r] == [0, 3]
+    both = np.concatenate([x["samples"] for x in r])                 # [C][k][S]
+    assert np.array_equal(_bits(both.transpose(0, 2, 1)), _bits(full.as_array()))   # sharding never changes a chain
+    for x in r:
+        assert list(x["hist_end"]) == [h[0] for h in chk.history]   # the same bulks, the same stop
+        assert np.allclose(x["hist_val"], [h[1] for h in chk.history], rtol=1e-9)
+        assert list(x["iters"]) == list(full.iters) and int(x["converged"]) == 1
+    assert np.array_equal(_bits(r[0]["hist_val"]), _bits(r[1]["hist_val"]))          # every rank decides identically
+
+
+def test_two_ranks_uneven_split_ram_with_burnin_and_thinning(setup, tmp_path):
+    f, fun = setup
+    nch = 5
+    init = np.array([0, 0, 0, 4.0])[None, :] + 0.2 * np.random.default_rng(2).standard_normal((nch, 4))
+    chk = f.convergence_gelman(300, threshold=1.02)
+    kr = f.kernel_ram()
+    full = f.MCMC(init, fun, 3000, seed=11, nchains=nch, burnin=30, thin=2, kernel=kr, conv_checker=chk)
+    r = _run_ranks(tmp_path, "ram_gelman")
+    assert [int(x["chain_base"]) for x in r] == [0, 2] and [x["samples"].shape[0] for x in r] == [2, 3]
+    both = np.concatenate([x["samples"] for x in r])
+    assert np.array_equal(_bits(both.transpose(0, 2, 1)), _bits(full.as_array()))
+    assert np.array_equal(_bits(np.concatenate([x["Sigma"] for x in r])), _bits(kr._state.Sigma.cpu().numpy()))
+    for x in r:
+        assert list(x["hist_end"]) == [h[0] for h in chk.history]
+        assert np.allclose(x["hist_val"], [h[1] for h in chk.history], rtol=1e-9)
+
+
+def test_fewer_chains_than_ranks(setup, tmp_path):
+    f, fun = setup
+    full = f.MCMC([0, 0, 0, 4.0], fun, 500, seed=3, nchains=1, kernel=f.kernel_normal(scale=0.05))
+    r = _run_ranks(tmp_path, "fewer")
+    shapes = [x["samples"].shape for x in r]
+    assert sorted(s[0] for s in shapes) == [0, 1]                    # one rank runs the chain, the other none
+    got = [x["samples"] for x in r if x["samples"].shape[0] == 1][0]
+    assert np.array_equal(_bits(got[0].T), _bits(full.data))
+
+
+def test_seed_none_is_rank_zeros_seed_everywhere(setup, tmp_path):
+    f, fun = setup
+    r = _run_ranks(tmp_path, "seed_none")
+    seed = int(r[0]["seed"][0])
+    assert int(r[1]["seed"][0]) == seed                              # broadcast from rank 0 (R/mcmc.R:455-456 sets ONE seed)
+    full = f.MCMC(np.tile([0, 0, 0, 4.0], (4, 1)), fun, 300, seed=seed, nchains=4, kernel=f.kernel_normal(scale=0.05))
+    both = np.concatenate([x["samples"] for x in r])
+    assert np.array_equal(_bits(both.transpose(0, 2, 1)), _bits(full.as_array()))   # MCMC_OUTPUT's seed reproduces the run
