@@ -16,101 +16,173 @@
 namespace {
 
 constexpr int GT = 256;  // threads per block
-constexpr int TT = 32;   // rows per LDS tile
 
-// One block per chain. work[c] = { xbar[p], Sc[p*p] } (centred at `center` for xbar).
-__global__ __launch_bounds__(GT) void gelman_chain_kernel(const double* __restrict__ samples, long long S,
-                                                          int k, long long row0, long long N,
-                                                          const int* __restrict__ cols, int p,
-                                                          const double* __restrict__ center,
-                                                          double* __restrict__ work) {
-  extern __shared__ double sm[];
-  double* s_mean = sm;          // [p]
-  double* s_tile = sm + p;      // [p][TT+1]
-  const int tid = threadIdx.x;
+// One block (4 wavefronts) per chain: work[c] = { xbar[p] - center, S_c[p*p] } of the window [row0, row0 + N).
+//
+// The window of one chain is a column-major N x p matrix D; its covariance is the rank-N update D'D -- the one GEMM-shaped
+// piece of the whole engine besides the log-posterior, and at config C4 (512 chains x p = 50 x 5,000 rows: 1 GB, 13 GFLOP)
+// it is as much arithmetic as memory traffic.  So it runs on the matrix cores: v_mfma_f64_16x16x4 with M = N = a block of
+// 16 columns and K = 4 consecutive rows.  Both operands have the SAME lane layout (lane l holds row t0 + l / 16 of column
+// 16 cb + l % 16), so a K-step loads one double per lane and column block and feeds all NCB (NCB + 1) / 2 tile pairs.
+// ONE pass over the data: rows are shifted by the chain's first window row (d = x - x[row0]; the shift is within a few
+// standard deviations of the mean, which keeps sum d d' - N dbar dbar' free of cancellation), the column sums ride along on
+// the VALU.  The four waves take four contiguous row ranges and are combined through LDS in wave order; the result does
+// not depend on the launch.  (The previous VALU version: one thread per column for the means, LDS-tiled pair products:
+// 4.8 ms = 215 GB/s at C4's width.)
+typedef double gd4_t __attribute__((ext_vector_type(4)));
+template <int NCB>
+__global__ __launch_bounds__(GT) void gelman_chain_mfma(const double* __restrict__ samples, long long S, int k, long long row0,
+                                                        long long N, const int* __restrict__ cols, int p,
+                                                        const double* __restrict__ center, double* __restrict__ work) {
+  constexpr int NT2 = NCB * (NCB + 1) / 2;          // tile pairs (a-block <= b-block)
+  __shared__ double s_acc[NT2 * 256];               // [tile][lane * 4 + r]
+  __shared__ double s_sum[NCB * 16];                // column sums of d
+  __shared__ double s_shift[NCB * 16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kk = lane >> 4, j = lane & 15;
   const long long c = blockIdx.x;
-  const double* base = samples + c * (long long)k * S;
-  // pass 1: means (thread a sums its column in row order; p <= 64 columns)
-  if (tid < p) {
-    const double* col = base + (long long)cols[tid] * S + row0;
-    double s = 0.0;
-    for (long long t = 0; t < N; t++) s += col[t];
-    s_mean[tid] = s / (double)N;
+  const double* base = samples + c * (long long)k * S + row0;
+  // this lane's column of every block (a padded column reads column 0 and is multiplied by 0)
+  const double* colp[NCB];
+  double shift[NCB], msk[NCB], csum[NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; cb++) {
+    const int a = cb * 16 + j;
+    colp[cb] = base + (long long)cols[a < p ? a : 0] * S;
+    shift[cb] = colp[cb][0];
+    msk[cb] = a < p ? 1.0 : 0.0;
+    csum[cb] = 0.0;
   }
-  __syncthreads();
-  // pass 2: covariance, pairs (a,b) a<=b dealt to threads; tiles staged through LDS
-  const int npairs = p * (p + 1) / 2;
-  constexpr int MAXPP = (FMCMC_MAX_K * (FMCMC_MAX_K + 1) / 2 + GT - 1) / GT;  // pairs per thread
-  double acc[MAXPP];
+  gd4_t acc[NT2];
 #pragma unroll
-  for (int q = 0; q < MAXPP; q++) acc[q] = 0.0;
-  for (long long t0 = 0; t0 < N; t0 += TT) {
-    const int nt = (int)((N - t0 < TT) ? (N - t0) : TT);
-    for (int e = tid; e < p * TT; e += GT) {
-      int a = e / TT, t = e % TT;
-      s_tile[a * (TT + 1) + t] = (t < nt) ? (base[(long long)cols[a] * S + row0 + t0 + t] - s_mean[a]) : 0.0;
+  for (int t = 0; t < NT2; t++) acc[t] = (gd4_t){0.0, 0.0, 0.0, 0.0};
+  // Rows of this wave: a contiguous quarter of the window, in groups of 16.  Lane (kk, j) loads rows 4 kk .. 4 kk + 3 of the
+  // group for its column -- 32 contiguous bytes, the four kk classes together a full 128-byte line per column -- and K-step s
+  // of the group multiplies rows {4 kk + s}: which four rows share a K-step only changes the order of a sum.  Two groups are
+  // in flight behind the one being multiplied (the loads come from HBM: ~2 us, a group's 40 MFMAs are ~1 us).
+  const long long groups = (N + 15) / 16, per = (groups + 3) / 4;
+  const long long g_lo = wave * per, g_hi = (g_lo + per < groups) ? g_lo + per : groups;
+  typedef double gd2_t __attribute__((ext_vector_type(2)));
+  double buf[3][NCB][4];
+  auto load = [&](long long gi, double (&v)[NCB][4]) {
+    const long long t = 16 * gi + 4 * kk;
+    if (t + 3 < N) {
+#pragma unroll
+      for (int cb = 0; cb < NCB; cb++) {
+        const gd2_t lo = *reinterpret_cast<const gd2_t*>(colp[cb] + t), hi = *reinterpret_cast<const gd2_t*>(colp[cb] + t + 2);
+        v[cb][0] = lo[0]; v[cb][1] = lo[1]; v[cb][2] = hi[0]; v[cb][3] = hi[1];
+      }
+    } else {
+#pragma unroll
+      for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[cb][u] = (t + u < N) ? colp[cb][t + u] : shift[cb];   // (a row beyond the window: d = 0)
     }
-    __syncthreads();
+  };
+  if (g_lo < g_hi) load(g_lo, buf[0]);
+  if (g_lo + 1 < g_hi) load(g_lo + 1, buf[1]);
+  for (long long gi = g_lo; gi < g_hi; gi += 3) {
 #pragma unroll
-    for (int q = 0; q < MAXPP; q++) {
-      int pr = tid + q * GT;
-      if (pr < npairs) {
-        // unrank pair index -> (a,b), a<=b, row-major upper triangle
-        int a = 0, rem = pr;
-        while (rem >= p - a) { rem -= p - a; a++; }
-        int b = a + rem;
-        double s = acc[q];
-        for (int t = 0; t < nt; t++) s = __builtin_fma(s_tile[a * (TT + 1) + t], s_tile[b * (TT + 1) + t], s);
-        acc[q] = s;
+    for (int ph = 0; ph < 3; ph++) {       // buffer roles rotate statically
+      if (gi + ph < g_hi) {
+        if (gi + ph + 2 < g_hi) load(gi + ph + 2, buf[(ph + 2) % 3]);
+        double (&cur)[NCB][4] = buf[ph];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          double d[NCB];
+#pragma unroll
+          for (int cb = 0; cb < NCB; cb++) { d[cb] = (cur[cb][u] - shift[cb]) * msk[cb]; csum[cb] += d[cb]; }
+          int t = 0;
+#pragma unroll
+          for (int ab = 0; ab < NCB; ab++)
+#pragma unroll
+            for (int bb = ab; bb < NCB; bb++, t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(d[ab], d[bb], acc[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // column sums: the four kk classes of a column sit in lanes j, j + 16, j + 32, j + 48
+#pragma unroll
+  for (int cb = 0; cb < NCB; cb++) {
+    double v = csum[cb];
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    csum[cb] = v;
+  }
+  // waves combine in wave order
+  for (int w = 0; w < 4; w++) {
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < NT2; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          double* d = &s_acc[t * 256 + lane * 4 + r];
+          *d = (w == 0) ? acc[t][r] : *d + acc[t][r];
+        }
+      if (lane < 16) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) {
+          double* d = &s_sum[cb * 16 + lane];
+          *d = (w == 0) ? csum[cb] : *d + csum[cb];
+          if (w == 0) s_shift[cb * 16 + lane] = shift[cb];
+        }
       }
     }
     __syncthreads();
   }
-  double* w = work + c * (long long)(p + p * p);
-  if (tid < p) w[tid] = s_mean[tid] - (center ? center[tid] : 0.0);
-#pragma unroll
-  for (int q = 0; q < MAXPP; q++) {
-    int pr = tid + q * GT;
-    if (pr < npairs) {
-      int a = 0, rem = pr;
-      while (rem >= p - a) { rem -= p - a; a++; }
-      int b = a + rem;
-      double v = acc[q] / (double)(N - 1);
-      w[p + a * p + b] = v;
-      w[p + b * p + a] = v;
+  // finish: D register r of lane l is row 4 r + l / 16, column l % 16 of its tile
+  double* wout = work + c * (long long)(p + p * p);
+  const double dn = (double)N;
+  if (tid < p) wout[tid] = (s_shift[tid] + s_sum[tid] / dn) - (center ? center[tid] : 0.0);
+  for (int e = tid; e < NT2 * 256; e += GT) {
+    const int t = e >> 8, q = e & 255, l = q >> 2, r = q & 3;
+    int ab = 0, rem = t;
+    while (rem >= NCB - ab) { rem -= NCB - ab; ab++; }
+    const int bb = ab + rem;
+    const int a = ab * 16 + 4 * r + (l >> 4), b2 = bb * 16 + (l & 15);
+    if (a < p && b2 < p && (ab < bb || a <= b2)) {
+      const double v = (s_acc[e] - s_sum[a] * s_sum[b2] / dn) / (dn - 1.0);
+      wout[p + a * p + b2] = v;
+      wout[p + b2 * p + a] = v;
     }
   }
 }
 
-// Single block: fixed-order sum over chains -> partial.
+// Fixed-order sum over the local chains -> partial.  64 elements of the partial per block, four threads per element: thread
+// g sums the chains g, g + 4, g + 8, ... in chain order, the four sums are joined as ((g0 + g1) + g2) + g3.  (One block for
+// everything -- 21 elements per thread, each a serial walk over 512 chains -- took 2.5 of the 3.0 ms of a check at C4.)
 __global__ __launch_bounds__(GT) void gelman_sum_kernel(const double* __restrict__ work, long long C, int p,
                                                         double* __restrict__ partial) {
-  const int tid = threadIdx.x;
+  __shared__ double s_g[4][64];
+  const int el = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int stride = p + p * p;
   const int len = 1 + 5 * p + 2 * p * p;
-  for (int e = tid; e < len; e += GT) {
-    double s = 0.0;
+  const int e = blockIdx.x * 64 + el;
+  double s = 0.0;
+  if (e < len) {
     if (e == 0) {
-      s = (double)C;
+      s = (g == 0) ? (double)C : 0.0;
     } else if (e < 1 + p) {  // sum xbar
       int a = e - 1;
-      for (long long c = 0; c < C; c++) s += work[c * stride + a];
+      for (long long c = g; c < C; c += 4) s += work[c * stride + a];
     } else if (e < 1 + p + p * p) {  // sum xbar xbar^T
       int ab = e - 1 - p, a = ab / p, b = ab % p;
-      for (long long c = 0; c < C; c++) s = __builtin_fma(work[c * stride + a], work[c * stride + b], s);
+      for (long long c = g; c < C; c += 4) s = __builtin_fma(work[c * stride + a], work[c * stride + b], s);
     } else if (e < 1 + p + 2 * p * p) {  // sum S_c
       int ab = e - 1 - p - p * p;
-      for (long long c = 0; c < C; c++) s += work[c * stride + p + ab];
+      for (long long c = g; c < C; c += 4) s += work[c * stride + p + ab];
     } else {
       int r = e - 1 - p - 2 * p * p, which = r / p, a = r % p;
-      for (long long c = 0; c < C; c++) {
+      for (long long c = g; c < C; c += 4) {
         double s2 = work[c * stride + p + a * p + a], xb = work[c * stride + a];
         double v = (which == 0) ? s2 : (which == 1) ? s2 * s2 : (which == 2) ? s2 * xb : s2 * xb * xb;
         s += v;
       }
     }
-    partial[e] = s;
   }
+  s_g[g][el] = s;
+  __syncthreads();
+  if (g == 0 && e < len) partial[e] = ((s_g[0][el] + s_g[1][el]) + s_g[2][el]) + s_g[3][el];
 }
 
 }  // namespace
@@ -127,10 +199,18 @@ int fmcmc_gelman_partial_dev(const double* samples, int64_t nchains, int32_t k, 
       row0 < 0 || row0 + N > S)
     return FMCMC_ERR_ARG;
   hipStream_t st = (hipStream_t)hip_stream;
-  size_t lds = sizeof(double) * ((size_t)p + (size_t)p * (TT + 1));
-  hipLaunchKernelGGL(gelman_chain_kernel, dim3((unsigned)nchains), dim3(GT), lds, st, samples,
-                     (long long)S, (int)k, (long long)row0, (long long)N, cols, (int)p, center, work);
-  hipLaunchKernelGGL(gelman_sum_kernel, dim3(1), dim3(GT), 0, st, work, (long long)nchains, (int)p, partial);
+#define GELMAN_LAUNCH(NCBV)                                                                                         \
+  hipLaunchKernelGGL(gelman_chain_mfma<NCBV>, dim3((unsigned)nchains), dim3(GT), 0, st, samples, (long long)S, (int)k, \
+                     (long long)row0, (long long)N, cols, (int)p, center, work)
+  switch ((p + 15) / 16) {
+    case 1: GELMAN_LAUNCH(1); break;
+    case 2: GELMAN_LAUNCH(2); break;
+    case 3: GELMAN_LAUNCH(3); break;
+    default: GELMAN_LAUNCH(4); break;
+  }
+#undef GELMAN_LAUNCH
+  const int plen = 1 + 5 * (int)p + 2 * (int)p * (int)p;
+  hipLaunchKernelGGL(gelman_sum_kernel, dim3((unsigned)((plen + 63) / 64)), dim3(GT), 0, st, work, (long long)nchains, (int)p, partial);
   return hipGetLastError() == hipSuccess ? FMCMC_OK : FMCMC_ERR_DEVICE;
 }
 

@@ -134,6 +134,41 @@ def test_gelman_partial_kernel(E, O):
     assert np.allclose(psrf, opsrf, rtol=1e-9) and abs(mps.value - ompsrf) < 1e-9 * ompsrf
 
 
+@pytest.mark.parametrize("Cn,k,S,row0,ncols", [(512, 50, 6000, 1000, 50), (9, 20, 333, 101, 17), (5, 40, 90, 7, 33)])
+def test_gelman_partial_kernel_wide(E, O, Cn, k, S, row0, ncols):
+    """The device reduction of convergence_gelman at config C4's width (512 chains x p = 50 x a 5,000-row window: the
+    v_mfma_f64_16x16x4 rank-N update) and at ragged shapes (1 to 3 column blocks, windows that are no multiple of the
+    K-step, a column subset): partial vector == its numpy definition, psrf / mpsrf == the oracle's coda restatement
+    (R/convergence.R:191-246 -> coda::gelman.diag)."""
+    import torch
+    from fmcmc_amd import _abi as abi
+    from test_abi import numpy_gelman_partial
+    g = torch.Generator(device="cuda"); g.manual_seed(Cn + k)
+    xd = torch.randn((Cn, k, S), dtype=torch.float64, device="cuda", generator=g) * 0.5 + 3.0
+    xd += torch.randn((Cn, k, 1), dtype=torch.float64, device="cuda", generator=g) * 0.05        # chains differ a little
+    xd += torch.cumsum(torch.randn((Cn, k, S), dtype=torch.float64, device="cuda", generator=g), 2) * 0.01   # autocorrelated
+    N = S - row0
+    cols = np.sort(np.random.default_rng(k).choice(k, size=ncols, replace=False)).astype(np.int32)
+    cd = torch.as_tensor(cols).cuda()
+    center = xd[0, cd.long(), row0].contiguous()
+    L = abi.lib()
+    p = ncols
+    part = torch.zeros(int(L.fmcmc_gelman_partial_len(p)), dtype=torch.float64, device="cuda")
+    work = torch.empty(int(L.fmcmc_gelman_work_len(Cn, p)), dtype=torch.float64, device="cuda")
+    rc = L.fmcmc_gelman_partial_dev(xd.data_ptr(), Cn, k, S, row0, N, cd.data_ptr(), p, center.data_ptr(),
+                                    work.data_ptr(), part.data_ptr(), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    win = xd[:, cd.long(), row0:].cpu().numpy().transpose(0, 2, 1)  # [m][N][p]
+    ref = numpy_gelman_partial(win, center.cpu().numpy())
+    got = part.cpu().numpy()
+    assert np.allclose(got, ref, rtol=1e-9, atol=1e-11 * np.abs(ref).max())
+    psrf = np.empty(p); mps = C.c_double(); dp = C.POINTER(C.c_double)
+    assert L.fmcmc_gelman_finish(got.ctypes.data_as(dp), p, N, psrf.ctypes.data_as(dp), C.byref(mps)) == 0
+    opsrf, ompsrf = O.gelman(win)
+    assert np.allclose(psrf, opsrf, rtol=1e-9) and abs(mps.value - ompsrf) < 1e-9 * ompsrf
+
+
 def test_mcmc_api_end_to_end(E, O, readme_data):
     import fmcmc_amd as f
     X, y = readme_data
