@@ -1,15 +1,24 @@
 #!/usr/bin/env python3
-"""Headline benchmark: MH samples/s (chains x iterations / s), BASELINE.json configs[1]:
-1024 chains x 5-parameter Gaussian linear regression, n = 10,000, kernel_normal, 1 MI355X.
+"""Benchmark of the hot path: MH samples/s (chains x iterations / s).
 
-One "step" = one full sweep of the hot path over the workload: all chains of the rank advance
-`--iters` MH iterations (default 10,000 = the config's nsteps) inside ONE fused kernel launch,
-writing ans, logpost and draws exactly like the reference (R/mcmc.R:728-734,822-823).
+Default = the headline, BASELINE.json configs[1]: 1024 chains x 5-parameter Gaussian linear regression, n = 10,000,
+kernel_normal, 1 MI355X.  `--config c3|c4|c5` runs the other GPU configs of BASELINE.md section 4 with their PER-GPU share
+of chains (C4 512, C5 1024) and prints the same JSON shape.
+
+One "step" = one full sweep of the hot path over the workload: all chains of the rank advance the config's number of MH
+iterations, writing ans / logpost / draws like the reference (R/mcmc.R:728-734,822-823).  C2, C3, C5: ONE fused kernel
+launch per step.  C4: the config runs under convergence_gelman(freq = 1000), so a step is ten 1000-iteration bulks appended
+to one preallocated history, each followed by the Gelman check (device reduction + the engine's only collective, an
+all-reduce over RCCL when N > 1); the threshold is set so that no check stops the run and every step does the same work.
 Inputs (X, y, initial states) are resident in HBM before the timed region.
 
-  python bench.py [--gpus N --steps K --warmup W]
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (weak scaling:
-  every rank runs its own 1024-chain shard, chain ids continue across ranks, no data-path collective)
+  python bench.py [--gpus N --steps K --warmup W] [--config c2|c3|c4|c5]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (weak scaling: every rank runs its own
+  shard, chain ids continue across ranks, no data-path collective)
+
+The line reports what was measured in THIS run: roofline.kernel is fmcmc_last_kernel() (and the run fails if the dispatcher
+did not pick the kernel the config is tuned for), roofline.kernel_ms comes from HIP events on the launch stream, and
+roofline.traffic is null unless a PMC pass of the same command is named (profiles/README.md says how those are taken).
 """
 import argparse
 import json
@@ -24,67 +33,147 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP64_TFLOPS = 78.6   # MI355X fp64 vector = fp64 matrix peak (256 CU x 128 flop/clk x 2.4 GHz)
 PEAK_HBM_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-
-N_OBS, P_COV, K_PAR = 10000, 3, 5
-CHAINS_PER_GPU = 1024
-SCALE = 0.02
-DATA_SEED, CHAIN_SEED = 20260102, 1215
+CHAIN_SEED = 1215
 
 
-def make_workload(chains, chain_base):
-    rng = np.random.default_rng(DATA_SEED)
-    X = rng.standard_normal((N_OBS, P_COV))
-    beta = np.array([3.0, 2.0, -1.0, 0.5])
-    y = beta[0] + X @ beta[1:] + 4.0 * rng.standard_normal(N_OBS)
-    irng = np.random.default_rng(DATA_SEED + 1)
-    jit = 0.1 * irng.standard_normal((chain_base + chains, K_PAR))[chain_base:]
-    init = np.array([0.0, 0.0, 0.0, 0.0, float(np.std(y, ddof=1))])[None, :] + jit
-    init[:, -1] = np.abs(init[:, -1])
-    return X, y, np.ascontiguousarray(init)
+# ------------------------------------------------------------------------------------------------ the four GPU configs
+class Config:
+    """BASELINE.md section 4 / SURVEY.md 8(d): data seeds 20260101 + config number, chain RNG seed 1215."""
+
+    def __init__(self, name):
+        self.name = name
+        if name in ("c2", "c3"):
+            self.num, self.n, self.p, self.k = (2, 10000, 3, 5) if name == "c2" else (3, 10000, 3, 5)
+            self.chains, self.iters, self.thin = 1024, 10000, 1
+            self.family = "linreg"
+            self.kernel_name = "kernel_normal(scale=0.02)" if name == "c2" else "kernel_adapt() (warmup 500)"
+            self.expect_kernel = "mfma" if name == "c2" else "spec"
+            self.flops = self.n * (2 * self.p + 3)          # E n (2(p-1)+3), p-1 = 3 covariates
+            self.flops_note = "SURVEY 8(d): n (2 x 3 + 3) = 9.0e4 per sample"
+            self.bulk = None
+        elif name == "c4":
+            self.num, self.n, self.p, self.k = 4, 10000, 48, 50
+            self.chains, self.iters, self.thin = 512, 10000, 1
+            self.family = "linreg"
+            self.kernel_name = "kernel_ram() + convergence_gelman(freq=1000)"
+            self.expect_kernel = "streamed-wide-sharded-mfma"
+            # unbounded kernel_ram evaluates the log-posterior ONCE per step (the un-reflected proposal IS the proposal):
+            # E = 1 -> n (2 x 48 + 3) + 3 k^2 (S u, factor update).  SURVEY 8(d) prices E = 2 (1.98e6); both are reported.
+            self.flops = self.n * (2 * self.p + 3) + 3 * self.k * self.k
+            self.flops_note = "executed: E = 1 evaluation per step (unbounded kernel_ram) = n (2 x 48 + 3) + 3 k^2 = 9.98e5; SURVEY 8(d) counts E = 2: 1.98e6"
+            self.bulk = 1000
+        elif name == "c5":
+            self.num, self.n, self.p, self.k = 5, 100000, 5, 6
+            self.chains, self.iters, self.thin = 1024, 5000, 10
+            self.family = "logistic"
+            self.kernel_name = "kernel_normal_reflective(scale=0.01, lb=-5, ub=5), thin 10"
+            self.expect_kernel = "streamed-logistic"
+            self.flops = self.n * (2 * self.p + 8)          # exp and log1p counted as 1 flop each
+            self.flops_note = "SURVEY 8(d): n (2 x 5 + 8) = 1.8e6 per sample, transcendentals counted as one flop each"
+            self.bulk = None
+        else:
+            raise SystemExit("unknown --config %s" % name)
+        self.data_seed = 20260100 + self.num
+
+    def workload(self, chains, chain_base):
+        rng = np.random.default_rng(self.data_seed)
+        n, p, k = self.n, self.p, self.k
+        X = rng.standard_normal((n, p))
+        if self.name in ("c2", "c3"):
+            beta = np.array([3.0, 2.0, -1.0, 0.5])
+            y = beta[0] + X @ beta[1:] + 4.0 * rng.standard_normal(n)
+            base = np.array([0.0, 0.0, 0.0, 0.0, float(np.std(y, ddof=1))])
+            jit = 0.1
+        elif self.name == "c4":
+            beta = rng.standard_normal(p + 1)
+            y = beta[0] + X @ beta[1:] + 2.0 * rng.standard_normal(n)
+            base = np.concatenate([beta, [2.0]])
+            jit = 0.01
+        else:
+            beta = np.array([-1.0, 0.5, -0.5, 0.25, -0.25, 1.0])
+            y = (rng.uniform(size=n) < 1.0 / (1.0 + np.exp(-(beta[0] + X @ beta[1:])))).astype(np.float64)
+            base = beta.copy()
+            jit = 0.01
+        irng = np.random.default_rng(self.data_seed + 1)
+        init = base[None, :] + jit * irng.standard_normal((chain_base + chains, k))[chain_base:]
+        if self.family == "linreg":
+            init[:, -1] = np.abs(init[:, -1])
+        return X, y, np.ascontiguousarray(init)
+
+    # kernel parameters shared by the engine's KernelSpec and the oracle's Kernel
+    def kernel_args(self):
+        k = self.k
+        if self.name == "c2":
+            return dict(kind=1, scale=0.02)
+        if self.name == "c3":
+            return dict(kind=3, warmup=500)
+        if self.name == "c4":
+            return dict(kind=4)
+        return dict(kind=2, scale=0.01, lb=-5.0, ub=5.0)
 
 
-def flops_per_sample():
-    # E * n * (2(p-1)+3), p-1 = 3 covariates: 3 fma + 1 sub + 1 fma per observation (the MFMA path
-    # executes 4 fma + 1 fma = 10 flop per observation; the ALGORITHMIC 9 is what achieved/peak is computed from)
-    return N_OBS * (2 * P_COV + 3)
+def device_objects(cfg, E, abi, X, y, dev):
+    big = E.DBL_MAX
+    k, ka = cfg.k, cfg.kernel_args()
+    fam = abi.FAM_GAUSSIAN_LINREG if cfg.family == "linreg" else abi.FAM_LOGISTIC
+    gm = E.DeviceModel(fam, X, y, device=dev) if cfg.family == "linreg" else \
+        E.DeviceModel(fam, X, y, intercept=True, guard=False, prior_div=8.0, device=dev)
+    gk = E.KernelSpec(ka["kind"], k, np.zeros(k), np.full(k, ka.get("scale", 1.0)), np.full(k, ka.get("lb", -big)),
+                      np.full(k, ka.get("ub", big)), np.zeros(k, np.uint8), warmup=ka.get("warmup", 0), device=dev)
+    return gm, gk
 
 
-def cpu_baseline(seconds_budget=24.0):
-    """The oracle (PHILOX/canonical mode = same outputs as the GPU) timed on the host cores, on a
-    bounded sample of the SAME workload: `m` chains x 10,000 iterations per host thread."""
+def oracle_objects(cfg, O, X, y):
+    ka = cfg.kernel_args()
+    if cfg.family == "linreg":
+        m = O.Model(O.FAM_LINREG, X, y)
+    else:
+        m = O.Model(O.FAM_LOGISTIC, X, y, intercept=True, guard=False, prior_div=8.0)
+    kw = {a: ka[a] for a in ("scale", "lb", "ub", "warmup") if a in ka}
+    return m, O.Kernel({1: O.K_NORMAL, 2: O.K_NORMAL_REFLECTIVE, 3: O.K_ADAPT, 4: O.K_RAM}[ka["kind"]], cfg.k, **kw)
+
+
+def cpu_baseline(cfg, seconds_budget=20.0):
+    """The oracle (PHILOX / canonical mode = the GPU's exact outputs) timed on the host cores on a bounded sample of the SAME
+    workload: (a) all host threads, one block of chains per thread -- the analogue of fmcmc's multicore = TRUE with
+    min(nchains, detectCores()) workers (R/mcmc.R:539-541); (b) one thread."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
     cores = os.cpu_count() or 1
-    iters = 10000
-    # calibrate with ALL host threads busy (SMT and memory contention included), then size the sample
-    X, y, init0 = make_workload(cores, 0)
-    m = O.Model(O.FAM_LINREG, X, y)
-    k = O.Kernel(O.K_NORMAL, K_PAR, scale=SCALE)
+    X, y, init0 = cfg.workload(cores, 0)
+    m, k = oracle_objects(cfg, O, X, y)
 
-    def cal(tix):
-        O.run(m, k, init0[tix:tix + 1], nsteps=201, seed=CHAIN_SEED, chain_base=tix, want_draws=True)
+    def run(init, lo, iters):
+        O.run(m, k, init, nsteps=iters, thin=cfg.thin if iters > cfg.thin else 1, seed=CHAIN_SEED, chain_base=lo, want_draws=True)
 
+    # (b) one thread: calibrate on a few iterations, then ~1/4 of the budget (whole chains when a chain fits)
+    t = time.time(); run(init0[:1], 0, 21); per1 = (time.time() - t) / 20
+    it1 = int(max(50, min(cfg.iters, 0.25 * seconds_budget / per1)))
+    ch1 = int(max(1, min(cores, 0.25 * seconds_budget / (per1 * it1))))
+    t = time.time(); run(init0[:ch1], 0, it1); dt1 = time.time() - t
+    single = {"value": ch1 * (it1 - 1) / dt1, "unit": "MH samples/s", "cores": 1,
+              "sample": "%d chain(s) x %d iterations" % (ch1, it1), "seconds": dt1}
+    # (a) all threads busy: calibrate under full load (SMT and memory contention included), then size the sample
     t = time.time()
     with ThreadPoolExecutor(cores) as ex:
-        list(ex.map(cal, range(cores)))
-    per = (time.time() - t) / 200            # seconds per iteration of one chain per thread, under load
-    per_thread = int(max(1, min(64, seconds_budget / (per * iters))))
+        list(ex.map(lambda tix: run(init0[tix:tix + 1], tix, 21), range(cores)))
+    per = (time.time() - t) / 20
+    want = 0.75 * seconds_budget
+    if per * cfg.iters <= want:                       # whole chains: several per thread
+        per_thread, iters = int(max(1, min(64, want / (per * cfg.iters)))), cfg.iters
+    else:                                             # a chain is longer than the budget: a prefix of its iterations
+        per_thread, iters = 1, int(max(50, want / per))
     chains = cores * per_thread
-    _, _, init = make_workload(chains, 0)
-
-    def one(tix):  # ctypes releases the GIL: one oracle call per host thread
-        lo = tix * per_thread
-        O.run(m, k, init[lo:lo + per_thread], nsteps=iters, seed=CHAIN_SEED, chain_base=lo, want_draws=True)
-
+    _, _, init = cfg.workload(chains, 0)
     t = time.time()
-    with ThreadPoolExecutor(cores) as ex:
-        list(ex.map(one, range(cores)))
+    with ThreadPoolExecutor(cores) as ex:             # ctypes releases the GIL: one oracle call per host thread
+        list(ex.map(lambda tix: run(init[tix * per_thread:(tix + 1) * per_thread], tix * per_thread, iters), range(cores)))
     dt = time.time() - t
-    return {"value": chains * (iters - 1) / dt, "unit": "MH samples/s", "cores": cores, "kind": "port",
-            "seconds": dt,
-            "sample": "%d chains x %d iterations of the same workload (%d chains per host thread), "
-                      "oracle/fmcmc_oracle.c in PHILOX/canonical mode: a C restatement of fmcmc's R loop that "
-                      "produces the GPU's exact outputs; optimistic vs interpreted R" % (chains, iters, per_thread)}
+    return {"value": chains * (iters - 1) / dt, "unit": "MH samples/s", "cores": cores, "kind": "port", "seconds": dt,
+            "sample": "%d chains x %d iterations of the same workload (%d chains per host thread), oracle/fmcmc_oracle.c in "
+                      "PHILOX/canonical mode: a C restatement of fmcmc's R loop that produces the GPU's exact outputs; "
+                      "optimistic vs interpreted R" % (chains, iters, per_thread),
+            "single_thread": single}
 
 
 def main():
@@ -92,10 +181,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--iters", type=int, default=10000, help="MH iterations per sweep (config nsteps)")
-    ap.add_argument("--chains", type=int, default=CHAINS_PER_GPU, help="chains per GPU")
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--iters", type=int, default=0, help="MH iterations per sweep (default: the config's nsteps)")
+    ap.add_argument("--chains", type=int, default=0, help="chains per GPU (default: the config's per-GPU share)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic-from", default=None, help="JSON of a PMC pass of this same command (hbm_bytes_per_launch)")
     args = ap.parse_args()
+    cfg = Config(args.config)
 
     import torch
     import torch.distributed as dist
@@ -112,32 +204,72 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    chains, iters = args.chains, args.iters
+    chains = args.chains or cfg.chains
+    iters = args.iters or cfg.iters
+    thin, k = cfg.thin, cfg.k
     chain_base = rank * chains
-    X, y, init = make_workload(chains, chain_base)
-    gm = E.DeviceModel(abi.FAM_GAUSSIAN_LINREG, X, y, device=dev)
-    gk = E.KernelSpec(abi.KERNEL_NORMAL, K_PAR, np.zeros(K_PAR), np.full(K_PAR, SCALE),
-                      np.full(K_PAR, -E.DBL_MAX), np.full(K_PAR, E.DBL_MAX), np.zeros(K_PAR, np.uint8), device=dev)
+    X, y, init = cfg.workload(chains, chain_base)
+    gm, gk = device_objects(cfg, E, abi, X, y, dev)
     init_d = torch.as_tensor(init).to(dev)
+    S = (iters - 0) // thin
+    picked = []
 
-    # the canonical Philox stream of a sweep is generated by its own small kernel into reusable HBM buffers,
-    # then the sweep consumes it (bit-identical to letting the library do both); two launches per step
-    logu_buf = torch.empty((chains, iters), dtype=torch.float64, device=dev)
-    z_buf = torch.empty((chains, iters, K_PAR), dtype=torch.float64, device=dev)
+    if cfg.name == "c4":
+        # the config's own loop: bulks of 1000 iterations appended to one preallocated history (fmcmc_out.ld_rows), the Gelman
+        # check behind each (fmcmc_gelman_partial_dev + all-reduce + fmcmc_gelman_finish); draws are not recorded (2 GB)
+        from fmcmc_amd.mcmc import DeviceChains
+        from fmcmc_amd.convergence import convergence_gelman
+        chk = convergence_gelman(cfg.bulk, threshold=0.0)      # R-hat >= 1 > 0: no check stops the run
+        bulks = [cfg.bulk] * (iters // cfg.bulk) + ([iters % cfg.bulk] if iters % cfg.bulk else [])
+        hist = DeviceChains.allocate(chains, k, S, thin, None, chain_base, world * chains, dev, want_logpost=True, want_draws=False)
+        free = np.arange(k)
+        ev_chk = []
+
+        def one_step():
+            st = E.ChainState(init_d, k, device=dev)
+            hist.nrows, hist.iters = 0, np.zeros(0, dtype=np.int64)
+            chk.flush()
+            out = None
+            tchk = 0.0
+            for nb in bulks:
+                out = E.sweep(gm, gk, st, nb, thin=thin, seed=CHAIN_SEED, chain_base=chain_base, want_bits=False, check=False,
+                              into=(hist._samples, hist._logpost, None), row0=hist.nrows)
+                picked.append(abi.last_kernel())
+                hist.extend(out.iters)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                chk.check_device(hist, free)
+                e1.record()
+                ev_chk.append((e0, e1))
+            return out
+    else:
+        # the canonical Philox stream of a sweep is generated by its own small kernel into reusable HBM buffers where the
+        # sweep kernel consumes a materialised stream (C2, C3: bit-identical to letting the library do both)
+        streamed_rng = cfg.name in ("c2", "c3")
+        if streamed_rng:
+            logu_buf = torch.empty((chains, iters), dtype=torch.float64, device=dev)
+            z_buf = torch.empty((chains, iters, gk.kz), dtype=torch.float64, device=dev)
+
+        def one_step():
+            st = E.ChainState(init_d, k, device=dev)
+            kw = {}
+            if streamed_rng:
+                E.rng_stream(st, gk, iters, seed=CHAIN_SEED, chain_base=chain_base, logu=logu_buf, z=z_buf)
+                kw = dict(fed_logu=logu_buf, fed_z=z_buf)
+            if cur["s"] is not None:
+                ev_mid[cur["s"]].record()
+            out = E.sweep(gm, gk, st, iters, thin=thin, seed=CHAIN_SEED, chain_base=chain_base, want_logpost=True,
+                          want_draws=True, want_bits=False, check=False, **kw)
+            picked.append(abi.last_kernel())
+            return out
+
     ev_mid = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     cur = {"s": None}
-
-    def one_step():
-        st = E.ChainState(init_d, K_PAR, device=dev)
-        E.rng_stream(st, gk, iters, seed=CHAIN_SEED, chain_base=chain_base, logu=logu_buf, z=z_buf)
-        if cur["s"] is not None:
-            ev_mid[cur["s"]].record()
-        return E.sweep(gm, gk, st, iters, seed=CHAIN_SEED, chain_base=chain_base, want_logpost=True,
-                       want_draws=True, want_bits=False, check=False, fed_logu=logu_buf, fed_z=z_buf)
-
     for _ in range(args.warmup):
         out = one_step()
     torch.cuda.synchronize()
+    if cfg.name == "c4":
+        ev_chk.clear()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -146,7 +278,7 @@ def main():
     for s in range(args.steps):
         cur["s"] = s
         ev[s][0].record()            # same stream the kernels are launched on
-        out = one_step()             # rng_fill_kernel | ev_mid | output allocation + mh_sweep kernel
+        out = one_step()
         ev[s][1].record()
     torch.cuda.synchronize()
     if world > 1:
@@ -158,43 +290,56 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert int(out.status.abs().sum().item()) == 0, "a chain reported an error"
-    # kernel duration: HIP events around the launch (the bracket also contains the output allocation
-    # memset, < 1% of the sweep); rocprofv3 --kernel-trace --stats of the same command: profiles/
-    kern_ms = float(np.mean([ev_mid[s].elapsed_time(ev[s][1]) for s in range(args.steps)]))   # sweep kernel (+ its output memsets)
-    rng_ms = float(np.mean([ev[s][0].elapsed_time(ev_mid[s]) for s in range(args.steps)]))
+    bad = sorted(set(n for n in picked if n != cfg.expect_kernel))
+    if bad and chains == cfg.chains and iters == cfg.iters:
+        raise SystemExit("bench.py --config %s: the dispatcher picked %s, the config is measured on '%s'" % (cfg.name, bad, cfg.expect_kernel))
+    # kernel duration from HIP events on the launch stream
+    step_ms = float(np.mean([ev[s][0].elapsed_time(ev[s][1]) for s in range(args.steps)]))
+    if cfg.name == "c4":
+        chk_ms = float(np.sum([a.elapsed_time(b) for a, b in ev_chk])) / args.steps      # all checks of a step
+        kern_ms, extra = step_ms - chk_ms, {"gelman_checks_ms_per_step": chk_ms, "bulks_per_step": len(bulks),
+                                            "launches_per_step": len(bulks), "rhat_last": chk.last}
+    elif cfg.name in ("c2", "c3"):
+        kern_ms = float(np.mean([ev_mid[s].elapsed_time(ev[s][1]) for s in range(args.steps)]))   # sweep kernel (+ output memsets)
+        extra = {"rng_fill_kernel_ms": step_ms - kern_ms}
+    else:
+        kern_ms, extra = step_ms, {}
     samples_per_step = chains * (iters - 1)
     value = world * samples_per_step * args.steps / elapsed
-    acc = float(out.accept_count.double().mean().item()) / (iters - 1)
+    acc = float(out.accept_count.double().mean().item()) / ((bulks[-1] if cfg.name == "c4" else iters) - 1)
 
     if rank == 0:
-        ach_tflops = samples_per_step * flops_per_sample() / (kern_ms * 1e-3) / 1e12
-        out_bytes = chains * iters * (2 * K_PAR + 1) * 8
-        traffic = None
-        pj = os.path.join(ROOT, "profiles", "latest_pmc.json")
-        if os.path.exists(pj):
-            try:
-                traffic = json.load(open(pj)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        ach_tflops = samples_per_step * cfg.flops / (kern_ms * 1e-3) / 1e12
+        out_bytes = chains * S * ((1 if cfg.name == "c4" else 2) * k + 1) * 8
+        traffic, tsrc = None, None
+        if args.traffic_from:
+            traffic, tsrc = json.load(open(args.traffic_from)).get("hbm_bytes_per_launch"), args.traffic_from
+        metric = "MH samples/sec (chains x iters / s), 1024 chains, 5-param linreg n=10k" if cfg.name == "c2" else \
+                 "MH samples/sec (chains x iters / s), config %s" % cfg.name.upper()
         line = {
-            "metric": "MH samples/sec (chains x iters / s), 1024 chains, 5-param linreg n=10k",
+            "metric": metric,
             "value": value, "unit": "MH samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "configs[1]: %d chains/GPU x %d-param Gaussian linreg n=%d, kernel_normal(scale=%g), "
-                                   "nsteps=%d, outputs ans+logpost+draws" % (chains, K_PAR, N_OBS, SCALE, iters),
-                       "chains_per_gpu": chains, "iters_per_step": iters, "accept_rate": acc,
-                       "parallelism": "chains sharded, %d rank(s), no data-path collective" % world},
-            "roofline": {"bound": "mfma", "pipe": "fp64 MFMA (v_mfma_f64_4x4x4: x.beta - y) + fp64 VALU (r^2 accumulate); MI355X fp64 matrix peak == fp64 vector peak",
+            "config": {"workload": "configs[%d] (%s): %d chains/GPU x %d-param %s n=%d, %s, nsteps=%d, outputs ans+logpost%s" % (
+                           cfg.num - 1, cfg.name.upper(), chains, k, "Gaussian linreg" if cfg.family == "linreg" else "logistic regression",
+                           cfg.n, cfg.kernel_name, iters, "" if cfg.name == "c4" else "+draws"),
+                       "chains_per_gpu": chains, "iters_per_step": iters, "thin": thin, "accept_rate": acc,
+                       "parallelism": "chains sharded, %d rank(s), %s" % (world, "one all-reduce of 1 + 5p + 2p^2 doubles per Gelman check"
+                                                                          if cfg.name == "c4" else "no data-path collective")},
+            "roofline": {"bound": "mfma", "pipe": "fp64 datapath (MFMA and VALU share it: MI355X fp64 matrix peak == fp64 vector peak)",
                          "achieved": ach_tflops, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach_tflops / PEAK_FP64_TFLOPS, "traffic": traffic,
-                         "kernel": "mh_sweep_mfma<1,1,20,false>", "kernel_ms": kern_ms, "rng_fill_kernel_ms": rng_ms,
-                         "flops_per_sample": flops_per_sample(),
+                         "frac": ach_tflops / PEAK_FP64_TFLOPS, "traffic": traffic, "traffic_source": tsrc,
+                         "kernel": sorted(set(picked))[0] if len(set(picked)) == 1 else sorted(set(picked)),
+                         "kernel_ms": kern_ms, "flops_per_sample": cfg.flops, "flops_note": cfg.flops_note,
                          "hbm": {"achieved_GBps": out_bytes / (kern_ms * 1e-3) / 1e9, "peak_GBps": PEAK_HBM_GBS,
-                                 "algorithmic_bytes_per_launch": out_bytes}},
+                                 "algorithmic_bytes_per_step": out_bytes}},
         }
+        line["roofline"].update(extra)
+        if cfg.name == "c4":
+            line["roofline"]["frac_survey_E2"] = samples_per_step * 1.98e6 / (kern_ms * 1e-3) / 1e12 / PEAK_FP64_TFLOPS
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+            line["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -1,0 +1,61 @@
+"""Perf guard: a short run of every GPU config of BASELINE.md section 4 must not be slower than 1.25x the time per MH
+iteration recorded in profiles/perf_guard.json (measured with this same test's loop, HIP events, best of three).  The
+round-1 history shows why: one more dword in a by-value argument struct cost 25 %, stamp code merely present 13 %.
+Record new values with  FMCMC_PERF_GUARD_RECORD=1 python -m pytest tests/test_gpu_perf_guard.py -m gpu  (on the GPU box)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REC = os.path.join(ROOT, "profiles", "perf_guard.json")
+SHORT = {"c2": 2000, "c3": 2000, "c4": 300, "c5": 150}      # MH iterations of the short run (chains: the config's per-GPU share)
+
+
+def _measure(name):
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from fmcmc_amd import engine as E, _abi as abi
+    cfg = bench.Config(name)
+    X, y, init = cfg.workload(cfg.chains, 0)
+    gm, gk = bench.device_objects(cfg, E, abi, X, y, torch.device("cuda", 0))
+    iters = SHORT[name]
+    best = float("inf")
+    for _ in range(4):
+        st = E.ChainState(init, cfg.k)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        r = E.sweep(gm, gk, st, iters, thin=cfg.thin, seed=1215, want_bits=False, check=False)
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 1e3 / iters)
+    assert int(r.status.abs().sum().item()) == 0
+    return best, abi.last_kernel(), cfg.expect_kernel
+
+
+@pytest.mark.parametrize("name", ["c2", "c3", "c4", "c5"])
+def test_time_per_iteration_within_125_percent_of_the_record(name):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    if torch.cuda.get_device_properties(0).multi_processor_count < 256:
+        pytest.skip("the records are for a whole MI355X (256 CUs)")
+    us, kernel, expect = _measure(name)
+    assert kernel == expect, "the dispatcher picked '%s' for %s (tuned: '%s')" % (kernel, name, expect)
+    rec = json.load(open(REC)) if os.path.exists(REC) else {}
+    if os.environ.get("FMCMC_PERF_GUARD_RECORD") == "1":
+        rec[name] = {"us_per_iteration": round(us, 3), "kernel": kernel, "iterations": SHORT[name]}
+        out = os.path.join(ROOT, "gpurun_out", "perf_guard.json")        # (copied into profiles/ by hand once accepted)
+        prev = json.load(open(out)) if os.path.exists(out) else {}
+        prev.update(rec)
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        json.dump(prev, open(out, "w"), indent=1, sort_keys=True)
+        return
+    assert name in rec, "no record for %s in profiles/perf_guard.json" % name
+    limit = 1.25 * rec[name]["us_per_iteration"]
+    assert us <= limit, "%s: %.2f us per MH iteration, the record is %.2f (limit %.2f)" % (name, us, rec[name]["us_per_iteration"], limit)
