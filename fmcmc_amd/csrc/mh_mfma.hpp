@@ -17,17 +17,22 @@ namespace {
 // fp64 pipe out of the VALU issue limit (~6.2 ticks per instruction at 2 waves per SIMD).
 //
 // Mapping that keeps the canonical reduction: wave w owns canonical lanes 64w..64w+63; MFMA t = 4*s + g covers
-// slot s (observations i = lane + 512 s) of lanes 64w + 16g + o, o = 4*blk + i_row; result lane L holds chain
-// j = L % 4 of canonical lane 64w + 16g + 4*((L/4)%4) + L/16, accumulated in acc[g] in slot order; the four
-// accumulators are written to the same transposed partial tile the owners fold with the canonical tree.
+// slot s of the canonical lanes 64w + 16*i_row + 4*blk + g (operand position o = 4*blk + i_row); result lane L holds
+// chain j = L % 4 of canonical lane 64w + 16*(L/16) + 4*((L/4)%4) + g, accumulated in acc[g] in slot order.  The bits of
+// a canonical lane index are laid out so that the xor-butterfly tree costs next to nothing: levels 1, 2 pair the four
+// ACCUMULATORS of a lane (three adds, no cross-lane traffic), levels 4, 8 the four blocks of a 16-lane row (two DPP row
+// shifts), levels 16, 32 the four rows (permlane16 / permlane32 swaps): 15 instructions per wave BEFORE the barrier leave
+// one double per chain and wave, and the owners finish levels 64..256 over 8 values behind it.  (Until round 2 the lanes
+// wrote all 4 x 512 partials to a transposed LDS tile and the owners folded them behind the barrier: 810 of the 1600 ticks
+// of the exposed owner phase.  Same tree, same bits.)
 // All four chains of the workgroup are evaluated together, so this kernel is not chain-pipelined: a step is
-// evaluation | barrier | 4 owner phases in parallel (waves 0..3, priority raised) | barrier.
+// evaluation + in-wave fold | barrier | 4 owner phases in parallel (waves 0..3, priority raised) | barrier.
 // ==============================================================================================
 constexpr int MF_NMF = 80;   // MFMAs per wave per step: 20 slots x 4 lane groups
 // chain stride of the partial tiles: here one ds_write_b64 carries 4 chains x 16 canonical lanes; with the row stride
 // 66 the 16 lanes of a write group land on double-banks {0,8,1,9} + 2*(l&7), so a chain stride == 2 (mod 16) spreads the
 // four chains over all 16 double-banks (8*66 = 528 == 0 mod 16 made every write a 4-way conflict)
-constexpr int MF_TCS = 8 * PIPE_TRS + 2;
+constexpr int MF_TCS = 8 * PIPE_TRS + 2;   // (the replicated kernel's tile, mh_mfma_rep.hpp)
 
 // DBG is a TEMPLATE parameter on purpose: the MFMA loop is sensitive to every live register (fewer free VGPRs = fewer
 // MFMA results in flight before their dependent fma); stamp code that is merely disabled at run time cost 13 %.
@@ -48,14 +53,16 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
   const int k = A.k, kz = A.kz;
   double* s_th1 = smem;                            // [CW][PIPE_KMAX]
   double* s_par = s_th1 + CW * PIPE_KMAX;          // [4][PIPE_KMAX]
-  double* s_tr = s_par + 4 * PIPE_KMAX;            // [CW][MF_TCS] transposed partial tiles, chain stride 530
+  double* s_fold = s_par + 4 * PIPE_KMAX;          // [CW][NW] per-wave sums of every chain (canonical levels 1..32 done)
   const long long cg0 = (long long)blockIdx.x * CW;
   const int ncw = (int)((A.nchains - cg0 < CW) ? (A.nchains - cg0) : CW);
   const int nsteps = (int)A.nsteps, burnin = (int)A.burnin, thin = (int)A.thin;
   const int ic = A.intercept;
 
-  // ---- A operand: feature kf_ = lane / 16 of observation (64 w + 16 g + lane % 16) + 512 s, for t = 4 s + g
+  // ---- A operand: feature kf_ = lane / 16 of the observation of canonical lane 64 w + 16 i_row + 4 blk + g in slot s, for
+  //      t = 4 s + g and operand position lane % 16 = 4 blk + i_row
   const int feat = lane >> 4, o16 = lane & 15;
+  const int cl_a = 16 * (o16 & 3) + 4 * (o16 >> 2);
   const int P = A.p;
   double areg[NG][TN];
 #pragma unroll
@@ -64,7 +71,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
 #pragma unroll
     for (int t = 0; t < TN; t++) {
       const int sl = t >> 2, g = t & 3;
-      const long long i = (long long)(64 * wave + 16 * g + o16) + (long long)NT * sl;
+      const long long i = (long long)(64 * wave + cl_a + g) + (long long)NT * sl;
       double a = 0.0;
       if (i < A.n) {
         if (f < P) a = A.X[(long long)f * A.n + i];
@@ -73,15 +80,13 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
       areg[q][t] = a;
     }
   }
-  // result lane L: chain j = L % 4, canonical lane 64 w + 16 g + 4*((L/4)%4) + L/16
+  // result lane L: chain j = L % 4, canonical lane 64 w + 16 (L/16) + 4 ((L/4)%4) + g
   const int jch = lane & 3;
-  const int cl_in_g = 4 * ((lane >> 2) & 3) + (lane >> 4);
+  const int cl_d = 16 * (lane >> 4) + 4 * ((lane >> 2) & 3);
   unsigned vbits = 0;    // validity of this lane's 4 results in the LAST slot (all earlier slots are full)
-  int trs[4];            // transposed tile slot of this lane's canonical lane, per group
 #pragma unroll
   for (int g = 0; g < 4; g++) {
-    const int l = 64 * wave + 16 * g + cl_in_g;
-    trs[g] = (l & 7) * PIPE_TRS + (l >> 3);
+    const int l = 64 * wave + cl_d + g;
     if ((long long)l + (long long)NT * (NS - 1) < A.n) vbits |= 1u << g;
   }
   if (tid < k) {
@@ -190,8 +195,28 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
             if (u < nu) acc[u & 3] = fmh_fma(d[u], d[u], acc[u & 3]);
         }
       }
-#pragma unroll
-      for (int g = 0; g < 4; g++) s_tr[jch * (MF_TCS) + trs[g]] = acc[g];
+      // canonical levels 1..32 inside the wave (see the mapping above); a lane only ever adds canonical partial sums, and
+      // the sums that matter end up in the lanes of block 3
+      double fs = (acc[0] + acc[1]) + (acc[2] + acc[3]);        // levels 1, 2: the four accumulators
+      fs = fs + dpp_d<0x114>(fs);                               // level 4: row_shr:4, blocks 1 and 3 hold (b, b - 1)
+      fs = fs + dpp_d<0x118>(fs);                               // level 8: row_shr:8, block 3 holds all four
+      {
+        const unsigned long long u = (unsigned long long)__double_as_longlong(fs);
+        const unsigned lo = (unsigned)u, hi = (unsigned)(u >> 32);
+        const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        fs = __longlong_as_double((long long)(((unsigned long long)rh[0] << 32) | rl[0])) +
+             __longlong_as_double((long long)(((unsigned long long)rh[1] << 32) | rl[1]));      // level 16: rows r, r ^ 1
+      }
+      {
+        const unsigned long long u = (unsigned long long)__double_as_longlong(fs);
+        const unsigned lo = (unsigned)u, hi = (unsigned)(u >> 32);
+        const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        fs = __longlong_as_double((long long)(((unsigned long long)rh[0] << 32) | rl[0])) +
+             __longlong_as_double((long long)(((unsigned long long)rh[1] << 32) | rl[1]));      // level 32: rows r, r ^ 2
+      }
+      if (lane >= 60) s_fold[jch * NW + wave] = fs;             // lanes 60..63: block 3 of row 3, chains 0..3
     }
     // (Measured: moving log(sigma) of the owners in front of, or right behind, their MFMAs makes the step SLOWER:
     //  fp64 VALU work issued while the SIMD partner runs MFMAs slows those -- one fp64 datapath -- whereas in
@@ -223,9 +248,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
     // ================= owners: fold, decide, propose =================
     if (owner) {
       __builtin_amdgcn_s_setprio(3);
-      const double* src = s_tr + myc * (MF_TCS) + lane;
-      const double v0 = src[0 * PIPE_TRS], v1 = src[1 * PIPE_TRS], v2 = src[2 * PIPE_TRS], v3 = src[3 * PIPE_TRS];
-      const double v4 = src[4 * PIPE_TRS], v5 = src[5 * PIPE_TRS], v6 = src[6 * PIPE_TRS], v7 = src[7 * PIPE_TRS];
+      double wsum = s_fold[myc * NW + (lane & 7)];              // the wave sums of this chain, one per lane of an octet
       // increment of the NEXT proposal: consumes the variate fetched one step ago and refills the same register at once, so
       // that load has a whole step to land and no vector-memory wait sits behind the decision below
       // The only vector-memory wait of the phase sits HERE, on loads issued one whole step ago; both registers are refilled
@@ -236,7 +259,9 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
       lu_nx = lu_row[v < nsteps ? v : nsteps - 1];
       if (kz > 0) z_nx = ld_z(v + 1 < nsteps ? v + 1 : nsteps - 1);
       const double dz = mu_l + sc_l * zc;   // (unused by fixed / idle lanes; mu and scale live in registers: no LDS read, no exec region)
-      const double tot = wave_xor_sum(((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7)));
+      wsum = wsum + dpp_d<0xB1>(wsum);                          // level 64:  waves w, w ^ 1 (quad_perm [1,0,3,2])
+      wsum = wsum + dpp_d<0x4E>(wsum);                          // level 128: quad_perm [2,3,0,1]
+      const double tot = wsum + dpp_d<0x141>(wsum);             // level 256: row_half_mirror (quads are uniform)
       unsigned long long t_a = dbg ? clk() : 0;
       // The owner phase is exposed, and a wave issues one instruction per ~6.5 cycles whatever their dependences: the
       // common case is straight-line (three instructions finish the division, one compare, selects, no guard: -inf needs
@@ -336,6 +361,6 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
   }
 }
 
-size_t mfma_lds_bytes() { return sizeof(double) * ((size_t)8 * PIPE_KMAX + 4 * MF_TCS); }
+size_t mfma_lds_bytes() { return sizeof(double) * ((size_t)8 * PIPE_KMAX + 4 * NW); }
 
 }  // namespace

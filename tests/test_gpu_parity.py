@@ -795,9 +795,9 @@ def test_full_size_headline_properties(E, monkeypatch):
     from fmcmc_amd import _abi as abi
     import bench
     chains, iters, k = 1024, 10000, 5
-    X, y, init = bench.make_workload(chains, 0)
+    X, y, init = bench.Config("c2").workload(chains, 0)
     gm = E.DeviceModel(abi.FAM_GAUSSIAN_LINREG, X, y)
-    gk = E.KernelSpec(abi.KERNEL_NORMAL, k, np.zeros(k), np.full(k, bench.SCALE), np.full(k, -E.DBL_MAX),
+    gk = E.KernelSpec(abi.KERNEL_NORMAL, k, np.zeros(k), np.full(k, 0.02), np.full(k, -E.DBL_MAX),
                       np.full(k, E.DBL_MAX), np.zeros(k, np.uint8))
 
     def launch(lo, hi):
