@@ -293,80 +293,60 @@ __device__ __forceinline__ ChainLds chain_lds(double* base, int k, int kf, int k
 // ---- chain-vectorised twin of fmh_log1p_exp_nonpos (include/fmh_detmath.h): the same operations in the same order for
 // every element, so the same bits -- but each constant is materialised ONCE per observation instead of once per chain
 // (FMH_K costs two scalar moves per use), the CW dependent chains interleave, and the out-of-range test is one branch
-// per observation.  Called once per observation, the scalar routine made the logistic loop ~1100 instructions per
-// observation and four chains, at the ~6 cycles per instruction one wave issues.
-// Tables of the softplus staged in LDS (the logistic-only kernel instantiations): a lookup from global memory is a
-// 64-address gather, ~64 cycles of the texture addresser each (16 per observation made the loop 31 % slower than the
-// arithmetic they replaced); from LDS it is one ds_read_b128.  Layout: 128 rows {invc, logc_hi, logc_lo, -} then 128 rows
-// {2^(j/128) hi, lo}.
-constexpr int SP_LDS_DOUBLES = 128 * 4 + 128 * 2;
+// per observation.
+// The table (2401 rows of 32 bytes: softplus(a_j) hi, lo, sigma_j, -) is staged in LDS by the logistic-only kernel
+// instantiations: a lookup from global memory is a 64-address gather, ~64 cycles of the texture addresser; from LDS it is
+// one ds_read_b128 + one ds_read_b64.
+constexpr int SP_LDS_DOUBLES = FMH_SPG_ROWS * 4;
 __device__ __forceinline__ void softplus_stage_tables(double* s_tab) {
-  const double* lt = fmh_sp_tab_();
-  const double* xt = fmh_sp_exp_tab_();
-  for (int i = threadIdx.x; i < 128 * 4; i += blockDim.x) s_tab[i] = ((i & 3) < 3) ? lt[3 * (i >> 2) + (i & 3)] : 0.0;
-  for (int i = threadIdx.x; i < 128 * 2; i += blockDim.x) s_tab[128 * 4 + i] = xt[i];
+  const double* t = fmh_spg_tab_();
+  for (int i = threadIdx.x; i < SP_LDS_DOUBLES; i += blockDim.x) s_tab[i] = t[i];
 }
 
 template <int CW>
 __device__ __forceinline__ void softplus_nonpos_vec(const double (&a)[CW], double (&out)[CW], const double* s_tab) {
-  // (without LDS tables -- the all-family kernels -- the tables are read as global memory: scalar base + 32-bit lane offset)
+  // (without the LDS copy -- the all-family kernels -- the table is read as global memory: scalar base + 32-bit lane offset)
   typedef const double __attribute__((address_space(1))) * gptr_t;
-  const gptr_t gtab = (gptr_t)(unsigned long long)fmh_sp_tab_();
-  const gptr_t gxtab = (gptr_t)(unsigned long long)fmh_sp_exp_tab_();
+  const gptr_t gtab = (gptr_t)(unsigned long long)fmh_spg_tab_();
   bool slow = false;
-  double r[CW], sc[CW], q[CW], xh[CW], xl[CW];
+  double r[CW], sh[CW], sl[CW], sg[CW], q[CW];
 #pragma unroll
-  for (int c = 0; c < CW; c++) slow = slow || !(a[c] <= FMH_SP_AMAX) || a[c] < FMH_SP_AMIN;
+  for (int c = 0; c < CW; c++) slow = slow || !(a[c] <= 0.0) || a[c] < FMH_SPG_AMIN;
   {
-    const double n_inv_ln2 = FMH_K(FMH_SP_N_INV_LN2), shift = FMH_K(FMH_SP_SHIFT);
-    const double ln2_hi = FMH_K(FMH_SP_LN2_N_HI), ln2_lo = FMH_K(FMH_SP_LN2_N_LO);
+    const double shift = FMH_K(FMH_SP_SHIFT);
 #pragma unroll
     for (int c = 0; c < CW; c++) {
-      const double t = fmh_fma(a[c], n_inv_ln2, shift);
+      const double t = fmh_fma(a[c], 64.0, shift);
       const double kd = t - shift;
-      const int32_t ki = (int32_t)(uint32_t)fmh_d2u(t);
-      r[c] = fmh_fma(-kd, ln2_lo, fmh_fma(-kd, ln2_hi, a[c]));
-      const unsigned int xi = 2u * (unsigned int)(ki & 127);
-      if (s_tab) { xh[c] = s_tab[128 * 4 + xi]; xl[c] = s_tab[128 * 4 + xi + 1]; }
-      else { xh[c] = gxtab[xi]; xl[c] = gxtab[xi + 1]; }
-      sc[c] = fmh_u2d((uint64_t)(1023 + (ki >> 7)) << 52);
+      // (a slow element may index anything: clamp, its result is replaced below)
+      int j = -(int32_t)(uint32_t)fmh_d2u(t);
+      j = (j < 0) ? 0 : (j > FMH_SPG_ROWS - 1 ? FMH_SPG_ROWS - 1 : j);
+      r[c] = fmh_fma(kd, -0.015625, a[c]);
+      const unsigned int ti = 4u * (unsigned int)j;
+      if (s_tab) { sh[c] = s_tab[ti]; sl[c] = s_tab[ti + 1]; sg[c] = s_tab[ti + 2]; }
+      else { sh[c] = gtab[ti]; sl[c] = gtab[ti + 1]; sg[c] = gtab[ti + 2]; }
     }
   }
   {
-    const double e5 = FMH_K(FMH_SP_E5), e4 = FMH_K(FMH_SP_E4);
+    const double e6 = FMH_K(FMH_SPG_E6), e5 = FMH_K(FMH_SP_E5);
 #pragma unroll
-    for (int c = 0; c < CW; c++) q[c] = fmh_fma(r[c], e5, e4);
+    for (int c = 0; c < CW; c++) q[c] = fmh_fma(r[c], e6, e5);
   }
 #define SP_STEP(arr, x, K) { const double kk = FMH_K(K); _Pragma("unroll") for (int c = 0; c < CW; c++) arr[c] = fmh_fma(x[c], arr[c], kk); }
-  SP_STEP(q, r, FMH_SP_E3) SP_STEP(q, r, FMH_SP_E2)
-  double u[CW], cc[CW], invc[CW], lch[CW], lcl[CW], rr[CW], p[CW];
+  SP_STEP(q, r, FMH_SP_E4) SP_STEP(q, r, FMH_SP_E3) SP_STEP(q, r, FMH_SP_E2)
+  double w[CW], p[CW];
 #pragma unroll
-  for (int c = 0; c < CW; c++) {
-    const double pm1 = fmh_fma(r[c] * r[c], q[c], r[c]);
-    const double w = fmh_fma(xh[c], pm1, xl[c]);
-    const double er = xh[c] + w;
-    const double el = w - (er - xh[c]);
-    const double e = er * sc[c];
-    u[c] = 1.0 + e;
-    cc[c] = fmh_fma(el, sc[c], e - (u[c] - 1.0));
-    const unsigned int ti = (uint32_t)(fmh_d2u(u[c]) >> 45) & 127u;
-    if (s_tab) { invc[c] = s_tab[4 * ti]; lch[c] = s_tab[4 * ti + 1]; lcl[c] = s_tab[4 * ti + 2]; }
-    else { invc[c] = gtab[3 * ti]; lch[c] = gtab[3 * ti + 1]; lcl[c] = gtab[3 * ti + 2]; }
-    rr[c] = fmh_fma(u[c], invc[c], -1.0);
-  }
+  for (int c = 0; c < CW; c++) w[c] = sg[c] * fmh_fma(r[c] * r[c], q[c], r[c]);
   {
-    const double l8 = FMH_K(FMH_SP_L8), l7 = FMH_K(FMH_SP_L7);
+    const double l6 = FMH_K(FMH_SP_L6), l5 = FMH_K(FMH_SP_L5);
 #pragma unroll
-    for (int c = 0; c < CW; c++) p[c] = fmh_fma(rr[c], l8, l7);
+    for (int c = 0; c < CW; c++) p[c] = fmh_fma(w[c], l6, l5);
   }
-  SP_STEP(p, rr, FMH_SP_L6) SP_STEP(p, rr, FMH_SP_L5) SP_STEP(p, rr, FMH_SP_L4) SP_STEP(p, rr, FMH_SP_L3) SP_STEP(p, rr, FMH_SP_L2)
+  SP_STEP(p, w, FMH_SP_L4) SP_STEP(p, w, FMH_SP_L3) SP_STEP(p, w, FMH_SP_L2)
 #undef SP_STEP
 #pragma unroll
-  for (int c = 0; c < CW; c++) {
-    const double s = fmh_fma(rr[c] * rr[c], p[c], fmh_fma(cc[c], invc[c], lcl[c]));
-    out[c] = lch[c] + (rr[c] + s);
-  }
-  if (__builtin_expect(slow, 0)) {   // |eta| < 2^-28, eta beyond +-700, NaN: the general functions, as in the scalar routine
+  for (int c = 0; c < CW; c++) out[c] = sh[c] + (sl[c] + fmh_fma(w[c] * w[c], p[c], w[c]));
+  if (__builtin_expect(slow, 0)) {   // eta beyond +-37.5, NaN: the general functions, as in the scalar routine
 #pragma unroll
     for (int c = 0; c < CW; c++) out[c] = fmh_log1p_exp_nonpos(a[c]);
   }
