@@ -303,27 +303,33 @@ __device__ __forceinline__ void softplus_stage_tables(double* s_tab) {
   for (int i = threadIdx.x; i < SP_LDS_DOUBLES; i += blockDim.x) s_tab[i] = t[i];
 }
 
-template <int CW>
+// LDSTAB is a COMPILE-TIME property (the logistic-only instantiations always stage the table): decided at run time the two
+// paths were an exec-masked branch per chain and the loads went through a generic pointer -- FLAT loads, whose s_waitcnt
+// covers vmcnt AND lgkmcnt, i.e. every lookup also waited for the prefetch of the next observation (an L2 round trip per
+// observation with two waves per SIMD to hide it).
+template <int CW, bool LDSTAB>
 __device__ __forceinline__ void softplus_nonpos_vec(const double (&a)[CW], double (&out)[CW], const double* s_tab) {
   // (without the LDS copy -- the all-family kernels -- the table is read as global memory: scalar base + 32-bit lane offset)
   typedef const double __attribute__((address_space(1))) * gptr_t;
+  typedef const double __attribute__((address_space(3))) * lptr_t;
   const gptr_t gtab = (gptr_t)(unsigned long long)fmh_spg_tab_();
+  const lptr_t ltab = (lptr_t)s_tab;
   bool slow = false;
   double r[CW], sh[CW], sl[CW], sg[CW], q[CW];
 #pragma unroll
-  for (int c = 0; c < CW; c++) slow = slow || !(a[c] <= 0.0) || a[c] < FMH_SPG_AMIN;
+  for (int c = 0; c < CW; c++) slow = slow || !(a[c] >= FMH_SPG_AMIN) || (!LDSTAB && !(a[c] <= 0.0));   // (the logistic loops pass -|eta|)
   {
     const double shift = FMH_K(FMH_SP_SHIFT);
 #pragma unroll
     for (int c = 0; c < CW; c++) {
       const double t = fmh_fma(a[c], 64.0, shift);
       const double kd = t - shift;
-      // (a slow element may index anything: clamp, its result is replaced below)
+      // (a slow element may index anything, its result is replaced below: clamped for global memory; an LDS read cannot fault)
       int j = -(int32_t)(uint32_t)fmh_d2u(t);
-      j = (j < 0) ? 0 : (j > FMH_SPG_ROWS - 1 ? FMH_SPG_ROWS - 1 : j);
+      if (!LDSTAB) j = (j < 0) ? 0 : (j > FMH_SPG_ROWS - 1 ? FMH_SPG_ROWS - 1 : j);
       r[c] = fmh_fma(kd, -0.015625, a[c]);
       const unsigned int ti = 4u * (unsigned int)j;
-      if (s_tab) { sh[c] = s_tab[ti]; sl[c] = s_tab[ti + 1]; sg[c] = s_tab[ti + 2]; }
+      if constexpr (LDSTAB) { sh[c] = ltab[ti]; sl[c] = ltab[ti + 1]; sg[c] = ltab[ti + 2]; }
       else { sh[c] = gtab[ti]; sl[c] = gtab[ti + 1]; sg[c] = gtab[ti + 2]; }
     }
   }
@@ -682,10 +688,13 @@ __device__ __forceinline__ void eval_partials(const SweepArgs& A, double* const*
     // log-likelihood terms of one observation for all CW chains: logq(eta) == logp(-eta), softplus tail on -|eta|
     auto add_terms = [&](const double (&eta)[CW], bool y1) {
       double sg[CW], ab[CW], l1[CW];
+      // sg = y ? eta : -eta and ab = -|sg| as sign-bit operations (one integer instruction each; written as selects they
+      // were seven per chain).  Same values as the oracle's selects: a -0 / +0 difference in ab cannot reach the result.
+      const unsigned long long flip = y1 ? 0ull : 0x8000000000000000ull;
 #pragma unroll
       for (int c = 0; c < CW; c++) {
-        sg[c] = y1 ? eta[c] : -eta[c];
-        ab[c] = (sg[c] < 0.0) ? sg[c] : -sg[c];
+        sg[c] = fmh_u2d(fmh_d2u(eta[c]) ^ flip);
+        ab[c] = fmh_u2d(fmh_d2u(sg[c]) | 0x8000000000000000ull);
       }
 #ifndef FMCMC_SP_GROUP
 #define FMCMC_SP_GROUP 4
@@ -696,12 +705,12 @@ __device__ __forceinline__ void eval_partials(const SweepArgs& A, double* const*
         double ag[G], lg[G];
 #pragma unroll
         for (int c = 0; c < G; c++) ag[c] = ab[g0 + c];
-        softplus_nonpos_vec<G>(ag, lg, s_sptab);
+        softplus_nonpos_vec<G, FAM == FMCMC_FAM_LOGISTIC>(ag, lg, s_sptab);
 #pragma unroll
         for (int c = 0; c < G; c++) l1[g0 + c] = lg[c];
       }
 #pragma unroll
-      for (int c = 0; c < CW; c++) acc[c] = acc[c] + ((sg[c] < 0.0) ? (sg[c] - l1[c]) : (-l1[c]));
+      for (int c = 0; c < CW; c++) acc[c] = acc[c] + (__builtin_fmin(sg[c], 0.0) - l1[c]);   // == (sg < 0) ? sg - l1 : -l1, bit for bit
     };
     // P known at compile time (P <= 8): straight-line loop body -- with a run-time p every `if (u < p)` was a basic
     // block of its own (6 scalar branches per observation, each with its LDS / memory wait in front) -- and the CW x
