@@ -56,7 +56,7 @@ class Config:
             self.chains, self.iters, self.thin = 512, 10000, 1
             self.family = "linreg"
             self.kernel_name = "kernel_ram() + convergence_gelman(freq=1000)"
-            self.expect_kernel = "streamed-wide-sharded-mfma"
+            self.expect_kernel = "wide-dataflow"
             # unbounded kernel_ram evaluates the log-posterior ONCE per step (the un-reflected proposal IS the proposal):
             # E = 1 -> n (2 x 48 + 3) + 3 k^2 (S u, factor update).  SURVEY 8(d) prices E = 2 (1.98e6); both are reported.
             self.flops = self.n * (2 * self.p + 3) + 3 * self.k * self.k

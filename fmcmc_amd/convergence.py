@@ -72,9 +72,13 @@ class convergence_gelman:
             if rc != abi.OK:
                 raise RuntimeError("fmcmc_gelman_partial_dev failed (%d)" % rc)
             if self.check_invariant:  # rm_invariant: sd of ALL entries (R/convergence.R:171-173)
-                win = samples[:, cols_d.long(), row0:]
-                partial[plen] = win.sum()
-                partial[plen + 1] = (win * win).sum()
+                # sum and sum of squares of the whole window from the per-chain means / variances the reduction just left in
+                # `work` (an indexed copy of the window itself was 1 GB and ~1 ms per check at config C4)
+                wk = work.view(Cn, p + p * p)
+                xb = wk[:, :p] + center
+                s2 = wk[:, p:].reshape(Cn, p, p).diagonal(dim1=1, dim2=2)
+                partial[plen] = float(N) * xb.sum()
+                partial[plen + 1] = ((N - 1.0) * s2 + float(N) * xb * xb).sum()
         if distributed:
             dist.all_reduce(partial, op=dist.ReduceOp.SUM, group=group)  # the engine's only collective
         ph = partial.cpu().numpy()

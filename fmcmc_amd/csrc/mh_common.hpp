@@ -526,16 +526,20 @@ constexpr int SHM_HDR = 32 + SHM_T * 64;        // doubles in front of the A til
 constexpr int SHM_KBMAX = 16;                   // K-blocks of 4 columns: p <= 64
 typedef double d4_t __attribute__((ext_vector_type(4)));
 struct ShardMfma {
-  const double* th;      // [k][NC + SH_PAD] proposals of all chains
+  const double* th;      // [k][ncp] proposals of all chains
   double* part;          // [NC][NT + SH_PAD] lane partials
   unsigned lds;          // LDS address of the block
-  int NC, p, ic, lane0, debug;
+  int NC, p, ic, lane0, debug;   // NC: chains of the set this call evaluates
+  int ncp;               // row stride of th (all chains of the launch + SH_PAD)
+  int cstride, coff;     // chain of the set's member l: cstride * l + coff (1, 0: all chains; 2, g: chain group g of mh_sweep_wide2)
+  int tfirst, tstep;     // N-tiles of the calling wave: tfirst, tfirst + tstep, ...
 };
 static_assert(sizeof(ShardMfma) <= 64, "ShardMfma must travel in registers (16 dwords)");
 template <int LPW, int NMT>
 __device__ __attribute__((noinline)) void shard_columns_mfma(ShardMfma c) {
-  const int lane = threadIdx.x & 63, wave = rfl_i((int)(threadIdx.x >> 6));
-  const int NC = rfl_i(c.NC), NCP = NC + SH_PAD, p = rfl_i(c.p), ic = rfl_i(c.ic), lane0 = rfl_i(c.lane0);
+  const int lane = threadIdx.x & 63;
+  const int NC = rfl_i(c.NC), NCP = rfl_i(c.ncp), p = rfl_i(c.p), ic = rfl_i(c.ic), lane0 = rfl_i(c.lane0);
+  const int cstride = rfl_i(c.cstride), coff = rfl_i(c.coff), tfirst = rfl_i(c.tfirst), tstep = rfl_i(c.tstep);
   const int KB = (p + 3) >> 2;
   const double* thg = (const double*)rfl_u64((unsigned long long)c.th);
   double* part = (double*)rfl_u64((unsigned long long)c.part);
@@ -556,7 +560,7 @@ __device__ __attribute__((noinline)) void shard_columns_mfma(ShardMfma c) {
 #define SHM_LOAD_B(T_, B_, c0_)                                                                          \
   {                                                                                                      \
     const int ch_ = 16 * (T_) + j;                                                                       \
-    const unsigned int chc_ = (unsigned int)(ch_ < NC ? ch_ : NC - 1);                                   \
+    const unsigned int chc_ = (unsigned int)(cstride * (ch_ < NC ? ch_ : NC - 1) + coff);                \
     c0_ = ic ? sh_load(thg + chc_) : 0.0;                                                                \
     _Pragma("unroll") for (int kb = 0; kb < SHM_KBMAX; kb++) {                                           \
       if (kb < KB) {                                                                                     \
@@ -567,10 +571,10 @@ __device__ __attribute__((noinline)) void shard_columns_mfma(ShardMfma c) {
   }
 #pragma unroll
   for (int kb = 0; kb < SHM_KBMAX; kb++) { Bc[kb] = 0.0; Bn[kb] = 0.0; }
-  int T = wave;                                  // N-tiles round robin over the waves
+  int T = tfirst;                                // N-tiles of this wave
   if (T < ntiles) SHM_LOAD_B(T, Bc, c0c)
-  for (; T < ntiles; T += NW) {
-    if (T + NW < ntiles) SHM_LOAD_B(T + NW, Bn, c0n)
+  for (; T < ntiles; T += tstep) {
+    if (T + tstep < ntiles) SHM_LOAD_B(T + tstep, Bn, c0n)
     d4_t acc[NMT];
 #pragma unroll
     for (int mt = 0; mt < NMT; mt++) acc[mt] = (d4_t){c0c, c0c, c0c, c0c};
@@ -596,19 +600,20 @@ __device__ __attribute__((noinline)) void shard_columns_mfma(ShardMfma c) {
     double a = 0.0;
 #pragma unroll
     for (int t = 0; t < 4 * NMT; t++) a = fmh_fma(rr[t], rr[t], a);
-    const int chain = 16 * T + j;
+    const int lch = 16 * T + j;                  // member of the set; its chain:
+    const int chain = cstride * lch + coff;
     if constexpr (LPW == 2) {
       double a2 = __shfl_xor(a, 16, 64);          // groups 1 and 3 continue where groups 0 and 2 stopped
 #pragma unroll
       for (int t = 0; t < 4 * NMT; t++) a2 = fmh_fma(rr[t], rr[t], a2);
       const double a_hi = __shfl_xor(a2, 32, 64); // canonical lane 1 of the slice (group 3) next to lane 0 (group 1)
-      if (kk == 1 && chain < NC) {
+      if (kk == 1 && lch < NC) {
         double* dst = &part[(long long)chain * (NT + SH_PAD) + lane0];
         sh_store(dst, a2);
         sh_store(dst + 1, a_hi);
       }
     } else {
-      if (chain < NC) sh_store(&part[(long long)chain * (NT + SH_PAD) + lane0 + kk], a);
+      if (lch < NC) sh_store(&part[(long long)chain * (NT + SH_PAD) + lane0 + kk], a);
     }
 #pragma unroll
     for (int kb = 0; kb < SHM_KBMAX; kb++) Bc[kb] = Bn[kb];
@@ -646,6 +651,7 @@ __device__ __forceinline__ bool eval_sharded(const SweepArgs& A, double* const* 
   if (s_mblk) {
     ShardMfma sm;
     sm.th = A.sh_th; sm.part = A.sh_part; sm.NC = NC; sm.p = p; sm.ic = ic; sm.lane0 = (int)blockIdx.x * LPW; sm.debug = A.debug;
+    sm.ncp = NCP; sm.cstride = 1; sm.coff = 0; sm.tfirst = (int)(threadIdx.x >> 6); sm.tstep = NW;   // all chains, N-tiles round robin
     sm.lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const double*)s_mblk;
     if (A.sh_nmt == 1) shard_columns_mfma<LPW, 1>(sm);
     else if (A.sh_nmt == 2) shard_columns_mfma<LPW, 2>(sm);

@@ -3,6 +3,7 @@
 //   mh_common.hpp  shared device helpers      mh_streamed.hpp  general kernel (all families / kernels / schemes)
 //   mh_pipe.hpp    RNG stream + pipelined VALU kernel   mh_mfma.hpp  fp64-MFMA kernel, owner waves (headline)
 //   mh_mfma_rep.hpp  fp64-MFMA kernel, replicated chain state   mh_spec.hpp  wave-specialised kernel
+//   mh_wide2.hpp  wide models: observation-sharded dataflow kernel (owner / evaluator waves, two chain groups)
 //
 // Replaces, for ALL chains of a call at once, the per-chain loop of the reference
 //   R/mcmc.R:720-838 (loop, accept, burn-in/thin)  x  R/kernel_normal.R / R/kernel_adapt.R /
@@ -42,6 +43,7 @@
 #include "mh_mfma.hpp"
 #include "mh_mfma_rep.hpp"
 #include "mh_spec.hpp"
+#include "mh_wide2.hpp"
 
 namespace {
 
@@ -602,6 +604,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
     if (A.debug & 256) fprintf(stderr, "fmcmc_amd: wide path nblk=%lld lpw=%d nslots=%d p=%d bounded=%d shard=%d\n", nblk, lpw, nslots, m->p, (int)ram_bounded, (int)shard);
     double* shw = nullptr;
     g_kernel = shard ? "streamed-wide-sharded" : "streamed-wide";
+    const size_t lds_plain = lds;   // what the chain-sharded kernel needs, should the sharded forms below not launch
     // the slice product on the matrix cores (shard_columns_mfma): the slice lives in LDS behind the chain blocks
     const int mf_spg = shard ? (nslots + 4 / lpw - 1) / (4 / lpw) : 0, nmt = (mf_spg + 3) / 4;
     const int mblk = SHM_HDR + nmt * ((m->p + 3) / 4) * 64;
@@ -609,6 +612,26 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
                      lds + sizeof(double) * (size_t)(mblk + 1) <= 160 * 1024;
     if (mfma_form) lds += sizeof(double) * (size_t)(mblk + 1);
     if (shard) g_kernel = mfma_form ? "streamed-wide-sharded-mfma" : "streamed-wide-sharded";
+    // the dataflow form (mh_wide2.hpp): owner and evaluator waves decoupled, two chain groups half a step out of phase.
+    // It pays where the owners have real work to hide -- kernel_ram: 35.8 -> 27.9 us per step at C4 -- and costs the normal
+    // kernels 6 % (26.2 against 24.6: their owner phase is short and two of eight waves no longer evaluate).
+    // FMCMC_AMD_WIDE2=0 keeps the sequential form everywhere, =1 takes the dataflow form for every eligible call (tests).
+    bool wide2 = false;
+    {
+      const char* w2env = getenv("FMCMC_AMD_WIDE2");
+      const bool w2on = (w2env && w2env[0] == '1') || (!(w2env && w2env[0] == '0') && kn->kind == FMCMC_KERNEL_RAM);
+      wide2 = shard && mfma_form && w2on && lpw == 2 && cw == 2 && nb_launch == 256 && ncu == 256 &&
+              !(kn->kind == FMCMC_KERNEL_RAM && kn->constr) && (kn->kind == FMCMC_KERNEL_RAM || kn->scheme == FMCMC_SCHEME_JOINT) &&
+              nmt >= 1 && nmt <= 3 && run->nsteps < 100000000 &&
+              sizeof(double) * wide2_lds_doubles(kn->k, kf, kn->kind, A.kz, mblk) <= 160 * 1024;
+    }
+    if (wide2) {
+#define W2K(KV) ((nmt == 1) ? (const void*)mh_sweep_wide2<KV, 1> : (nmt == 2) ? (const void*)mh_sweep_wide2<KV, 2> : (const void*)mh_sweep_wide2<KV, 3>)
+      kfn = (kv == 1) ? W2K(1) : (kv == 2) ? W2K(2) : W2K(4);
+#undef W2K
+      lds = sizeof(double) * wide2_lds_doubles(kn->k, kf, kn->kind, A.kz, mblk);
+      g_kernel = "wide-dataflow";
+    }
     if (shard) {
       int coop = 0, perCU = 0;
       (void)hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev);
@@ -618,13 +641,13 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
         if (A.debug & 256) fprintf(stderr, "fmcmc_amd: sharded evaluation not launched: err=%d coop=%d perCU=%d lds=%zu\n", (int)e, coop, perCU, lds);
         shard = false;
         g_kernel = "streamed-wide";
-        if (mfma_form) lds -= sizeof(double) * (size_t)(mblk + 1);
+        lds = lds_plain;
       }
       e = hipSuccess;
     }
     if (shard) {
       const size_t nxs = mfma_form ? 0 : (size_t)nb_launch * m->p * SH_MAXO, nys = mfma_form ? 0 : (size_t)nb_launch * SH_MAXO, nth = (size_t)kn->k * (ch_launch + SH_PAD),
-                   npt = (size_t)(NT + SH_PAD) * ch_launch, nbar = 32 * 20 / 2;   // (barrier words counted in doubles)
+                   npt = (size_t)(NT + SH_PAD) * ch_launch, nbar = wide2 ? 4 * W2_BARW / 2 : 32 * 20 / 2;   // (barrier words counted in doubles)
       const size_t nmf = mfma_form ? (size_t)nb_launch * mblk : 0;
       e = hipMallocAsync((void**)&shw, sizeof(double) * (nxs + nys + nth + npt + nbar + nmf), stream);
       if (e != hipSuccess) { set_err("hipMallocAsync(sharded evaluation) failed: %s", hipGetErrorString(e)); return FMCMC_ERR_DEVICE; }
@@ -654,7 +677,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
         g_kernel = "streamed-wide";
         A.shard = 0; A.sh_xs = nullptr; A.sh_ys = nullptr; A.sh_th = nullptr; A.sh_part = nullptr; A.sh_bar = nullptr;
         A.sh_mfma = nullptr; A.sh_mblk = 0; A.sh_nmt = 0;
-        if (mfma_form) lds -= sizeof(double) * (size_t)(mblk + 1);
+        lds = lds_plain;
       }
     }
     if (shard) {

@@ -1,0 +1,374 @@
+// mh_wide2.hpp -- mh_sweep_wide2<KIND>: the observation-sharded sweep of wide Gaussian linear models (config C4: kernel_ram,
+// k = 50, 512 chains per GPU) as a DATAFLOW kernel.
+//
+// Same decomposition as the sharded instantiations of mh_sweep_kernel (mh_common.hpp, eval_sharded): workgroup b of 256
+// owns the canonical lanes 2b, 2b + 1 of ALL chains -- a constant slice of <= 40 observations, kept in LDS in fp64-MFMA
+// operand layout -- and the chains 2b, 2b + 1; per step the proposals of all chains cross the chip one way and the lane
+// partials the other way.  What is different is WHEN things happen.  There a step was one sequence for all 512 threads:
+// propose | hand-over | matrix cores | hand-over | adapt, accept -- 13 us of one-wave scalar work with the matrix cores
+// idle, 14 us of matrix-core work with the owners idle, 10 us of hand-over latency with everything idle.  Here
+//   * the chains form two groups (even / odd chain of every workgroup) that run HALF A STEP OUT OF PHASE;
+//   * waves 0 and 1 are the OWNERS of the workgroup's two chains and never evaluate: wait for the partials of their chain,
+//     finish the log-posterior, adapt the factor (kernel_ram), accept, store, propose, publish -- and draw the variates of
+//     the step after next while they wait;
+//   * waves 2..7 are EVALUATORS and never decide anything: wait for a group's proposals, run that group's slice product
+//     on the matrix cores (shard_columns_mfma, chain set {2l + g}), publish the lane partials, turn to the other group;
+//   * the two kinds of waves meet only through the exchange tables in HBM and four grid-wide arrival counters (per group:
+//     proposals complete, partials complete), each waited for by ONE lane per workgroup.
+// So one group's scalar phase and hand-over latencies run under the other group's matrix-core work.  Arithmetic, its order
+// and the canonical tree are those of every other kernel: bit-identical results.
+//
+// Hand-over protocol (MI355X_MICROARCH.md, inter-workgroup visibility; the form the sharded kernels have used since round
+// 1): payload moved with agent-scope (sc1) stores and loads only; every storing wave drains its stores (s_waitcnt vmcnt(0))
+// before it, or the last of its workgroup's storing waves (told by a counter in LDS), adds to the arrival counter; a
+// consumer loads only after the ONE polling lane of its workgroup has seen the release word (other waves: after an LDS
+// word that wave then sets).  Every spin is bounded; a hand-over that does not complete marks the chains of the workgroup
+// FMCMC_CHAIN_SYNC_TIMEOUT and lets every loop run out.
+#pragma once
+
+namespace {
+
+constexpr int W2_NEVAL = NW - 2;       // evaluator waves
+constexpr int W2_BARW = 32 * 20;       // 32-bit words of one arrival counter set: arrive[8] | top | release[8], one 128-byte line each
+
+// Grid-wide "everybody has published" in two levels, as in the sequential form (shard_barrier): workgroup b adds to shard
+// b % 8 (one XCD under round-robin placement), the last of a shard adds to the top counter, the last of those writes the
+// eight release words, ONE wave per waiting workgroup polls its shard's release word.  The counters are only ever touched
+// by the adds and the release words only written once per epoch: tried and dropped, both bit-identical -- every waiter
+// polling the eight (sharded, non-returning) arrival counters directly: 27.5 -> 40.9 us per step, 512 pollers and the
+// atomic adds fight for the same eight lines; per-producer flag words polled by every consumer wave (no atomics at all):
+// 38.8 us, 2048 polling waves on the fabric.
+__device__ __forceinline__ void w2_arrive(unsigned* bar, unsigned epoch) {   // ONE lane, after the drain of every wave it signals for
+  const unsigned ngroups = 8, gsize = gridDim.x / 8, g = blockIdx.x % ngroups;
+  unsigned* top = bar + 8 * 32;
+  unsigned* rel = bar + 9 * 32;
+  const unsigned old = __hip_atomic_fetch_add(&bar[g * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (old + 1 == epoch * gsize) {
+    const unsigned t = __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t + 1 == epoch * ngroups)
+      for (unsigned q = 0; q < ngroups; q++) __hip_atomic_store(&rel[q * 32], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+typedef __attribute__((address_space(3))) unsigned* w2_ldsu_t;
+__device__ __forceinline__ unsigned w2_lds_ld(unsigned* p) {   // (LDS address space: a generic pointer would make these FLAT accesses)
+  return __hip_atomic_load((w2_ldsu_t)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void w2_lds_st(unsigned* p, unsigned v) {
+  __hip_atomic_store((w2_ldsu_t)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// lane 0 of the calling wave polls the release word of its shard; wave-uniform result; false: timed out (or the workgroup
+// is already lost)
+__device__ __forceinline__ bool w2_wait(unsigned* bar, unsigned epoch, unsigned* s_lost) {
+  const unsigned g = blockIdx.x % 8;
+  unsigned* rel = bar + 9 * 32;
+  bool ok = true;
+  if ((threadIdx.x & 63) == 0) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(&rel[g * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > 20000000u || w2_lds_ld(s_lost)) { ok = false; break; }
+    }
+  }
+  return __builtin_amdgcn_readfirstlane(ok ? 1 : 0) != 0;
+}
+
+__host__ __device__ inline size_t wide2_lds_doubles(int k, int kf, int kind, int kz, int mblk) {
+  return 4 * (size_t)k + (k / 2 + 1) + 4 * (size_t)(kz + 1) + 4 + 2 * (size_t)chain_lds_doubles(k, kf, kind) + 2 + (size_t)mblk;
+}
+
+template <int KIND, int NMT>
+__global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
+  SweepArgs A = A0;
+  A.kind = KIND;
+  extern __shared__ double smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int k = A.k, kz = A.kz, p = A.p, ic = A.intercept, nb = ic + p;
+  const int NC = (int)A.nchains, NCP = NC + SH_PAD;
+  // ---- LDS: kernel parameters | which[] | variates [2 chains][2 parities][kz + 1] | sync words | 2 chain blocks | slice block
+  double* s_mu = smem;
+  double* s_scale = s_mu + k;
+  double* s_lb = s_scale + k;
+  double* s_ub = s_lb + k;
+  int* s_which = (int*)(s_ub + k);
+  double* s_z = s_ub + k + (k / 2 + 1);
+  unsigned* s_sync = (unsigned*)(s_z + 4 * (kz + 1));     // [0..1] proposals of group g seen (epoch), [2..3] evaluator arrivals, [4] lost, [5] kf
+  double* s_chains = s_z + 4 * (kz + 1) + 4;
+  if (tid == 0) {
+    int kf0 = 0;
+    for (int j = 0; j < k; j++)
+      if (!A.fixed[j]) s_which[kf0++] = j;
+    s_sync[0] = 0; s_sync[1] = 0; s_sync[2] = 0; s_sync[3] = 0; s_sync[4] = 0; s_sync[5] = (unsigned)kf0;
+  }
+  if (tid < k) {
+    s_mu[tid] = A.mu[tid];
+    s_scale[tid] = A.scale[tid];
+    s_lb[tid] = A.lb[tid];
+    s_ub[tid] = A.ub[tid];
+  }
+  __syncthreads();
+  const int kf = (int)s_sync[5];
+  const int LD = kf | 1;
+  const int CHS = chain_lds_doubles(k, kf, KIND);
+  double* s_blk = s_chains + 2 * CHS + ((2 * CHS) & 1);
+  {
+    const double* src = A.sh_mfma + (long long)blockIdx.x * A.sh_mblk;
+    for (int i = tid; i < A.sh_mblk; i += NT) s_blk[i] = src[i];
+  }
+  __syncthreads();
+  const int nsteps = (int)A.nsteps;
+  unsigned* const s_lost = &s_sync[4];
+
+  if (wave >= 2) {
+    // =========================================== evaluator waves ===========================================
+    // N-tiles of a group dealt so that the four SIMDs get the same number (waves w and w + 4 share SIMD w % 4; waves 0, 1 are
+    // the owners): SIMD 0 -> wave 4, SIMD 1 -> wave 5, SIMD 2 -> waves 2, 6 alternating, SIMD 3 -> waves 3, 7
+    const int tfirst = (wave == 4) ? 0 : (wave == 5) ? 1 : (wave == 2) ? 2 : (wave == 6) ? 6 : (wave == 3) ? 3 : 7;
+    const int tstep = (wave == 4 || wave == 5) ? 4 : 8;
+    ShardMfma sm;
+    sm.th = A.sh_th; sm.part = A.sh_part; sm.p = p; sm.ic = ic; sm.lane0 = (int)blockIdx.x * 2; sm.debug = A.debug;
+    sm.lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const double*)s_blk;
+    sm.ncp = NCP; sm.cstride = 2; sm.tfirst = tfirst; sm.tstep = tstep;
+    bool lost = false;
+    for (int v = 1; v <= nsteps && !lost; v++) {
+      for (int g = 0; g < 2 && !lost; g++) {
+        unsigned* X1 = A.sh_bar + (2 * g) * W2_BARW;
+        unsigned* X2 = A.sh_bar + (2 * g + 1) * W2_BARW;
+        // the proposals of group g, version v, are complete: wave 2 polls, the other evaluators watch an LDS word it then sets
+        if (wave == 2) {
+          const bool ok = w2_wait(X1, (unsigned)v, s_lost);
+          if (!ok) { if (lane == 0) w2_lds_st(s_lost, 1u); lost = true; }
+          else if (lane == 0) w2_lds_st(&s_sync[g], (unsigned)v);
+        } else {
+          unsigned spins = 0;
+          while (w2_lds_ld(&s_sync[g]) < (unsigned)v) {
+            __builtin_amdgcn_s_sleep(1);
+            if (w2_lds_ld(s_lost) || ++spins > 40000000u) { lost = true; break; }
+          }
+        }
+        if (lost) break;
+        const int Ng = (NC + 1 - g) >> 1;                       // chains of the group in this launch
+        if (Ng > 0) {
+          sm.NC = Ng; sm.coff = g;
+          shard_columns_mfma<2, NMT>(sm);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's partials have been acknowledged
+        if (lane == 0) {
+          const unsigned old = __hip_atomic_fetch_add((w2_ldsu_t)&s_sync[2 + g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (old + 1 == (unsigned)W2_NEVAL * (unsigned)v) w2_arrive(X2, (unsigned)v);   // the last evaluator of the workgroup signals for all
+        }
+      }
+    }
+    return;
+  }
+
+  // =============================================== owner waves ===============================================
+  const int g = wave;                                          // chain group == chain slot of the workgroup
+  const long long cl = (long long)blockIdx.x * 2 + g;          // local chain
+  const bool has = cl < A.nchains;
+  const unsigned int cgid = (unsigned int)(A.chain_base + cl);
+  unsigned* X1 = A.sh_bar + (2 * g) * W2_BARW;
+  unsigned* X2 = A.sh_bar + (2 * g + 1) * W2_BARW;
+  ChainLds L = chain_lds(s_chains + g * CHS, k, kf, KIND);
+  double* const Scur = L.SigA;
+  double f0 = 0.0, f1 = 0.0;
+  long long abs_iter = 0, nacc = 0;
+  int nerr = 0, status = FMCMC_CHAIN_OK;
+  unsigned int bitword = 0;
+  if (has) {
+    if (lane < k) {
+      const double t = A.theta0[cl * k + lane];
+      L.th0[lane] = t;
+      L.th1[lane] = t;
+    }
+    if (KIND == FMCMC_KERNEL_RAM) {
+      for (int e = lane; e < kf * LD; e += 64) {
+        const int a = e / LD, b = e % LD;
+        L.SigA[e] = A.fresh ? ((a == b) ? 1.0 * A.eps : 0.0) : ((b < kf && b <= a) ? A.Sigma[(cl * kf + a) * kf + b] : 0.0);
+        L.SigB[e] = 0.0;
+      }
+      if (!A.fresh) {
+        abs_iter = A.abs_iter[cl];
+        if (A.nerrors) nerr = A.nerrors[cl];
+      }
+    }
+  }
+  wave_sync_lds();
+  // variates of loop step ii into the buffer of its parity: lanes 0..kz-1 the proposal's, lane kz the log accept uniform
+  auto draw = [&](int ii) {
+    if (!has || ii > nsteps || lane > kz) return;
+    double* zb = s_z + (g * 2 + (ii & 1)) * (kz + 1);
+    const unsigned int st = (unsigned int)(A.step_base + ii);
+    double v;
+    if (lane == kz) {
+      v = (A.rng_mode == FMCMC_RNG_FED) ? A.fed_logu[cl * A.nsteps + (ii - 1)] : fmh_log_accept_u(A.seed, st, cgid);
+    } else {
+      if (A.rng_mode == FMCMC_RNG_FED) v = A.fed_z[(cl * A.nsteps + (ii - 1)) * kz + lane];
+      else if (KIND == FMCMC_KERNEL_RAM) v = fmh_student_t(A.seed, st, cgid, (unsigned int)lane, (double)kf);
+      else if (A.variate == 1) v = fmh_unif(A.seed, st, cgid, (unsigned int)lane);
+      else v = fmh_normal(A.seed, st, cgid, (unsigned int)lane);
+    }
+    zb[lane] = v;
+  };
+  // publish theta1 of this chain ([coefficient][chain] table) and signal; a wave without a chain only signals
+  auto publish = [&](unsigned epoch, bool store) {
+    if (has && store && lane < nb) sh_store(&A.sh_th[(long long)lane * NCP + cl], L.th1[lane]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) w2_arrive(X1, epoch);
+  };
+  // row bookkeeping (R/mcmc.R:786-813), as in mh_sweep_kernel
+  const int burnin = (int)A.burnin, thin = (int)A.thin;
+  int thin_ctr = 0;
+  long long srow = 0;
+  double* const out_s = A.samples + (cl * k + (lane < k ? lane : 0)) * A.ldS;
+  double* const out_d = A.draws ? A.draws + (cl * k + (lane < k ? lane : 0)) * A.ldS : nullptr;
+  double* const out_l = A.logpost ? A.logpost + cl * A.ldS : nullptr;
+  auto store_row = [&](int r, double lpv) {
+    if (r > burnin) {
+      thin_ctr += 1;
+      if (thin_ctr == thin) {
+        thin_ctr = 0;
+        if (lane < k) {
+          out_s[srow] = L.th0[lane];
+          if (out_d) out_d[srow] = L.th1[lane];
+        }
+        if (out_l && lane == 0) out_l[srow] = lpv;
+        srow += 1;
+      }
+    }
+  };
+
+  publish(1u, true);                       // version 1: the initial state
+  draw(2);
+  bool ram_gate = false;                   // gate of the pending proposal (R/kernel_ram.R:129), decided when it was made
+  bool lost = false;
+  for (int v = 1; v <= nsteps; v++) {
+    // ---- the lane partials of version v of this group are complete
+    // (a wave without a chain waits and signals like the others: an arrival for version v + 1 must not come before every
+    //  workgroup's arrival for version v)
+    {
+      const bool ok = w2_wait(X2, (unsigned)v, s_lost);
+      if (!ok) { if (lane == 0) w2_lds_st(s_lost, 1u); lost = true; break; }
+    }
+    if (has && (status == FMCMC_CHAIN_OK)) {
+      const double* pr = A.sh_part + (unsigned int)cl * (unsigned int)(NT + SH_PAD) + 8 * lane;
+      const double v0 = sh_load(pr + 0), v1 = sh_load(pr + 1), v2 = sh_load(pr + 2), v3 = sh_load(pr + 3);
+      const double v4 = sh_load(pr + 4), v5 = sh_load(pr + 5), v6 = sh_load(pr + 6), v7 = sh_load(pr + 7);
+      const double tot = wave_xor_sum(((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7)));   // canonical levels 1, 2, 4 | 8 .. 256
+      f1 = finish_logpost<FMCMC_FAM_GAUSSIAN_LINREG>(A, L.th1, tot);
+      if (v == 1) {
+        f0 = f1;
+        store_row(1, f0);
+      } else {
+        const int i = v;
+        const double* zt = s_z + (g * 2 + (i & 1)) * (kz + 1);
+        if (KIND == FMCMC_KERNEL_RAM) {   // adaptation with f(theta1) of the (un-reflected == final) proposal, R/kernel_ram.R:129-152
+          if (ram_gate) {
+            double a_n = fmh_exp(f1 - f0);
+            if (fmh_isnan(a_n)) a_n = 0.0;
+            else if (a_n > 1.0) a_n = 1.0;
+            double eta = (double)kf * fmh_exp((-2.0 / 3.0) * fmh_log((double)i));
+            if (eta > 1.0) eta = 1.0;
+            const double zl = (lane < kf) ? zt[lane] : 0.0;
+            const double Pj1 = lane_scan_wave(zl * zl);
+            double Pj = __shfl_up(Pj1, 1, 64);
+            Pj = (lane == 0) ? 0.0 : Pj;
+            const double nrm2 = readlane_d(Pj1, kf - 1);
+            const double cp = (eta * (a_n - A.arate)) / nrm2;
+            if (cp != 0.0 && fmh_isfinite(cp)) {
+              double dl, kl;
+              const bool okl = ram_coef(cp, Pj, Pj1, zl, dl, kl);
+              if (__any(lane < kf && !okl)) {
+                nerr += 1;
+              } else {
+                if (lane < kf) { L.vmp[lane] = dl; L.vmt[lane] = kl; }
+                wave_sync_lds();
+                ram_update_rows((lds_dptr_t)Scur, (lds_dptr_t)L.SigB, (lds_dptr_t)L.vmp, LD, kf);
+                wave_sync_lds();
+              }
+            }
+          }
+          abs_iter += 1;
+        }
+        // accept / store (R/mcmc.R:754-778)
+        if (fmh_isnan(f1)) status = FMCMC_CHAIN_NAN_LOGPOST;
+        const double ratio = f1 - f0;
+        if (status == FMCMC_CHAIN_OK && fmh_isnan(ratio)) status = FMCMC_CHAIN_NAN_RATIO;
+        if (status != FMCMC_CHAIN_OK) {
+          if (lane == 0) { A.status[cl] = status; A.status_step[cl] = i; }
+          if (lane < k) A.status_theta[cl * k + lane] = L.th1[lane];
+        } else {
+          const double lu = zt[kz];
+          if (lu < ratio) {
+            if (lane < k) L.th0[lane] = L.th1[lane];
+            f0 = f1;
+            nacc += 1;
+            bitword |= (1u << ((i - 1) & 31));
+          }
+          wave_sync_lds();
+          store_row(i, f1);
+        }
+      }
+    }
+    if (has && v >= 2 && A.accept_bits && lane == 0 && (((v - 1) & 31) == 31 || v == nsteps)) {
+      A.accept_bits[cl * (long long)((nsteps + 31) >> 5) + ((v - 1) >> 5)] = bitword;
+      bitword = 0;
+    }
+    // ---- proposal of loop step v + 1 (a failed chain keeps its theta1: the table still holds it)
+    if (v < nsteps) {
+      bool fresh_prop = false;
+      if (has && status == FMCMC_CHAIN_OK) {
+        const int i = v + 1;
+        const double* zt = s_z + (g * 2 + (i & 1)) * (kz + 1);
+        if (KIND == FMCMC_KERNEL_RAM) {   // R/kernel_ram.R:123-126
+          const double s = ram_propose_rows((lds_dptr_t)Scur, (lds_dptr_t)L.SigB, (lds_dptr_t)zt, LD, kf);
+          if (lane < kf) {
+            const int j = s_which[lane];
+            L.th1[j] = L.th0[j] + s;
+          }
+          ram_gate = (A.until > (double)abs_iter && abs_iter > A.warmup && (i % A.freq) == 0);
+        } else {                          // kernel_normal(_reflective), joint scheme (R/kernel_normal.R:67-72, :159-164)
+          if (lane < k) L.th1[lane] = L.th0[lane];
+          wave_sync_lds();
+          if (lane < kf) {
+            const int j = s_which[lane];
+            double t = L.th0[j] + (s_mu[j] + s_scale[j] * zt[lane]);
+            if (KIND == FMCMC_KERNEL_NORMAL_REFLECTIVE) t = reflect1(t, s_lb[j], s_ub[j]);
+            L.th1[j] = t;
+          }
+        }
+        wave_sync_lds();
+        fresh_prop = true;
+      }
+      publish((unsigned)(v + 1), fresh_prop);
+      draw(v + 2);                        // in the shadow of the hand-overs and of this group's matrix-core work
+      wave_sync_lds();
+    }
+  }
+  // ---- write state back
+  if (has) {
+    if (lost) {
+      status = FMCMC_CHAIN_SYNC_TIMEOUT;
+      if (lane == 0) { A.status[cl] = status; A.status_step[cl] = 0; }
+    }
+    if (lane < k) A.theta0[cl * k + lane] = L.th0[lane];
+    if (lane == 0) {
+      A.f0[cl] = f0;
+      A.accept_count[cl] = nacc;
+      if (status == FMCMC_CHAIN_OK) { A.status[cl] = FMCMC_CHAIN_OK; A.status_step[cl] = 0; }
+      if (KIND == FMCMC_KERNEL_RAM) {
+        A.abs_iter[cl] = abs_iter;
+        if (A.nerrors) A.nerrors[cl] = nerr;
+      }
+    }
+    if (KIND == FMCMC_KERNEL_RAM) {
+      wave_sync_lds();
+      for (int e = lane; e < kf * kf; e += 64) {
+        const int a = e / kf, b = e % kf;
+        A.Sigma[(cl * kf + a) * kf + b] = Scur[a * LD + b];
+      }
+    }
+  }
+}
+
+}  // namespace

@@ -562,6 +562,16 @@ def test_logistic_on_the_general_kernel(E, O, kind_name):
         run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_NORMAL, 4, init, nsteps=150, prior_div=8.0, scale=0.1, scheme="ordered")
 
 
+SHARDED = ("streamed-wide-sharded-mfma", "wide-dataflow")     # the sequential and the dataflow form of the observation-sharded sweep
+
+
+@pytest.fixture(params=["dataflow", "sequential"])
+def wide_form(request, monkeypatch):
+    """Both forms of the observation-sharded sweep (mh_wide2.hpp / eval_sharded): FMCMC_AMD_WIDE2=0 keeps the sequential one."""
+    monkeypatch.setenv("FMCMC_AMD_WIDE2", "1" if request.param == "dataflow" else "0")
+    return request.param
+
+
 @pytest.mark.parametrize("chains,cw,n,p,intercept", [
     (256, "1", 10000, 16, True),      # 256 workgroups x 2 canonical lanes, 20 slots: the full slice of 40 observations
     (128, "1", 4099, 21, True),       # 128 workgroups x 4 lanes, ragged last slot
@@ -571,7 +581,7 @@ def test_logistic_on_the_general_kernel(E, O, kind_name):
     (77, "1", 10240, 23, True),       # 77 of 256 workgroups hold a chain
     (130, "1", 9000, 62, True),       # k = 64, the widest model: the slice (19.8 KB) no longer fits the scalar cache
 ])
-def test_observation_sharded_evaluation(E, O, monkeypatch, chains, cw, n, p, intercept):
+def test_observation_sharded_evaluation(E, O, monkeypatch, wide_form, chains, cw, n, p, intercept):
     """Wide linear models whose workgroups split the 512 canonical lanes evenly evaluate observation-sharded
     (eval_sharded, cooperative launch, two grid barriers per step): the oracle's bits for the normal, reflective and RAM
     kernels, continued over two calls, and the same bits as the chain-sharded kernel (FMCMC_AMD_SHARD=0)."""
@@ -581,7 +591,9 @@ def test_observation_sharded_evaluation(E, O, monkeypatch, chains, cw, n, p, int
     monkeypatch.setenv("FMCMC_AMD_SHARD", "1")      # every eligible shape, also where the cost model prefers chain-sharded
     nb = p + (1 if intercept else 0)
     # co-residency needs one CU per workgroup of the launch (256, or exactly 128): a partitioned GPU falls back
-    sharded = "streamed-wide-sharded-mfma" if torch.cuda.get_device_properties(0).multi_processor_count >= 256 else "streamed-wide"
+    full = torch.cuda.get_device_properties(0).multi_processor_count >= 256
+    # (the dataflow form needs two chains per workgroup and 256 workgroups; everything else runs the sequential form)
+    sharded = ("wide-dataflow" if (wide_form == "dataflow" and cw == "2" and chains > 256) else "streamed-wide-sharded-mfma") if full else "streamed-wide"
     X, y = synth_linreg(n, p, 9100 + n + p, beta=np.linspace(1.0, -1.0, p + 1))
     init = jitter_init(list(np.linspace(1.0, -1.0, p + 1))[(0 if intercept else 1):] + [4.0], chains, n + p)
     init[:, -1] = np.abs(init[:, -1])
@@ -598,7 +610,7 @@ def test_observation_sharded_evaluation(E, O, monkeypatch, chains, cw, n, p, int
     assert _bits_equal(a.samples.cpu().numpy(), b.samples.cpu().numpy())
 
 
-def test_observation_sharded_long_run_equals_chain_sharded(E, monkeypatch):
+def test_observation_sharded_long_run_equals_chain_sharded(E, monkeypatch, wide_form):
     """Config C4's shape (512 chains, n = 10,000, k = 50, kernel_ram), 400 steps: 800 grid barriers without a stale read --
     the sharded and the chain-sharded kernels return identical bits for every output."""
     import torch
@@ -618,7 +630,7 @@ def test_observation_sharded_long_run_equals_chain_sharded(E, monkeypatch):
         r = E.sweep(gm, gk, st, 400, seed=77, check=True)
         torch.cuda.synchronize()
         if torch.cuda.get_device_properties(0).multi_processor_count >= 256:
-            assert abi.last_kernel() == ("streamed-wide-sharded-mfma" if sh == "1" else "streamed-wide")
+            assert abi.last_kernel() == (("wide-dataflow" if wide_form == "dataflow" else "streamed-wide-sharded-mfma") if sh == "1" else "streamed-wide")
         outs.append([t.cpu().numpy() for t in (r.samples, r.logpost, r.draws, r.accept_count, st.Sigma, st.theta0)])
     for u, v in zip(*outs):
         assert _bits_equal(u, v) if u.dtype == np.float64 else np.array_equal(u, v)
@@ -751,9 +763,9 @@ def test_randomised_sharded_shapes(E, O, monkeypatch):
         run_both(E, O, O.FAM_LINREG, X, y, kind, k, init, nsteps=nsteps, burnin=case % 3, thin=1 + case % 2, seed=100 + case,
                  chain_base=17 * case, calls=1 + case % 2, **opts)
         picked.append(abi.last_kernel())
-    assert all(name.startswith("streamed-wide") for name in picked), picked
+    assert all(name.startswith("streamed-wide") or name == "wide-dataflow" for name in picked), picked
     if torch.cuda.get_device_properties(0).multi_processor_count >= 256:
-        assert sum(name == "streamed-wide-sharded-mfma" for name in picked) >= 12, picked
+        assert sum(name in SHARDED for name in picked) >= 12, picked
 
 
 def test_sharded_evaluation_with_failing_chains(E, O, monkeypatch):
@@ -774,7 +786,7 @@ def test_sharded_evaluation_with_failing_chains(E, O, monkeypatch):
     scale = np.full(p + 2, 0.001); scale[-1] = 0.05
     rg, ro = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, p + 2, init, nsteps=40, guard=False, scale=scale)
     if torch.cuda.get_device_properties(0).multi_processor_count >= 256:
-        assert abi.last_kernel() == "streamed-wide-sharded-mfma"
+        assert abi.last_kernel() in SHARDED
     assert (ro.status == 1).sum() >= 10 and (ro.status == 0).sum() >= 200
     assert np.array_equal(rg.status_step.cpu().numpy(), ro.status_step)
     with pytest.raises(RuntimeError, match="undefined"):
@@ -988,7 +1000,7 @@ def test_sharded_evaluation_in_consecutive_launches(E, O, monkeypatch, kind_name
     opts = dict(scale=0.01, fixed=[False] * 3 + [True] + [False] * (p - 2)) if kind_name == "normal" else {}
     a, _ = run_both(E, O, O.FAM_LINREG, X, y, kind, p + 2, init, nsteps=16, burnin=1, thin=2, calls=2, chain_base=40, **opts)
     if torch.cuda.get_device_properties(0).multi_processor_count >= 256:
-        assert abi.last_kernel() == "streamed-wide-sharded-mfma"
+        assert abi.last_kernel() in SHARDED
     monkeypatch.setenv("FMCMC_AMD_SHARD", "0")
     b, _ = run_both(E, O, O.FAM_LINREG, X, y, kind, p + 2, init, nsteps=16, burnin=1, thin=2, calls=2, chain_base=40, **opts)
     assert abi.last_kernel() in ("streamed-wide", "streamed")

@@ -1,0 +1,4 @@
+set -o pipefail
+cd /root/repo
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -k "sharded or wide" > gpurun_out/r02_gpu_tests_k.log 2>&1; echo "pytest rc=$?"; tail -8 gpurun_out/r02_gpu_tests_k.log
+timeout -k 10 120 python tools/bench_c4.py 400 > gpurun_out/r02_c4_e.log 2>&1; grep -v amdgpu.ids gpurun_out/r02_c4_e.log
