@@ -87,6 +87,49 @@ __device__ __attribute__((noinline)) void ram_update_rows(lds_dptr_t S, lds_dptr
   }
 }
 
+// Both at once, for an owner that goes straight from the adaptation of step i to the proposal of step i + 1 (mh_wide2.hpp):
+// S'_ij = fma(G_ij, kappa_j, S_ij d_j) is used the moment it exists -- (S' z')_i accumulated from the last column down, its
+// partial sums G'_ij written over G_ij.  One pass over the two matrices instead of two; the same operations on every
+// element in the same order as ram_update_rows followed by ram_propose_rows.
+__device__ __attribute__((noinline)) double ram_update_propose_rows(lds_dptr_t S, lds_dptr_t G, lds_dptr_t dk, lds_dptr_t z,
+                                                                    int LD_, int kf_) {
+  const int lane = threadIdx.x & 63;
+  const int LD = __builtin_amdgcn_readfirstlane(LD_), kf = __builtin_amdgcn_readfirstlane(kf_);
+  double s = 0.0;
+  if (lane < kf) {
+    const lds_dptr_t row = S + lane * LD, grow = G + lane * LD, kap = dk + kf;
+    int j = kf - 1;
+    double sc[4], gc[4], dc[4], kc[4], zc[4];
+    if (j >= 3) {
+#pragma unroll
+      for (int u = 0; u < 4; u++) { sc[u] = row[j - u]; gc[u] = grow[j - u]; dc[u] = dk[j - u]; kc[u] = kap[j - u]; zc[u] = z[j - u]; }
+    }
+    for (; j >= 3; j -= 4) {
+      const int jn = (j - 4 >= 3) ? j - 4 : j;       // the next group (the last round re-reads its own before it is rewritten: unused)
+      double sn[4], gn[4], dn[4], kn[4], zn[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { sn[u] = row[jn - u]; gn[u] = grow[jn - u]; dn[u] = dk[jn - u]; kn[u] = kap[jn - u]; zn[u] = z[jn - u]; }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const double nw = (lane >= j - u) ? fmh_fma(gc[u], kc[u], sc[u] * dc[u]) : sc[u];
+        row[j - u] = nw;
+        grow[j - u] = s;
+        s = fmh_fma(nw, zc[u], s);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) { sc[u] = sn[u]; gc[u] = gn[u]; dc[u] = dn[u]; kc[u] = kn[u]; zc[u] = zn[u]; }
+    }
+    for (; j >= 0; j--) {
+      const double sij = row[j];
+      const double nw = (lane >= j) ? fmh_fma(grow[j], kap[j], sij * dk[j]) : sij;
+      row[j] = nw;
+      grow[j] = s;
+      s = fmh_fma(nw, z[j], s);
+    }
+  }
+  return s;
+}
+
 template <int CW, int P, int OPT, int KIND, int FAM = 0, int MINB = 1>
 __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) {
   constexpr bool RESIDENT = (P >= 0);

@@ -130,6 +130,12 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
     sm.lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const double*)s_blk;
     sm.ncp = NCP; sm.cstride = 2; sm.tfirst = tfirst; sm.tstep = tstep;
     bool lost = false;
+#ifdef FMCMC_STAMP
+    unsigned long long ev_acc[4] = {0, 0, 0, 0}, ev_prev = stamp_clk();
+#define W2_EV_STAMP(i) do { if (wave == 2) { const unsigned long long t_ = stamp_clk(); ev_acc[i] += t_ - ev_prev; ev_prev = t_; } } while (0)
+#else
+#define W2_EV_STAMP(i) do { } while (0)
+#endif
     for (int v = 1; v <= nsteps && !lost; v++) {
       for (int g = 0; g < 2 && !lost; g++) {
         unsigned* X1 = A.sh_bar + (2 * g) * W2_BARW;
@@ -147,18 +153,26 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
           }
         }
         if (lost) break;
+        W2_EV_STAMP(0);
         const int Ng = (NC + 1 - g) >> 1;                       // chains of the group in this launch
         if (Ng > 0) {
           sm.NC = Ng; sm.coff = g;
           shard_columns_mfma<2, NMT>(sm);
         }
+        W2_EV_STAMP(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's partials have been acknowledged
+        W2_EV_STAMP(2);
         if (lane == 0) {
           const unsigned old = __hip_atomic_fetch_add((w2_ldsu_t)&s_sync[2 + g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           if (old + 1 == (unsigned)W2_NEVAL * (unsigned)v) w2_arrive(X2, (unsigned)v);   // the last evaluator of the workgroup signals for all
         }
+        W2_EV_STAMP(3);
       }
     }
+#ifdef FMCMC_STAMP
+    if (wave == 2 && lane < 4 && k >= 32 && (long long)blockIdx.x * 2 < A.nchains)
+      A.status_theta[(long long)blockIdx.x * 2 * k + 16 + lane] = (double)ev_acc[lane];
+#endif
     return;
   }
 
@@ -223,23 +237,46 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
   double* const out_s = A.samples + (cl * k + (lane < k ? lane : 0)) * A.ldS;
   double* const out_d = A.draws ? A.draws + (cl * k + (lane < k ? lane : 0)) * A.ldS : nullptr;
   double* const out_l = A.logpost ? A.logpost + cl * A.ldS : nullptr;
-  auto store_row = [&](int r, double lpv) {
-    if (r > burnin) {
-      thin_ctr += 1;
-      if (thin_ctr == thin) {
-        thin_ctr = 0;
-        if (lane < k) {
-          out_s[srow] = L.th0[lane];
-          if (out_d) out_d[srow] = L.th1[lane];
-        }
-        if (out_l && lane == 0) out_l[srow] = lpv;
-        srow += 1;
-      }
+  // What the decision of step i needs and f(theta1) does not enter, prepared while the wave waits for the partials:
+  // the sigma-only part of the closed form of the pending proposal; for kernel_ram eta(i, k) = min(1, k i^(-2/3))
+  // (R/kernel_ram.R:67) and the prefix sums of z^2 (their last one is |z|^2).
+  double pre_nt1 = 0.0, pre_ss = 1.0, pre_eta = 0.0, pre_zl = 0.0, pre_Pj = 0.0, pre_Pj1 = 0.0, pre_nrm2 = 1.0;
+  bool pre_sigma_ok = false;
+  const double dn = (double)A.n;
+  auto prepare = [&](int i) {
+    if (!has) return;
+    const double sigma = L.th1[k - 1];
+    const unsigned sg_hi = (unsigned)(fmh_d2u(sigma) >> 32);
+    pre_sigma_ok = (sg_hi - 0x00100000u) < 0x7fe00000u;                 // positive, finite, normal: the closed form's main branch
+    const double sg = pre_sigma_ok ? sigma : 1.0;
+    pre_nt1 = dn * (fmh_log(sg) + FMH_LN_SQRT_2PI);
+    pre_ss = sg * sg;
+    if (KIND == FMCMC_KERNEL_RAM && i >= 2) {
+      double eta = (double)kf * fmh_exp((-2.0 / 3.0) * fmh_log((double)i));
+      if (eta > 1.0) eta = 1.0;
+      pre_eta = eta;
+      const double* zt = s_z + (g * 2 + (i & 1)) * (kz + 1);
+      pre_zl = (lane < kf) ? zt[lane] : 0.0;
+      pre_Pj1 = lane_scan_wave(pre_zl * pre_zl);
+      const double up = __shfl_up(pre_Pj1, 1, 64);
+      pre_Pj = (lane == 0) ? 0.0 : up;
+      pre_nrm2 = readlane_d(pre_Pj1, kf - 1);
     }
   };
 
+#ifdef FMCMC_STAMP
+  unsigned long long ow_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ow_prev = 0;
+#define W2_OW_STAMP(i) do { if (wave == 0) { const unsigned long long t_ = stamp_clk(); ow_acc[i] += t_ - ow_prev; ow_prev = t_; } } while (0)
+#else
+#define W2_OW_STAMP(i) do { } while (0)
+#endif
   publish(1u, true);                       // version 1: the initial state
   draw(2);
+  wave_sync_lds();
+  prepare(1);
+#ifdef FMCMC_STAMP
+  ow_prev = stamp_clk();
+#endif
   bool ram_gate = false;                   // gate of the pending proposal (R/kernel_ram.R:129), decided when it was made
   bool lost = false;
   for (int v = 1; v <= nsteps; v++) {
@@ -250,15 +287,28 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
       const bool ok = w2_wait(X2, (unsigned)v, s_lost);
       if (!ok) { if (lane == 0) w2_lds_st(s_lost, 1u); lost = true; break; }
     }
+    W2_OW_STAMP(0);
+    bool row_keep = false, fresh_prop = false;
+    double row_th0 = 0.0, row_th1 = 0.0, row_f1 = 0.0;
     if (has && (status == FMCMC_CHAIN_OK)) {
       const double* pr = A.sh_part + (unsigned int)cl * (unsigned int)(NT + SH_PAD) + 8 * lane;
       const double v0 = sh_load(pr + 0), v1 = sh_load(pr + 1), v2 = sh_load(pr + 2), v3 = sh_load(pr + 3);
       const double v4 = sh_load(pr + 4), v5 = sh_load(pr + 5), v6 = sh_load(pr + 6), v7 = sh_load(pr + 7);
       const double tot = wave_xor_sum(((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7)));   // canonical levels 1, 2, 4 | 8 .. 256
-      f1 = finish_logpost<FMCMC_FAM_GAUSSIAN_LINREG>(A, L.th1, tot);
+      // closed form: -(n (log sigma + ln sqrt 2 pi)) - (tot / 2) / sigma^2 with the sigma-only part prepared while this wave
+      // waited (same operations, same bits as finish_logpost)
+      if (pre_sigma_ok) {
+        f1 = -pre_nt1 - (0.5 * tot) / pre_ss;
+        if (A.guard && !fmh_isfinite(f1)) f1 = -fmh_inf();
+      } else {
+        f1 = finish_logpost<FMCMC_FAM_GAUSSIAN_LINREG>(A, L.th1, tot);
+      }
+      W2_OW_STAMP(1);
+      row_th1 = (lane < k) ? L.th1[lane] : 0.0;
+      bool do_update = false;                 // kernel_ram: d_j | kappa_j of this step are in L.vmp | L.vmt
       if (v == 1) {
         f0 = f1;
-        store_row(1, f0);
+        row_keep = true;
       } else {
         const int i = v;
         const double* zt = s_z + (g * 2 + (i & 1)) * (kz + 1);
@@ -267,30 +317,22 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
             double a_n = fmh_exp(f1 - f0);
             if (fmh_isnan(a_n)) a_n = 0.0;
             else if (a_n > 1.0) a_n = 1.0;
-            double eta = (double)kf * fmh_exp((-2.0 / 3.0) * fmh_log((double)i));
-            if (eta > 1.0) eta = 1.0;
-            const double zl = (lane < kf) ? zt[lane] : 0.0;
-            const double Pj1 = lane_scan_wave(zl * zl);
-            double Pj = __shfl_up(Pj1, 1, 64);
-            Pj = (lane == 0) ? 0.0 : Pj;
-            const double nrm2 = readlane_d(Pj1, kf - 1);
-            const double cp = (eta * (a_n - A.arate)) / nrm2;
+            const double cp = (pre_eta * (a_n - A.arate)) / pre_nrm2;
             if (cp != 0.0 && fmh_isfinite(cp)) {
               double dl, kl;
-              const bool okl = ram_coef(cp, Pj, Pj1, zl, dl, kl);
+              const bool okl = ram_coef(cp, pre_Pj, pre_Pj1, pre_zl, dl, kl);
               if (__any(lane < kf && !okl)) {
                 nerr += 1;
               } else {
                 if (lane < kf) { L.vmp[lane] = dl; L.vmt[lane] = kl; }
-                wave_sync_lds();
-                ram_update_rows((lds_dptr_t)Scur, (lds_dptr_t)L.SigB, (lds_dptr_t)L.vmp, LD, kf);
-                wave_sync_lds();
+                do_update = true;
               }
             }
           }
           abs_iter += 1;
         }
-        // accept / store (R/mcmc.R:754-778)
+        W2_OW_STAMP(2);
+        // accept (R/mcmc.R:754-778); the row is stored behind the hand-over
         if (fmh_isnan(f1)) status = FMCMC_CHAIN_NAN_LOGPOST;
         const double ratio = f1 - f0;
         if (status == FMCMC_CHAIN_OK && fmh_isnan(ratio)) status = FMCMC_CHAIN_NAN_RATIO;
@@ -305,23 +347,20 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
             nacc += 1;
             bitword |= (1u << ((i - 1) & 31));
           }
-          wave_sync_lds();
-          store_row(i, f1);
+          row_keep = true;
         }
       }
-    }
-    if (has && v >= 2 && A.accept_bits && lane == 0 && (((v - 1) & 31) == 31 || v == nsteps)) {
-      A.accept_bits[cl * (long long)((nsteps + 31) >> 5) + ((v - 1) >> 5)] = bitword;
-      bitword = 0;
-    }
-    // ---- proposal of loop step v + 1 (a failed chain keeps its theta1: the table still holds it)
-    if (v < nsteps) {
-      bool fresh_prop = false;
-      if (has && status == FMCMC_CHAIN_OK) {
+      wave_sync_lds();
+      row_th0 = (lane < k) ? L.th0[lane] : 0.0;
+      row_f1 = f1;
+      W2_OW_STAMP(3);
+      // ---- factor update of step v and proposal of loop step v + 1 (a failed chain keeps its theta1: the table still holds it)
+      if (status == FMCMC_CHAIN_OK && v < nsteps) {
         const int i = v + 1;
         const double* zt = s_z + (g * 2 + (i & 1)) * (kz + 1);
         if (KIND == FMCMC_KERNEL_RAM) {   // R/kernel_ram.R:123-126
-          const double s = ram_propose_rows((lds_dptr_t)Scur, (lds_dptr_t)L.SigB, (lds_dptr_t)zt, LD, kf);
+          const double s = do_update ? ram_update_propose_rows((lds_dptr_t)Scur, (lds_dptr_t)L.SigB, (lds_dptr_t)L.vmp, (lds_dptr_t)zt, LD, kf)
+                                     : ram_propose_rows((lds_dptr_t)Scur, (lds_dptr_t)L.SigB, (lds_dptr_t)zt, LD, kf);
           if (lane < kf) {
             const int j = s_which[lane];
             L.th1[j] = L.th0[j] + s;
@@ -339,12 +378,44 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
         }
         wave_sync_lds();
         fresh_prop = true;
+      } else if (KIND == FMCMC_KERNEL_RAM && do_update) {   // the last step of the call (or a chain that just failed): S only
+        wave_sync_lds();
+        ram_update_rows((lds_dptr_t)Scur, (lds_dptr_t)L.SigB, (lds_dptr_t)L.vmp, LD, kf);
+        wave_sync_lds();
       }
-      publish((unsigned)(v + 1), fresh_prop);
-      draw(v + 2);                        // in the shadow of the hand-overs and of this group's matrix-core work
+    }
+    W2_OW_STAMP(4);
+    if (v < nsteps) publish((unsigned)(v + 1), fresh_prop);
+    W2_OW_STAMP(5);
+    // ---- everything below runs in the shadow of the hand-overs and of this group's matrix-core work
+    if (row_keep) {   // row v of ans / draws / logpost (store_row reads L.th0 / L.th1: the saved values go through its registers)
+      if (v > burnin) {
+        thin_ctr += 1;
+        if (thin_ctr == thin) {
+          thin_ctr = 0;
+          if (lane < k) {
+            out_s[srow] = row_th0;
+            if (out_d) out_d[srow] = row_th1;
+          }
+          if (out_l && lane == 0) out_l[srow] = row_f1;
+          srow += 1;
+        }
+      }
+    }
+    if (has && v >= 2 && A.accept_bits && lane == 0 && (((v - 1) & 31) == 31 || v == nsteps)) {
+      A.accept_bits[cl * (long long)((nsteps + 31) >> 5) + ((v - 1) >> 5)] = bitword;
+      bitword = 0;
+    }
+    if (v < nsteps) {
+      draw(v + 2);
       wave_sync_lds();
+      prepare(v + 1);                     // what step v + 1 needs that does not depend on f(theta1)
+      W2_OW_STAMP(6);
     }
   }
+#ifdef FMCMC_STAMP
+  if (wave == 0 && has && lane < 8 && k >= 32) A.status_theta[cl * k + lane] = (double)ow_acc[lane];
+#endif
   // ---- write state back
   if (has) {
     if (lost) {

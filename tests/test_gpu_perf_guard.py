@@ -52,7 +52,7 @@ def test_time_per_iteration_within_125_percent_of_the_record(name):
         rec[name] = {"us_per_iteration": round(us, 3), "kernel": kernel, "iterations": SHORT[name]}
         out = os.path.join(ROOT, "gpurun_out", "perf_guard.json")        # (copied into profiles/ by hand once accepted)
         prev = json.load(open(out)) if os.path.exists(out) else {}
-        prev.update(rec)
+        prev[name] = rec[name]
         os.makedirs(os.path.dirname(out), exist_ok=True)
         json.dump(prev, open(out, "w"), indent=1, sort_keys=True)
         return
