@@ -277,14 +277,39 @@ static SweepArgs chain_window(const SweepArgs& A, long long off, long long cnt, 
 // chain-sharded kernel.  Cost model (us per step, fitted at k = 50): chain-sharded ~4 + X bytes / 65 GB/s (the per-CU L2
 // rate); sharded ~14 of hand-overs and fixed work + 0.0085 per column and walked observation slot (+ ~6 of barrier
 // imbalance under kernel_ram): n = 2500 loses (23.9 vs 19.1), n = 5000 wins (24.3 vs 30.1), C4 wins 2x.
-// FMCMC_AMD_SHARD=1 forces the sharded kernel for every eligible shape (tests), =0 disables it.
-static bool shard_mfma_enabled() {   // FMCMC_AMD_SHARD_MFMA=0: the VALU form of the slice product (A/B partner)
-  const char* e = getenv("FMCMC_AMD_SHARD_MFMA");
-  return !(e && e[0] == '0');
+// Knob shard=1 (FMCMC_AMD_DEBUG) forces the sharded kernel for every eligible shape (tests), shard=0 disables it.
+// ---- diagnosis knobs: ONE environment variable, read once per call --------------------------------------------------------
+//   FMCMC_AMD_DEBUG="key=value,key=value"   (unset = product behaviour; nothing else in the environment is looked at)
+//   streamed=1   general streamed kernel for everything          cw=1|2|4|8  chains per workgroup of the streamed kernels
+//   pipe=0       no materialised-stream kernels (mfma/spec/pipe)  spec=0      mh_sweep_pipe instead of mh_sweep_spec
+//   mfma=0       VALU evaluation instead of the fp64-MFMA kernels owners=0|1  replicated-state / owner-wave MFMA kernel
+//   shard=0|1    wide models: never / always (when eligible) observation-sharded; unset: cost model
+//   shard_mfma=0 VALU form of the sharded slice product           wide2=0|1   never / always (when eligible) the dataflow form
+//   mode=<bits>  timing ablations and stamps (SweepArgs.debug)
+// The kernel a call ended up on is reported by fmcmc_last_kernel(); DESIGN.md section 5 has the shape -> kernel table.
+struct Knobs {
+  int streamed = -1, cw = -1, pipe = -1, spec = -1, mfma = -1, owners = -1, shard = -1, shard_mfma = -1, wide2 = -1, mode = 0;
+};
+static Knobs read_knobs() {
+  Knobs K;
+  const char* e = getenv("FMCMC_AMD_DEBUG");
+  if (!e) return K;
+  struct { const char* name; int* dst; } tab[] = {{"streamed", &K.streamed}, {"cw", &K.cw}, {"pipe", &K.pipe}, {"spec", &K.spec},
+      {"mfma", &K.mfma}, {"owners", &K.owners}, {"shard_mfma", &K.shard_mfma}, {"shard", &K.shard}, {"wide2", &K.wide2}, {"mode", &K.mode}};
+  while (*e) {
+    const char* eq = strchr(e, '=');
+    const char* end = strchr(e, ',');
+    if (!end) end = e + strlen(e);
+    if (eq && eq < end)
+      for (auto& t : tab)
+        if ((size_t)(eq - e) == strlen(t.name) && !strncmp(e, t.name, (size_t)(eq - e))) *t.dst = atoi(eq + 1);
+    e = (*end == ',') ? end + 1 : end;
+  }
+  return K;
 }
-static int wide_sharded_lanes(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_run* run, int ram_bounded, int ncu, long long nb) {
-  const char* shenv = getenv("FMCMC_AMD_SHARD");
-  if (shenv && shenv[0] == '0') return 0;
+static bool shard_mfma_enabled(const Knobs& K) { return K.shard_mfma != 0; }
+static int wide_sharded_lanes(const Knobs& K, const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_run* run, int ram_bounded, int ncu, long long nb) {
+  if (K.shard == 0) return 0;
   if (m->family != FMCMC_FAM_GAUSSIAN_LINREG || m->p < 16) return 0;
   if (kn->kind != FMCMC_KERNEL_RAM && kn->kind != FMCMC_KERNEL_NORMAL && kn->kind != FMCMC_KERNEL_NORMAL_REFLECTIVE) return 0;
   const int nslots = (int)((m->n + NT - 1) / NT);
@@ -293,12 +318,12 @@ static int wide_sharded_lanes(const fmcmc_model* m, const fmcmc_kernel* kn, cons
   // A slice of more than 49 columns (15.5 KB) no longer stays in the scalar cache: 2.1x per walked slot, still ahead for the
   // normal kernels (k = 64, n = 10k: 57 us per step against 78); kernel_ram stays chain-sharded there, its owner phase
   // dominates at that width and runs slower in the sharded instantiation (121 against 108).
-  const bool cached = shard_mfma_enabled() || (size_t)m->p * SH_MAXO * sizeof(double) <= 15872;   // (the MFMA form keeps the slice in LDS)
+  const bool cached = shard_mfma_enabled(K) || (size_t)m->p * SH_MAXO * sizeof(double) <= 15872;   // (the MFMA form keeps the slice in LDS)
   const bool ok = lpw > 0 && !(kn->kind == FMCMC_KERNEL_RAM && (ram_bounded || !cached)) && lpw * nslots <= SH_MAXO && nb <= ncu &&
                   (long long)m->p * SH_MAXO * nb < (1ll << 28) && (long long)(m->p + 1) * (per_launch + SH_PAD) < (1ll << 31) &&
                   run->nsteps < 30000000;   /* barrier epochs (2 per step) x workgroups per group stay below 2^32 */
   if (!ok) return 0;
-  if (!(shenv && shenv[0] == '1')) {
+  if (K.shard != 1) {
     const double walked = (cached ? 1.0 : 2.1) * ((lpw * nslots <= SH_MAXO / 2) ? SH_MAXO / 2 : SH_MAXO);
     const double est_chain = 4.0 + (double)m->n * (double)m->p * 8.0 / 65000.0;
     const double est_shard = 14.0 + 0.0085 * (double)m->p * walked + (kn->kind == FMCMC_KERNEL_RAM ? 6.0 : 0.0);
@@ -306,8 +331,8 @@ static int wide_sharded_lanes(const fmcmc_model* m, const fmcmc_kernel* kn, cons
   }
   return lpw;
 }
-static bool wide_sharded_pays(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_run* run, int ram_bounded, int ncu, long long nb) {
-  return wide_sharded_lanes(m, kn, run, ram_bounded, ncu, nb) > 0;
+static bool wide_sharded_pays(const Knobs& K, const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_run* run, int ram_bounded, int ncu, long long nb) {
+  return wide_sharded_lanes(K, m, kn, run, ram_bounded, ncu, nb) > 0;
 }
 
 // stream-ordered scratch that is released on EVERY way out of launch_sweep
@@ -363,7 +388,8 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
   A.rng_mode = run->rng_mode; A.fresh = st->fresh; A.ram_bounded = ram_bounded;
   A.kz = variates_per_step(kn, kf);
   A.fed_logu = run->fed_logu; A.fed_z = run->fed_z;
-  { const char* dbg = getenv("FMCMC_AMD_DEBUG_MODE"); A.debug = dbg ? atoi(dbg) : 0; }  // timing ablations only
+  const Knobs K = read_knobs();
+  A.debug = K.mode;   // timing ablations only
   A.theta0 = st->theta0; A.f0 = st->f0; A.abs_iter = (long long*)st->abs_iter; A.Sigma = st->Sigma;
   A.mean_prev = st->mean_prev; A.have_mean = st->have_mean; A.nerrors = st->nerrors;
   A.samples = out->samples; A.logpost = out->logpost; A.draws = out->draws;
@@ -377,8 +403,8 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
   if (ncu <= 0) ncu = 256;
   // register-resident variant: Gaussian linreg whose data fits the VGPR budget of 512 threads
   int res_p = -1, res_opt = 0;
-  const char* force = getenv("FMCMC_AMD_FORCE_STREAMED");
-  if (!(force && force[0] == '1') && m->family == FMCMC_FAM_GAUSSIAN_LINREG && !mirror) {
+  const bool force = K.streamed == 1;
+  if (!force && m->family == FMCMC_FAM_GAUSSIAN_LINREG && !mirror) {
     static const int variants[][2] = {{1, 4}, {3, 20}};
     for (auto& v : variants)
       if (m->p == v[0] && m->n > (long long)NT * (v[1] - RES_MASKED) && m->n <= (long long)NT * v[1]) {
@@ -393,13 +419,12 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
     cw = 4;
   } else {
     while (cw < NW && (long long)cw * ncu < run->nchains) cw <<= 1;
-    const char* cwenv = getenv("FMCMC_AMD_CW");   // diagnosis: chains per workgroup of the streamed kernel (1, 2, 4, 8)
-    if (cwenv && (cwenv[0] == '1' || cwenv[0] == '2' || cwenv[0] == '4' || cwenv[0] == '8')) cw = cwenv[0] - '0';
+    if (K.cw == 1 || K.cw == 2 || K.cw == 4 || K.cw == 8) cw = K.cw;   // diagnosis: chains per workgroup of the streamed kernel
     // wide linear models with more than two chains per CU: two chains per workgroup, so that the sweep can run as
     // consecutive observation-sharded launches of 2 x CUs chains each (below) when that pays off
     // (measured at k = 50, n = 10k: 1024 chains 63.8 us per step instead of 71.6 with four chains per workgroup; at 2048
     //  chains the general kernel with eight chains per workgroup is level, 123 vs 128, and keeps the sweep)
-    else if (cw == 4 && wide_sharded_pays(m, kn, run, ram_bounded, ncu, (long long)ncu)) cw = 2;
+    else if (cw == 4 && wide_sharded_pays(K, m, kn, run, ram_bounded, ncu, (long long)ncu)) cw = 2;
   }
   int tb = 32;
   while (tb > 1 && sweep_lds_bytes(kn->k, kf, kn->kind, cw, tb, A.kz, resident) > 60 * 1024) tb >>= 1;
@@ -425,25 +450,23 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
     default: LAUNCH(CWV, PV, OV, 4); break;                                                          \
   }
   // software-pipelined fast path: normal kernels, joint scheme, k <= 16, linreg data in registers
-  const char* nopipe = getenv("FMCMC_AMD_NO_PIPE");
-  const char* nospec0 = getenv("FMCMC_AMD_NO_SPEC");
+  const bool nopipe = K.pipe == 0, nospec = K.spec == 0;
   int pipe_opt = 0, mfma_ng = 0;
-  if (!(force && force[0] == '1') && !(nopipe && nopipe[0] == '1') && m->family == FMCMC_FAM_GAUSSIAN_LINREG &&
+  if (!force && !nopipe && m->family == FMCMC_FAM_GAUSSIAN_LINREG &&
       (kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE ||
-       (((kn->kind == FMCMC_KERNEL_ADAPT && !adapt_hist) || (kn->kind == FMCMC_KERNEL_RAM && !ram_bounded && !kn->constr)) && !(nospec0 && nospec0[0] == '1'))) &&
+       (((kn->kind == FMCMC_KERNEL_ADAPT && !adapt_hist) || (kn->kind == FMCMC_KERNEL_RAM && !ram_bounded && !kn->constr)) && !nospec)) &&
       (kn->scheme == FMCMC_SCHEME_JOINT || kn->kind >= FMCMC_KERNEL_ADAPT) && kn->k <= PIPE_KMAX &&
       (unsigned long long)run->nchains * kn->k * (unsigned long long)A.ldS * 8ull < (1ull << 32) &&
       (unsigned long long)run->nchains * (unsigned long long)run->nsteps * (unsigned long long)A.kz * 8ull < (1ull << 32)) {
     if (m->p == 3 && m->n > (long long)NT * 19 && m->n <= (long long)NT * 20) pipe_opt = 20;
     if (m->p == 1 && m->n > (long long)NT * 1 && m->n <= (long long)NT * 2) pipe_opt = 2;
     // fp64-MFMA evaluation: general in n and p up to what 80 operand registers per lane hold (normal / uniform kernels)
-    const char* usemf0 = getenv("FMCMC_AMD_MFMA");
-    if (!(usemf0 && usemf0[0] == '0') && kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE && kn->scheme == FMCMC_SCHEME_JOINT) {
+    if (K.mfma != 0 && kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE && kn->scheme == FMCMC_SCHEME_JOINT) {
       if (m->p <= 3 && m->n <= (long long)NT * 20) mfma_ng = 1;
       else if (m->p <= 7 && m->n <= (long long)NT * 10) mfma_ng = 2;
       // (the wave-specialised VALU kernel, which overlaps owners and evaluation, used to win at its small shape
       //  (p = 1, n ~ 1000); since the instruction diet of the owner phase the MFMA kernel is 1.2-1.35x ahead there too:
-      //  tools/bench_small.py.  FMCMC_AMD_MFMA=0 still selects it.)
+      //  tools/bench_small.py.  Knob mfma=0 still selects it.)
     }
   }
   if (pipe_opt || mfma_ng) {
@@ -472,18 +495,16 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
       if (e == hipSuccess)                                                                             \
         hipLaunchKernelGGL((mh_sweep_pipe<PV, OV, KV>), dim3((unsigned)pblk), dim3(NT), plds, stream, A); \
     } while (0)
-    const char* nospec = getenv("FMCMC_AMD_NO_SPEC");
-    g_kernel = mfma_ng ? "mfma" : (!(nospec && nospec[0] == '1')) ? "spec" : "pipe";
+    g_kernel = mfma_ng ? "mfma" : !nospec ? "spec" : "pipe";
     if (mfma_ng) {
       // Two MFMA kernels with identical results.  mh_sweep_mfma (owner waves) is the product path for every shape;
       // mh_sweep_mfmar (chain state replicated in every wave, one barrier per step) was 2-10 % ahead below n = 8192
       // until the owner phase of mh_sweep_mfma went through the same instruction diet, and is 1-7 % behind since
       // (tools/bench_shapes_ab.py).  It stays compiled in for n > 8192, p <= 3, non-reflective kernels as the A/B
-      // partner (FMCMC_AMD_MFMA_OWNERS=0, tools/exp_mfmar.hip) and as a second implementation the parity tests compare.
+      // partner (knob owners=0, tools/exp_mfmar.hip) and as a second implementation the parity tests compare.
       const int ns = (int)((m->n + NT - 1) / NT);   // observation slots of 512
       const int kv = (kn->kind == FMCMC_KERNEL_NORMAL) ? 1 : 2;
-      const char* own0 = getenv("FMCMC_AMD_MFMA_OWNERS");
-      const bool owners = !(own0 && own0[0] == '0' && kv == 1 && mfma_ng == 1 && ns > 16);
+      const bool owners = !(K.owners == 0 && kv == 1 && mfma_ng == 1 && ns > 16);
       const size_t mlds = owners ? mfma_lds_bytes() : mfmar_lds_bytes();
       if (!owners) g_kernel = "mfma-replicated";
       const bool dbgk = (A.debug & 8) != 0 && mfma_ng == 1 && ns == 20;
@@ -514,7 +535,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
 #undef MF_CASES10
 #undef MF_CASE
     } else
-    if (!(nospec && nospec[0] == '1')) {
+    if (!nospec) {
       const size_t slds = spec_lds_bytes(pipe_opt, kn->kind >= FMCMC_KERNEL_ADAPT);
 #define LAUNCH_SPEC(PV, OV, KV)                                                                        \
       do {                                                                                             \
@@ -591,7 +612,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
     //  up to 512 chains run as one launch of 256 workgroups, exactly 128 workgroups keep 4 lanes each when n allows)
     const long long nb_launch = (nblk == 128 && 4 * nslots <= SH_MAXO) ? 128 : 256;
     const long long ch_launch = (nblk > nb_launch) ? nb_launch * cw : (long long)run->nchains;
-    const int lpw = wide_sharded_lanes(m, kn, run, ram_bounded, ncu, nb_launch);
+    const int lpw = wide_sharded_lanes(K, m, kn, run, ram_bounded, ncu, nb_launch);
     bool shard = lpw > 0;
     // the sharded evaluation is its own instantiation (OPT = lanes per workgroup): sharing one with the streamed loop
     // cost 200-300 spilled registers in BOTH paths
@@ -608,18 +629,17 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
     // the slice product on the matrix cores (shard_columns_mfma): the slice lives in LDS behind the chain blocks
     const int mf_spg = shard ? (nslots + 4 / lpw - 1) / (4 / lpw) : 0, nmt = (mf_spg + 3) / 4;
     const int mblk = SHM_HDR + nmt * ((m->p + 3) / 4) * 64;
-    bool mfma_form = shard && shard_mfma_enabled() && m->p <= 4 * SHM_KBMAX && mf_spg <= SHM_T &&
+    bool mfma_form = shard && shard_mfma_enabled(K) && m->p <= 4 * SHM_KBMAX && mf_spg <= SHM_T &&
                      lds + sizeof(double) * (size_t)(mblk + 1) <= 160 * 1024;
     if (mfma_form) lds += sizeof(double) * (size_t)(mblk + 1);
     if (shard) g_kernel = mfma_form ? "streamed-wide-sharded-mfma" : "streamed-wide-sharded";
     // the dataflow form (mh_wide2.hpp): owner and evaluator waves decoupled, two chain groups half a step out of phase.
     // It pays where the owners have real work to hide -- kernel_ram: 35.8 -> 27.9 us per step at C4 -- and costs the normal
     // kernels 6 % (26.2 against 24.6: their owner phase is short and two of eight waves no longer evaluate).
-    // FMCMC_AMD_WIDE2=0 keeps the sequential form everywhere, =1 takes the dataflow form for every eligible call (tests).
+    // Knob wide2=0 keeps the sequential form everywhere, wide2=1 takes the dataflow form for every eligible call (tests).
     bool wide2 = false;
     {
-      const char* w2env = getenv("FMCMC_AMD_WIDE2");
-      const bool w2on = (w2env && w2env[0] == '1') || (!(w2env && w2env[0] == '0') && kn->kind == FMCMC_KERNEL_RAM);
+      const bool w2on = K.wide2 == 1 || (K.wide2 != 0 && kn->kind == FMCMC_KERNEL_RAM);
       wide2 = shard && mfma_form && w2on && lpw == 2 && cw == 2 && nb_launch == 256 && ncu == 256 &&
               !(kn->kind == FMCMC_KERNEL_RAM && kn->constr) && (kn->kind == FMCMC_KERNEL_RAM || kn->scheme == FMCMC_SCHEME_JOINT) &&
               nmt >= 1 && nmt <= 3 && run->nsteps < 100000000 &&
@@ -897,7 +917,7 @@ int fmcmc_mcmc_run_host(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcm
         case FMCMC_CHAIN_NAN_RATIO: what = "fun(par) is undefined (f1 - f0 is NaN)."; break;
         case FMCMC_CHAIN_NOT_PD: what = "'Sigma' is not positive definite."; break;
         case FMCMC_CHAIN_BAD_WINDOW: what = "subscript out of bounds: the rows kernel_adapt(bw / freq) adapts on reach before the first row of this call."; break;
-        case FMCMC_CHAIN_SYNC_TIMEOUT: what = "a grid-wide hand-over of the observation-sharded evaluation timed out; the results of this call are invalid (FMCMC_AMD_SHARD=0 selects the chain-sharded kernel)."; break;
+        case FMCMC_CHAIN_SYNC_TIMEOUT: what = "a grid-wide hand-over of the observation-sharded evaluation timed out; the results of this call are invalid (FMCMC_AMD_DEBUG=shard=0 selects the chain-sharded kernel)."; break;
         default: break;
       }
       set_err("%s (chain %lld, status %d). Check either -fun- or the -lb- and -ub- "

@@ -18,7 +18,7 @@ namespace {
 //   dependency stalls are filled by the two compute waves' independent FMAs (hardware multithreading instead
 //   of compiler interleaving).  Register budget: 12 waves -> 168 VGPRs; one chain per evaluation pass keeps the
 //   compute role at 120 (data) + ~30: 148 VGPRs, no scratch.
-//   FMCMC_AMD_DEBUG_MODE=8 stamps (s_memtime) flag-wait / work time per wave into the draws buffer.
+//   FMCMC_AMD_DEBUG=mode=8 stamps (s_memtime) flag-wait / work time per wave into the draws buffer.
 // ==============================================================================================
 constexpr int SPEC_NT = 768;
 constexpr int SPEC_NCW = 8;   // compute wavefronts

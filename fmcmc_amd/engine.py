@@ -258,7 +258,7 @@ def raise_on_chain_error(out, chain_base=0):
         if (st == abi.CHAIN_SYNC_TIMEOUT).any():
             raise RuntimeError("fmcmc_amd: a grid-wide hand-over of the observation-sharded evaluation timed out (a device "
                                "fault, or the workgroups of the sweep were not co-resident); the results of this call are "
-                               "invalid. FMCMC_AMD_SHARD=0 selects the chain-sharded kernel.")
+                               "invalid. FMCMC_AMD_DEBUG=shard=0 selects the chain-sharded kernel.")
         c = int(bad[0])
         step = int(out.status_step[c].item())
         theta = out.status_theta[c].cpu().numpy()

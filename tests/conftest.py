@@ -36,3 +36,10 @@ def synth_linreg(n, p, seed, beta=None, sigma=4.0):
         beta = np.array([3.0, 2.0, -1.0, 0.5, 0.25, -0.75, 1.5, -2.0])[: p + 1]
     y = beta[0] + X @ beta[1:] + sigma * rng.standard_normal(n)
     return X, y
+
+
+def set_knob(monkeypatch, key, value):
+    """One diagnosis knob of the engine: merges `key=value` into FMCMC_AMD_DEBUG (the only variable the library reads)."""
+    cur = dict(kv.split("=", 1) for kv in os.environ.get("FMCMC_AMD_DEBUG", "").split(",") if "=" in kv)
+    cur[key] = str(value)
+    monkeypatch.setenv("FMCMC_AMD_DEBUG", ",".join("%s=%s" % kv for kv in cur.items()))

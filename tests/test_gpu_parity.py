@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import synth_linreg
+from conftest import synth_linreg, set_knob
 
 pytestmark = pytest.mark.gpu
 
@@ -242,7 +242,7 @@ def test_streamed_equals_resident(E, O, monkeypatch):
     X, y = synth_linreg(10000, 3, 20260102)
     init = jitter_init([0, 0, 0, 0, float(np.std(y))], 6, 14)
     a, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=100, scale=0.02)
-    monkeypatch.setenv("FMCMC_AMD_FORCE_STREAMED", "1")
+    set_knob(monkeypatch, "streamed", "1")
     b, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=100, scale=0.02)
     assert _bits_equal(a.samples.cpu().numpy(), b.samples.cpu().numpy())
 
@@ -271,9 +271,9 @@ def test_mfma_equals_valu_kernels(E, O, monkeypatch):
     X, y = synth_linreg(10000, 3, 20260102)
     init = jitter_init([0, 0, 0, 0, float(np.std(y))], 6, 23)
     a, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=80, scale=0.02)
-    monkeypatch.setenv("FMCMC_AMD_MFMA", "0")
+    set_knob(monkeypatch, "mfma", "0")
     b, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=80, scale=0.02)
-    monkeypatch.setenv("FMCMC_AMD_NO_SPEC", "1")
+    set_knob(monkeypatch, "spec", "0")
     c, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=80, scale=0.02)
     assert _bits_equal(a.samples.cpu().numpy(), b.samples.cpu().numpy())
     assert _bits_equal(a.samples.cpu().numpy(), c.samples.cpu().numpy())
@@ -292,7 +292,7 @@ def test_mfma_replicated_equals_owner_kernel(E, O, monkeypatch, n):
     bad[:, -1] = 0.03                                     # sigma steps below zero within a few proposals of scale 1
     out = {}
     for force in ("1", "0"):
-        monkeypatch.setenv("FMCMC_AMD_MFMA_OWNERS", force)
+        set_knob(monkeypatch, "owners", force)
         a, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=150, burnin=11, thin=4, calls=2, scale=0.02)
         b, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=90, scale=0.03, fixed=[False, False, True, False, False])
         c, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_UNIF, 5, init, nsteps=90, min_=-0.03, max_=0.04)
@@ -478,7 +478,7 @@ def test_logistic_specialised_loops(E, O, monkeypatch, cw, p, intercept):
     """Every compile-time-p loop body of the logistic instantiations (p <= 28 / CW - 1 coefficients in SGPRs, beyond
     that the run-time loop), for 1, 2 and 4 chains per workgroup, normal and reflective kernels, ragged n, a chain count
     that is not a multiple of CW, plus large |eta| (both softplus tails)."""
-    monkeypatch.setenv("FMCMC_AMD_CW", cw)
+    set_knob(monkeypatch, "cw", cw)
     rng = np.random.default_rng(100 + 10 * p + int(cw))
     n = 1500 + 37 * p
     X = rng.standard_normal((n, p)) * (3.0 if p == 5 else 1.0)        # p = 5: |eta| up to ~40
@@ -499,7 +499,7 @@ def test_logistic_specialised_loops(E, O, monkeypatch, cw, p, intercept):
 def test_wide_linreg_instantiations(E, O, monkeypatch, cw, n, p):
     """Wide linear models (p >= 16) run one-family / one-kernel instantiations with two observations per thread: odd
     observation counts (padded second slot), column remainders (p % 8), normal / reflective / RAM kernels."""
-    monkeypatch.setenv("FMCMC_AMD_CW", cw)
+    set_knob(monkeypatch, "cw", cw)
     X, y = synth_linreg(n, p, 7000 + n + p, beta=np.linspace(1.0, -1.0, p + 1))
     C = 2 * int(cw) + 1
     init = jitter_init(list(np.linspace(1.0, -1.0, p + 1)) + [4.0], C, n + p)
@@ -531,13 +531,13 @@ def test_adaptive_owner_variants(E, O, kind_name, n, p, intercept, fixed):
 
 def test_small_shape_mfma_equals_wave_specialised_kernel(E, O, monkeypatch):
     """README-size data (p = 1, n ~ 1000): the MFMA kernel (default) and the wave-specialised VALU kernel it replaced there
-    (FMCMC_AMD_MFMA=0) give the oracle's bits, normal and reflective kernels."""
+    (knob mfma=0) give the oracle's bits, normal and reflective kernels."""
     X, y = synth_linreg(1000, 1, 4242)
     init = jitter_init([0.0, 0.0, float(np.std(y))], 7, 77)
     init[:, -1] = np.abs(init[:, -1])
     out = []
     for mf in ("1", "0"):
-        monkeypatch.setenv("FMCMC_AMD_MFMA", mf)
+        set_knob(monkeypatch, "mfma", mf)
         a, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 3, init, nsteps=200, burnin=10, thin=3, calls=2, scale=0.05)
         b, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL_REFLECTIVE, 3, init, nsteps=150, scale=0.5, lb=[-4, -4, 0.5], ub=[6, 6, 8.0])
         out.append((a.samples.cpu().numpy(), b.samples.cpu().numpy()))
@@ -567,8 +567,8 @@ SHARDED = ("streamed-wide-sharded-mfma", "wide-dataflow")     # the sequential a
 
 @pytest.fixture(params=["dataflow", "sequential"])
 def wide_form(request, monkeypatch):
-    """Both forms of the observation-sharded sweep (mh_wide2.hpp / eval_sharded): FMCMC_AMD_WIDE2=0 keeps the sequential one."""
-    monkeypatch.setenv("FMCMC_AMD_WIDE2", "1" if request.param == "dataflow" else "0")
+    """Both forms of the observation-sharded sweep (mh_wide2.hpp / eval_sharded): knob wide2=0 keeps the sequential one."""
+    set_knob(monkeypatch, "wide2", "1" if request.param == "dataflow" else "0")
     return request.param
 
 
@@ -584,11 +584,11 @@ def wide_form(request, monkeypatch):
 def test_observation_sharded_evaluation(E, O, monkeypatch, wide_form, chains, cw, n, p, intercept):
     """Wide linear models whose workgroups split the 512 canonical lanes evenly evaluate observation-sharded
     (eval_sharded, cooperative launch, two grid barriers per step): the oracle's bits for the normal, reflective and RAM
-    kernels, continued over two calls, and the same bits as the chain-sharded kernel (FMCMC_AMD_SHARD=0)."""
+    kernels, continued over two calls, and the same bits as the chain-sharded kernel (knob shard=0)."""
     import torch
     from fmcmc_amd import _abi as abi
-    monkeypatch.setenv("FMCMC_AMD_CW", cw)
-    monkeypatch.setenv("FMCMC_AMD_SHARD", "1")      # every eligible shape, also where the cost model prefers chain-sharded
+    set_knob(monkeypatch, "cw", cw)
+    set_knob(monkeypatch, "shard", "1")      # every eligible shape, also where the cost model prefers chain-sharded
     nb = p + (1 if intercept else 0)
     # co-residency needs one CU per workgroup of the launch (256, or exactly 128): a partitioned GPU falls back
     full = torch.cuda.get_device_properties(0).multi_processor_count >= 256
@@ -604,7 +604,7 @@ def test_observation_sharded_evaluation(E, O, monkeypatch, wide_form, chains, cw
     assert abi.last_kernel() == sharded
     a, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, nb + 1, init, nsteps=24, calls=2, **kw)
     assert abi.last_kernel() == sharded
-    monkeypatch.setenv("FMCMC_AMD_SHARD", "0")
+    set_knob(monkeypatch, "shard", "0")
     b, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, nb + 1, init, nsteps=24, calls=2, **kw)
     assert abi.last_kernel() == "streamed-wide"
     assert _bits_equal(a.samples.cpu().numpy(), b.samples.cpu().numpy())
@@ -623,7 +623,7 @@ def test_observation_sharded_long_run_equals_chain_sharded(E, monkeypatch, wide_
     gm = E.DeviceModel(abi.FAM_GAUSSIAN_LINREG, X, y)
     outs = []
     for sh in ("1", "0"):
-        monkeypatch.setenv("FMCMC_AMD_SHARD", sh)
+        set_knob(monkeypatch, "shard", sh)
         gk = E.KernelSpec(abi.KERNEL_RAM, k, np.zeros(k), np.ones(k), np.full(k, -E.DBL_MAX), np.full(k, E.DBL_MAX),
                           np.zeros(k, np.uint8))
         st = E.ChainState(init, k)
@@ -734,7 +734,7 @@ def test_randomised_sharded_shapes(E, O, monkeypatch):
     must actually have run sharded."""
     import torch
     from fmcmc_amd import _abi as abi
-    monkeypatch.setenv("FMCMC_AMD_SHARD", "1")      # every eligible shape, also where the cost model prefers chain-sharded
+    set_knob(monkeypatch, "shard", "1")      # every eligible shape, also where the cost model prefers chain-sharded
     picked = []
     for case in range(18):
         rng = np.random.default_rng(4200 + case)
@@ -774,7 +774,7 @@ def test_sharded_evaluation_with_failing_chains(E, O, monkeypatch):
     status, step and theta of the failure), for kernel_normal and kernel_ram."""
     import torch
     from fmcmc_amd import _abi as abi
-    monkeypatch.setenv("FMCMC_AMD_SHARD", "1")
+    set_knob(monkeypatch, "shard", "1")
     n, p, chains = 3000, 20, 256
     rng = np.random.default_rng(77)
     beta = rng.uniform(-1.0, 1.0, p + 1)
@@ -841,7 +841,7 @@ def test_full_size_headline_properties(E, monkeypatch):
     rate = float(full.accept_count.double().mean().item()) / (iters - 1)
     assert 0.45 < rate < 0.65                                                  # the config's frozen scale: ~0.56
     # (d) a second implementation of the same sweep
-    monkeypatch.setenv("FMCMC_AMD_MFMA", "0")
+    set_knob(monkeypatch, "mfma", "0")
     other, _ = launch(0, chains)
     assert abi.last_kernel() == "spec"
     for name in ("samples", "logpost", "draws", "accept_count", "accept_bits"):
@@ -988,7 +988,7 @@ def test_sharded_evaluation_in_consecutive_launches(E, O, monkeypatch, kind_name
     chains, continued over two calls, and the bits of the chain-sharded kernel."""
     import torch
     from fmcmc_amd import _abi as abi
-    monkeypatch.setenv("FMCMC_AMD_SHARD", "1")
+    set_knob(monkeypatch, "shard", "1")
     n, p, chains = 1500, 18, 1024
     rng = np.random.default_rng(31)
     beta = rng.uniform(-1.0, 1.0, p + 1)
@@ -1001,7 +1001,7 @@ def test_sharded_evaluation_in_consecutive_launches(E, O, monkeypatch, kind_name
     a, _ = run_both(E, O, O.FAM_LINREG, X, y, kind, p + 2, init, nsteps=16, burnin=1, thin=2, calls=2, chain_base=40, **opts)
     if torch.cuda.get_device_properties(0).multi_processor_count >= 256:
         assert abi.last_kernel() in SHARDED
-    monkeypatch.setenv("FMCMC_AMD_SHARD", "0")
+    set_knob(monkeypatch, "shard", "0")
     b, _ = run_both(E, O, O.FAM_LINREG, X, y, kind, p + 2, init, nsteps=16, burnin=1, thin=2, calls=2, chain_base=40, **opts)
     assert abi.last_kernel() in ("streamed-wide", "streamed")
     assert _bits_equal(a.samples.cpu().numpy(), b.samples.cpu().numpy())

@@ -1,4 +1,4 @@
-"""Streamed kernel, chains per workgroup (FMCMC_AMD_CW): L2 traffic per evaluation vs CUs kept busy."""
+"""Streamed kernel, chains per workgroup (FMCMC_AMD_DEBUG=cw=N): L2 traffic per evaluation vs CUs kept busy."""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,7 +13,7 @@ for k, kind in ((30, 4), (50, 1), (50, 4), (30, 1)):
     z, o = np.zeros(k), np.ones(k)
     gk = E.KernelSpec(kind, k, z, o * 0.002, -big * o, big * o, np.zeros(k, np.uint8))
     for cw in ("1", "2", "4", "8"):
-        os.environ["FMCMC_AMD_CW"] = cw
+        os.environ["FMCMC_AMD_DEBUG"] = "cw=" + cw
         best = 1e9
         try:
             for _ in range(2):

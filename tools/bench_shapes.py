@@ -1,5 +1,5 @@
 """Throughput of Gaussian linreg shapes around the headline one: MFMA evaluation (default) vs the paths the same shapes
-took before the MFMA kernel was made general in n and p (FMCMC_AMD_MFMA=0)."""
+took before the MFMA kernel was made general in n and p (FMCMC_AMD_DEBUG=mfma=0)."""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,7 +14,7 @@ for n, p in [(10000, 3), (8000, 3), (5000, 3), (2000, 3), (600, 3), (10000, 1), 
     gk = E.KernelSpec(abi.KERNEL_NORMAL, k, np.zeros(k), np.full(k, .02), np.full(k, -E.DBL_MAX), np.full(k, E.DBL_MAX), np.zeros(k, np.uint8))
     res = {}
     for mode in ("1", "0"):
-        os.environ["FMCMC_AMD_MFMA"] = mode
+        os.environ["FMCMC_AMD_DEBUG"] = "mfma=" + mode
         best = 0.0
         for rep in range(3):
             st = E.ChainState(init, k)

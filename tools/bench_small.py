@@ -14,7 +14,7 @@ for n, p in [(1000, 1), (600, 1), (1024, 1), (900, 1)]:
         gk = E.KernelSpec(kind, k, np.zeros(k), np.full(k, .05), lb, ub, np.zeros(k, np.uint8))
         res = {}
         for mode in ("0", "1"):
-            os.environ["FMCMC_AMD_NO_SPEC"] = mode
+            os.environ["FMCMC_AMD_DEBUG"] = "spec=" + ("0" if mode == "1" else "1")
             best = 0.0
             for rep in range(3):
                 st = E.ChainState(init, k)

@@ -1,6 +1,6 @@
-"""Diagnostic: per-wave cycle shares of mh_sweep_mfma (FMCMC_AMD_MFMA=1, FMCMC_AMD_DEBUG_MODE=8)."""
+"""Diagnostic: per-wave cycle shares of mh_sweep_mfma (FMCMC_AMD_DEBUG=mode=8,mfma=1)."""
 import os, sys
-os.environ["FMCMC_AMD_DEBUG_MODE"] = "8"; os.environ["FMCMC_AMD_MFMA"] = "1"
+os.environ["FMCMC_AMD_DEBUG"] = "mode=8,mfma=1"
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from fmcmc_amd import engine as E, _abi as abi

@@ -1,6 +1,6 @@
 """Diagnostic: per-wave cycle shares of mh_sweep_spec for kernel_adapt (KIND=3) or kernel_ram (KIND=4)."""
 import os, sys
-os.environ["FMCMC_AMD_DEBUG_MODE"] = "8"
+os.environ["FMCMC_AMD_DEBUG"] = "mode=8"
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from fmcmc_amd import engine as E, _abi as abi
@@ -14,7 +14,7 @@ gk = E.KernelSpec(KIND, 5, np.zeros(5), np.full(5, .02), np.full(5, -E.DBL_MAX),
 st = E.ChainState(init, 5)
 r = E.sweep(gm, gk, st, nsteps, want_draws=True, check=False)
 torch.cuda.synchronize()
-NWV = 8 if os.environ.get("FMCMC_AMD_NO_SPEC") == "1" else 12
+NWV = 8 if "spec=0" in os.environ.get("FMCMC_AMD_DEBUG", "") else 12
 d = r.draws.reshape(-1)[: (C // 4) * NWV * 4].cpu().numpy().reshape(C // 4, NWV, 4)
 per = d[:, :, :3] / d[:, :, 3:4]
 print("cycles per MH step (s_memtime ticks), median over workgroups")
