@@ -10,6 +10,7 @@ _dp = C.POINTER(C.c_double)
 
 FAM_GAUSSIAN_LINREG, FAM_LOGISTIC, FAM_IID_NORMAL = 1, 2, 3
 KERNEL_NORMAL, KERNEL_NORMAL_REFLECTIVE, KERNEL_ADAPT, KERNEL_RAM, KERNEL_UNIF, KERNEL_UNIF_REFLECTIVE = 1, 2, 3, 4, 5, 6
+RAM_QFUN_T_K, RAM_QFUN_NORMAL, RAM_QFUN_T_DF = 0, 1, 2   # fmcmc_kernel.ram_qfun
 KERNEL_NMIRROR, KERNEL_UMIRROR = 7, 8
 MIRROR_KERNELS = (KERNEL_NMIRROR, KERNEL_UMIRROR)
 SIMPLE_KERNELS = (KERNEL_NORMAL, KERNEL_NORMAL_REFLECTIVE, KERNEL_UNIF, KERNEL_UNIF_REFLECTIVE) + MIRROR_KERNELS
@@ -39,7 +40,8 @@ class Kernel(C.Structure):
                 ("eps", C.c_double), ("arate", C.c_double), ("Sd", C.c_double),
                 ("scheme_seq", C.c_void_p), ("scheme_len", C.c_int32), ("nadapt", C.c_int32),
                 ("constr", C.c_void_p), ("h_fixed", C.c_void_p), ("h_lb", C.c_void_p), ("h_ub", C.c_void_p),
-                ("h_scale", C.c_void_p), ("h_scheme_seq", C.c_void_p)]
+                ("h_scale", C.c_void_p), ("h_scheme_seq", C.c_void_p),
+                ("ram_qfun", C.c_int32), ("reserved", C.c_int32), ("ram_df", C.c_double), ("ram_eta_exp", C.c_double)]
 
 
 class Run(C.Structure):

@@ -42,6 +42,8 @@ struct SweepArgs {
   double Sd;                 // adapt, bw > 0
   double* hist;              // [C][hist_rows][kf] ring of the last rows of ans[, which.] (row r in slot r % hist_rows)
   double until, eps, arate;
+  double ram_df;             // ram: degrees of freedom of the Student-t variates (qfun), 0 = standard normal variates
+  double ram_neg_exp;        // ram: eta(i, k) = min(1, k * exp(ram_neg_exp * log(i))), default -2/3
   const double* mu;
   const double* scale;
   const double* lb;

@@ -204,6 +204,20 @@ int fmcmc_validate(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_run
     return FMCMC_ERR_ARG;
   }
   const bool simple = is_simple_kind(kn->kind);
+  if (kn->kind == FMCMC_KERNEL_RAM) {
+    if (kn->ram_qfun < FMCMC_RAM_QFUN_T_K || kn->ram_qfun > FMCMC_RAM_QFUN_T_DF) {
+      set_err("kernel_ram: unknown -qfun- family %d (0 = rt(k, k), 1 = rnorm(k), 2 = rt(k, df)).", kn->ram_qfun);
+      return FMCMC_ERR_ARG;
+    }
+    if (kn->ram_qfun == FMCMC_RAM_QFUN_T_DF && !(kn->ram_df > 0.0 && kn->ram_df <= DBL_MAX)) {
+      set_err("kernel_ram: -qfun- = rt(k, df) needs a finite df > 0.");
+      return FMCMC_ERR_ARG;
+    }
+    if (!(kn->ram_eta_exp >= 0.0 && kn->ram_eta_exp <= DBL_MAX)) {
+      set_err("kernel_ram: the exponent of -eta- must be finite and positive (0 selects the default 2/3).");
+      return FMCMC_ERR_ARG;
+    }
+  }
   if (simple && (kn->scheme < FMCMC_SCHEME_JOINT || kn->scheme > FMCMC_SCHEME_EXPLICIT)) {
     set_err("-scheme- update must be either an integer sequence, 'joint', 'ordered', or 'random'.");
     return FMCMC_ERR_ARG;
@@ -379,6 +393,9 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
   A.n = m->n; A.X = m->X; A.y = m->y; A.prior_div = m->prior_div;
   A.kind = kn->kind; A.k = kn->k; A.scheme = kn->scheme; A.warmup = kn->warmup;
   A.until = kn->until; A.eps = kn->eps; A.arate = kn->arate;
+  // kernel_ram's qfun / eta families (R/kernel_ram.R:67-68): df of the t variates (0 = normal) and the exponent of eta
+  A.ram_df = (kn->ram_qfun == FMCMC_RAM_QFUN_NORMAL) ? 0.0 : (kn->ram_qfun == FMCMC_RAM_QFUN_T_DF ? kn->ram_df : (double)kf);
+  A.ram_neg_exp = (kn->ram_eta_exp != 0.0) ? -kn->ram_eta_exp : (-2.0 / 3.0);
   A.mu = kn->mu; A.scale = kn->scale; A.lb = kn->lb; A.ub = kn->ub; A.fixed = kn->fixed;
   A.nchains = run->nchains; A.nsteps = run->nsteps; A.burnin = run->burnin; A.thin = run->thin;
   A.S = fmcmc_kept_rows(run->nsteps, run->burnin, run->thin);
@@ -482,7 +499,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
       hipLaunchKernelGGL(rng_fill_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream,
                          (unsigned long long)run->seed, (long long)run->step_base, (long long)run->chain_base,
                          (long long)run->nchains, (long long)run->nsteps, A.kz,
-                         (kn->kind == FMCMC_KERNEL_RAM) ? kf : (A.variate == 1 ? -1 : 0), ws, ws + items);
+                         (kn->kind == FMCMC_KERNEL_RAM) ? A.ram_df : (A.variate == 1 ? -1.0 : 0.0), ws, ws + items);
       A.fed_logu = ws;
       A.fed_z = ws + items;
       A.rng_mode = FMCMC_RNG_FED;
@@ -725,7 +742,7 @@ int fmcmc_rng_stream_dev(uint64_t seed, int64_t step_base, int64_t chain_base, i
   const size_t items = (size_t)nchains * (size_t)nsteps;
   hipLaunchKernelGGL(rng_fill_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream,
                      (unsigned long long)seed, (long long)step_base, (long long)chain_base, (long long)nchains,
-                     (long long)nsteps, (int)kz, (int)student_df, logu, z);
+                     (long long)nsteps, (int)kz, (double)student_df, logu, z);
   return hipGetLastError() == hipSuccess ? FMCMC_OK : FMCMC_ERR_DEVICE;
 }
 

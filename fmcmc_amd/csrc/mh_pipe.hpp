@@ -29,7 +29,7 @@ constexpr int PIPE_TRS = 66;  // row stride (doubles) of the transposed lane-par
 // to the observation data.  48 B per chain-step at k = 5: noise next to the 8 TB/s of HBM.
 __global__ __launch_bounds__(256) void rng_fill_kernel(unsigned long long seed, long long step_base,
                                                        long long chain_base, long long nchains,
-                                                       long long nsteps, int kz, int student_df,
+                                                       long long nsteps, int kz, double student_df,
                                                        double* __restrict__ logu, double* __restrict__ z) {
   const long long item = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (item >= nchains * nsteps) return;
@@ -42,8 +42,8 @@ __global__ __launch_bounds__(256) void rng_fill_kernel(unsigned long long seed, 
     return;
   }
   logu[item] = fmh_log_accept_u(seed, st, cg);
-  if (student_df > 0) {  // kernel_ram: qfun = rt(k, k)
-    for (int a = 0; a < kz; a++) z[item * kz + a] = fmh_student_t(seed, st, cg, (unsigned int)a, (double)student_df);
+  if (student_df > 0) {  // kernel_ram: qfun = rt(k, df)
+    for (int a = 0; a < kz; a++) z[item * kz + a] = fmh_student_t(seed, st, cg, (unsigned int)a, student_df);
     return;
   }
   if (student_df < 0) {  // uniform kernels: the unif_rand() behind runif (R/kernel_unif.R:74)

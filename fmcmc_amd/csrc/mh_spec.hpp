@@ -120,7 +120,7 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
           double a_n = fmh_exp(f1 - f0);
           if (fmh_isnan(a_n)) a_n = 0.0;
           else if (a_n > 1.0) a_n = 1.0;
-          double eta = (double)kf * fmh_exp((-2.0 / 3.0) * fmh_log((double)i));
+          double eta = (double)kf * fmh_exp(A.ram_neg_exp * fmh_log((double)i));
           if (eta > 1.0) eta = 1.0;
           // S <- S T in place (mh_common.hpp, ram_coef; twin of the oracle's ram_factor_update_canon)
           const double zl = (lane < kf) ? vz[lane] : 0.0;
@@ -390,7 +390,7 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
           double a_n = fmh_exp(f1 - f0);
           if (fmh_isnan(a_n)) a_n = 0.0;
           else if (a_n > 1.0) a_n = 1.0;
-          double eta = (double)kf * fmh_exp((-2.0 / 3.0) * fmh_log((double)i));
+          double eta = (double)kf * fmh_exp(A.ram_neg_exp * fmh_log((double)i));
           if (eta > 1.0) eta = 1.0;
           // S <- S T (mh_common.hpp, ram_coef): square root and divisions once per update, lane = column; then row `lane`
           // in registers, two fma per element, column values by v_readlane

@@ -367,7 +367,7 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
         s_lu[c * TB + t] = v;
       } else {
         if (A.rng_mode == FMCMC_RNG_FED) v = A.fed_z[(clc * A.nsteps + (ii - 1)) * kz + a];
-        else if (A.kind == FMCMC_KERNEL_RAM) v = fmh_student_t(A.seed, st, cg, (unsigned int)a, (double)kf);
+        else if (A.kind == FMCMC_KERNEL_RAM && A.ram_df > 0.0) v = fmh_student_t(A.seed, st, cg, (unsigned int)a, A.ram_df);
         else if (A.variate == 1) v = fmh_unif(A.seed, st, cg, (unsigned int)a);
         else v = fmh_normal(A.seed, st, cg, (unsigned int)a);
         s_zt[(c * TB + t) * kz + a] = v;
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
           double a_n = fmh_exp(f1u - f0);
           if (fmh_isnan(a_n)) a_n = 0.0;
           else if (a_n > 1.0) a_n = 1.0;
-          double eta = (double)kf * fmh_exp((-2.0 / 3.0) * fmh_log((double)i));
+          double eta = (double)kf * fmh_exp(A.ram_neg_exp * fmh_log((double)i));
           if (eta > 1.0) eta = 1.0;
           FMH_STAMP(stp, 11);
           const double zl = (lane < kf) ? zt[lane] : 0.0;

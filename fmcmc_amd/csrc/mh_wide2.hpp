@@ -218,7 +218,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
       v = (A.rng_mode == FMCMC_RNG_FED) ? A.fed_logu[cl * A.nsteps + (ii - 1)] : fmh_log_accept_u(A.seed, st, cgid);
     } else {
       if (A.rng_mode == FMCMC_RNG_FED) v = A.fed_z[(cl * A.nsteps + (ii - 1)) * kz + lane];
-      else if (KIND == FMCMC_KERNEL_RAM) v = fmh_student_t(A.seed, st, cgid, (unsigned int)lane, (double)kf);
+      else if (KIND == FMCMC_KERNEL_RAM && A.ram_df > 0.0) v = fmh_student_t(A.seed, st, cgid, (unsigned int)lane, A.ram_df);
       else if (A.variate == 1) v = fmh_unif(A.seed, st, cgid, (unsigned int)lane);
       else v = fmh_normal(A.seed, st, cgid, (unsigned int)lane);
     }
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
     pre_nt1 = dn * (fmh_log(sg) + FMH_LN_SQRT_2PI);
     pre_ss = sg * sg;
     if (KIND == FMCMC_KERNEL_RAM && i >= 2) {
-      double eta = (double)kf * fmh_exp((-2.0 / 3.0) * fmh_log((double)i));
+      double eta = (double)kf * fmh_exp(A.ram_neg_exp * fmh_log((double)i));
       if (eta > 1.0) eta = 1.0;
       pre_eta = eta;
       const double* zt = s_z + (g * 2 + (i & 1)) * (kz + 1);

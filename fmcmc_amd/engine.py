@@ -72,7 +72,7 @@ class KernelSpec:
 
     def __init__(self, kind, k, mu, scale, lb, ub, fixed, scheme=abi.SCHEME_JOINT, freq=1, warmup=0,
                  bw=0, until=float("inf"), eps=1e-4, arate=0.234, Sd=0.0, scheme_seq=None, constr=None, nadapt=4,
-                 device=None):
+                 ram_qfun=0, ram_df=0.0, ram_eta_exp=0.0, device=None):
         self.device = _dev(device)
         self.kind, self.k = int(kind), int(k)
         self.h_fixed = np.ascontiguousarray(np.asarray(fixed, dtype=np.uint8))
@@ -91,6 +91,8 @@ class KernelSpec:
         self.scheme, self.freq, self.warmup, self.bw = int(scheme), int(freq), int(warmup), int(bw)
         self.until, self.eps, self.arate, self.Sd = float(until), float(eps), float(arate), float(Sd)
         self.nadapt = int(nadapt)
+        # kernel_ram's built-in qfun / eta families (fmcmc_kernel.ram_*; zeros = the defaults of R/kernel_ram.R:67-68)
+        self.ram_qfun, self.ram_df, self.ram_eta_exp = int(ram_qfun), float(ram_df), float(ram_eta_exp)
         # explicit update sequence: 0-based parameter indices (R/kernel.R:69-92); ram: constr[which., which.] mask
         self.scheme_seq = None if scheme_seq is None else _t(np.asarray(scheme_seq, dtype=np.int32), torch.int32, self.device)
         self.constr = None if constr is None else _t(np.asarray(constr, dtype=np.float64).reshape(self.kf, self.kf),
@@ -109,7 +111,8 @@ class KernelSpec:
                           int(self.scheme_seq.numel()) if self.scheme_seq is not None else 0, self.nadapt,
                           self.constr.data_ptr() if self.constr is not None else None,
                           self.h_fixed.ctypes.data, self.h_lb.ctypes.data, self.h_ub.ctypes.data, self.h_scale.ctypes.data,
-                          self.h_seq.ctypes.data if self.h_seq is not None else None)
+                          self.h_seq.ctypes.data if self.h_seq is not None else None,
+                          self.ram_qfun, 0, self.ram_df, self.ram_eta_exp)
 
 
 class ChainState:

@@ -184,7 +184,8 @@ class fmcmc_kernel:
                           warmup=getattr(self, "warmup", 0), bw=getattr(self, "bw", 0), until=until,
                           eps=getattr(self, "eps", 1e-4), arate=getattr(self, "arate", 0.234),
                           Sd=getattr(self, "Sd", 0.0) or 0.0, scheme_seq=getattr(self, "_scheme_seq", None),
-                          constr=constr, nadapt=getattr(self, "nadapt", 4), device=device)
+                          constr=constr, nadapt=getattr(self, "nadapt", 4), ram_qfun=getattr(self, "ram_qfun", 0),
+                          ram_df=getattr(self, "ram_df", 0.0), ram_eta_exp=getattr(self, "ram_eta_exp", 0.0), device=device)
 
     def state_for(self, initial, device):
         """Chain state for this call: the kernel's persistent part survives, theta0 := initial."""
@@ -275,12 +276,53 @@ def kernel_adapt(mu=0.0, bw=0, lb=-DBL_MAX, ub=DBL_MAX, freq=1, warmup=500, Sigm
 kernel_am = kernel_adapt
 
 
+class eta_power:
+    """kernel_ram(eta = function(i, k) min(c(1.0, i^(-exponent) * k))): the family the default belongs to
+    (exponent = 2/3, R/kernel_ram.R:67); any exponent in (0, 1] keeps the adaptation diminishing (Vihola 2012)."""
+
+    def __init__(self, exponent=2.0 / 3.0):
+        if not (0.0 < float(exponent) < float("inf")):
+            raise ValueError("the exponent of -eta- must be finite and positive.")
+        self.exponent = float(exponent)
+
+    def __call__(self, i, k):
+        return min(1.0, float(i) ** (-self.exponent) * k)
+
+
+class qfun_t:
+    """kernel_ram(qfun = function(k) stats::rt(k, df)); df = None is the default rt(k, k) (R/kernel_ram.R:68)."""
+
+    def __init__(self, df=None):
+        if df is not None and not (0.0 < float(df) < float("inf")):
+            raise ValueError("-df- must be finite and positive.")
+        self.df = None if df is None else float(df)
+
+
+class qfun_normal:
+    """kernel_ram(qfun = function(k) stats::rnorm(k)): the Gaussian variates of Vihola (2012)."""
+
+
 def kernel_ram(mu=0.0, eta=None, qfun=None, arate=0.234, freq=1, warmup=0, Sigma=None, eps=1e-4,
                lb=-DBL_MAX, ub=DBL_MAX, fixed=False, until=float("inf"), constr=None):
-    if eta is not None or qfun is not None:
-        raise NotImplementedError("user-supplied eta/qfun are R closures; the device kernel implements the "
-                                  "defaults eta(i,k) = min(1, k i^(-2/3)) and qfun = rt(k, k) (R/kernel_ram.R:67-68).")
+    """R/kernel_ram.R:65-176.  eta / qfun are R closures there; closures cannot run inside the device loop, so the engine
+    offers the families they are used for: eta = eta_power(exponent), qfun = qfun_t(df) | qfun_normal() (None = the
+    reference's defaults).  Anything else raises."""
+    ram_qfun, ram_df, ram_eta_exp = abi.RAM_QFUN_T_K, 0.0, 0.0
+    if isinstance(qfun, qfun_normal) or qfun == "normal":
+        ram_qfun = abi.RAM_QFUN_NORMAL
+    elif isinstance(qfun, qfun_t):
+        if qfun.df is not None:
+            ram_qfun, ram_df = abi.RAM_QFUN_T_DF, qfun.df
+    elif qfun is not None:
+        raise NotImplementedError("-qfun- must be None (rt(k, k), R/kernel_ram.R:68), qfun_t(df) or qfun_normal(): an "
+                                  "arbitrary closure cannot run inside the device loop.")
+    if isinstance(eta, eta_power):
+        ram_eta_exp = eta.exponent
+    elif eta is not None:
+        raise NotImplementedError("-eta- must be None (min(1, k i^(-2/3)), R/kernel_ram.R:67) or eta_power(exponent): an "
+                                  "arbitrary closure cannot run inside the device loop.")
     if int(freq) < 1:
         raise ValueError("-freq- must be >= 1.")
     return fmcmc_kernel(abi.KERNEL_RAM, mu=mu, arate=arate, freq=int(freq), warmup=int(warmup), Sigma=Sigma,
-                        eps=eps, lb=lb, ub=ub, fixed=fixed, until=until, constr=constr)
+                        eps=eps, lb=lb, ub=ub, fixed=fixed, until=until, constr=constr, eta=eta, qfun=qfun,
+                        ram_qfun=ram_qfun, ram_df=ram_df, ram_eta_exp=ram_eta_exp)

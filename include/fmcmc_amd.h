@@ -90,6 +90,12 @@ enum {
   FMCMC_SCHEME_EXPLICIT = 3  /* one parameter per step, scheme_seq[(i-1) mod scheme_len] (:69-92) */
 };
 
+enum {
+  FMCMC_RAM_QFUN_T_K = 0,    /* stats::rt(k, k), the default (R/kernel_ram.R:68) */
+  FMCMC_RAM_QFUN_NORMAL = 1, /* stats::rnorm(k): the Gaussian proposal of Vihola (2012) */
+  FMCMC_RAM_QFUN_T_DF = 2    /* stats::rt(k, ram_df) */
+};
+
 typedef struct fmcmc_kernel {
   int32_t kind;         /* FMCMC_KERNEL_* */
   int32_t k;            /* number of parameters (length of theta) */
@@ -120,6 +126,12 @@ typedef struct fmcmc_kernel {
   const double* h_ub;
   const double* h_scale;
   const int32_t* h_scheme_seq;
+  /* ram: built-in alternatives to the defaults of R/kernel_ram.R:67-68 (user closures cannot cross a C boundary; these
+   * are the families the arguments are used for).  All zero = the defaults. */
+  int32_t ram_qfun;     /* FMCMC_RAM_QFUN_*: the variates U = qfun(k) of R/kernel_ram.R:124 */
+  int32_t reserved;
+  double ram_df;        /* FMCMC_RAM_QFUN_T_DF: degrees of freedom (> 0) */
+  double ram_eta_exp;   /* eta(i, k) = min(1, k * i^(-ram_eta_exp)); 0 = the default 2/3 (R/kernel_ram.R:67) */
 } fmcmc_kernel;
 
 /* ---- one call of MCMC_without_conv_checker over all chains ------------------------ */

@@ -677,7 +677,12 @@ static int propose_ram(const ocfg* cfg, const fmcmc_model* m, const fmcmc_kernel
                        double* theta1 /* in: previous theta1; out: new proposal */) {
   const int kf = ks->kf;
   double U[MAXK], v[MAXK];
-  for (int a = 0; a < kf; a++) U[a] = draw_t(cfg, step, chain, (uint32_t)a, (double)kf);
+  /* U <- qfun(k) (R/kernel_ram.R:124): the default rt(k, k) or one of the built-in families of fmcmc_kernel.ram_qfun */
+  const double df = (kn->ram_qfun == FMCMC_RAM_QFUN_T_DF) ? kn->ram_df : (double)kf;
+  const double eta_exp = (kn->ram_eta_exp != 0.0) ? kn->ram_eta_exp : (2.0 / 3.0);
+  for (int a = 0; a < kf; a++)
+    U[a] = (kn->ram_qfun == FMCMC_RAM_QFUN_NORMAL) ? draw_normal(cfg, step, chain, (uint32_t)a)
+                                                   : draw_t(cfg, step, chain, (uint32_t)a, df);
   if (cfg->math_mode == ORACLE_MATH_R) {
     for (int a = 0; a < kf; a++) {
       double s = 0.0;
@@ -702,7 +707,7 @@ static int propose_ram(const ocfg* cfg, const fmcmc_model* m, const fmcmc_kernel
       a_n = exp(f1u - f0); /* min(1, NaN) is NaN in R, then !is.finite -> 0 :132-134 */
       if (a_n > 1.0) a_n = 1.0;
       if (!isfinite(a_n)) a_n = 0.0;
-      eta = pow((double)i, -2.0 / 3.0) * (double)kf;
+      eta = pow((double)i, -eta_exp) * (double)kf; /* eta(env$i, k) :67 */
       if (eta > 1.0) eta = 1.0;
       /* Sigma %*% (Ik + eta*(a_n-arate)*UU^T/||U||^2) %*% t(Sigma); t(chol()) :136-146 */
       double nrm = 0.0;
@@ -734,7 +739,7 @@ static int propose_ram(const ocfg* cfg, const fmcmc_model* m, const fmcmc_kernel
       a_n = fmh_exp(f1u - f0);
       if (fmh_isnan(a_n)) a_n = 0.0;
       else if (a_n > 1.0) a_n = 1.0;
-      eta = (double)kf * fmh_exp((-2.0 / 3.0) * fmh_log((double)i));
+      eta = (double)kf * fmh_exp((-eta_exp) * fmh_log((double)i));
       if (eta > 1.0) eta = 1.0;
       double Pz[MAXK + 1];
       scan_sq_canon(U, kf, Pz);

@@ -42,7 +42,8 @@ class CKernel(C.Structure):
                 ("eps", C.c_double), ("arate", C.c_double), ("Sd", C.c_double),
                 ("scheme_seq", C.POINTER(C.c_int32)), ("scheme_len", C.c_int32), ("nadapt", C.c_int32),
                 ("constr", _dp), ("h_fixed", C.c_void_p), ("h_lb", C.c_void_p), ("h_ub", C.c_void_p),
-                ("h_scale", C.c_void_p), ("h_scheme_seq", C.c_void_p)]   # (v3 host mirrors: device entry only)
+                ("h_scale", C.c_void_p), ("h_scheme_seq", C.c_void_p),   # (v3 host mirrors: device entry only)
+                ("ram_qfun", C.c_int32), ("reserved", C.c_int32), ("ram_df", C.c_double), ("ram_eta_exp", C.c_double)]
 
 
 class CRun(C.Structure):
@@ -238,7 +239,7 @@ def _rec(x, k, name):
 class Kernel:
     def __init__(self, kind, k, mu=0.0, scale=1.0, lb=-DBL_MAX, ub=DBL_MAX, fixed=False,
                  scheme="joint", freq=1, warmup=None, bw=0, until=np.inf, eps=1e-4, arate=0.234,
-                 Sd=None, constr=None, min_=None, max_=None, nadapt=4):
+                 Sd=None, constr=None, min_=None, max_=None, nadapt=4, ram_qfun=0, ram_df=0.0, ram_eta_exp=0.0):
         self.kind, self.k = kind, k
         if kind in (K_UNIF, K_UNIF_REFLECTIVE):   # R/kernel_unif.R: runif(k, min., max.) = min. + (max. - min.) * u
             mn = _f64(_rec(-1.0 if min_ is None else min_, k, "min."))
@@ -270,6 +271,7 @@ class Kernel:
         else:
             self.scheme = {"joint": SCHEME_JOINT, "ordered": SCHEME_ORDERED, "random": SCHEME_RANDOM}[scheme]
         self.freq, self.bw, self.nadapt = int(freq), int(bw), int(nadapt)
+        self.ram_qfun, self.ram_df, self.ram_eta_exp = int(ram_qfun), float(ram_df), float(ram_eta_exp)
         if warmup is None:
             warmup = 500 if kind in (K_ADAPT, K_NMIRROR, K_UMIRROR) else 0
         if kind in (K_NMIRROR, K_UMIRROR) and arate == 0.234:
@@ -290,7 +292,8 @@ class Kernel:
                      self.warmup, self.bw, self.until, self.eps, self.arate, self.Sd,
                      self.scheme_seq.ctypes.data_as(C.POINTER(C.c_int32)) if self.scheme_seq is not None else None,
                      0 if self.scheme_seq is None else int(self.scheme_seq.size), self.nadapt,
-                     _p(self.constr) if self.constr is not None else None)
+                     _p(self.constr) if self.constr is not None else None, None, None, None, None, None,
+                     self.ram_qfun, 0, self.ram_df, self.ram_eta_exp)
         return kk
 
 

@@ -52,13 +52,31 @@ amd_available <- function() {
 
 # ---- which of fmcmc's kernels is this environment? ------------------------------------------------------------------
 # The closures carry no type tag; the set of variables they keep does (R/kernel_*.R).  A kernel whose `eta` / `qfun`
-# were replaced by the user (R/kernel_ram.R:67-68) is not supported: arbitrary closures cannot run inside a GPU kernel.
+# were replaced by arbitrary closures (R/kernel_ram.R:67-68) is not supported: they cannot run inside a GPU kernel.  The
+# families those arguments are used for are offered as TAGGED closures: ordinary R functions (the interpreted path runs
+# them unchanged) whose attributes tell the engine which built-in to use (fmcmc_kernel.ram_qfun / ram_df / ram_eta_exp).
+amd_eta_power   <- function(exponent = 2 / 3) {
+  stopifnot(is.finite(exponent), exponent > 0)
+  structure(function(i, k) min(c(1.0, i^(-exponent) * k)), class = c("fmcmc_amd_eta", "function"), exponent = exponent)
+}
+amd_qfun_t      <- function(df) {
+  stopifnot(is.finite(df), df > 0)
+  structure(function(k) stats::rt(k, df), class = c("fmcmc_amd_qfun", "function"), ram_qfun = 2L, df = df)
+}
+amd_qfun_normal <- function()
+  structure(function(k) stats::rnorm(k), class = c("fmcmc_amd_qfun", "function"), ram_qfun = 1L, df = 0)
+amd_ram_families <- function(k) {          # list(ram_qfun, ram_df, ram_eta_exp), or NULL when a closure is not one of ours
+  dflt <- formals(kernel_ram)
+  q <- if (inherits(k$qfun, "fmcmc_amd_qfun")) list(attr(k$qfun, "ram_qfun"), attr(k$qfun, "df"))
+       else if (isTRUE(all.equal(k$qfun, eval(dflt$qfun), check.environment = FALSE))) list(0L, 0) else return(NULL)
+  e <- if (inherits(k$eta, "fmcmc_amd_eta")) attr(k$eta, "exponent")
+       else if (isTRUE(all.equal(k$eta, eval(dflt$eta), check.environment = FALSE))) 0 else return(NULL)
+  list(ram_qfun = as.integer(q[[1L]]), ram_df = as.double(q[[2L]]), ram_eta_exp = as.double(e))
+}
 amd_kernel_kind <- function(k) {
   v <- ls(k, all.names = TRUE)
   if (all(c("eta", "qfun", "arate") %in% v)) {
-    dflt <- formals(kernel_ram)
-    if (!isTRUE(all.equal(k$eta, eval(dflt$eta), check.environment = FALSE)) ||
-        !isTRUE(all.equal(k$qfun, eval(dflt$qfun), check.environment = FALSE))) return(NA_integer_)
+    if (is.null(amd_ram_families(k))) return(NA_integer_)
     return(4L)
   }
   if (all(c("bw", "Sd", "Mean_t_prev") %in% v)) return(3L)
@@ -108,7 +126,9 @@ kernel_spec <- function(k1, k, nsteps) {
   }
   kf <- length(which.)
   constr <- if (kind == 4L && !is.null(k1$constr)) as.double(t(k1$constr[which., , drop = FALSE][, which., drop = FALSE])) else NULL
-  list(kind = kind, k = as.integer(k), mu = as.double(mu), scale = as.double(scale), lb = as.double(lb), ub = as.double(ub),
+  ram <- if (kind == 4L) amd_ram_families(k1) else list(ram_qfun = 0L, ram_df = 0, ram_eta_exp = 0)
+  list(kind = kind, k = as.integer(k), ram_qfun = ram$ram_qfun, ram_df = ram$ram_df, ram_eta_exp = ram$ram_eta_exp,
+       mu = as.double(mu), scale = as.double(scale), lb = as.double(lb), ub = as.double(ub),
        fixed = fixed, scheme = scheme, scheme_seq = scheme_seq,
        freq = as.integer(if (is.null(k1$freq)) 1L else k1$freq), warmup = as.integer(if (is.null(k1$warmup)) 0L else k1$warmup),
        bw = as.integer(if (is.null(k1$bw)) 0L else k1$bw), until = as.double(if (is.null(k1$until)) Inf else k1$until),

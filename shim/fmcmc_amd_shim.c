@@ -99,7 +99,8 @@ static void fill_model(SEXP model, fmcmc_model* m) {
 }
 
 /* kernel = list(kind, k, mu, scale, lb, ub, fixed (logical), scheme, freq, warmup, bw, until, eps, arate, Sd,
- *               scheme_seq (0-based integer) or NULL, nadapt, constr (kf x kf double, ROW-major = t() of R's) or NULL) */
+ *               scheme_seq (0-based integer) or NULL, nadapt, constr (kf x kf double, ROW-major = t() of R's) or NULL,
+ *               ram_qfun, ram_df, ram_eta_exp (optional)) */
 static void fill_kernel(SEXP kernel, fmcmc_kernel* k) {
   memset(k, 0, sizeof(*k));
   k->kind = el_int(kernel, "kind", 0);
@@ -131,6 +132,10 @@ static void fill_kernel(SEXP kernel, fmcmc_kernel* k) {
     k->scheme_len = (int32_t)XLENGTH(seq);
   }
   k->constr = el_real(kernel, "constr", (R_xlen_t)kf * kf, 0);
+  /* kernel_ram's qfun / eta families (amd_qfun_t / amd_qfun_normal / amd_eta_power of amd_hook.R); absent = defaults */
+  k->ram_qfun = el_int(kernel, "ram_qfun", FMCMC_RAM_QFUN_T_K);
+  k->ram_df = el_dbl(kernel, "ram_df", 0.0);
+  k->ram_eta_exp = el_dbl(kernel, "ram_eta_exp", 0.0);
   /* host entry point: the arrays above ARE host memory, the mirrors are not needed */
 }
 

@@ -87,6 +87,20 @@ def test_validate_accepts_a_good_call(abi):
     assert abi.lib().fmcmc_validate(C.byref(m), C.byref(kk), C.byref(r)) == abi.OK
 
 
+@pytest.mark.parametrize("ram,substr", [((3, 0.0, 0.0), "unknown -qfun- family"), ((2, 0.0, 0.0), "finite df > 0"),
+                                        ((2, float("inf"), 0.0), "finite df > 0"), ((0, 0.0, -1.0), "exponent of -eta-"),
+                                        ((0, 0.0, float("nan")), "exponent of -eta-")])
+def test_validate_ram_families(abi, ram, substr):
+    """fmcmc_kernel.ram_qfun / ram_df / ram_eta_exp (the built-in families behind kernel_ram's qfun and eta)."""
+    m, kk, r, keep = _host_specs(abi, kind=4, lb=[-1, -1, 0.0], ub=[1, 1, 5.0])
+    assert abi.lib().fmcmc_validate(C.byref(m), C.byref(kk), C.byref(r)) == abi.OK
+    kk.ram_qfun, kk.ram_df, kk.ram_eta_exp = ram
+    assert abi.lib().fmcmc_validate(C.byref(m), C.byref(kk), C.byref(r)) == abi.ERR_ARG
+    assert substr in abi.last_error()
+    kk.ram_qfun, kk.ram_df, kk.ram_eta_exp = 2, 2.5, 0.8
+    assert abi.lib().fmcmc_validate(C.byref(m), C.byref(kk), C.byref(r)) == abi.OK
+
+
 def numpy_gelman_partial(x, center=None):
     """Definition of the partial vector of include/fmcmc_amd.h in numpy (x: [m][N][p])."""
     m_, N, p = x.shape

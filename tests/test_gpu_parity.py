@@ -37,7 +37,8 @@ def run_both(E, O, fam, X, y, kind, k, initial, nsteps, burnin=0, thin=1, seed=1
     gm = E.DeviceModel(fam, X, y, intercept=intercept, guard=guard, prior_div=prior_div)
     gk = E.KernelSpec(kind, k, ok.mu, ok.scale, ok.lb, ok.ub, ok.fixed, scheme=ok.scheme, freq=ok.freq,
                       warmup=ok.warmup, bw=ok.bw, until=ok.until, eps=ok.eps, arate=ok.arate, Sd=ok.Sd,
-                      scheme_seq=ok.scheme_seq, constr=ok.constr, nadapt=ok.nadapt)
+                      scheme_seq=ok.scheme_seq, constr=ok.constr, nadapt=ok.nadapt, ram_qfun=ok.ram_qfun, ram_df=ok.ram_df,
+                      ram_eta_exp=ok.ram_eta_exp)
     initial = np.ascontiguousarray(initial, dtype=np.float64)
     ost = O.ChainState(initial, ok.kf)
     gst = E.ChainState(initial, ok.kf)
@@ -398,6 +399,18 @@ def test_ram_freq_and_constr(E, O, C, n, p, freq, constr):
         assert np.all(ro.state.Sigma[:, M == 0] == 0) and np.any(ro.state.Sigma[:, 1, 0] != 0)
 
 
+@pytest.mark.parametrize("C,n,p", [(6, 900, 3), (5, 10000, 3), (70, 2600, 30)])
+@pytest.mark.parametrize("fam", [dict(ram_qfun=1), dict(ram_qfun=2, ram_df=3.0), dict(ram_qfun=2, ram_df=0.7, ram_eta_exp=0.9),
+                                 dict(ram_eta_exp=0.51)])
+def test_ram_qfun_and_eta_families(E, O, C, n, p, fam):
+    """The built-in alternatives to kernel_ram's `qfun` and `eta` (R/kernel_ram.R:67-68, fmcmc_kernel.ram_*): normal and
+    t(df) variates, eta = min(1, k i^-g); streamed, wave-specialised and (wide model) dataflow kernels."""
+    X, y = synth_linreg(n, p, 78, beta=np.linspace(1.0, -1.0, p + 1))
+    k = p + 2
+    init = jitter_init([0.0] * (p + 1) + [float(np.std(y)) + 1.0], C, 10)
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, k, init, nsteps=160, calls=2, **fam)
+
+
 @pytest.mark.parametrize("n,p", [(1, 0), (37, 1), (511, 2), (512, 3), (513, 3), (1025, 2), (3000, 0), (5000, 3), (8192, 3),
                                  (9728, 3), (9729, 1), (10240, 2),                      # one group of K = 4: p <= 3
                                  (700, 4), (2049, 5), (4096, 6), (5120, 7), (5119, 7)])  # two chained groups: p <= 7
@@ -570,6 +583,20 @@ def wide_form(request, monkeypatch):
     """Both forms of the observation-sharded sweep (mh_wide2.hpp / eval_sharded): knob wide2=0 keeps the sequential one."""
     set_knob(monkeypatch, "wide2", "1" if request.param == "dataflow" else "0")
     return request.param
+
+
+def test_ram_families_in_the_dataflow_form(E, O, monkeypatch):
+    """kernel_ram's qfun / eta families through mh_sweep_wide2 (its owners draw the variates themselves)."""
+    import torch
+    from fmcmc_amd import _abi as abi
+    set_knob(monkeypatch, "cw", "2"); set_knob(monkeypatch, "shard", "1"); set_knob(monkeypatch, "wide2", "1")
+    X, y = synth_linreg(1500, 20, 4242, beta=np.linspace(1.0, -1.0, 21))
+    init = jitter_init(list(np.linspace(1.0, -1.0, 21)) + [4.0], 512, 6)
+    init[:, -1] = np.abs(init[:, -1])
+    for fam in (dict(ram_qfun=1, ram_eta_exp=0.8), dict(ram_qfun=2, ram_df=5.0)):
+        run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, 22, init, nsteps=20, calls=2, **fam)
+        if torch.cuda.get_device_properties(0).multi_processor_count >= 256:
+            assert abi.last_kernel() == "wide-dataflow"
 
 
 @pytest.mark.parametrize("chains,cw,n,p,intercept", [

@@ -157,6 +157,41 @@ def test_ram_freq_and_constr_oracle(O):
         assert np.array_equal(r.state.Sigma[0], 1e-4 * np.eye(4))
 
 
+def test_ram_qfun_eta_families_oracle(O):
+    """fmcmc_kernel.ram_qfun / ram_df / ram_eta_exp: zeros are the defaults (rt(k, k), exponent 2/3); each family changes
+    the stream; in R arithmetic the variates come from norm_rand / rt of the restated generator."""
+    X, y = synth_linreg(300, 2, 6)
+    m = O.Model(O.FAM_LINREG, X, y)
+    init = np.array([[0, 0, 0, 3.0]])
+    base = O.run(m, O.Kernel(O.K_RAM, 4), initial=init, nsteps=150, seed=8)
+    same = O.run(m, O.Kernel(O.K_RAM, 4, ram_qfun=2, ram_df=4.0, ram_eta_exp=2.0 / 3.0), initial=init, nsteps=150, seed=8)
+    assert np.array_equal(base.samples, same.samples) and np.array_equal(base.state.Sigma, same.state.Sigma)
+    seen = [base.samples.tobytes()]
+    for kw in (dict(ram_qfun=1), dict(ram_qfun=2, ram_df=2.5), dict(ram_eta_exp=0.9)):
+        r = O.run(m, O.Kernel(O.K_RAM, 4, **kw), initial=init, nsteps=150, seed=8)
+        assert r.samples.tobytes() not in seen and np.all(np.isfinite(r.state.Sigma))
+        seen.append(r.samples.tobytes())
+    # qfun = rnorm in R arithmetic: the proposal of row 2 is theta0 + eps * norm_rand() draws taken after runif(nsteps)
+    g = O.RRng(5)
+    r = O.run(m, O.Kernel(O.K_RAM, 4, ram_qfun=1, warmup=1000), initial=init, nsteps=5, rng_mode=O.RNG_RMT, math_mode=O.MATH_R, rng=g)
+    g2 = O.RRng(5); g2.runif(5)
+    z = g2.rnorm(4)
+    assert np.allclose(r.draws[0, 1], init[0] + 1e-4 * z, rtol=0, atol=1e-15)
+    import fmcmc_amd as f
+    from fmcmc_amd import _abi as abi
+    k = f.kernel_ram(qfun=f.qfun_normal(), eta=f.eta_power(0.75))
+    assert k.ram_qfun == abi.RAM_QFUN_NORMAL and k.ram_eta_exp == 0.75 and k.eta(8, 2) == min(1.0, 8 ** -0.75 * 2)
+    k = f.kernel_ram(qfun=f.qfun_t(3))
+    assert k.ram_qfun == abi.RAM_QFUN_T_DF and k.ram_df == 3.0
+    assert f.kernel_ram(qfun=f.qfun_t()).ram_qfun == abi.RAM_QFUN_T_K
+    with pytest.raises(NotImplementedError, match="closure"):
+        f.kernel_ram(qfun=lambda k: np.zeros(k))
+    with pytest.raises(NotImplementedError, match="closure"):
+        f.kernel_ram(eta=lambda i, k: 0.5)
+    with pytest.raises(ValueError):
+        f.eta_power(0.0)
+
+
 def test_host_kernel_constructors(monkeypatch):
     import fmcmc_amd as f
     from fmcmc_amd import _abi as abi
