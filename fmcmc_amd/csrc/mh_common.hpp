@@ -534,6 +534,7 @@ struct ShardMfma {
   int NC, p, ic, lane0, debug;   // NC: chains of the set this call evaluates
   int ncp;               // row stride of th (all chains of the launch + SH_PAD)
   int cstride, coff;     // chain of the set's member l: cstride * l + coff (1, 0: all chains; 2, g: chain group g of mh_sweep_wide2)
+  int thoff;             // column of member 0 in a row of th; the set's members are CONTIGUOUS there (0: all chains; g NH: group g)
   int tfirst, tstep;     // N-tiles of the calling wave: tfirst, tfirst + tstep, ...
 };
 static_assert(sizeof(ShardMfma) <= 64, "ShardMfma must travel in registers (16 dwords)");
@@ -541,7 +542,7 @@ template <int LPW, int NMT>
 __device__ __attribute__((noinline)) void shard_columns_mfma(ShardMfma c) {
   const int lane = threadIdx.x & 63;
   const int NC = rfl_i(c.NC), NCP = rfl_i(c.ncp), p = rfl_i(c.p), ic = rfl_i(c.ic), lane0 = rfl_i(c.lane0);
-  const int cstride = rfl_i(c.cstride), coff = rfl_i(c.coff), tfirst = rfl_i(c.tfirst), tstep = rfl_i(c.tstep);
+  const int cstride = rfl_i(c.cstride), coff = rfl_i(c.coff), thoff = rfl_i(c.thoff), tfirst = rfl_i(c.tfirst), tstep = rfl_i(c.tstep);
   const int KB = (p + 3) >> 2;
   const double* thg = (const double*)rfl_u64((unsigned long long)c.th);
   double* part = (double*)rfl_u64((unsigned long long)c.part);
@@ -562,7 +563,7 @@ __device__ __attribute__((noinline)) void shard_columns_mfma(ShardMfma c) {
 #define SHM_LOAD_B(T_, B_, c0_)                                                                          \
   {                                                                                                      \
     const int ch_ = 16 * (T_) + j;                                                                       \
-    const unsigned int chc_ = (unsigned int)(cstride * (ch_ < NC ? ch_ : NC - 1) + coff);                \
+    const unsigned int chc_ = (unsigned int)(thoff + (ch_ < NC ? ch_ : NC - 1));                         \
     c0_ = ic ? sh_load(thg + chc_) : 0.0;                                                                \
     _Pragma("unroll") for (int kb = 0; kb < SHM_KBMAX; kb++) {                                           \
       if (kb < KB) {                                                                                     \
@@ -653,7 +654,7 @@ __device__ __forceinline__ bool eval_sharded(const SweepArgs& A, double* const* 
   if (s_mblk) {
     ShardMfma sm;
     sm.th = A.sh_th; sm.part = A.sh_part; sm.NC = NC; sm.p = p; sm.ic = ic; sm.lane0 = (int)blockIdx.x * LPW; sm.debug = A.debug;
-    sm.ncp = NCP; sm.cstride = 1; sm.coff = 0; sm.tfirst = (int)(threadIdx.x >> 6); sm.tstep = NW;   // all chains, N-tiles round robin
+    sm.ncp = NCP; sm.cstride = 1; sm.coff = 0; sm.thoff = 0; sm.tfirst = (int)(threadIdx.x >> 6); sm.tstep = NW;   // all chains, N-tiles round robin
     sm.lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const double*)s_mblk;
     if (A.sh_nmt == 1) shard_columns_mfma<LPW, 1>(sm);
     else if (A.sh_nmt == 2) shard_columns_mfma<LPW, 2>(sm);

@@ -72,6 +72,115 @@ __device__ __forceinline__ bool w2_wait(unsigned* bar, unsigned epoch, unsigned*
   return __builtin_amdgcn_readfirstlane(ok ? 1 : 0) != 0;
 }
 
+// kernel_ram on an owner wave of this kernel: lane = row of the lower factor, as in mh_streamed.hpp (ram_propose_rows,
+// ram_update_rows, ram_update_propose_rows: same operations on every element in the same order, same bits), but S and G
+// INTERLEAVED -- SG[(i LD + j)] = (S_ij, G_ij) -- and the coefficients of the update as pairs C[j] = (d_j, kappa_j): one
+// two-address LDS instruction per pair instead of one per double, and no predicate per column: above the diagonal S and G
+// hold +0 and stay +0 (fma(+0, kappa, +0 d) = +0 for the finite kappa and d > 0 that ram_coef lets through; the proposal's
+// chain adds nw z = +-0 there, as it always has).  21 -> 9 instructions per column of the fused pass, which at k = 50 was
+// 5.2 of the owner's 8 us between the partials and the next proposal.
+// (software pipeline: two register sets used alternately, the loads of a group of four columns issued a whole group ahead
+//  of its arithmetic, every address an immediate offset from three pointers that move by one group -- copying a "next" set
+//  into a "current" one made the compiler wait for the loads it had just issued)
+// (the address as a value the optimiser knows nothing about: it then keeps `pointer + constant` as the instruction's
+//  unsigned offset field instead of re-deriving every address from the loop's start with an add of its own)
+#define W2_OPAQUE(ptr) { unsigned a_ = (unsigned)(unsigned long long)(ptr); asm volatile("" : "+v"(a_)); (ptr) = (lds_dptr_t)(unsigned long long)a_; }
+#define W2_LOAD4(S_, G_, D_, K_, Z_, rp, cp, zp)                                                         \
+  _Pragma("unroll") for (int u = 0; u < 4; u++) {                                                        \
+    S_[u] = (rp)[2 * u]; G_[u] = (rp)[2 * u + 1]; D_[u] = (cp)[2 * u]; K_[u] = (cp)[2 * u + 1]; Z_[u] = (zp)[u]; }
+#define W2_STEP4(S_, G_, D_, K_, Z_, rp)                                                                 \
+  _Pragma("unroll") for (int u = 3; u >= 0; u--) {                                                       \
+    const double nw = fmh_fma(G_[u], K_[u], S_[u] * D_[u]);                                              \
+    (rp)[2 * u] = nw; (rp)[2 * u + 1] = s;                                                               \
+    s = fmh_fma(nw, Z_[u], s); }
+__device__ __attribute__((noinline)) double w2_ram_update_propose(lds_dptr_t SG, lds_dptr_t C, lds_dptr_t z, int LD_, int kf_) {
+  const int lane = threadIdx.x & 63;
+  const int LD = __builtin_amdgcn_readfirstlane(LD_), kf = __builtin_amdgcn_readfirstlane(kf_);
+  double s = 0.0;
+  if (lane < kf) {
+    const lds_dptr_t row = SG + 2 * lane * LD;
+    const int ng = kf >> 2;                    // full groups of four columns: columns 0 .. 4 ng - 1
+    for (int j = kf - 1; j >= 4 * ng; j--) {   // the (at most three) columns above them come first
+      const double nw = fmh_fma(row[2 * j + 1], C[2 * j + 1], row[2 * j] * C[2 * j]);
+      row[2 * j] = nw;
+      row[2 * j + 1] = s;
+      s = fmh_fma(nw, z[j], s);
+    }
+    if (ng > 0) {
+      int g = ng - 1;                          // group g: columns 4 g .. 4 g + 3
+      lds_dptr_t rq = row + 8 * g, cq = C + 8 * g, zq = z + 4 * g;
+      double s0[4], g0[4], d0[4], k0[4], z0[4], s1[4], g1[4], d1[4], k1[4], z1[4];
+      W2_LOAD4(s0, g0, d0, k0, z0, rq, cq, zq)
+      while (g >= 2) {                         // (pointers at the LOWEST of the three groups in flight: LDS offsets are unsigned)
+        rq -= 16; cq -= 16; zq -= 8;
+        W2_OPAQUE(rq) W2_OPAQUE(cq) W2_OPAQUE(zq)
+        W2_LOAD4(s1, g1, d1, k1, z1, rq + 8, cq + 8, zq + 4)
+        W2_STEP4(s0, g0, d0, k0, z0, rq + 16)
+        W2_LOAD4(s0, g0, d0, k0, z0, rq, cq, zq)
+        W2_STEP4(s1, g1, d1, k1, z1, rq + 8)
+        g -= 2;
+      }
+      if (g == 1) {
+        rq -= 8; cq -= 8; zq -= 4;
+        W2_OPAQUE(rq) W2_OPAQUE(cq) W2_OPAQUE(zq)
+        W2_LOAD4(s1, g1, d1, k1, z1, rq, cq, zq)
+        W2_STEP4(s0, g0, d0, k0, z0, rq + 8)
+        W2_STEP4(s1, g1, d1, k1, z1, rq)
+      } else {
+        W2_STEP4(s0, g0, d0, k0, z0, rq)
+      }
+    }
+  }
+  return s;
+}
+__device__ __attribute__((noinline)) double w2_ram_propose(lds_dptr_t SG, lds_dptr_t z, int LD_, int kf_) {
+  const int lane = threadIdx.x & 63;
+  const int LD = __builtin_amdgcn_readfirstlane(LD_), kf = __builtin_amdgcn_readfirstlane(kf_);
+  double s = 0.0;
+  if (lane < kf) {
+    const lds_dptr_t row = SG + 2 * lane * LD;
+    int j = kf - 1;
+    double sc[4], zc[4];
+    if (j >= 3) {
+#pragma unroll
+      for (int u = 0; u < 4; u++) { sc[u] = row[2 * (j - u)]; zc[u] = z[j - u]; }
+    }
+    for (; j >= 3; j -= 4) {
+      const int jn = (j - 4 >= 3) ? j - 4 : j;
+      double sn[4], zn[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { sn[u] = row[2 * (jn - u)]; zn[u] = z[jn - u]; }
+      const double g0 = s, g1 = fmh_fma(sc[0], zc[0], g0), g2 = fmh_fma(sc[1], zc[1], g1), g3 = fmh_fma(sc[2], zc[2], g2);
+      s = fmh_fma(sc[3], zc[3], g3);
+      row[2 * j + 1] = g0; row[2 * (j - 1) + 1] = g1; row[2 * (j - 2) + 1] = g2; row[2 * (j - 3) + 1] = g3;
+#pragma unroll
+      for (int u = 0; u < 4; u++) { sc[u] = sn[u]; zc[u] = zn[u]; }
+    }
+    for (; j >= 0; j--) {
+      const double sij = row[2 * j];
+      row[2 * j + 1] = s;
+      s = fmh_fma(sij, z[j], s);
+    }
+  }
+  return s;
+}
+__device__ __attribute__((noinline)) void w2_ram_update(lds_dptr_t SG, lds_dptr_t C, int LD_, int kf_) {
+  const int lane = threadIdx.x & 63;
+  const int LD = __builtin_amdgcn_readfirstlane(LD_), kf = __builtin_amdgcn_readfirstlane(kf_);
+  if (lane < kf) {
+    const lds_dptr_t row = SG + 2 * lane * LD;
+    int j = 0;
+    for (; j + 3 < kf; j += 4) {
+      double nw[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) nw[u] = fmh_fma(row[2 * (j + u) + 1], C[2 * (j + u) + 1], row[2 * (j + u)] * C[2 * (j + u)]);
+#pragma unroll
+      for (int u = 0; u < 4; u++) row[2 * (j + u)] = nw[u];
+    }
+    for (; j < kf; j++) row[2 * j] = fmh_fma(row[2 * j + 1], C[2 * j + 1], row[2 * j] * C[2 * j]);
+  }
+}
+
 __host__ __device__ inline size_t wide2_lds_doubles(int k, int kf, int kind, int kz, int mblk) {
   return 4 * (size_t)k + (k / 2 + 1) + 4 * (size_t)(kz + 1) + 4 + 2 * (size_t)chain_lds_doubles(k, kf, kind) + 2 + (size_t)mblk;
 }
@@ -85,6 +194,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int k = A.k, kz = A.kz, p = A.p, ic = A.intercept, nb = ic + p;
   const int NC = (int)A.nchains, NCP = NC + SH_PAD;
+  const int NH = (NC + 1) >> 1;          // the proposal table keeps each group's chains together: row j = [group 0 | group 1]
   // ---- LDS: kernel parameters | which[] | variates [2 chains][2 parities][kz + 1] | sync words | 2 chain blocks | slice block
   double* s_mu = smem;
   double* s_scale = s_mu + k;
@@ -156,7 +266,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
         W2_EV_STAMP(0);
         const int Ng = (NC + 1 - g) >> 1;                       // chains of the group in this launch
         if (Ng > 0) {
-          sm.NC = Ng; sm.coff = g;
+          sm.NC = Ng; sm.coff = g; sm.thoff = g * NH;
           shard_columns_mfma<2, NMT>(sm);
         }
         W2_EV_STAMP(1);
@@ -184,7 +294,8 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
   unsigned* X1 = A.sh_bar + (2 * g) * W2_BARW;
   unsigned* X2 = A.sh_bar + (2 * g + 1) * W2_BARW;
   ChainLds L = chain_lds(s_chains + g * CHS, k, kf, KIND);
-  double* const Scur = L.SigA;
+  double* const SG = L.SigA;      // kernel_ram: the pairs (S_ij, G_ij), [kf][LD][2] over SigA | SigB
+  double* const CF = L.vz;        // kernel_ram: the pairs (d_j, kappa_j) of the pending update, [kf][2] over vz | vv
   double f0 = 0.0, f1 = 0.0;
   long long abs_iter = 0, nacc = 0;
   int nerr = 0, status = FMCMC_CHAIN_OK;
@@ -198,8 +309,8 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
     if (KIND == FMCMC_KERNEL_RAM) {
       for (int e = lane; e < kf * LD; e += 64) {
         const int a = e / LD, b = e % LD;
-        L.SigA[e] = A.fresh ? ((a == b) ? 1.0 * A.eps : 0.0) : ((b < kf && b <= a) ? A.Sigma[(cl * kf + a) * kf + b] : 0.0);
-        L.SigB[e] = 0.0;
+        SG[2 * e] = A.fresh ? ((a == b) ? 1.0 * A.eps : 0.0) : ((b < kf && b <= a) ? A.Sigma[(cl * kf + a) * kf + b] : 0.0);
+        SG[2 * e + 1] = 0.0;
       }
       if (!A.fresh) {
         abs_iter = A.abs_iter[cl];
@@ -226,7 +337,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
   };
   // publish theta1 of this chain ([coefficient][chain] table) and signal; a wave without a chain only signals
   auto publish = [&](unsigned epoch, bool store) {
-    if (has && store && lane < nb) sh_store(&A.sh_th[(long long)lane * NCP + cl], L.th1[lane]);
+    if (has && store && lane < nb) sh_store(&A.sh_th[(long long)lane * NCP + g * NH + (cl >> 1)], L.th1[lane]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) w2_arrive(X1, epoch);
   };
@@ -305,7 +416,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
       }
       W2_OW_STAMP(1);
       row_th1 = (lane < k) ? L.th1[lane] : 0.0;
-      bool do_update = false;                 // kernel_ram: d_j | kappa_j of this step are in L.vmp | L.vmt
+      bool do_update = false;                 // kernel_ram: (d_j, kappa_j) of this step are in CF
       if (v == 1) {
         f0 = f1;
         row_keep = true;
@@ -324,7 +435,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
               if (__any(lane < kf && !okl)) {
                 nerr += 1;
               } else {
-                if (lane < kf) { L.vmp[lane] = dl; L.vmt[lane] = kl; }
+                if (lane < kf) { CF[2 * lane] = dl; CF[2 * lane + 1] = kl; }
                 do_update = true;
               }
             }
@@ -359,8 +470,8 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
         const int i = v + 1;
         const double* zt = s_z + (g * 2 + (i & 1)) * (kz + 1);
         if (KIND == FMCMC_KERNEL_RAM) {   // R/kernel_ram.R:123-126
-          const double s = do_update ? ram_update_propose_rows((lds_dptr_t)Scur, (lds_dptr_t)L.SigB, (lds_dptr_t)L.vmp, (lds_dptr_t)zt, LD, kf)
-                                     : ram_propose_rows((lds_dptr_t)Scur, (lds_dptr_t)L.SigB, (lds_dptr_t)zt, LD, kf);
+          const double s = do_update ? w2_ram_update_propose((lds_dptr_t)SG, (lds_dptr_t)CF, (lds_dptr_t)zt, LD, kf)
+                                     : w2_ram_propose((lds_dptr_t)SG, (lds_dptr_t)zt, LD, kf);
           if (lane < kf) {
             const int j = s_which[lane];
             L.th1[j] = L.th0[j] + s;
@@ -380,7 +491,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
         fresh_prop = true;
       } else if (KIND == FMCMC_KERNEL_RAM && do_update) {   // the last step of the call (or a chain that just failed): S only
         wave_sync_lds();
-        ram_update_rows((lds_dptr_t)Scur, (lds_dptr_t)L.SigB, (lds_dptr_t)L.vmp, LD, kf);
+        w2_ram_update((lds_dptr_t)SG, (lds_dptr_t)CF, LD, kf);
         wave_sync_lds();
       }
     }
@@ -436,7 +547,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
       wave_sync_lds();
       for (int e = lane; e < kf * kf; e += 64) {
         const int a = e / kf, b = e % kf;
-        A.Sigma[(cl * kf + a) * kf + b] = Scur[a * LD + b];
+        A.Sigma[(cl * kf + a) * kf + b] = SG[2 * (a * LD + b)];
       }
     }
   }
