@@ -65,6 +65,7 @@ struct SweepArgs {
   int* have_mean;
   int* nerrors;
   // observation-sharded evaluation (wide linear models, cooperative launch; 0 = off)
+  int sh_ngrp;               // dataflow form (mh_sweep_wide2): chain groups, 2 or 4
   int shard;                 // canonical lanes per workgroup (512 / number of workgroups: 2 or 4)
   int sh_nslots;             // observations per canonical lane, ceil(n / 512); shard * sh_nslots <= SH_MAXO
   const double* sh_xs;       // [G][p][SH_MAXO] the workgroup's observations, column by column, slot-major (0 beyond n)

@@ -299,17 +299,18 @@ static SweepArgs chain_window(const SweepArgs& A, long long off, long long cnt, 
 //   mfma=0       VALU evaluation instead of the fp64-MFMA kernels owners=0|1  replicated-state / owner-wave MFMA kernel
 //   shard=0|1    wide models: never / always (when eligible) observation-sharded; unset: cost model
 //   shard_mfma=0 VALU form of the sharded slice product           wide2=0|1   never / always (when eligible) the dataflow form
+//   groups=4     four chain groups in the dataflow form (default two)
 //   mode=<bits>  timing ablations and stamps (SweepArgs.debug)
 // The kernel a call ended up on is reported by fmcmc_last_kernel(); DESIGN.md section 5 has the shape -> kernel table.
 struct Knobs {
-  int streamed = -1, cw = -1, pipe = -1, spec = -1, mfma = -1, owners = -1, shard = -1, shard_mfma = -1, wide2 = -1, mode = 0;
+  int streamed = -1, cw = -1, pipe = -1, spec = -1, mfma = -1, owners = -1, shard = -1, shard_mfma = -1, wide2 = -1, groups = -1, mode = 0;
 };
 static Knobs read_knobs() {
   Knobs K;
   const char* e = getenv("FMCMC_AMD_DEBUG");
   if (!e) return K;
   struct { const char* name; int* dst; } tab[] = {{"streamed", &K.streamed}, {"cw", &K.cw}, {"pipe", &K.pipe}, {"spec", &K.spec},
-      {"mfma", &K.mfma}, {"owners", &K.owners}, {"shard_mfma", &K.shard_mfma}, {"shard", &K.shard}, {"wide2", &K.wide2}, {"mode", &K.mode}};
+      {"mfma", &K.mfma}, {"owners", &K.owners}, {"shard_mfma", &K.shard_mfma}, {"shard", &K.shard}, {"wide2", &K.wide2}, {"groups", &K.groups}, {"mode", &K.mode}};
   while (*e) {
     const char* eq = strchr(e, '=');
     const char* end = strchr(e, ',');
@@ -668,6 +669,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
 #undef W2K
       lds = sizeof(double) * wide2_lds_doubles(kn->k, kf, kn->kind, A.kz, mblk);
       g_kernel = "wide-dataflow";
+      A.sh_ngrp = (K.groups == 4) ? 4 : 2;
     }
     if (shard) {
       int coop = 0, perCU = 0;
@@ -684,7 +686,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
     }
     if (shard) {
       const size_t nxs = mfma_form ? 0 : (size_t)nb_launch * m->p * SH_MAXO, nys = mfma_form ? 0 : (size_t)nb_launch * SH_MAXO, nth = (size_t)kn->k * (ch_launch + SH_PAD),
-                   npt = (size_t)(NT + SH_PAD) * ch_launch, nbar = wide2 ? 4 * W2_BARW / 2 : 32 * 20 / 2;   // (barrier words counted in doubles)
+                   npt = (size_t)(NT + SH_PAD) * ch_launch, nbar = wide2 ? 8 * W2_BARW / 2 : 32 * 20 / 2;   // (barrier words counted in doubles)
       const size_t nmf = mfma_form ? (size_t)nb_launch * mblk : 0;
       e = hipMallocAsync((void**)&shw, sizeof(double) * (nxs + nys + nth + npt + nbar + nmf), stream);
       if (e != hipSuccess) { set_err("hipMallocAsync(sharded evaluation) failed: %s", hipGetErrorString(e)); return FMCMC_ERR_DEVICE; }

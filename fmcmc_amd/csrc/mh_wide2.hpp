@@ -17,11 +17,14 @@
 //     proposals complete, partials complete), each waited for by ONE lane per workgroup.
 // So one group's scalar phase and hand-over latencies run under the other group's matrix-core work.  Arithmetic, its order
 // and the canonical tree are those of every other kernel: bit-identical results.
+// (Knob groups=4: four groups a quarter step apart, chain c in group c % 4.  Measured at C4: 30.5 us per step against 25.7
+//  with two -- a visit of the evaluators costs 2.3 us + 0.8 us per N-tile, so halving the tiles per visit does not halve it,
+//  and eight counter sets in flight lengthen every hand-over.  Kept as a tested alternative, not the default.)
 //
 // Hand-over protocol (MI355X_MICROARCH.md, inter-workgroup visibility; the form the sharded kernels have used since round
 // 1): payload moved with agent-scope (sc1) stores and loads only; every storing wave drains its stores (s_waitcnt vmcnt(0))
 // before it, or the last of its workgroup's storing waves (told by a counter in LDS), adds to the arrival counter; a
-// consumer loads only after the ONE polling lane of its workgroup has seen the release word (other waves: after an LDS
+// consumer loads only after the ONE polling lane of its workgroup has seen the counter complete (other waves: after an LDS
 // word that wave then sets).  Every spin is bounded; a hand-over that does not complete marks the chains of the workgroup
 // FMCMC_CHAIN_SYNC_TIMEOUT and lets every loop run out.
 #pragma once
@@ -29,24 +32,23 @@
 namespace {
 
 constexpr int W2_NEVAL = NW - 2;       // evaluator waves
-constexpr int W2_BARW = 32 * 20;       // 32-bit words of one arrival counter set: arrive[8] | top | release[8], one 128-byte line each
+constexpr int W2_BARW = 32 * 20;       // 32-bit words of one arrival counter set: arrive[8] | (unused) | top replicas[8], one 128-byte line each
 
-// Grid-wide "everybody has published" in two levels, as in the sequential form (shard_barrier): workgroup b adds to shard
-// b % 8 (one XCD under round-robin placement), the last of a shard adds to the top counter, the last of those writes the
-// eight release words, ONE wave per waiting workgroup polls its shard's release word.  The counters are only ever touched
-// by the adds and the release words only written once per epoch: tried and dropped, both bit-identical -- every waiter
-// polling the eight (sharded, non-returning) arrival counters directly: 27.5 -> 40.9 us per step, 512 pollers and the
-// atomic adds fight for the same eight lines; per-producer flag words polled by every consumer wave (no atomics at all):
-// 38.8 us, 2048 polling waves on the fabric.
+// Grid-wide "everybody has published" in two levels: workgroup b adds (returning) to shard b % 8 (one XCD under round-robin
+// placement); the last of a shard adds -- not waited for -- to each of EIGHT REPLICAS of the top counter; ONE wave per
+// waiting workgroup polls the replica of its own shard until it holds (shards that take part) x epoch.  Eight adds and 32
+// pollers per replica line and epoch, no release stage (the sequential form, shard_barrier, has one: last of the shards ->
+// release words; here that was 0.2 us per step slower).  Tried and dropped, both bit-identical: every waiter polling the
+// eight (sharded, non-returning) arrival counters directly: 27.5 -> 40.9 us per step, 512 pollers and 256 atomic adds fight
+// for the same eight lines; per-producer flag words polled by every consumer wave (no atomics at all): 38.8 us, 2048 polling
+// waves on the fabric.  Shards that take part: 8; 4 for the proposals of one of FOUR chain groups (knob groups=4), where only
+// the workgroups of one parity, i.e. every second shard, own chains of the group.
 __device__ __forceinline__ void w2_arrive(unsigned* bar, unsigned epoch) {   // ONE lane, after the drain of every wave it signals for
   const unsigned ngroups = 8, gsize = gridDim.x / 8, g = blockIdx.x % ngroups;
-  unsigned* top = bar + 8 * 32;
-  unsigned* rel = bar + 9 * 32;
+  unsigned* rep = bar + 9 * 32;
   const unsigned old = __hip_atomic_fetch_add(&bar[g * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (old + 1 == epoch * gsize) {
-    const unsigned t = __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (t + 1 == epoch * ngroups)
-      for (unsigned q = 0; q < ngroups; q++) __hip_atomic_store(&rel[q * 32], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (old + 1 == epoch * gsize) {   // the last of its shard
+    for (unsigned q = 0; q < ngroups; q++) (void)__hip_atomic_fetch_add(&rep[q * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 typedef __attribute__((address_space(3))) unsigned* w2_ldsu_t;
@@ -56,10 +58,11 @@ __device__ __forceinline__ unsigned w2_lds_ld(unsigned* p) {   // (LDS address s
 __device__ __forceinline__ void w2_lds_st(unsigned* p, unsigned v) {
   __hip_atomic_store((w2_ldsu_t)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-// lane 0 of the calling wave polls the release word of its shard; wave-uniform result; false: timed out (or the workgroup
-// is already lost)
-__device__ __forceinline__ bool w2_wait(unsigned* bar, unsigned epoch, unsigned* s_lost) {
+// lane 0 of the calling wave polls its shard's replica of the top counter for `target` = shards that take part x epoch;
+// wave-uniform result; false: timed out (or the workgroup is already lost)
+__device__ __forceinline__ bool w2_wait(unsigned* bar, unsigned target, unsigned* s_lost) {
   const unsigned g = blockIdx.x % 8;
+  const unsigned epoch = target;
   unsigned* rel = bar + 9 * 32;
   bool ok = true;
   if ((threadIdx.x & 63) == 0) {
@@ -182,7 +185,7 @@ __device__ __attribute__((noinline)) void w2_ram_update(lds_dptr_t SG, lds_dptr_
 }
 
 __host__ __device__ inline size_t wide2_lds_doubles(int k, int kf, int kind, int kz, int mblk) {
-  return 4 * (size_t)k + (k / 2 + 1) + 4 * (size_t)(kz + 1) + 4 + 2 * (size_t)chain_lds_doubles(k, kf, kind) + 2 + (size_t)mblk;
+  return 4 * (size_t)k + (k / 2 + 1) + 4 * (size_t)(kz + 1) + 6 + 2 * (size_t)chain_lds_doubles(k, kf, kind) + 2 + (size_t)mblk;
 }
 
 template <int KIND, int NMT>
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int k = A.k, kz = A.kz, p = A.p, ic = A.intercept, nb = ic + p;
   const int NC = (int)A.nchains, NCP = NC + SH_PAD;
-  const int NH = (NC + 1) >> 1;          // the proposal table keeps each group's chains together: row j = [group 0 | group 1]
+  const int NH = (NC + A.sh_ngrp - 1) / A.sh_ngrp;   // the proposal table keeps each group's chains together: row j = [group 0 | group 1 | ..]
   // ---- LDS: kernel parameters | which[] | variates [2 chains][2 parities][kz + 1] | sync words | 2 chain blocks | slice block
   double* s_mu = smem;
   double* s_scale = s_mu + k;
@@ -202,13 +205,15 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
   double* s_ub = s_lb + k;
   int* s_which = (int*)(s_ub + k);
   double* s_z = s_ub + k + (k / 2 + 1);
-  unsigned* s_sync = (unsigned*)(s_z + 4 * (kz + 1));     // [0..1] proposals of group g seen (epoch), [2..3] evaluator arrivals, [4] lost, [5] kf
-  double* s_chains = s_z + 4 * (kz + 1) + 4;
+  unsigned* s_sync = (unsigned*)(s_z + 4 * (kz + 1));     // [0..3] proposals of group q seen (epoch), [4..7] evaluator arrivals, [8] lost, [9] kf
+  double* s_chains = s_z + 4 * (kz + 1) + 6;
+  const int ng = A.sh_ngrp;                                // chain groups: 2 (chain c in group c % 2) or 4 (c % 4)
   if (tid == 0) {
     int kf0 = 0;
     for (int j = 0; j < k; j++)
       if (!A.fixed[j]) s_which[kf0++] = j;
-    s_sync[0] = 0; s_sync[1] = 0; s_sync[2] = 0; s_sync[3] = 0; s_sync[4] = 0; s_sync[5] = (unsigned)kf0;
+    for (int q = 0; q < 9; q++) s_sync[q] = 0;
+    s_sync[9] = (unsigned)kf0;
   }
   if (tid < k) {
     s_mu[tid] = A.mu[tid];
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
     s_ub[tid] = A.ub[tid];
   }
   __syncthreads();
-  const int kf = (int)s_sync[5];
+  const int kf = (int)s_sync[9];
   const int LD = kf | 1;
   const int CHS = chain_lds_doubles(k, kf, KIND);
   double* s_blk = s_chains + 2 * CHS + ((2 * CHS) & 1);
@@ -227,7 +232,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
   }
   __syncthreads();
   const int nsteps = (int)A.nsteps;
-  unsigned* const s_lost = &s_sync[4];
+  unsigned* const s_lost = &s_sync[8];
 
   if (wave >= 2) {
     // =========================================== evaluator waves ===========================================
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
     ShardMfma sm;
     sm.th = A.sh_th; sm.part = A.sh_part; sm.p = p; sm.ic = ic; sm.lane0 = (int)blockIdx.x * 2; sm.debug = A.debug;
     sm.lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const double*)s_blk;
-    sm.ncp = NCP; sm.cstride = 2; sm.tfirst = tfirst; sm.tstep = tstep;
+    sm.ncp = NCP; sm.cstride = ng; sm.tfirst = tfirst; sm.tstep = tstep;
     bool lost = false;
 #ifdef FMCMC_STAMP
     unsigned long long ev_acc[4] = {0, 0, 0, 0}, ev_prev = stamp_clk();
@@ -247,12 +252,12 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
 #define W2_EV_STAMP(i) do { } while (0)
 #endif
     for (int v = 1; v <= nsteps && !lost; v++) {
-      for (int g = 0; g < 2 && !lost; g++) {
+      for (int g = 0; g < ng && !lost; g++) {
         unsigned* X1 = A.sh_bar + (2 * g) * W2_BARW;
         unsigned* X2 = A.sh_bar + (2 * g + 1) * W2_BARW;
         // the proposals of group g, version v, are complete: wave 2 polls, the other evaluators watch an LDS word it then sets
         if (wave == 2) {
-          const bool ok = w2_wait(X1, (unsigned)v, s_lost);
+          const bool ok = w2_wait(X1, (unsigned)v * ((ng == 4) ? 4u : 8u), s_lost);   // (shards that own chains of the group)
           if (!ok) { if (lane == 0) w2_lds_st(s_lost, 1u); lost = true; }
           else if (lane == 0) w2_lds_st(&s_sync[g], (unsigned)v);
         } else {
@@ -264,7 +269,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
         }
         if (lost) break;
         W2_EV_STAMP(0);
-        const int Ng = (NC + 1 - g) >> 1;                       // chains of the group in this launch
+        const int Ng = (NC + ng - 1 - g) / ng;                  // chains of the group in this launch
         if (Ng > 0) {
           sm.NC = Ng; sm.coff = g; sm.thoff = g * NH;
           shard_columns_mfma<2, NMT>(sm);
@@ -273,7 +278,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's partials have been acknowledged
         W2_EV_STAMP(2);
         if (lane == 0) {
-          const unsigned old = __hip_atomic_fetch_add((w2_ldsu_t)&s_sync[2 + g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          const unsigned old = __hip_atomic_fetch_add((w2_ldsu_t)&s_sync[4 + g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           if (old + 1 == (unsigned)W2_NEVAL * (unsigned)v) w2_arrive(X2, (unsigned)v);   // the last evaluator of the workgroup signals for all
         }
         W2_EV_STAMP(3);
@@ -287,13 +292,14 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
   }
 
   // =============================================== owner waves ===============================================
-  const int g = wave;                                          // chain group == chain slot of the workgroup
-  const long long cl = (long long)blockIdx.x * 2 + g;          // local chain
+  const int slot = wave;                                       // chain slot of the workgroup
+  const long long cl = (long long)blockIdx.x * 2 + slot;       // local chain
+  const int g = (int)(cl % ng);                                // its group
   const bool has = cl < A.nchains;
   const unsigned int cgid = (unsigned int)(A.chain_base + cl);
   unsigned* X1 = A.sh_bar + (2 * g) * W2_BARW;
   unsigned* X2 = A.sh_bar + (2 * g + 1) * W2_BARW;
-  ChainLds L = chain_lds(s_chains + g * CHS, k, kf, KIND);
+  ChainLds L = chain_lds(s_chains + slot * CHS, k, kf, KIND);
   double* const SG = L.SigA;      // kernel_ram: the pairs (S_ij, G_ij), [kf][LD][2] over SigA | SigB
   double* const CF = L.vz;        // kernel_ram: the pairs (d_j, kappa_j) of the pending update, [kf][2] over vz | vv
   double f0 = 0.0, f1 = 0.0;
@@ -322,7 +328,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
   // variates of loop step ii into the buffer of its parity: lanes 0..kz-1 the proposal's, lane kz the log accept uniform
   auto draw = [&](int ii) {
     if (!has || ii > nsteps || lane > kz) return;
-    double* zb = s_z + (g * 2 + (ii & 1)) * (kz + 1);
+    double* zb = s_z + (slot * 2 + (ii & 1)) * (kz + 1);
     const unsigned int st = (unsigned int)(A.step_base + ii);
     double v;
     if (lane == kz) {
@@ -337,7 +343,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
   };
   // publish theta1 of this chain ([coefficient][chain] table) and signal; a wave without a chain only signals
   auto publish = [&](unsigned epoch, bool store) {
-    if (has && store && lane < nb) sh_store(&A.sh_th[(long long)lane * NCP + g * NH + (cl >> 1)], L.th1[lane]);
+    if (has && store && lane < nb) sh_store(&A.sh_th[(long long)lane * NCP + g * NH + (int)(cl / ng)], L.th1[lane]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) w2_arrive(X1, epoch);
   };
@@ -366,7 +372,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
       double eta = (double)kf * fmh_exp(A.ram_neg_exp * fmh_log((double)i));
       if (eta > 1.0) eta = 1.0;
       pre_eta = eta;
-      const double* zt = s_z + (g * 2 + (i & 1)) * (kz + 1);
+      const double* zt = s_z + (slot * 2 + (i & 1)) * (kz + 1);
       pre_zl = (lane < kf) ? zt[lane] : 0.0;
       pre_Pj1 = lane_scan_wave(pre_zl * pre_zl);
       const double up = __shfl_up(pre_Pj1, 1, 64);
@@ -395,7 +401,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
     // (a wave without a chain waits and signals like the others: an arrival for version v + 1 must not come before every
     //  workgroup's arrival for version v)
     {
-      const bool ok = w2_wait(X2, (unsigned)v, s_lost);
+      const bool ok = w2_wait(X2, (unsigned)v * 8u, s_lost);
       if (!ok) { if (lane == 0) w2_lds_st(s_lost, 1u); lost = true; break; }
     }
     W2_OW_STAMP(0);
@@ -422,7 +428,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
         row_keep = true;
       } else {
         const int i = v;
-        const double* zt = s_z + (g * 2 + (i & 1)) * (kz + 1);
+        const double* zt = s_z + (slot * 2 + (i & 1)) * (kz + 1);
         if (KIND == FMCMC_KERNEL_RAM) {   // adaptation with f(theta1) of the (un-reflected == final) proposal, R/kernel_ram.R:129-152
           if (ram_gate) {
             double a_n = fmh_exp(f1 - f0);
@@ -468,7 +474,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
       // ---- factor update of step v and proposal of loop step v + 1 (a failed chain keeps its theta1: the table still holds it)
       if (status == FMCMC_CHAIN_OK && v < nsteps) {
         const int i = v + 1;
-        const double* zt = s_z + (g * 2 + (i & 1)) * (kz + 1);
+        const double* zt = s_z + (slot * 2 + (i & 1)) * (kz + 1);
         if (KIND == FMCMC_KERNEL_RAM) {   // R/kernel_ram.R:123-126
           const double s = do_update ? w2_ram_update_propose((lds_dptr_t)SG, (lds_dptr_t)CF, (lds_dptr_t)zt, LD, kf)
                                      : w2_ram_propose((lds_dptr_t)SG, (lds_dptr_t)zt, LD, kf);

@@ -578,11 +578,14 @@ def test_logistic_on_the_general_kernel(E, O, kind_name):
 SHARDED = ("streamed-wide-sharded-mfma", "wide-dataflow")     # the sequential and the dataflow form of the observation-sharded sweep
 
 
-@pytest.fixture(params=["dataflow", "sequential"])
+@pytest.fixture(params=["dataflow", "dataflow4", "sequential"])
 def wide_form(request, monkeypatch):
-    """Both forms of the observation-sharded sweep (mh_wide2.hpp / eval_sharded): knob wide2=0 keeps the sequential one."""
-    set_knob(monkeypatch, "wide2", "1" if request.param == "dataflow" else "0")
-    return request.param
+    """The forms of the observation-sharded sweep (mh_wide2.hpp with two or -- knob groups=4, slower, kept as a measured
+    alternative -- four chain groups / eval_sharded): knob wide2=0 keeps the sequential one."""
+    set_knob(monkeypatch, "wide2", "0" if request.param == "sequential" else "1")
+    if request.param == "dataflow4":
+        set_knob(monkeypatch, "groups", "4")
+    return "dataflow" if request.param == "dataflow4" else request.param
 
 
 def test_ram_families_in_the_dataflow_form(E, O, monkeypatch):
