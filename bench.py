@@ -311,9 +311,16 @@ def main():
     if rank == 0:
         ach_tflops = samples_per_step * cfg.flops / (kern_ms * 1e-3) / 1e12
         out_bytes = chains * S * ((1 if cfg.name == "c4" else 2) * k + 1) * 8
+        # HBM bytes per launch of the sweep kernel: PMC counters cannot be read from inside this process, so the value comes
+        # from the committed PMC pass of this same command (profiles/latest_pmc_<config>.json, taken by
+        # tools/profile_bench.sh) -- only while the dispatcher still picks the kernel that pass measured; null otherwise
         traffic, tsrc = None, None
-        if args.traffic_from:
-            traffic, tsrc = json.load(open(args.traffic_from)).get("hbm_bytes_per_launch"), args.traffic_from
+        tfile = args.traffic_from or os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "latest_pmc_%s.json" % cfg.name)
+        if os.path.exists(tfile):
+            trec = json.load(open(tfile))
+            names = {"mfma": "mh_sweep_mfma", "wide-dataflow": "mh_sweep_wide2", "spec": "mh_sweep_spec"}
+            if args.traffic_from or all(names.get(pk, pk) in trec.get("kernel", "") for pk in set(picked)):
+                traffic, tsrc = trec.get("hbm_bytes_per_launch"), os.path.relpath(tfile, os.path.dirname(os.path.abspath(__file__)))
         metric = "MH samples/sec (chains x iters / s), 1024 chains, 5-param linreg n=10k" if cfg.name == "c2" else \
                  "MH samples/sec (chains x iters / s), config %s" % cfg.name.upper()
         line = {

@@ -369,13 +369,42 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
     return f;
   };
 
+  // What the decision of a step needs and f(theta1) does not enter is prepared while the compute waves evaluate the
+  // pending proposal (this wave would only poll): the sigma-only part of the closed form -- n (log sigma + ln sqrt 2 pi),
+  // sigma^2 and the reciprocal half of the division (div_recip / div_finish: bit for bit the plain quotient in the safe
+  // range, anything else takes logpost_of) -- and for kernel_ram eta(i, k) and the prefix sums of z^2.
+  double pre_nt1 = 0.0, pre_ss = 1.0, pre_rs = 1.0, pre_eta = 0.0, pre_Pj = 0.0, pre_Pj1 = 0.0, pre_nrm2 = 1.0;
+  bool pre_ok = false;
+  auto prepare = [&](int i) {   // i: loop step whose proposal is pending (1: the initial state)
+    const double sigma = readlane_d(th1, k - 1);
+    const unsigned sg_hi = (unsigned)(fmh_d2u(sigma) >> 32);
+    const bool sg_fast = (sg_hi - 0x00100000u) < 0x7fe00000u;            // positive, finite, normal
+    const double sg = sg_fast ? sigma : 1.0;
+    pre_nt1 = dn * (fmh_log(sg) + FMH_K(FMH_LN_SQRT_2PI));
+    pre_ss = sg * sg;
+    pre_ok = sg_fast && mfr_div_safe(pre_ss);
+    pre_rs = div_recip(pre_ok ? pre_ss : 1.0);
+    if (KIND == FMCMC_KERNEL_RAM && i >= 2) {
+      double eta = (double)kf * fmh_exp(A.ram_neg_exp * fmh_log((double)i));
+      if (eta > 1.0) eta = 1.0;
+      pre_eta = eta;
+      pre_Pj1 = lane_scan_row16(zcur * zcur);                // (zcur is 0 beyond the parameters)
+      pre_Pj = dpp_d<0x111>(pre_Pj1);                        // row_shr:1, lane 0 reads 0
+      pre_nrm2 = readlane_d(pre_Pj1, kf - 1);
+    }
+  };
+  prepare(1);
+
   for (int v = 1; v <= nsteps; v++) {
     while (lds_ld_u32(&s_done[myc]) < 8u * (unsigned)v) __builtin_amdgcn_s_sleep(1);
     const double* src = s_tr + myc * (8 * PIPE_TRS) + lane;
     const double v0 = src[0 * PIPE_TRS], v1 = src[1 * PIPE_TRS], v2 = src[2 * PIPE_TRS], v3 = src[3 * PIPE_TRS];
     const double v4 = src[4 * PIPE_TRS], v5 = src[5 * PIPE_TRS], v6 = src[6 * PIPE_TRS], v7 = src[7 * PIPE_TRS];
     const double tot = wave_xor_sum(((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7)));
-    const double f1 = logpost_of(tot, readlane_d(th1, k - 1));
+    const double h = 0.5 * tot;
+    double f1;
+    if (pre_ok && mfr_div_safe(h)) f1 = -pre_nt1 - div_finish(h, pre_ss, pre_rs);   // (finite: the guard has nothing to do)
+    else f1 = logpost_of(tot, readlane_d(th1, k - 1));
     bool st_row = false;
     double st_th0 = 0.0;
     const double st_dr = th1;
@@ -390,13 +419,9 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
           double a_n = fmh_exp(f1 - f0);
           if (fmh_isnan(a_n)) a_n = 0.0;
           else if (a_n > 1.0) a_n = 1.0;
-          double eta = (double)kf * fmh_exp(A.ram_neg_exp * fmh_log((double)i));
-          if (eta > 1.0) eta = 1.0;
           // S <- S T (mh_common.hpp, ram_coef): square root and divisions once per update, lane = column; then row `lane`
           // in registers, two fma per element, column values by v_readlane
-          const double Pj1 = lane_scan_row16(zcur * zcur);     // (zcur is 0 beyond the parameters)
-          const double Pj = dpp_d<0x111>(Pj1);                 // row_shr:1, lane 0 reads 0
-          const double nrm2 = readlane_d(Pj1, kf - 1);
+          const double eta = pre_eta, Pj1 = pre_Pj1, Pj = pre_Pj, nrm2 = pre_nrm2;
           const double cp = (eta * (a_n - A.arate)) / nrm2;
           if (cp != 0.0 && fmh_isfinite(cp)) {
             double dl, kl;
@@ -515,6 +540,7 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
       if (A.logpost && lane == 0) *reinterpret_cast<double*>(reinterpret_cast<char*>(A.logpost) + (lp_off + srow8)) = f1;
       srow8 += 8;
     }
+    if (v < nsteps) prepare(v + 1);
   }
   // ---- write state back
   if (rl) A.theta0[(long long)cl * k + lane] = th0;
