@@ -24,11 +24,19 @@
  *   rng_mode = ORACLE_RNG_PHILOX, math_mode = ORACLE_MATH_CANON
  *       the HIP engine's bit-exact twin: Philox stream (include/fmh_philox.h), deterministic
  *       math (include/fmh_detmath.h), the engine's canonical summation tree (512 lanes,
- *       xor-butterfly), Cholesky instead of eigen for mvrnorm, rank-1 factor update for RAM.
+ *       xor-butterfly), Cholesky instead of eigen for mvrnorm, product-form factor update
+ *       (S' = S chol(I +- p p^T), ram_factor_update_canon) for RAM.
  *   Third-party arithmetic not under /root/reference and how it is pinned: see r_rng.c
  *   (base R RNG: pinned by KATs + G1-G5), MASS::mvrnorm -> LAPACK dsyevr (parity UNPINNED at
  *   bit level, statistical only: G6), coda::gelman.diag mpsrf (pinned by G2/G3), psrf
  *   univariate branch (UNPINNED), Matrix::nearPD fallback (UNPINNED, never triggered).
+ *   Also UNPINNED -- the reference prints no output of them, so they are restated from its source
+ *   (and, for coda, from the published algorithms) and checked against independent numpy replays
+ *   only: kernel_unif(_reflective) and the ordered / random / explicit update schemes
+ *   (R/kernel_unif.R, R/kernel.R:60-113), kernel_nmirror / kernel_umirror (R/kernel_mirror.R),
+ *   kernel_adapt(bw > 0 | freq > 1), kernel_ram(freq, constr) and the qfun / eta families
+ *   (fmcmc_kernel.ram_*), convergence_geweke / heidel / auto (oracle.py: spectrum0.ar etc.).
+ *   DESIGN.md section 3 carries the same list.
  */
 #include <math.h>
 #include <stdint.h>
