@@ -179,7 +179,7 @@ def cpu_baseline(cfg, seconds_budget=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (default: about 5 s of GPU time for the config: c2 240, c3 140, c4 20, c5 6)")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"])
     ap.add_argument("--iters", type=int, default=0, help="MH iterations per sweep (default: the config's nsteps)")
@@ -188,6 +188,8 @@ def main():
     ap.add_argument("--traffic-from", default=None, help="JSON of a PMC pass of this same command (hbm_bytes_per_launch)")
     args = ap.parse_args()
     cfg = Config(args.config)
+    if args.steps <= 0:   # a timed region of about five seconds (one step = one sweep of the config's nsteps iterations)
+        args.steps = {"c2": 240, "c3": 140, "c4": 20, "c5": 6}[cfg.name]
 
     import torch
     import torch.distributed as dist
