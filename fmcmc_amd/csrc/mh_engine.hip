@@ -685,7 +685,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
       e = hipSuccess;
     }
     if (shard) {
-      const size_t nxs = mfma_form ? 0 : (size_t)nb_launch * m->p * SH_MAXO, nys = mfma_form ? 0 : (size_t)nb_launch * SH_MAXO, nth = (size_t)kn->k * (ch_launch + SH_PAD),
+      const size_t nxs = mfma_form ? 0 : (size_t)nb_launch * m->p * SH_MAXO, nys = mfma_form ? 0 : (size_t)nb_launch * SH_MAXO, nth = ((size_t)kn->k * (ch_launch + SH_PAD) + 7) & ~(size_t)7,   // (the partials behind it stay 64-byte aligned)
                    npt = (size_t)(NT + SH_PAD) * ch_launch, nbar = wide2 ? 8 * W2_BARW / 2 : 32 * 20 / 2;   // (barrier words counted in doubles)
       const size_t nmf = mfma_form ? (size_t)nb_launch * mblk : 0;
       e = hipMallocAsync((void**)&shw, sizeof(double) * (nxs + nys + nth + npt + nbar + nmf), stream);

@@ -409,8 +409,17 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
     double row_th0 = 0.0, row_th1 = 0.0, row_f1 = 0.0;
     if (has && (status == FMCMC_CHAIN_OK)) {
       const double* pr = A.sh_part + (unsigned int)cl * (unsigned int)(NT + SH_PAD) + 8 * lane;
-      const double v0 = sh_load(pr + 0), v1 = sh_load(pr + 1), v2 = sh_load(pr + 2), v3 = sh_load(pr + 3);
-      const double v4 = sh_load(pr + 4), v5 = sh_load(pr + 5), v6 = sh_load(pr + 6), v7 = sh_load(pr + 7);
+      // (eight consecutive partials per lane, 64-byte aligned: four 16-byte loads; an 8-byte sc1 access runs at 0.54-0.70 of
+      //  the 16-byte rate)
+      typedef double d2v_t __attribute__((ext_vector_type(2)));
+      d2v_t q0, q1, q2, q3;
+      asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
+                   "global_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
+                   "global_load_dwordx4 %2, %4, off offset:32 sc1\n\t"
+                   "global_load_dwordx4 %3, %4, off offset:48 sc1\n\t"
+                   "s_waitcnt vmcnt(0)"
+                   : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3) : "v"(pr) : "memory");
+      const double v0 = q0.x, v1 = q0.y, v2 = q1.x, v3 = q1.y, v4 = q2.x, v5 = q2.y, v6 = q3.x, v7 = q3.y;
       const double tot = wave_xor_sum(((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7)));   // canonical levels 1, 2, 4 | 8 .. 256
       // closed form: -(n (log sigma + ln sqrt 2 pi)) - (tot / 2) / sigma^2 with the sigma-only part prepared while this wave
       // waited (same operations, same bits as finish_logpost)
