@@ -749,12 +749,16 @@ __device__ __forceinline__ void eval_partials(const SweepArgs& A, double* const*
       for (int u = 0; u < PL; u++) colp[u] = (gptr_t)(unsigned long long)(A.X + (long long)u * n);
       const gptr_t yp = (gptr_t)(unsigned long long)A.y;
       const unsigned int nn = (unsigned int)n;
+      // (the lane's offset in BYTES as a 32-bit value -- n < 2^28 -- so that every load is `scalar base + 32-bit VGPR offset`;
+      //  indexed with the observation number the compiler widened the scaled index and made a 64-bit add per column)
+      typedef const char __attribute__((address_space(1))) * gcptr_t;
+      auto ldg = [](gptr_t base, unsigned int boff) -> double { return *(gptr_t)((gcptr_t)base + boff); };
       double xb[PL > 0 ? PL : 1], yv = 0.0;
       unsigned int i = (unsigned int)tid;
       if (i < nn) {
 #pragma unroll
-        for (int u = 0; u < PL; u++) xb[u] = colp[u][i];
-        yv = yp[i];
+        for (int u = 0; u < PL; u++) xb[u] = ldg(colp[u], 8u * i);
+        yv = ldg(yp, 8u * i);
       }
       for (; i < nn; i += NT) {
         double eta[CW];
@@ -767,9 +771,10 @@ __device__ __forceinline__ void eval_partials(const SweepArgs& A, double* const*
         }
         const bool y1 = (yv != 0.0);
         const unsigned int inx = (i + NT < nn) ? i + NT : i;   // clamped: the last prefetch re-reads this observation
+        const unsigned int binx = 8u * inx;
 #pragma unroll
-        for (int u = 0; u < PL; u++) xb[u] = colp[u][inx];
-        yv = yp[inx];
+        for (int u = 0; u < PL; u++) xb[u] = ldg(colp[u], binx);
+        yv = ldg(yp, binx);
         add_terms(eta, y1);
       }
     };

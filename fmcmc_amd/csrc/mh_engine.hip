@@ -593,20 +593,22 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
     // logistic-only instantiations: the number of covariates is a compile-time constant of the evaluation loop and the
     // coefficients of the CW chains live in SGPRs (mh_common.hpp); with the division-free softplus 2x the general kernel
     g_kernel = "streamed-logistic";
-#define LAUNCH_LOGIT(CWV, KV)                                                                                          \
+#define LAUNCH_LOGIT(CWV, KV, MB)                                                                                      \
     do {                                                                                                               \
       if (lds > 48 * 1024)                                                                                             \
-        e = hipFuncSetAttribute((const void*)mh_sweep_kernel<CWV, -1, 0, KV, FMCMC_FAM_LOGISTIC>,                      \
+        e = hipFuncSetAttribute((const void*)mh_sweep_kernel<CWV, -1, 0, KV, FMCMC_FAM_LOGISTIC, MB>,                  \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
       if (e == hipSuccess)                                                                                             \
-        hipLaunchKernelGGL((mh_sweep_kernel<CWV, -1, 0, KV, FMCMC_FAM_LOGISTIC>), dim3((unsigned)nblk), dim3(NT), lds, stream, A); \
+        hipLaunchKernelGGL((mh_sweep_kernel<CWV, -1, 0, KV, FMCMC_FAM_LOGISTIC, MB>), dim3((unsigned)nblk), dim3(NT), lds, stream, A); \
     } while (0)
     const bool refl = kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE;
     lds += sizeof(double) * (SP_LDS_DOUBLES + 1);   // the softplus tables staged behind the chain blocks
     switch (cw) {
-      case 1: if (refl) LAUNCH_LOGIT(1, 2); else LAUNCH_LOGIT(1, 1); break;
-      case 2: if (refl) LAUNCH_LOGIT(2, 2); else LAUNCH_LOGIT(2, 1); break;
-      default: if (refl) LAUNCH_LOGIT(4, 2); else LAUNCH_LOGIT(4, 1); break;
+      case 1: if (refl) LAUNCH_LOGIT(1, 2, 1); else LAUNCH_LOGIT(1, 1, 1); break;
+      // (measured at C5 with two chains per workgroup, 128 VGPRs and two workgroups per CU = 4 waves per SIMD: 5.0 cycles per
+      //  instruction instead of 6.3, but 27 % more instructions per chain: 5.99e6 against 6.26e6 samples/s; not taken)
+      case 2: if (refl) LAUNCH_LOGIT(2, 2, 1); else LAUNCH_LOGIT(2, 1, 1); break;
+      default: if (refl) LAUNCH_LOGIT(4, 2, 1); else LAUNCH_LOGIT(4, 1, 1); break;
     }
 #undef LAUNCH_LOGIT
   }
