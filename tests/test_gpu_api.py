@@ -432,7 +432,10 @@ class RStream:
         for c in range(nchains):
             logu[c] = np.log(self.g.runif(nsteps))
             for i in range(1, nsteps):
-                z[c, i] = self.g.rt(kz, float(kz)) if kernel.kind == abi.KERNEL_RAM else self.g.rnorm(kz)
+                if kernel.kind != abi.KERNEL_RAM or getattr(kernel, "ram_qfun", 0) == abi.RAM_QFUN_NORMAL:
+                    z[c, i] = self.g.rnorm(kz)       # (kernel_ram(qfun = function(k) rnorm(k)) included)
+                else:
+                    z[c, i] = self.g.rt(kz, float(kernel.ram_df) if getattr(kernel, "ram_qfun", 0) == abi.RAM_QFUN_T_DF else float(kz))
         return logu, z
 
 
@@ -497,6 +500,23 @@ def test_readme_session_through_MCMC_on_R_stream(E, O, readme_data):
     assert sig(acc(a3), 7) == G["G4"]["ram_accept_rate"]
     a4 = f.MCMC(a2, fun, 5000, kernel=f.kernel_adapt(), fed=rs)
     assert abs(acc(a4) - G["G6"]["adapt_accept_rate"]) < 0.025, acc(a4)
+
+
+@pytest.mark.parametrize("fam", ["normal", "t3", "eta"])
+def test_kernel_ram_families_on_R_stream_equal_the_oracle(E, O, readme_data, fam):
+    """kernel_ram(qfun = rnorm | rt(k, 3), eta = i^-0.8 k) through MCMC() on R's own stream (the draws qfun would make,
+    in R's order) against the oracle restating R's loop with the same generator: the same states, bit for bit."""
+    import fmcmc_amd as f
+    X, y = readme_data
+    kw = {"normal": dict(qfun=f.qfun_normal()), "t3": dict(qfun=f.qfun_t(3)), "eta": dict(eta=f.eta_power(0.8))}[fam]
+    okw = {"normal": dict(ram_qfun=1), "t3": dict(ram_qfun=2, ram_df=3.0), "eta": dict(ram_eta_exp=0.8)}[fam]
+    init = [0.0, 0.0, O.r_sd(y)]
+    a = f.MCMC(init, f.gaussian_linreg(X, y), 1500, kernel=f.kernel_ram(**kw), fed=RStream(O, 77))
+    g = O.RRng(77)
+    ro = O.run(O.Model(O.FAM_LINREG, X, y), O.Kernel(O.K_RAM, 3, **okw), initial=np.asarray(init)[None, :], nsteps=1500,
+               rng_mode=O.RNG_RMT, math_mode=O.MATH_CANON, rng=g)
+    assert np.array_equal(np.asarray(a.data).view(np.uint64), np.ascontiguousarray(ro.samples[0]).view(np.uint64))
+    assert 0.05 < float(np.mean(np.any(np.diff(a.data, axis=0) != 0, axis=1))) < 0.9
 
 
 def test_kernel_adapt_acceptance_on_the_philox_stream(E, O, readme_data):
