@@ -2,6 +2,12 @@
 // DPP / permlane swaps, reflection, per-chain LDS layout, streamed evaluation and the closed forms of the families.
 // Included by mh_engine.hip only (one translation unit; everything lives in its anonymous namespace).
 #pragma once
+// Device code for gfx950 only: MFMA lane layouts, DPP / permlane forms, LDS sizes and -- for the wide kernels -- the
+// behaviour of sc1 (write-through, L1-bypassing) accesses that the inter-workgroup hand-overs rest on are this target's.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "fmcmc_amd device code is written for gfx950 (MI355X) only"
+#endif
+
 
 namespace {
 

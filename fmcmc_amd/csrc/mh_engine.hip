@@ -419,6 +419,14 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
   if (ncu <= 0) ncu = 256;
+  {   // the code object is gfx950 only, and the hand-overs of the wide kernels rest on ITS cache behaviour (mh_common.hpp)
+    static int arch_ok = -1;
+    if (arch_ok < 0) {
+      hipDeviceProp_t prop;
+      arch_ok = (hipGetDeviceProperties(&prop, dev) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) ? 1 : 0;
+    }
+    if (!arch_ok) { set_err("this library is built for gfx950 (MI355X); the current device is another architecture"); return FMCMC_ERR_DEVICE; }
+  }
   // register-resident variant: Gaussian linreg whose data fits the VGPR budget of 512 threads
   int res_p = -1, res_opt = 0;
   const bool force = K.streamed == 1;
@@ -710,6 +718,12 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
         (void)hipMemsetAsync(bar, 0, sizeof(double) * nbar, stream);
         void* kargs[] = {(void*)&W};
         e = hipLaunchCooperativeKernel(kfn, dim3((unsigned)nb_launch), dim3(NT), kargs, (unsigned int)lds, stream);
+      }
+      if (e != hipSuccess && done > ch_launch) {    // a LATER window failed: the chains of the earlier windows have run
+        set_err("HIP launch of chain window %lld failed (%s): the state of the first %lld chains is already advanced, the results of this call are invalid",
+                (long long)(done / ch_launch), hipGetErrorString(e), (long long)(done - ch_launch));
+        (void)hipGetLastError();
+        return FMCMC_ERR_DEVICE;
       }
       if (e != hipSuccess && done <= ch_launch) {   // the runtime refused the first cooperative launch after all: nothing ran,
         (void)hipGetLastError();                    // take the chain-sharded kernel
