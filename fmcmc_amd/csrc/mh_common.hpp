@@ -553,12 +553,15 @@ struct ShardMfma {
   int tfirst, tstep;     // N-tiles of the calling wave: tfirst, tfirst + tstep, ...
 };
 static_assert(sizeof(ShardMfma) <= 64, "ShardMfma must travel in registers (16 dwords)");
-template <int LPW, int NMT>
+// KBC > 0: the number of K-blocks is the compile-time constant KBC (config C4: 12).  With a run-time count every K-block is
+// a basic block of its own -- a branch, reloads of spilled scalars, and nothing of one block scheduled into the next: a
+// lone wave ran a tile in 2.6 us (tools/exp_shard_mfma.hip), 1.9 us with the count known, 1.04 us being its matrix-core time.
+template <int LPW, int NMT, int KBC = 0>
 __device__ __attribute__((noinline)) void shard_columns_mfma(ShardMfma c) {
   const int lane = threadIdx.x & 63;
   const int NC = rfl_i(c.NC), NCP = rfl_i(c.ncp), p = rfl_i(c.p), ic = rfl_i(c.ic), lane0 = rfl_i(c.lane0);
   const int cstride = rfl_i(c.cstride), coff = rfl_i(c.coff), thoff = rfl_i(c.thoff), tfirst = rfl_i(c.tfirst), tstep = rfl_i(c.tstep);
-  const int KB = (p + 3) >> 2;
+  const int KB = KBC > 0 ? KBC : (p + 3) >> 2;
   const double* thg = (const double*)rfl_u64((unsigned long long)c.th);
   double* part = (double*)rfl_u64((unsigned long long)c.part);
   typedef __attribute__((address_space(3))) const double* ldsc_t;
@@ -580,7 +583,7 @@ __device__ __attribute__((noinline)) void shard_columns_mfma(ShardMfma c) {
     const int ch_ = 16 * (T_) + j;                                                                       \
     const unsigned int chc_ = (unsigned int)(thoff + (ch_ < NC ? ch_ : NC - 1));                         \
     c0_ = ic ? sh_load(thg + chc_) : 0.0;                                                                \
-    _Pragma("unroll") for (int kb = 0; kb < SHM_KBMAX; kb++) {                                           \
+    _Pragma("unroll") for (int kb = 0; kb < (KBC > 0 ? KBC : SHM_KBMAX); kb++) {                         \
       if (kb < KB) {                                                                                     \
         const int col_ = 4 * kb + kk;                                                                    \
         B_[kb] = sh_load(thg + ((unsigned int)((ic + (col_ < p ? col_ : p - 1)) * NCP) + chc_));         \
@@ -600,14 +603,23 @@ __device__ __attribute__((noinline)) void shard_columns_mfma(ShardMfma c) {
 #pragma unroll
     for (int mt = 0; mt < NMT; mt++) a_cur[mt] = xa[(mt * KB) * 64];
 #pragma unroll
-    for (int kb = 0; kb < SHM_KBMAX; kb++) {
+    for (int kb = 0; kb < (KBC > 0 ? KBC : SHM_KBMAX); kb++) {
       if (kb < KB) {
         const int kn = (kb + 1 < KB) ? kb + 1 : kb;
 #pragma unroll
         for (int mt = 0; mt < NMT; mt++) a_nxt[mt] = xa[(mt * KB + kn) * 64];
-        const double b = (4 * kb + kk < p) ? Bc[kb] : 0.0;    // (a padded column must not turn an infinite coefficient into NaN)
+        // (a padded column must not turn an infinite coefficient into NaN; with KBC only the last block can hold one)
+        const double b = (KBC > 0 && kb < KBC - 1) ? Bc[kb] : ((4 * kb + kk < p) ? Bc[kb] : 0.0);
 #pragma unroll
         for (int mt = 0; mt < NMT; mt++) acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[mt], b, acc[mt], 0, 0, 0);
+        if constexpr (KBC > 0) {   // the block's other instructions BETWEEN its MFMAs: a wave issues in order, and an MFMA
+#pragma unroll                     // holds the issue port until the matrix core takes it, 64 cycles after the previous one
+          for (int mt = 0; mt < NMT; mt++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+          }
+        }
 #pragma unroll
         for (int mt = 0; mt < NMT; mt++) a_cur[mt] = a_nxt[mt];
       }
@@ -670,8 +682,10 @@ __device__ __forceinline__ bool eval_sharded(const SweepArgs& A, double* const* 
     sm.th = A.sh_th; sm.part = A.sh_part; sm.NC = NC; sm.p = p; sm.ic = ic; sm.lane0 = (int)blockIdx.x * LPW; sm.debug = A.debug;
     sm.ncp = NCP; sm.cstride = 1; sm.coff = 0; sm.thoff = 0; sm.tfirst = (int)(threadIdx.x >> 6); sm.tstep = NW;   // all chains, N-tiles round robin
     sm.lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const double*)s_mblk;
+    const bool kb12 = ((p + 3) >> 2) == 12;   // (config C4's width gets the instantiation with a compile-time K-block count)
     if (A.sh_nmt == 1) shard_columns_mfma<LPW, 1>(sm);
     else if (A.sh_nmt == 2) shard_columns_mfma<LPW, 2>(sm);
+    else if (kb12) shard_columns_mfma<LPW, 3, 12>(sm);
     else shard_columns_mfma<LPW, 3>(sm);
   } else
   if (A.sh_nslots * LPW <= SH_MAXO / 2) shard_columns<LPW, SH_MAXO / 2>(sc);   // half-empty slices: half the FMAs

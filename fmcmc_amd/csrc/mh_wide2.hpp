@@ -246,10 +246,13 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
     sm.ncp = NCP; sm.cstride = ng; sm.tfirst = tfirst; sm.tstep = tstep;
     bool lost = false;
 #ifdef FMCMC_STAMP
+#define W2_EVENT(cond, idx) do { if ((cond) && lane == 0 && k >= 48 && (long long)blockIdx.x * 2 < A.nchains) \
+    A.status_theta[(long long)blockIdx.x * 2 * k + (idx)] = (double)__builtin_amdgcn_s_memrealtime(); } while (0)
     unsigned long long ev_acc[4] = {0, 0, 0, 0}, ev_prev = stamp_clk();
 #define W2_EV_STAMP(i) do { if (wave == 2) { const unsigned long long t_ = stamp_clk(); ev_acc[i] += t_ - ev_prev; ev_prev = t_; } } while (0)
 #else
 #define W2_EV_STAMP(i) do { } while (0)
+#define W2_EVENT(cond, idx) do { } while (0)
 #endif
     for (int v = 1; v <= nsteps && !lost; v++) {
       for (int g = 0; g < ng && !lost; g++) {
@@ -269,10 +272,12 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
         }
         if (lost) break;
         W2_EV_STAMP(0);
+        W2_EVENT(wave == 2 && v == 300, 26 + 2 * g);          // proposals of group g, version 300, seen
         const int Ng = (NC + ng - 1 - g) / ng;                  // chains of the group in this launch
         if (Ng > 0) {
           sm.NC = Ng; sm.coff = g; sm.thoff = g * NH;
-          shard_columns_mfma<2, NMT>(sm);
+          if (NMT == 3 && ((p + 3) >> 2) == 12) shard_columns_mfma<2, NMT, (NMT == 3 ? 12 : 0)>(sm);   // (C4's width: compile-time K-block count)
+          else shard_columns_mfma<2, NMT>(sm);
         }
         W2_EV_STAMP(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's partials have been acknowledged
@@ -282,6 +287,8 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
           if (old + 1 == (unsigned)W2_NEVAL * (unsigned)v) w2_arrive(X2, (unsigned)v);   // the last evaluator of the workgroup signals for all
         }
         W2_EV_STAMP(3);
+        W2_EVENT(wave == 2 && v == 300, 27 + 2 * g);          // this wave is past its part of the arrival for the partials
+        W2_EVENT(wave == 5 && v == 300, 36 + g);              // (another evaluator wave, for the spread inside a workgroup)
       }
     }
 #ifdef FMCMC_STAMP
@@ -405,6 +412,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
       if (!ok) { if (lane == 0) w2_lds_st(s_lost, 1u); lost = true; break; }
     }
     W2_OW_STAMP(0);
+    W2_EVENT(v == 300, 24 + 6 * g);                            // partials of version 300 seen (owner of group g)
     bool row_keep = false, fresh_prop = false;
     double row_th0 = 0.0, row_th1 = 0.0, row_f1 = 0.0;
     if (has && (status == FMCMC_CHAIN_OK)) {
@@ -513,6 +521,8 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
     W2_OW_STAMP(4);
     if (v < nsteps) publish((unsigned)(v + 1), fresh_prop);
     W2_OW_STAMP(5);
+    W2_EVENT(v == 300, 25 + 6 * g);                            // version 301 published
+    W2_EVENT(v == 299, 32 + g);                                // version 300 published
     // ---- everything below runs in the shadow of the hand-overs and of this group's matrix-core work
     if (row_keep) {   // row v of ans / draws / logpost (store_row reads L.th0 / L.th1: the saved values go through its registers)
       if (v > burnin) {

@@ -12,7 +12,7 @@ X4 = rng.standard_normal((n, K - 2)); b4 = rng.standard_normal(K - 1); y4 = b4[0
 init4 = np.concatenate([b4, [2.0]])[None, :] + 0.01 * rng.standard_normal((CH, K)); init4[:, -1] = np.abs(init4[:, -1])
 z, o = np.zeros(K), np.ones(K)
 gm = E.DeviceModel(abi.FAM_GAUSSIAN_LINREG, X4, y4)
-gk = E.KernelSpec(kind, K, z, o * (0.002 if kind == 1 else 1.0), -big * o, big * o, np.zeros(K, np.uint8))
+gk = E.KernelSpec(kind, K, z, o * (0.002 if kind == 1 else 1.0), -big * o, big * o, np.zeros(K, np.uint8), until=float(os.environ.get("STAMP_UNTIL", "inf")))
 for _ in range(2):
     st = E.ChainState(init4, gk.kf)
     torch.cuda.synchronize(); t0 = time.time()
