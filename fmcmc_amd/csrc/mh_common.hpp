@@ -72,6 +72,7 @@ struct SweepArgs {
   int* nerrors;
   // observation-sharded evaluation (wide linear models, cooperative launch; 0 = off)
   int sh_ngrp;               // dataflow form (mh_sweep_wide2): chain groups, 2 or 4
+  int sh_tiles;              // dataflow form: 1 = the uneven N-tile shares of its evaluator waves (default), 0 = the even split
   int shard;                 // canonical lanes per workgroup (512 / number of workgroups: 2 or 4)
   int sh_nslots;             // observations per canonical lane, ceil(n / 512); shard * sh_nslots <= SH_MAXO
   const double* sh_xs;       // [G][p][SH_MAXO] the workgroup's observations, column by column, slot-major (0 beyond n)
@@ -546,7 +547,7 @@ struct ShardMfma {
   const double* th;      // [k][ncp] proposals of all chains
   double* part;          // [NC][NT + SH_PAD] lane partials
   unsigned lds;          // LDS address of the block
-  int NC, p, ic, lane0, debug;   // NC: chains of the set this call evaluates
+  int NC, p, ic, lane0, tcount;  // NC: chains of the set this call evaluates; tcount: at most this many tiles (0: no limit)
   int ncp;               // row stride of th (all chains of the launch + SH_PAD)
   int cstride, coff;     // chain of the set's member l: cstride * l + coff (1, 0: all chains; 2, g: chain group g of mh_sweep_wide2)
   int thoff;             // column of member 0 in a row of th; the set's members are CONTIGUOUS there (0: all chains; g NH: group g)
@@ -561,6 +562,7 @@ __device__ __attribute__((noinline)) void shard_columns_mfma(ShardMfma c) {
   const int lane = threadIdx.x & 63;
   const int NC = rfl_i(c.NC), NCP = rfl_i(c.ncp), p = rfl_i(c.p), ic = rfl_i(c.ic), lane0 = rfl_i(c.lane0);
   const int cstride = rfl_i(c.cstride), coff = rfl_i(c.coff), thoff = rfl_i(c.thoff), tfirst = rfl_i(c.tfirst), tstep = rfl_i(c.tstep);
+  const int tcount = rfl_i(c.tcount);
   const int KB = KBC > 0 ? KBC : (p + 3) >> 2;
   const double* thg = (const double*)rfl_u64((unsigned long long)c.th);
   double* part = (double*)rfl_u64((unsigned long long)c.part);
@@ -574,7 +576,9 @@ __device__ __attribute__((noinline)) void shard_columns_mfma(ShardMfma c) {
   for (int t = 0; t < 4 * NMT; t++) ya[t] = blk[32 + 64 * t + lane];
   const ldsc_t xa = blk + SHM_HDR + lane;       // tile (mt, kb) at xa[(mt KB + kb) 64]
   const int kk = lane >> 4, j = lane & 15;
-  const int ntiles = (NC + 15) >> 4;
+  const int ntiles_all = (NC + 15) >> 4;
+  // (the wave's share: tfirst, tfirst + tstep, ..., at most tcount of them)
+  const int ntiles = (tcount > 0 && tfirst + tcount * tstep < ntiles_all) ? tfirst + (tcount - 1) * tstep + 1 : ntiles_all;
   // B operand of N-tile T: coefficient column 4 kb + kk of chain 16 T + j; C operand: its intercept.  Written by other
   // XCDs a barrier ago: every load is a miss of 1-3 us, so the next tile's are in flight under this tile's MFMAs.
   double Bc[SHM_KBMAX], Bn[SHM_KBMAX], c0c = 0.0, c0n = 0.0;
@@ -679,7 +683,7 @@ __device__ __forceinline__ bool eval_sharded(const SweepArgs& A, double* const* 
   sc.lane0 = (int)blockIdx.x * LPW; sc.debug = A.debug;
   if (s_mblk) {
     ShardMfma sm;
-    sm.th = A.sh_th; sm.part = A.sh_part; sm.NC = NC; sm.p = p; sm.ic = ic; sm.lane0 = (int)blockIdx.x * LPW; sm.debug = A.debug;
+    sm.th = A.sh_th; sm.part = A.sh_part; sm.NC = NC; sm.p = p; sm.ic = ic; sm.lane0 = (int)blockIdx.x * LPW; sm.tcount = 0;
     sm.ncp = NCP; sm.cstride = 1; sm.coff = 0; sm.thoff = 0; sm.tfirst = (int)(threadIdx.x >> 6); sm.tstep = NW;   // all chains, N-tiles round robin
     sm.lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const double*)s_mblk;
     const bool kb12 = ((p + 3) >> 2) == 12;   // (config C4's width gets the instantiation with a compile-time K-block count)

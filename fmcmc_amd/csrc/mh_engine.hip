@@ -303,14 +303,14 @@ static SweepArgs chain_window(const SweepArgs& A, long long off, long long cnt, 
 //   mode=<bits>  timing ablations and stamps (SweepArgs.debug)
 // The kernel a call ended up on is reported by fmcmc_last_kernel(); DESIGN.md section 5 has the shape -> kernel table.
 struct Knobs {
-  int streamed = -1, cw = -1, pipe = -1, spec = -1, mfma = -1, owners = -1, shard = -1, shard_mfma = -1, wide2 = -1, groups = -1, mode = 0;
+  int streamed = -1, cw = -1, pipe = -1, spec = -1, mfma = -1, owners = -1, shard = -1, shard_mfma = -1, wide2 = -1, groups = -1, tiles = -1, mode = 0;
 };
 static Knobs read_knobs() {
   Knobs K;
   const char* e = getenv("FMCMC_AMD_DEBUG");
   if (!e) return K;
   struct { const char* name; int* dst; } tab[] = {{"streamed", &K.streamed}, {"cw", &K.cw}, {"pipe", &K.pipe}, {"spec", &K.spec},
-      {"mfma", &K.mfma}, {"owners", &K.owners}, {"shard_mfma", &K.shard_mfma}, {"shard", &K.shard}, {"wide2", &K.wide2}, {"groups", &K.groups}, {"mode", &K.mode}};
+      {"mfma", &K.mfma}, {"owners", &K.owners}, {"shard_mfma", &K.shard_mfma}, {"shard", &K.shard}, {"wide2", &K.wide2}, {"groups", &K.groups}, {"tiles", &K.tiles}, {"mode", &K.mode}};
   while (*e) {
     const char* eq = strchr(e, '=');
     const char* end = strchr(e, ',');
@@ -680,6 +680,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
       lds = sizeof(double) * wide2_lds_doubles(kn->k, kf, kn->kind, A.kz, mblk);
       g_kernel = "wide-dataflow";
       A.sh_ngrp = (K.groups == 4) ? 4 : 2;
+      A.sh_tiles = (K.tiles == 0 || A.sh_ngrp == 4) ? 0 : 1;
     }
     if (shard) {
       int coop = 0, perCU = 0;

@@ -238,10 +238,20 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
     // =========================================== evaluator waves ===========================================
     // N-tiles of a group dealt so that the four SIMDs get the same number (waves w and w + 4 share SIMD w % 4; waves 0, 1 are
     // the owners): SIMD 0 -> wave 4, SIMD 1 -> wave 5, SIMD 2 -> waves 2, 6 alternating, SIMD 3 -> waves 3, 7
-    const int tfirst = (wave == 4) ? 0 : (wave == 5) ? 1 : (wave == 2) ? 2 : (wave == 6) ? 6 : (wave == 3) ? 3 : 7;
-    const int tstep = (wave == 4 || wave == 5) ? 4 : 8;
+    // The single evaluator waves of SIMDs 0 and 1 share their SIMD with an owner wave and have no partner to overlap a tile's
+    // epilogue with: of 16 tiles they take 3 each (wave 4: 0, 1, 2; wave 5: 3, 4, 5), the pairs of SIMDs 2 and 3 take 5
+    // (waves 2 / 6: 6, 8, 10 / 7, 9; waves 3 / 7: 11, 13, 15 / 12, 14).  Knob tiles=0: the even split 4 | 4 | 2 + 2 | 2 + 2.
+    int tfirst, tstep, tcount = 0;
+    if (A.sh_tiles == 0) {
+      tfirst = (wave == 4) ? 0 : (wave == 5) ? 1 : (wave == 2) ? 2 : (wave == 6) ? 6 : (wave == 3) ? 3 : 7;
+      tstep = (wave == 4 || wave == 5) ? 4 : 8;
+    } else {
+      tfirst = (wave == 4) ? 0 : (wave == 5) ? 3 : (wave == 2) ? 6 : (wave == 6) ? 7 : (wave == 3) ? 11 : 12;
+      tstep = (wave == 4 || wave == 5) ? 1 : 2;
+      tcount = (wave == 6 || wave == 7) ? 2 : 3;
+    }
     ShardMfma sm;
-    sm.th = A.sh_th; sm.part = A.sh_part; sm.p = p; sm.ic = ic; sm.lane0 = (int)blockIdx.x * 2; sm.debug = A.debug;
+    sm.th = A.sh_th; sm.part = A.sh_part; sm.p = p; sm.ic = ic; sm.lane0 = (int)blockIdx.x * 2; sm.tcount = tcount;
     sm.lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const double*)s_blk;
     sm.ncp = NCP; sm.cstride = ng; sm.tfirst = tfirst; sm.tstep = tstep;
     bool lost = false;

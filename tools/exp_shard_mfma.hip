@@ -34,7 +34,7 @@ __global__ __launch_bounds__(NT) void bench(const double* th, double* part, doub
   if (tid < 64) ((unsigned*)smem)[tid] = 0xfffu;
   __syncthreads();
   ShardMfma sm;
-  sm.th = th; sm.part = part; sm.p = p; sm.ic = 1; sm.lane0 = (int)blockIdx.x * 2; sm.debug = 0;
+  sm.th = th; sm.part = part; sm.p = p; sm.ic = 1; sm.lane0 = (int)blockIdx.x * 2; sm.tcount = 0;
   sm.lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const double*)smem;
   sm.NC = nchains; sm.ncp = 2 * nchains + SH_PAD; sm.cstride = 2; sm.coff = 0; sm.thoff = 0;
   bool active = false;
