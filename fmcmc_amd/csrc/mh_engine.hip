@@ -299,7 +299,7 @@ static SweepArgs chain_window(const SweepArgs& A, long long off, long long cnt, 
 //   mfma=0       VALU evaluation instead of the fp64-MFMA kernels owners=0|1  replicated-state / owner-wave MFMA kernel
 //   shard=0|1    wide models: never / always (when eligible) observation-sharded; unset: cost model
 //   shard_mfma=0 VALU form of the sharded slice product           wide2=0|1   never / always (when eligible) the dataflow form
-//   groups=4     four chain groups in the dataflow form (default two)
+//   groups=4     four chain groups in the dataflow form (default two)       tiles=0     even N-tile shares of its evaluator waves
 //   mode=<bits>  timing ablations and stamps (SweepArgs.debug)
 // The kernel a call ended up on is reported by fmcmc_last_kernel(); DESIGN.md section 5 has the shape -> kernel table.
 struct Knobs {
