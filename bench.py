@@ -17,8 +17,12 @@ Inputs (X, y, initial states) are resident in HBM before the timed region.
   shard, chain ids continue across ranks, no data-path collective)
 
 The line reports what was measured in THIS run: roofline.kernel is fmcmc_last_kernel() (and the run fails if the dispatcher
-did not pick the kernel the config is tuned for), roofline.kernel_ms comes from HIP events on the launch stream, and
-roofline.traffic is null unless a PMC pass of the same command is named (profiles/README.md says how those are taken).
+did not pick the kernel the config is tuned for), roofline.kernel_ms comes from HIP events on the launch stream.  roofline.traffic cannot be measured from inside the process
+(PMC counters): it is the figure of the newest COMMITTED PMC pass of this same command, labelled as such in
+roofline.traffic_source (file, the commit that pass measured, its kernel and duration) and shown only while the dispatcher
+still picks the kernel that pass measured; null otherwise (profiles/README.md says how those passes are taken).
+The default (headline) invocation on one GPU additionally runs a short full-size sweep of C3, C4 and C5 and reports them
+under `configs` (value, kernel, kernel_ms, bound, frac each), so that one driver-timed run covers all four GPU configs.
 """
 import argparse
 import json
@@ -133,88 +137,97 @@ def oracle_objects(cfg, O, X, y):
     return m, O.Kernel({1: O.K_NORMAL, 2: O.K_NORMAL_REFLECTIVE, 3: O.K_ADAPT, 4: O.K_RAM}[ka["kind"]], cfg.k, **kw)
 
 
-def cpu_baseline(cfg, seconds_budget=20.0):
+def host_cores():
+    """Threads this process may really use: the affinity mask, capped by the cgroup CPU quota (os.cpu_count() ignores both)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(cfg, seconds_budget=24.0):
     """The oracle (PHILOX / canonical mode = the GPU's exact outputs) timed on the host cores on a bounded sample of the SAME
-    workload: (a) all host threads, one block of chains per thread -- the analogue of fmcmc's multicore = TRUE with
-    min(nchains, detectCores()) workers (R/mcmc.R:539-541); (b) one thread."""
+    workload: (a) all usable host threads, one block of chains per thread -- the analogue of fmcmc's multicore = TRUE with
+    min(nchains, detectCores()) workers (R/mcmc.R:539-541); (b) one thread.  Both samples are sized
+    from the STEADY-STATE cost per iteration (the difference of two short runs: thread start-up, the first evaluation and
+    the page faults of the outputs cancel), so that each really runs for its share of the budget."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     X, y, init0 = cfg.workload(cores, 0)
     m, k = oracle_objects(cfg, O, X, y)
 
     def run(init, lo, iters):
         O.run(m, k, init, nsteps=iters, thin=cfg.thin if iters > cfg.thin else 1, seed=CHAIN_SEED, chain_base=lo, want_draws=True)
 
-    # (b) one thread: calibrate on a few iterations, then ~1/4 of the budget (whole chains when a chain fits)
-    t = time.time(); run(init0[:1], 0, 21); per1 = (time.time() - t) / 20
-    it1 = int(max(50, min(cfg.iters, 0.25 * seconds_budget / per1)))
-    ch1 = int(max(1, min(cores, 0.25 * seconds_budget / (per1 * it1))))
-    t = time.time(); run(init0[:ch1], 0, it1); dt1 = time.time() - t
+    def timed(fn):
+        t = time.perf_counter(); fn(); return time.perf_counter() - t
+
+    def steady(fn, lo_it, hi_it):           # seconds per iteration of one chain, fixed costs removed
+        a, b = timed(lambda: fn(lo_it)), timed(lambda: fn(hi_it))
+        return max(b - a, 1e-9) / (hi_it - lo_it)
+
+    def all_threads(inits, per_thread, iters):
+        with ThreadPoolExecutor(cores) as ex:             # ctypes releases the GIL: one oracle call per host thread
+            list(ex.map(lambda tix: run(inits[tix * per_thread:(tix + 1) * per_thread], tix * per_thread, iters), range(cores)))
+
+    # (b) one thread: ~1/4 of the budget (whole chains when a chain fits)
+    per1 = steady(lambda it: run(init0[:1], 0, it), 11, 61)
+    want1 = 0.25 * seconds_budget
+    it1 = int(max(50, min(cfg.iters, want1 / per1)))
+    ch1 = int(max(1, min(cores, want1 / (per1 * it1))))
+    dt1 = timed(lambda: run(init0[:ch1], 0, it1))
     single = {"value": ch1 * (it1 - 1) / dt1, "unit": "MH samples/s", "cores": 1,
               "sample": "%d chain(s) x %d iterations" % (ch1, it1), "seconds": dt1}
-    # (a) all threads busy: calibrate under full load (SMT and memory contention included), then size the sample
-    t = time.time()
-    with ThreadPoolExecutor(cores) as ex:
-        list(ex.map(lambda tix: run(init0[tix:tix + 1], tix, 21), range(cores)))
-    per = (time.time() - t) / 20
+    # (a) all threads busy: steady-state cost under full load (SMT and memory contention included), then size the sample
+    per = steady(lambda it: all_threads(init0, 1, it), 11, 61)
     want = 0.75 * seconds_budget
     if per * cfg.iters <= want:                       # whole chains: several per thread
-        per_thread, iters = int(max(1, min(64, want / (per * cfg.iters)))), cfg.iters
+        per_thread, iters = int(max(1, min(256, want / (per * cfg.iters)))), cfg.iters
     else:                                             # a chain is longer than the budget: a prefix of its iterations
         per_thread, iters = 1, int(max(50, want / per))
     chains = cores * per_thread
     _, _, init = cfg.workload(chains, 0)
-    t = time.time()
-    with ThreadPoolExecutor(cores) as ex:             # ctypes releases the GIL: one oracle call per host thread
-        list(ex.map(lambda tix: run(init[tix * per_thread:(tix + 1) * per_thread], tix * per_thread, iters), range(cores)))
-    dt = time.time() - t
-    return {"value": chains * (iters - 1) / dt, "unit": "MH samples/s", "cores": cores, "kind": "port", "seconds": dt,
+    dt = timed(lambda: all_threads(init, per_thread, iters))
+    value = chains * (iters - 1) / dt
+    return {"value": value, "unit": "MH samples/s", "cores": cores, "kind": "port", "seconds": dt,
+            "cores_note": "threads used = len(os.sched_getaffinity(0)) capped by the cgroup cpu.max quota (os.cpu_count() = %d)" % (os.cpu_count() or 0),
+            "parallel_efficiency": value / (cores * single["value"]),
             "sample": "%d chains x %d iterations of the same workload (%d chains per host thread), oracle/fmcmc_oracle.c in "
                       "PHILOX/canonical mode: a C restatement of fmcmc's R loop that produces the GPU's exact outputs; "
                       "optimistic vs interpreted R" % (chains, iters, per_thread),
             "single_thread": single}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=0, help="timed steps (default: about 5 s of GPU time for the config: c2 240, c3 140, c4 20, c5 6)")
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"])
-    ap.add_argument("--iters", type=int, default=0, help="MH iterations per sweep (default: the config's nsteps)")
-    ap.add_argument("--chains", type=int, default=0, help="chains per GPU (default: the config's per-GPU share)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--traffic-from", default=None, help="JSON of a PMC pass of this same command (hbm_bytes_per_launch)")
-    args = ap.parse_args()
-    cfg = Config(args.config)
-    if args.steps <= 0:   # a timed region of about five seconds (one step = one sweep of the config's nsteps iterations)
-        args.steps = {"c2": 240, "c3": 140, "c4": 20, "c5": 6}[cfg.name]
+KERNEL_FN = {"mfma": "mh_sweep_mfma", "wide-dataflow": "mh_sweep_wide2", "spec": "mh_sweep_spec", "streamed-logistic": "mh_sweep_kernel"}
+# what the dominant kernel of a config is bound by: C2 / C4 evaluate on the matrix cores, C3 / C5 on the fp64 VALU.  Either
+# way the peak is the ONE fp64 datapath of MI355X (fp64 matrix peak == fp64 vector peak, 78.6 TFLOP/s).
+BOUND = {"c2": "mfma", "c3": "valu", "c4": "mfma", "c5": "valu"}
+DEFAULT_STEPS = {"c2": 240, "c3": 140, "c4": 20, "c5": 6}
+EXTRA_STEPS = {"c3": 20, "c4": 3, "c5": 2}     # the short sweeps of the other configs inside the default (headline) invocation
 
-    import torch
-    import torch.distributed as dist
-    from fmcmc_amd import engine as E, _abi as abi
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-
-    chains = args.chains or cfg.chains
-    iters = args.iters or cfg.iters
+def run_config(cfg, chains, iters, steps, warmup, world, rank, dev, dist, torch, E, abi):
+    """W warm-up steps, then exactly K timed steps of one config between barriers; returns what was measured."""
     thin, k = cfg.thin, cfg.k
     chain_base = rank * chains
     X, y, init = cfg.workload(chains, chain_base)
     gm, gk = device_objects(cfg, E, abi, X, y, dev)
     init_d = torch.as_tensor(init).to(dev)
-    S = (iters - 0) // thin
+    S = iters // thin
     picked = []
+    cur = {"s": None}
+    ev_mid = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    ev_chk = []
+    bulks = None
+    chk = None
 
     if cfg.name == "c4":
         # the config's own loop: bulks of 1000 iterations appended to one preallocated history (fmcmc_out.ld_rows), the Gelman
@@ -225,14 +238,12 @@ def main():
         bulks = [cfg.bulk] * (iters // cfg.bulk) + ([iters % cfg.bulk] if iters % cfg.bulk else [])
         hist = DeviceChains.allocate(chains, k, S, thin, None, chain_base, world * chains, dev, want_logpost=True, want_draws=False)
         free = np.arange(k)
-        ev_chk = []
 
         def one_step():
             st = E.ChainState(init_d, k, device=dev)
             hist.nrows, hist.iters = 0, np.zeros(0, dtype=np.int64)
             chk.flush()
             out = None
-            tchk = 0.0
             for nb in bulks:
                 out = E.sweep(gm, gk, st, nb, thin=thin, seed=CHAIN_SEED, chain_base=chain_base, want_bits=False, check=False,
                               into=(hist._samples, hist._logpost, None), row0=hist.nrows)
@@ -265,19 +276,17 @@ def main():
             picked.append(abi.last_kernel())
             return out
 
-    ev_mid = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    cur = {"s": None}
-    for _ in range(args.warmup):
+    out = None
+    for _ in range(warmup):
         out = one_step()
     torch.cuda.synchronize()
-    if cfg.name == "c4":
-        ev_chk.clear()
+    ev_chk.clear()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     t0 = time.perf_counter()
-    for s in range(args.steps):
+    for s in range(steps):
         cur["s"] = s
         ev[s][0].record()            # same stream the kernels are launched on
         out = one_step()
@@ -296,57 +305,141 @@ def main():
     if bad and chains == cfg.chains and iters == cfg.iters:
         raise SystemExit("bench.py --config %s: the dispatcher picked %s, the config is measured on '%s'" % (cfg.name, bad, cfg.expect_kernel))
     # kernel duration from HIP events on the launch stream
-    step_ms = float(np.mean([ev[s][0].elapsed_time(ev[s][1]) for s in range(args.steps)]))
+    step_ms = float(np.mean([ev[s][0].elapsed_time(ev[s][1]) for s in range(steps)]))
     if cfg.name == "c4":
-        chk_ms = float(np.sum([a.elapsed_time(b) for a, b in ev_chk])) / args.steps      # all checks of a step
+        chk_ms = float(np.sum([a.elapsed_time(b) for a, b in ev_chk])) / steps      # all checks of a step
         kern_ms, extra = step_ms - chk_ms, {"gelman_checks_ms_per_step": chk_ms, "bulks_per_step": len(bulks),
                                             "launches_per_step": len(bulks), "rhat_last": chk.last}
     elif cfg.name in ("c2", "c3"):
-        kern_ms = float(np.mean([ev_mid[s].elapsed_time(ev[s][1]) for s in range(args.steps)]))   # sweep kernel (+ output memsets)
+        kern_ms = float(np.mean([ev_mid[s].elapsed_time(ev[s][1]) for s in range(steps)]))   # sweep kernel (+ output memsets)
         extra = {"rng_fill_kernel_ms": step_ms - kern_ms}
     else:
         kern_ms, extra = step_ms, {}
     samples_per_step = chains * (iters - 1)
-    value = world * samples_per_step * args.steps / elapsed
     acc = float(out.accept_count.double().mean().item()) / ((bulks[-1] if cfg.name == "c4" else iters) - 1)
+    return {"cfg": cfg, "chains": chains, "iters": iters, "steps": steps, "warmup": warmup, "world": world, "S": S,
+            "elapsed": elapsed, "value": world * samples_per_step * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps,
+            "kern_ms": kern_ms, "extra": extra, "picked": sorted(set(picked)), "accept_rate": acc,
+            "samples_per_step": samples_per_step, "chain_base": chain_base}
+
+
+def roofline_block(res, traffic_from=None):
+    cfg, kern_ms, chains, iters = res["cfg"], res["kern_ms"], res["chains"], res["iters"]
+    k, S = cfg.k, res["S"]
+    ach_tflops = res["samples_per_step"] * cfg.flops / (kern_ms * 1e-3) / 1e12
+    out_bytes = chains * S * ((1 if cfg.name == "c4" else 2) * k + 1) * 8
+    # HBM bytes per launch of the sweep kernel: PMC counters cannot be read from inside this process, so `traffic` is NOT a
+    # measurement of this run: it is the figure of the newest committed PMC pass of this same command
+    # (profiles/latest_pmc_<config>.json, written by tools/profile_bench.sh, which records the commit it measured), shown only
+    # while the dispatcher still picks the kernel that pass measured, and labelled as such in traffic_source; null otherwise.
+    traffic, tsrc = None, None
+    here = os.path.dirname(os.path.abspath(__file__))
+    tfile = traffic_from or os.path.join(here, "profiles", "latest_pmc_%s.json" % cfg.name)
+    if os.path.exists(tfile):
+        trec = json.load(open(tfile))
+        if traffic_from or all(KERNEL_FN.get(pk, pk) in trec.get("kernel", "") for pk in res["picked"]):
+            traffic = trec.get("hbm_bytes_per_launch")
+            tsrc = {"measured_in_this_run": False, "file": os.path.relpath(tfile, here), "pass_of_commit": trec.get("head"),
+                    "pass_kernel": trec.get("kernel"), "pass_kernel_avg_ns": trec.get("kernel_avg_ns_rocprof")}
+    rl = {"bound": BOUND[cfg.name],
+          "pipe": "fp64 datapath (MFMA and VALU share it: MI355X fp64 matrix peak == fp64 vector peak); this config evaluates on the %s"
+                  % ("matrix cores (v_mfma_f64)" if BOUND[cfg.name] == "mfma" else "fp64 VALU"),
+          "achieved": ach_tflops, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+          "frac": ach_tflops / PEAK_FP64_TFLOPS, "traffic": traffic, "traffic_source": tsrc,
+          "kernel": res["picked"][0] if len(res["picked"]) == 1 else res["picked"],
+          "kernel_ms": kern_ms, "flops_per_sample": cfg.flops, "flops_note": cfg.flops_note,
+          "hbm": {"achieved_GBps": out_bytes / (kern_ms * 1e-3) / 1e9, "peak_GBps": PEAK_HBM_GBS,
+                  "algorithmic_bytes_per_step": out_bytes}}
+    rl.update(res["extra"])
+    if cfg.name == "c4":
+        rl["frac_survey_E2"] = res["samples_per_step"] * 1.98e6 / (kern_ms * 1e-3) / 1e12 / PEAK_FP64_TFLOPS
+    return rl
+
+
+def workload_text(res):
+    cfg = res["cfg"]
+    return "configs[%d] (%s): %d chains/GPU x %d-param %s n=%d, %s, nsteps=%d, outputs ans+logpost%s" % (
+        cfg.num - 1, cfg.name.upper(), res["chains"], cfg.k, "Gaussian linreg" if cfg.family == "linreg" else "logistic regression",
+        cfg.n, cfg.kernel_name, res["iters"], "" if cfg.name == "c4" else "+draws")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (default: about 5 s of GPU time for the config: c2 240, c3 140, c4 20, c5 6)")
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--iters", type=int, default=0, help="MH iterations per sweep (default: the config's nsteps)")
+    ap.add_argument("--chains", type=int, default=0, help="chains per GPU (default: the config's per-GPU share)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true", help="headline invocation only: skip the short C3 / C4 / C5 sweeps reported under `configs`")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for N > 1 (nccl = RCCL; gloo moves the tensors through the host: tests on one GPU)")
+    ap.add_argument("--traffic-from", default=None, help="JSON of a PMC pass of this same command (hbm_bytes_per_launch)")
+    args = ap.parse_args()
+    cfg = Config(args.config)
+    if args.steps <= 0:   # a timed region of about five seconds (one step = one sweep of the config's nsteps iterations)
+        args.steps = DEFAULT_STEPS[cfg.name]
+
+    import torch
+    import torch.distributed as dist
+    from fmcmc_amd import engine as E, _abi as abi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    if args.backend == "gloo":
+        local_rank = local_rank % max(1, torch.cuda.device_count())      # several ranks may share the one GPU of a test box
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+
+    chains = args.chains or cfg.chains
+    iters = args.iters or cfg.iters
+    res = run_config(cfg, chains, iters, args.steps, args.warmup, world, rank, dev, dist, torch, E, abi)
+
+    # the other GPU configs of BASELINE.md section 4 as short full-size sweeps, so that the driver's clock covers them too
+    # (headline invocation on one GPU only; `--config cX` gives each its own full line, `--gpus N` its scaling)
+    extras = {}
+    if cfg.name == "c2" and world == 1 and not args.no_extra_configs and not args.chains and not args.iters:
+        for name in ("c3", "c4", "c5"):
+            xc = Config(name)
+            t_x = time.perf_counter()
+            xr = run_config(xc, xc.chains, xc.iters, EXTRA_STEPS[name], 1, 1, 0, dev, dist, torch, E, abi)
+            rl = roofline_block(xr)
+            extras[name] = {"workload": workload_text(xr), "value": xr["value"], "unit": "MH samples/s", "steps": xr["steps"], "warmup": 1,
+                            "ms_per_step": xr["ms_per_step"], "accept_rate": xr["accept_rate"], "kernel": rl["kernel"],
+                            "kernel_ms": rl["kernel_ms"], "bound": rl["bound"], "achieved": rl["achieved"], "peak": rl["peak"],
+                            "frac": rl["frac"], "flops_per_sample": rl["flops_per_sample"], "traffic": rl["traffic"],
+                            "traffic_source": rl["traffic_source"], "wall_s_incl_setup": None}
+            for key in ("gelman_checks_ms_per_step", "rng_fill_kernel_ms", "frac_survey_E2"):
+                if key in rl:
+                    extras[name][key] = rl[key]
+            extras[name]["wall_s_incl_setup"] = time.perf_counter() - t_x
 
     if rank == 0:
-        ach_tflops = samples_per_step * cfg.flops / (kern_ms * 1e-3) / 1e12
-        out_bytes = chains * S * ((1 if cfg.name == "c4" else 2) * k + 1) * 8
-        # HBM bytes per launch of the sweep kernel: PMC counters cannot be read from inside this process, so the value comes
-        # from the committed PMC pass of this same command (profiles/latest_pmc_<config>.json, taken by
-        # tools/profile_bench.sh) -- only while the dispatcher still picks the kernel that pass measured; null otherwise
-        traffic, tsrc = None, None
-        tfile = args.traffic_from or os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "latest_pmc_%s.json" % cfg.name)
-        if os.path.exists(tfile):
-            trec = json.load(open(tfile))
-            names = {"mfma": "mh_sweep_mfma", "wide-dataflow": "mh_sweep_wide2", "spec": "mh_sweep_spec"}
-            if args.traffic_from or all(names.get(pk, pk) in trec.get("kernel", "") for pk in set(picked)):
-                traffic, tsrc = trec.get("hbm_bytes_per_launch"), os.path.relpath(tfile, os.path.dirname(os.path.abspath(__file__)))
         metric = "MH samples/sec (chains x iters / s), 1024 chains, 5-param linreg n=10k" if cfg.name == "c2" else \
                  "MH samples/sec (chains x iters / s), config %s" % cfg.name.upper()
         line = {
             "metric": metric,
-            "value": value, "unit": "MH samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "value": res["value"], "unit": "MH samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "configs[%d] (%s): %d chains/GPU x %d-param %s n=%d, %s, nsteps=%d, outputs ans+logpost%s" % (
-                           cfg.num - 1, cfg.name.upper(), chains, k, "Gaussian linreg" if cfg.family == "linreg" else "logistic regression",
-                           cfg.n, cfg.kernel_name, iters, "" if cfg.name == "c4" else "+draws"),
-                       "chains_per_gpu": chains, "iters_per_step": iters, "thin": thin, "accept_rate": acc,
+            "config": {"workload": workload_text(res),
+                       "chains_per_gpu": chains, "iters_per_step": iters, "thin": cfg.thin, "accept_rate": res["accept_rate"],
                        "parallelism": "chains sharded, %d rank(s), %s" % (world, "one all-reduce of 1 + 5p + 2p^2 doubles per Gelman check"
-                                                                          if cfg.name == "c4" else "no data-path collective")},
-            "roofline": {"bound": "mfma", "pipe": "fp64 datapath (MFMA and VALU share it: MI355X fp64 matrix peak == fp64 vector peak)",
-                         "achieved": ach_tflops, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach_tflops / PEAK_FP64_TFLOPS, "traffic": traffic, "traffic_source": tsrc,
-                         "kernel": sorted(set(picked))[0] if len(set(picked)) == 1 else sorted(set(picked)),
-                         "kernel_ms": kern_ms, "flops_per_sample": cfg.flops, "flops_note": cfg.flops_note,
-                         "hbm": {"achieved_GBps": out_bytes / (kern_ms * 1e-3) / 1e9, "peak_GBps": PEAK_HBM_GBS,
-                                 "algorithmic_bytes_per_step": out_bytes}},
+                                                                          if cfg.name == "c4" else "no data-path collective"),
+                       "backend": (args.backend if world > 1 else None), "chain_base_of_rank": {"0": res["chain_base"]}},
+            "roofline": roofline_block(res, args.traffic_from),
         }
-        line["roofline"].update(extra)
-        if cfg.name == "c4":
-            line["roofline"]["frac_survey_E2"] = samples_per_step * 1.98e6 / (kern_ms * 1e-3) / 1e12 / PEAK_FP64_TFLOPS
+        if extras:
+            line["configs"] = extras
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(line))
