@@ -304,13 +304,21 @@ __device__ __forceinline__ ChainLds chain_lds(double* base, int k, int kf, int k
 // every element, so the same bits -- but each constant is materialised ONCE per observation instead of once per chain
 // (FMH_K costs two scalar moves per use), the CW dependent chains interleave, and the out-of-range test is one branch
 // per observation.
-// The table (2401 rows of 32 bytes: softplus(a_j) hi, lo, sigma_j, -) is staged in LDS by the logistic-only kernel
-// instantiations: a lookup from global memory is a 64-address gather, ~64 cycles of the texture addresser; from LDS it is
-// one ds_read_b128 + one ds_read_b64.
-constexpr int SP_LDS_DOUBLES = FMH_SPG_ROWS * 4;
+// The table (2401 rows: softplus(a_j) hi, lo, sigma_j) is staged in LDS by the logistic-only kernel instantiations: a lookup
+// from global memory is a 64-address gather, ~64 cycles of the texture addresser.  In LDS it is three arrays (SoA) read with
+// three ds_read_b64: the rows a wave looks up are scattered (one per lane, by eta), so what a lookup costs is bank
+// conflicts, and those depend on how many distinct bank positions the rows of ONE read can fall on.  As 32-byte rows
+// (round 2: ds_read2_b64 + ds_read_b64) a row started on one of 8 positions and 32 lanes into 8 positions is a 7-way
+// conflict on average: rocprofv3 PMC at config C5, SQ_LDS_BANK_CONFLICT = 83 % of SQ_LDS_IDX_ACTIVE and the LDS busy for
+// the whole kernel (profiles/r03_a_c5_summary.json) -- the loop was LDS-bound, not issue-bound.  With 8-byte elements a
+// read has 32 positions (~3.3-way for random rows) and the table takes 57.6 KB instead of 76.8.
+constexpr int SP_LDS_DOUBLES = FMH_SPG_ROWS * 3;
 __device__ __forceinline__ void softplus_stage_tables(double* s_tab) {
   const double* t = fmh_spg_tab_();
-  for (int i = threadIdx.x; i < SP_LDS_DOUBLES; i += blockDim.x) s_tab[i] = t[i];
+  for (int i = threadIdx.x; i < FMH_SPG_ROWS * 4; i += blockDim.x) {
+    const int j = i >> 2, c = i & 3;
+    if (c < 3) s_tab[c * FMH_SPG_ROWS + j] = t[i];
+  }
 }
 
 // LDSTAB is a COMPILE-TIME property (the logistic-only instantiations always stage the table): decided at run time the two
@@ -338,9 +346,8 @@ __device__ __forceinline__ void softplus_nonpos_vec(const double (&a)[CW], doubl
       int j = -(int32_t)(uint32_t)fmh_d2u(t);
       if (!LDSTAB) j = (j < 0) ? 0 : (j > FMH_SPG_ROWS - 1 ? FMH_SPG_ROWS - 1 : j);
       r[c] = fmh_fma(kd, -0.015625, a[c]);
-      const unsigned int ti = 4u * (unsigned int)j;
-      if constexpr (LDSTAB) { sh[c] = ltab[ti]; sl[c] = ltab[ti + 1]; sg[c] = ltab[ti + 2]; }
-      else { sh[c] = gtab[ti]; sl[c] = gtab[ti + 1]; sg[c] = gtab[ti + 2]; }
+      if constexpr (LDSTAB) { sh[c] = ltab[j]; sl[c] = ltab[FMH_SPG_ROWS + j]; sg[c] = ltab[2 * FMH_SPG_ROWS + j]; }
+      else { const unsigned int ti = 4u * (unsigned int)j; sh[c] = gtab[ti]; sl[c] = gtab[ti + 1]; sg[c] = gtab[ti + 2]; }
     }
   }
   {
@@ -705,6 +712,273 @@ __device__ __forceinline__ bool eval_sharded(const SweepArgs& A, double* const* 
   return ok;
 }
 
+// ---- logistic family: log-likelihood terms of one observation for all CW chains: logq(eta) == logp(-eta), softplus tail
+// on -|eta| (twin of the oracle's logistic loop; R: vignettes/workflow-with-fmcmc.Rmd:35-41)
+#ifndef FMCMC_SP_GROUP
+#define FMCMC_SP_GROUP 4
+#endif
+template <int CW, bool LDSTAB>
+__device__ __forceinline__ void logit_add_terms(const double (&eta)[CW], bool y1, double (&acc)[CW], const double* s_sptab) {
+  double sg[CW], ab[CW], l1[CW];
+  // sg = y ? eta : -eta and ab = -|sg| as sign-bit operations (one integer instruction each; written as selects they
+  // were seven per chain).  Same values as the oracle's selects: a -0 / +0 difference in ab cannot reach the result.
+  const unsigned long long flip = y1 ? 0ull : 0x8000000000000000ull;
+#pragma unroll
+  for (int c = 0; c < CW; c++) {
+    sg[c] = fmh_u2d(fmh_d2u(eta[c]) ^ flip);
+    ab[c] = fmh_u2d(fmh_d2u(sg[c]) | 0x8000000000000000ull);
+  }
+  constexpr int G = (CW < FMCMC_SP_GROUP) ? CW : FMCMC_SP_GROUP;   // chains per softplus batch (register pressure vs constant re-use)
+#pragma unroll
+  for (int g0 = 0; g0 < CW; g0 += G) {
+    double ag[G], lg[G];
+#pragma unroll
+    for (int c = 0; c < G; c++) ag[c] = ab[g0 + c];
+    softplus_nonpos_vec<G, LDSTAB>(ag, lg, s_sptab);
+#pragma unroll
+    for (int c = 0; c < G; c++) l1[g0 + c] = lg[c];
+  }
+#pragma unroll
+  for (int c = 0; c < CW; c++) acc[c] = acc[c] + (__builtin_fmin(sg[c], 0.0) - l1[c]);   // == (sg < 0) ? sg - l1 : -l1, bit for bit
+}
+
+// The evaluation of the logistic-only instantiations (PL covariates known at compile time, the CW (PL + 1) coefficients in
+// SGPRs for the whole pass, softplus table in LDS) as a REAL function: the sweep kernel calls it from two places (row 1 and the
+// step loop), and inlined the copy inside the step loop shared its register allocation with everything the sweep keeps
+// live across an evaluation -- 256 VGPRs, 228 bytes of scratch per lane, 1118 spilled SGPRs, 18 v_readlane reloads in
+// every pass of the observation loop (210 instructions per observation against 188 in the copy in front of the loop).
+// Arguments travel in registers (16 dwords); everything uniform goes through v_readfirstlane.
+struct LogitEval {
+  const double* X;       // [p][n]
+  const double* y;       // [n]
+  long long n;
+  int ic, p;
+  unsigned th0, thstride, ncw;   // LDS address of chain 0's coefficient vector, bytes between chains, chains of the workgroup
+  unsigned tab;          // LDS address of the softplus table (logistic-only instantiations)
+  unsigned part;         // LDS address of s_part [NW][CW]
+};
+static_assert(sizeof(LogitEval) <= 64, "LogitEval must travel in registers (16 dwords)");
+__device__ __forceinline__ unsigned logit_th_addr(const LogitEval& a, int c) {   // (a slot without a chain re-reads chain 0)
+  const unsigned ncw = (unsigned)__builtin_amdgcn_readfirstlane((int)a.ncw);
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)a.th0) + ((unsigned)c < ncw ? (unsigned)c : 0u) * (unsigned)__builtin_amdgcn_readfirstlane((int)a.thstride);
+}
+template <int CW, int PL>
+__device__ __attribute__((noinline)) void logit_partials(LogitEval a) {
+  typedef __attribute__((address_space(3))) const double* ldsc_t;
+  typedef __attribute__((address_space(3))) double* ldsw_t;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ic = __builtin_amdgcn_readfirstlane(a.ic);
+  const unsigned int nn = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned)a.n);
+  const unsigned long long Xu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)a.X >> 32)) << 32) |
+                                (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)a.X);
+  const unsigned long long yu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)a.y >> 32)) << 32) |
+                                (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)a.y);
+  const double* s_sptab = (const double*)(ldsc_t)(unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)a.tab);
+  double b0[CW], bs[CW][PL > 0 ? PL : 1];
+#pragma unroll
+  for (int c = 0; c < CW; c++) {
+    const ldsc_t th = (ldsc_t)(unsigned long long)logit_th_addr(a, c);
+    b0[c] = ic ? sgpr_d(th[0]) : 0.0;
+#pragma unroll
+    for (int u = 0; u < PL; u++) bs[c][u] = sgpr_d(th[ic + u]);
+  }
+  // global (not generic) pointers, scalar column bases and a 32-bit lane index: one global_load per value with no
+  // 64-bit address arithmetic
+  typedef const double __attribute__((address_space(1))) * gptr_t;
+  typedef const char __attribute__((address_space(1))) * gcptr_t;
+  gptr_t colp[PL > 0 ? PL : 1];
+#pragma unroll
+  for (int u = 0; u < PL; u++) colp[u] = (gptr_t)(Xu + 8ull * (unsigned long long)u * nn);
+  const gptr_t yp = (gptr_t)yu;
+  // (the lane's offset in BYTES as a 32-bit value -- n < 2^28 -- so that every load is `scalar base + 32-bit VGPR offset`)
+  auto ldg = [](gptr_t base, unsigned int boff) -> double { return *(gptr_t)((gcptr_t)base + boff); };
+  double acc[CW];
+#pragma unroll
+  for (int c = 0; c < CW; c++) acc[c] = 0.0;
+  // ---- the observation loop, written out (round 3).  Per element EXACTLY the operations of fmh_log1p_exp_nonpos /
+  // softplus_nonpos_vec / logit_add_terms in their order -- the oracle's bits -- but:
+  //  * the polynomial constants are pinned in VGPRs ONCE (FMH_K pins an SGPR copy per use with a volatile asm that cannot
+  //    leave the loop: 11 s_mov_b64 + 3 v_mov_b64 per observation, and two SGPR operands in one instruction are not encodable);
+  //  * the grid index comes from t' = fma(|eta|, 64, SHIFT) = SHIFT + j instead of t = fma(-|eta|, 64, SHIFT) = SHIFT - j:
+  //    j is the low word as it stands, kd' = t' - SHIFT = -kd exactly and r = fma(kd', 1/64, -|eta|) is the same real number as
+  //    fma(kd, -1/64, -|eta|), i.e. the same double; the three table reads are one address + immediate offsets
+  //    (was: a 64-bit negation, three shifts and three adds per chain);
+  //  * min(sg, 0) is issued as v_min_f64 itself (__builtin_fmin on a value that comes out of an integer xor gets a
+  //    canonicalising v_max_f64 in front);
+  //  * the trip count is uniform (scalar branch): all lanes are valid in every pass but the last, which runs once more
+  //    under the exec mask; the prefetch index is clamped with one v_min_u32.
+  // 184 -> ~140 instructions per observation of four chains.
+  typedef __attribute__((address_space(3))) const char* ldsb_t;
+  auto vconst = [](double c) -> double { asm volatile("" : "+v"(c)); return c; };
+  const double kSHIFT = vconst(FMH_SP_SHIFT), k64 = vconst(64.0), kI64 = vconst(0.015625), kAMAX = vconst(-FMH_SPG_AMIN);
+  const double kE6 = vconst(FMH_SPG_E6), kE5 = vconst(FMH_SP_E5), kE4 = vconst(FMH_SP_E4), kE3 = vconst(FMH_SP_E3);
+  const double kL6 = vconst(FMH_SP_L6), kL5 = vconst(FMH_SP_L5), kL4 = vconst(FMH_SP_L4), kL3 = vconst(FMH_SP_L3);
+  const unsigned int tabaddr = (unsigned int)__builtin_amdgcn_readfirstlane((int)a.tab);
+  const unsigned int blast = 8u * (nn - 1u);
+  double xb[PL > 0 ? PL : 1], yv = 0.0;
+  unsigned int boff = 8u * (unsigned int)tid;
+  {
+    const unsigned int b = boff < blast ? boff : blast;
+#pragma unroll
+    for (int u = 0; u < PL; u++) xb[u] = ldg(colp[u], b);
+    yv = ldg(yp, b);
+  }
+  auto one_observation = [&]() {
+    double eta[CW];
+#pragma unroll
+    for (int c = 0; c < CW; c++) eta[c] = b0[c];
+#pragma unroll
+    for (int u = 0; u < PL; u++) {
+#pragma unroll
+      for (int c = 0; c < CW; c++) eta[c] = fmh_fma(xb[u], bs[c][u], eta[c]);
+    }
+    const unsigned int flip = (yv != 0.0) ? 0u : 0x80000000u;     // sg = y ? eta : -eta, on the sign bit
+    boff += 8u * NT;
+    {
+      const unsigned int b = boff < blast ? boff : blast;         // clamped: the last prefetch re-reads the last observation
+#pragma unroll
+      for (int u = 0; u < PL; u++) xb[u] = ldg(colp[u], b);
+      yv = ldg(yp, b);
+    }
+    bool slow = false;
+    double r[CW], sh[CW], sl[CW], sg[CW], q[CW], w[CW], pp[CW], out[CW];
+#pragma unroll
+    for (int c = 0; c < CW; c++) slow = slow || !(__builtin_fabs(eta[c]) <= kAMAX);
+#pragma unroll
+    for (int c = 0; c < CW; c++) {
+      const double ae = __builtin_fabs(eta[c]);
+      const double t = fmh_fma(ae, k64, kSHIFT);
+      const double kd = t - kSHIFT;
+      const unsigned int j = (unsigned int)fmh_d2u(t);
+      r[c] = fmh_fma(kd, kI64, -ae);
+      const ldsb_t row = (ldsb_t)(unsigned long long)(tabaddr + 8u * j);   // (a slow element may index anything: an LDS read cannot fault)
+      sh[c] = *(ldsc_t)(row);
+      sl[c] = *(ldsc_t)(row + 8 * FMH_SPG_ROWS);
+      sg[c] = *(ldsc_t)(row + 16 * FMH_SPG_ROWS);
+    }
+#pragma unroll
+    for (int c = 0; c < CW; c++) q[c] = fmh_fma(r[c], kE6, kE5);
+#pragma unroll
+    for (int c = 0; c < CW; c++) q[c] = fmh_fma(r[c], q[c], kE4);
+#pragma unroll
+    for (int c = 0; c < CW; c++) q[c] = fmh_fma(r[c], q[c], kE3);
+#pragma unroll
+    for (int c = 0; c < CW; c++) q[c] = fmh_fma(r[c], q[c], FMH_SP_E2);
+#pragma unroll
+    for (int c = 0; c < CW; c++) w[c] = sg[c] * fmh_fma(r[c] * r[c], q[c], r[c]);
+#pragma unroll
+    for (int c = 0; c < CW; c++) pp[c] = fmh_fma(w[c], kL6, kL5);
+#pragma unroll
+    for (int c = 0; c < CW; c++) pp[c] = fmh_fma(w[c], pp[c], kL4);
+#pragma unroll
+    for (int c = 0; c < CW; c++) pp[c] = fmh_fma(w[c], pp[c], kL3);
+#pragma unroll
+    for (int c = 0; c < CW; c++) pp[c] = fmh_fma(w[c], pp[c], FMH_SP_L2);
+#pragma unroll
+    for (int c = 0; c < CW; c++) out[c] = sh[c] + (sl[c] + fmh_fma(w[c] * w[c], pp[c], w[c]));
+    if (__builtin_expect(slow, 0)) {   // |eta| beyond 37.5, NaN: the general functions, as in the scalar routine
+#pragma unroll
+      for (int c = 0; c < CW; c++) out[c] = fmh_log1p_exp_nonpos(-__builtin_fabs(eta[c]));
+    }
+#pragma unroll
+    for (int c = 0; c < CW; c++) {
+      const unsigned long long eb = fmh_d2u(eta[c]);
+      const double sgn = fmh_u2d((eb & 0xffffffffull) | ((unsigned long long)((unsigned int)(eb >> 32) ^ flip) << 32));
+      double mn;
+      asm("v_min_f64 %0, %1, 0" : "=v"(mn) : "v"(sgn));          // == (sg < 0) ? sg : 0 (NaN: 0; its out[] is NaN anyway)
+      acc[c] = acc[c] + (mn - out[c]);
+    }
+  };
+  const unsigned int T = (nn + NT - 1u) / NT;        // uniform
+  for (unsigned int it = 0; it + 1u < T; it++) one_observation();
+  if ((unsigned int)tid + NT * (T - 1u) < nn) one_observation();
+  const ldsw_t s_part = (ldsw_t)(unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)a.part);
+#pragma unroll
+  for (int c = 0; c < CW; c++) {
+    const double v = wave_xor_sum(acc[c]);
+    if (lane == 0) s_part[wave * CW + c] = v;
+  }
+}
+
+// Every other logistic shape (any p, any n; all-family kernels: table in global memory), a real function for the same reason.
+template <int CW, bool LDSTAB>
+__device__ __attribute__((noinline)) void logit_partials_any(LogitEval a) {
+  typedef __attribute__((address_space(3))) const double* ldsc_t;
+  typedef __attribute__((address_space(3))) double* ldsw_t;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ic = __builtin_amdgcn_readfirstlane(a.ic), p = __builtin_amdgcn_readfirstlane(a.p);
+  const long long n = (long long)rfl_u64((unsigned long long)a.n);
+  const double* X = (const double*)rfl_u64((unsigned long long)a.X);
+  const double* y = (const double*)rfl_u64((unsigned long long)a.y);
+  const double* s_sptab = LDSTAB ? (const double*)(ldsc_t)(unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)a.tab) : nullptr;
+  ldsc_t th[CW];
+#pragma unroll
+  for (int c = 0; c < CW; c++) th[c] = (ldsc_t)(unsigned long long)logit_th_addr(a, c);
+  double acc[CW];
+#pragma unroll
+  for (int c = 0; c < CW; c++) acc[c] = 0.0;
+  // The data comes from L2 (~1 us under load) and only two waves share a SIMD: a load-use chain per column made this
+  // loop latency-bound (6 dependent round trips per observation).  All columns of an observation are fetched as one
+  // batch, and the batch of the NEXT observation is in flight while exp / log1p of the current one run.
+  constexpr int JB = 8;
+  if (p <= JB) {
+    double xb[JB], yv = 0.0;
+    long long i = tid;
+    if (i < n) {
+#pragma unroll
+      for (int u = 0; u < JB; u++) xb[u] = (u < p) ? X[(long long)u * n + i] : 0.0;
+      yv = y[i];
+    }
+    for (; i < n; i += NT) {
+      double eta[CW];
+#pragma unroll
+      for (int c = 0; c < CW; c++) eta[c] = ic ? th[c][0] : 0.0;
+#pragma unroll
+      for (int u = 0; u < JB; u++)
+        if (u < p) {
+#pragma unroll
+          for (int c = 0; c < CW; c++) eta[c] = fmh_fma(xb[u], th[c][ic + u], eta[c]);
+        }
+      const bool y1 = (yv != 0.0);
+      const long long inx = (i + NT < n) ? i + NT : i;   // clamped: the last prefetch re-reads this observation
+#pragma unroll
+      for (int u = 0; u < JB; u++) xb[u] = (u < p) ? X[(long long)u * n + inx] : 0.0;
+      yv = y[inx];
+      logit_add_terms<CW, LDSTAB>(eta, y1, acc, s_sptab);
+    }
+  } else {
+    for (long long i = tid; i < n; i += NT) {
+      double eta[CW];
+#pragma unroll
+      for (int c = 0; c < CW; c++) eta[c] = ic ? th[c][0] : 0.0;
+      const bool y1 = (y[i] != 0.0);
+      int j = 0;
+      for (; j + JB <= p; j += JB) {
+        double xb[JB];
+#pragma unroll
+        for (int u = 0; u < JB; u++) xb[u] = X[(long long)(j + u) * n + i];
+#pragma unroll
+        for (int u = 0; u < JB; u++) {
+#pragma unroll
+          for (int c = 0; c < CW; c++) eta[c] = fmh_fma(xb[u], th[c][ic + j + u], eta[c]);
+        }
+      }
+      for (; j < p; j++) {
+        const double x = X[(long long)j * n + i];
+#pragma unroll
+        for (int c = 0; c < CW; c++) eta[c] = fmh_fma(x, th[c][ic + j], eta[c]);
+      }
+      logit_add_terms<CW, LDSTAB>(eta, y1, acc, s_sptab);
+    }
+  }
+  const ldsw_t s_part = (ldsw_t)(unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)a.part);
+#pragma unroll
+  for (int c = 0; c < CW; c++) {
+    const double v = wave_xor_sum(acc[c]);
+    if (lane == 0) s_part[wave * CW + c] = v;
+  }
+}
+
 // ---- workgroup-collective log-posterior partial sums (streamed variant) ------------------
 // Every thread accumulates its canonical lane for all CW chains, then the wavefront butterfly
 // (levels 1..32) runs and lane 0 of each wavefront publishes its partial to s_part[w][c].
@@ -722,150 +996,41 @@ __device__ __forceinline__ void eval_partials(const SweepArgs& A, double* const*
 #pragma unroll
   for (int c = 0; c < CW; c++) acc[c] = 0.0;
   if (family == FMCMC_FAM_LOGISTIC) {
-    // The data comes from L2 (~1 us under load) and only two waves share a SIMD: a load-use chain per column made this
-    // loop latency-bound (6 dependent round trips per observation).  All columns of an observation are fetched as one
-    // batch, and the batch of the NEXT observation is in flight while exp / log1p of the current one run.
-    constexpr int JB = 8;
-    // log-likelihood terms of one observation for all CW chains: logq(eta) == logp(-eta), softplus tail on -|eta|
-    auto add_terms = [&](const double (&eta)[CW], bool y1) {
-      double sg[CW], ab[CW], l1[CW];
-      // sg = y ? eta : -eta and ab = -|sg| as sign-bit operations (one integer instruction each; written as selects they
-      // were seven per chain).  Same values as the oracle's selects: a -0 / +0 difference in ab cannot reach the result.
-      const unsigned long long flip = y1 ? 0ull : 0x8000000000000000ull;
+    // Real functions with their own register allocation (logit_partials / logit_partials_any above); they also run the wave
+    // butterfly and publish s_part.  P known at compile time (the logistic-only instantiations, CW (P + 1) <= 28
+    // coefficients in SGPRs): straight-line loop body; with a run-time p every `if (u < p)` was a basic block of its own.
+    typedef __attribute__((address_space(3))) const double* ldsc_t;
+    LogitEval le;
+    le.X = A.X; le.y = A.y; le.n = n; le.ic = ic; le.p = p;
+    le.th0 = (unsigned)(unsigned long long)(ldsc_t)th[0];
+    // (the caller's layout: th[c] = th[0] + c * stride for the chains the workgroup holds, th[0] again for empty slots)
+    le.thstride = 0u; le.ncw = 1u;
 #pragma unroll
-      for (int c = 0; c < CW; c++) {
-        sg[c] = fmh_u2d(fmh_d2u(eta[c]) ^ flip);
-        ab[c] = fmh_u2d(fmh_d2u(sg[c]) | 0x8000000000000000ull);
-      }
-#ifndef FMCMC_SP_GROUP
-#define FMCMC_SP_GROUP 4
-#endif
-      constexpr int G = (CW < FMCMC_SP_GROUP) ? CW : FMCMC_SP_GROUP;   // chains per softplus batch (register pressure vs constant re-use)
-#pragma unroll
-      for (int g0 = 0; g0 < CW; g0 += G) {
-        double ag[G], lg[G];
-#pragma unroll
-        for (int c = 0; c < G; c++) ag[c] = ab[g0 + c];
-        softplus_nonpos_vec<G, FAM == FMCMC_FAM_LOGISTIC>(ag, lg, s_sptab);
-#pragma unroll
-        for (int c = 0; c < G; c++) l1[g0 + c] = lg[c];
-      }
-#pragma unroll
-      for (int c = 0; c < CW; c++) acc[c] = acc[c] + (__builtin_fmin(sg[c], 0.0) - l1[c]);   // == (sg < 0) ? sg - l1 : -l1, bit for bit
-    };
-    // P known at compile time (P <= 8): straight-line loop body -- with a run-time p every `if (u < p)` was a basic
-    // block of its own (6 scalar branches per observation, each with its LDS / memory wait in front) -- and the CW x
-    // (P + 1) coefficients sit in SGPRs for the whole evaluation instead of being re-read from LDS per observation.
-    auto fixed_p = [&](auto PC) {
-      constexpr int PL = decltype(PC)::value;
-      double b0[CW], bs[CW][PL > 0 ? PL : 1];
-#pragma unroll
-      for (int c = 0; c < CW; c++) {
-        b0[c] = ic ? sgpr_d(th[c][0]) : 0.0;
-#pragma unroll
-        for (int u = 0; u < PL; u++) bs[c][u] = sgpr_d(th[c][ic + u]);
-      }
-      // global (not generic) pointers, scalar column bases and a 32-bit lane index: one global_load per value with no
-      // 64-bit address arithmetic (through the by-value copy of the arguments the loads were FLAT loads)
-      typedef const double __attribute__((address_space(1))) * gptr_t;
-      gptr_t colp[PL > 0 ? PL : 1];
-#pragma unroll
-      for (int u = 0; u < PL; u++) colp[u] = (gptr_t)(unsigned long long)(A.X + (long long)u * n);
-      const gptr_t yp = (gptr_t)(unsigned long long)A.y;
-      const unsigned int nn = (unsigned int)n;
-      // (the lane's offset in BYTES as a 32-bit value -- n < 2^28 -- so that every load is `scalar base + 32-bit VGPR offset`;
-      //  indexed with the observation number the compiler widened the scaled index and made a 64-bit add per column)
-      typedef const char __attribute__((address_space(1))) * gcptr_t;
-      auto ldg = [](gptr_t base, unsigned int boff) -> double { return *(gptr_t)((gcptr_t)base + boff); };
-      double xb[PL > 0 ? PL : 1], yv = 0.0;
-      unsigned int i = (unsigned int)tid;
-      if (i < nn) {
-#pragma unroll
-        for (int u = 0; u < PL; u++) xb[u] = ldg(colp[u], 8u * i);
-        yv = ldg(yp, 8u * i);
-      }
-      for (; i < nn; i += NT) {
-        double eta[CW];
-#pragma unroll
-        for (int c = 0; c < CW; c++) eta[c] = b0[c];
-#pragma unroll
-        for (int u = 0; u < PL; u++) {
-#pragma unroll
-          for (int c = 0; c < CW; c++) eta[c] = fmh_fma(xb[u], bs[c][u], eta[c]);
-        }
-        const bool y1 = (yv != 0.0);
-        const unsigned int inx = (i + NT < nn) ? i + NT : i;   // clamped: the last prefetch re-reads this observation
-        const unsigned int binx = 8u * inx;
-#pragma unroll
-        for (int u = 0; u < PL; u++) xb[u] = ldg(colp[u], binx);
-        yv = ldg(yp, binx);
-        add_terms(eta, y1);
-      }
-    };
-    // (the logistic-only instantiations of the kernel carry these loop bodies; CW (P + 1) <= 28 coefficients fit the SGPRs)
+    for (int c = 1; c < CW; c++) {
+      const unsigned d = (unsigned)((unsigned long long)(ldsc_t)th[c] - (unsigned long long)(ldsc_t)th[0]);
+      if (d != 0u) { le.thstride = d / (unsigned)c; le.ncw = (unsigned)c + 1u; }
+    }
+    le.tab = (unsigned)(unsigned long long)(ldsc_t)s_sptab;
+    le.part = (unsigned)(unsigned long long)(ldsc_t)s_part;
     constexpr int PMAX = (FAM == FMCMC_FAM_LOGISTIC) ? (28 / CW - 1 > 8 ? 8 : 28 / CW - 1) : -1;
-    if (p <= PMAX && n < (1ll << 28)) {
-      switch (p) {
-        case 0: fixed_p(std::integral_constant<int, 0>()); break;
-        case 1: fixed_p(std::integral_constant<int, (PMAX >= 1 ? 1 : 0)>()); break;
-        case 2: fixed_p(std::integral_constant<int, (PMAX >= 2 ? 2 : 0)>()); break;
-        case 3: fixed_p(std::integral_constant<int, (PMAX >= 3 ? 3 : 0)>()); break;
-        case 4: fixed_p(std::integral_constant<int, (PMAX >= 4 ? 4 : 0)>()); break;
-        case 5: fixed_p(std::integral_constant<int, (PMAX >= 5 ? 5 : 0)>()); break;
-        case 6: fixed_p(std::integral_constant<int, (PMAX >= 6 ? 6 : 0)>()); break;
-        case 7: fixed_p(std::integral_constant<int, (PMAX >= 7 ? 7 : 0)>()); break;
-        default: fixed_p(std::integral_constant<int, (PMAX >= 8 ? 8 : 0)>()); break;
-      }
-    } else if (p <= JB) {
-      double xb[JB], yv = 0.0;
-      long long i = tid;
-      if (i < n) {
-#pragma unroll
-        for (int u = 0; u < JB; u++) xb[u] = (u < p) ? A.X[(long long)u * n + i] : 0.0;
-        yv = A.y[i];
-      }
-      for (; i < n; i += NT) {
-        double eta[CW];
-#pragma unroll
-        for (int c = 0; c < CW; c++) eta[c] = ic ? th[c][0] : 0.0;
-#pragma unroll
-        for (int u = 0; u < JB; u++)
-          if (u < p) {
-#pragma unroll
-            for (int c = 0; c < CW; c++) eta[c] = fmh_fma(xb[u], th[c][ic + u], eta[c]);
-          }
-        const bool y1 = (yv != 0.0);
-        const long long inx = (i + NT < n) ? i + NT : i;   // clamped: the last prefetch re-reads this observation
-#pragma unroll
-        for (int u = 0; u < JB; u++) xb[u] = (u < p) ? A.X[(long long)u * n + inx] : 0.0;
-        yv = A.y[inx];
-        add_terms(eta, y1);
-      }
-    } else {
-      for (long long i = tid; i < n; i += NT) {
-        double eta[CW];
-#pragma unroll
-        for (int c = 0; c < CW; c++) eta[c] = ic ? th[c][0] : 0.0;
-        const bool y1 = (A.y[i] != 0.0);
-        int j = 0;
-        for (; j + JB <= p; j += JB) {
-          double xb[JB];
-#pragma unroll
-          for (int u = 0; u < JB; u++) xb[u] = A.X[(long long)(j + u) * n + i];
-#pragma unroll
-          for (int u = 0; u < JB; u++) {
-#pragma unroll
-            for (int c = 0; c < CW; c++) eta[c] = fmh_fma(xb[u], th[c][ic + j + u], eta[c]);
-          }
+    if constexpr (FAM == FMCMC_FAM_LOGISTIC) {
+      if (p <= PMAX && n < (1ll << 28)) {
+        switch (p) {
+          case 0: logit_partials<CW, 0>(le); break;
+          case 1: logit_partials<CW, (PMAX >= 1 ? 1 : 0)>(le); break;
+          case 2: logit_partials<CW, (PMAX >= 2 ? 2 : 0)>(le); break;
+          case 3: logit_partials<CW, (PMAX >= 3 ? 3 : 0)>(le); break;
+          case 4: logit_partials<CW, (PMAX >= 4 ? 4 : 0)>(le); break;
+          case 5: logit_partials<CW, (PMAX >= 5 ? 5 : 0)>(le); break;
+          case 6: logit_partials<CW, (PMAX >= 6 ? 6 : 0)>(le); break;
+          case 7: logit_partials<CW, (PMAX >= 7 ? 7 : 0)>(le); break;
+          default: logit_partials<CW, (PMAX >= 8 ? 8 : 0)>(le); break;
         }
-        for (; j < p; j++) {
-          double x = A.X[(long long)j * n + i];
-#pragma unroll
-          for (int c = 0; c < CW; c++) eta[c] = fmh_fma(x, th[c][ic + j], eta[c]);
-        }
-        add_terms(eta, y1);
+        return;
       }
     }
+    logit_partials_any<CW, FAM == FMCMC_FAM_LOGISTIC>(le);
+    return;
   } else if constexpr (FAM == FMCMC_FAM_GAUSSIAN_LINREG && CW <= 2 && SHL > 0) {
     const bool ok = eval_sharded<CW, SHL>(A, th, acc, *sh_epoch, s_sptab, stp);
     if (!ok && tid == 0 && (long long)blockIdx.x * CW < A.nchains)      // (a workgroup without chains has no status slot)

@@ -66,7 +66,7 @@ int main(int argc, char** argv) {
   A.family = FMCMC_FAM_LOGISTIC; A.p = p; A.intercept = 1; A.guard = 0; A.n = n; A.X = dX; A.y = dy; A.prior_div = 8.0;
   A.kind = FMCMC_KERNEL_NORMAL_REFLECTIVE; A.k = k; A.scheme = FMCMC_SCHEME_JOINT; A.freq = 1;
   A.mu = dmu; A.scale = dsc; A.lb = dlb; A.ub = dub; A.fixed = dfx;
-  A.nchains = C; A.nsteps = nsteps; A.burnin = 0; A.thin = thin; A.S = S; A.seed = 1215; A.rng_mode = FMCMC_RNG_PHILOX; A.fresh = 1; A.kz = kz;
+  A.nchains = C; A.nsteps = nsteps; A.burnin = 0; A.thin = thin; A.S = S; A.ldS = S; A.seed = 1215; A.rng_mode = FMCMC_RNG_PHILOX; A.fresh = 1; A.kz = kz;
   A.tb = 32;
   A.theta0 = dth; A.f0 = df0; A.samples = dsam; A.logpost = dlp; A.draws = ddr; A.accept_count = dacc; A.accept_bits = dbits;
   A.status = dstat; A.status_step = dss; A.status_theta = dst_th;
