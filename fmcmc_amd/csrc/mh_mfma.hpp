@@ -44,7 +44,12 @@ constexpr int MF_TCS = 8 * PIPE_TRS + 2;   // (the replicated kernel's tile, mh_
 template <int KIND, int NG, int NS, bool DBG>
 __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
   constexpr int CW = 4;
-  constexpr int MB = 8;             // (slot, lane group) pairs per batch = 2 observation slots
+#ifndef MFO_MB
+#define MFO_MB 12
+#endif
+  // (slot, lane group) pairs per batch: 8 until round 3; 12 is 1.9 % faster per step (tools/probe_mfma4_pattern.hip: a pair costs
+  //  21.5 / 21.0 cycles at 8 / 16 per batch), 16 another 0.5 % but spills six registers
+  constexpr int MB = MFO_MB;
   constexpr int TN = NS * 4;        // pairs held per lane and group (NG * TN <= MF_NMF registers)
   static_assert(NG * TN <= MF_NMF, "operand registers");
   extern __shared__ double smem[];
@@ -151,6 +156,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
 
   constexpr bool dbg = DBG;
   bool st_keep = false;                      // row of the step just decided, stored after the barrier
+  bool st_acc = false;
   double st_th0 = 0.0, st_th1 = 0.0, st_f1 = 0.0;
   unsigned long long te = 0, tb1 = 0, to = 0, tb2 = 0, tf = 0, tc = 0, td = 0;
   for (int v = 1; v <= nsteps; v++) {
@@ -249,15 +255,11 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
     if (owner) {
       __builtin_amdgcn_s_setprio(3);
       double wsum = s_fold[myc * NW + (lane & 7)];              // the wave sums of this chain, one per lane of an octet
-      // increment of the NEXT proposal: consumes the variate fetched one step ago and refills the same register at once, so
-      // that load has a whole step to land and no vector-memory wait sits behind the decision below
-      // The only vector-memory wait of the phase sits HERE, on loads issued one whole step ago; both registers are refilled
-      // at once, so nothing younger than an evaluation is ever waited for (a wait behind the decision would also cover the
-      // refill of the variate, an HBM miss every third step).
+      // increment of the NEXT proposal: consumes the variate fetched behind the previous step's releasing barrier, a whole
+      // evaluation ago.  The only vector-memory wait of the phase sits HERE, on those loads (and on the row stores issued
+      // with them); the registers are refilled behind the barrier below.
       double lu = lu_nx, zc = z_nx;
       asm volatile("" : "+v"(lu), "+v"(zc));
-      lu_nx = lu_row[v < nsteps ? v : nsteps - 1];
-      if (kz > 0) z_nx = ld_z(v + 1 < nsteps ? v + 1 : nsteps - 1);
       const double dz = mu_l + sc_l * zc;   // (unused by fixed / idle lanes; mu and scale live in registers: no LDS read, no exec region)
       wsum = wsum + dpp_d<0xB1>(wsum);                          // level 64:  waves w, w ^ 1 (quad_perm [1,0,3,2])
       wsum = wsum + dpp_d<0x4E>(wsum);                          // level 128: quad_perm [2,3,0,1]
@@ -318,8 +320,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
         th0_row = th0;
         propose(status != FMCMC_CHAIN_OK);
       }
-      nacc += acc ? 1 : 0;
-      bitword |= (acc ? 1u : 0u) << ((v - 1) & 31);
+      st_acc = acc;
       unsigned long long t_c = dbg ? clk() : 0;
       if (dbg) { tf += t_a - t_2; tc += t_b - t_a; td += t_c - t_b; }
       __builtin_amdgcn_s_setprio(0);
@@ -332,6 +333,12 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
     // waves are the first of their SIMD to finish their MFMAs (~1400 ticks of slack), the stores ride in that slack
     // instead of sitting in the exposed owner phase.
     if (owner) {
+      // The refills of the two stream registers (consumed in the owner phase of the NEXT step, a whole evaluation away) and the
+      // accept bookkeeping ride here too (round 3: -1.9 % per step; they were 13 instructions of the exposed owner phase).
+      lu_nx = lu_row[v < nsteps ? v : nsteps - 1];
+      if (kz > 0) z_nx = ld_z(v + 1 < nsteps ? v + 1 : nsteps - 1);
+      nacc += st_acc ? 1 : 0;
+      bitword |= (st_acc ? 1u : 0u) << ((v - 1) & 31);
       if (st_keep && v > burnin) {
         thin_ctr += 1;
         if (thin_ctr == thin) {

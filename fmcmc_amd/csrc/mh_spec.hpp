@@ -394,9 +394,16 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
     }
   };
   prepare(1);
+#ifdef SPEC_STAMP   /* diagnostic build (tools/exp_spec.hip): s_memtime shares of the owner's phases */
+  unsigned long long stt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stp = clk();
+#define SPEC_ST(i) do { const unsigned long long t_ = clk(); stt[i] += t_ - stp; stp = t_; } while (0)
+#else
+#define SPEC_ST(i) do { } while (0)
+#endif
 
   for (int v = 1; v <= nsteps; v++) {
     while (lds_ld_u32(&s_done[myc]) < 8u * (unsigned)v) __builtin_amdgcn_s_sleep(1);
+    SPEC_ST(0);
     const double* src = s_tr + myc * (8 * PIPE_TRS) + lane;
     const double v0 = src[0 * PIPE_TRS], v1 = src[1 * PIPE_TRS], v2 = src[2 * PIPE_TRS], v3 = src[3 * PIPE_TRS];
     const double v4 = src[4 * PIPE_TRS], v5 = src[5 * PIPE_TRS], v6 = src[6 * PIPE_TRS], v7 = src[7 * PIPE_TRS];
@@ -408,6 +415,7 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
     bool st_row = false;
     double st_th0 = 0.0;
     const double st_dr = th1;
+    SPEC_ST(1);
     if (v == 1) {
       f0 = f1;
       run_sum = th0;
@@ -462,6 +470,7 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
         if (((i - 1) & 31) == 31 || i == nsteps) flush_bits(i);
       }
     }
+    SPEC_ST(2);
     // ---- proposal of loop step i = v + 1
     if (v < nsteps) {
       if (status == FMCMC_CHAIN_OK) {
@@ -488,6 +497,7 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
             have_mean = 1;
           }
           abs_iter += 1;
+          SPEC_ST(3);
           // left-looking Cholesky: column j, lane = row (twin of oracle chol_lower_canon)
           bool notpd = false;
 #pragma unroll
@@ -508,6 +518,7 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
               }
             }
           }
+          SPEC_ST(4);
           if (notpd) {
             status = FMCMC_CHAIN_NOT_PD;
             if (lane == 0) { A.status[cl] = status; A.status_step[cl] = i; }
@@ -532,6 +543,7 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (lane == 0) __hip_atomic_store(&s_ready[myc], (unsigned)(v + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+    SPEC_ST(5);
     if (st_row) {   // row v of ans / draws / logpost, off the compute waves' critical path
       if (rl) {
         *reinterpret_cast<double*>(reinterpret_cast<char*>(A.samples) + (sd_off + srow8)) = st_th0;
@@ -540,8 +552,15 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
       if (A.logpost && lane == 0) *reinterpret_cast<double*>(reinterpret_cast<char*>(A.logpost) + (lp_off + srow8)) = f1;
       srow8 += 8;
     }
+    SPEC_ST(6);
     if (v < nsteps) prepare(v + 1);
+    SPEC_ST(7);
   }
+#ifdef SPEC_STAMP
+  __builtin_amdgcn_s_waitcnt(0);
+  if (lane < 16 && A.draws) A.draws[(long long)cl * 16 + lane] = (lane < 8) ? (double)stt[lane & 7] : (double)nsteps;
+#endif
+#undef SPEC_ST
   // ---- write state back
   if (rl) A.theta0[(long long)cl * k + lane] = th0;
   if (lane == 0) {
@@ -662,6 +681,15 @@ __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
   // =========================== OWNER ROLE ===========================
   const int myc = wave - SPEC_NCW;
   if (myc >= ncw) return;
+  // Owners issue ahead of the compute waves of their SIMD (round 3).  The s_memtime shares of an adaptive owner's phases
+  // (tools/exp_spec.hip -DSPEC_STAMP) showed every one of its instructions waiting ~26 cycles: two compute waves keep the
+  // SIMD's fp64 pipe full and the arbiter serves the oldest wave first.  With the priority raised its work per step falls
+  // from 8760 to 5270 ticks (the compute waves fill what it leaves): C3 3.55 -> 3.34 us per step, kernel_ram k = 5
+  // 3.67 -> 3.41; priority 3 measures the same as 1.
+#ifndef SPEC_OWNER_PRIO
+#define SPEC_OWNER_PRIO 1
+#endif
+  if (SPEC_OWNER_PRIO > 0) __builtin_amdgcn_s_setprio(SPEC_OWNER_PRIO);
   const int cl = __builtin_amdgcn_readfirstlane((int)cg0 + myc);
   if constexpr (KIND == FMCMC_KERNEL_ADAPT || KIND == FMCMC_KERNEL_RAM) {
     bool nofixed = true;

@@ -422,6 +422,8 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
       if (!ok) { if (lane == 0) w2_lds_st(s_lost, 1u); lost = true; break; }
     }
     W2_OW_STAMP(0);
+    // (measured and dropped, round 3: s_setprio 1 / 3 for the owner between here and the publish -- what gave C3's owners 6 % --
+    //  is 18.5 us per step against 18.3: the evaluator wave that shares the SIMD is on the critical path as well)
     W2_EVENT(v == 300, 24 + 6 * g);                            // partials of version 300 seen (owner of group g)
     bool row_keep = false, fresh_prop = false;
     double row_th0 = 0.0, row_th1 = 0.0, row_f1 = 0.0;
