@@ -16,6 +16,8 @@ from . import _abi as abi
 def _window(iters):
     """coda's autoburnin: if start(x) < end(x)/2 keep iterations >= end/2 + 1."""
     iters = np.asarray(iters)
+    if iters.size == 0:          # a bulk that kept no row (burnin / thin): nothing to test yet
+        return 0, 0
     start, end = iters[0], iters[-1]
     if start < end / 2:
         row0 = int(np.searchsorted(iters, end / 2 + 1, side="left"))

@@ -62,7 +62,9 @@ __global__ __launch_bounds__(GT) void gelman_chain_mfma(const double* __restrict
   // in flight behind the one being multiplied (the loads come from HBM: ~2 us, a group's 40 MFMAs are ~1 us).
   const long long groups = (N + 15) / 16, per = (groups + 3) / 4;
   const long long g_lo = wave * per, g_hi = (g_lo + per < groups) ? g_lo + per : groups;
-  typedef double gd2_t __attribute__((ext_vector_type(2)));
+  // (a pair is 8-byte aligned only: the window starts at any row of a history whose row stride may be odd -- the vector type
+  //  says so, the loads are still one global_load_dwordx4 each, which gfx950 serves at any 4-byte alignment)
+  typedef double gd2_t __attribute__((ext_vector_type(2), aligned(8)));
   double buf[3][NCB][4];
   auto load = [&](long long gi, double (&v)[NCB][4]) {
     const long long t = 16 * gi + 4 * kk;

@@ -41,7 +41,9 @@
 #include "mh_streamed.hpp"
 #include "mh_pipe.hpp"
 #include "mh_mfma.hpp"
+#ifdef FMCMC_AB   /* A/B partners of the product kernels (tools/, -DFMCMC_AB builds): not in libfmcmc_amd.so */
 #include "mh_mfma_rep.hpp"
+#endif
 #include "mh_spec.hpp"
 #include "mh_wide2.hpp"
 
@@ -476,7 +478,11 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
     default: LAUNCH(CWV, PV, OV, 4); break;                                                          \
   }
   // software-pipelined fast path: normal kernels, joint scheme, k <= 16, linreg data in registers
+#ifdef FMCMC_AB
   const bool nopipe = K.pipe == 0, nospec = K.spec == 0;
+#else
+  const bool nopipe = K.pipe == 0, nospec = false;   // (spec=0 / owners=0 select kernels that only -DFMCMC_AB builds carry)
+#endif
   int pipe_opt = 0, mfma_ng = 0;
   if (!force && !nopipe && m->family == FMCMC_FAM_GAUSSIAN_LINREG &&
       (kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE ||
@@ -513,6 +519,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
       A.fed_z = ws + items;
       A.rng_mode = FMCMC_RNG_FED;
     }
+#ifdef FMCMC_AB
 #define LAUNCH_PIPE(PV, OV, KV)                                                                        \
     do {                                                                                               \
       if (plds > 48 * 1024)                                                                            \
@@ -521,32 +528,42 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
       if (e == hipSuccess)                                                                             \
         hipLaunchKernelGGL((mh_sweep_pipe<PV, OV, KV>), dim3((unsigned)pblk), dim3(NT), plds, stream, A); \
     } while (0)
+#endif
     g_kernel = mfma_ng ? "mfma" : !nospec ? "spec" : "pipe";
     if (mfma_ng) {
       // Two MFMA kernels with identical results.  mh_sweep_mfma (owner waves) is the product path for every shape;
       // mh_sweep_mfmar (chain state replicated in every wave, one barrier per step) was 2-10 % ahead below n = 8192
       // until the owner phase of mh_sweep_mfma went through the same instruction diet, and is 1-7 % behind since
-      // (tools/bench_shapes_ab.py).  It stays compiled in for n > 8192, p <= 3, non-reflective kernels as the A/B
-      // partner (knob owners=0, tools/exp_mfmar.hip) and as a second implementation the parity tests compare.
+      // (tools/bench_shapes_ab.py).  It is compiled into -DFMCMC_AB builds only (n > 8192, p <= 3, non-reflective
+      // kernels: knob owners=0, tools/exp_mfmar.hip), as the A/B partner and as a second implementation the parity tests
+      // compare when they run against such a build.
       const int ns = (int)((m->n + NT - 1) / NT);   // observation slots of 512
       const int kv = (kn->kind == FMCMC_KERNEL_NORMAL) ? 1 : 2;
+#ifdef FMCMC_AB
       const bool owners = !(K.owners == 0 && kv == 1 && mfma_ng == 1 && ns > 16);
       const size_t mlds = owners ? mfma_lds_bytes() : mfmar_lds_bytes();
+#else
+      const bool owners = true;
+      const size_t mlds = mfma_lds_bytes();
+#endif
       if (!owners) g_kernel = "mfma-replicated";
-      const bool dbgk = (A.debug & 8) != 0 && mfma_ng == 1 && ns == 20;
+      const bool dbgk = (A.debug & 8) != 0 && mfma_ng == 1 && ns == 20; (void)dbgk;
 #define MF_CASE(KN, KV, GV, SV) case SV: hipLaunchKernelGGL((KN<KV, GV, SV, false>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A); break;
 #define MF_CASES10(KN, KV, GV) MF_CASE(KN, KV, GV, 1) MF_CASE(KN, KV, GV, 2) MF_CASE(KN, KV, GV, 3) MF_CASE(KN, KV, GV, 4) MF_CASE(KN, KV, GV, 5) \
                                MF_CASE(KN, KV, GV, 6) MF_CASE(KN, KV, GV, 7) MF_CASE(KN, KV, GV, 8) MF_CASE(KN, KV, GV, 9) MF_CASE(KN, KV, GV, 10)
 #define MF_CASES16(KN, KV, GV) MF_CASES10(KN, KV, GV) MF_CASE(KN, KV, GV, 11) MF_CASE(KN, KV, GV, 12) MF_CASE(KN, KV, GV, 13) \
                                MF_CASE(KN, KV, GV, 14) MF_CASE(KN, KV, GV, 15) MF_CASE(KN, KV, GV, 16)
 #define MF_CASES17(KN, KV, GV) MF_CASE(KN, KV, GV, 17) MF_CASE(KN, KV, GV, 18) MF_CASE(KN, KV, GV, 19) MF_CASE(KN, KV, GV, 20)
-      if (dbgk && owners) {
+      if (false) {
+#ifdef FMCMC_AB   /* the stamped (DBG) instantiations: tools/stamp_mfma.py against an -DFMCMC_AB build */
+      } else if (dbgk && owners) {
         if (kv == 1) hipLaunchKernelGGL((mh_sweep_mfma<1, 1, 20, true>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A);
         else hipLaunchKernelGGL((mh_sweep_mfma<2, 1, 20, true>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A);
       } else if (dbgk) {
         hipLaunchKernelGGL((mh_sweep_mfmar<1, 1, 20, true>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A);
       } else if (!owners) {
         switch (ns) { MF_CASES17(mh_sweep_mfmar, 1, 1) default: break; }
+#endif
       } else if (mfma_ng == 2 && kv == 1) {
         switch (ns) { MF_CASES10(mh_sweep_mfma, 1, 2) default: break; }
       } else if (mfma_ng == 2) {
@@ -587,12 +604,14 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
         }
       }
 #undef LAUNCH_SPEC
-    } else
-    if (pipe_opt == 20 && kn->kind == FMCMC_KERNEL_NORMAL) LAUNCH_PIPE(3, 20, 1);
+    }
+#ifdef FMCMC_AB
+    else if (pipe_opt == 20 && kn->kind == FMCMC_KERNEL_NORMAL) LAUNCH_PIPE(3, 20, 1);
     else if (pipe_opt == 20) LAUNCH_PIPE(3, 20, 2);
     else if (kn->kind == FMCMC_KERNEL_NORMAL) LAUNCH_PIPE(1, 2, 1);
     else LAUNCH_PIPE(1, 2, 2);
 #undef LAUNCH_PIPE
+#endif
   } else
   if (resident && res_p == 1) { g_kernel = "resident"; LAUNCH_KIND(4, 1, 4); }
   else if (resident && res_p == 3) { g_kernel = "resident"; LAUNCH_KIND(4, 3, 20); }
@@ -756,12 +775,12 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
 }
 
 int fmcmc_rng_stream_dev(uint64_t seed, int64_t step_base, int64_t chain_base, int64_t nchains, int64_t nsteps,
-                         int32_t kz, int32_t student_df, double* logu, double* z, void* hip_stream) {
+                         int32_t kz, double student_df, double* logu, double* z, void* hip_stream) {
   if (!logu || !z || nchains < 1 || nsteps < 1 || kz < 1) { set_err("fmcmc_rng_stream_dev: bad argument"); return FMCMC_ERR_ARG; }
   const size_t items = (size_t)nchains * (size_t)nsteps;
   hipLaunchKernelGGL(rng_fill_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream,
                      (unsigned long long)seed, (long long)step_base, (long long)chain_base, (long long)nchains,
-                     (long long)nsteps, (int)kz, (double)student_df, logu, z);
+                     (long long)nsteps, (int)kz, student_df, logu, z);
   return hipGetLastError() == hipSuccess ? FMCMC_OK : FMCMC_ERR_DEVICE;
 }
 

@@ -72,6 +72,13 @@ __device__ __forceinline__ bool w2_wait(unsigned* bar, unsigned target, unsigned
       if (++spins > 20000000u || w2_lds_ld(s_lost)) { ok = false; break; }
     }
   }
+  // Acquire side of the hand-over FOR THE COMPILER: the payload is read with relaxed agent-scope (sc1) loads, which the
+  // hardware serves from the coherent level once the counter has been seen (MI355X_MICROARCH.md, hand-offs with sc1 loads in
+  // place of the acquire; an agent-scope acquire fence would be a buffer_inv sc1 that also drops this workgroup's slice from
+  // the caches: 11.8 -> 32.6 us per step, tools/scalar_slice_probe.hip).  What relaxed atomics do NOT give is an order the
+  // optimiser has to respect -- it may hoist a payload load above the polling loop -- so the wait ends in a compiler-level
+  // barrier (no instruction).  The producer side has one in the s_waitcnt vmcnt(0) asm in front of every w2_arrive.
+  asm volatile("" ::: "memory");
   return __builtin_amdgcn_readfirstlane(ok ? 1 : 0) != 0;
 }
 
@@ -279,6 +286,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
             __builtin_amdgcn_s_sleep(1);
             if (w2_lds_ld(s_lost) || ++spins > 40000000u) { lost = true; break; }
           }
+          asm volatile("" ::: "memory");   // (compiler-level acquire of the LDS relay, as in w2_wait)
         }
         if (lost) break;
         W2_EV_STAMP(0);

@@ -243,12 +243,17 @@ def rng_stream(state, kernel, nsteps, seed=0, chain_base=0, logu=None, z=None, s
         z = torch.empty((Cn, nsteps, kz), dtype=torch.float64, device=dev)
     if stream is None:
         stream = torch.cuda.current_stream(dev)
+    # the variate family the kernel's own in-library stream draws (mh_engine.hip, launch_sweep): kernel_ram's qfun families
+    # (fmcmc_kernel.ram_qfun: rt(k, k) / rnorm(k) / rt(k, df)), U(0,1) for the uniform kernels, N(0,1) otherwise
+    if kernel.kind == abi.KERNEL_RAM:
+        df = {abi.RAM_QFUN_NORMAL: 0.0, abi.RAM_QFUN_T_DF: kernel.ram_df}.get(kernel.ram_qfun, float(kernel.kf))
+    elif kernel.kind in (abi.KERNEL_UNIF, abi.KERNEL_UNIF_REFLECTIVE, abi.KERNEL_UMIRROR):
+        df = -1.0
+    else:
+        df = 0.0
     with torch.cuda.device(dev):
-        rc = L.fmcmc_rng_stream_dev(seed & 0xFFFFFFFFFFFFFFFF, state.step_base, chain_base, Cn, nsteps, kz,
-                                    kernel.kf if kernel.kind == abi.KERNEL_RAM else
-                                    (-1 if kernel.kind in (abi.KERNEL_UNIF, abi.KERNEL_UNIF_REFLECTIVE, abi.KERNEL_UMIRROR) else 0),
-                                    logu.data_ptr(), z.data_ptr(),
-                                    C.c_void_p(stream.cuda_stream))
+        rc = L.fmcmc_rng_stream_dev(seed & 0xFFFFFFFFFFFFFFFF, state.step_base, chain_base, Cn, nsteps, kz, float(df),
+                                    logu.data_ptr(), z.data_ptr(), C.c_void_p(stream.cuda_stream))
     if rc != abi.OK:
         raise RuntimeError("fmcmc_rng_stream_dev failed (%d): %s" % (rc, abi.last_error()))
     return logu, z

@@ -362,6 +362,11 @@ def MCMC_with_conv_checker(initial, fun, nsteps, nchains, burnin, thin, kernel, 
     bulks[0] += burnin
     if kernel is None:
         kernel = kernel_normal()
+    if not isinstance(fun, LogPosterior):
+        raise TypeError("-fun- must be one of the engine's closed-form families (gaussian_linreg, logistic, "
+                        "iid_normal): an arbitrary closure cannot run inside the fused GPU kernel.")
+    if not isinstance(kernel, fmcmc_kernel):
+        raise TypeError("-kernel- must be an fmcmc_kernel (kernel_normal, kernel_normal_reflective, kernel_adapt, kernel_ram).")
     init, names = check_initial(initial, nchains)
     dist, rank, world = _dist()
     lo, hi = shard_bounds(nchains, world, rank)
@@ -380,7 +385,10 @@ def MCMC_with_conv_checker(initial, fun, nsteps, nchains, burnin, thin, kernel, 
             burnin = 0
             # initial <- ans[niter(ans), ]: the last KEPT row of every chain (R/mcmc.R:908-911), which with thin > 1 is not
             # the last row the loop visited
-            init_local = ans._samples[:, :, ans.nrows - 1]
+            # (a first bulk can end without a kept row -- burnin > 0 and freq < thin < freq + burnin pass the argument checks --
+            #  where R's `ans[niter(ans), ]` has no row to take; the chains then continue from the state the kernel carries,
+            #  their true last row, instead of from the NaN prefill of the history)
+            init_local = ans._samples[:, :, ans.nrows - 1] if ans.nrows > 0 else kernel._state.theta0
         _validate_common(nb, nchains, burnin, thin, multicore)
         _run_call(init_local, fun, nb, burnin, thin, kernel, seed, lo, nchains, names, device, history=ans, fed=fed)
         if free is None:

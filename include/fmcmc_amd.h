@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FMCMC_ABI_VERSION 3
+#define FMCMC_ABI_VERSION 4
 #define FMCMC_MAX_K 64 /* parameters per chain supported by the device kernels */
 
 /* ---- log-posterior families: the `fun` argument of MCMC() (R/mcmc.R:327) ---------- */
@@ -252,13 +252,14 @@ int fmcmc_gelman_finish(const double* partial, int32_t p, int64_t N, double* psr
                         double* mpsrf);
 
 /* Materialises the canonical Philox stream of a call in device memory, in the FED layout of fmcmc_run:
- * logu[C][nsteps] (entry i-1 = log accept-uniform of loop step i), z[C][nsteps][kz] (N(0,1); Student-t
- * with student_df degrees of freedom when student_df > 0, the qfun of R/kernel_ram.R:68; U(0,1) of the uniform
- * kernels when student_df == -1).  A sweep run with
+ * logu[C][nsteps] (entry i-1 = log accept-uniform of loop step i), z[C][nsteps][kz] (N(0,1) when student_df == 0;
+ * Student-t with student_df degrees of freedom when student_df > 0 -- kernel_ram: kf for the default qfun rt(k, k),
+ * fmcmc_kernel.ram_df for FMCMC_RAM_QFUN_T_DF, 0 for FMCMC_RAM_QFUN_NORMAL (R/kernel_ram.R:68) -- ; U(0,1) of the uniform
+ * kernels when student_df == -1).  A double since ABI 4 (it was an int32 and could not carry a fractional df).  A sweep run with
  * rng_mode = FMCMC_RNG_FED on these buffers is bit-identical to rng_mode = FMCMC_RNG_PHILOX; callers that
  * launch many sweeps can reuse the buffers instead of letting the library allocate them per call. */
 int fmcmc_rng_stream_dev(uint64_t seed, int64_t step_base, int64_t chain_base, int64_t nchains, int64_t nsteps,
-                         int32_t kz, int32_t student_df, double* logu, double* z, void* hip_stream);
+                         int32_t kz, double student_df, double* logu, double* z, void* hip_stream);
 
 /* Diagnostic: evaluate the canonical math / RNG primitives on the device, element-wise
  * (which: 0 log, 1 exp, 2 log1p, 3 qnorm, 4 log accept-u, 5 normal, 6 student-t(df=x), 7 sqrt,

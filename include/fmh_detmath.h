@@ -180,22 +180,11 @@ FMH_HD double fmh_exp(double x) {
 }
 
 /* log1p(exp(a)) for a <= 0 -- the softplus tail of the logistic log-likelihood (R: log1p(exp(x)), vignettes/
- * workflow-with-fmcmc.Rmd:37-38), one fused routine WITHOUT a division: the logistic model evaluates it n times per
- * log-posterior and the composition fmh_log1p(fmh_exp(a)) costs three fp64 divisions (12 instructions each on gfx950, five of
- * them quarter rate) out of ~100 instructions; this one is ~45.  (On the device both tables are staged in LDS: a lookup from
- * global memory is a 64-address gather.)
- *   e = exp(a):  a = (128 kk + j) ln2/128 + r, |r| <= ln2/256 (round-to-integer by adding 1.5 2^52; two-word ln2/128);
- *                exp(r) - 1 = r + r^2 q(r), q = Taylor terms up to r^5/120 (truncation 5e-19);  2^(j/128) from a table
- *                (hi + lo);  e = 2^kk (T_hi + (T_lo + T_hi (exp(r) - 1))), exact scaling (kk >= -1010 on the fast range).
- *   log1p(e):    u = fl(1 + e) in [1, 2), c = e - (u - 1) exactly (Fast2Sum);  i = top 7 mantissa bits of u;
- *                invc_i = fl(1 / (1 + i/128)), logc_i = -log(invc_i) as hi + lo (table, tools/gen_softplus_table.py);
- *                r = fma(u, invc_i, -1) in [0, 2^-7]:  log(u) = logc_i + log1p(r) EXACTLY for the tabulated doubles, and
- *                log1p(r) = r + r^2 p(r), p = Taylor terms up to r^8/8 (truncation 1.5e-18 r);  + c / u ~ c invc_i.
- *                All terms are non-negative: no cancellation; entry 0 is (1, 0, 0), so tiny e returns e.
- * e is carried as a double-double (the rounding error of its last sum is exact and joins c), so the only roundings that
- * count are those of the reduced argument and of the final sums: against the exact log1p(exp(a)) the result is within
- * 1.5 ulp (tests/test_detmath.py, 60-digit reference; 0.30 ulp on average) -- the composition of two faithfully rounded libm
- * calls that R evaluates reaches 1.5 ulp.  Arguments outside -700 <= a <= -2^-28 (and NaN) take the general functions. */
+ * workflow-with-fmcmc.Rmd:37-38): the logistic model evaluates it n times per log-posterior, and the composition
+ * fmh_log1p(fmh_exp(a)) costs three fp64 divisions (12 instructions each on gfx950) out of ~100 instructions.  The routine
+ * is fmh_log1p_exp_nonpos below: softplus on a grid of spacing 1/64 with two degree-6 Taylor polynomials (round 2; the
+ * round-1 routine -- a table-driven exp carried as a double-double into a table-driven logarithm, ~45 operations and two
+ * lookups, 1.5 ulp -- is gone, its description with it).  The constants that follow are the polynomial coefficients. */
 /* coefficients of fmh_log1p_exp_nonpos (shared with the chain-vectorised device twin in mh_common.hpp) */
 #define FMH_SP_SHIFT 0x1.8p52                 /* adding it rounds to an integer and leaves that integer in the low mantissa bits */
 #define FMH_SP_E2 0x1.0000000000000p-1

@@ -14,8 +14,11 @@
  *   * the reference's stop() texts come from the library (fmcmc_last_error), the NaN log-posterior message of
  *     R/mcmc.R:759-765 is rebuilt here with the step and theta1 of the failing chain.
  *
- * Not compiled in this repository's image (no R headers); examples/c_abi_linreg.c is the compiled stand-in that exercises
- * the same entry point with the same layouts, and fmcmc_amd/_abi.py + engine.py mirror this file field by field.
+ * R is not installed in this repository's image, so here the file is compiled and run against a stand-in for the handful of
+ * R API calls it makes (tests/rapi_stub/, written from "Writing R Extensions"): tests/test_shim.py builds it with
+ * -Wall -Werror -fsanitize=address,undefined, checks the argument errors against the reference's texts
+ * (inst/tinytest/test-mcmc.R:3-23) and, on the GPU, drives C_fmcmc_amd_run from a C harness (tests/shim_harness.c) and
+ * compares every returned array with the oracle bit for bit.  fmcmc_amd/_abi.py + engine.py mirror this file field by field.
  *
  * Build (inside the fmcmc package): src/Makevars from shim/Makevars.
  */
@@ -24,6 +27,8 @@
 #include <R_ext/Rdynload.h>
 #include <R_ext/Utils.h>
 #include <float.h>
+#include <limits.h>
+#include <math.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -141,19 +146,36 @@ static void fill_kernel(SEXP kernel, fmcmc_kernel* k) {
 
 /* run = list(nchains, nsteps, burnin, thin, seed (double, < 2^53), chain_base, step_base, rng_mode,
  *            fed_logu (nsteps x C) , fed_z (kz x nsteps x C)) */
-static void fill_run(SEXP run, fmcmc_run* r) {
+/* a count that arrives as an R double: finite, integral and inside [lo, 2^53) (casting anything else is undefined behaviour) */
+static int64_t el_count(SEXP list, const char* name, double dflt, double lo) {
+  const double v = el_dbl(list, name, dflt);
+  if (!(v >= lo && v < 9007199254740992.0) || v != floor(v))
+    error("fmcmc_amd shim: -%s- must be a whole number in [%.0f, 2^53) (got %g)", name, lo, v);
+  return (int64_t)v;
+}
+/* kz: proposal variates per step -- one for the single-parameter schemes of the simple kernels, else one per free parameter */
+static R_xlen_t variates_per_step(const fmcmc_kernel* k) {
+  R_xlen_t kf = 0;
+  for (int j = 0; j < k->k; j++) kf += !k->fixed[j];
+  const int simple = (k->kind == FMCMC_KERNEL_NORMAL || k->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE || k->kind == FMCMC_KERNEL_UNIF ||
+                      k->kind == FMCMC_KERNEL_UNIF_REFLECTIVE || k->kind == FMCMC_KERNEL_NMIRROR || k->kind == FMCMC_KERNEL_UMIRROR);
+  return (simple && k->scheme != FMCMC_SCHEME_JOINT) ? 1 : kf;
+}
+static void fill_run(SEXP run, const fmcmc_kernel* k, fmcmc_run* r) {
   memset(r, 0, sizeof(*r));
-  r->nchains = (int64_t)el_dbl(run, "nchains", 1);
-  r->nsteps = (int64_t)el_dbl(run, "nsteps", 0);
-  r->burnin = (int64_t)el_dbl(run, "burnin", 0);
-  r->thin = (int64_t)el_dbl(run, "thin", 1);
-  r->seed = (uint64_t)el_dbl(run, "seed", 0);
-  r->chain_base = (int64_t)el_dbl(run, "chain_base", 0);
-  r->step_base = (int64_t)el_dbl(run, "step_base", 0);
+  /* (signed counts keep their sign: the range checks with the reference's messages are fmcmc_validate's) */
+  r->nchains = (int64_t)el_count(run, "nchains", 1, -9007199254740991.0);
+  r->nsteps = (int64_t)el_count(run, "nsteps", 0, -9007199254740991.0);
+  r->burnin = (int64_t)el_count(run, "burnin", 0, -9007199254740991.0);
+  r->thin = (int64_t)el_count(run, "thin", 1, -9007199254740991.0);
+  r->seed = (uint64_t)el_count(run, "seed", 0, 0.0);          /* NA, negative or fractional seeds are refused, not cast */
+  r->chain_base = el_count(run, "chain_base", 0, 0.0);
+  r->step_base = el_count(run, "step_base", 0, 0.0);
   r->rng_mode = el_int(run, "rng_mode", FMCMC_RNG_PHILOX);
-  if (r->rng_mode == FMCMC_RNG_FED) {
-    r->fed_logu = el_real(run, "fed_logu", (R_xlen_t)(r->nchains * r->nsteps), 1);   /* [C][nsteps] */
-    r->fed_z = el_real(run, "fed_z", -1, 1);                                          /* [C][nsteps][kz] */
+  if (r->rng_mode == FMCMC_RNG_FED && r->nchains > 0 && r->nsteps > 0) {
+    const R_xlen_t cn = (R_xlen_t)(r->nchains * r->nsteps);
+    r->fed_logu = el_real(run, "fed_logu", cn, 1);                               /* [C][nsteps] */
+    r->fed_z = el_real(run, "fed_z", cn * variates_per_step(k), 1);              /* [C][nsteps][kz]: a short vector would be read out of bounds */
   }
 }
 
@@ -169,9 +191,12 @@ SEXP C_fmcmc_amd_run(SEXP model, SEXP kernel, SEXP run, SEXP state) {
   fmcmc_model m; fmcmc_kernel k; fmcmc_run r; fmcmc_state s; fmcmc_out o;
   fill_model(model, &m);
   fill_kernel(kernel, &k);
-  fill_run(run, &r);
+  fill_run(run, &k, &r);
   if (fmcmc_validate(&m, &k, &r) != FMCMC_OK) error("%s", fmcmc_last_error());   /* the reference's own stop() texts */
   const R_xlen_t C = (R_xlen_t)r.nchains, K = k.k, S = (R_xlen_t)fmcmc_kept_rows(r.nsteps, r.burnin, r.thin);
+  /* allocMatrix / alloc3DArray take int extents: refuse what would be truncated instead of allocating something else */
+  if (C > INT_MAX || S > INT_MAX || r.nsteps > INT_MAX)
+    error("fmcmc_amd shim: %ld chains x %ld kept rows (%ld steps) exceed the extents of an R array", (long)C, (long)S, (long)r.nsteps);
   R_xlen_t kf = 0;
   for (R_xlen_t j = 0; j < K; j++) kf += !k.fixed[j];
   const int adaptive = (k.kind == FMCMC_KERNEL_ADAPT || k.kind == FMCMC_KERNEL_RAM);
@@ -270,8 +295,19 @@ SEXP C_fmcmc_amd_run(SEXP model, SEXP kernel, SEXP run, SEXP state) {
       R_xlen_t bad = 0;
       while (bad < C && INTEGER(status)[bad] == FMCMC_CHAIN_OK) bad++;
       if (bad == C) bad = 0;
-      int off = snprintf(msg, sizeof msg, "%s This error ocurred during step i = %.0f (chain %ld) and proposal parameters theta1 = c(",
-                         fmcmc_last_error(), REAL(status_step)[bad], (long)(r.chain_base + bad + 1));
+      /* (built from the chain's status, not from fmcmc_last_error(): the library's text already ends in its own
+       *  "This error ocurred during step i = N" and the sentence would appear twice) */
+      const char* what = "fun(par) is undefined.";
+      switch (INTEGER(status)[bad]) {
+        case FMCMC_CHAIN_NAN_LOGPOST: what = "fun(par) is undefined (NaN)."; break;
+        case FMCMC_CHAIN_NAN_RATIO: what = "fun(par) is undefined (f1 - f0 is NaN)."; break;
+        case FMCMC_CHAIN_NOT_PD: what = "'Sigma' is not positive definite."; break;
+        case FMCMC_CHAIN_BAD_WINDOW: what = "subscript out of bounds: the rows kernel_adapt(bw / freq) adapts on reach before the first row of this call."; break;
+        case FMCMC_CHAIN_SYNC_TIMEOUT: what = "a grid-wide hand-over of the observation-sharded evaluation timed out; the results of this call are invalid."; break;
+        default: break;
+      }
+      int off = snprintf(msg, sizeof msg, "%s Check either -fun- or the -lb- and -ub- parameters. This error ocurred during step i = %.0f "
+                         "(chain %ld) and proposal parameters theta1 = c(", what, REAL(status_step)[bad], (long)(r.chain_base + bad + 1));
       for (R_xlen_t j = 0; j < K && off < (int)sizeof msg - 40; j++)
         off += snprintf(msg + off, sizeof msg - (size_t)off, "%s%.4f", j ? ", " : "", REAL(status_theta)[bad * K + j]);
       snprintf(msg + off, sizeof msg - (size_t)off, ")");
@@ -319,7 +355,7 @@ SEXP C_fmcmc_amd_validate(SEXP model, SEXP kernel, SEXP run) {
   fmcmc_model m; fmcmc_kernel k; fmcmc_run r;
   fill_model(model, &m);
   fill_kernel(kernel, &k);
-  fill_run(run, &r);
+  fill_run(run, &k, &r);
   if (fmcmc_validate(&m, &k, &r) != FMCMC_OK) error("%s", fmcmc_last_error());
   return ScalarLogical(1);
 }

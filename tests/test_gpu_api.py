@@ -264,16 +264,20 @@ def test_host_pointer_entry_point(E, O):
     assert "-burnin- (10) cannot be >= than -nsteps- (10)." in abi.last_error()
 
 
-@pytest.mark.parametrize("kind", ["normal", "ram"])
+@pytest.mark.parametrize("kind", ["normal", "ram", "ram_qfun_normal", "ram_qfun_t2.5", "unif"])
 def test_rng_stream_entry_point_equals_in_library_stream(E, O, kind):
-    """fmcmc_rng_stream_dev + rng_mode FED is bit-identical to rng_mode PHILOX (what bench.py relies on)."""
+    """fmcmc_rng_stream_dev + rng_mode FED is bit-identical to rng_mode PHILOX (what bench.py relies on), for every variate
+    family a kernel draws: N(0,1), kernel_ram's rt(k, k) / rnorm(k) / rt(k, df) (R/kernel_ram.R:68), U(0,1)."""
     import torch
     from fmcmc_amd import _abi as abi
     X, y = synth_linreg(10000, 3, 20260102)
     init = np.array([0, 0, 0, 0, float(np.std(y))])[None, :] + 0.1 * np.random.default_rng(3).standard_normal((6, 5))
     init[:, -1] = np.abs(init[:, -1])
-    ok = O.Kernel(O.K_NORMAL if kind == "normal" else O.K_RAM, 5, **(dict(scale=0.02) if kind == "normal" else {}))
-    gk = E.KernelSpec(ok.kind, 5, ok.mu, ok.scale, ok.lb, ok.ub, ok.fixed, warmup=ok.warmup, eps=ok.eps, arate=ok.arate)
+    okw = {"normal": dict(scale=0.02), "ram": {}, "ram_qfun_normal": dict(ram_qfun=1), "ram_qfun_t2.5": dict(ram_qfun=2, ram_df=2.5),
+           "unif": dict(min_=-0.03, max_=0.04)}[kind]
+    ok = O.Kernel(O.K_NORMAL if kind == "normal" else (O.K_UNIF if kind == "unif" else O.K_RAM), 5, **okw)
+    gk = E.KernelSpec(ok.kind, 5, ok.mu, ok.scale, ok.lb, ok.ub, ok.fixed, warmup=ok.warmup, eps=ok.eps, arate=ok.arate,
+                      ram_qfun=ok.ram_qfun, ram_df=ok.ram_df, ram_eta_exp=ok.ram_eta_exp)
     gm = E.DeviceModel(abi.FAM_GAUSSIAN_LINREG, X, y)
     st1, st2 = E.ChainState(init, 5), E.ChainState(init, 5)
     a = E.sweep(gm, gk, st1, 120, seed=11, chain_base=40)
@@ -556,6 +560,23 @@ def test_autostop_with_thinning_restarts_from_the_last_kept_row(E, O, readme_dat
     assert np.array_equal(_bits(ans.as_array()), _bits(ro.samples))
     assert list(ans.iters) == list(ro.iters)
     assert len(f.get_logpost()) == 4 and f.get_logpost()[0].shape[0] == ans.niter
+
+
+def test_autostop_first_bulk_without_a_kept_row_and_argument_types(E, O, readme_data):
+    """burnin = 30, thin = 45, freq = 20: the first bulk (50 steps) passes the argument checks and keeps no row; the second
+    bulk (20 steps < thin) is then refused with the reference's own message (R/mcmc.R:508-510 inside the second
+    MCMC_without_conv_checker call) -- not with a chain error from a restart on the NaN prefill of the history.  And a
+    closure / a non-kernel are refused with the documented TypeError before anything is allocated."""
+    import fmcmc_amd as f
+    X, y = readme_data
+    init = np.tile([0, 0, O.r_sd(y)], (3, 1)) + 0.2 * np.random.default_rng(8).standard_normal((3, 3))
+    with pytest.raises(ValueError, match=r"-thin- \(45\) cannot be > than -nsteps- \(20\)"):
+        f.MCMC(init, f.gaussian_linreg(X, y), 400, seed=3, nchains=3, burnin=30, thin=45, kernel=f.kernel_normal(scale=0.05),
+               conv_checker=f.convergence_gelman(20, threshold=0.0))
+    with pytest.raises(TypeError, match="-fun- must be one of"):
+        f.MCMC(init, lambda p: 0.0, 400, nchains=3, conv_checker=f.convergence_gelman(20))
+    with pytest.raises(TypeError, match="-kernel- must be"):
+        f.MCMC(init, f.gaussian_linreg(X, y), 400, nchains=3, kernel="normal", conv_checker=f.convergence_gelman(20))
 
 
 def test_preallocated_history_equals_separate_calls(E, O):

@@ -274,16 +274,20 @@ def test_mfma_equals_valu_kernels(E, O, monkeypatch):
     a, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=80, scale=0.02)
     set_knob(monkeypatch, "mfma", "0")
     b, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=80, scale=0.02)
-    set_knob(monkeypatch, "spec", "0")
-    c, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=80, scale=0.02)
     assert _bits_equal(a.samples.cpu().numpy(), b.samples.cpu().numpy())
+    from fmcmc_amd import _abi as abi
+    assert abi.last_kernel() == "spec"
+    set_knob(monkeypatch, "spec", "0")     # the software-pipelined kernel: an A/B partner, in -DFMCMC_AB builds only
+    c, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=80, scale=0.02)
     assert _bits_equal(a.samples.cpu().numpy(), c.samples.cpu().numpy())
+    assert abi.last_kernel() in ("pipe", "spec")
 
 
 @pytest.mark.parametrize("n", [10000, 9000, 600])
 def test_mfma_replicated_equals_owner_kernel(E, O, monkeypatch, n):
     """The two MFMA kernels (owner waves = the product path / chain state replicated in every wave, one barrier) give the
-    same bits as the oracle and as each other wherever both are compiled in (n > 8192; below that the switch is a no-op),
+    same bits as the oracle and as each other wherever both are compiled in (-DFMCMC_AB builds, n > 8192; elsewhere the
+    switch is a no-op and the test covers the product kernel on these cases),
     incl. thinning, continuation, a fixed parameter, the uniform kernel and a chain that fails with a NaN (the rare-path
     branch of either kernel)."""
     X, y = synth_linreg(n, 3, 31 + n)
@@ -300,6 +304,9 @@ def test_mfma_replicated_equals_owner_kernel(E, O, monkeypatch, n):
         d, ro = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, bad, nsteps=60, guard=False, scale=1.0)
         assert (ro.status == 1).any()
         out[force] = [r.samples.cpu().numpy() for r in (a, b, c)] + [d.status.cpu().numpy()]
+        if force == "0":   # (the replicated-state kernel is an A/B partner: -DFMCMC_AB builds carry it, the product library does not)
+            from fmcmc_amd import _abi as abi
+            assert abi.last_kernel() in ("mfma", "mfma-replicated")
     for u, w in zip(out["1"][:3], out["0"][:3]):
         assert _bits_equal(u, w)
     assert np.array_equal(out["1"][3], out["0"][3])

@@ -1,5 +1,5 @@
 """Perf guard: a short run of every GPU config of BASELINE.md section 4 must not be slower than 1.25x the time per MH
-iteration recorded in profiles/perf_guard.json (measured with this same test's loop, HIP events, best of three).  The
+iteration recorded in profiles/perf_guard.json (measured with this same test's loop, HIP events, best of four).  The
 round-1 history shows why: one more dword in a by-value argument struct cost 25 %, stamp code merely present 13 %.
 Record new values with  FMCMC_PERF_GUARD_RECORD=1 python -m pytest tests/test_gpu_perf_guard.py -m gpu  (on the GPU box)."""
 import json
