@@ -60,6 +60,14 @@ struct SweepArgs {
   long long ldS;             // row stride of the samples / draws columns and of logpost (>= S: fmcmc_out.ld_rows)
   unsigned long long seed;
   int rng_mode, fresh, ram_bounded, kz, tb, debug;
+  // A long call of the stream-fed kernels (normal / uniform proposals: mh_sweep_mfma, mh_sweep_spec) runs as consecutive
+  // STEP WINDOWS, each with a bounded materialised RNG stream (launch_sweep).  A continuation window is a launch whose
+  // step 1 re-evaluates the state it starts from (same bits as the f0 it replaces) and whose steps 2.. are the call's steps
+  // step_off + 2 ..: win_cont = 1 makes it take over the chain status and the partly filled word of the accept bitmap (the
+  // accept COUNT is per launch: launch_sweep adds the windows up); thin_ctr0 is the thinning counter it starts with,
+  // bits_stride the words per chain of the WHOLE call's bitmap, step_off what to add to a local step for status_step.
+  int win_cont, thin_ctr0;
+  long long bits_stride, step_off;
   const double* fed_logu;
   const double* fed_z;
   // state

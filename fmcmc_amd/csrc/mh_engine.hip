@@ -127,6 +127,12 @@ __global__ void shard_build_mfma(const double* X, const double* y, long long n, 
   }
 }
 
+// accept counts of a continuation window (step windows, launch_sweep) added to the call's
+__global__ void add_counts_kernel(long long* total, const long long* part, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) total[i] += part[i];
+}
+
 size_t sweep_lds_bytes(int k, int kf, int kind, int CW, int tb, int kz, bool resident) {
   size_t d = 4 * (size_t)k + (k / 2 + 1) + (size_t)NW * CW + 1 + (size_t)CW * tb * (kz + 1) +
              (resident ? (size_t)CW * NT : 0) + (size_t)CW * chain_lds_doubles(k, kf, kind);
@@ -302,17 +308,18 @@ static SweepArgs chain_window(const SweepArgs& A, long long off, long long cnt, 
 //   shard=0|1    wide models: never / always (when eligible) observation-sharded; unset: cost model
 //   shard_mfma=0 VALU form of the sharded slice product           wide2=0|1   never / always (when eligible) the dataflow form
 //   groups=4     four chain groups in the dataflow form (default two)       tiles=0     even N-tile shares of its evaluator waves
+//   window=N     step-window length of the stream-fed kernels (multiple of 32; default: ~256 MiB of stream per window)
 //   mode=<bits>  timing ablations and stamps (SweepArgs.debug)
 // The kernel a call ended up on is reported by fmcmc_last_kernel(); DESIGN.md section 5 has the shape -> kernel table.
 struct Knobs {
-  int streamed = -1, cw = -1, pipe = -1, spec = -1, mfma = -1, owners = -1, shard = -1, shard_mfma = -1, wide2 = -1, groups = -1, tiles = -1, mode = 0;
+  int streamed = -1, cw = -1, pipe = -1, spec = -1, mfma = -1, owners = -1, shard = -1, shard_mfma = -1, wide2 = -1, groups = -1, tiles = -1, window = -1, mode = 0;
 };
 static Knobs read_knobs() {
   Knobs K;
   const char* e = getenv("FMCMC_AMD_DEBUG");
   if (!e) return K;
   struct { const char* name; int* dst; } tab[] = {{"streamed", &K.streamed}, {"cw", &K.cw}, {"pipe", &K.pipe}, {"spec", &K.spec},
-      {"mfma", &K.mfma}, {"owners", &K.owners}, {"shard_mfma", &K.shard_mfma}, {"shard", &K.shard}, {"wide2", &K.wide2}, {"groups", &K.groups}, {"tiles", &K.tiles}, {"mode", &K.mode}};
+      {"mfma", &K.mfma}, {"owners", &K.owners}, {"shard_mfma", &K.shard_mfma}, {"shard", &K.shard}, {"wide2", &K.wide2}, {"groups", &K.groups}, {"tiles", &K.tiles}, {"window", &K.window}, {"mode", &K.mode}};
   while (*e) {
     const char* eq = strchr(e, '=');
     const char* end = strchr(e, ',');
@@ -364,7 +371,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
                         fmcmc_state* st, fmcmc_out* out, int kf, int ram_bounded, hipStream_t stream) {
   SweepArgs A;
   memset(&A, 0, sizeof(A));
-  AsyncScratch hist_guard, ws_guard, shw_guard;
+  AsyncScratch hist_guard, ws_guard, shw_guard, wc_guard;
   // the uniform kernels ARE the normal kernels with mu = min., scale = max. - min. and U(0,1) variates
   fmcmc_kernel ke = *kn_in;
   if (ke.kind == FMCMC_KERNEL_UNIF) { ke.kind = FMCMC_KERNEL_NORMAL; A.variate = 1; }
@@ -488,8 +495,14 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
       (kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE ||
        (((kn->kind == FMCMC_KERNEL_ADAPT && !adapt_hist) || (kn->kind == FMCMC_KERNEL_RAM && !ram_bounded && !kn->constr)) && !nospec)) &&
       (kn->scheme == FMCMC_SCHEME_JOINT || kn->kind >= FMCMC_KERNEL_ADAPT) && kn->k <= PIPE_KMAX &&
-      (unsigned long long)run->nchains * kn->k * (unsigned long long)A.ldS * 8ull < (1ull << 32) &&
-      (unsigned long long)run->nchains * (unsigned long long)run->nsteps * (unsigned long long)A.kz * 8ull < (1ull << 32)) {
+      // Sizes (round 3: rows and variates are addressed as 64-bit chain base + 32-bit offset, and a long call of the normal /
+      // uniform kernels runs as step windows with a bounded stream, so a call no longer leaves these kernels at 4 GiB of
+      // samples or stream).  What is left: offsets inside one chain's blocks are 32 bits, and the adaptive kernels -- whose
+      // step-dependent rules make a window a different call -- materialise their whole stream, which is kept below 8 GiB.
+      (unsigned long long)run->nsteps * (unsigned long long)A.kz * 8ull < (1ull << 32) && run->nsteps < (1ll << 30) &&
+      (unsigned long long)kn->k * (unsigned long long)A.ldS * 8ull < (1ull << 32) &&      /* 32-bit offsets inside ONE chain's block */
+      (kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE ||
+       (unsigned long long)run->nchains * (unsigned long long)run->nsteps * (unsigned long long)(A.kz + 1) * 8ull < (8ull << 30))) {
     if (m->p == 3 && m->n > (long long)NT * 19 && m->n <= (long long)NT * 20) pipe_opt = 20;
     if (m->p == 1 && m->n > (long long)NT * 1 && m->n <= (long long)NT * 2) pipe_opt = 2;
     // fp64-MFMA evaluation: general in n and p up to what 80 operand registers per lane hold (normal / uniform kernels)
@@ -505,20 +518,48 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
     const size_t plds = pipe_opt ? pipe_lds_bytes(pipe_opt) : 0;
     const long long pblk = (run->nchains + 3) / 4;
     double* ws = nullptr;
+    const double fill_df = (kn->kind == FMCMC_KERNEL_RAM) ? A.ram_df : (A.variate == 1 ? -1.0 : 0.0);
+    // Step windows: the normal / uniform kernels with the library's own stream.  Window 0 is an ordinary launch of the call's
+    // first n0 steps; every later window is a launch of w + 1 steps whose step 1 re-evaluates the state the window starts
+    // from (bit for bit the f0 it replaces) and whose steps 2 .. w + 1 are the call's next w steps (SweepArgs.win_cont).
+    // The stream of a window (rows of w + 1 steps) is filled right in front of it into ONE reused buffer of <= ~256 MiB
+    // (it was nchains x nsteps x (kz + 1) doubles, and the reason for the 4 GiB limit; measured at C2's shape, 1.2e5 steps:
+    // windows of 320 / 1344 / 8192 steps 2.17 / 2.08 / 2.05 us per step -- a window costs ~40 us of launches, refill of the
+    // 80 operand registers and one extra evaluation, so the buffer is as large as is reasonable, not cache-sized).  The Philox counter
+    // is the ABSOLUTE step, so the variates, and with them every bit of the output, do not depend on the cut
+    // (windows begin behind a step = 1 mod 32: the accept bitmap's words then line up).
+#ifdef FMCMC_AB
+    const bool ab_partner = (K.spec == 0 || K.owners == 0);   // (the A/B partner kernels know nothing of windows)
+#else
+    const bool ab_partner = false;
+#endif
+    const bool windowed = A.rng_mode == FMCMC_RNG_PHILOX && kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE && !ab_partner;
+    long long win = run->nsteps;
+    if (windowed) {
+      const long long per_step = (long long)run->nchains * (A.kz + 1) * 8;
+      win = ((256ll << 20) / (per_step > 0 ? per_step : 1)) & ~31ll;
+      if (win < 512) win = 512;
+      if (K.window >= 32) win = (long long)K.window & ~31ll;      // (diagnosis / tests: a window length)
+    }
+    const long long n0 = (windowed && run->nsteps > win + 1) ? win + 1 : run->nsteps;   // steps of window 0
     if (A.rng_mode == FMCMC_RNG_PHILOX) {
-      // materialise the canonical stream: [C][nsteps] log u, then [C][nsteps][kz] z
-      const size_t items = (size_t)run->nchains * (size_t)run->nsteps;
+      // materialise the canonical stream: [C][rows] log u, then [C][rows][kz] z; rows = a window's steps (or the whole call)
+      const long long rows = (n0 < run->nsteps) ? win + 1 : run->nsteps;
+      const size_t items = (size_t)run->nchains * (size_t)rows;
       e = hipMallocAsync((void**)&ws, sizeof(double) * items * (size_t)(A.kz + 1), stream);
       if (e != hipSuccess) { set_err("hipMallocAsync(rng stream) failed: %s", hipGetErrorString(e)); return FMCMC_ERR_DEVICE; }
       ws_guard.p = ws; ws_guard.s = stream;
-      hipLaunchKernelGGL(rng_fill_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream,
-                         (unsigned long long)run->seed, (long long)run->step_base, (long long)run->chain_base,
-                         (long long)run->nchains, (long long)run->nsteps, A.kz,
-                         (kn->kind == FMCMC_KERNEL_RAM) ? A.ram_df : (A.variate == 1 ? -1.0 : 0.0), ws, ws + items);
-      A.fed_logu = ws;
-      A.fed_z = ws + items;
-      A.rng_mode = FMCMC_RNG_FED;
     }
+    auto fill_stream = [&](SweepArgs& W, long long step_base_eff) {   // the stream of launch W, rows = W.nsteps
+      const size_t items = (size_t)W.nchains * (size_t)W.nsteps;
+      hipLaunchKernelGGL(rng_fill_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream,
+                         (unsigned long long)run->seed, step_base_eff, (long long)run->chain_base,
+                         (long long)W.nchains, (long long)W.nsteps, A.kz, fill_df, ws, ws + items);
+      W.fed_logu = ws;
+      W.fed_z = ws + items;
+      W.rng_mode = FMCMC_RNG_FED;
+    };
+    auto launch_fast = [&](const SweepArgs& A) {   // (shadows the call's arguments: the launch macros below name `A`)
 #ifdef FMCMC_AB
 #define LAUNCH_PIPE(PV, OV, KV)                                                                        \
     do {                                                                                               \
@@ -548,7 +589,13 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
 #endif
       if (!owners) g_kernel = "mfma-replicated";
       const bool dbgk = (A.debug & 8) != 0 && mfma_ng == 1 && ns == 20; (void)dbgk;
-#define MF_CASE(KN, KV, GV, SV) case SV: hipLaunchKernelGGL((KN<KV, GV, SV, false>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A); break;
+      // (offsets from the buffer bases stay 32 bits -- the cheaper form, see mh_sweep_mfma's BIG -- while the samples of all chains
+      //  and the stream of this launch stay below 4 GiB)
+      const bool big = (unsigned long long)A.nchains * kn->k * (unsigned long long)A.ldS * 8ull >= (1ull << 32) ||
+                       (unsigned long long)A.nchains * (unsigned long long)A.nsteps * (unsigned long long)A.kz * 8ull >= (1ull << 32);
+#define MF_CASE(KN, KV, GV, SV) case SV: if (big) hipLaunchKernelGGL((KN<KV, GV, SV, false, true>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A); \
+                                         else hipLaunchKernelGGL((KN<KV, GV, SV, false, false>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A); break;
+#define MF_CASE_AB(KN, KV, GV, SV) case SV: hipLaunchKernelGGL((KN<KV, GV, SV, false>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A); break;
 #define MF_CASES10(KN, KV, GV) MF_CASE(KN, KV, GV, 1) MF_CASE(KN, KV, GV, 2) MF_CASE(KN, KV, GV, 3) MF_CASE(KN, KV, GV, 4) MF_CASE(KN, KV, GV, 5) \
                                MF_CASE(KN, KV, GV, 6) MF_CASE(KN, KV, GV, 7) MF_CASE(KN, KV, GV, 8) MF_CASE(KN, KV, GV, 9) MF_CASE(KN, KV, GV, 10)
 #define MF_CASES16(KN, KV, GV) MF_CASES10(KN, KV, GV) MF_CASE(KN, KV, GV, 11) MF_CASE(KN, KV, GV, 12) MF_CASE(KN, KV, GV, 13) \
@@ -562,7 +609,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
       } else if (dbgk) {
         hipLaunchKernelGGL((mh_sweep_mfmar<1, 1, 20, true>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A);
       } else if (!owners) {
-        switch (ns) { MF_CASES17(mh_sweep_mfmar, 1, 1) default: break; }
+        switch (ns) { MF_CASE_AB(mh_sweep_mfmar, 1, 1, 17) MF_CASE_AB(mh_sweep_mfmar, 1, 1, 18) MF_CASE_AB(mh_sweep_mfmar, 1, 1, 19) MF_CASE_AB(mh_sweep_mfmar, 1, 1, 20) default: break; }
 #endif
       } else if (mfma_ng == 2 && kv == 1) {
         switch (ns) { MF_CASES10(mh_sweep_mfma, 1, 2) default: break; }
@@ -577,6 +624,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
 #undef MF_CASES16
 #undef MF_CASES10
 #undef MF_CASE
+#undef MF_CASE_AB
     } else
     if (!nospec) {
       const size_t slds = spec_lds_bytes(pipe_opt, kn->kind >= FMCMC_KERNEL_ADAPT);
@@ -612,6 +660,43 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
     else LAUNCH_PIPE(1, 2, 2);
 #undef LAUNCH_PIPE
 #endif
+    };   // launch_fast
+    {
+      SweepArgs W = A;
+      W.nsteps = n0;
+      W.bits_stride = (run->nsteps + 31) >> 5;
+      if (A.rng_mode == FMCMC_RNG_PHILOX) fill_stream(W, (long long)run->step_base);
+      launch_fast(W);
+      const long long kept_all = A.S;
+      long long* wcount = nullptr;                                          // accept counts of one continuation window
+      if (n0 < run->nsteps) {
+        e = hipMallocAsync((void**)&wcount, sizeof(long long) * (size_t)run->nchains, stream);
+        if (e != hipSuccess) { set_err("hipMallocAsync(window counts) failed: %s", hipGetErrorString(e)); return FMCMC_ERR_DEVICE; }
+        wc_guard.p = wcount; wc_guard.s = stream;
+      }
+      for (long long s0 = n0; s0 < run->nsteps && e == hipSuccess; ) {     // continuation windows
+        const long long w = (run->nsteps - s0 < win) ? run->nsteps - s0 : win;
+        const long long rows_done = fmcmc_kept_rows(s0, run->burnin, run->thin);
+        W = A;
+        W.nsteps = w + 1;
+        W.win_cont = 1;
+        W.step_off = s0 - 1;
+        W.burnin = (run->burnin - s0 + 1 > 1) ? run->burnin - s0 + 1 : 1;
+        W.thin_ctr0 = (s0 > run->burnin) ? (int)((s0 - run->burnin) % run->thin) : 0;
+        W.bits_stride = (run->nsteps + 31) >> 5;
+        W.samples = A.samples + rows_done;
+        if (A.logpost) W.logpost = A.logpost + rows_done;
+        if (A.draws) W.draws = A.draws + rows_done;
+        if (A.accept_bits) W.accept_bits = A.accept_bits + ((s0 - 1) >> 5);
+        W.S = kept_all - rows_done;
+        W.accept_count = wcount;
+        fill_stream(W, (long long)run->step_base + s0 - 1);
+        launch_fast(W);
+        hipLaunchKernelGGL(add_counts_kernel, dim3((unsigned)((run->nchains + 255) / 256)), dim3(256), 0, stream, A.accept_count, wcount,
+                           (long long)run->nchains);
+        s0 += w;
+      }
+    }
   } else
   if (resident && res_p == 1) { g_kernel = "resident"; LAUNCH_KIND(4, 1, 4); }
   else if (resident && res_p == 3) { g_kernel = "resident"; LAUNCH_KIND(4, 3, 20); }

@@ -41,7 +41,11 @@ constexpr int MF_TCS = 8 * PIPE_TRS + 2;   // (the replicated kernel's tile, mh_
 // NG = 2: p <= 7, n <= 5120.  The number of observation slots NS = ceil(n / 512) is a TEMPLATE parameter: with a run-time
 // count every batch of MFMAs becomes a basic block, the scheduler can no longer overlap the FMAs of one batch with the
 // MFMAs of the next, and the step is 22 % slower (measured).  Only the last slot holds padding and pays for masks.
-template <int KIND, int NG, int NS, bool DBG>
+// BIG: offsets of rows and variates are 32 bits from the CHAIN's own blocks (64-bit wave-uniform bases computed here) instead
+// of 32 bits from the buffer bases (kernel arguments): the form for calls with more than 4 GiB of samples or of fed
+// variates.  A template parameter because the extra scalar registers cost the headline shape 1.7 % (the kernel sits at
+// the SGPR limit); the dispatcher takes BIG only where the sizes need it.
+template <int KIND, int NG, int NS, bool DBG, bool BIG = false>
 __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
   constexpr int CW = 4;
 #ifndef MFO_MB
@@ -118,15 +122,29 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
   double th0 = plane ? A.theta0[(long long)cl * k + lane] : 0.0;
   double th1 = th0;
   double f0 = 0.0;
-  int nacc = 0, status = FMCMC_CHAIN_OK, thin_ctr = 0;
-  unsigned int srow8 = 0, bitword = 0;
-  const unsigned int sd_off = (unsigned int)((((long long)cl * k + jl) * A.ldS) * 8);
-  const unsigned int z_off = (unsigned int)((((long long)cl * nsteps) * kz + zidx) * 8);
-  const unsigned int lp_off = (unsigned int)(((long long)cl * A.ldS) * 8);
+  // (a continuation window of a long call takes over what the windows before it left: SweepArgs.win_cont)
+  // (accept counts are per launch and launch_sweep adds the windows up: taking the earlier count over in here cost 1.7 % per
+  //  step -- the kernel sits at the SGPR limit and one more value live across the loop tipped the allocation, 11 -> 24 spills)
+  int nacc = 0;
+  int status = (A.win_cont && owner) ? A.status[cl] : FMCMC_CHAIN_OK, thin_ctr = A.thin_ctr0;
+  unsigned int bitword = 0;
+  // Row stores: until round 3 the byte offsets were 32-bit from the BUFFER bases, which capped a call at 4 GiB of samples
+  // (1024 chains x 5 parameters: 1.04e5 kept rows) and sent anything longer to the general kernel.  Now the 64-bit part of an
+  // address is the chain's own block and only the offset inside it is 32 bits (k ldS 8 < 2^32: the dispatcher's condition).
+  // (wave-uniform 64-bit bases -- the chain's block -- plus a 32-bit byte offset per lane: one scalar-base store each)
+  char* const s_base = reinterpret_cast<char*>(A.samples) + (BIG ? ((long long)cl * k) * A.ldS * 8 : 0ll);
+  char* const d_base = A.draws ? reinterpret_cast<char*>(A.draws) + (BIG ? ((long long)cl * k) * A.ldS * 8 : 0ll) : nullptr;
+  char* const l_base = A.logpost ? reinterpret_cast<char*>(A.logpost) + (BIG ? (long long)cl * A.ldS * 8 : 0ll) : nullptr;
+  const unsigned int lane_off = (unsigned int)(((BIG ? 0ll : (long long)cl * k) + jl) * A.ldS * 8);
+  const unsigned int lp_off = BIG ? 0u : (unsigned int)((long long)cl * A.ldS * 8);
+  unsigned int srow8 = 0;
+  // (wave-uniform 64-bit base + a 32-bit offset per lane and row: nsteps kz 8 < 2^32 is the dispatcher's condition)
+  const char* const z_base = reinterpret_cast<const char*>(A.fed_z) + (BIG ? ((long long)cl * nsteps) * kz * 8 : 0ll);   // wave-uniform
+  const unsigned int z_lane = (unsigned int)(((BIG ? 0ll : (long long)cl * nsteps) * kz + zidx) * 8);
   const double* const lu_row = A.fed_logu + (long long)cl * nsteps;
   const double dn = uniform_d((double)A.n);
   auto ld_z = [&](int row) -> double {
-    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(A.fed_z) + (z_off + (unsigned int)row * (unsigned int)(kz * 8)));
+    return *reinterpret_cast<const double*>(z_base + (z_lane + (unsigned int)row * (unsigned int)(kz * 8)));
   };
   // every lane of an owner wavefront keeps one variate and the log-uniform of the next step in flight (unconditional,
   // clamped addresses: a conditional load costs a register copy behind the load, i.e. an exposed wait)
@@ -148,8 +166,11 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
     return f;
   };
   auto flush_bits = [&](int i) {
-    if (A.accept_bits && lane == 0)
-      A.accept_bits[(long long)cl * ((nsteps + 31) >> 5) + ((i - 1) >> 5)] = bitword;
+    if (A.accept_bits && lane == 0) {   // (bits_stride: words per chain of the whole call's bitmap, set by launch_sweep for every launch)
+      unsigned int* w = A.accept_bits + ((long long)cl * A.bits_stride + ((i - 1) >> 5));
+      // the first word of a continuation window also holds the last bit of the window before it
+      *w = (A.win_cont && i <= 32) ? (*w | bitword) : bitword;
+    }
     bitword = 0;
   };
   lds_barrier();
@@ -307,7 +328,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
           const double ratio = f1 - f0;
           if (fmh_isnan(f1) || fmh_isnan(ratio)) {
             status = fmh_isnan(f1) ? FMCMC_CHAIN_NAN_LOGPOST : FMCMC_CHAIN_NAN_RATIO;
-            if (lane == 0) { A.status[cl] = status; A.status_step[cl] = v; }
+            if (lane == 0) { A.status[cl] = status; A.status_step[cl] = v + A.step_off; }
             if (plane) A.status_theta[(long long)cl * k + lane] = th1;
             flush_bits(v);
           } else {
@@ -344,10 +365,10 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
         if (thin_ctr == thin) {
           thin_ctr = 0;
           if (plane) {
-            *reinterpret_cast<double*>(reinterpret_cast<char*>(A.samples) + (sd_off + srow8)) = st_th0;
-            if (A.draws) *reinterpret_cast<double*>(reinterpret_cast<char*>(A.draws) + (sd_off + srow8)) = st_th1;
+            *reinterpret_cast<double*>(s_base + (lane_off + srow8)) = st_th0;
+            if (d_base) *reinterpret_cast<double*>(d_base + (lane_off + srow8)) = st_th1;
           }
-          if (A.logpost && lane == 0 && !dbg) *reinterpret_cast<double*>(reinterpret_cast<char*>(A.logpost) + (lp_off + srow8)) = st_f1;
+          if (l_base && lane == 0 && !dbg) *reinterpret_cast<double*>(l_base + (lp_off + srow8)) = st_f1;
           srow8 += 8;
         }
       }
@@ -362,7 +383,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
     if (plane) A.theta0[(long long)cl * k + lane] = th0;
     if (lane == 0) {
       A.f0[cl] = f0;
-      A.accept_count[cl] = nacc;
+      A.accept_count[cl] = nacc;   // (of THIS launch: launch_sweep adds the windows up)
       if (status == FMCMC_CHAIN_OK) { A.status[cl] = FMCMC_CHAIN_OK; A.status_step[cl] = 0; }
     }
   }

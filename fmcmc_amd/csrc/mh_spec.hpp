@@ -67,7 +67,7 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
   double f0 = 0.0;
   long long abs_iter = 0;
   int nacc = 0, status = FMCMC_CHAIN_OK, thin_ctr = 0, have_mean = 0, nerr = 0;
-  unsigned int srow8 = 0, bitword = 0;
+  unsigned int bitword = 0;
   double* const Scur = SigA;
   if (lane < k) { double t = A.theta0[(long long)cl * k + lane]; th0[lane] = t; th1[lane] = t; }
   for (int e = lane; e < kf * LD; e += 64) {
@@ -85,12 +85,19 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
   }
   wave_sync_lds();
   const int jl = (lane < k) ? lane : 0;
-  const unsigned int sd_off = (unsigned int)((((long long)cl * k + jl) * A.ldS) * 8);
-  const unsigned int z_off = (unsigned int)((((long long)cl * nsteps) * kz + (lane < kz ? lane : 0)) * 8);
-  const unsigned int lp_off = (unsigned int)(((long long)cl * A.ldS) * 8);
+  // (row stores and variates: wave-uniform 64-bit bases of the chain's own blocks + 32-bit offsets -- 32-bit offsets from the
+  //  BUFFER bases capped a call at 4 GiB)
+  // (wave-uniform 64-bit bases -- the chain's block -- plus a 32-bit byte offset per lane: one scalar-base store each)
+  char* const s_base = reinterpret_cast<char*>(A.samples) + ((long long)cl * k) * A.ldS * 8;
+  char* const d_base = A.draws ? reinterpret_cast<char*>(A.draws) + ((long long)cl * k) * A.ldS * 8 : nullptr;
+  char* const l_base = A.logpost ? reinterpret_cast<char*>(A.logpost) + (long long)cl * A.ldS * 8 : nullptr;
+  const unsigned int lane_off = (unsigned int)((long long)jl * A.ldS * 8);
+  unsigned int srow8 = 0;
+  const char* const z_base = reinterpret_cast<const char*>(A.fed_z) + ((long long)cl * nsteps) * kz * 8;   // wave-uniform
+  const unsigned int z_lane = (unsigned int)((lane < kz ? lane : 0)) * 8u;
   const double* const lu_row = A.fed_logu + (long long)cl * nsteps;
   auto ld_z = [&](int row) -> double {
-    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(A.fed_z) + (z_off + (unsigned int)row * (unsigned int)(kz * 8)));
+    return *reinterpret_cast<const double*>(z_base + (z_lane + (unsigned int)row * (unsigned int)(kz * 8)));
   };
   double z_nx = (lane < kz && nsteps >= 2) ? ld_z(1) : 0.0;
   double lu_nx = (nsteps >= 2) ? lu_row[1] : 0.0;
@@ -187,10 +194,10 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
       if (thin_ctr == thin) {
         thin_ctr = 0;
         if (lane < k) {
-          *reinterpret_cast<double*>(reinterpret_cast<char*>(A.samples) + (sd_off + srow8)) = th0[lane];
-          if (A.draws) *reinterpret_cast<double*>(reinterpret_cast<char*>(A.draws) + (sd_off + srow8)) = th1[lane];
+          *reinterpret_cast<double*>(s_base + (lane_off + srow8)) = th0[lane];
+          if (d_base) *reinterpret_cast<double*>(d_base + (lane_off + srow8)) = th1[lane];
         }
-        if (A.logpost && lane == 0) *reinterpret_cast<double*>(reinterpret_cast<char*>(A.logpost) + (lp_off + srow8)) = f1;
+        if (l_base && lane == 0) *reinterpret_cast<double*>(l_base + srow8) = f1;
         srow8 += 8;
       }
     }
@@ -274,10 +281,10 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
     }
     if (st_row) {   // row v of ans / draws / logpost, off the compute waves' critical path
       if (lane < k) {
-        *reinterpret_cast<double*>(reinterpret_cast<char*>(A.samples) + (sd_off + srow8)) = st_th0;
-        if (A.draws) *reinterpret_cast<double*>(reinterpret_cast<char*>(A.draws) + (sd_off + srow8)) = st_dr;
+        *reinterpret_cast<double*>(s_base + (lane_off + srow8)) = st_th0;
+        if (d_base) *reinterpret_cast<double*>(d_base + (lane_off + srow8)) = st_dr;
       }
-      if (A.logpost && lane == 0) *reinterpret_cast<double*>(reinterpret_cast<char*>(A.logpost) + (lp_off + srow8)) = f1;
+      if (l_base && lane == 0) *reinterpret_cast<double*>(l_base + srow8) = f1;
       srow8 += 8;
     }
   }
@@ -332,7 +339,7 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
   double f0 = 0.0, mean_prev = 0.0, run_sum = 0.0, zcur = 0.0;
   long long abs_iter = 0;
   int nacc = 0, status = FMCMC_CHAIN_OK, thin_ctr = 0, have_mean = 0, nerr = 0;
-  unsigned int srow8 = 0, bitword = 0;
+  unsigned int bitword = 0;
   if (!A.fresh) {
     abs_iter = A.abs_iter[cl];
     if (A.nerrors) nerr = A.nerrors[cl];
@@ -341,13 +348,20 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
       if (rl) mean_prev = A.mean_prev[(long long)cl * kf + lane];
     }
   }
-  const unsigned int sd_off = (unsigned int)((((long long)cl * k + jl) * A.ldS) * 8);
-  const unsigned int z_off = (unsigned int)((((long long)cl * nsteps) * kz + jl) * 8);
-  const unsigned int lp_off = (unsigned int)(((long long)cl * A.ldS) * 8);
+  // (row stores and variates: wave-uniform 64-bit bases of the chain's own blocks + 32-bit offsets -- 32-bit offsets from the
+  //  BUFFER bases capped a call at 4 GiB)
+  // (wave-uniform 64-bit bases -- the chain's block -- plus a 32-bit byte offset per lane: one scalar-base store each)
+  char* const s_base = reinterpret_cast<char*>(A.samples) + ((long long)cl * k) * A.ldS * 8;
+  char* const d_base = A.draws ? reinterpret_cast<char*>(A.draws) + ((long long)cl * k) * A.ldS * 8 : nullptr;
+  char* const l_base = A.logpost ? reinterpret_cast<char*>(A.logpost) + (long long)cl * A.ldS * 8 : nullptr;
+  const unsigned int lane_off = (unsigned int)((long long)jl * A.ldS * 8);
+  unsigned int srow8 = 0;
+  const char* const z_base = reinterpret_cast<const char*>(A.fed_z) + ((long long)cl * nsteps) * kz * 8;   // wave-uniform
+  const unsigned int z_lane = (unsigned int)(jl) * 8u;
   const double* const lu_row = A.fed_logu + (long long)cl * nsteps;
   const double dn = uniform_d((double)A.n);
   auto ld_z = [&](int row) -> double {
-    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(A.fed_z) + (z_off + (unsigned int)row * (unsigned int)(kz * 8)));
+    return *reinterpret_cast<const double*>(z_base + (z_lane + (unsigned int)row * (unsigned int)(kz * 8)));
   };
   double z_nx = (rl && nsteps >= 2) ? ld_z(1) : 0.0;
   double lu_nx = (nsteps >= 2) ? lu_row[1] : 0.0;
@@ -546,10 +560,10 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
     SPEC_ST(5);
     if (st_row) {   // row v of ans / draws / logpost, off the compute waves' critical path
       if (rl) {
-        *reinterpret_cast<double*>(reinterpret_cast<char*>(A.samples) + (sd_off + srow8)) = st_th0;
-        if (A.draws) *reinterpret_cast<double*>(reinterpret_cast<char*>(A.draws) + (sd_off + srow8)) = st_dr;
+        *reinterpret_cast<double*>(s_base + (lane_off + srow8)) = st_th0;
+        if (d_base) *reinterpret_cast<double*>(d_base + (lane_off + srow8)) = st_dr;
       }
-      if (A.logpost && lane == 0) *reinterpret_cast<double*>(reinterpret_cast<char*>(A.logpost) + (lp_off + srow8)) = f1;
+      if (l_base && lane == 0) *reinterpret_cast<double*>(l_base + srow8) = f1;
       srow8 += 8;
     }
     SPEC_ST(6);
@@ -712,15 +726,24 @@ __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
   double th0 = plane ? A.theta0[(long long)cl * k + lane] : 0.0;
   double th1 = th0;
   double f0 = 0.0;
-  int nacc = 0, status = FMCMC_CHAIN_OK, thin_ctr = 0;
-  unsigned int srow8 = 0, bitword = 0;
-  const unsigned int sd_off = (unsigned int)((((long long)cl * k + jl) * A.ldS) * 8);
-  const unsigned int z_off = (unsigned int)((((long long)cl * nsteps) * kz + zidx) * 8);
-  const unsigned int lp_off = (unsigned int)(((long long)cl * A.ldS) * 8);
+  // (a continuation window of a long call takes over what the windows before it left: SweepArgs.win_cont, mh_common.hpp)
+  int nacc = 0;                               // (per launch: launch_sweep adds the windows up)
+  int status = A.win_cont ? A.status[cl] : FMCMC_CHAIN_OK, thin_ctr = A.thin_ctr0;
+  unsigned int bitword = 0;
+  // (row stores and variates: wave-uniform 64-bit bases of the chain's own blocks + 32-bit offsets -- 32-bit offsets from the
+  //  BUFFER bases capped a call at 4 GiB)
+  // (wave-uniform 64-bit bases -- the chain's block -- plus a 32-bit byte offset per lane: one scalar-base store each)
+  char* const s_base = reinterpret_cast<char*>(A.samples) + ((long long)cl * k) * A.ldS * 8;
+  char* const d_base = A.draws ? reinterpret_cast<char*>(A.draws) + ((long long)cl * k) * A.ldS * 8 : nullptr;
+  char* const l_base = A.logpost ? reinterpret_cast<char*>(A.logpost) + (long long)cl * A.ldS * 8 : nullptr;
+  const unsigned int lane_off = (unsigned int)((long long)jl * A.ldS * 8);
+  unsigned int srow8 = 0;
+  const char* const z_base = reinterpret_cast<const char*>(A.fed_z) + ((long long)cl * nsteps) * kz * 8;   // wave-uniform
+  const unsigned int z_lane = (unsigned int)(zidx) * 8u;
   const double* const lu_row = A.fed_logu + (long long)cl * nsteps;
   const double dn = uniform_d((double)A.n);
   auto ld_z = [&](int row) -> double {
-    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(A.fed_z) + (z_off + (unsigned int)row * (unsigned int)(kz * 8)));
+    return *reinterpret_cast<const double*>(z_base + (z_lane + (unsigned int)row * (unsigned int)(kz * 8)));
   };
   double z_nx = (plane && !fixed_l && nsteps >= 2) ? ld_z(1) : 0.0;   // variates of the NEXT proposal / decision
   double lu_nx = (nsteps >= 2) ? lu_row[1] : 0.0;
@@ -740,8 +763,11 @@ __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
     return f;
   };
   auto flush_bits = [&](int i) {
-    if (A.accept_bits && lane == 0)
-      A.accept_bits[(long long)cl * ((nsteps + 31) >> 5) + ((i - 1) >> 5)] = bitword;
+    if (A.accept_bits && lane == 0) {   // (bits_stride: words per chain of the whole call's bitmap, set by launch_sweep for every launch)
+      unsigned int* w = A.accept_bits + ((long long)cl * A.bits_stride + ((i - 1) >> 5));
+      // the first word of a continuation window also holds the last bit of the window before it
+      *w = (A.win_cont && i <= 32) ? (*w | bitword) : bitword;
+    }
     bitword = 0;
   };
 
@@ -766,7 +792,7 @@ __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
       const double ratio = f1 - f0;
       if (fmh_isnan(f1) || fmh_isnan(ratio)) {
         status = fmh_isnan(f1) ? FMCMC_CHAIN_NAN_LOGPOST : FMCMC_CHAIN_NAN_RATIO;
-        if (lane == 0) { A.status[cl] = status; A.status_step[cl] = v; }
+        if (lane == 0) { A.status[cl] = status; A.status_step[cl] = v + A.step_off; }
         if (plane) A.status_theta[(long long)cl * k + lane] = th1;
         flush_bits(v);
       } else {
@@ -804,10 +830,10 @@ __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
       if (thin_ctr == thin) {
         thin_ctr = 0;
         if (plane) {
-          *reinterpret_cast<double*>(reinterpret_cast<char*>(A.samples) + (sd_off + srow8)) = th0_row;
-          if (A.draws) *reinterpret_cast<double*>(reinterpret_cast<char*>(A.draws) + (sd_off + srow8)) = th1_eval;
+          *reinterpret_cast<double*>(s_base + (lane_off + srow8)) = th0_row;
+          if (d_base) *reinterpret_cast<double*>(d_base + (lane_off + srow8)) = th1_eval;
         }
-        if (A.logpost && lane == 0) *reinterpret_cast<double*>(reinterpret_cast<char*>(A.logpost) + (lp_off + srow8)) = f1;
+        if (l_base && lane == 0) *reinterpret_cast<double*>(l_base + srow8) = f1;
         srow8 += 8;
       }
     }
@@ -822,7 +848,7 @@ __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
   if (plane) A.theta0[(long long)cl * k + lane] = th0;
   if (lane == 0) {
     A.f0[cl] = f0;
-    A.accept_count[cl] = nacc;
+    A.accept_count[cl] = nacc;   // (of THIS launch: launch_sweep adds the windows up)
     if (status == FMCMC_CHAIN_OK) { A.status[cl] = FMCMC_CHAIN_OK; A.status_step[cl] = 0; }
   }
 }

@@ -834,6 +834,88 @@ def test_sharded_evaluation_with_failing_chains(E, O, monkeypatch):
     assert np.array_equal(rg.status_step.cpu().numpy(), ro.status_step)
 
 
+@pytest.mark.parametrize("path", ["mfma", "spec"])
+@pytest.mark.parametrize("window", ["32", "96"])
+def test_step_windows_do_not_change_a_bit(E, O, monkeypatch, path, window):
+    """A long call of the stream-fed kernels runs as consecutive step windows with a bounded RNG stream (mh_engine.hip,
+    launch_sweep).  With the window forced down to 32 / 96 steps a call of a few hundred steps is cut 4 - 12 times: outputs,
+    accept bitmap, counts, state and error reports equal the oracle's (inside run_both) -- burn-in and thinning that do not
+    divide the window, a second call continuing the first, the reflective and the uniform kernel, a fixed parameter, and a
+    chain that fails with a NaN in a LATER window (its status step is the call's step, not the window's)."""
+    from fmcmc_amd import _abi as abi
+    set_knob(monkeypatch, "window", window)
+    if path == "spec":
+        set_knob(monkeypatch, "mfma", "0")
+    X, y = synth_linreg(10000, 3, 20260102)
+    init = jitter_init([0, 0, 0, 0, float(np.std(y))], 9, 31)
+    init[:, -1] = np.abs(init[:, -1])
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=397, burnin=41, thin=7, calls=2, scale=0.02)
+    assert abi.last_kernel() == path
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=130, scale=0.03, fixed=[False, False, True, False, False])
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL_REFLECTIVE, 5, init, nsteps=301, burnin=3, thin=2, scale=0.3,
+             lb=[-5, -5, -5, -5, 0.1], ub=[5, 5, 5, 5, 5.0], guard=False)
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_UNIF, 5, init, nsteps=200, thin=3, min_=-0.03, max_=0.04)
+    assert abi.last_kernel() == path
+    # proposals of sigma with scale 2 around ~4.5 step below zero every few dozen steps: without the guard eight of the
+    # nine chains fail, at steps 45 .. 280 of the call (one survives)
+    rg, ro = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=400, guard=False, scale=[0.02, 0.02, 0.02, 0.02, 2.0])
+    assert (ro.status == 1).sum() >= 5 and (ro.status == 0).any() and ro.status_step[ro.status == 1].max() > 2 * int(window) + 1
+
+
+def test_a_call_longer_than_4_gib_of_samples_stays_on_the_headline_kernel(E, monkeypatch):
+    """BASELINE configs[1] with nsteps = 120,000: 4.9 GB of samples (and as much again of draws) -- until round 3 such a call
+    left mh_sweep_mfma for the general kernel at the 4 GiB limit of its 32-bit offsets and of its materialised RNG stream.
+    Now: (a) it runs on "mfma"; (b) the size-independent properties of the 10^4-step test hold (rows follow the accept bits,
+    counts are popcounts); (c) a 64-chain shard with the same chain ids equals the general kernel (knob streamed=1) bit for
+    bit; (d) the time per step is within 3 % of a 10^4-step call's (HIP events, best of three)."""
+    import torch
+    from fmcmc_amd import _abi as abi
+    import bench
+    chains, iters, k = 1024, 120000, 5
+    X, y, init = bench.Config("c2").workload(chains, 0)
+    gm = E.DeviceModel(abi.FAM_GAUSSIAN_LINREG, X, y)
+    gk = E.KernelSpec(abi.KERNEL_NORMAL, k, np.zeros(k), np.full(k, 0.02), np.full(k, -E.DBL_MAX),
+                      np.full(k, E.DBL_MAX), np.zeros(k, np.uint8))
+
+    def timed(nsteps, lo=0, hi=chains, **kw):
+        st = E.ChainState(init[lo:hi], k)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        r = E.sweep(gm, gk, st, nsteps, seed=bench.CHAIN_SEED, chain_base=lo, check=True, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        return r, st, e0.elapsed_time(e1) * 1e3 / nsteps
+
+    short_us = min(timed(10000, want_bits=False)[2] for _ in range(3))
+    long_us = min(timed(iters, want_bits=False)[2] for _ in range(3))              # (the first one also loads the kernel's code)
+    full, st_full, _ = timed(iters)
+    assert abi.last_kernel() == "mfma"                                             # (a)
+    assert full.samples.numel() * 8 > (4 << 30)
+    # (b) structure, chunked over the chains (the bitmap expands to one byte per row)
+    s64, d64 = full.samples.view(torch.int64), full.draws.view(torch.int64)
+    bits = full.accept_bits.view(torch.int32)
+    r_idx = torch.arange(iters, device=bits.device)
+    assert torch.equal(s64[:, :, 0], torch.as_tensor(init, device=bits.device).view(torch.int64))
+    for lo in range(0, chains, 64):
+        acc = ((bits[lo:lo + 64][:, (r_idx >> 5)] >> (r_idx & 31)) & 1).bool()
+        assert not bool(acc[:, 0].any())
+        expect = torch.where(acc[:, None, 1:], d64[lo:lo + 64, :, 1:], s64[lo:lo + 64, :, :-1])
+        assert torch.equal(s64[lo:lo + 64, :, 1:], expect)
+        assert torch.equal(acc.sum(dim=1), full.accept_count[lo:lo + 64].to(torch.int64))
+        del acc, expect
+    # (c) the general kernel on a shard
+    set_knob(monkeypatch, "streamed", "1")
+    part, st_part, _ = timed(iters, 448, 512)
+    assert abi.last_kernel() == "streamed"
+    for name in ("samples", "logpost", "draws", "accept_count", "accept_bits"):
+        assert torch.equal(getattr(part, name), getattr(full, name)[448:512]), name
+    assert torch.equal(st_part.theta0, st_full.theta0[448:512]) and torch.equal(st_part.f0, st_full.f0[448:512])
+    del part
+    # (d) no cliff
+    assert long_us <= 1.03 * short_us, "%.3f us per step at 1.2e5 steps, %.3f at 1e4" % (long_us, short_us)
+
+
 def test_full_size_headline_properties(E, monkeypatch):
     """BASELINE configs[1] at its full size (1024 chains x 10,000 iterations, n = 10,000, k = 5; the oracle would need
     minutes), through properties that do not depend on the size: (a) two shards of 512 chains with their chain_base give

@@ -55,7 +55,7 @@ int main(int argc, char** argv) {
   A.family = FMCMC_FAM_GAUSSIAN_LINREG; A.p = p; A.intercept = 1; A.guard = 1; A.n = n; A.X = dX; A.y = dy;
   A.kind = FMCMC_KERNEL_NORMAL; A.k = k; A.scheme = FMCMC_SCHEME_JOINT; A.freq = 1;
   A.mu = dmu; A.scale = dsc; A.lb = dlb; A.ub = dub; A.fixed = dfx;
-  A.nchains = C; A.nsteps = nsteps; A.burnin = 0; A.thin = 1; A.S = S; A.ldS = S; A.seed = 1215; A.rng_mode = FMCMC_RNG_FED; A.fresh = 1; A.kz = kz;
+  A.nchains = C; A.nsteps = nsteps; A.burnin = 0; A.thin = 1; A.S = S; A.ldS = S; A.bits_stride = (nsteps + 31) / 32; A.seed = 1215; A.rng_mode = FMCMC_RNG_FED; A.fresh = 1; A.kz = kz;
   A.fed_logu = ws; A.fed_z = ws + items;
   A.theta0 = dth; A.f0 = df0; A.samples = dsam; A.logpost = dlp; A.draws = ddr; A.accept_count = dacc; A.accept_bits = dbits;
   A.status = dstat; A.status_step = dss; A.status_theta = dst_th;
@@ -65,7 +65,11 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(dth, th.data(), th.size() * 8, hipMemcpyHostToDevice));
     CK(hipEventRecord(e0, 0));
 #ifdef EXP_OWNERS
+#ifdef EXP_BIG
+    hipLaunchKernelGGL((mh_sweep_mfma<1, 1, 20, false, true>), dim3(C / 4), dim3(NT), mfma_lds_bytes(), 0, A);
+#else
     hipLaunchKernelGGL((mh_sweep_mfma<1, 1, 20, false>), dim3(C / 4), dim3(NT), mfma_lds_bytes(), 0, A);
+#endif
 #elif defined(EXP_DBG)
     hipLaunchKernelGGL((mh_sweep_mfmar<1, 1, 20, true>), dim3(C / 4), dim3(NT), mfmar_lds_bytes(), 0, A);
 #else

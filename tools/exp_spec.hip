@@ -59,7 +59,7 @@ int main(int argc, char** argv) {
   A.kind = EXP_KIND; A.k = k; A.scheme = FMCMC_SCHEME_JOINT; A.freq = 1;
   A.warmup = (EXP_KIND == 3) ? 500 : 0; A.until = INFINITY; A.eps = 1e-4; A.arate = 0.234; A.ram_df = (EXP_KIND == 4) ? (double)k : 0.0; A.ram_neg_exp = -2.0 / 3.0;
   A.mu = dmu; A.scale = dsc; A.lb = dlb; A.ub = dub; A.fixed = dfx;
-  A.nchains = C; A.nsteps = nsteps; A.burnin = 0; A.thin = 1; A.S = S; A.ldS = S; A.seed = 1215; A.rng_mode = FMCMC_RNG_FED; A.fresh = 1; A.kz = kz;
+  A.nchains = C; A.nsteps = nsteps; A.burnin = 0; A.thin = 1; A.S = S; A.ldS = S; A.bits_stride = (nsteps + 31) / 32; A.seed = 1215; A.rng_mode = FMCMC_RNG_FED; A.fresh = 1; A.kz = kz;
   A.fed_logu = ws; A.fed_z = ws + items;
   A.theta0 = dth; A.f0 = df0; A.samples = dsam; A.logpost = dlp; A.draws = ddr; A.accept_count = dacc; A.accept_bits = dbits;
   A.status = dstat; A.status_step = dss; A.status_theta = dst_th;
