@@ -285,6 +285,17 @@ def run_config(cfg, chains, iters, steps, warmup, world, rank, dev, dist, torch,
         dist.barrier()
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    # collectives issued inside the timed region (the engine's only one is the all-reduce of the Gelman check): counted, so
+    # that the line says whether the measured steps contained it
+    ncoll = {"all_reduce": 0}
+    real_all_reduce = dist.all_reduce
+
+    def counting_all_reduce(*a, **kw):
+        ncoll["all_reduce"] += 1
+        return real_all_reduce(*a, **kw)
+
+    if world > 1:
+        dist.all_reduce = counting_all_reduce
     t0 = time.perf_counter()
     for s in range(steps):
         cur["s"] = s
@@ -292,14 +303,20 @@ def run_config(cfg, chains, iters, steps, warmup, world, rank, dev, dist, torch,
         out = one_step()
         ev[s][1].record()
     torch.cuda.synchronize()
+    dist.all_reduce = real_all_reduce
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    bases = [chain_base]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        b = torch.zeros(world, dtype=torch.float64, device=dev)     # what every rank really used as its first global chain id
+        b[rank] = float(chain_base)
+        dist.all_reduce(b, op=dist.ReduceOp.SUM)
+        bases = [int(v) for v in b.tolist()]
     assert int(out.status.abs().sum().item()) == 0, "a chain reported an error"
     bad = sorted(set(n for n in picked if n != cfg.expect_kernel))
     if bad and chains == cfg.chains and iters == cfg.iters:
@@ -320,7 +337,8 @@ def run_config(cfg, chains, iters, steps, warmup, world, rank, dev, dist, torch,
     return {"cfg": cfg, "chains": chains, "iters": iters, "steps": steps, "warmup": warmup, "world": world, "S": S,
             "elapsed": elapsed, "value": world * samples_per_step * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps,
             "kern_ms": kern_ms, "extra": extra, "picked": sorted(set(picked)), "accept_rate": acc,
-            "samples_per_step": samples_per_step, "chain_base": chain_base}
+            "samples_per_step": samples_per_step, "chain_base": chain_base, "chain_bases": bases,
+            "all_reduce_calls_in_timed_steps": ncoll["all_reduce"]}
 
 
 def roofline_block(res, traffic_from=None):
@@ -435,7 +453,8 @@ def main():
                        "chains_per_gpu": chains, "iters_per_step": iters, "thin": cfg.thin, "accept_rate": res["accept_rate"],
                        "parallelism": "chains sharded, %d rank(s), %s" % (world, "one all-reduce of 1 + 5p + 2p^2 doubles per Gelman check"
                                                                           if cfg.name == "c4" else "no data-path collective"),
-                       "backend": (args.backend if world > 1 else None), "chain_base_of_rank": {"0": res["chain_base"]}},
+                       "backend": (args.backend if world > 1 else None), "chain_base_of_rank": res["chain_bases"],
+                       "all_reduce_calls_in_timed_steps": res["all_reduce_calls_in_timed_steps"]},
             "roofline": roofline_block(res, args.traffic_from),
         }
         if extras:

@@ -104,3 +104,54 @@ def test_seed_none_is_rank_zeros_seed_everywhere(setup, tmp_path):
     full = f.MCMC(np.tile([0, 0, 0, 4.0], (4, 1)), fun, 300, seed=seed, nchains=4, kernel=f.kernel_normal(scale=0.05))
     both = np.concatenate([x["samples"] for x in r])
     assert np.array_equal(_bits(both.transpose(0, 2, 1)), _bits(full.as_array()))   # MCMC_OUTPUT's seed reproduces the run
+
+
+def _bench(args, env_extra=None, timeout=600):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update(env_extra or {})
+    return subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, stdout=subprocess.PIPE,
+                            stderr=subprocess.PIPE, text=True)
+
+
+def test_bench_multi_rank_path_runs_and_matches_the_single_rank_run():
+    """bench.py's N > 1 path executed: two FRESH processes (started before anything touches the GPU; both on the one GPU of
+    the box, gloo instead of RCCL) run `--gpus 2 --config c4` with 64 chains per rank -- process group, barriers, the MAX
+    all-reduce of the elapsed time, chain_base = rank x chains, and C4's Gelman check with its all-reduce INSIDE the timed
+    steps.  The R-hat the line reports is the one of a single process running all 128 chains: sharding changes nothing
+    (replaces the PSOCK fan-out of R/mcmc.R:536-641)."""
+    import json
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    common = ["--config", "c4", "--chains", "64", "--iters", "2000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    port = 29100 + os.getpid() % 800
+    procs = [_bench(["--gpus", "2", "--backend", "gloo"] + common,
+                    dict(RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)))
+             for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=600))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-3000:]
+    line = json.loads([l for l in outs[0][0].strip().splitlines() if l.startswith("{")][-1])
+    assert not [l for l in outs[1][0].splitlines() if l.startswith("{")]          # rank 0 alone prints the line
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["backend"] == "gloo"
+    assert line["config"]["chain_base_of_rank"] == [0, 64]
+    # 2 steps x 2 bulks of 1000 iterations, each followed by one check = two all-reduces (centre + partial sums)
+    assert line["config"]["all_reduce_calls_in_timed_steps"] == 2 * 2 * 2
+    assert line["value"] > 0 and line["roofline"]["bulks_per_step"] == 2
+    single = _bench(["--gpus", "1", "--config", "c4", "--chains", "128", "--iters", "2000", "--steps", "2", "--warmup", "1",
+                     "--no-cpu-baseline"])
+    o, e = single.communicate(timeout=600)
+    assert single.returncode == 0, e[-3000:]
+    one = json.loads([l for l in o.strip().splitlines() if l.startswith("{")][-1])
+    assert one["n_gpus"] == 1 and one["config"]["chain_base_of_rank"] == [0]
+    # the same 128 chains, bit for bit; their R-hat to the last ulps (the sum over the chains is rank 0's + rank 1's partial
+    # instead of one fixed-order sum over 128)
+    assert abs(line["roofline"]["rhat_last"] - one["roofline"]["rhat_last"]) <= 1e-13 * one["roofline"]["rhat_last"]
