@@ -292,6 +292,9 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
         W2_EV_STAMP(0);
         W2_EVENT(wave == 2 && v == 300, 26 + 2 * g);          // proposals of group g, version 300, seen
         const int Ng = (NC + ng - 1 - g) / ng;                  // chains of the group in this launch
+        // (measured and dropped, round 3: the second evaluator of SIMDs 2 / 3 starting a visit 0.2 .. 1.3 us late, so that the pair does
+        //  not run its B loads, MFMA blocks and epilogues in lockstep -- MI355X_MICROARCH.md, two waves per SIMD, item 9 --: 18.6 ..
+        //  18.8 us per step against 18.5; the pairs drift apart by themselves)
         if (Ng > 0) {
           sm.NC = Ng; sm.coff = g; sm.thoff = g * NH;
           if (NMT == 3 && ((p + 3) >> 2) == 12) shard_columns_mfma<2, NMT, (NMT == 3 ? 12 : 0)>(sm);   // (C4's width: compile-time K-block count)
