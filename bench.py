@@ -178,8 +178,13 @@ def cpu_baseline(cfg, seconds_budget=24.0):
         with ThreadPoolExecutor(cores) as ex:             # ctypes releases the GIL: one oracle call per host thread
             list(ex.map(lambda tix: run(inits[tix * per_thread:(tix + 1) * per_thread], tix * per_thread, iters), range(cores)))
 
+    def refine(per, fn):                    # a pilot of ~1.5 s sized from the first estimate gives the rate the sample is sized with
+        it = int(max(60, min(cfg.iters, 1.5 / per)))
+        return max(timed(lambda: fn(it)) - 10 * per, 1e-9) / (it - 10)
+
     # (b) one thread: ~1/4 of the budget (whole chains when a chain fits)
     per1 = steady(lambda it: run(init0[:1], 0, it), 11, 61)
+    per1 = refine(per1, lambda it: run(init0[:1], 0, it))
     want1 = 0.25 * seconds_budget
     it1 = int(max(50, min(cfg.iters, want1 / per1)))
     ch1 = int(max(1, min(cores, want1 / (per1 * it1))))
@@ -188,6 +193,7 @@ def cpu_baseline(cfg, seconds_budget=24.0):
               "sample": "%d chain(s) x %d iterations" % (ch1, it1), "seconds": dt1}
     # (a) all threads busy: steady-state cost under full load (SMT and memory contention included), then size the sample
     per = steady(lambda it: all_threads(init0, 1, it), 11, 61)
+    per = refine(per, lambda it: all_threads(init0, 1, it))
     want = 0.75 * seconds_budget
     if per * cfg.iters <= want:                       # whole chains: several per thread
         per_thread, iters = int(max(1, min(256, want / (per * cfg.iters)))), cfg.iters
