@@ -22,7 +22,8 @@ FIELDS = {"TotalSGPRs": "sgprs", "VGPRs": "vgprs", "AGPRs": "agprs", "ScratchSiz
           "Occupancy [waves/SIMD]": "occupancy_waves_per_simd", "SGPRs Spill": "sgpr_spills", "VGPRs Spill": "vgpr_spills",
           "LDS Size [bytes/block]": "static_lds_bytes"}
 # the kernels the four GPU configs of BASELINE.md section 4 run on (bench.py fails if the dispatcher picks another one)
-PRODUCT = [("C2 headline", r"mh_sweep_mfma<1, 1, 20, false>"), ("C3", r"mh_sweep_spec<3, 20, 3>"),
+PRODUCT = [("C2 headline", r"mh_sweep_mfma<1, 1, 20, false, false>"), ("C2 shape, > 4 GiB of samples", r"mh_sweep_mfma<1, 1, 20, false, true>"),
+           ("C3", r"mh_sweep_spec<3, 20, 3>"),
            ("C3' kernel_ram k=5", r"mh_sweep_spec<3, 20, 4>"), ("C4", r"mh_sweep_wide2<4, 3>"),
            ("C4 slice product", r"shard_columns_mfma<2, 3, 12>"),
            ("C5", r"mh_sweep_kernel<4, -1, 0, 2, 2, 1>"), ("rng stream", r"rng_fill_kernel"),
@@ -56,6 +57,52 @@ def collect(extra_flags=()):
     return rows, time.time() - t0
 
 
+# real (noinline) device functions that carry the hot loops of a product kernel: the remark pass reports kernels only, so
+# their registers and spill code are read off the ISA (-S): highest VGPR named, scratch instructions, and v_readlane /
+# v_writelane (SGPR spill traffic) inside their innermost hot loop (the largest backward-branch body below 400 instructions)
+DEVICE_FUNCS = [("C5 observation loop", "logit_partials<4, 5>"), ("C4 slice product", "shard_columns_mfma<2, 3, 12>"),
+                ("C4 factor update + proposal", "w2_ram_update_propose")]
+
+
+def isa_functions(extra_flags=()):
+    out = []
+    src = B.SRC[0]
+    asm = "/tmp/fmcmc_amd_engine.s"
+    cmd = [B.HIPCC] + [f for f in B.FLAGS if f != "-shared"] + list(extra_flags) + ["--cuda-device-only", "-S", src, "-o", asm]
+    subprocess.run(cmd, capture_output=True, text=True)
+    funcs, cur = {}, None
+    for line in open(asm):
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            cur = m.group(1); funcs[cur] = []
+        elif cur is not None:
+            funcs[cur].append(line.rstrip("\n"))
+            if line.startswith(".Lfunc_end"):
+                cur = None
+    names = list(funcs)
+    for role, pat in DEVICE_FUNCS:
+        for mangled, dem in zip(names, demangle(names)):
+            if dem != pat:
+                continue
+            body = funcs[mangled]
+            ins = [x for x in body if x.startswith("\t") and not x.strip().startswith((";", "."))]
+            vg = [int(g) for x in ins for g in re.findall(r"\bv(\d+)\b", x)] + [int(b) for x in ins for _, b in re.findall(r"v\[(\d+):(\d+)\]", x)]
+            labels = {m.group(1): i for i, l in enumerate(body) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+            best = None
+            for i, l in enumerate(body):
+                m = re.search(r"s_(?:cbranch_\w+|branch)\s+(\.LBB\d+_\d+)", l)
+                if m and m.group(1) in labels and labels[m.group(1)] < i:
+                    loop = [x for x in body[labels[m.group(1)]:i + 1] if x.startswith("\t") and not x.strip().startswith((";", "."))]
+                    if len(loop) < 400 and (best is None or len(loop) > len(best)):
+                        best = loop
+            cnt = lambda seq, pat_: sum(1 for x in seq if re.search(pat_, x))
+            out.append({"role": role, "name": dem, "highest_vgpr": max(vg) if vg else -1, "instructions": len(ins),
+                        "scratch_instructions": cnt(ins, "scratch_"), "hot_loop_instructions": len(best or []),
+                        "hot_loop_fp64": cnt(best or [], "_f64"), "hot_loop_mfma": cnt(best or [], "v_mfma"),
+                        "hot_loop_scratch": cnt(best or [], "scratch_"), "hot_loop_readlane_writelane": cnt(best or [], "v_readlane|v_writelane")})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tag", default="r03")
@@ -63,7 +110,8 @@ def main():
     args = ap.parse_args()
     rows, secs = collect(args.flags.split())
     head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
-    rec = {"head": head, "flags": B.FLAGS + args.flags.split(), "device_compile_seconds": round(secs, 1), "kernels": rows,
+    fns = isa_functions(args.flags.split())
+    rec = {"head": head, "flags": B.FLAGS + args.flags.split(), "device_compile_seconds": round(secs, 1), "kernels": rows, "device_functions": fns,
            "n_kernels": len(rows), "n_with_scratch": sum(1 for r in rows if r.get("scratch_bytes_per_lane", 0))}
     json.dump(rec, open(os.path.join(ROOT, "profiles", "%s_resources.json" % args.tag), "w"), indent=1)
     cols = ["vgprs", "agprs", "sgprs", "scratch_bytes_per_lane", "vgpr_spills", "sgpr_spills", "occupancy_waves_per_simd"]
@@ -77,12 +125,17 @@ def main():
         for r in rows:
             if pat in r["name"]:
                 md.append("| %s | `%s` | %s |\n" % (role, r["name"], " | ".join(str(r.get(c, "")) for c in cols)))
+    md.append("\n## Device functions that carry a product kernel's hot loop (read off the ISA)\n\n"
+              "| role | function | highest VGPR | scratch instructions (whole function) | hot loop: instructions | fp64 VALU | MFMA | scratch | v_readlane / v_writelane |\n|---|---|---|---|---|---|---|---|---|\n")
+    for f in fns:
+        md.append("| %s | `%s` | %d | %d | %d | %d | %d | %d | %d |\n" % (f["role"], f["name"], f["highest_vgpr"], f["scratch_instructions"],
+                  f["hot_loop_instructions"], f["hot_loop_fp64"], f["hot_loop_mfma"], f["hot_loop_scratch"], f["hot_loop_readlane_writelane"]))
     md.append("\n## Every kernel with scratch\n\n" + hdr)
     for r in sorted(rows, key=lambda r: -int(r.get("scratch_bytes_per_lane", 0) or 0)):
         if r.get("scratch_bytes_per_lane", 0):
             md.append("| | `%s` | %s |\n" % (r["name"], " | ".join(str(r.get(c, "")) for c in cols)))
     open(os.path.join(ROOT, "profiles", "%s_resources.md" % args.tag), "w").write("".join(md))
-    print("".join(md[:4 + len(PRODUCT) + 2]))
+    print("".join(md))
 
 
 if __name__ == "__main__":
