@@ -1024,6 +1024,19 @@ def test_full_size_logistic_and_wide_properties(E, monkeypatch):
         assert torch.equal(st2.Sigma, st1.Sigma[lo:hi]) and torch.equal(st2.abs_iter, st1.abs_iter[lo:hi])
 
 
+def test_c4_exact_shape_equals_the_oracle(E, O):
+    """BASELINE configs[3] at EXACTLY its per-GPU shape -- 512 chains, n = 10,000, 48 covariates (k = 50), kernel_ram -- against
+    the oracle for 24 steps (the oracle needs a few seconds for 512 x 24 evaluations of 10,000 x 48): every output, the accept
+    bitmap, the adapted factors.  The dataflow kernel with its compile-time K-block count (12) is what runs."""
+    import bench
+    from fmcmc_amd import _abi as abi
+    cfg = bench.Config("c4")
+    X, y, init = cfg.workload(cfg.chains, 0)
+    assert X.shape == (10000, 48) and init.shape == (512, 50)
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, 50, init, nsteps=24, seed=bench.CHAIN_SEED)
+    assert abi.last_kernel() == "wide-dataflow"
+
+
 @pytest.mark.parametrize("case", range(int(os.environ.get("FMCMC_TEST_RANDOM_CASES2", "80"))))   # soak: 2000 passed
 def test_randomised_option_cases(E, O, case):
     """Second randomised sweep, over the options the first one leaves at their defaults: unguarded log-posteriors,
