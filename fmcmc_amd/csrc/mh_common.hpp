@@ -90,6 +90,7 @@ struct SweepArgs {
   unsigned* sh_bar;          // barrier words, zeroed per launch (shard_barrier)
   const double* sh_mfma;     // [G][sh_mblk] the slices once more, in fp64-MFMA operand layout (shard_columns_mfma), or NULL
   int sh_mblk, sh_nmt;       // doubles per workgroup block; M-tiles of 16 observations per slice (1..3)
+  int sh_t10;                // 1: the third M-tile holds 8 rows only and is laid out for two 4x4x4 MFMAs (shard_columns_mfma, T10)
   // out
   double* samples;
   double* logpost;
@@ -554,6 +555,15 @@ __device__ __attribute__((noinline)) void shard_columns(ShardCols c) {
 // group's value (lane ^ 16).  Rows / columns beyond the data are 0 in A and masked out of the chain.
 // LDS block per workgroup (doubles), staged once per launch: [0, 32) validity bits (u32 per lane, bit t), [32, 32 + 12 x 64)
 // y in D layout [t][lane], then the A tiles [mt][kb][lane].
+// T10 (three M-tiles of which the third carries values t = 8, 9 only, i.e. 8 of its 16 rows -- config C4: 20 slots per lane,
+// 10 per lane group): a 16x16x4 tile would spend 64 matrix-core cycles per K-block on 8 rows of zeros.  Its two live D
+// registers are computed by two v_mfma_f64_4x4x4_4b instead (16.7 cycles each): that instruction's four blocks take the SAME
+// B register (B at lane 16 kk + 4 blk + j = chain 4 blk + j of the N-tile, which is where the 16x16x4 form keeps chain
+// l % 16), deliver D at lane 16 i + 4 blk + j = row i of chain 4 blk + j, which is the 16x16x4 form's D register r for rows
+// 4 r + l / 16, and it is the same fma chain bit for bit (mh_mfma.hpp, tools/mfma64_exact.hip).  Only A differs: lane
+// 16 kk + 4 blk + i wants row 4 r + i of the tile whatever blk is, so the third tile's region holds, per K-block, the 32
+// doubles [kk][i][r] (one ds_read_b128 per lane and K-block) instead of 64.  Matrix-core time per tile: 12 x (2 x 64 + 2 x 16.7)
+// = 1936 cycles against 2304.
 constexpr int SHM_T = 12;                       // D values per lane and N-tile (3 M-tiles x 4 registers)
 constexpr int SHM_HDR = 32 + SHM_T * 64;        // doubles in front of the A tiles
 constexpr int SHM_KBMAX = 16;                   // K-blocks of 4 columns: p <= 64
@@ -572,8 +582,11 @@ static_assert(sizeof(ShardMfma) <= 64, "ShardMfma must travel in registers (16 d
 // KBC > 0: the number of K-blocks is the compile-time constant KBC (config C4: 12).  With a run-time count every K-block is
 // a basic block of its own -- a branch, reloads of spilled scalars, and nothing of one block scheduled into the next: a
 // lone wave ran a tile in 2.6 us (tools/exp_shard_mfma.hip), 1.9 us with the count known, 1.04 us being its matrix-core time.
-template <int LPW, int NMT, int KBC = 0>
+template <int LPW, int NMT, int KBC = 0, bool T10 = false>
 __device__ __attribute__((noinline)) void shard_columns_mfma(ShardMfma c) {
+  static_assert(!T10 || (NMT == 3 && KBC > 0), "T10 is the form of three M-tiles with a compile-time K-block count");
+  constexpr int NM16 = T10 ? 2 : NMT;           // M-tiles computed as 16x16x4
+  constexpr int NTV = T10 ? 10 : 4 * NMT;       // D values per lane
   const int lane = threadIdx.x & 63;
   const int NC = rfl_i(c.NC), NCP = rfl_i(c.ncp), p = rfl_i(c.p), ic = rfl_i(c.ic), lane0 = rfl_i(c.lane0);
   const int cstride = rfl_i(c.cstride), coff = rfl_i(c.coff), thoff = rfl_i(c.thoff), tfirst = rfl_i(c.tfirst), tstep = rfl_i(c.tstep);
@@ -588,9 +601,13 @@ __device__ __attribute__((noinline)) void shard_columns_mfma(ShardMfma c) {
   const unsigned vmask = ((ldsu_t)(unsigned long long)lbase)[lane];
   double ya[SHM_T];
 #pragma unroll
-  for (int t = 0; t < 4 * NMT; t++) ya[t] = blk[32 + 64 * t + lane];
+  for (int t = 0; t < NTV; t++) ya[t] = blk[32 + 64 * t + lane];
   const ldsc_t xa = blk + SHM_HDR + lane;       // tile (mt, kb) at xa[(mt KB + kb) 64]
   const int kk = lane >> 4, j = lane & 15;
+  typedef double d2_t __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(3))) const d2_t* ldsc2_t;
+  // (T10) rows 4 r + i of the third tile, r = 0, 1, for column kk of K-block kb: xa4[kb * 32]
+  const ldsc2_t xa4 = (ldsc2_t)(blk + SHM_HDR + 2 * KB * 64 + 2 * (4 * kk + (lane & 3)));
   const int ntiles_all = (NC + 15) >> 4;
   // (the wave's share: tfirst, tfirst + tstep, ..., at most tcount of them)
   const int ntiles = (tcount > 0 && tfirst + tcount * tstep < ntiles_all) ? tfirst + (tcount - 1) * tstep + 1 : ntiles_all;
@@ -615,46 +632,63 @@ __device__ __attribute__((noinline)) void shard_columns_mfma(ShardMfma c) {
   if (T < ntiles) SHM_LOAD_B(T, Bc, c0c)
   for (; T < ntiles; T += tstep) {
     if (T + tstep < ntiles) SHM_LOAD_B(T + tstep, Bn, c0n)
-    d4_t acc[NMT];
+    d4_t acc[NM16];
 #pragma unroll
-    for (int mt = 0; mt < NMT; mt++) acc[mt] = (d4_t){c0c, c0c, c0c, c0c};
-    double a_cur[NMT], a_nxt[NMT];
+    for (int mt = 0; mt < NM16; mt++) acc[mt] = (d4_t){c0c, c0c, c0c, c0c};
+    double acc4[2] = {c0c, c0c};                 // (T10) D registers 0, 1 of the third tile
+    double a_cur[NM16], a_nxt[NM16];
+    d2_t a4_cur = (d2_t){0.0, 0.0}, a4_nxt = (d2_t){0.0, 0.0};
 #pragma unroll
-    for (int mt = 0; mt < NMT; mt++) a_cur[mt] = xa[(mt * KB) * 64];
+    for (int mt = 0; mt < NM16; mt++) a_cur[mt] = xa[(mt * KB) * 64];
+    if constexpr (T10) a4_cur = xa4[0];
 #pragma unroll
     for (int kb = 0; kb < (KBC > 0 ? KBC : SHM_KBMAX); kb++) {
       if (kb < KB) {
         const int kn = (kb + 1 < KB) ? kb + 1 : kb;
 #pragma unroll
-        for (int mt = 0; mt < NMT; mt++) a_nxt[mt] = xa[(mt * KB + kn) * 64];
+        for (int mt = 0; mt < NM16; mt++) a_nxt[mt] = xa[(mt * KB + kn) * 64];
+        if constexpr (T10) a4_nxt = xa4[kn * 32];
         // (a padded column must not turn an infinite coefficient into NaN; with KBC only the last block can hold one)
         const double b = (KBC > 0 && kb < KBC - 1) ? Bc[kb] : ((4 * kb + kk < p) ? Bc[kb] : 0.0);
 #pragma unroll
-        for (int mt = 0; mt < NMT; mt++) acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[mt], b, acc[mt], 0, 0, 0);
+        for (int mt = 0; mt < NM16; mt++) acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[mt], b, acc[mt], 0, 0, 0);
+        if constexpr (T10) {
+          acc4[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a4_cur[0], b, acc4[0], 0, 0, 0);
+          acc4[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a4_cur[1], b, acc4[1], 0, 0, 0);
+        }
         if constexpr (KBC > 0) {   // the block's other instructions BETWEEN its MFMAs: a wave issues in order, and an MFMA
 #pragma unroll                     // holds the issue port until the matrix core takes it, 64 cycles after the previous one
-          for (int mt = 0; mt < NMT; mt++) {
+          for (int mt = 0; mt < NM16; mt++) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+          }
+          if constexpr (T10) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
           }
         }
 #pragma unroll
-        for (int mt = 0; mt < NMT; mt++) a_cur[mt] = a_nxt[mt];
+        for (int mt = 0; mt < NM16; mt++) a_cur[mt] = a_nxt[mt];
+        if constexpr (T10) a4_cur = a4_nxt;
       }
     }
-    double rr[4 * NMT];
+    double rr[NTV];
 #pragma unroll
-    for (int t = 0; t < 4 * NMT; t++) rr[t] = ((vmask >> t) & 1u) ? ya[t] - acc[t >> 2][t & 3] : 0.0;   // fma(0, 0, a) == a exactly
+    for (int t = 0; t < NTV; t++) {
+      const double mu = (T10 && t >= 8) ? acc4[t & 1] : acc[(T10 && t >= 8) ? 0 : (t >> 2)][t & 3];
+      rr[t] = ((vmask >> t) & 1u) ? ya[t] - mu : 0.0;   // fma(0, 0, a) == a exactly
+    }
     double a = 0.0;
 #pragma unroll
-    for (int t = 0; t < 4 * NMT; t++) a = fmh_fma(rr[t], rr[t], a);
+    for (int t = 0; t < NTV; t++) a = fmh_fma(rr[t], rr[t], a);
     const int lch = 16 * T + j;                  // member of the set; its chain:
     const int chain = cstride * lch + coff;
     if constexpr (LPW == 2) {
       double a2 = __shfl_xor(a, 16, 64);          // groups 1 and 3 continue where groups 0 and 2 stopped
 #pragma unroll
-      for (int t = 0; t < 4 * NMT; t++) a2 = fmh_fma(rr[t], rr[t], a2);
+      for (int t = 0; t < NTV; t++) a2 = fmh_fma(rr[t], rr[t], a2);
       const double a_hi = __shfl_xor(a2, 32, 64); // canonical lane 1 of the slice (group 3) next to lane 0 (group 1)
       if (kk == 1 && lch < NC) {
         double* dst = &part[(long long)chain * (NT + SH_PAD) + lane0];
@@ -704,6 +738,7 @@ __device__ __forceinline__ bool eval_sharded(const SweepArgs& A, double* const* 
     const bool kb12 = ((p + 3) >> 2) == 12;   // (config C4's width gets the instantiation with a compile-time K-block count)
     if (A.sh_nmt == 1) shard_columns_mfma<LPW, 1>(sm);
     else if (A.sh_nmt == 2) shard_columns_mfma<LPW, 2>(sm);
+    else if (kb12 && A.sh_t10) shard_columns_mfma<LPW, 3, 12, true>(sm);
     else if (kb12) shard_columns_mfma<LPW, 3, 12>(sm);
     else shard_columns_mfma<LPW, 3>(sm);
   } else

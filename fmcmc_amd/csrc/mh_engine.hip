@@ -91,7 +91,9 @@ __global__ void shard_build_slices(const double* X, const double* y, long long n
 
 // the same slices in fp64-MFMA operand layout (mh_common.hpp, shard_columns_mfma): per workgroup a block of
 // SHM_HDR + nmt KB 64 doubles = validity bits | y in D layout | A tiles [mt][kb][lane]
-__global__ void shard_build_mfma(const double* X, const double* y, long long n, int p, int lpw, int nslots, int nmt,
+// t10: the third M-tile in the layout of the two 4x4x4 MFMAs that compute its 8 live rows, per K-block 32 doubles [kk][i][r]
+// = row 4 r + i of the tile (value t = 8 + r of lane group i), column 4 kb + kk; the other 32 doubles of the K-block stay 0
+__global__ void shard_build_mfma(const double* X, const double* y, long long n, int p, int lpw, int nslots, int nmt, int t10,
                                  double* out, int blk_doubles) {
   const int b = blockIdx.x, KB = (p + 3) >> 2, H = 4 / lpw, spg = (nslots + H - 1) / H;
   double* o = out + (long long)b * blk_doubles;
@@ -120,6 +122,12 @@ __global__ void shard_build_mfma(const double* X, const double* y, long long n, 
       o[idx] = i >= 0 ? y[i] : 0.0;
     } else {
       const int e = idx - SHM_HDR, lane = e & 63, kb = (e >> 6) % KB, mt = (e >> 6) / KB;
+      if (t10 && mt == 2) {
+        const int kk4 = lane >> 3, i4 = (lane >> 1) & 3, r4 = lane & 1, col4 = 4 * kb + kk4;
+        const long long i = lane < 32 ? obs_of(i4, 8 + r4) : -1;
+        o[idx] = (i >= 0 && col4 < p) ? X[(long long)col4 * n + i] : 0.0;
+        continue;
+      }
       const int row = lane & 15, kk = lane >> 4, col = 4 * kb + kk;
       const long long i = obs_of(row & 3, 4 * mt + (row >> 2));   // D register r of lane group g is row 4 r + g of the tile
       o[idx] = (i >= 0 && col < p && mt < nmt) ? X[(long long)col * n + i] : 0.0;
@@ -309,17 +317,18 @@ static SweepArgs chain_window(const SweepArgs& A, long long off, long long cnt, 
 //   shard_mfma=0 VALU form of the sharded slice product           wide2=0|1   never / always (when eligible) the dataflow form
 //   groups=4     four chain groups in the dataflow form (default two)       tiles=0     even N-tile shares of its evaluator waves
 //   window=N     step-window length of the stream-fed kernels (multiple of 32; default: ~256 MiB of stream per window)
+//   t10=0        the sharded slice product's third M-tile as a 16x16x4 tile even where 8 of its rows are padding
 //   mode=<bits>  timing ablations and stamps (SweepArgs.debug)
 // The kernel a call ended up on is reported by fmcmc_last_kernel(); DESIGN.md section 5 has the shape -> kernel table.
 struct Knobs {
-  int streamed = -1, cw = -1, pipe = -1, spec = -1, mfma = -1, owners = -1, shard = -1, shard_mfma = -1, wide2 = -1, groups = -1, tiles = -1, window = -1, mode = 0;
+  int streamed = -1, cw = -1, pipe = -1, spec = -1, mfma = -1, owners = -1, shard = -1, shard_mfma = -1, wide2 = -1, groups = -1, tiles = -1, t10 = -1, window = -1, mode = 0;
 };
 static Knobs read_knobs() {
   Knobs K;
   const char* e = getenv("FMCMC_AMD_DEBUG");
   if (!e) return K;
   struct { const char* name; int* dst; } tab[] = {{"streamed", &K.streamed}, {"cw", &K.cw}, {"pipe", &K.pipe}, {"spec", &K.spec},
-      {"mfma", &K.mfma}, {"owners", &K.owners}, {"shard_mfma", &K.shard_mfma}, {"shard", &K.shard}, {"wide2", &K.wide2}, {"groups", &K.groups}, {"tiles", &K.tiles}, {"window", &K.window}, {"mode", &K.mode}};
+      {"mfma", &K.mfma}, {"owners", &K.owners}, {"shard_mfma", &K.shard_mfma}, {"shard", &K.shard}, {"wide2", &K.wide2}, {"groups", &K.groups}, {"tiles", &K.tiles}, {"t10", &K.t10}, {"window", &K.window}, {"mode", &K.mode}};
   while (*e) {
     const char* eq = strchr(e, '=');
     const char* end = strchr(e, ',');
@@ -761,6 +770,9 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
     // the slice product on the matrix cores (shard_columns_mfma): the slice lives in LDS behind the chain blocks
     const int mf_spg = shard ? (nslots + 4 / lpw - 1) / (4 / lpw) : 0, nmt = (mf_spg + 3) / 4;
     const int mblk = SHM_HDR + nmt * ((m->p + 3) / 4) * 64;
+    // (three M-tiles of which the third holds values 8, 9 only, at the width with a compile-time K-block count -- config C4:
+    //  its 8 rows go through two 4x4x4 MFMAs per K-block instead of a 16x16x4 that is half padding; knob t10=0: off)
+    const int t10 = (nmt == 3 && mf_spg <= 10 && (m->p + 3) / 4 == 12 && K.t10 != 0) ? 1 : 0;
     bool mfma_form = shard && shard_mfma_enabled(K) && m->p <= 4 * SHM_KBMAX && mf_spg <= SHM_T &&
                      lds + sizeof(double) * (size_t)(mblk + 1) <= 160 * 1024;
     if (mfma_form) lds += sizeof(double) * (size_t)(mblk + 1);
@@ -814,8 +826,8 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
       if (mfma_form) {
         double* mf = ptw + npt + nbar;
         hipLaunchKernelGGL(shard_build_mfma, dim3((unsigned)nb_launch), dim3(256), 0, stream, m->X, m->y, (long long)m->n, m->p, lpw, nslots,
-                           nmt, mf, mblk);
-        A.sh_mfma = mf; A.sh_mblk = mblk; A.sh_nmt = nmt;
+                           nmt, t10, mf, mblk);
+        A.sh_mfma = mf; A.sh_mblk = mblk; A.sh_nmt = nmt; A.sh_t10 = t10;
       }
       long long done = 0;
       for (; done < run->nchains && e == hipSuccess; done += ch_launch) {   // (the slices and tables serve every launch)
@@ -836,7 +848,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
         shard = false;
         g_kernel = "streamed-wide";
         A.shard = 0; A.sh_xs = nullptr; A.sh_ys = nullptr; A.sh_th = nullptr; A.sh_part = nullptr; A.sh_bar = nullptr;
-        A.sh_mfma = nullptr; A.sh_mblk = 0; A.sh_nmt = 0;
+        A.sh_mfma = nullptr; A.sh_mblk = 0; A.sh_nmt = 0; A.sh_t10 = 0;
         lds = lds_plain;
       }
     }

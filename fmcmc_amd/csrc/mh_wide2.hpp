@@ -261,6 +261,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
     sm.th = A.sh_th; sm.part = A.sh_part; sm.p = p; sm.ic = ic; sm.lane0 = (int)blockIdx.x * 2; sm.tcount = tcount;
     sm.lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const double*)s_blk;
     sm.ncp = NCP; sm.cstride = ng; sm.tfirst = tfirst; sm.tstep = tstep;
+    const bool t10 = __builtin_amdgcn_readfirstlane(A.sh_t10) != 0;
     bool lost = false;
 #ifdef FMCMC_STAMP
 #define W2_EVENT(cond, idx) do { if ((cond) && lane == 0 && k >= 48 && (long long)blockIdx.x * 2 < A.nchains) \
@@ -297,8 +298,10 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
         //  18.8 us per step against 18.5; the pairs drift apart by themselves)
         if (Ng > 0) {
           sm.NC = Ng; sm.coff = g; sm.thoff = g * NH;
-          if (NMT == 3 && ((p + 3) >> 2) == 12) shard_columns_mfma<2, NMT, (NMT == 3 ? 12 : 0)>(sm);   // (C4's width: compile-time K-block count)
-          else shard_columns_mfma<2, NMT>(sm);
+          if (NMT == 3 && ((p + 3) >> 2) == 12) {              // (C4's width: compile-time K-block count)
+            if (t10) shard_columns_mfma<2, NMT, (NMT == 3 ? 12 : 0), NMT == 3>(sm);   // (and its 10 values per lane group)
+            else shard_columns_mfma<2, NMT, (NMT == 3 ? 12 : 0)>(sm);
+          } else shard_columns_mfma<2, NMT>(sm);
         }
         W2_EV_STAMP(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's partials have been acknowledged

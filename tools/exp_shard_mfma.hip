@@ -50,7 +50,11 @@ __global__ __launch_bounds__(NT) void bench(const double* th, double* part, doub
   unsigned long long t0 = __builtin_amdgcn_s_memtime();
   if (active) {
     for (int r = 0; r < reps; r++) {
+      #ifdef EXP_T10
+      shard_columns_mfma<2, 3, EXP_KBC, true>(sm);
+#else
       shard_columns_mfma<2, 3, EXP_KBC>(sm);
+#endif
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
   } else if (mode == 3 && wave < 2) {
