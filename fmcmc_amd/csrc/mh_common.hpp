@@ -614,24 +614,44 @@ __device__ __attribute__((noinline)) void shard_columns_mfma(ShardMfma c) {
   // B operand of N-tile T: coefficient column 4 kb + kk of chain 16 T + j; C operand: its intercept.  Written by other
   // XCDs a barrier ago: every load is a miss of 1-3 us, so the next tile's are in flight under this tile's MFMAs.
   double Bc[SHM_KBMAX], Bn[SHM_KBMAX], c0c = 0.0, c0n = 0.0;
+  const char* thb = (const char*)thg;
+// (addresses as a wave-uniform row pointer + a 32-bit lane offset in bytes: one global_load with an SGPR base per operand;
+//  as 64-bit lane arithmetic every load cost three more vector instructions, 0.17 us per tile for the 13 of them)
 #define SHM_LOAD_B(T_, B_, c0_)                                                                          \
   {                                                                                                      \
     const int ch_ = 16 * (T_) + j;                                                                       \
     const unsigned int chc_ = (unsigned int)(thoff + (ch_ < NC ? ch_ : NC - 1));                         \
-    c0_ = ic ? sh_load(thg + chc_) : 0.0;                                                                \
+    const unsigned int cb_ = chc_ * 8u, rb_ = (unsigned int)((ic + kk) * NCP) * 8u + cb_;                \
+    c0_ = ic ? sh_load((const double*)(thb + cb_)) : 0.0;                                                \
     _Pragma("unroll") for (int kb = 0; kb < (KBC > 0 ? KBC : SHM_KBMAX); kb++) {                         \
       if (kb < KB) {                                                                                     \
         const int col_ = 4 * kb + kk;                                                                    \
-        B_[kb] = sh_load(thg + ((unsigned int)((ic + (col_ < p ? col_ : p - 1)) * NCP) + chc_));         \
+        if (KBC > 0 && kb < KBC - 1)                                                                     \
+          B_[kb] = sh_load((const double*)(thb + (size_t)(4 * kb) * (size_t)NCP * 8 + rb_));             \
+        else                                                                                             \
+          B_[kb] = sh_load(thg + ((unsigned int)((ic + (col_ < p ? col_ : p - 1)) * NCP) + chc_));       \
       }                                                                                                  \
     }                                                                                                    \
   }
 #pragma unroll
   for (int kb = 0; kb < SHM_KBMAX; kb++) { Bc[kb] = 0.0; Bn[kb] = 0.0; }
+  // Where the wave WAITS for a tile's operands is pinned by hand (SHM_PIN: an empty asm that reads the registers, so the
+  // compiler's s_waitcnt lands in front of it and the values are plain registers afterwards): the first tile's right behind
+  // their loads, the next tile's at the end of the current one, BEFORE its store.  Left to the compiler's wait-count
+  // bookkeeping, the loads of tile T + 1 (issued behind a branch) met "none issued" at the join, which put s_waitcnt vmcnt(0)
+  // in front of tile T's fifth MFMA: every tile waited out the full latency of the next tile's loads and the prefetch hid
+  // nothing (lone wave: 1.59 us per tile against 0.83 us of matrix-core time).  For the same reason the loads are issued
+  // unconditionally (the last tile loads itself once more) and the wait sits in front of the store, not behind it (vmcnt
+  // counts the store too).
+#define SHM_PIN(B_, c0_)                                                                                 \
+  {                                                                                                      \
+    asm volatile("" : "+v"(c0_));                                                                        \
+    _Pragma("unroll") for (int kb = 0; kb < (KBC > 0 ? KBC : SHM_KBMAX); kb++) asm volatile("" : "+v"(B_[kb])); \
+  }
   int T = tfirst;                                // N-tiles of this wave
-  if (T < ntiles) SHM_LOAD_B(T, Bc, c0c)
+  if (T < ntiles) { SHM_LOAD_B(T, Bc, c0c) SHM_PIN(Bc, c0c) }
   for (; T < ntiles; T += tstep) {
-    if (T + tstep < ntiles) SHM_LOAD_B(T + tstep, Bn, c0n)
+    SHM_LOAD_B((T + tstep < ntiles ? T + tstep : T), Bn, c0n)
     d4_t acc[NM16];
 #pragma unroll
     for (int mt = 0; mt < NM16; mt++) acc[mt] = (d4_t){c0c, c0c, c0c, c0c};
@@ -685,6 +705,9 @@ __device__ __attribute__((noinline)) void shard_columns_mfma(ShardMfma c) {
     for (int t = 0; t < NTV; t++) a = fmh_fma(rr[t], rr[t], a);
     const int lch = 16 * T + j;                  // member of the set; its chain:
     const int chain = cstride * lch + coff;
+    asm volatile("" : "+v"(a), "+v"(c0n));       // (behind the tile's last MFMA: the pins below follow this one in order,
+    __builtin_amdgcn_sched_barrier(0);           //  and the scheduler must not hoist the register copies they imply)
+    SHM_PIN(Bn, c0n)
     if constexpr (LPW == 2) {
       double a2 = __shfl_xor(a, 16, 64);          // groups 1 and 3 continue where groups 0 and 2 stopped
 #pragma unroll
@@ -702,6 +725,7 @@ __device__ __attribute__((noinline)) void shard_columns_mfma(ShardMfma c) {
     c0c = c0n;
   }
 #undef SHM_LOAD_B
+#undef SHM_PIN
 }
 
 // lane partials acc[c] of canonical lane `tid` for the CW chains of this workgroup, via the sharded evaluation
