@@ -173,6 +173,23 @@ __device__ __forceinline__ double wave_xor_sum(double v) {
   return v;
 }
 
+// v of the EVEN 16-lane row of each row pair, in both rows of the pair (v_permlane16_swap: no LDS round trip as __shfl_xor(v, 16)
+// would make) / v of the upper 32 lanes in both halves (v_permlane32_swap)
+__device__ __forceinline__ double even_row_d(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = (unsigned)u, hi = (unsigned)(u >> 32);
+  const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __longlong_as_double((long long)(((unsigned long long)rh[0] << 32) | rl[0]));
+}
+__device__ __forceinline__ double upper_half_d(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = (unsigned)u, hi = (unsigned)(u >> 32);
+  const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __longlong_as_double((long long)(((unsigned long long)rh[1] << 32) | rl[1]));
+}
+
 __device__ __forceinline__ double uniform_d(double v) { return sgpr_d(v); }
 
 // Diagnostic build only (-DFMCMC_STAMP, tools/stamp_wide.py): s_memtime shares of the phases of a step, wave 0 of every
@@ -709,10 +726,10 @@ __device__ __attribute__((noinline)) void shard_columns_mfma(ShardMfma c) {
     __builtin_amdgcn_sched_barrier(0);           //  and the scheduler must not hoist the register copies they imply)
     SHM_PIN(Bn, c0n)
     if constexpr (LPW == 2) {
-      double a2 = __shfl_xor(a, 16, 64);          // groups 1 and 3 continue where groups 0 and 2 stopped
+      double a2 = even_row_d(a);                  // groups 1 and 3 continue where groups 0 and 2 stopped (what 0 and 2 make of it is not used)
 #pragma unroll
       for (int t = 0; t < NTV; t++) a2 = fmh_fma(rr[t], rr[t], a2);
-      const double a_hi = __shfl_xor(a2, 32, 64); // canonical lane 1 of the slice (group 3) next to lane 0 (group 1)
+      const double a_hi = upper_half_d(a2);       // canonical lane 1 of the slice (group 3) next to lane 0 (group 1)
       if (kk == 1 && lch < NC) {
         double* dst = &part[(long long)chain * (NT + SH_PAD) + lane0];
         sh_store2(dst, a2, a_hi);
@@ -724,9 +741,100 @@ __device__ __attribute__((noinline)) void shard_columns_mfma(ShardMfma c) {
     for (int kb = 0; kb < SHM_KBMAX; kb++) Bc[kb] = Bn[kb];
     c0c = c0n;
   }
+}
+
+// ---- the same product with v_mfma_f64_4x4x4_4b ONLY (form "T4") ---------------------------------------------------------
+// NV values per lane group (NV = ceil(nslots / H), even, <= 12), each by its own chain of 4x4x4 MFMAs: instruction r of a K-block
+// computes value t = r of all four lane groups (rows i = 0..3 of its 4x4 blocks = lane groups, block blk = chains 4 blk ..
+// 4 blk + 3 of the N-tile).  Same matrix-core time as the 16x16x4 form without padding (NV x 16 cycles per K-block), same fma
+// chain per output, but the matrix core is handed over every 16 cycles instead of every 64: an OWNER wave on the same SIMD
+// (fp64 VALU and fp64 MFMA share the datapath) waits a quarter as long per dependent instruction.
+// LDS block: header as above, then per K-block 16 x NV doubles [q = 4 kk + i][r]: row (lane group i, value r), column 4 kb + kk.
+template <int LPW, int KBC, int NV>
+__device__ __attribute__((noinline)) void shard_columns_mfma4(ShardMfma c) {
+  static_assert(KBC > 0 && NV % 2 == 0 && NV <= SHM_T, "compile-time K-block count, an even number of values");
+  const int lane = threadIdx.x & 63;
+  const int NC = rfl_i(c.NC), NCP = rfl_i(c.ncp), p = rfl_i(c.p), ic = rfl_i(c.ic), lane0 = rfl_i(c.lane0);
+  const int cstride = rfl_i(c.cstride), coff = rfl_i(c.coff), thoff = rfl_i(c.thoff), tfirst = rfl_i(c.tfirst), tstep = rfl_i(c.tstep);
+  const int tcount = rfl_i(c.tcount);
+  constexpr int KB = KBC;
+  const double* thg = (const double*)rfl_u64((unsigned long long)c.th);
+  double* part = (double*)rfl_u64((unsigned long long)c.part);
+  typedef __attribute__((address_space(3))) const double* ldsc_t;
+  typedef __attribute__((address_space(3))) const unsigned* ldsu_t;
+  typedef double d2_t __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(3))) const d2_t* ldsc2_t;
+  const unsigned lbase = (unsigned)rfl_i((int)c.lds);
+  const ldsc_t blk = (ldsc_t)(unsigned long long)lbase;
+  const unsigned vmask = ((ldsu_t)(unsigned long long)lbase)[lane];
+  double ya[NV];
+#pragma unroll
+  for (int t = 0; t < NV; t++) ya[t] = blk[32 + 64 * t + lane];
+  const int kk = lane >> 4, j = lane & 15;
+  const ldsc2_t xa = (ldsc2_t)(blk + SHM_HDR + NV * (4 * kk + (lane & 3)));   // K-block kb: xa[kb * 8 NV + r / 2]
+  const int ntiles_all = (NC + 15) >> 4;
+  const int ntiles = (tcount > 0 && tfirst + tcount * tstep < ntiles_all) ? tfirst + (tcount - 1) * tstep + 1 : ntiles_all;
+  double Bc[SHM_KBMAX], Bn[SHM_KBMAX], c0c = 0.0, c0n = 0.0;
+  const char* thb = (const char*)thg;
+#pragma unroll
+  for (int kb = 0; kb < SHM_KBMAX; kb++) { Bc[kb] = 0.0; Bn[kb] = 0.0; }
+  int T = tfirst;
+  if (T < ntiles) { SHM_LOAD_B(T, Bc, c0c) SHM_PIN(Bc, c0c) }
+  for (; T < ntiles; T += tstep) {
+    SHM_LOAD_B((T + tstep < ntiles ? T + tstep : T), Bn, c0n)
+    double acc[NV];
+#pragma unroll
+    for (int r = 0; r < NV; r++) acc[r] = c0c;
+    d2_t a_cur[NV / 2], a_nxt[NV / 2];
+#pragma unroll
+    for (int h = 0; h < NV / 2; h++) a_cur[h] = xa[h];
+#pragma unroll
+    for (int kb = 0; kb < KBC; kb++) {
+      const int kn = (kb + 1 < KB) ? kb + 1 : kb;
+#pragma unroll
+      for (int h = 0; h < NV / 2; h++) a_nxt[h] = xa[kn * 8 * NV + h];
+      const double b = (kb < KBC - 1) ? Bc[kb] : ((4 * kb + kk < p) ? Bc[kb] : 0.0);
+#pragma unroll
+      for (int r = 0; r < NV; r++) acc[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a_cur[r >> 1][r & 1], b, acc[r], 0, 0, 0);
+#pragma unroll
+      for (int h = 0; h < NV / 2; h++) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      }
+#pragma unroll
+      for (int h = 0; h < NV / 2; h++) a_cur[h] = a_nxt[h];
+    }
+    double rr[NV];
+#pragma unroll
+    for (int t = 0; t < NV; t++) rr[t] = ((vmask >> t) & 1u) ? ya[t] - acc[t] : 0.0;   // fma(0, 0, a) == a exactly
+    double a = 0.0;
+#pragma unroll
+    for (int t = 0; t < NV; t++) a = fmh_fma(rr[t], rr[t], a);
+    const int lch = 16 * T + j;
+    const int chain = cstride * lch + coff;
+    asm volatile("" : "+v"(a), "+v"(c0n));
+    __builtin_amdgcn_sched_barrier(0);
+    SHM_PIN(Bn, c0n)
+    if constexpr (LPW == 2) {
+      double a2 = even_row_d(a);
+#pragma unroll
+      for (int t = 0; t < NV; t++) a2 = fmh_fma(rr[t], rr[t], a2);
+      const double a_hi = upper_half_d(a2);
+      if (kk == 1 && lch < NC) {
+        double* dst = &part[(long long)chain * (NT + SH_PAD) + lane0];
+        sh_store2(dst, a2, a_hi);
+      }
+    } else {
+      if (lch < NC) sh_store(&part[(long long)chain * (NT + SH_PAD) + lane0 + kk], a);
+    }
+#pragma unroll
+    for (int kb = 0; kb < SHM_KBMAX; kb++) Bc[kb] = Bn[kb];
+    c0c = c0n;
+  }
+}
 #undef SHM_LOAD_B
 #undef SHM_PIN
-}
 
 // lane partials acc[c] of canonical lane `tid` for the CW chains of this workgroup, via the sharded evaluation
 template <int CW, int LPW>

@@ -3,7 +3,8 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o /tmp/exp tools/exp_shard_mfma.hip && /tmp/exp
 // mode 0: the evaluator waves of mh_sweep_wide2 (2..7) with their tile shares, waves 0, 1 idle
 // mode 1: ONE wave per SIMD (4..7 -> 4 tiles each), the others idle           mode 2: waves 4, 5 alone (4 tiles each)
-// mode 3: as mode 0 with waves 0, 1 running dependent fp64 FMAs (an owner's arithmetic on the same SIMDs)
+// mode 3: as mode 0 with waves 0, 1 running dependent fp64 FMAs (an owner's arithmetic on the same SIMDs)   mode 4: those FMAs alone
+// (1500 dependent FMAs per "visit": w0 / 1500 = time per dependent fp64 instruction of an owner)
 // Prints the time of one visit (us) per wave, median over workgroups; the B operands come from an L2-resident table here
 // (in the sweep they were written by other XCDs a hand-over ago and miss).
 #include <hip/hip_runtime.h>
@@ -44,22 +45,29 @@ __global__ __launch_bounds__(NT) void bench(const double* th, double* part, doub
     sm.tstep = (wave == 4 || wave == 5) ? 4 : 8;
   } else if (mode == 1) {
     active = wave >= 4; sm.tfirst = wave - 4; sm.tstep = 4;
-  } else {
+  } else if (mode == 2) {
     active = wave == 4 || wave == 5; sm.tfirst = wave - 4; sm.tstep = 4;
+  } else {
+    active = false; sm.tfirst = 0; sm.tstep = 4;
   }
   unsigned long long t0 = __builtin_amdgcn_s_memtime();
   if (active) {
     for (int r = 0; r < reps; r++) {
-      #ifdef EXP_T10
+      #if defined(EXP_T4)
+      shard_columns_mfma4<2, EXP_KBC, 10>(sm);
+#elif defined(EXP_T10)
       shard_columns_mfma<2, 3, EXP_KBC, true>(sm);
 #else
       shard_columns_mfma<2, 3, EXP_KBC>(sm);
 #endif
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-  } else if (mode == 3 && wave < 2) {
+  } else if ((mode == 3 || mode == 4) && wave < 2) {
     double a = 1.0 + lane * 1e-9, b = 0.999999;
-    for (int r = 0; r < reps * 1500; r++) a = fmh_fma(a, b, 1e-9);
+    for (int r = 0; r < reps * 25; r++) {
+#pragma unroll
+      for (int u = 0; u < 60; u++) a = fmh_fma(a, b, 1e-9);
+    }
     if (a == 0.123) part[0] = a;
   }
   unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -75,7 +83,7 @@ int main() {
   for (size_t i = 0; i < nth; i++) h[i] = 1e-3 * (double)(i % 977);
   CK(hipMemcpy(th, h.data(), nth * 8, hipMemcpyHostToDevice));
   const int KB = (p + 3) / 4; const size_t lds = sizeof(double) * (SHM_HDR + 3 * KB * 64);
-  for (int mode = 0; mode < 4; mode++) {
+  for (int mode = 0; mode < 5; mode++) {
     for (int w = 0; w < 2; w++) {
       hipLaunchKernelGGL(bench, dim3(256), dim3(NT), lds, 0, th, part, out, reps, mode, p, ng);
       CK(hipDeviceSynchronize());
