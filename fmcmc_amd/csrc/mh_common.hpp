@@ -743,7 +743,11 @@ __device__ __attribute__((noinline)) void shard_columns_mfma(ShardMfma c) {
   }
 }
 
-// ---- the same product with v_mfma_f64_4x4x4_4b ONLY (form "T4") ---------------------------------------------------------
+// ---- the same product with v_mfma_f64_4x4x4_4b ONLY (form "T4"; -DFMCMC_AB: an experiment, not in the product) -------------
+// Measured (tools/exp_shard_mfma.hip -DEXP_T4): a lone wave 9.3 us per visit of four tiles against 6.1 -- five ds_read_b128 per
+// K-block one block ahead do not arrive in time for 10 MFMAs of 16 cycles -- and an owner's dependent fp64 chain next to it is no
+// faster (1500 FMAs: 3.65 us alone, 6.05 next to the T10 form, 6.86 next to three 16x16x4 tiles per K-block).
+#ifdef FMCMC_AB
 // NV values per lane group (NV = ceil(nslots / H), even, <= 12), each by its own chain of 4x4x4 MFMAs: instruction r of a K-block
 // computes value t = r of all four lane groups (rows i = 0..3 of its 4x4 blocks = lane groups, block blk = chains 4 blk ..
 // 4 blk + 3 of the N-tile).  Same matrix-core time as the 16x16x4 form without padding (NV x 16 cycles per K-block), same fma
@@ -833,6 +837,7 @@ __device__ __attribute__((noinline)) void shard_columns_mfma4(ShardMfma c) {
     c0c = c0n;
   }
 }
+#endif  // FMCMC_AB
 #undef SHM_LOAD_B
 #undef SHM_PIN
 

@@ -1,6 +1,7 @@
 // Standalone timing harness of shard_columns_mfma<2, 3> (the slice product of the wide sweeps, mh_common.hpp) at config C4's
 // shape: 256 workgroups x 8 waves, p = 48 (12 K-blocks), 3 M-tiles, one chain group of 256 chains = 16 N-tiles per visit.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o /tmp/exp tools/exp_shard_mfma.hip && /tmp/exp
+//   -DEXP_T10: the form C4 runs (third M-tile as two 4x4x4 MFMAs per K-block)   -DEXP_T4: every value by 4x4x4 MFMAs (experiment)
 // mode 0: the evaluator waves of mh_sweep_wide2 (2..7) with their tile shares, waves 0, 1 idle
 // mode 1: ONE wave per SIMD (4..7 -> 4 tiles each), the others idle           mode 2: waves 4, 5 alone (4 tiles each)
 // mode 3: as mode 0 with waves 0, 1 running dependent fp64 FMAs (an owner's arithmetic on the same SIMDs)   mode 4: those FMAs alone
@@ -18,6 +19,9 @@
 #include <vector>
 #include <algorithm>
 #include <type_traits>
+#ifdef EXP_T4
+#define FMCMC_AB 1
+#endif
 #include "../include/fmcmc_amd.h"
 #include "../include/fmh_detmath.h"
 #include "../include/fmh_philox.h"
