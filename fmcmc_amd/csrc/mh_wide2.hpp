@@ -248,6 +248,10 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
     // The single evaluator waves of SIMDs 0 and 1 share their SIMD with an owner wave and have no partner to overlap a tile's
     // epilogue with: of 16 tiles they take 3 each (wave 4: 0, 1, 2; wave 5: 3, 4, 5), the pairs of SIMDs 2 and 3 take 5
     // (waves 2 / 6: 6, 8, 10 / 7, 9; waves 3 / 7: 11, 13, 15 / 12, 14).  Knob tiles=0: the even split 4 | 4 | 2 + 2 | 2 + 2.
+    // (measured and dropped, round 3, after the T10 form: the single evaluator of an owner's SIMD working only in the visits of that
+    //  owner's OWN group -- 4 or 5 tiles, the pairs 12 or 11 -- and sitting out the other group's, which is when the owner runs its
+    //  critical section, slowed 1.66x by an evaluator next to it (tools/exp_shard_mfma.hip, mode 3): 17.2 / 17.3 us per step against
+    //  16.9 -- what the owner gains, the longer visits of the pairs lose)
     int tfirst, tstep, tcount = 0;
     if (A.sh_tiles == 0) {
       tfirst = (wave == 4) ? 0 : (wave == 5) ? 1 : (wave == 2) ? 2 : (wave == 6) ? 6 : (wave == 3) ? 3 : 7;
