@@ -647,6 +647,38 @@ def test_observation_sharded_evaluation(E, O, monkeypatch, wide_form, chains, cw
     assert _bits_equal(a.samples.cpu().numpy(), b.samples.cpu().numpy())
 
 
+@pytest.mark.parametrize("chains,cw,n,p,intercept", [
+    (512, "2", 10240, 48, True),      # 20 full slots: 10 values per lane group, every one valid; 12 full K-blocks
+    (512, "2", 9300, 47, True),       # 19 slots: value 9 of the second half missing, slot 18 ragged
+    (512, "2", 8193, 45, False),      # 17 slots (9 values per group, the last of the second half missing); 1 + 3 padded columns
+    (128, "1", 5000, 46, True),       # sequential form with four lanes per workgroup (one lane group per canonical lane): 10 values
+])
+@pytest.mark.parametrize("form", ["dataflow", "sequential"])
+def test_slice_product_with_the_half_padded_third_tile_as_4x4x4(E, O, monkeypatch, form, chains, cw, n, p, intercept):
+    """shard_columns_mfma's form T10: three M-tiles of which the third carries 8 rows only, at the width
+    with the compile-time K-block count (45..48 covariates) -- its two live D registers come from two v_mfma_f64_4x4x4 per
+    K-block.  The oracle's bits, and the same bits with the knob t10=0 (a plain third 16x16x4 tile)."""
+    import torch
+    from fmcmc_amd import _abi as abi
+    if form == "dataflow" and cw != "2":
+        pytest.skip("the dataflow form needs two chains per workgroup")
+    set_knob(monkeypatch, "cw", cw); set_knob(monkeypatch, "shard", "1"); set_knob(monkeypatch, "wide2", "1" if form == "dataflow" else "0")
+    full = torch.cuda.get_device_properties(0).multi_processor_count >= 256
+    nb = p + (1 if intercept else 0)
+    X, y = synth_linreg(n, p, 777 + n + p, beta=np.linspace(1.0, -1.0, p + 1))
+    init = jitter_init(list(np.linspace(1.0, -1.0, p + 1))[(0 if intercept else 1):] + [4.0], chains, n + p)
+    init[:, -1] = np.abs(init[:, -1])
+    out = {}
+    for t10 in ("1", "0"):
+        set_knob(monkeypatch, "t10", t10)
+        a, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, nb + 1, init, nsteps=12, calls=2, intercept=intercept)
+        if full:
+            assert abi.last_kernel() == ("wide-dataflow" if form == "dataflow" else "streamed-wide-sharded-mfma")
+        b, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, nb + 1, init, nsteps=10, scale=0.01, intercept=intercept)
+        out[t10] = (a.samples.cpu().numpy(), b.samples.cpu().numpy())
+    assert _bits_equal(out["1"][0], out["0"][0]) and _bits_equal(out["1"][1], out["0"][1])
+
+
 def test_observation_sharded_long_run_equals_chain_sharded(E, monkeypatch, wide_form):
     """Config C4's shape (512 chains, n = 10,000, k = 50, kernel_ram), 400 steps: 800 grid barriers without a stale read --
     the sharded and the chain-sharded kernels return identical bits for every output."""
