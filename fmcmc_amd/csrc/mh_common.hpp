@@ -995,27 +995,42 @@ __device__ __attribute__((noinline)) void logit_partials(LogitEval a) {
   const double kL6 = vconst(FMH_SP_L6), kL5 = vconst(FMH_SP_L5), kL4 = vconst(FMH_SP_L4), kL3 = vconst(FMH_SP_L3);
   const unsigned int tabaddr = (unsigned int)__builtin_amdgcn_readfirstlane((int)a.tab);
   const unsigned int blast = 8u * (nn - 1u);
-  double xb[PL > 0 ? PL : 1], yv = 0.0;
-  unsigned int boff = 8u * (unsigned int)tid;
+  // Two operand sets used alternately (round 3, second series): an observation's columns and y are re-loaded for the observation TWO
+  // passes ahead the moment its eta is formed.  With one set the loads had ~125 instructions (~0.5 us with two waves on the SIMD)
+  // to come back from L2 before the next pass needed them, and the compiler kept the old y alive to the end of the pass, so
+  // every pass ended in s_waitcnt vmcnt(0) + a copy of the new y (`flip` is pinned where it is computed for that reason).  The
+  // intercepts sit in VGPRs: as SGPRs each cost a v_mov_b64 per observation (an fma takes one scalar operand).
+  constexpr int PLX = PL > 0 ? PL : 1;
+  double xb0[PLX], xb1[PLX], yv0 = 0.0, yv1 = 0.0;
+  double b0v[CW];
+#pragma unroll
+  for (int c = 0; c < CW; c++) b0v[c] = vconst(b0[c]);
+  unsigned int boff = 8u * (unsigned int)tid;          // byte offset of the observation the NEXT reload is for, minus one pass
   {
     const unsigned int b = boff < blast ? boff : blast;
 #pragma unroll
-    for (int u = 0; u < PL; u++) xb[u] = ldg(colp[u], b);
-    yv = ldg(yp, b);
+    for (int u = 0; u < PL; u++) xb0[u] = ldg(colp[u], b);
+    yv0 = ldg(yp, b);
+    boff += 8u * NT;
+    const unsigned int b1 = boff < blast ? boff : blast;
+#pragma unroll
+    for (int u = 0; u < PL; u++) xb1[u] = ldg(colp[u], b1);
+    yv1 = ldg(yp, b1);
   }
-  auto one_observation = [&]() {
+  auto one_observation = [&](double (&xb)[PLX], double& yv) {
     double eta[CW];
 #pragma unroll
-    for (int c = 0; c < CW; c++) eta[c] = b0[c];
+    for (int c = 0; c < CW; c++) eta[c] = b0v[c];
 #pragma unroll
     for (int u = 0; u < PL; u++) {
 #pragma unroll
       for (int c = 0; c < CW; c++) eta[c] = fmh_fma(xb[u], bs[c][u], eta[c]);
     }
-    const unsigned int flip = (yv != 0.0) ? 0u : 0x80000000u;     // sg = y ? eta : -eta, on the sign bit
+    unsigned int flip = (yv != 0.0) ? 0u : 0x80000000u;           // sg = y ? eta : -eta, on the sign bit
+    asm volatile("" : "+v"(flip));                                // (here, so that the reload below can land in y's own register)
     boff += 8u * NT;
     {
-      const unsigned int b = boff < blast ? boff : blast;         // clamped: the last prefetch re-reads the last observation
+      const unsigned int b = boff < blast ? boff : blast;         // clamped: the last prefetches re-read the last observation
 #pragma unroll
       for (int u = 0; u < PL; u++) xb[u] = ldg(colp[u], b);
       yv = ldg(yp, b);
@@ -1070,8 +1085,15 @@ __device__ __attribute__((noinline)) void logit_partials(LogitEval a) {
     }
   };
   const unsigned int T = (nn + NT - 1u) / NT;        // uniform
-  for (unsigned int it = 0; it + 1u < T; it++) one_observation();
-  if ((unsigned int)tid + NT * (T - 1u) < nn) one_observation();
+  const bool last_valid = (unsigned int)tid + NT * (T - 1u) < nn;
+  unsigned int it = 0;
+  for (; it + 2u < T; it += 2u) { one_observation(xb0, yv0); one_observation(xb1, yv1); }
+  if (T - it == 2u) {
+    one_observation(xb0, yv0);
+    if (last_valid) one_observation(xb1, yv1);
+  } else if (T - it == 1u) {
+    if (last_valid) one_observation(xb0, yv0);
+  }
   const ldsw_t s_part = (ldsw_t)(unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)a.part);
 #pragma unroll
   for (int c = 0; c < CW; c++) {
