@@ -584,6 +584,7 @@ __device__ __attribute__((noinline)) void shard_columns(ShardCols c) {
 constexpr int SHM_T = 12;                       // D values per lane and N-tile (3 M-tiles x 4 registers)
 constexpr int SHM_HDR = 32 + SHM_T * 64;        // doubles in front of the A tiles
 constexpr int SHM_KBMAX = 16;                   // K-blocks of 4 columns: p <= 64
+constexpr int SHM_T10_FULL = 7;                 // form T10: values 0..6 of every lane group are observations (checked by the host)
 typedef double d4_t __attribute__((ext_vector_type(4)));
 struct ShardMfma {
   const double* th;      // [k][ncp] proposals of all chains
@@ -604,6 +605,9 @@ __device__ __attribute__((noinline)) void shard_columns_mfma(ShardMfma c) {
   static_assert(!T10 || (NMT == 3 && KBC > 0), "T10 is the form of three M-tiles with a compile-time K-block count");
   constexpr int NM16 = T10 ? 2 : NMT;           // M-tiles computed as 16x16x4
   constexpr int NTV = T10 ? 10 : 4 * NMT;       // D values per lane
+  // (T10) values t < SHM_T10_FULL are observations in EVERY lane of every workgroup (the host takes the form only then:
+  // slots spg h + t <= nslots - 2 are full), so their residuals need no mask: 14 vector instructions less per tile
+  constexpr int NFULL = T10 ? SHM_T10_FULL : 0;
   const int lane = threadIdx.x & 63;
   const int NC = rfl_i(c.NC), NCP = rfl_i(c.ncp), p = rfl_i(c.p), ic = rfl_i(c.ic), lane0 = rfl_i(c.lane0);
   const int cstride = rfl_i(c.cstride), coff = rfl_i(c.coff), thoff = rfl_i(c.thoff), tfirst = rfl_i(c.tfirst), tstep = rfl_i(c.tstep);
@@ -632,6 +636,16 @@ __device__ __attribute__((noinline)) void shard_columns_mfma(ShardMfma c) {
   // XCDs a barrier ago: every load is a miss of 1-3 us, so the next tile's are in flight under this tile's MFMAs.
   double Bc[SHM_KBMAX], Bn[SHM_KBMAX], c0c = 0.0, c0n = 0.0;
   const char* thb = (const char*)thg;
+  // (KBC) the rows' base addresses as opaque SCALAR values, so that a load is `global_load v, voffset, s[base]` with no vector
+  // address arithmetic at all: the fp64 datapath a tile's ~100 vector instructions run on is the one its MFMAs run on
+  unsigned long long rowb[KBC > 0 ? KBC : 1];
+  if constexpr (KBC > 0) {
+#pragma unroll
+    for (int kb = 0; kb < KBC; kb++) {
+      rowb[kb] = (unsigned long long)thb + (unsigned long long)(4 * kb) * (unsigned long long)NCP * 8ull;
+      asm volatile("" : "+s"(rowb[kb]));
+    }
+  }
 // (addresses as a wave-uniform row pointer + a 32-bit lane offset in bytes: one global_load with an SGPR base per operand;
 //  as 64-bit lane arithmetic every load cost three more vector instructions, 0.17 us per tile for the 13 of them)
 #define SHM_LOAD_B(T_, B_, c0_)                                                                          \
@@ -644,7 +658,7 @@ __device__ __attribute__((noinline)) void shard_columns_mfma(ShardMfma c) {
       if (kb < KB) {                                                                                     \
         const int col_ = 4 * kb + kk;                                                                    \
         if (KBC > 0 && kb < KBC - 1)                                                                     \
-          B_[kb] = sh_load((const double*)(thb + (size_t)(4 * kb) * (size_t)NCP * 8 + rb_));             \
+          B_[kb] = sh_load((const double*)((const char*)rowb[kb] + rb_));                                \
         else                                                                                             \
           B_[kb] = sh_load(thg + ((unsigned int)((ic + (col_ < p ? col_ : p - 1)) * NCP) + chc_));       \
       }                                                                                                  \
@@ -657,22 +671,44 @@ __device__ __attribute__((noinline)) void shard_columns_mfma(ShardMfma c) {
   // their loads, the next tile's at the end of the current one, BEFORE its store.  Left to the compiler's wait-count
   // bookkeeping, the loads of tile T + 1 (issued behind a branch) met "none issued" at the join, which put s_waitcnt vmcnt(0)
   // in front of tile T's fifth MFMA: every tile waited out the full latency of the next tile's loads and the prefetch hid
-  // nothing (lone wave: 1.59 us per tile against 0.83 us of matrix-core time).  For the same reason the loads are issued
-  // unconditionally (the last tile loads itself once more) and the wait sits in front of the store, not behind it (vmcnt
-  // counts the store too).
+  // nothing (lone wave: 1.59 us per tile against 0.83 us of matrix-core time).  With the wait pinned at the end of the tile
+  // -- in front of the store, not behind it: vmcnt counts the store too -- the loads may sit behind a branch again (the pin's
+  // wait is then the conservative vmcnt(0), which at that place is what is wanted): the last tile of a visit loads nothing.
 #define SHM_PIN(B_, c0_)                                                                                 \
   {                                                                                                      \
     asm volatile("" : "+v"(c0_));                                                                        \
     _Pragma("unroll") for (int kb = 0; kb < (KBC > 0 ? KBC : SHM_KBMAX); kb++) asm volatile("" : "+v"(B_[kb])); \
   }
   int T = tfirst;                                // N-tiles of this wave
-  if (T < ntiles) { SHM_LOAD_B(T, Bc, c0c) SHM_PIN(Bc, c0c) }
-  for (; T < ntiles; T += tstep) {
-    SHM_LOAD_B((T + tstep < ntiles ? T + tstep : T), Bn, c0n)
+#ifndef SHM_DEPTH
+#define SHM_DEPTH 1
+#endif
+  // The register sets of the operands change roles from tile to tile (the loop below is unrolled) instead of being copied: a copy
+  // was 13 v_mov_b64 per tile, and every vector instruction of a tile runs on the fp64 datapath its MFMAs need (a tile is 1920
+  // matrix-core cycles + ~4.4 per vector instruction: 105 -> 66 of them took the harness from 6.1 to 5.5 us per visit of a pair).
+  // SHM_DEPTH = 2 (three sets, the loads of tile T + 2 issued at the start of tile T; compile-time knob) was measured at C4 and
+  // dropped: 17.4 us per step against 16.7 with loads issued only for tiles that exist, 19.1 with the unconditional form -- a
+  // visit's loads all at once are a burst of 20 MB of sc1 reads from every workgroup at the same moment.
+  double Bx[SHM_KBMAX], c0x = 0.0;
+#pragma unroll
+  for (int kb = 0; kb < SHM_KBMAX; kb++) Bx[kb] = 0.0;
+  if (T >= ntiles) return;                       // (a wave without a tile)
+  SHM_LOAD_B(T, Bc, c0c)
+  if (SHM_DEPTH == 2 && T + tstep < ntiles) SHM_LOAD_B(T + tstep, Bn, c0n)
+  SHM_PIN(Bc, c0c)
+  // one tile: operands in (Bc_, c0c_); the next tile's are (being) loaded into (Bn_, c0n_) and waited for at the end of this one;
+  // (Bl_, c0l_) is the set this tile issues loads into (depth 2: the tile after the next; depth 1: the next = Bn_)
+  auto one_tile = [&](double (&Bc_)[SHM_KBMAX], double& c0c_, double (&Bn_)[SHM_KBMAX], double& c0n_,
+                      double (&Bl_)[SHM_KBMAX], double& c0l_) __attribute__((always_inline)) {
+#ifndef SHM_UNCOND_LOAD
+    if (T + SHM_DEPTH * tstep < ntiles) SHM_LOAD_B(T + SHM_DEPTH * tstep, Bl_, c0l_)
+#else
+    SHM_LOAD_B((T + SHM_DEPTH * tstep < ntiles ? T + SHM_DEPTH * tstep : T), Bl_, c0l_)
+#endif
     d4_t acc[NM16];
 #pragma unroll
-    for (int mt = 0; mt < NM16; mt++) acc[mt] = (d4_t){c0c, c0c, c0c, c0c};
-    double acc4[2] = {c0c, c0c};                 // (T10) D registers 0, 1 of the third tile
+    for (int mt = 0; mt < NM16; mt++) acc[mt] = (d4_t){c0c_, c0c_, c0c_, c0c_};
+    double acc4[2] = {c0c_, c0c_};                 // (T10) D registers 0, 1 of the third tile
     double a_cur[NM16], a_nxt[NM16];
     d2_t a4_cur = (d2_t){0.0, 0.0}, a4_nxt = (d2_t){0.0, 0.0};
 #pragma unroll
@@ -686,7 +722,7 @@ __device__ __attribute__((noinline)) void shard_columns_mfma(ShardMfma c) {
         for (int mt = 0; mt < NM16; mt++) a_nxt[mt] = xa[(mt * KB + kn) * 64];
         if constexpr (T10) a4_nxt = xa4[kn * 32];
         // (a padded column must not turn an infinite coefficient into NaN; with KBC only the last block can hold one)
-        const double b = (KBC > 0 && kb < KBC - 1) ? Bc[kb] : ((4 * kb + kk < p) ? Bc[kb] : 0.0);
+        const double b = (KBC > 0 && kb < KBC - 1) ? Bc_[kb] : ((4 * kb + kk < p) ? Bc_[kb] : 0.0);
 #pragma unroll
         for (int mt = 0; mt < NM16; mt++) acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[mt], b, acc[mt], 0, 0, 0);
         if constexpr (T10) {
@@ -715,16 +751,16 @@ __device__ __attribute__((noinline)) void shard_columns_mfma(ShardMfma c) {
 #pragma unroll
     for (int t = 0; t < NTV; t++) {
       const double mu = (T10 && t >= 8) ? acc4[t & 1] : acc[(T10 && t >= 8) ? 0 : (t >> 2)][t & 3];
-      rr[t] = ((vmask >> t) & 1u) ? ya[t] - mu : 0.0;   // fma(0, 0, a) == a exactly
+      rr[t] = (t < NFULL || ((vmask >> t) & 1u)) ? ya[t] - mu : 0.0;   // fma(0, 0, a) == a exactly
     }
     double a = 0.0;
 #pragma unroll
     for (int t = 0; t < NTV; t++) a = fmh_fma(rr[t], rr[t], a);
     const int lch = 16 * T + j;                  // member of the set; its chain:
     const int chain = cstride * lch + coff;
-    asm volatile("" : "+v"(a), "+v"(c0n));       // (behind the tile's last MFMA: the pins below follow this one in order,
+    asm volatile("" : "+v"(a), "+v"(c0n_));       // (behind the tile's last MFMA: the pins below follow this one in order,
     __builtin_amdgcn_sched_barrier(0);           //  and the scheduler must not hoist the register copies they imply)
-    SHM_PIN(Bn, c0n)
+    SHM_PIN(Bn_, c0n_)
     if constexpr (LPW == 2) {
       double a2 = even_row_d(a);                  // groups 1 and 3 continue where groups 0 and 2 stopped (what 0 and 2 make of it is not used)
 #pragma unroll
@@ -737,107 +773,24 @@ __device__ __attribute__((noinline)) void shard_columns_mfma(ShardMfma c) {
     } else {
       if (lch < NC) sh_store(&part[(long long)chain * (NT + SH_PAD) + lane0 + kk], a);
     }
-#pragma unroll
-    for (int kb = 0; kb < SHM_KBMAX; kb++) Bc[kb] = Bn[kb];
-    c0c = c0n;
+  };
+  if (SHM_DEPTH == 2) {
+    while (T < ntiles) {
+      one_tile(Bc, c0c, Bn, c0n, Bx, c0x); T += tstep;
+      if (T >= ntiles) break;
+      one_tile(Bn, c0n, Bx, c0x, Bc, c0c); T += tstep;
+      if (T >= ntiles) break;
+      one_tile(Bx, c0x, Bc, c0c, Bn, c0n); T += tstep;
+    }
+  } else {
+    while (T < ntiles) {
+      one_tile(Bc, c0c, Bn, c0n, Bn, c0n); T += tstep;
+      if (T >= ntiles) break;
+      one_tile(Bn, c0n, Bc, c0c, Bc, c0c); T += tstep;
+    }
   }
 }
 
-// ---- the same product with v_mfma_f64_4x4x4_4b ONLY (form "T4"; -DFMCMC_AB: an experiment, not in the product) -------------
-// Measured (tools/exp_shard_mfma.hip -DEXP_T4): a lone wave 9.3 us per visit of four tiles against 6.1 -- five ds_read_b128 per
-// K-block one block ahead do not arrive in time for 10 MFMAs of 16 cycles -- and an owner's dependent fp64 chain next to it is no
-// faster (1500 FMAs: 3.65 us alone, 6.05 next to the T10 form, 6.86 next to three 16x16x4 tiles per K-block).
-#ifdef FMCMC_AB
-// NV values per lane group (NV = ceil(nslots / H), even, <= 12), each by its own chain of 4x4x4 MFMAs: instruction r of a K-block
-// computes value t = r of all four lane groups (rows i = 0..3 of its 4x4 blocks = lane groups, block blk = chains 4 blk ..
-// 4 blk + 3 of the N-tile).  Same matrix-core time as the 16x16x4 form without padding (NV x 16 cycles per K-block), same fma
-// chain per output, but the matrix core is handed over every 16 cycles instead of every 64: an OWNER wave on the same SIMD
-// (fp64 VALU and fp64 MFMA share the datapath) waits a quarter as long per dependent instruction.
-// LDS block: header as above, then per K-block 16 x NV doubles [q = 4 kk + i][r]: row (lane group i, value r), column 4 kb + kk.
-template <int LPW, int KBC, int NV>
-__device__ __attribute__((noinline)) void shard_columns_mfma4(ShardMfma c) {
-  static_assert(KBC > 0 && NV % 2 == 0 && NV <= SHM_T, "compile-time K-block count, an even number of values");
-  const int lane = threadIdx.x & 63;
-  const int NC = rfl_i(c.NC), NCP = rfl_i(c.ncp), p = rfl_i(c.p), ic = rfl_i(c.ic), lane0 = rfl_i(c.lane0);
-  const int cstride = rfl_i(c.cstride), coff = rfl_i(c.coff), thoff = rfl_i(c.thoff), tfirst = rfl_i(c.tfirst), tstep = rfl_i(c.tstep);
-  const int tcount = rfl_i(c.tcount);
-  constexpr int KB = KBC;
-  const double* thg = (const double*)rfl_u64((unsigned long long)c.th);
-  double* part = (double*)rfl_u64((unsigned long long)c.part);
-  typedef __attribute__((address_space(3))) const double* ldsc_t;
-  typedef __attribute__((address_space(3))) const unsigned* ldsu_t;
-  typedef double d2_t __attribute__((ext_vector_type(2)));
-  typedef __attribute__((address_space(3))) const d2_t* ldsc2_t;
-  const unsigned lbase = (unsigned)rfl_i((int)c.lds);
-  const ldsc_t blk = (ldsc_t)(unsigned long long)lbase;
-  const unsigned vmask = ((ldsu_t)(unsigned long long)lbase)[lane];
-  double ya[NV];
-#pragma unroll
-  for (int t = 0; t < NV; t++) ya[t] = blk[32 + 64 * t + lane];
-  const int kk = lane >> 4, j = lane & 15;
-  const ldsc2_t xa = (ldsc2_t)(blk + SHM_HDR + NV * (4 * kk + (lane & 3)));   // K-block kb: xa[kb * 8 NV + r / 2]
-  const int ntiles_all = (NC + 15) >> 4;
-  const int ntiles = (tcount > 0 && tfirst + tcount * tstep < ntiles_all) ? tfirst + (tcount - 1) * tstep + 1 : ntiles_all;
-  double Bc[SHM_KBMAX], Bn[SHM_KBMAX], c0c = 0.0, c0n = 0.0;
-  const char* thb = (const char*)thg;
-#pragma unroll
-  for (int kb = 0; kb < SHM_KBMAX; kb++) { Bc[kb] = 0.0; Bn[kb] = 0.0; }
-  int T = tfirst;
-  if (T < ntiles) { SHM_LOAD_B(T, Bc, c0c) SHM_PIN(Bc, c0c) }
-  for (; T < ntiles; T += tstep) {
-    SHM_LOAD_B((T + tstep < ntiles ? T + tstep : T), Bn, c0n)
-    double acc[NV];
-#pragma unroll
-    for (int r = 0; r < NV; r++) acc[r] = c0c;
-    d2_t a_cur[NV / 2], a_nxt[NV / 2];
-#pragma unroll
-    for (int h = 0; h < NV / 2; h++) a_cur[h] = xa[h];
-#pragma unroll
-    for (int kb = 0; kb < KBC; kb++) {
-      const int kn = (kb + 1 < KB) ? kb + 1 : kb;
-#pragma unroll
-      for (int h = 0; h < NV / 2; h++) a_nxt[h] = xa[kn * 8 * NV + h];
-      const double b = (kb < KBC - 1) ? Bc[kb] : ((4 * kb + kk < p) ? Bc[kb] : 0.0);
-#pragma unroll
-      for (int r = 0; r < NV; r++) acc[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a_cur[r >> 1][r & 1], b, acc[r], 0, 0, 0);
-#pragma unroll
-      for (int h = 0; h < NV / 2; h++) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-      }
-#pragma unroll
-      for (int h = 0; h < NV / 2; h++) a_cur[h] = a_nxt[h];
-    }
-    double rr[NV];
-#pragma unroll
-    for (int t = 0; t < NV; t++) rr[t] = ((vmask >> t) & 1u) ? ya[t] - acc[t] : 0.0;   // fma(0, 0, a) == a exactly
-    double a = 0.0;
-#pragma unroll
-    for (int t = 0; t < NV; t++) a = fmh_fma(rr[t], rr[t], a);
-    const int lch = 16 * T + j;
-    const int chain = cstride * lch + coff;
-    asm volatile("" : "+v"(a), "+v"(c0n));
-    __builtin_amdgcn_sched_barrier(0);
-    SHM_PIN(Bn, c0n)
-    if constexpr (LPW == 2) {
-      double a2 = even_row_d(a);
-#pragma unroll
-      for (int t = 0; t < NV; t++) a2 = fmh_fma(rr[t], rr[t], a2);
-      const double a_hi = upper_half_d(a2);
-      if (kk == 1 && lch < NC) {
-        double* dst = &part[(long long)chain * (NT + SH_PAD) + lane0];
-        sh_store2(dst, a2, a_hi);
-      }
-    } else {
-      if (lch < NC) sh_store(&part[(long long)chain * (NT + SH_PAD) + lane0 + kk], a);
-    }
-#pragma unroll
-    for (int kb = 0; kb < SHM_KBMAX; kb++) Bc[kb] = Bn[kb];
-    c0c = c0n;
-  }
-}
-#endif  // FMCMC_AB
 #undef SHM_LOAD_B
 #undef SHM_PIN
 

@@ -772,7 +772,9 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
     const int mblk = SHM_HDR + nmt * ((m->p + 3) / 4) * 64;
     // (three M-tiles of which the third holds values 8, 9 only, at the width with a compile-time K-block count -- config C4:
     //  its 8 rows go through two 4x4x4 MFMAs per K-block instead of a 16x16x4 that is half padding; knob t10=0: off)
-    const int t10 = (nmt == 3 && mf_spg <= 10 && (m->p + 3) / 4 == 12 && K.t10 != 0) ? 1 : 0;
+    //  (the form reads values 0 .. SHM_T10_FULL - 1 of every lane group without a mask: slots spg h + t <= nslots - 2 are full)
+    const bool t10_full = shard && mf_spg * (4 / lpw - 1) + (SHM_T10_FULL - 1) <= nslots - 2;
+    const int t10 = (nmt == 3 && mf_spg <= 10 && (m->p + 3) / 4 == 12 && t10_full && K.t10 != 0) ? 1 : 0;
     bool mfma_form = shard && shard_mfma_enabled(K) && m->p <= 4 * SHM_KBMAX && mf_spg <= SHM_T &&
                      lds + sizeof(double) * (size_t)(mblk + 1) <= 160 * 1024;
     if (mfma_form) lds += sizeof(double) * (size_t)(mblk + 1);
