@@ -651,6 +651,7 @@ def test_observation_sharded_evaluation(E, O, monkeypatch, wide_form, chains, cw
     (512, "2", 10240, 48, True),      # 20 full slots: 10 values per lane group, every one valid; 12 full K-blocks
     (512, "2", 9300, 47, True),       # 19 slots: value 9 of the second half missing, slot 18 ragged
     (512, "2", 8193, 45, False),      # 17 slots (9 values per group, the last of the second half missing); 1 + 3 padded columns
+    (512, "2", 9216, 46, True),       # 18 slots, all of them full (n = 18 x 512): 9 values per group, none ragged
     (128, "1", 5000, 46, True),       # sequential form with four lanes per workgroup (one lane group per canonical lane): 10 values
 ])
 @pytest.mark.parametrize("form", ["dataflow", "sequential"])
