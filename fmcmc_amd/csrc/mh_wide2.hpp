@@ -392,6 +392,9 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
   // What the decision of step i needs and f(theta1) does not enter, prepared while the wave waits for the partials:
   // the sigma-only part of the closed form of the pending proposal; for kernel_ram eta(i, k) = min(1, k i^(-2/3))
   // (R/kernel_ram.R:67) and the prefix sums of z^2 (their last one is |z|^2).
+  // (measured and dropped, round 3: the reciprocal halves of (tot / 2) / sigma^2 and of the division by |z|^2 prepared here as
+  //  well (div_recip / div_finish) and no exp when f1 - f0 >= 0 -- ~27 dependent instructions less in the owner's critical
+  //  section: 16.4-16.5 us per step against 16.3-16.5, old and new library alternating on one box)
   double pre_nt1 = 0.0, pre_ss = 1.0, pre_eta = 0.0, pre_zl = 0.0, pre_Pj = 0.0, pre_Pj1 = 0.0, pre_nrm2 = 1.0;
   bool pre_sigma_ok = false;
   const double dn = (double)A.n;
