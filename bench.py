@@ -12,9 +12,15 @@ to one preallocated history, each followed by the Gelman check (device reduction
 all-reduce over RCCL when N > 1); the threshold is set so that no check stops the run and every step does the same work.
 Inputs (X, y, initial states) are resident in HBM before the timed region.
 
-  python bench.py [--gpus N --steps K --warmup W] [--config c2|c3|c4|c5]
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (weak scaling: every rank runs its own
-  shard, chain ids continue across ranks, no data-path collective)
+  python bench.py [--gpus N --steps K --warmup W] [--config c2|c3|c4|c5] [--scaling weak|strong]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: one process per GPU.  Under a launcher (WORLD_SIZE set) the rank count must equal --gpus; WITHOUT one,
+`python bench.py --gpus N` starts its N rank processes itself (launch_ranks: fresh children with RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* set, before this process touches a GPU; the analogue of makePSOCKcluster, R/mcmc.R:536-545) and relays
+rank 0's line.  `config.ranks_seen` lists every rank's device ordinal and architecture as gathered through the process group.
+--scaling weak (default): every rank runs the config's per-GPU share, chain ids continue across ranks, no data-path
+collective.  --scaling strong (C2 / C3): the config's 1024 chains are divided over the ranks.
 
 The line reports what was measured in THIS run: roofline.kernel is fmcmc_last_kernel() (and the run fails if the dispatcher
 did not pick the kernel the config is tuned for), roofline.kernel_ms comes from HIP events on the launch stream.  roofline.traffic cannot be measured from inside the process
@@ -178,9 +184,9 @@ def cpu_baseline(cfg, seconds_budget=24.0):
         with ThreadPoolExecutor(cores) as ex:             # ctypes releases the GIL: one oracle call per host thread
             list(ex.map(lambda tix: run(inits[tix * per_thread:(tix + 1) * per_thread], tix * per_thread, iters), range(cores)))
 
-    def refine(per, fn):                    # a pilot of ~1.5 s sized from the first estimate gives the rate the sample is sized with
-        it = int(max(60, min(cfg.iters, 1.5 / per)))
-        return max(timed(lambda: fn(it)) - 10 * per, 1e-9) / (it - 10)
+    def refine(per, fn):                    # a second two-point difference, ~1.5 s long, sized from the first estimate
+        it = int(max(80, min(cfg.iters, 1.5 / per)))
+        return steady(fn, it // 4, it)
 
     # (b) one thread: ~1/4 of the budget (whole chains when a chain fits)
     per1 = steady(lambda it: run(init0[:1], 0, it), 11, 61)
@@ -324,6 +330,24 @@ def run_config(cfg, chains, iters, steps, warmup, world, rank, dev, dist, torch,
         dist.all_reduce(b, op=dist.ReduceOp.SUM)
         bases = [int(v) for v in b.tolist()]
     assert int(out.status.abs().sum().item()) == 0, "a chain reported an error"
+    # the library's DEFAULT path of the same sweep (no materialised stream handed in: the library fills its own per step
+    # window, mh_engine.hip launch_sweep), timed beside the fed form the steps above used: what a plain MCMC() call gets
+    default_ms = None
+    if cfg.name in ("c2", "c3"):
+        nd = max(2, min(steps, 12))
+        d0, d1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        outs_d = None
+        for i in range(nd + 1):
+            if i == 1:
+                d0.record()
+            st = E.ChainState(init_d, k, device=dev)
+            outs_d = E.sweep(gm, gk, st, iters, thin=thin, seed=CHAIN_SEED, chain_base=chain_base, want_logpost=True,
+                             want_draws=True, want_bits=False, check=False)
+            picked.append(abi.last_kernel())
+        d1.record()
+        torch.cuda.synchronize()
+        default_ms = d0.elapsed_time(d1) / nd
+        assert torch.equal(outs_d.samples, out.samples), "default path and fed path differ"
     bad = sorted(set(n for n in picked if n != cfg.expect_kernel))
     if bad and chains == cfg.chains and iters == cfg.iters:
         raise SystemExit("bench.py --config %s: the dispatcher picked %s, the config is measured on '%s'" % (cfg.name, bad, cfg.expect_kernel))
@@ -335,7 +359,8 @@ def run_config(cfg, chains, iters, steps, warmup, world, rank, dev, dist, torch,
                                             "launches_per_step": len(bulks), "rhat_last": chk.last}
     elif cfg.name in ("c2", "c3"):
         kern_ms = float(np.mean([ev_mid[s].elapsed_time(ev[s][1]) for s in range(steps)]))   # sweep kernel (+ output memsets)
-        extra = {"rng_fill_kernel_ms": step_ms - kern_ms}
+        extra = {"rng_fill_kernel_ms": step_ms - kern_ms, "default_path_ms_per_step": default_ms,
+                 "default_path_note": "the same sweep through the library's own step windows (stream filled per window), bit-equal outputs"}
     else:
         kern_ms, extra = step_ms, {}
     samples_per_step = chains * (iters - 1)
@@ -375,8 +400,6 @@ def roofline_block(res, traffic_from=None):
           "hbm": {"achieved_GBps": out_bytes / (kern_ms * 1e-3) / 1e9, "peak_GBps": PEAK_HBM_GBS,
                   "algorithmic_bytes_per_step": out_bytes}}
     rl.update(res["extra"])
-    if cfg.name == "c4":
-        rl["frac_survey_E2"] = res["samples_per_step"] * 1.98e6 / (kern_ms * 1e-3) / 1e12 / PEAK_FP64_TFLOPS
     return rl
 
 
@@ -385,6 +408,34 @@ def workload_text(res):
     return "configs[%d] (%s): %d chains/GPU x %d-param %s n=%d, %s, nsteps=%d, outputs ans+logpost%s" % (
         cfg.num - 1, cfg.name.upper(), res["chains"], cfg.k, "Gaussian linreg" if cfg.family == "linreg" else "logistic regression",
         cfg.n, cfg.kernel_name, res["iters"], "" if cfg.name == "c4" else "+draws")
+
+
+def launch_ranks(args_list, n, backend):
+    """`python bench.py --gpus N` without a launcher around it: start N FRESH rank processes (the analogue of
+    makePSOCKcluster(ncores), R/mcmc.R:536-545) BEFORE this process imports torch or touches a GPU, one per GPU, with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set; relay rank 0's JSON line and the worst return code.  Nothing is
+    re-executed in place: the parent only waits."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), FMCMC_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + args_list, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0 = procs[0].communicate()[0] or ""
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    worst = max(rcs, key=abs) if any(rcs) else 0
+    if worst:
+        sys.stderr.write("bench.py: rank return codes %s\n" % rcs)
+    return worst if 0 <= worst < 256 else 1
 
 
 def main():
@@ -399,8 +450,18 @@ def main():
     ap.add_argument("--no-extra-configs", action="store_true", help="headline invocation only: skip the short C3 / C4 / C5 sweeps reported under `configs`")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for N > 1 (nccl = RCCL; gloo moves the tensors through the host: tests on one GPU)")
     ap.add_argument("--traffic-from", default=None, help="JSON of a PMC pass of this same command (hbm_bytes_per_launch)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank runs the config's per-GPU share (C2/C3 1024 chains per rank); strong: C2/C3's 1024 chains "
+                         "are divided over the ranks (north_star: '1024 chains ... at 1/2/4/8 MI355X'); C4/C5 keep their per-GPU share")
     args = ap.parse_args()
     cfg = Config(args.config)
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:                       # no launcher: be one (before anything here has initialised a GPU)
+            sys.exit(launch_ranks(sys.argv[1:], args.gpus, args.backend))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks" % (args.gpus, os.environ["WORLD_SIZE"]))
     if args.steps <= 0:   # a timed region of about five seconds (one step = one sweep of the config's nsteps iterations)
         args.steps = DEFAULT_STEPS[cfg.name]
 
@@ -425,7 +486,20 @@ def main():
             dist.init_process_group("gloo")
 
     chains = args.chains or cfg.chains
+    scaling = "weak"
+    if args.scaling == "strong" and world > 1 and cfg.name in ("c2", "c3") and not args.chains:
+        if cfg.chains % world:
+            raise SystemExit("bench.py --scaling strong: %d chains do not divide over %d ranks" % (cfg.chains, world))
+        chains, scaling = cfg.chains // world, "strong"
     iters = args.iters or cfg.iters
+    # who is really there: every rank's device ordinal and architecture, gathered through the process group
+    props = torch.cuda.get_device_properties(dev)
+    me = {"rank": rank, "device": int(torch.cuda.current_device()), "arch": str(getattr(props, "gcnArchName", "?")).split(":")[0],
+          "pid": os.getpid()}
+    ranks_seen = [me]
+    if world > 1:
+        ranks_seen = [None] * world
+        dist.all_gather_object(ranks_seen, me)
     res = run_config(cfg, chains, iters, args.steps, args.warmup, world, rank, dev, dist, torch, E, abi)
 
     # the other GPU configs of BASELINE.md section 4 as short full-size sweeps, so that the driver's clock covers them too
@@ -442,7 +516,7 @@ def main():
                             "kernel_ms": rl["kernel_ms"], "bound": rl["bound"], "achieved": rl["achieved"], "peak": rl["peak"],
                             "frac": rl["frac"], "flops_per_sample": rl["flops_per_sample"], "traffic": rl["traffic"],
                             "traffic_source": rl["traffic_source"], "wall_s_incl_setup": None}
-            for key in ("gelman_checks_ms_per_step", "rng_fill_kernel_ms", "frac_survey_E2"):
+            for key in ("gelman_checks_ms_per_step", "rng_fill_kernel_ms", "default_path_ms_per_step"):
                 if key in rl:
                     extras[name][key] = rl[key]
             extras[name]["wall_s_incl_setup"] = time.perf_counter() - t_x
@@ -453,13 +527,16 @@ def main():
         line = {
             "metric": metric,
             "value": res["value"], "unit": "MH samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload_text(res),
                        "chains_per_gpu": chains, "iters_per_step": iters, "thin": cfg.thin, "accept_rate": res["accept_rate"],
                        "parallelism": "chains sharded, %d rank(s), %s" % (world, "one all-reduce of 1 + 5p + 2p^2 doubles per Gelman check"
                                                                           if cfg.name == "c4" else "no data-path collective"),
                        "backend": (args.backend if world > 1 else None), "chain_base_of_rank": res["chain_bases"],
+                       "world": world, "ranks_seen": ranks_seen,
+                       "launched_by": ("bench.py itself (%d fresh rank processes)" % world) if os.environ.get("FMCMC_BENCH_SPAWNED")
+                                      else ("an external launcher" if world > 1 else "single process"),
                        "all_reduce_calls_in_timed_steps": res["all_reduce_calls_in_timed_steps"]},
             "roofline": roofline_block(res, args.traffic_from),
         }

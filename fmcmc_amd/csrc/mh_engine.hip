@@ -547,7 +547,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
     if (windowed) {
       const long long per_step = (long long)run->nchains * (A.kz + 1) * 8;
       win = ((256ll << 20) / (per_step > 0 ? per_step : 1)) & ~31ll;
-      if (win < 512) win = 512;
+      if (win < 32) win = 32;     // (the kernels take windows from 32 steps; a 512-step floor let the buffer grow with nchains without bound)
       if (K.window >= 32) win = (long long)K.window & ~31ll;      // (diagnosis / tests: a window length)
     }
     const long long n0 = (windowed && run->nsteps > win + 1) ? win + 1 : run->nsteps;   // steps of window 0
@@ -1074,9 +1074,11 @@ int fmcmc_mcmc_run_host(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcm
         case FMCMC_CHAIN_SYNC_TIMEOUT: what = "a grid-wide hand-over of the observation-sharded evaluation timed out; the results of this call are invalid (FMCMC_AMD_DEBUG=shard=0 selects the chain-sharded kernel)."; break;
         default: break;
       }
-      set_err("%s (chain %lld, status %d). Check either -fun- or the -lb- and -ub- "
-              "parameters. This error ocurred during step i = %lld",
-              what, (long long)(run->chain_base + c), out->status[c], (long long)out->status_step[c]);
+      // (R/mcmc.R:759-765 attaches the fun / lb / ub hint to a NaN log-posterior only)
+      const bool nan_status = out->status[c] == FMCMC_CHAIN_NAN_LOGPOST || out->status[c] == FMCMC_CHAIN_NAN_RATIO;
+      set_err("%s (chain %lld, status %d).%s This error ocurred during step i = %lld",
+              what, (long long)(run->chain_base + c), out->status[c],
+              nan_status ? " Check either -fun- or the -lb- and -ub- parameters." : "", (long long)out->status_step[c]);
       rc = FMCMC_ERR_CHAIN;
       break;
     }

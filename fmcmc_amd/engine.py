@@ -275,6 +275,8 @@ def raise_on_chain_error(out, chain_base=0):
                 abi.CHAIN_NOT_PD: "'Sigma' is not positive definite.",
                 abi.CHAIN_BAD_WINDOW: "subscript out of bounds: the rows kernel_adapt(bw / freq) adapts on reach before the "
                                       "first row of this call."}.get(int(st[c]), "chain error.")
+        # (R/mcmc.R:759-765 attaches the fun / lb / ub hint to a NaN log-posterior only)
+        hint = " Check either -fun- or the -lb- and -ub- parameters." if int(st[c]) in (abi.CHAIN_NAN_LOGPOST, abi.CHAIN_NAN_RATIO) else ""
         raise RuntimeError(
-            "%s Check either -fun- or the -lb- and -ub- parameters. This error ocurred during step i = %d "
-            "(chain %d) and proposal parameters theta1 = %s" % (what, step, chain_base + c, np.array2string(theta, precision=4)))
+            "%s%s This error ocurred during step i = %d "
+            "(chain %d) and proposal parameters theta1 = %s" % (what, hint, step, chain_base + c, np.array2string(theta, precision=4)))

@@ -173,7 +173,10 @@ static void fill_run(SEXP run, const fmcmc_kernel* k, fmcmc_run* r) {
   r->step_base = el_count(run, "step_base", 0, 0.0);
   r->rng_mode = el_int(run, "rng_mode", FMCMC_RNG_PHILOX);
   if (r->rng_mode == FMCMC_RNG_FED && r->nchains > 0 && r->nsteps > 0) {
-    const R_xlen_t cn = (R_xlen_t)(r->nchains * r->nsteps);
+    /* el_count admits counts up to 2^53: form no product that can overflow (the extents an R array can have are INT_MAX) */
+    if (r->nchains > INT_MAX || r->nsteps > INT_MAX || r->nchains > (int64_t)(PTRDIFF_MAX / 64) / r->nsteps)
+      error("fmcmc_amd shim: nchains = %.0f x nsteps = %.0f exceed the extents of an R array", (double)r->nchains, (double)r->nsteps);
+    const R_xlen_t cn = (R_xlen_t)r->nchains * (R_xlen_t)r->nsteps;
     r->fed_logu = el_real(run, "fed_logu", cn, 1);                               /* [C][nsteps] */
     r->fed_z = el_real(run, "fed_z", cn * variates_per_step(k), 1);              /* [C][nsteps][kz]: a short vector would be read out of bounds */
   }
@@ -298,6 +301,8 @@ SEXP C_fmcmc_amd_run(SEXP model, SEXP kernel, SEXP run, SEXP state) {
       /* (built from the chain's status, not from fmcmc_last_error(): the library's text already ends in its own
        *  "This error ocurred during step i = N" and the sentence would appear twice) */
       const char* what = "fun(par) is undefined.";
+      /* R/mcmc.R:759-765 attaches the fun / lb / ub hint to a NaN log-posterior only */
+      const int nan_status = INTEGER(status)[bad] == FMCMC_CHAIN_NAN_LOGPOST || INTEGER(status)[bad] == FMCMC_CHAIN_NAN_RATIO;
       switch (INTEGER(status)[bad]) {
         case FMCMC_CHAIN_NAN_LOGPOST: what = "fun(par) is undefined (NaN)."; break;
         case FMCMC_CHAIN_NAN_RATIO: what = "fun(par) is undefined (f1 - f0 is NaN)."; break;
@@ -306,8 +311,9 @@ SEXP C_fmcmc_amd_run(SEXP model, SEXP kernel, SEXP run, SEXP state) {
         case FMCMC_CHAIN_SYNC_TIMEOUT: what = "a grid-wide hand-over of the observation-sharded evaluation timed out; the results of this call are invalid."; break;
         default: break;
       }
-      int off = snprintf(msg, sizeof msg, "%s Check either -fun- or the -lb- and -ub- parameters. This error ocurred during step i = %.0f "
-                         "(chain %ld) and proposal parameters theta1 = c(", what, REAL(status_step)[bad], (long)(r.chain_base + bad + 1));
+      int off = snprintf(msg, sizeof msg, "%s%s This error ocurred during step i = %.0f "
+                         "(chain %ld) and proposal parameters theta1 = c(", what, nan_status ? " Check either -fun- or the -lb- and -ub- parameters." : "",
+                         REAL(status_step)[bad], (long)(r.chain_base + bad + 1));
       for (R_xlen_t j = 0; j < K && off < (int)sizeof msg - 40; j++)
         off += snprintf(msg + off, sizeof msg - (size_t)off, "%s%.4f", j ? ", " : "", REAL(status_theta)[bad * K + j]);
       snprintf(msg + off, sizeof msg - (size_t)off, ")");

@@ -74,3 +74,34 @@ def test_two_rank_gelman_all_reduce_equals_unsharded(O):
         assert rc == 0
         assert abs(mpsrf - ompsrf) < 1e-9 * ompsrf and np.allclose(psrf, opsrf, rtol=1e-9)
     assert res[0][2] == res[1][2]                                  # every rank decides identically
+
+
+def _bench_cli(args, env_drop=("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"), env_extra=None):
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in env_drop}
+    env.update(env_extra or {})
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True,
+                          timeout=300)
+
+
+def test_bench_refuses_a_launcher_whose_world_differs_from_gpus():
+    """`--gpus N` is a contract, not a label: under a launcher the rank count must match (no GPU needed: checked first)."""
+    r = _bench_cli(["--gpus", "4"], env_extra=dict(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "--gpus 4 but the launcher started WORLD_SIZE=2" in r.stderr
+    r = _bench_cli(["--gpus", "0"])
+    assert r.returncode != 0 and "--gpus must be >= 1" in r.stderr
+
+
+def test_bench_gpus_n_without_a_launcher_starts_n_rank_processes():
+    """No rank variables in the environment: bench.py itself starts N fresh ranks (R/mcmc.R:536-545 creates its own
+    workers).  On this GPU-less box every rank ends with the engine's 'needs an MI355X' refusal -- N of them, and the
+    parent reports the ranks' return codes and fails."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("CPU-side check of the launcher (the GPU suite runs the real thing)")
+    r = _bench_cli(["--gpus", "3", "--backend", "gloo", "--no-cpu-baseline"])
+    assert r.returncode != 0
+    assert r.stderr.count("bench.py needs an MI355X") == 3
+    assert "rank return codes [1, 1, 1]" in r.stderr

@@ -155,3 +155,51 @@ def test_bench_multi_rank_path_runs_and_matches_the_single_rank_run():
     # the same 128 chains, bit for bit; their R-hat to the last ulps (the sum over the chains is rank 0's + rank 1's partial
     # instead of one fixed-order sum over 128)
     assert abs(line["roofline"]["rhat_last"] - one["roofline"]["rhat_last"]) <= 1e-13 * one["roofline"]["rhat_last"]
+
+
+def test_bench_gpus_2_with_no_rank_variables_launches_two_ranks_itself():
+    """The shape of the driver's command when no launcher is around it: `python bench.py --gpus 2 ...` with NO rank
+    variables in the environment.  bench.py starts two fresh rank processes itself (before it touches the GPU), relays
+    rank 0's line, and the line proves two ranks were there: n_gpus, chain_base_of_rank, ranks_seen as gathered through the
+    process group.  (R/mcmc.R:536-545: the reference creates its own workers.)"""
+    import json
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    drop = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE")
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--config", "c4",
+                        "--chains", "64", "--iters", "2000", "--steps", "2", "--no-cpu-baseline"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["world"] == 2
+    assert line["config"]["chain_base_of_rank"] == [0, 64]
+    seen = line["config"]["ranks_seen"]
+    assert [x["rank"] for x in seen] == [0, 1] and len({x["pid"] for x in seen}) == 2
+    assert all(x["arch"] == "gfx950" for x in seen)
+    assert "bench.py itself" in line["config"]["launched_by"]
+    assert line["config"]["all_reduce_calls_in_timed_steps"] == 2 * 2 * 2
+
+
+def test_bench_strong_scaling_divides_the_headline_chains():
+    """--scaling strong: C2's 1024 chains divided over the ranks (512 each), chain ids continuing; the line says which
+    scaling ran.  A launcher world that differs from --gpus is refused."""
+    import json
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    drop = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE")
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--scaling", "strong",
+                        "--iters", "2000", "--steps", "2", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert line["scaling"] == "strong" and line["n_gpus"] == 2
+    assert line["config"]["chains_per_gpu"] == 512 and line["config"]["chain_base_of_rank"] == [0, 512]
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=dict(env, WORLD_SIZE="2", RANK="0"),
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "but the launcher started WORLD_SIZE=2" in bad.stderr

@@ -946,7 +946,9 @@ def test_a_call_longer_than_4_gib_of_samples_stays_on_the_headline_kernel(E, mon
     assert torch.equal(st_part.theta0, st_full.theta0[448:512]) and torch.equal(st_part.f0, st_full.f0[448:512])
     del part
     # (d) no cliff
-    assert long_us <= 1.03 * short_us, "%.3f us per step at 1.2e5 steps, %.3f at 1e4" % (long_us, short_us)
+    # (a timing bound has no place beside bitwise assertions on a shared box: 10 % here only catches a fall to another
+    #  kernel class -- the general kernel is 2.5-6.5x slower; the 3 % figure of DESIGN 5.6 is tools/bench_long.py's)
+    assert long_us <= 1.10 * short_us, "%.3f us per step at 1.2e5 steps, %.3f at 1e4" % (long_us, short_us)
 
 
 def test_full_size_headline_properties(E, monkeypatch):
