@@ -31,6 +31,7 @@ struct SweepArgs {
   const double* X;
   const double* y;
   double prior_div;
+  const double* lg_hs;       // logistic: [intercept + p] data-only sums sum_i (y_i - 1/2) x_ij, then [p] largest |x| per column (logit_hs_kernel)
   // kernel
   int kind, k, scheme, warmup;
   int variate;               // 0: N(0,1) / Student-t by kind; 1: U(0,1) (uniform kernels)
@@ -326,78 +327,55 @@ __device__ __forceinline__ ChainLds chain_lds(double* base, int k, int kf, int k
   return c;
 }
 
-// ---- chain-vectorised twin of fmh_log1p_exp_nonpos (include/fmh_detmath.h): the same operations in the same order for
-// every element, so the same bits -- but each constant is materialised ONCE per observation instead of once per chain
-// (FMH_K costs two scalar moves per use), the CW dependent chains interleave, and the out-of-range test is one branch
-// per observation.
-// The table (2401 rows: softplus(a_j) hi, lo, sigma_j) is staged in LDS by the logistic-only kernel instantiations: a lookup
-// from global memory is a 64-address gather, ~64 cycles of the texture addresser.  In LDS it is three arrays (SoA) read with
-// three ds_read_b64: the rows a wave looks up are scattered (one per lane, by eta), so what a lookup costs is bank
-// conflicts, and those depend on how many distinct bank positions the rows of ONE read can fall on.  As 32-byte rows
-// (round 2: ds_read2_b64 + ds_read_b64) a row started on one of 8 positions and 32 lanes into 8 positions is a 7-way
-// conflict on average: rocprofv3 PMC at config C5, SQ_LDS_BANK_CONFLICT = 83 % of SQ_LDS_IDX_ACTIVE and the LDS busy for
-// the whole kernel (profiles/r03_a_c5_summary.json) -- the loop was LDS-bound, not issue-bound.  With 8-byte elements a
-// read has 32 positions (~3.3-way for random rows) and the table takes 57.6 KB instead of 76.8.
-constexpr int SP_LDS_DOUBLES = FMH_SPG_ROWS * 3;
-__device__ __forceinline__ void softplus_stage_tables(double* s_tab) {
-  const double* t = fmh_spg_tab_();
-  for (int i = threadIdx.x; i < FMH_SPG_ROWS * 4; i += blockDim.x) {
-    const int j = i >> 2, c = i & 3;
-    if (c < 3) s_tab[c * FMH_SPG_ROWS + j] = t[i];
+// ---- logistic family: g(|eta|) = log(2 cosh(eta / 2)) off the row-polynomial table (include/fmh_detmath.h, fmh_logit_g):
+// chain-vectorised twin of fmh_logit_g_scaled, the same operations in the same order for every element, so the same bits.
+// The table (2400 rows x 6 coefficients, 115 KB) is staged in LDS by the logistic-only instantiations as THREE arrays of
+// 16-byte coefficient PAIRS (c0 c1 | c2 c3 | c4 c5) read with three ds_read_b128 from one address + immediate offsets: 16-byte
+// reads run at the full LDS rate (256 B/clk) with four waves per CU, 8-byte reads need four waves per SIMD for theirs
+// (MI355X_MICROARCH.md, LDS), and tools/probe_logit_grid.hip measured the 8-byte form a third slower.  What a lookup costs
+// beyond that is bank conflicts between the rows the lanes of one read hit: lanes = observations (the chain-sharded loops)
+// scatter over the table, ~2.9-way; lanes = chains of one observation (the observation-sharded loop, logit_shard) hit equal or
+// neighbouring rows, which neighbouring addresses serve without conflict.
+typedef double lg_v2d __attribute__((ext_vector_type(2)));
+constexpr int LG_STRIDE = FMH_LG_ROWS + 1;            // 16-byte elements from one pair array to the next
+constexpr int LG_LDS_DOUBLES = 3 * LG_STRIDE * 2;
+__device__ __forceinline__ double* logit_table_align(double* p) {   // 16-byte aligned start inside [p, p + 2)
+  return (double*)(((unsigned long long)p + 15ull) & ~15ull);
+}
+__device__ __forceinline__ void logit_stage_table(double* s_tab) {
+  const double* t = fmh_lg_tab_();
+  for (int i = threadIdx.x; i < FMH_LG_ROWS * 6; i += blockDim.x) {
+    const int j = i / 6, c = i - 6 * j;
+    s_tab[((c >> 1) * LG_STRIDE + j) * 2 + (c & 1)] = t[i];
   }
 }
 
-// LDSTAB is a COMPILE-TIME property (the logistic-only instantiations always stage the table): decided at run time the two
-// paths were an exec-masked branch per chain and the loads went through a generic pointer -- FLAT loads, whose s_waitcnt
-// covers vmcnt AND lgkmcnt, i.e. every lookup also waited for the prefetch of the next observation (an L2 round trip per
-// observation with two waves per SIMD to hide it).
+// LDSTAB is a COMPILE-TIME property (the logistic-only instantiations always stage the table; the all-family kernels read
+// the rows from global memory: scalar base + 32-bit lane offset).  us[] = 64 |eta| (>= 0 or NaN).
 template <int CW, bool LDSTAB>
-__device__ __forceinline__ void softplus_nonpos_vec(const double (&a)[CW], double (&out)[CW], const double* s_tab) {
-  // (without the LDS copy -- the all-family kernels -- the table is read as global memory: scalar base + 32-bit lane offset)
-  typedef const double __attribute__((address_space(1))) * gptr_t;
-  typedef const double __attribute__((address_space(3))) * lptr_t;
-  const gptr_t gtab = (gptr_t)(unsigned long long)fmh_spg_tab_();
-  const lptr_t ltab = (lptr_t)s_tab;
-  bool slow = false;
-  double r[CW], sh[CW], sl[CW], sg[CW], q[CW];
+__device__ __forceinline__ void logit_g_vec(const double (&us)[CW], double (&out)[CW], const double* s_tab) {
+  typedef const lg_v2d __attribute__((address_space(1))) * gptr2_t;
+  typedef const lg_v2d __attribute__((address_space(3))) * lptr2_t;
+  const gptr2_t gtab = (gptr2_t)(unsigned long long)fmh_lg_tab_();
+  const lptr2_t ltab = (lptr2_t)s_tab;
+  double s[CW];
+  lg_v2d p0[CW], p1[CW], p2[CW];
 #pragma unroll
-  for (int c = 0; c < CW; c++) slow = slow || !(a[c] >= FMH_SPG_AMIN) || (!LDSTAB && !(a[c] <= 0.0));   // (the logistic loops pass -|eta|)
-  {
-    const double shift = FMH_K(FMH_SP_SHIFT);
-#pragma unroll
-    for (int c = 0; c < CW; c++) {
-      const double t = fmh_fma(a[c], 64.0, shift);
-      const double kd = t - shift;
-      // (a slow element may index anything, its result is replaced below: clamped for global memory; an LDS read cannot fault)
-      int j = -(int32_t)(uint32_t)fmh_d2u(t);
-      if (!LDSTAB) j = (j < 0) ? 0 : (j > FMH_SPG_ROWS - 1 ? FMH_SPG_ROWS - 1 : j);
-      r[c] = fmh_fma(kd, -0.015625, a[c]);
-      if constexpr (LDSTAB) { sh[c] = ltab[j]; sl[c] = ltab[FMH_SPG_ROWS + j]; sg[c] = ltab[2 * FMH_SPG_ROWS + j]; }
-      else { const unsigned int ti = 4u * (unsigned int)j; sh[c] = gtab[ti]; sl[c] = gtab[ti + 1]; sg[c] = gtab[ti + 2]; }
-    }
+  for (int c = 0; c < CW; c++) {
+    s[c] = __builtin_amdgcn_fract(us[c]);
+    unsigned j = (unsigned)us[c];                      // (saturating; NaN -> 0)
+    j = (j < (unsigned)FMH_LG_ROWS) ? j : (unsigned)(FMH_LG_ROWS - 1);   // an element beyond the table is replaced below
+    if constexpr (LDSTAB) { p0[c] = ltab[j]; p1[c] = ltab[LG_STRIDE + j]; p2[c] = ltab[2 * LG_STRIDE + j]; }
+    else { p0[c] = gtab[3u * j]; p1[c] = gtab[3u * j + 1u]; p2[c] = gtab[3u * j + 2u]; }
   }
-  {
-    const double e6 = FMH_K(FMH_SPG_E6), e5 = FMH_K(FMH_SP_E5);
 #pragma unroll
-    for (int c = 0; c < CW; c++) q[c] = fmh_fma(r[c], e6, e5);
-  }
-#define SP_STEP(arr, x, K) { const double kk = FMH_K(K); _Pragma("unroll") for (int c = 0; c < CW; c++) arr[c] = fmh_fma(x[c], arr[c], kk); }
-  SP_STEP(q, r, FMH_SP_E4) SP_STEP(q, r, FMH_SP_E3) SP_STEP(q, r, FMH_SP_E2)
-  double w[CW], p[CW];
-#pragma unroll
-  for (int c = 0; c < CW; c++) w[c] = sg[c] * fmh_fma(r[c] * r[c], q[c], r[c]);
-  {
-    const double l6 = FMH_K(FMH_SP_L6), l5 = FMH_K(FMH_SP_L5);
-#pragma unroll
-    for (int c = 0; c < CW; c++) p[c] = fmh_fma(w[c], l6, l5);
-  }
-  SP_STEP(p, w, FMH_SP_L4) SP_STEP(p, w, FMH_SP_L3) SP_STEP(p, w, FMH_SP_L2)
-#undef SP_STEP
-#pragma unroll
-  for (int c = 0; c < CW; c++) out[c] = sh[c] + (sl[c] + fmh_fma(w[c] * w[c], p[c], w[c]));
-  if (__builtin_expect(slow, 0)) {   // eta beyond +-37.5, NaN: the general functions, as in the scalar routine
-#pragma unroll
-    for (int c = 0; c < CW; c++) out[c] = fmh_log1p_exp_nonpos(a[c]);
+  for (int c = 0; c < CW; c++) {
+    double q = fmh_fma(s[c], p2[c].y, p2[c].x);
+    q = fmh_fma(s[c], q, p1[c].y);
+    q = fmh_fma(s[c], q, p1[c].x);
+    q = fmh_fma(s[c], q, p0[c].y);
+    q = fmh_fma(s[c], q, p0[c].x);
+    out[c] = (us[c] < (double)FMH_LG_ROWS) ? q : us[c] * FMH_LG_HALF_INV_SCALE;   // |eta| >= 37.5: |eta| / 2; NaN stays NaN
   }
 }
 
@@ -795,9 +773,12 @@ __device__ __attribute__((noinline)) void shard_columns_mfma(ShardMfma c) {
 #undef SHM_PIN
 
 // lane partials acc[c] of canonical lane `tid` for the CW chains of this workgroup, via the sharded evaluation
-template <int CW, int LPW>
+// (the logistic family's step 2, logit_shard below, is reached through this forward-declared hook)
+template <int LPW>
+__device__ __forceinline__ void eval_sharded_logit_step(const SweepArgs& A, const double* s_tab);
+template <int CW, int LPW, int FAM = FMCMC_FAM_GAUSSIAN_LINREG>
 __device__ __forceinline__ bool eval_sharded(const SweepArgs& A, double* const* th, double (&acc)[CW], unsigned& epoch,
-                                             const double* s_mblk /* LDS block of the MFMA form, or NULL */, Stamps* stp = nullptr) {
+                                             const double* s_mblk /* LDS block of the MFMA form (logistic: the g table), or NULL */, Stamps* stp = nullptr) {
   const int tid = threadIdx.x;
   const int NC = (int)A.nchains, NCP = NC + SH_PAD, p = A.p, ic = A.intercept, nb = ic + p;
   const long long cg0 = (long long)blockIdx.x * CW;
@@ -815,6 +796,9 @@ __device__ __forceinline__ bool eval_sharded(const SweepArgs& A, double* const* 
   if (!(A.debug & 32) && !(epoch & LOST)) { ok = shard_barrier(A.sh_bar, ++epoch); if (!ok) epoch |= LOST; }
   FMH_STAMP(stp, 4);
   // 2. thread = chain: the slice's observations for that chain
+  if constexpr (FAM == FMCMC_FAM_LOGISTIC) {
+    eval_sharded_logit_step<LPW>(A, s_mblk);
+  } else {
   ShardCols sc;
   sc.xs = A.sh_xs + (long long)blockIdx.x * p * SH_MAXO;
   sc.ys = A.sh_ys + (long long)blockIdx.x * SH_MAXO;
@@ -834,6 +818,7 @@ __device__ __forceinline__ bool eval_sharded(const SweepArgs& A, double* const* 
   } else
   if (A.sh_nslots * LPW <= SH_MAXO / 2) shard_columns<LPW, SH_MAXO / 2>(sc);   // half-empty slices: half the FMAs
   else shard_columns<LPW, SH_MAXO>(sc);
+  }
   FMH_STAMP(stp, 5);
   if (!(A.debug & 32) && !(epoch & LOST)) { ok = shard_barrier(A.sh_bar, ++epoch); if (!ok) epoch |= LOST; }
   FMH_STAMP(stp, 6);
@@ -845,49 +830,30 @@ __device__ __forceinline__ bool eval_sharded(const SweepArgs& A, double* const* 
   return ok;
 }
 
-// ---- logistic family: log-likelihood terms of one observation for all CW chains: logq(eta) == logp(-eta), softplus tail
-// on -|eta| (twin of the oracle's logistic loop; R: vignettes/workflow-with-fmcmc.Rmd:35-41)
-#ifndef FMCMC_SP_GROUP
-#define FMCMC_SP_GROUP 4
-#endif
+// ---- logistic family: sum_i g(|eta_i|) per canonical lane (twin of the oracle's logistic loop; R: vignettes/
+// workflow-with-fmcmc.Rmd:35-41).  The linear part sum_i (y_i - 1/2) eta_i = sum_j b_j hs_j never enters a loop: hs (and the
+// columns' largest |x|, for the range check below) come from logit_hs_kernel, once per launch.
 template <int CW, bool LDSTAB>
-__device__ __forceinline__ void logit_add_terms(const double (&eta)[CW], bool y1, double (&acc)[CW], const double* s_sptab) {
-  double sg[CW], ab[CW], l1[CW];
-  // sg = y ? eta : -eta and ab = -|sg| as sign-bit operations (one integer instruction each; written as selects they
-  // were seven per chain).  Same values as the oracle's selects: a -0 / +0 difference in ab cannot reach the result.
-  const unsigned long long flip = y1 ? 0ull : 0x8000000000000000ull;
+__device__ __forceinline__ void logit_add_terms(const double (&es)[CW] /* 64 eta */, double (&acc)[CW], const double* s_tab) {
+  double us[CW], gv[CW];
 #pragma unroll
-  for (int c = 0; c < CW; c++) {
-    sg[c] = fmh_u2d(fmh_d2u(eta[c]) ^ flip);
-    ab[c] = fmh_u2d(fmh_d2u(sg[c]) | 0x8000000000000000ull);
-  }
-  constexpr int G = (CW < FMCMC_SP_GROUP) ? CW : FMCMC_SP_GROUP;   // chains per softplus batch (register pressure vs constant re-use)
+  for (int c = 0; c < CW; c++) us[c] = __builtin_fabs(es[c]);
+  logit_g_vec<CW, LDSTAB>(us, gv, s_tab);
 #pragma unroll
-  for (int g0 = 0; g0 < CW; g0 += G) {
-    double ag[G], lg[G];
-#pragma unroll
-    for (int c = 0; c < G; c++) ag[c] = ab[g0 + c];
-    softplus_nonpos_vec<G, LDSTAB>(ag, lg, s_sptab);
-#pragma unroll
-    for (int c = 0; c < G; c++) l1[g0 + c] = lg[c];
-  }
-#pragma unroll
-  for (int c = 0; c < CW; c++) acc[c] = acc[c] + (__builtin_fmin(sg[c], 0.0) - l1[c]);   // == (sg < 0) ? sg - l1 : -l1, bit for bit
+  for (int c = 0; c < CW; c++) acc[c] = acc[c] + gv[c];
 }
 
 // The evaluation of the logistic-only instantiations (PL covariates known at compile time, the CW (PL + 1) coefficients in
-// SGPRs for the whole pass, softplus table in LDS) as a REAL function: the sweep kernel calls it from two places (row 1 and the
+// SGPRs for the whole pass, table in LDS) as a REAL function: the sweep kernel calls it from two places (row 1 and the
 // step loop), and inlined the copy inside the step loop shared its register allocation with everything the sweep keeps
-// live across an evaluation -- 256 VGPRs, 228 bytes of scratch per lane, 1118 spilled SGPRs, 18 v_readlane reloads in
-// every pass of the observation loop (210 instructions per observation against 188 in the copy in front of the loop).
-// Arguments travel in registers (16 dwords); everything uniform goes through v_readfirstlane.
+// live across an evaluation.  Arguments travel in registers (16 dwords); everything uniform goes through v_readfirstlane.
 struct LogitEval {
   const double* X;       // [p][n]
-  const double* y;       // [n]
+  const double* hs;      // [ic + p] data-only sums, then [p] largest |x| of every column (logit_hs_kernel)
   long long n;
   int ic, p;
-  unsigned th0, thstride, ncw;   // LDS address of chain 0's coefficient vector, bytes between chains, chains of the workgroup
-  unsigned tab;          // LDS address of the softplus table (logistic-only instantiations)
+  unsigned th0, thstride, ncw;   // LDS address of chain 0's SCALED coefficient vector (64 b), bytes between chains, chains of the workgroup
+  unsigned tab;          // LDS address of the table (logistic-only instantiations)
   unsigned part;         // LDS address of s_part [NW][CW]
 };
 static_assert(sizeof(LogitEval) <= 64, "LogitEval must travel in registers (16 dwords)");
@@ -904,9 +870,8 @@ __device__ __attribute__((noinline)) void logit_partials(LogitEval a) {
   const unsigned int nn = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned)a.n);
   const unsigned long long Xu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)a.X >> 32)) << 32) |
                                 (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)a.X);
-  const unsigned long long yu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)a.y >> 32)) << 32) |
-                                (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)a.y);
-  const double* s_sptab = (const double*)(ldsc_t)(unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)a.tab);
+  const double* hs = (const double*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)a.hs >> 32)) << 32) |
+                                     (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)a.hs));
   double b0[CW], bs[CW][PL > 0 ? PL : 1];
 #pragma unroll
   for (int c = 0; c < CW; c++) {
@@ -915,6 +880,17 @@ __device__ __attribute__((noinline)) void logit_partials(LogitEval a) {
 #pragma unroll
     for (int u = 0; u < PL; u++) bs[c][u] = sgpr_d(th[ic + u]);
   }
+  // Range: |64 eta| <= |64 b0| + sum_u |64 b_u| max_i |x_iu| (+ a few ulps); below the table's 2400 rows NO observation needs the
+  // "beyond the table" branch and the loop runs without it (uniform: the coefficients are).  Otherwise every element checks.
+  bool fast = true;
+#pragma unroll
+  for (int c = 0; c < CW; c++) {
+    double B = __builtin_fabs(b0[c]);
+#pragma unroll
+    for (int u = 0; u < PL; u++) B = fmh_fma(__builtin_fabs(bs[c][u]), sgpr_d(hs[ic + PL + u]), B);
+    fast = fast && (B < (double)(FMH_LG_ROWS - 1));
+  }
+  fast = __builtin_amdgcn_ballot_w64(!fast) == 0ull;
   // global (not generic) pointers, scalar column bases and a 32-bit lane index: one global_load per value with no
   // 64-bit address arithmetic
   typedef const double __attribute__((address_space(1))) * gptr_t;
@@ -922,39 +898,24 @@ __device__ __attribute__((noinline)) void logit_partials(LogitEval a) {
   gptr_t colp[PL > 0 ? PL : 1];
 #pragma unroll
   for (int u = 0; u < PL; u++) colp[u] = (gptr_t)(Xu + 8ull * (unsigned long long)u * nn);
-  const gptr_t yp = (gptr_t)yu;
   // (the lane's offset in BYTES as a 32-bit value -- n < 2^28 -- so that every load is `scalar base + 32-bit VGPR offset`)
   auto ldg = [](gptr_t base, unsigned int boff) -> double { return *(gptr_t)((gcptr_t)base + boff); };
   double acc[CW];
 #pragma unroll
   for (int c = 0; c < CW; c++) acc[c] = 0.0;
-  // ---- the observation loop, written out (round 3).  Per element EXACTLY the operations of fmh_log1p_exp_nonpos /
-  // softplus_nonpos_vec / logit_add_terms in their order -- the oracle's bits -- but:
-  //  * the polynomial constants are pinned in VGPRs ONCE (FMH_K pins an SGPR copy per use with a volatile asm that cannot
-  //    leave the loop: 11 s_mov_b64 + 3 v_mov_b64 per observation, and two SGPR operands in one instruction are not encodable);
-  //  * the grid index comes from t' = fma(|eta|, 64, SHIFT) = SHIFT + j instead of t = fma(-|eta|, 64, SHIFT) = SHIFT - j:
-  //    j is the low word as it stands, kd' = t' - SHIFT = -kd exactly and r = fma(kd', 1/64, -|eta|) is the same real number as
-  //    fma(kd, -1/64, -|eta|), i.e. the same double; the three table reads are one address + immediate offsets
-  //    (was: a 64-bit negation, three shifts and three adds per chain);
-  //  * min(sg, 0) is issued as v_min_f64 itself (__builtin_fmin on a value that comes out of an integer xor gets a
-  //    canonicalising v_max_f64 in front);
-  //  * the trip count is uniform (scalar branch): all lanes are valid in every pass but the last, which runs once more
-  //    under the exec mask; the prefetch index is clamped with one v_min_u32.
-  // 184 -> ~140 instructions per observation of four chains.
+  // ---- the observation loop.  Per element EXACTLY the operations of fmh_logit_g_scaled (the oracle's bits): 64 eta as the fma
+  // chain over the scaled coefficients, s = fract, j = trunc, three 16-byte table reads at one address + immediate offsets,
+  // five fmas, one add.  Two operand sets used alternately: an observation's columns are re-loaded for the observation TWO
+  // passes ahead the moment its eta is formed; the trip count is uniform (scalar branch), the last pass runs once more under
+  // the exec mask, the prefetch index is clamped with one v_min_u32.  The intercepts sit in VGPRs: as SGPRs each cost a
+  // v_mov_b64 per observation (an fma takes one scalar operand).
   typedef __attribute__((address_space(3))) const char* ldsb_t;
+  typedef __attribute__((address_space(3))) const lg_v2d* lds2_t;
   auto vconst = [](double c) -> double { asm volatile("" : "+v"(c)); return c; };
-  const double kSHIFT = vconst(FMH_SP_SHIFT), k64 = vconst(64.0), kI64 = vconst(0.015625), kAMAX = vconst(-FMH_SPG_AMIN);
-  const double kE6 = vconst(FMH_SPG_E6), kE5 = vconst(FMH_SP_E5), kE4 = vconst(FMH_SP_E4), kE3 = vconst(FMH_SP_E3);
-  const double kL6 = vconst(FMH_SP_L6), kL5 = vconst(FMH_SP_L5), kL4 = vconst(FMH_SP_L4), kL3 = vconst(FMH_SP_L3);
   const unsigned int tabaddr = (unsigned int)__builtin_amdgcn_readfirstlane((int)a.tab);
   const unsigned int blast = 8u * (nn - 1u);
-  // Two operand sets used alternately (round 3, second series): an observation's columns and y are re-loaded for the observation TWO
-  // passes ahead the moment its eta is formed.  With one set the loads had ~125 instructions (~0.5 us with two waves on the SIMD)
-  // to come back from L2 before the next pass needed them, and the compiler kept the old y alive to the end of the pass, so
-  // every pass ended in s_waitcnt vmcnt(0) + a copy of the new y (`flip` is pinned where it is computed for that reason).  The
-  // intercepts sit in VGPRs: as SGPRs each cost a v_mov_b64 per observation (an fma takes one scalar operand).
   constexpr int PLX = PL > 0 ? PL : 1;
-  double xb0[PLX], xb1[PLX], yv0 = 0.0, yv1 = 0.0;
+  double xb0[PLX], xb1[PLX];
   double b0v[CW];
 #pragma unroll
   for (int c = 0; c < CW; c++) b0v[c] = vconst(b0[c]);
@@ -963,90 +924,65 @@ __device__ __attribute__((noinline)) void logit_partials(LogitEval a) {
     const unsigned int b = boff < blast ? boff : blast;
 #pragma unroll
     for (int u = 0; u < PL; u++) xb0[u] = ldg(colp[u], b);
-    yv0 = ldg(yp, b);
     boff += 8u * NT;
     const unsigned int b1 = boff < blast ? boff : blast;
 #pragma unroll
     for (int u = 0; u < PL; u++) xb1[u] = ldg(colp[u], b1);
-    yv1 = ldg(yp, b1);
   }
-  auto one_observation = [&](double (&xb)[PLX], double& yv) {
-    double eta[CW];
+  auto one_observation = [&](double (&xb)[PLX], auto checked) {
+    constexpr bool CHECKED = decltype(checked)::value;
+    double es[CW];
 #pragma unroll
-    for (int c = 0; c < CW; c++) eta[c] = b0v[c];
+    for (int c = 0; c < CW; c++) es[c] = b0v[c];
 #pragma unroll
     for (int u = 0; u < PL; u++) {
 #pragma unroll
-      for (int c = 0; c < CW; c++) eta[c] = fmh_fma(xb[u], bs[c][u], eta[c]);
+      for (int c = 0; c < CW; c++) es[c] = fmh_fma(xb[u], bs[c][u], es[c]);
     }
-    unsigned int flip = (yv != 0.0) ? 0u : 0x80000000u;           // sg = y ? eta : -eta, on the sign bit
-    asm volatile("" : "+v"(flip));                                // (here, so that the reload below can land in y's own register)
     boff += 8u * NT;
     {
       const unsigned int b = boff < blast ? boff : blast;         // clamped: the last prefetches re-read the last observation
 #pragma unroll
       for (int u = 0; u < PL; u++) xb[u] = ldg(colp[u], b);
-      yv = ldg(yp, b);
     }
-    bool slow = false;
-    double r[CW], sh[CW], sl[CW], sg[CW], q[CW], w[CW], pp[CW], out[CW];
-#pragma unroll
-    for (int c = 0; c < CW; c++) slow = slow || !(__builtin_fabs(eta[c]) <= kAMAX);
+    double sv[CW];
+    lg_v2d p0[CW], p1[CW], p2[CW];
 #pragma unroll
     for (int c = 0; c < CW; c++) {
-      const double ae = __builtin_fabs(eta[c]);
-      const double t = fmh_fma(ae, k64, kSHIFT);
-      const double kd = t - kSHIFT;
-      const unsigned int j = (unsigned int)fmh_d2u(t);
-      r[c] = fmh_fma(kd, kI64, -ae);
-      const ldsb_t row = (ldsb_t)(unsigned long long)(tabaddr + 8u * j);   // (a slow element may index anything: an LDS read cannot fault)
-      sh[c] = *(ldsc_t)(row);
-      sl[c] = *(ldsc_t)(row + 8 * FMH_SPG_ROWS);
-      sg[c] = *(ldsc_t)(row + 16 * FMH_SPG_ROWS);
-    }
-#pragma unroll
-    for (int c = 0; c < CW; c++) q[c] = fmh_fma(r[c], kE6, kE5);
-#pragma unroll
-    for (int c = 0; c < CW; c++) q[c] = fmh_fma(r[c], q[c], kE4);
-#pragma unroll
-    for (int c = 0; c < CW; c++) q[c] = fmh_fma(r[c], q[c], kE3);
-#pragma unroll
-    for (int c = 0; c < CW; c++) q[c] = fmh_fma(r[c], q[c], FMH_SP_E2);
-#pragma unroll
-    for (int c = 0; c < CW; c++) w[c] = sg[c] * fmh_fma(r[c] * r[c], q[c], r[c]);
-#pragma unroll
-    for (int c = 0; c < CW; c++) pp[c] = fmh_fma(w[c], kL6, kL5);
-#pragma unroll
-    for (int c = 0; c < CW; c++) pp[c] = fmh_fma(w[c], pp[c], kL4);
-#pragma unroll
-    for (int c = 0; c < CW; c++) pp[c] = fmh_fma(w[c], pp[c], kL3);
-#pragma unroll
-    for (int c = 0; c < CW; c++) pp[c] = fmh_fma(w[c], pp[c], FMH_SP_L2);
-#pragma unroll
-    for (int c = 0; c < CW; c++) out[c] = sh[c] + (sl[c] + fmh_fma(w[c] * w[c], pp[c], w[c]));
-    if (__builtin_expect(slow, 0)) {   // |eta| beyond 37.5, NaN: the general functions, as in the scalar routine
-#pragma unroll
-      for (int c = 0; c < CW; c++) out[c] = fmh_log1p_exp_nonpos(-__builtin_fabs(eta[c]));
+      const double ue = __builtin_fabs(es[c]);
+      sv[c] = __builtin_amdgcn_fract(ue);
+      unsigned int j = (unsigned int)ue;
+      if (CHECKED) j = (j < (unsigned)FMH_LG_ROWS) ? j : (unsigned)(FMH_LG_ROWS - 1);
+      const ldsb_t row = (ldsb_t)(unsigned long long)(tabaddr + 16u * j);
+      p0[c] = *(lds2_t)(row);
+      p1[c] = *(lds2_t)(row + 16 * LG_STRIDE);
+      p2[c] = *(lds2_t)(row + 32 * LG_STRIDE);
     }
 #pragma unroll
     for (int c = 0; c < CW; c++) {
-      const unsigned long long eb = fmh_d2u(eta[c]);
-      const double sgn = fmh_u2d((eb & 0xffffffffull) | ((unsigned long long)((unsigned int)(eb >> 32) ^ flip) << 32));
-      double mn;
-      asm("v_min_f64 %0, %1, 0" : "=v"(mn) : "v"(sgn));          // == (sg < 0) ? sg : 0 (NaN: 0; its out[] is NaN anyway)
-      acc[c] = acc[c] + (mn - out[c]);
+      double q = fmh_fma(sv[c], p2[c].y, p2[c].x);
+      q = fmh_fma(sv[c], q, p1[c].y);
+      q = fmh_fma(sv[c], q, p1[c].x);
+      q = fmh_fma(sv[c], q, p0[c].y);
+      q = fmh_fma(sv[c], q, p0[c].x);
+      if (CHECKED) { const double ue = __builtin_fabs(es[c]); q = (ue < (double)FMH_LG_ROWS) ? q : ue * FMH_LG_HALF_INV_SCALE; }
+      acc[c] = acc[c] + q;
     }
   };
   const unsigned int T = (nn + NT - 1u) / NT;        // uniform
   const bool last_valid = (unsigned int)tid + NT * (T - 1u) < nn;
-  unsigned int it = 0;
-  for (; it + 2u < T; it += 2u) { one_observation(xb0, yv0); one_observation(xb1, yv1); }
-  if (T - it == 2u) {
-    one_observation(xb0, yv0);
-    if (last_valid) one_observation(xb1, yv1);
-  } else if (T - it == 1u) {
-    if (last_valid) one_observation(xb0, yv0);
-  }
+  auto all_observations = [&](auto checked) {
+    unsigned int it = 0;
+    for (; it + 2u < T; it += 2u) { one_observation(xb0, checked); one_observation(xb1, checked); }
+    if (T - it == 2u) {
+      one_observation(xb0, checked);
+      if (last_valid) one_observation(xb1, checked);
+    } else if (T - it == 1u) {
+      if (last_valid) one_observation(xb0, checked);
+    }
+  };
+  if (fast) all_observations(std::false_type{});
+  else all_observations(std::true_type{});
   const ldsw_t s_part = (ldsw_t)(unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)a.part);
 #pragma unroll
   for (int c = 0; c < CW; c++) {
@@ -1064,9 +1000,8 @@ __device__ __attribute__((noinline)) void logit_partials_any(LogitEval a) {
   const int ic = __builtin_amdgcn_readfirstlane(a.ic), p = __builtin_amdgcn_readfirstlane(a.p);
   const long long n = (long long)rfl_u64((unsigned long long)a.n);
   const double* X = (const double*)rfl_u64((unsigned long long)a.X);
-  const double* y = (const double*)rfl_u64((unsigned long long)a.y);
-  const double* s_sptab = LDSTAB ? (const double*)(ldsc_t)(unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)a.tab) : nullptr;
-  ldsc_t th[CW];
+  const double* s_tab = LDSTAB ? (const double*)(ldsc_t)(unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)a.tab) : nullptr;
+  ldsc_t th[CW];                       // the SCALED coefficient vectors (64 b)
 #pragma unroll
   for (int c = 0; c < CW; c++) th[c] = (ldsc_t)(unsigned long long)logit_th_addr(a, c);
   double acc[CW];
@@ -1074,39 +1009,35 @@ __device__ __attribute__((noinline)) void logit_partials_any(LogitEval a) {
   for (int c = 0; c < CW; c++) acc[c] = 0.0;
   // The data comes from L2 (~1 us under load) and only two waves share a SIMD: a load-use chain per column made this
   // loop latency-bound (6 dependent round trips per observation).  All columns of an observation are fetched as one
-  // batch, and the batch of the NEXT observation is in flight while exp / log1p of the current one run.
+  // batch, and the batch of the NEXT observation is in flight while the terms of the current one are formed.
   constexpr int JB = 8;
   if (p <= JB) {
-    double xb[JB], yv = 0.0;
+    double xb[JB];
     long long i = tid;
     if (i < n) {
 #pragma unroll
       for (int u = 0; u < JB; u++) xb[u] = (u < p) ? X[(long long)u * n + i] : 0.0;
-      yv = y[i];
     }
     for (; i < n; i += NT) {
-      double eta[CW];
+      double es[CW];
 #pragma unroll
-      for (int c = 0; c < CW; c++) eta[c] = ic ? th[c][0] : 0.0;
+      for (int c = 0; c < CW; c++) es[c] = ic ? th[c][0] : 0.0;
 #pragma unroll
       for (int u = 0; u < JB; u++)
         if (u < p) {
 #pragma unroll
-          for (int c = 0; c < CW; c++) eta[c] = fmh_fma(xb[u], th[c][ic + u], eta[c]);
+          for (int c = 0; c < CW; c++) es[c] = fmh_fma(xb[u], th[c][ic + u], es[c]);
         }
-      const bool y1 = (yv != 0.0);
       const long long inx = (i + NT < n) ? i + NT : i;   // clamped: the last prefetch re-reads this observation
 #pragma unroll
       for (int u = 0; u < JB; u++) xb[u] = (u < p) ? X[(long long)u * n + inx] : 0.0;
-      yv = y[inx];
-      logit_add_terms<CW, LDSTAB>(eta, y1, acc, s_sptab);
+      logit_add_terms<CW, LDSTAB>(es, acc, s_tab);
     }
   } else {
     for (long long i = tid; i < n; i += NT) {
-      double eta[CW];
+      double es[CW];
 #pragma unroll
-      for (int c = 0; c < CW; c++) eta[c] = ic ? th[c][0] : 0.0;
-      const bool y1 = (y[i] != 0.0);
+      for (int c = 0; c < CW; c++) es[c] = ic ? th[c][0] : 0.0;
       int j = 0;
       for (; j + JB <= p; j += JB) {
         double xb[JB];
@@ -1115,15 +1046,15 @@ __device__ __attribute__((noinline)) void logit_partials_any(LogitEval a) {
 #pragma unroll
         for (int u = 0; u < JB; u++) {
 #pragma unroll
-          for (int c = 0; c < CW; c++) eta[c] = fmh_fma(xb[u], th[c][ic + j + u], eta[c]);
+          for (int c = 0; c < CW; c++) es[c] = fmh_fma(xb[u], th[c][ic + j + u], es[c]);
         }
       }
       for (; j < p; j++) {
         const double x = X[(long long)j * n + i];
 #pragma unroll
-        for (int c = 0; c < CW; c++) eta[c] = fmh_fma(x, th[c][ic + j], eta[c]);
+        for (int c = 0; c < CW; c++) es[c] = fmh_fma(x, th[c][ic + j], es[c]);
       }
-      logit_add_terms<CW, LDSTAB>(eta, y1, acc, s_sptab);
+      logit_add_terms<CW, LDSTAB>(es, acc, s_tab);
     }
   }
   const ldsw_t s_part = (ldsw_t)(unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)a.part);
@@ -1134,14 +1065,185 @@ __device__ __attribute__((noinline)) void logit_partials_any(LogitEval a) {
   }
 }
 
+// ---- observation-sharded logistic evaluation (config C5; the decomposition of the wide linear models above) ---------------
+// Chain-sharded, every workgroup streams the whole data set from L2 once per step (4 MB at C5: the per-CU L2 rate alone is
+// ~62 us per step, tools/probe_logit_grid.hip) and its lanes -- observations -- scatter over the g table (~2.9-way bank
+// conflicts on every lookup).  Here workgroup b of 256 owns the canonical lanes 2b, 2b + 1 for ALL chains: a constant slice of
+// 2 x ceil(n / 512) observations whose covariates arrive as SCALAR operands (s_load from a compact copy, logit_build_slices),
+// thread = chain (NCH chains per thread side by side), the chain's scaled coefficients in its lane's VGPRs.  The lanes of a
+// wave then look up g for the SAME observation and neighbouring chains: equal or neighbouring rows, no conflicts once the
+// chains have found the posterior.  Per observation and chain: 5 + 2 + 1 + 5 + 1 vector instructions and three ds_read_b128
+// (every instruction of any kind costs a SIMD ~4.5 cycles at two waves: tools/probe_dp_ops.hip), against 39 in the round-3 loop.
+// A pass = one slot = the two observations of the slice's two canonical lanes; the loop is software-pipelined BY HAND: a pass
+// issues the lookups of pass p + 1 (one burst of ds_read_b128) and then runs the polynomials of pass p, whose coefficients
+// were read a pass ago, so the LDS round trip hides under a pass of arithmetic.  ONE wait per pass, at its top: lgkmcnt(0) --
+// scalar loads share the counter with LDS reads and return out of order, a counted wait is not available -- and the scalar
+// loads of pass p + 2 go out right behind it (tools/probe_logit_shard.hip: 98 us per evaluation left to the compiler's
+// schedule, 76 with the phases fenced, 70 pipelined).
+struct LogitShard {
+  const double* xs;      // this workgroup's slice [nslots][2][PL] (0 beyond n)
+  const double* th;      // [k][ncp] proposals of all chains (unscaled)
+  double* part;          // [NC][NT + SH_PAD] lane partials
+  const double* hs;      // logit_hs_kernel's block: [ic + p] sums, [p] largest |x| per column
+  unsigned tab;          // LDS address of the table
+  int NC, ncp, ic, lane0;
+  int nv0, nv1;          // slots of canonical lane lane0 / lane0 + 1 that hold an observation (nv1 <= nv0 <= nslots)
+  int pad_;
+};
+static_assert(sizeof(LogitShard) == 64, "LogitShard must stay at 16 dwords");
+template <int PL, int NCH>
+__device__ __attribute__((noinline)) void logit_shard(LogitShard c) {
+  typedef const double __attribute__((address_space(4))) * cptr_t;
+  typedef __attribute__((address_space(3))) const char* ldsb_t;
+  typedef __attribute__((address_space(3))) const lg_v2d* lds2_t;
+  const int tid = threadIdx.x;
+  const int NC = rfl_i(c.NC), NCP = rfl_i(c.ncp), ic = rfl_i(c.ic), lane0 = rfl_i(c.lane0), nv0 = rfl_i(c.nv0), nv1 = rfl_i(c.nv1);
+  const unsigned tabaddr = (unsigned)rfl_i((int)c.tab);
+  const cptr_t slice = (cptr_t)rfl_u64((unsigned long long)c.xs);
+  const double* thg = (const double*)rfl_u64((unsigned long long)c.th);
+  const double* hs = (const double*)rfl_u64((unsigned long long)c.hs);
+  double* part = (double*)rfl_u64((unsigned long long)c.part);
+  double cmax[PL];
+#pragma unroll
+  for (int u = 0; u < PL; u++) cmax[u] = sgpr_d(hs[ic + PL + u]);
+  const int npass = nv1 < nv0 ? nv1 : nv0;       // slots in which BOTH lanes hold an observation
+  for (int cb = 0; cb < NC; cb += NT * NCH) {
+    double b0[NCH], bs[NCH][PL], a0[NCH], a1[NCH];
+    bool fast = true;
+#pragma unroll
+    for (int h = 0; h < NCH; h++) {
+      const int chain = cb + h * NT + tid;
+      const unsigned int chc = (unsigned int)(chain < NC ? chain : 0);
+      b0[h] = ic ? sh_load(thg + chc) * FMH_LG_SCALE : 0.0;
+      double B = __builtin_fabs(b0[h]);
+#pragma unroll
+      for (int u = 0; u < PL; u++) {
+        bs[h][u] = sh_load(thg + ((unsigned int)((ic + u) * NCP) + chc)) * FMH_LG_SCALE;
+        B = fmh_fma(__builtin_fabs(bs[h][u]), cmax[u], B);
+      }
+      fast = fast && (B < (double)(FMH_LG_ROWS - 1));   // no observation of this chain leaves the table (NaN: checked form)
+      a0[h] = 0.0; a1[h] = 0.0;
+    }
+    fast = __builtin_amdgcn_ballot_w64(!fast) == 0ull;
+    // one observation (pass, q) for chain slot h, every element checked: the tail slot and the waves with a chain off the table
+    auto checked_term = [&](int pass, int q, int h) -> double {
+      double es = b0[h];
+#pragma unroll
+      for (int u = 0; u < PL; u++) es = fmh_fma(slice[(pass * 2 + q) * PL + u], bs[h][u], es);
+      const double us1[1] = {__builtin_fabs(es)};
+      double g1[1];
+      logit_g_vec<1, true>(us1, g1, (const double*)(__attribute__((address_space(3))) const double*)(unsigned long long)tabaddr);
+      return g1[0];
+    };
+    if (fast && npass > 0) {
+      double xa[2][PL], xb[2][PL], sva[2][NCH], svb[2][NCH];
+      lg_v2d pra[2][NCH][3], prb[2][NCH][3];
+      auto sload = [&](double (&x)[2][PL], int pass) {
+        const int pc = pass < npass ? pass : npass - 1;      // (beyond the end: a repeat that is not accumulated)
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+          for (int u = 0; u < PL; u++) x[q][u] = slice[(pc * 2 + q) * PL + u];
+      };
+      auto front = [&](const double (&x)[2][PL], double (&sv)[2][NCH], lg_v2d (&pr)[2][NCH][3]) {   // 64 eta, reduction, lookups
+        unsigned ad[2][NCH];
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+          for (int h = 0; h < NCH; h++) {
+            double es = b0[h];
+#pragma unroll
+            for (int u = 0; u < PL; u++) es = fmh_fma(x[q][u], bs[h][u], es);
+            const double ue = __builtin_fabs(es);
+            sv[q][h] = __builtin_amdgcn_fract(ue);
+            ad[q][h] = tabaddr + 16u * (unsigned)ue;
+          }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+          for (int h = 0; h < NCH; h++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) pr[q][h][k] = *(lds2_t)((ldsb_t)(unsigned long long)ad[q][h] + 16 * LG_STRIDE * k);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      auto back = [&](const double (&sv)[2][NCH], const lg_v2d (&pr)[2][NCH][3]) {                     // polynomials
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+          for (int h = 0; h < NCH; h++) {
+            double v = fmh_fma(sv[q][h], pr[q][h][2].y, pr[q][h][2].x);
+            v = fmh_fma(sv[q][h], v, pr[q][h][1].y);
+            v = fmh_fma(sv[q][h], v, pr[q][h][1].x);
+            v = fmh_fma(sv[q][h], v, pr[q][h][0].y);
+            v = fmh_fma(sv[q][h], v, pr[q][h][0].x);
+            if (q) a1[h] = a1[h] + v; else a0[h] = a0[h] + v;
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      sload(xa, 0);
+      sload(xb, 1);
+      front(xa, sva, pra);                        // pass 0's lookups in flight
+      for (int ps = 0; ps < npass; ps += 2) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0): pass ps's coefficients, pass ps + 1's covariates
+        sload(xa, ps + 2);
+        front(xb, svb, prb);                      // pass ps + 1
+        back(sva, pra);                           // pass ps
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        sload(xb, ps + 3);
+        front(xa, sva, pra);                      // pass ps + 2
+        if (ps + 1 < npass) back(svb, prb);       // pass ps + 1
+      }
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+    } else {
+      for (int ps = 0; ps < npass; ps++) {
+#pragma unroll
+        for (int h = 0; h < NCH; h++) { a0[h] = a0[h] + checked_term(ps, 0, h); a1[h] = a1[h] + checked_term(ps, 1, h); }
+      }
+    }
+    for (int ps = npass; ps < nv0; ps++) {        // the last slot where only the lower lane holds an observation
+#pragma unroll
+      for (int h = 0; h < NCH; h++) a0[h] = a0[h] + checked_term(ps, 0, h);
+    }
+#pragma unroll
+    for (int h = 0; h < NCH; h++) {
+      const int chain = cb + h * NT + tid;
+      if (chain < NC) sh_store2(&part[(long long)chain * (NT + SH_PAD) + lane0], a0[h], a1[h]);
+    }
+  }
+}
+
+template <int LPW>
+__device__ __forceinline__ void eval_sharded_logit_step(const SweepArgs& A, const double* s_tab) {
+  static_assert(LPW == 2, "the observation-sharded logistic evaluation is written for 256 workgroups of two canonical lanes");
+  typedef __attribute__((address_space(3))) const double* ldsc_t;
+  LogitShard ls;
+  const int nslots = A.sh_nslots, lane0 = (int)blockIdx.x * LPW;
+  ls.xs = A.sh_xs + (long long)blockIdx.x * nslots * 2 * A.p;
+  ls.th = A.sh_th; ls.part = A.sh_part; ls.hs = A.lg_hs;
+  ls.tab = (unsigned)(unsigned long long)(ldsc_t)s_tab;
+  ls.NC = (int)A.nchains; ls.ncp = (int)A.nchains + SH_PAD; ls.ic = A.intercept; ls.lane0 = lane0;
+  // slots of lane l that hold an observation: i = 512 slot + l < n
+  auto nvalid = [&](int l) -> int { const long long v = (A.n - l + NT - 1) / NT; return (int)(v < 0 ? 0 : (v > nslots ? nslots : v)); };
+  ls.nv0 = nvalid(lane0); ls.nv1 = nvalid(lane0 + 1); ls.pad_ = 0;
+  const bool two = A.nchains > NT;     // (uniform) more than 512 chains in the launch: two chains per thread side by side
+  switch (A.p) {
+#define LG_CASE(P_) case P_: if (two) logit_shard<P_, 2>(ls); else logit_shard<P_, 1>(ls); break;
+    LG_CASE(1) LG_CASE(2) LG_CASE(3) LG_CASE(4) LG_CASE(5) LG_CASE(6) LG_CASE(7) LG_CASE(8)
+#undef LG_CASE
+    default: break;                    // (the host takes this form for 1 <= p <= 8 only)
+  }
+}
+
 // ---- workgroup-collective log-posterior partial sums (streamed variant) ------------------
 // Every thread accumulates its canonical lane for all CW chains, then the wavefront butterfly
 // (levels 1..32) runs and lane 0 of each wavefront publishes its partial to s_part[w][c].
 // FAM > 0 compiles one family in (leaner kernels for the logistic model), FAM == 0 keeps all behind A.family.
 template <int CW, int FAM = 0, int SHL = 0 /* > 0: observation-sharded evaluation, SHL canonical lanes per workgroup */>
 __device__ __forceinline__ void eval_partials(const SweepArgs& A, double* const* th /*[CW] -> theta in LDS*/,
-                                              double* s_part, const double* s_sptab = nullptr /* LDS: softplus tables (logistic) / MFMA slice block (sharded linreg) */,
-                                              unsigned* sh_epoch = nullptr /* barrier epoch of the sharded evaluation */, Stamps* stp = nullptr) {
+                                              double* s_part, const double* s_sptab = nullptr /* LDS: g table (logistic) / MFMA slice block (sharded linreg) */,
+                                              unsigned* sh_epoch = nullptr /* barrier epoch of the sharded evaluation */, Stamps* stp = nullptr,
+                                              double* s_lgb = nullptr /* LDS [CW][k]: scaled coefficient copies (logistic) */) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long long n = A.n;
   const int family = FAM ? FAM : A.family;
@@ -1151,20 +1253,43 @@ __device__ __forceinline__ void eval_partials(const SweepArgs& A, double* const*
 #pragma unroll
   for (int c = 0; c < CW; c++) acc[c] = 0.0;
   if (family == FMCMC_FAM_LOGISTIC) {
+    typedef __attribute__((address_space(3))) const double* ldsc_t;
+    if constexpr (FAM == FMCMC_FAM_LOGISTIC && SHL > 0) {
+      // observation-sharded: this thread's canonical lane of the workgroup's chains comes back from the grid (eval_sharded),
+      // then the wave butterfly as everywhere
+      const bool ok = eval_sharded<CW, SHL, FMCMC_FAM_LOGISTIC>(A, th, acc, *sh_epoch, s_sptab, stp);
+      if (!ok && tid == 0 && (long long)blockIdx.x * CW < A.nchains) A.status[(long long)blockIdx.x * CW] = FMCMC_CHAIN_SYNC_TIMEOUT;
+#pragma unroll
+      for (int c = 0; c < CW; c++) {
+        const double v = wave_xor_sum(acc[c]);
+        if (lane == 0) s_part[wave * CW + c] = v;
+      }
+      return;
+    }
     // Real functions with their own register allocation (logit_partials / logit_partials_any above); they also run the wave
     // butterfly and publish s_part.  P known at compile time (the logistic-only instantiations, CW (P + 1) <= 28
     // coefficients in SGPRs): straight-line loop body; with a run-time p every `if (u < p)` was a basic block of its own.
-    typedef __attribute__((address_space(3))) const double* ldsc_t;
-    LogitEval le;
-    le.X = A.X; le.y = A.y; le.n = n; le.ic = ic; le.p = p;
-    le.th0 = (unsigned)(unsigned long long)(ldsc_t)th[0];
-    // (the caller's layout: th[c] = th[0] + c * stride for the chains the workgroup holds, th[0] again for empty slots)
-    le.thstride = 0u; le.ncw = 1u;
+    // The loops form 64 eta from SCALED coefficients (the table's argument, include/fmh_detmath.h): copies of the workgroup's
+    // coefficient vectors times 64 (exact), refreshed here for every evaluation.
+    const int nb = ic + p;
+    {
+      int nlive = 1;
 #pragma unroll
-    for (int c = 1; c < CW; c++) {
-      const unsigned d = (unsigned)((unsigned long long)(ldsc_t)th[c] - (unsigned long long)(ldsc_t)th[0]);
-      if (d != 0u) { le.thstride = d / (unsigned)c; le.ncw = (unsigned)c + 1u; }
+      for (int c = 1; c < CW; c++) if (th[c] != th[0]) nlive = c + 1;
+      lds_barrier();                                    // (the previous evaluation's readers are done with the copies)
+      for (int idx = tid; idx < nlive * nb; idx += NT) {
+        const int c = idx / nb, j = idx - c * nb;
+        s_lgb[c * A.k + j] = th[c][j] * FMH_LG_SCALE;
+      }
+      lds_barrier();
     }
+    LogitEval le;
+    le.X = A.X; le.hs = A.lg_hs; le.n = n; le.ic = ic; le.p = p;
+    le.th0 = (unsigned)(unsigned long long)(ldsc_t)s_lgb;
+    // (the caller's layout: th[c] = th[0] + c * stride for the chains the workgroup holds, th[0] again for empty slots)
+    le.thstride = (unsigned)(A.k * sizeof(double)); le.ncw = 1u;
+#pragma unroll
+    for (int c = 1; c < CW; c++) if (th[c] != th[0]) le.ncw = (unsigned)c + 1u;
     le.tab = (unsigned)(unsigned long long)(ldsc_t)s_sptab;
     le.part = (unsigned)(unsigned long long)(ldsc_t)s_part;
     constexpr int PMAX = (FAM == FMCMC_FAM_LOGISTIC) ? (28 / CW - 1 > 8 ? 8 : 28 / CW - 1) : -1;
@@ -1296,11 +1421,15 @@ __device__ __forceinline__ void eval_partials(const SweepArgs& A, double* const*
 
 // closed form of the family given the canonical total `tot`. Uniform over the wave.
 template <int FAM = 0>
-__device__ __forceinline__ double finish_logpost(const SweepArgs& A, const double* th, double tot) {
+__device__ __forceinline__ double finish_logpost(const SweepArgs& A, const double* th, double tot, const double* hs = nullptr /* LDS copy of A.lg_hs */) {
   double f;
   const int family = FAM ? FAM : A.family;
   if (family == FMCMC_FAM_LOGISTIC) {
-    f = tot;
+    // logl = sum_j b_j hs_j - sum_i g(|eta_i|) (include/fmh_detmath.h, fmh_logit_g; the oracle's logpost_canon)
+    double lin = 0.0;
+    if (!hs) hs = A.lg_hs;
+    for (int j = 0; j < A.intercept + A.p; j++) lin = fmh_fma(th[j], hs[j], lin);
+    f = lin - tot;
     if (A.prior_div != 0.0) {
       double ss = 0.0;
       const int nb = A.intercept + A.p;

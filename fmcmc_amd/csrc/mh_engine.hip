@@ -66,12 +66,56 @@ __global__ void detmath_kernel(int which, const double* x, double* out, long lon
     case 6: r = fmh_student_t(seed, (unsigned)(i & 0xffff), (unsigned)(i >> 16), (unsigned)(i % 7), v); break;
     case 7: r = fmh_sqrt(v); break;
     case 8: r = 1.0 / v; break;
-    case 9: r = fmh_log1p_exp_nonpos(v); break;   // the fused softplus tail of the logistic family
+    case 9: r = fmh_logit_g(v); break;   // g(|v|), the per-observation term of the logistic family
     case 10: r = fmh_unif(seed, (unsigned)(i & 0xffff), (unsigned)(i >> 16), (unsigned)(i % 7)); break;
     case 12: r = fmh_tan_0_halfpi(v); break;
     default: r = fmh_nan();
   }
   out[i] = r;
+}
+
+// Data-only sums of the canonical logistic form (include/fmh_detmath.h, fmh_logit_g; oracle: logit_hs): hs[0] = sum_i w_i when
+// the model has an intercept, hs[ic + j] = sum_i w_i x_ij, w_i = +1/2 (y_i != 0) or -1/2 -- every product exact, the sums over
+// the 512 canonical lanes in index order and their tree -- and behind them, for the range check of the fast loops, the largest
+// |x| of every column (a NaN stays).  One workgroup, once per launch: n (p + 1) additions.
+__global__ __launch_bounds__(NT) void logit_hs_kernel(const double* X, const double* y, long long n, int p, int ic, double* hs) {
+  __shared__ double s_w[NW], s_m[NW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int col = -ic; col < p; col++) {
+    double acc = 0.0, mx = 0.0;
+    for (long long i = tid; i < n; i += NT) {
+      const double w = (y[i] != 0.0) ? 0.5 : -0.5;
+      if (col < 0) { acc = acc + w; }
+      else {
+        const double x = X[(long long)col * n + i], ax = __builtin_fabs(x);
+        acc = acc + w * x;
+        mx = (ax > mx || ax != ax) ? ax : mx;
+      }
+    }
+    const double v = wave_xor_sum(acc);
+    for (int o = 32; o >= 1; o >>= 1) { const double t = __shfl_xor(mx, o, 64); mx = (t > mx || t != t) ? t : mx; }
+    if (lane == 0) { s_w[wave] = v; s_m[wave] = mx; }
+    __syncthreads();
+    if (tid == 0) {
+      hs[ic + col] = ((s_w[0] + s_w[1]) + (s_w[2] + s_w[3])) + ((s_w[4] + s_w[5]) + (s_w[6] + s_w[7]));
+      if (col >= 0) {
+        double m = s_m[0];
+        for (int q = 1; q < NW; q++) m = (s_m[q] > m || s_m[q] != s_m[q]) ? s_m[q] : m;
+        hs[ic + p + col] = m;
+      }
+    }
+    __syncthreads();
+  }
+}
+// per-workgroup slices for the observation-sharded logistic evaluation (mh_common.hpp, logit_shard): workgroup b owns the
+// canonical lanes 2 b, 2 b + 1; xs[((b nslots + slot) 2 + q) p + j] = x_ij of observation i = 512 slot + 2 b + q (0 beyond n)
+__global__ void logit_build_slices(const double* X, long long n, int p, int nslots, double* xs) {
+  const int b = blockIdx.x;
+  for (int idx = threadIdx.x; idx < nslots * 2 * p; idx += blockDim.x) {
+    const int o = idx / p, j = idx - o * p;
+    const long long i = (long long)NT * (o >> 1) + 2 * b + (o & 1);
+    xs[(long long)b * nslots * 2 * p + idx] = (i < n) ? X[(long long)j * n + i] : 0.0;
+  }
 }
 
 // compact per-workgroup slices of X and y for the observation-sharded evaluation (mh_common.hpp, eval_sharded):
@@ -142,7 +186,7 @@ __global__ void add_counts_kernel(long long* total, const long long* part, long 
 }
 
 size_t sweep_lds_bytes(int k, int kf, int kind, int CW, int tb, int kz, bool resident) {
-  size_t d = 4 * (size_t)k + (k / 2 + 1) + (size_t)NW * CW + 1 + (size_t)CW * tb * (kz + 1) +
+  size_t d = 5 * (size_t)k + (k / 2 + 1) + (size_t)NW * CW + 1 + (size_t)CW * tb * (kz + 1) + (size_t)CW * k +
              (resident ? (size_t)CW * NT : 0) + (size_t)CW * chain_lds_doubles(k, kf, kind);
   return d * sizeof(double);
 }
@@ -432,6 +476,16 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
   A.accept_count = (long long*)out->accept_count; A.accept_bits = out->accept_bits;
   A.status = out->status; A.status_step = (long long*)out->status_step; A.status_theta = out->status_theta;
 
+  // logistic family: the data-only sums of the linear part and the columns' largest |x| (logit_hs_kernel), once per launch
+  AsyncScratch hs_guard;
+  if (m->family == FMCMC_FAM_LOGISTIC) {
+    double* hs = nullptr;
+    hipError_t eh = hipMallocAsync((void**)&hs, sizeof(double) * (size_t)(2 * MAXK + 2), stream);
+    if (eh != hipSuccess) { set_err("hipMallocAsync(logistic sums) failed: %s", hipGetErrorString(eh)); return FMCMC_ERR_DEVICE; }
+    hs_guard.p = hs; hs_guard.s = stream;
+    hipLaunchKernelGGL(logit_hs_kernel, dim3(1), dim3(NT), 0, stream, m->X, m->y, (long long)m->n, m->p, m->intercept ? 1 : 0, hs);
+    A.lg_hs = hs;
+  }
   // ---- launch geometry
   int dev = 0, ncu = 256;
   (void)hipGetDevice(&dev);
@@ -712,8 +766,70 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
   else if (m->family == FMCMC_FAM_LOGISTIC && cw <= 4 && m->p <= 28 / cw - 1 &&
            (kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE)) {
     // logistic-only instantiations: the number of covariates is a compile-time constant of the evaluation loop and the
-    // coefficients of the CW chains live in SGPRs (mh_common.hpp); with the division-free softplus 2x the general kernel
+    // coefficients of the CW chains live in SGPRs (mh_common.hpp), the g table in LDS
     g_kernel = "streamed-logistic";
+    const bool refl = kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE;
+    lds += sizeof(double) * (LG_LDS_DOUBLES + 2);   // the table staged behind the chain blocks (16-byte aligned)
+    // Observation-sharded form (mh_common.hpp, logit_shard): 256 workgroups of two canonical lanes each evaluate ALL chains
+    // of the launch, up to 256 x cw of them; more chains run as consecutive launches.  Cost model (us per step, fitted at
+    // C5: n = 1e5, p = 5): chain-sharded ~ n cw 2.6e-4 (its lookups scatter over the table: LDS-bound), sharded ~ 15 of
+    // hand-overs + chains n 6.8e-7.  Knob shard=1 forces it for every eligible shape (tests), shard=0 disables it.
+    bool lshard = false;
+    const long long nb_launch = 256;
+    const long long ch_launch = (nblk > nb_launch) ? nb_launch * cw : (long long)run->nchains;
+    const int nslots = (int)((m->n + NT - 1) / NT);
+    if (K.shard != 0 && m->p >= 1 && m->p <= 8 && ncu == 256 && m->n >= 2 * NT && m->n < (1ll << 28)) {
+      const double est_chain = 2.6e-4 * (double)m->n * cw, est_shard = 15.0 + 6.8e-7 * (double)m->n * (double)ch_launch;
+      lshard = K.shard == 1 || est_shard < 0.9 * est_chain;
+    }
+    const void* kfn = nullptr;
+#define LSK(CWV) (refl ? (const void*)mh_sweep_kernel<CWV, -1, 2, 2, FMCMC_FAM_LOGISTIC, 1> : (const void*)mh_sweep_kernel<CWV, -1, 2, 1, FMCMC_FAM_LOGISTIC, 1>)
+    if (lshard) kfn = (cw == 1) ? LSK(1) : (cw == 2) ? LSK(2) : LSK(4);
+#undef LSK
+    if (lshard) {
+      int coop = 0, perCU = 0;
+      (void)hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev);
+      e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess || !coop ||
+          hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kfn, NT, lds) != hipSuccess || (long long)perCU * ncu < nb_launch) {
+        if (A.debug & 256) fprintf(stderr, "fmcmc_amd: sharded logistic evaluation not launched: err=%d coop=%d perCU=%d lds=%zu\n", (int)e, coop, perCU, lds);
+        lshard = false;
+      }
+      e = hipSuccess;
+    }
+    if (lshard) {
+      double* shw = nullptr;
+      const size_t nxs = (size_t)nb_launch * nslots * 2 * m->p, nth = ((size_t)kn->k * (ch_launch + SH_PAD) + 7) & ~(size_t)7,
+                   npt = (size_t)(NT + SH_PAD) * ch_launch, nbar = 32 * 20 / 2;
+      e = hipMallocAsync((void**)&shw, sizeof(double) * (nxs + nth + npt + nbar), stream);
+      if (e != hipSuccess) { set_err("hipMallocAsync(sharded evaluation) failed: %s", hipGetErrorString(e)); return FMCMC_ERR_DEVICE; }
+      shw_guard.p = shw; shw_guard.s = stream;
+      double* thw = shw; double* ptw = thw + nth; unsigned* bar = (unsigned*)(ptw + npt); double* xs = ptw + npt + nbar;
+      hipLaunchKernelGGL(logit_build_slices, dim3((unsigned)nb_launch), dim3(256), 0, stream, m->X, (long long)m->n, m->p, nslots, xs);
+      A.shard = 2; A.sh_nslots = nslots; A.sh_xs = xs; A.sh_ys = nullptr; A.sh_th = thw; A.sh_part = ptw; A.sh_bar = bar;
+      g_kernel = "logistic-sharded";
+      long long done = 0;
+      for (; done < run->nchains && e == hipSuccess; done += ch_launch) {   // (the slices and tables serve every launch)
+        SweepArgs W = chain_window(A, done, (run->nchains - done < ch_launch) ? run->nchains - done : ch_launch, kf);
+        (void)hipMemsetAsync(bar, 0, sizeof(double) * nbar, stream);
+        void* kargs[] = {(void*)&W};
+        e = hipLaunchCooperativeKernel(kfn, dim3((unsigned)nb_launch), dim3(NT), kargs, (unsigned int)lds, stream);
+      }
+      if (e != hipSuccess && done > ch_launch) {    // a LATER window failed: the chains of the earlier windows have run
+        set_err("HIP launch of chain window %lld failed (%s): the state of the first %lld chains is already advanced, the results of this call are invalid",
+                (long long)(done / ch_launch), hipGetErrorString(e), (long long)(done - ch_launch));
+        (void)hipGetLastError();
+        return FMCMC_ERR_DEVICE;
+      }
+      if (e != hipSuccess) {                         // the runtime refused the first cooperative launch: nothing ran
+        (void)hipGetLastError();
+        e = hipSuccess;
+        lshard = false;
+        g_kernel = "streamed-logistic";
+        A.shard = 0; A.sh_xs = nullptr; A.sh_th = nullptr; A.sh_part = nullptr; A.sh_bar = nullptr;
+      }
+    }
+    if (!lshard) {
 #define LAUNCH_LOGIT(CWV, KV, MB)                                                                                      \
     do {                                                                                                               \
       if (lds > 48 * 1024)                                                                                             \
@@ -722,16 +838,13 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
       if (e == hipSuccess)                                                                                             \
         hipLaunchKernelGGL((mh_sweep_kernel<CWV, -1, 0, KV, FMCMC_FAM_LOGISTIC, MB>), dim3((unsigned)nblk), dim3(NT), lds, stream, A); \
     } while (0)
-    const bool refl = kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE;
-    lds += sizeof(double) * (SP_LDS_DOUBLES + 1);   // the softplus tables staged behind the chain blocks
     switch (cw) {
       case 1: if (refl) LAUNCH_LOGIT(1, 2, 1); else LAUNCH_LOGIT(1, 1, 1); break;
-      // (measured at C5 with two chains per workgroup, 128 VGPRs and two workgroups per CU = 4 waves per SIMD: 5.0 cycles per
-      //  instruction instead of 6.3, but 27 % more instructions per chain: 5.99e6 against 6.26e6 samples/s; not taken)
       case 2: if (refl) LAUNCH_LOGIT(2, 2, 1); else LAUNCH_LOGIT(2, 1, 1); break;
       default: if (refl) LAUNCH_LOGIT(4, 2, 1); else LAUNCH_LOGIT(4, 1, 1); break;
     }
 #undef LAUNCH_LOGIT
+    }
   }
   else if (m->family == FMCMC_FAM_GAUSSIAN_LINREG && m->p >= 16 && cw <= 2 &&
            (kn->kind == FMCMC_KERNEL_RAM || kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE)) {

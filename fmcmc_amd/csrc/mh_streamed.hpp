@@ -144,13 +144,15 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
   double* s_scale = s_mu + k;
   double* s_lb = s_scale + k;
   double* s_ub = s_lb + k;
-  int* s_which = (int*)(s_ub + k);          // [k] ints (k/2+1 doubles)
-  double* s_part = s_ub + k + (k / 2 + 1);  // [NW*CW]
+  double* s_hs = s_ub + k;                  // [k] logistic: the data-only sums of the linear part (SweepArgs.lg_hs)
+  int* s_which = (int*)(s_hs + k);          // [k] ints (k/2+1 doubles)
+  double* s_part = s_hs + k + (k / 2 + 1);  // [NW*CW]
   int* s_flag = (int*)(s_part + NW * CW);   // [2] ints
   double* s_zt = s_part + NW * CW + 1;      // [CW][TB][kz] proposal variates of the tile
   double* s_lu = s_zt + CW * TB * kz;       // [CW][TB]     log accept uniforms of the tile
-  double* s_tr = s_lu + CW * TB;            // RESIDENT: [CW][NT] lane partials
-  double* s_chains = s_tr + (RESIDENT ? CW * NT : 0);   // [CW][CHS], then (logistic-only instantiations) the softplus tables
+  double* s_lgb = s_lu + CW * TB;           // [CW][k]      logistic: the coefficient vectors times 64 (eval_partials)
+  double* s_tr = s_lgb + CW * k;            // RESIDENT: [CW][NT] lane partials
+  double* s_chains = s_tr + (RESIDENT ? CW * NT : 0);   // [CW][CHS], then (logistic-only instantiations) the g table
 
   __shared__ int s_kf;
   if (tid == 0) {
@@ -165,6 +167,7 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
     s_scale[tid] = A.scale[tid];
     s_lb[tid] = A.lb[tid];
     s_ub[tid] = A.ub[tid];
+    s_hs[tid] = (A.family == FMCMC_FAM_LOGISTIC && A.lg_hs && tid < A.intercept + A.p) ? A.lg_hs[tid] : 0.0;
   }
   __syncthreads();
   const int kf = s_kf;
@@ -172,8 +175,8 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
   const int CHS = chain_lds_doubles(k, kf, A.kind);
   const double* s_sptab = nullptr;
   if constexpr (FAM == FMCMC_FAM_LOGISTIC) {
-    double* tabs = s_chains + CW * CHS + ((CW * CHS) & 1);    // 16-byte aligned rows
-    softplus_stage_tables(tabs);
+    double* tabs = logit_table_align(s_chains + CW * CHS);    // 16-byte aligned pairs
+    logit_stage_table(tabs);
     s_sptab = tabs;
   }
   if constexpr (FAM == FMCMC_FAM_GAUSSIAN_LINREG && P < 0 && OPT > 0) {
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
         if (lane == 0) s_part[h * CW + c] = v;
       }
     } else {
-      eval_partials<CW, FAM, (P < 0 ? OPT : 0)>(A, thp, s_part, s_sptab, &sh_epoch, stp);
+      eval_partials<CW, FAM, (P < 0 ? OPT : 0)>(A, thp, s_part, s_sptab, &sh_epoch, stp, s_lgb);
     }
   };
   auto total_of = [&](int c) -> double {
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
     }
   };
   if (owner) {
-    f0 = finish_logpost<FAM>(A, L.th1, total_of(myc));
+    f0 = finish_logpost<FAM>(A, L.th1, total_of(myc), s_hs);
     f1 = f0;
     if (lane < kf) L.vrs[lane] = L.th0[s_which[lane]];
     if (A.hist_rows > 0 && lane < kf) A.hist[((long long)cl * A.hist_rows + (1 % A.hist_rows)) * kf + lane] = L.th0[s_which[lane]];
@@ -611,7 +614,7 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
       bool changed = false;
       if (owner && status == FMCMC_CHAIN_OK) {
         if (ram_gate) {
-          double f1u = finish_logpost<FAM>(A, L.th1, total_of(myc));
+          double f1u = finish_logpost<FAM>(A, L.th1, total_of(myc), s_hs);
           f1_pre = f1u;
           have_f1 = !A.ram_bounded;
           double a_n = fmh_exp(f1u - f0);
@@ -672,7 +675,7 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
     FMH_STAMP(stp, 9);
     // ================= scalar phase C: accept / store (R/mcmc.R:754-778) =================
     if (owner && status == FMCMC_CHAIN_OK) {
-      f1 = have_f1 ? f1_pre : finish_logpost<FAM>(A, L.th1, total_of(myc));
+      f1 = have_f1 ? f1_pre : finish_logpost<FAM>(A, L.th1, total_of(myc), s_hs);
       FMH_STAMP(stp, 15);
       if (fmh_isnan(f1)) status = FMCMC_CHAIN_NAN_LOGPOST;
       const double ratio = f1 - f0;

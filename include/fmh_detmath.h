@@ -22,8 +22,8 @@
  *               degree-5 minimax c(r) = r - r^2 P(r^2).
  *   fmh_log1p : u = fl(1+x), c = exact rounding error of 1+x (Fast2Sum);
  *               log1p(x) = log(u) + c/u folded into the low-order sum of fmh_log's core.
- *   fmh_log1p_exp_nonpos : the softplus tail log1p(exp(a)), a <= 0, of the logistic family as ONE division-free routine
- *               (Taylor exp on the reduced argument, table-driven logarithm with 128 entries); described at the function.
+ *   fmh_logit_g : g(u) = log(2 cosh(u / 2)), the per-observation term of the logistic family, off a per-row polynomial
+ *               table (grid 1/64, degree 5); described at the function.
  *   fmh_qnorm : Wichura (1988) Algorithm AS 241, PPND16 — the routine behind R's qnorm()
  *               (R/kernel_normal.R:71 -> stats::rnorm -> norm_rand inversion), here with
  *               fma-Horner evaluation and fmh_log in the tails.
@@ -179,60 +179,39 @@ FMH_HD double fmh_exp(double x) {
   return y * fmh_u2d((uint64_t)(1023 + k) << 52);
 }
 
-/* log1p(exp(a)) for a <= 0 -- the softplus tail of the logistic log-likelihood (R: log1p(exp(x)), vignettes/
- * workflow-with-fmcmc.Rmd:37-38): the logistic model evaluates it n times per log-posterior, and the composition
- * fmh_log1p(fmh_exp(a)) costs three fp64 divisions (12 instructions each on gfx950) out of ~100 instructions.  The routine
- * is fmh_log1p_exp_nonpos below: softplus on a grid of spacing 1/64 with two degree-6 Taylor polynomials (round 2; the
- * round-1 routine -- a table-driven exp carried as a double-double into a table-driven logarithm, ~45 operations and two
- * lookups, 1.5 ulp -- is gone, its description with it).  The constants that follow are the polynomial coefficients. */
-/* coefficients of fmh_log1p_exp_nonpos (shared with the chain-vectorised device twin in mh_common.hpp) */
-#define FMH_SP_SHIFT 0x1.8p52                 /* adding it rounds to an integer and leaves that integer in the low mantissa bits */
-#define FMH_SP_E2 0x1.0000000000000p-1
-#define FMH_SP_E3 0x1.5555555555555p-3
-#define FMH_SP_E4 0x1.5555555555555p-5
-#define FMH_SP_E5 0x1.1111111111111p-7
-#define FMH_SP_L2 (-0x1.0000000000000p-1)
-#define FMH_SP_L3 0x1.5555555555555p-2
-#define FMH_SP_L4 (-0x1.0000000000000p-2)
-#define FMH_SP_L5 0x1.999999999999ap-3
-#define FMH_SP_L6 (-0x1.5555555555555p-3)
-
-/* The softplus tail on a grid (round 2).  For -37.5 <= a <= 0:  a = a_j + r,  a_j = -j/64 the nearest grid point (r exact,
- * |r| <= 2^-7), and
- *     log(1 + e^a) = softplus(a_j) + log1p(sigma_j expm1(r)),        sigma_j = 1 / (1 + e^-a_j),
- * since (1 + e^a_j e^r) / (1 + e^a_j) = 1 + sigma_j (e^r - 1).  softplus(a_j) (double-double) and sigma_j come from a table
- * of 2401 rows (include/fmh_softplus_tab.h, generated from 50-digit arithmetic); expm1 on |r| <= 2^-7 and log1p on
- * |w| <= 2^-8 are their Taylor polynomials of degree 6 (relative truncation 2^-54 and 2^-50.8 of a term that is at most
- * 2^-7 of the result).  19 dependent-free fma-class operations and ONE 32-byte table row per value instead of ~45 and two
- * lookups (table-driven exp carried as a double-double into a table-driven logarithm), and the result is within 0.6 ulp
- * instead of 1.5 (tests/test_detmath.py).  Below -37.5 (where log1p(e^a) is e^a to the last bit) and for NaN / positive
- * arguments the general functions answer. */
-#define FMH_SPG_AMIN (-37.5)
-#define FMH_SPG_E6 0x1.6c16c16c16c17p-10 /* 1/720 */
-FMH_HD const double* fmh_spg_tab_(void) {
-#include "fmh_softplus_tab.h"
-  return FMH_SPG_TAB_;
+/* The per-observation term of the logistic log-likelihood (round 4; replaces the softplus tail log1p(exp(-|eta|)) of rounds
+ * 1-3).  R evaluates, per observation, logp = -log1p(exp(-eta)) (y = 1) or logq = -eta - log1p(exp(-eta)) (y = 0), split at
+ * eta < 0 for stability (vignettes/workflow-with-fmcmc.Rmd:35-41).  Both are
+ *     (y - 1/2) eta - g(|eta|),      g(u) = log(2 cosh(u / 2)) = u / 2 + log1p(exp(-u)),
+ * so the log-likelihood is a dot product of the coefficients with the data-only sums  sum_i (y_i - 1/2) x_ij  MINUS
+ * sum_i g(|eta_i|): the sign of eta, y, the min(.., 0) and one of the two additions leave the observation loop.  g is even,
+ * smooth (nearest singularity at distance pi) and is read off a table: on the grid u_j = j / 64, j = 0..2399, ONE degree-5
+ * polynomial per row in the exact reduced argument s = 64 u - j in [0, 1) (include/fmh_logit_tab.h, generated from 60-digit
+ * arithmetic by tools/gen_logit_table.py).  The argument arrives ALREADY SCALED, us = 64 |eta| -- every caller forms eta with
+ * the coefficients multiplied by 64 (exact), which is the same fma chain bit for bit -- so a value costs 2 + 5 operations:
+ * s = fract(us), j = trunc(us), five fmas (v_fract_f64, v_cvt_u32_f64 and three 16-byte table reads on the device), against 19
+ * operations + the sign / min / add around them for the softplus form.  Worst case 1.01 ulp against a 60-digit reference
+ * (rounding of c0 + the last fma; tests/test_detmath.py); the composition of two libm calls R evaluates reaches 1.5.
+ * For us >= 2400 (|eta| >= 37.5) g(u) = u / 2 to 0.02 ulp; NaN propagates. */
+#define FMH_LG_SCALE 64.0
+#define FMH_LG_HALF_INV_SCALE 0.0078125 /* 0.5 / 64 */
+FMH_HD const double* fmh_lg_tab_(void) {
+#include "fmh_logit_tab.h"
+  return FMH_LG_TAB_;
 }
-FMH_HD double fmh_log1p_exp_nonpos(double a) {
-  if (!(a <= 0.0) || a < FMH_SPG_AMIN) return fmh_log1p(fmh_exp(a));
-  const double t = fmh_fma(a, 64.0, FMH_K(FMH_SP_SHIFT));      /* the low mantissa bits hold round(64 a) <= 0 */
-  const double kd = t - FMH_K(FMH_SP_SHIFT);
-  const int32_t j = -(int32_t)(uint32_t)fmh_d2u(t);
-  const double r = fmh_fma(kd, -0.015625, a);                   /* a - a_j, exact */
-  const double* T = fmh_spg_tab_() + 4 * j;
-  double q = fmh_fma(r, FMH_K(FMH_SPG_E6), FMH_K(FMH_SP_E5));
-  q = fmh_fma(r, q, FMH_K(FMH_SP_E4));
-  q = fmh_fma(r, q, FMH_K(FMH_SP_E3));
-  q = fmh_fma(r, q, FMH_K(FMH_SP_E2));
-  const double em1 = fmh_fma(r * r, q, r);                      /* expm1(r) */
-  const double w = T[2] * em1;
-  double p = fmh_fma(w, FMH_K(FMH_SP_L6), FMH_K(FMH_SP_L5));
-  p = fmh_fma(w, p, FMH_K(FMH_SP_L4));
-  p = fmh_fma(w, p, FMH_K(FMH_SP_L3));
-  p = fmh_fma(w, p, FMH_K(FMH_SP_L2));
-  const double lp = fmh_fma(w * w, p, w);                       /* log1p(w) */
-  return T[0] + (T[1] + lp);
+FMH_HD double fmh_logit_g_scaled(double us) { /* us = 64 |eta| >= 0 (or NaN) */
+  if (!(us < (double)FMH_LG_ROWS)) return (us != us) ? us : us * FMH_LG_HALF_INV_SCALE;
+  const double fl = __builtin_floor(us);
+  const double s = us - fl;                                     /* exact; the device's v_fract_f64 */
+  const double* T = fmh_lg_tab_() + 6 * (int)fl;
+  double q = fmh_fma(s, T[5], T[4]);
+  q = fmh_fma(s, q, T[3]);
+  q = fmh_fma(s, q, T[2]);
+  q = fmh_fma(s, q, T[1]);
+  return fmh_fma(s, q, T[0]);
 }
+/* g(|eta|) from an unscaled eta (tests, diagnostics) */
+FMH_HD double fmh_logit_g(double eta) { return fmh_logit_g_scaled(fmh_abs(eta) * FMH_LG_SCALE); }
 
 
 /* tan(x) for 0 <= x <= fl(pi/2): the only use is the one-off scale adaptation of the mirror kernels,

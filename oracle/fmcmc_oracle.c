@@ -60,6 +60,7 @@ typedef struct {
   int rng_mode, math_mode;
   r_rng* g;
   uint64_t seed;
+  const double* lg_hs; /* canonical logistic: the data-only sums of logit_hs(), or NULL (then logpost_canon forms them) */
 } ocfg;
 
 /* ------------------------------------------------------------------------------------------
@@ -159,7 +160,24 @@ static double logpost_R(const fmcmc_model* m, const double* th) {
   return NAN;
 }
 
-static double logpost_canon(const fmcmc_model* m, const double* th) {
+/* canonical logistic: hs[0] = sum_i w_i (intercept), hs[ic + j] = sum_i w_i x_ij with w_i = +1/2 (y_i != 0) or -1/2: every
+ * product is exact, the sums run over the 512 canonical lanes in index order and their tree (the device: logit_hs_kernel) */
+static void logit_hs(const fmcmc_model* m, double* hs) {
+  const int64_t n = m->n;
+  const int p = m->p, ic = m->intercept ? 1 : 0;
+  double acc[ORACLE_LANES];
+  for (int j = -ic; j < p; j++) {
+    for (int l = 0; l < ORACLE_LANES; l++) acc[l] = 0.0;
+    for (int64_t i = 0; i < n; i++) {
+      const double w = (m->y[i] != 0.0) ? 0.5 : -0.5;
+      const int l = (int)(i & (ORACLE_LANES - 1));
+      acc[l] = acc[l] + (j < 0 ? w : w * m->X[(int64_t)j * n + i]);
+    }
+    hs[ic + j] = tree512(acc);
+  }
+}
+
+static double logpost_canon(const fmcmc_model* m, const double* th, const double* hs) {
   const int64_t n = m->n;
   const int p = m->p, ic = m->intercept ? 1 : 0;
   double acc[ORACLE_LANES];
@@ -190,17 +208,21 @@ static double logpost_canon(const fmcmc_model* m, const double* th) {
     return f;
   }
   if (m->family == FMCMC_FAM_LOGISTIC) {
+    /* canonical form (include/fmh_detmath.h, fmh_logit_g): logl = sum_j b_j hs_j - sum_i g(|eta_i|), with eta formed from
+     * the coefficients scaled by 64 (exact) so that the table's reduced argument falls out of it */
+    double hs_own[MAXK], bsc[MAXK];
+    if (!hs) { logit_hs(m, hs_own); hs = hs_own; }
+    for (int j = 0; j < ic + p; j++) bsc[j] = th[j] * FMH_LG_SCALE;
     for (int64_t i = 0; i < n; i++) {
-      double eta = ic ? th[0] : 0.0;
-      for (int j = 0; j < p; j++) eta = fmh_fma(m->X[(int64_t)j * n + i], th[ic + j], eta);
-      double s = (m->y[i] != 0.0) ? eta : -eta; /* logq(eta) == logp(-eta) exactly */
-      double a = (s < 0.0) ? s : -s;            /* -|s| */
-      double l1 = fmh_log1p_exp_nonpos(a);   /* the canonical softplus tail (include/fmh_detmath.h) */
-      double term = (s < 0.0) ? (s - l1) : (-l1);
+      double es = ic ? bsc[0] : 0.0;
+      for (int j = 0; j < p; j++) es = fmh_fma(m->X[(int64_t)j * n + i], bsc[ic + j], es);
       int l = (int)(i & (ORACLE_LANES - 1));
-      acc[l] = acc[l] + term;
+      acc[l] = acc[l] + fmh_logit_g_scaled(fmh_abs(es));
     }
-    double ll = tree512(acc);
+    double gs = tree512(acc);
+    double lin = 0.0;
+    for (int j = 0; j < ic + p; j++) lin = fmh_fma(th[j], hs[j], lin);
+    double ll = lin - gs;
     if (m->prior_div != 0.0) {
       double ss = 0.0;
       for (int j = 0; j < ic + p; j++) ss = fmh_fma(th[j], th[j], ss);
@@ -213,12 +235,12 @@ static double logpost_canon(const fmcmc_model* m, const double* th) {
 }
 
 static double logpost(const ocfg* cfg, const fmcmc_model* m, const double* th) {
-  return cfg->math_mode == ORACLE_MATH_R ? logpost_R(m, th) : logpost_canon(m, th);
+  return cfg->math_mode == ORACLE_MATH_R ? logpost_R(m, th) : logpost_canon(m, th, cfg->lg_hs);
 }
 
 /* exported for tests */
 double fmcmc_oracle_logpost(const fmcmc_model* m, const double* theta, int math_mode) {
-  ocfg c; c.rng_mode = 0; c.math_mode = math_mode; c.g = NULL; c.seed = 0;
+  ocfg c; c.rng_mode = 0; c.math_mode = math_mode; c.g = NULL; c.seed = 0; c.lg_hs = NULL;
   return logpost(&c, m, theta);
 }
 
@@ -789,7 +811,9 @@ int fmcmc_oracle_run(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_r
   const int simple = (kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE ||
                       kn->kind == FMCMC_KERNEL_UNIF || kn->kind == FMCMC_KERNEL_UNIF_REFLECTIVE || mirror);
   if (simple && kn->scheme == FMCMC_SCHEME_EXPLICIT && (!kn->scheme_seq || kn->scheme_len < 1)) return FMCMC_ERR_ARG;
-  ocfg cfg; cfg.rng_mode = rng_mode; cfg.math_mode = math_mode; cfg.g = g; cfg.seed = run->seed;
+  ocfg cfg; cfg.rng_mode = rng_mode; cfg.math_mode = math_mode; cfg.g = g; cfg.seed = run->seed; cfg.lg_hs = NULL;
+  double lg_hs[MAXK];   /* data-only sums of the canonical logistic form: once per run */
+  if (m->family == FMCMC_FAM_LOGISTIC && math_mode == ORACLE_MATH_CANON) { logit_hs(m, lg_hs); cfg.lg_hs = lg_hs; }
   const int64_t C = run->nchains, nsteps = run->nsteps;
   const int64_t S = fmcmc_oracle_kept_rows(nsteps, run->burnin, run->thin);
   const int64_t nwords = (nsteps + 31) / 32;
@@ -1090,7 +1114,7 @@ void fmcmc_oracle_detmath(int which, const double* x, double* out, int64_t n) {
       case 2: out[i] = fmh_log1p(x[i]); break;
       case 3: out[i] = fmh_qnorm(x[i]); break;
       case 9: out[i] = fmh_log1p(fmh_exp(x[i])); break;       /* the composition (accuracy yardstick of the fused routine) */
-      case 11: out[i] = fmh_log1p_exp_nonpos(x[i]); break;    /* the canonical softplus tail, host build */
+      case 11: out[i] = fmh_logit_g(x[i]); break;    /* the canonical logistic term g(|x|), host build */
       case 12: out[i] = fmh_tan_0_halfpi(x[i]); break;
       default: out[i] = NAN;
     }

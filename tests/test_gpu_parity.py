@@ -514,6 +514,56 @@ def test_logistic_specialised_loops(E, O, monkeypatch, cw, p, intercept):
              scale=0.3, lb=-2.0, ub=2.0, intercept=intercept)
 
 
+@pytest.mark.parametrize("p,intercept,C", [(1, True, 5), (3, False, 9), (5, True, 7), (8, True, 3), (5, True, 600), (2, True, 513)])
+def test_logistic_observation_sharded(E, O, monkeypatch, p, intercept, C):
+    """The observation-sharded logistic evaluation (logit_shard, knob shard=1 forces it at these sizes): 256 workgroups of two
+    canonical lanes each evaluate ALL chains, thread = chain -- one chain per thread up to 512 chains, two side by side
+    above --, hand-pipelined fast loop and the checked form (large |eta|: beyond the table's 2400 rows), ragged n (a last
+    slot that only some lanes hold), chain counts that leave workgroups without chains, two consecutive calls."""
+    from fmcmc_amd import _abi as abi
+    set_knob(monkeypatch, "shard", "1")
+    rng = np.random.default_rng(900 + 10 * p + C)
+    n = 512 * 3 + 37 * p + 1                                              # odd: the last slot holds lanes 0 .. 37 p only
+    X = rng.standard_normal((n, p)) * (12.0 if p == 3 else 1.0)           # p = 3: |eta| up to ~60, off the table
+    k = p + (1 if intercept else 0)
+    beta = rng.uniform(-1.5, 1.5, k)
+    eta = (beta[0] if intercept else 0.0) + X @ beta[(1 if intercept else 0):]
+    y = (rng.uniform(size=n) < 1 / (1 + np.exp(-eta))).astype(np.float64)
+    init = jitter_init(beta, C, 40 + p)
+    steps = 24 if C > 100 else 60
+    run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_NORMAL, k, init, nsteps=steps, burnin=5, thin=2, calls=2,
+             prior_div=8.0, scale=0.04, intercept=intercept)
+    assert abi.last_kernel() == "logistic-sharded"
+    run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_NORMAL_REFLECTIVE, k, init, nsteps=steps, prior_div=0.0,
+             scale=0.3, lb=-2.0, ub=2.0, intercept=intercept)
+    assert abi.last_kernel() == "logistic-sharded"
+
+
+@pytest.mark.parametrize("n", [100000, 99841, 100351])
+@pytest.mark.parametrize("form", ["chain-sharded", "observation-sharded"])
+def test_c5_exact_shape_equals_the_oracle(E, O, monkeypatch, n, form):
+    """BASELINE config C5 at its real shape -- logistic, n = 100,000 (195 / 196 observations per canonical lane: ~98 trips of
+    the two-operand-set loop and both of its tails; 99,841 / 100,351: the neighbouring tail cases), p = 5 + intercept,
+    kernel_normal_reflective(scale = .01, lb = -5, ub = 5) -- against the ORACLE, bit for bit: 10 chains at four per
+    workgroup, thin 10 and thin 1, on the chain-sharded loop (logit_partials<4, 5>) and on the observation-sharded one
+    (logit_shard<5, 1>), the form the full config runs on."""
+    import bench
+    from fmcmc_amd import _abi as abi
+    cfg = bench.Config("c5")
+    X, y, init = cfg.workload(10, 0)
+    X, y = X[:n], y[:n]
+    if n > cfg.n:                                                       # (the config's generator, continued)
+        rng = np.random.default_rng(77)
+        Xe = rng.standard_normal((n - cfg.n, cfg.p))
+        X, y = np.vstack([X, Xe]), np.concatenate([y, (rng.uniform(size=n - cfg.n) < 0.3).astype(np.float64)])
+    set_knob(monkeypatch, "cw", "4")
+    set_knob(monkeypatch, "shard", "1" if form == "observation-sharded" else "0")
+    for thin, steps in ((10, 31), (1, 12)):
+        run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_NORMAL_REFLECTIVE, 6, init, nsteps=steps, thin=thin, prior_div=8.0,
+                 guard=False, scale=0.01, lb=-5.0, ub=5.0)
+        assert abi.last_kernel() == ("logistic-sharded" if form == "observation-sharded" else "streamed-logistic")
+
+
 @pytest.mark.parametrize("cw", ["1", "2"])
 @pytest.mark.parametrize("n,p", [(1023, 16), (2500, 21), (1024 * 3 + 1, 33)])
 def test_wide_linreg_instantiations(E, O, monkeypatch, cw, n, p):
@@ -1027,7 +1077,7 @@ def test_full_size_logistic_and_wide_properties(E, monkeypatch):
         return r, st
 
     full, _ = run5(0, C5, 10)
-    assert abi.last_kernel() == "streamed-logistic"
+    assert abi.last_kernel() == "logistic-sharded"
     assert full.samples.shape[-1] == steps5 // 10
     assert bool((full.samples.abs() <= 5.0).all())
     part, _ = run5(256, 768, 10)
