@@ -71,6 +71,9 @@ struct SweepArgs {
   long long bits_stride, step_off;
   const double* fed_logu;
   const double* fed_z;
+  const double* mf_stream;   // mh_sweep_mfma<.., EXT>: the observation slots beyond the operand registers, in operand order (mfma_build_stream)
+  int mf_next;               //                          their number
+  int spec_opt;              // mh_sweep_spec: observation slots per lane of this launch, rounded up to even (<= the instantiation's OPTMAX)
   // state
   double* theta0;
   double* f0;

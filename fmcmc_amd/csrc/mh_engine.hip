@@ -74,6 +74,27 @@ __global__ void detmath_kernel(int which, const double* x, double* out, long lon
   out[i] = r;
 }
 
+// the observation slots beyond the operand registers of mh_sweep_mfma<.., EXT>, in operand order: for wave w, streamed slot e
+// (observation slot ns_res + e), group q, lane l, lane-group value g: column 4 q + l / 16 of [x_1 .. x_p, y, 0 ..] for
+// observation i = 64 w + cl_a(l % 16) + g + 512 (ns_res + e); 0 beyond n.  out[((((w next + e) ng + q) 64 + l) 4 + g]
+__global__ void mfma_build_stream(const double* X, const double* y, long long n, int p, int ng, int ns_res, int next, double* out) {
+  const long long total = (long long)NW * next * ng * 64 * 4;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(idx & 3), l = (int)((idx >> 2) & 63);
+    long long r = idx >> 8;
+    const int q = (int)(r % ng); r /= ng;
+    const int e = (int)(r % next), w = (int)(r / next);
+    const int f = 4 * q + (l >> 4), o16 = l & 15;
+    const long long i = (long long)(64 * w + 16 * (o16 & 3) + 4 * (o16 >> 2) + g) + (long long)NT * (ns_res + e);
+    double a = 0.0;
+    if (i < n) {
+      if (f < p) a = X[(long long)f * n + i];
+      else if (f == p) a = y[i];
+    }
+    out[idx] = a;
+  }
+}
+
 // Data-only sums of the canonical logistic form (include/fmh_detmath.h, fmh_logit_g; oracle: logit_hs): hs[0] = sum_i w_i when
 // the model has an intercept, hs[ic + j] = sum_i w_i x_ij, w_i = +1/2 (y_i != 0) or -1/2 -- every product exact, the sums over
 // the 512 canonical lanes in index order and their tree -- and behind them, for the range check of the fast loops, the largest
@@ -553,7 +574,8 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
 #else
   const bool nopipe = K.pipe == 0, nospec = false;   // (spec=0 / owners=0 select kernels that only -DFMCMC_AB builds carry)
 #endif
-  int pipe_opt = 0, mfma_ng = 0;
+  int pipe_opt = 0, mfma_ng = 0, mfma_ext = 0;   // mfma_ext: resident slots of the EXT form (0: everything resident)
+  AsyncScratch mfs_guard;
   if (!force && !nopipe && m->family == FMCMC_FAM_GAUSSIAN_LINREG &&
       (kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE ||
        (((kn->kind == FMCMC_KERNEL_ADAPT && !adapt_hist) || (kn->kind == FMCMC_KERNEL_RAM && !ram_bounded && !kn->constr)) && !nospec)) &&
@@ -566,17 +588,29 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
       (unsigned long long)kn->k * (unsigned long long)A.ldS * 8ull < (1ull << 32) &&      /* 32-bit offsets inside ONE chain's block */
       (kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE ||
        (unsigned long long)run->nchains * (unsigned long long)run->nsteps * (unsigned long long)(A.kz + 1) * 8ull < (8ull << 30))) {
-    if (m->p == 3 && m->n > (long long)NT * 19 && m->n <= (long long)NT * 20) pipe_opt = 20;
-    if (m->p == 1 && m->n > (long long)NT * 1 && m->n <= (long long)NT * 2) pipe_opt = 2;
+    // the wave-specialised kernel (mh_sweep_spec): x of a compute lane in VGPRs, the slot count an (even) run-time choice among
+    // its compute loops: any n <= 10240 at p <= 3, n <= 5120 at p = 4, 5, n <= 4096 at p = 6, 7 (OPTMAX P doubles per lane)
+    {
+      const long long nsl = (m->n + NT - 1) / NT, nsl2 = (nsl + 1) & ~1ll;
+      const int optmax = (m->p >= 1 && m->p <= 3) ? 20 : (m->p <= 5 ? 10 : (m->p <= 7 ? 8 : 0));
+      if (m->p >= 1 && nsl2 <= optmax && kn->kind >= FMCMC_KERNEL_ADAPT) pipe_opt = (int)nsl2;
+      // (normal / uniform kernels run on the MFMA kernel; knob mfma=0 keeps them here for the two shapes they were tuned at)
+      if (m->p == 3 && nsl == 20 && kn->kind < FMCMC_KERNEL_ADAPT) pipe_opt = 20;
+      if (m->p == 1 && nsl == 2 && kn->kind < FMCMC_KERNEL_ADAPT) pipe_opt = 2;
+    }
     // fp64-MFMA evaluation: general in n and p up to what 80 operand registers per lane hold (normal / uniform kernels)
     if (K.mfma != 0 && kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE && kn->scheme == FMCMC_SCHEME_JOINT) {
       if (m->p <= 3 && m->n <= (long long)NT * 20) mfma_ng = 1;
       else if (m->p <= 7 && m->n <= (long long)NT * 10) mfma_ng = 2;
+      // beyond the operand registers: 16 (8) slots resident, the rest streamed from an operand-order copy every step (EXT)
+      else if (m->p <= 3 && m->n < (1ll << 29)) { mfma_ng = 1; mfma_ext = 16; }
+      else if (m->p <= 7 && m->n < (1ll << 29)) { mfma_ng = 2; mfma_ext = 8; }
       // (the wave-specialised VALU kernel, which overlaps owners and evaluation, used to win at its small shape
       //  (p = 1, n ~ 1000); since the instruction diet of the owner phase the MFMA kernel is 1.2-1.35x ahead there too:
       //  tools/bench_small.py.  Knob mfma=0 still selects it.)
     }
   }
+  A.spec_opt = pipe_opt;
   if (pipe_opt || mfma_ng) {
     const size_t plds = pipe_opt ? pipe_lds_bytes(pipe_opt) : 0;
     const long long pblk = (run->nchains + 3) / 4;
@@ -612,6 +646,16 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
       e = hipMallocAsync((void**)&ws, sizeof(double) * items * (size_t)(A.kz + 1), stream);
       if (e != hipSuccess) { set_err("hipMallocAsync(rng stream) failed: %s", hipGetErrorString(e)); return FMCMC_ERR_DEVICE; }
       ws_guard.p = ws; ws_guard.s = stream;
+    }
+    if (mfma_ng && mfma_ext) {
+      const int ns_all = (int)((m->n + NT - 1) / NT), next = ns_all - mfma_ext;
+      double* mfs = nullptr;
+      const size_t nd = (size_t)NW * next * mfma_ng * 64 * 4;
+      e = hipMallocAsync((void**)&mfs, sizeof(double) * nd, stream);
+      if (e != hipSuccess) { set_err("hipMallocAsync(operand stream) failed: %s", hipGetErrorString(e)); return FMCMC_ERR_DEVICE; }
+      mfs_guard.p = mfs; mfs_guard.s = stream;
+      hipLaunchKernelGGL(mfma_build_stream, dim3(512), dim3(256), 0, stream, m->X, m->y, (long long)m->n, m->p, mfma_ng, mfma_ext, next, mfs);
+      A.mf_stream = mfs; A.mf_next = next;
     }
     auto fill_stream = [&](SweepArgs& W, long long step_base_eff) {   // the stream of launch W, rows = W.nsteps
       const size_t items = (size_t)W.nchains * (size_t)W.nsteps;
@@ -664,7 +708,14 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
 #define MF_CASES16(KN, KV, GV) MF_CASES10(KN, KV, GV) MF_CASE(KN, KV, GV, 11) MF_CASE(KN, KV, GV, 12) MF_CASE(KN, KV, GV, 13) \
                                MF_CASE(KN, KV, GV, 14) MF_CASE(KN, KV, GV, 15) MF_CASE(KN, KV, GV, 16)
 #define MF_CASES17(KN, KV, GV) MF_CASE(KN, KV, GV, 17) MF_CASE(KN, KV, GV, 18) MF_CASE(KN, KV, GV, 19) MF_CASE(KN, KV, GV, 20)
-      if (false) {
+      if (mfma_ext) {
+        g_kernel = "mfma-streamed";
+#define MF_EXT(KV, GV, SV) do { if (big) hipLaunchKernelGGL((mh_sweep_mfma<KV, GV, SV, false, true, true>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A); \
+                                else hipLaunchKernelGGL((mh_sweep_mfma<KV, GV, SV, false, false, true>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A); } while (0)
+        if (mfma_ng == 1) { if (kv == 1) MF_EXT(1, 1, 16); else MF_EXT(2, 1, 16); }
+        else { if (kv == 1) MF_EXT(1, 2, 8); else MF_EXT(2, 2, 8); }
+#undef MF_EXT
+      } else if (false) {
 #ifdef FMCMC_AB   /* the stamped (DBG) instantiations: tools/stamp_mfma.py against an -DFMCMC_AB build */
       } else if (dbgk && owners) {
         if (kv == 1) hipLaunchKernelGGL((mh_sweep_mfma<1, 1, 20, true>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A);
@@ -699,20 +750,21 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
         if (e == hipSuccess)                                                                           \
           hipLaunchKernelGGL((mh_sweep_spec<PV, OV, KV>), dim3((unsigned)pblk), dim3(SPEC_NT), slds, stream, A); \
       } while (0)
-      if (pipe_opt == 20) {
-        switch (kn->kind) {
-          case FMCMC_KERNEL_NORMAL: LAUNCH_SPEC(3, 20, 1); break;
-          case FMCMC_KERNEL_NORMAL_REFLECTIVE: LAUNCH_SPEC(3, 20, 2); break;
-          case FMCMC_KERNEL_ADAPT: LAUNCH_SPEC(3, 20, 3); break;
-          default: LAUNCH_SPEC(3, 20, 4); break;
-        }
+      if (kn->kind < FMCMC_KERNEL_ADAPT) {
+        if (m->p == 3) { if (kn->kind == FMCMC_KERNEL_NORMAL) LAUNCH_SPEC(3, 20, 1); else LAUNCH_SPEC(3, 20, 2); }
+        else { if (kn->kind == FMCMC_KERNEL_NORMAL) LAUNCH_SPEC(1, 20, 1); else LAUNCH_SPEC(1, 20, 2); }
       } else {
-        switch (kn->kind) {
-          case FMCMC_KERNEL_NORMAL: LAUNCH_SPEC(1, 2, 1); break;
-          case FMCMC_KERNEL_NORMAL_REFLECTIVE: LAUNCH_SPEC(1, 2, 2); break;
-          case FMCMC_KERNEL_ADAPT: LAUNCH_SPEC(1, 2, 3); break;
-          default: LAUNCH_SPEC(1, 2, 4); break;
+#define SPEC_AD(PV, OV) do { if (kn->kind == FMCMC_KERNEL_ADAPT) LAUNCH_SPEC(PV, OV, 3); else LAUNCH_SPEC(PV, OV, 4); } while (0)
+        switch (m->p) {
+          case 1: SPEC_AD(1, 20); break;
+          case 2: SPEC_AD(2, 20); break;
+          case 3: SPEC_AD(3, 20); break;
+          case 4: SPEC_AD(4, 10); break;
+          case 5: SPEC_AD(5, 10); break;
+          case 6: SPEC_AD(6, 8); break;
+          default: SPEC_AD(7, 8); break;
         }
+#undef SPEC_AD
       }
 #undef LAUNCH_SPEC
     }

@@ -45,7 +45,14 @@ constexpr int MF_TCS = 8 * PIPE_TRS + 2;   // (the replicated kernel's tile, mh_
 // of 32 bits from the buffer bases (kernel arguments): the form for calls with more than 4 GiB of samples or of fed
 // variates.  A template parameter because the extra scalar registers cost the headline shape 1.7 % (the kernel sits at
 // the SGPR limit); the dispatcher takes BIG only where the sizes need it.
-template <int KIND, int NG, int NS, bool DBG, bool BIG = false>
+// EXT (round 4): data sets beyond the operand registers (n > 10240 at p <= 3, n > 5120 at p <= 7).  NS observation slots
+// stay resident as before; the remaining A.mf_next slots are STREAMED every step from A.mf_stream, a copy of the data in
+// operand order (mfma_build_stream: [wave][slot][group][lane][4 lane-group values], 32 contiguous bytes per lane, so a slot is
+// two global_load_dwordx4 per lane and group, fully coalesced, L2-resident and shared by all workgroups), RD slots ahead in
+// a register ring.  Same MFMA chain, same accumulators in slot order: the canonical bits.  The streamed part runs at what a
+// CU gets out of its L2 (~16 KB per slot and workgroup), so the rate per flop falls off gently with n instead of dropping to
+// the general kernel's at observation 10,241 (profiles/r04_shape_map.md).
+template <int KIND, int NG, int NS, bool DBG, bool BIG = false, bool EXT = false>
 __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
   constexpr int CW = 4;
 #ifndef MFO_MB
@@ -96,7 +103,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
 #pragma unroll
   for (int g = 0; g < 4; g++) {
     const int l = 64 * wave + cl_d + g;
-    if ((long long)l + (long long)NT * (NS - 1) < A.n) vbits |= 1u << g;
+    if ((long long)l + (long long)NT * (NS - 1 + (EXT ? A.mf_next : 0)) < A.n) vbits |= 1u << g;
   }
   if (tid < k) {
     s_par[0 * PIPE_KMAX + tid] = A.mu[tid];
@@ -208,7 +215,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
           for (int u = 0; u < MB; u++)
             if (u < nu) {
               const int t = t0 + u;
-              const double cm = (t >= LAST) ? (((vbits >> (t - LAST)) & 1u) ? cop : 0.0) : cop;
+              const double cm = (!EXT && t >= LAST) ? (((vbits >> (t - LAST)) & 1u) ? cop : 0.0) : cop;
               d[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(areg[0][t], bop[0], cm, 0, 0, 0);
             }
 #pragma unroll
@@ -220,6 +227,45 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
 #pragma unroll
           for (int u = 0; u < MB; u++)
             if (u < nu) acc[u & 3] = fmh_fma(d[u], d[u], acc[u & 3]);
+        }
+      }
+      if constexpr (EXT) {
+        // the streamed slots: operands of slot e, group q, for this lane = 4 doubles at ((wave next + e) NG + q) 64 + lane
+        typedef double mf_d4 __attribute__((ext_vector_type(4)));
+        constexpr int RD = (NG == 1) ? 4 : 2;                     // slots in flight per wave (register ring)
+        const int next = A.mf_next;
+        const mf_d4* sp = reinterpret_cast<const mf_d4*>(A.mf_stream) + ((long long)wave * next * NG) * 64 + lane;
+        mf_d4 ring[RD][NG];
+#pragma unroll
+        for (int r = 0; r < RD; r++)
+#pragma unroll
+          for (int q = 0; q < NG; q++) ring[r][q] = sp[(((r < next) ? r : next - 1) * NG + q) * 64];
+        double cml[4];                                              // C operands of the LAST slot (padding: 0, see above)
+#pragma unroll
+        for (int g = 0; g < 4; g++) cml[g] = ((vbits >> g) & 1u) ? cop : 0.0;
+        for (int e0 = 0; e0 < next; e0 += RD) {
+#pragma unroll
+          for (int r = 0; r < RD; r++) {
+            const int e = e0 + r;
+            if (e < next) {                                         // (uniform)
+              mf_d4 a[NG];
+#pragma unroll
+              for (int q = 0; q < NG; q++) a[q] = ring[r][q];
+              const int en = (e + RD < next) ? e + RD : next - 1;   // refill this ring position (clamped: the tail re-reads)
+#pragma unroll
+              for (int q = 0; q < NG; q++) ring[r][q] = sp[(en * NG + q) * 64];
+              const bool last = (e == next - 1);
+              double d[4];
+#pragma unroll
+              for (int g = 0; g < 4; g++) d[g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[0][g], bop[0], last ? cml[g] : cop, 0, 0, 0);
+#pragma unroll
+              for (int q = 1; q < NG; q++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) d[g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[q][g], bop[q], d[g], 0, 0, 0);
+#pragma unroll
+              for (int g = 0; g < 4; g++) acc[g] = fmh_fma(d[g], d[g], acc[g]);
+            }
+          }
         }
       }
       // canonical levels 1..32 inside the wave (see the mapping above); a lane only ever adds canonical partial sums, and

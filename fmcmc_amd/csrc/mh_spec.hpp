@@ -591,10 +591,79 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
   if (KIND == FMCMC_KERNEL_ADAPT && rl) A.mean_prev[(long long)cl * kf + lane] = mean_prev;
 }
 
-template <int P, int OPT, int KIND>
+// The compute role of mh_sweep_spec for OPT (even) observation slots of P covariates per lane: one instantiation per slot count,
+// selected at run time by the kernel (round 4: the kernel used to exist for n in (9728, 10240] at p = 3 and (512, 1024] at p = 1
+// only, every other shape fell to the general kernel).
+template <int P, int OPT>
+__device__ __forceinline__ void spec_compute(const SweepArgs& A, const double* s_y, const double* s_th1, unsigned* s_ready, unsigned* s_done,
+                                             double* s_tr, int ncw, int nsteps, int ic, bool dbg, int wave, int tid, int lane) {
+    double xr[OPT][P > 0 ? P : 1];
+    double wlast = 1.0, wprev = 1.0;   // validity of this lane's observation in the last two slots (an odd slot count leaves the last one empty)
+#pragma unroll
+    for (int s = 0; s < OPT; s++) {
+      const long long i = (long long)tid + (long long)NT * s;
+      const bool valid = i < A.n;
+#pragma unroll
+      for (int j = 0; j < P; j++) xr[s][j] = valid ? A.X[(long long)j * A.n + i] : 0.0;
+      if (s == OPT - 1) wlast = valid ? 1.0 : 0.0;
+      if (s == OPT - 2) wprev = valid ? 1.0 : 0.0;
+    }
+    const int tr_slot = (tid & 7) * PIPE_TRS + (tid >> 3);
+    const double2* yp = reinterpret_cast<const double2*>(s_y) + tid;
+    unsigned long long tw = 0, te = 0;
+    for (int v = 1; v <= nsteps; v++) {
+      for (int c = 0; c < ncw; c++) {
+        unsigned long long t_a = dbg ? clk() : 0;
+        while (lds_ld_u32(&s_ready[c]) < (unsigned)v) __builtin_amdgcn_s_sleep(1);
+        unsigned long long t_b = dbg ? clk() : 0;
+        const double* t0 = s_th1 + c * PIPE_KMAX;
+        const double m00 = ic ? t0[0] : 0.0;
+        double b0[P > 0 ? P : 1];
+#pragma unroll
+        for (int j = 0; j < P; j++) b0[j] = t0[ic + j];
+        double a0 = 0.0;
+        // y pairs come from LDS three pairs (~30 FMAs) ahead of their use: LDS latency is ~130 cycles and only two
+        // compute waves share the SIMD, so a one-pair lookahead leaves the FMA pipe waiting on lgkmcnt
+        constexpr int YD = 3;
+        double2 yq[YD];
+#pragma unroll
+        for (int d = 0; d < YD; d++) yq[d] = yp[(d < OPT / 2 ? d : OPT / 2 - 1) * NT];
+#pragma unroll
+        for (int s2 = 0; s2 < OPT / 2; s2++) {
+          const double2 yy = yq[s2 % YD];
+          if (s2 + YD < OPT / 2) yq[s2 % YD] = yp[(s2 + YD) * NT];
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            const int s = 2 * s2 + h;
+            const double yv = h ? yy.y : yy.x;
+            double m0 = m00;
+#pragma unroll
+            for (int j = 0; j < P; j++) m0 = fmh_fma(xr[s][j], b0[j], m0);
+            const double r0 = yv - m0;
+            if (s == OPT - 1) a0 = fmh_fma(r0 * wlast, r0, a0);
+            else if (s == OPT - 2) a0 = fmh_fma(r0 * wprev, r0, a0);   // (r0 * 1 == r0: the same bits where the slot is full)
+            else a0 = fmh_fma(r0, r0, a0);
+          }
+        }
+        s_tr[c * (8 * PIPE_TRS) + tr_slot] = a0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // partials landed before the arrival is visible
+        if (lane == 0) __hip_atomic_fetch_add(&s_done[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (dbg) { unsigned long long t_c = clk(); tw += t_b - t_a; te += t_c - t_b; }
+      }
+    }
+    if (dbg && lane == 0 && A.draws) {
+      double* d = A.draws + ((long long)blockIdx.x * 12 + wave) * 4;
+      d[0] = (double)tw; d[1] = (double)te; d[2] = 0.0; d[3] = (double)nsteps;
+    }
+}
+
+// OPTMAX: the most observation slots a compute lane holds (x in VGPRs: OPTMAX P doubles); the launch's (even) slot count
+// A.spec_opt <= OPTMAX selects the compute loop.
+template <int P, int OPTMAX, int KIND>
 __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
   constexpr int CW = 4;
-  static_assert(OPT % 2 == 0, "OPT must be even (y is read back in pairs)");
+  static_assert(OPTMAX % 2 == 0, "slot counts are even (y is read back in pairs)");
+  const int OPT = A.spec_opt;                      // (uniform) even, 2 .. OPTMAX
   extern __shared__ double smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -633,61 +702,11 @@ __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
 
   if (wave < SPEC_NCW) {
     // =========================== COMPUTE ROLE ===========================
-    double xr[OPT][P > 0 ? P : 1];
-    double wlast = 1.0;
-#pragma unroll
-    for (int s = 0; s < OPT; s++) {
-      const long long i = (long long)tid + (long long)NT * s;
-      const bool valid = i < A.n;
-#pragma unroll
-      for (int j = 0; j < P; j++) xr[s][j] = valid ? A.X[(long long)j * A.n + i] : 0.0;
-      if (s == OPT - 1) wlast = valid ? 1.0 : 0.0;
-    }
-    const int tr_slot = (tid & 7) * PIPE_TRS + (tid >> 3);
-    const double2* yp = reinterpret_cast<const double2*>(s_y) + tid;
-    unsigned long long tw = 0, te = 0;
-    for (int v = 1; v <= nsteps; v++) {
-      for (int c = 0; c < ncw; c++) {
-        unsigned long long t_a = dbg ? clk() : 0;
-        while (lds_ld_u32(&s_ready[c]) < (unsigned)v) __builtin_amdgcn_s_sleep(1);
-        unsigned long long t_b = dbg ? clk() : 0;
-        const double* t0 = s_th1 + c * PIPE_KMAX;
-        const double m00 = ic ? t0[0] : 0.0;
-        double b0[P > 0 ? P : 1];
-#pragma unroll
-        for (int j = 0; j < P; j++) b0[j] = t0[ic + j];
-        double a0 = 0.0;
-        // y pairs come from LDS three pairs (~30 FMAs) ahead of their use: LDS latency is ~130 cycles and only two
-        // compute waves share the SIMD, so a one-pair lookahead leaves the FMA pipe waiting on lgkmcnt
-        constexpr int YD = 3;
-        double2 yq[YD];
-#pragma unroll
-        for (int d = 0; d < YD; d++) yq[d] = yp[(d < OPT / 2 ? d : OPT / 2 - 1) * NT];
-#pragma unroll
-        for (int s2 = 0; s2 < OPT / 2; s2++) {
-          const double2 yy = yq[s2 % YD];
-          if (s2 + YD < OPT / 2) yq[s2 % YD] = yp[(s2 + YD) * NT];
-#pragma unroll
-          for (int h = 0; h < 2; h++) {
-            const int s = 2 * s2 + h;
-            const double yv = h ? yy.y : yy.x;
-            double m0 = m00;
-#pragma unroll
-            for (int j = 0; j < P; j++) m0 = fmh_fma(xr[s][j], b0[j], m0);
-            const double r0 = yv - m0;
-            if (s == OPT - 1) a0 = fmh_fma(r0 * wlast, r0, a0);
-            else a0 = fmh_fma(r0, r0, a0);
-          }
-        }
-        s_tr[c * (8 * PIPE_TRS) + tr_slot] = a0;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // partials landed before the arrival is visible
-        if (lane == 0) __hip_atomic_fetch_add(&s_done[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (dbg) { unsigned long long t_c = clk(); tw += t_b - t_a; te += t_c - t_b; }
-      }
-    }
-    if (dbg && lane == 0 && A.draws) {
-      double* d = A.draws + ((long long)blockIdx.x * 12 + wave) * 4;
-      d[0] = (double)tw; d[1] = (double)te; d[2] = 0.0; d[3] = (double)nsteps;
+    switch (OPT) {
+#define SPEC_CC(O_) case O_: if constexpr (O_ <= OPTMAX) spec_compute<P, O_>(A, s_y, s_th1, s_ready, s_done, s_tr, ncw, nsteps, ic, dbg, wave, tid, lane); break;
+      SPEC_CC(2) SPEC_CC(4) SPEC_CC(6) SPEC_CC(8) SPEC_CC(10) SPEC_CC(12) SPEC_CC(14) SPEC_CC(16) SPEC_CC(18) SPEC_CC(20)
+#undef SPEC_CC
+      default: break;
     }
     return;
   }

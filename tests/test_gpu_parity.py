@@ -599,6 +599,39 @@ def test_adaptive_owner_variants(E, O, kind_name, n, p, intercept, fixed):
         run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, k, init, nsteps=120, calls=2, **kw)
 
 
+@pytest.mark.parametrize("n,p", [(600, 3), (5000, 3), (9000, 3), (9217, 3), (10240, 3), (3000, 2), (700, 1), (5120, 4), (4000, 5), (4096, 7), (2049, 6)])
+def test_wave_specialised_kernel_at_any_shape(E, O, n, p):
+    """mh_sweep_spec (kernel_adapt / kernel_ram) with its slot count a run-time choice among compute loops (round 4; it
+    existed for n in (9728, 10240] at p = 3 and (512, 1024] at p = 1 only): even and odd slot counts (9217: 19 slots, the
+    partly filled one is then the second to last of the 20 the loop walks), ragged n, every p the kernel takes."""
+    from fmcmc_amd import _abi as abi
+    X, y = synth_linreg(n, p, 4100 + n + p)
+    k = p + 2
+    init = jitter_init([0.0] * (p + 1) + [float(np.std(y))], 5, 90 + p)
+    init[:, -1] = np.abs(init[:, -1])
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_ADAPT, k, init, nsteps=90, calls=2, warmup=20)
+    assert abi.last_kernel() == "spec"
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, k, init, nsteps=70, calls=2)
+    assert abi.last_kernel() == "spec"
+
+
+@pytest.mark.parametrize("n,p", [(10241, 3), (12000, 3), (20000, 3), (20481, 2), (50001, 3), (5121, 5), (9000, 7), (12345, 4)])
+def test_mfma_kernel_beyond_its_operand_registers(E, O, n, p):
+    """mh_sweep_mfma<.., EXT> (round 4): 16 (p <= 3) or 8 (p <= 7) observation slots resident, the rest streamed every step
+    from the operand-order copy -- the shapes that fell to the general kernel at observation 10,241 / 5,121.  Ragged last
+    slot, one and many streamed slots, normal and reflective kernels, two consecutive calls."""
+    from fmcmc_amd import _abi as abi
+    X, y = synth_linreg(n, p, 5200 + n + p)
+    k = p + 2
+    init = jitter_init([0.0] * (p + 1) + [float(np.std(y))], 6, 95 + p)
+    init[:, -1] = np.abs(init[:, -1])
+    steps = 40 if n > 20000 else 80
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, k, init, nsteps=steps, burnin=3, thin=2, calls=2, scale=0.02)
+    assert abi.last_kernel() == "mfma-streamed"
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL_REFLECTIVE, k, init, nsteps=steps, scale=0.3, lb=-6.0, ub=9.0)
+    assert abi.last_kernel() == "mfma-streamed"
+
+
 def test_small_shape_mfma_equals_wave_specialised_kernel(E, O, monkeypatch):
     """README-size data (p = 1, n ~ 1000): the MFMA kernel (default) and the wave-specialised VALU kernel it replaced there
     (knob mfma=0) give the oracle's bits, normal and reflective kernels."""
