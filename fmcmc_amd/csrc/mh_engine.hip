@@ -46,6 +46,7 @@
 #endif
 #include "mh_spec.hpp"
 #include "mh_wide2.hpp"
+#include "mh_mfma_ad.hpp"
 
 namespace {
 
@@ -574,7 +575,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
 #else
   const bool nopipe = K.pipe == 0, nospec = false;   // (spec=0 / owners=0 select kernels that only -DFMCMC_AB builds carry)
 #endif
-  int pipe_opt = 0, mfma_ng = 0, mfma_ext = 0;   // mfma_ext: resident slots of the EXT form (0: everything resident)
+  int pipe_opt = 0, mfma_ng = 0, mfma_ad = 0, mfma_ext = 0;   // mfma_ext: resident slots of the EXT form (0: everything resident)
   AsyncScratch mfs_guard;
   if (!force && !nopipe && m->family == FMCMC_FAM_GAUSSIAN_LINREG &&
       (kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE ||
@@ -608,6 +609,14 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
       // (the wave-specialised VALU kernel, which overlaps owners and evaluation, used to win at its small shape
       //  (p = 1, n ~ 1000); since the instruction diet of the owner phase the MFMA kernel is 1.2-1.35x ahead there too:
       //  tools/bench_small.py.  Knob mfma=0 still selects it.)
+    }
+    // kernel_adapt / kernel_ram beyond mh_sweep_spec's registers: the same streamed MFMA evaluation with the register-row
+    // adaptive owners between barriers (mh_mfma_ad.hpp); no fixed parameter, k <= 8
+    if (K.mfma != 0 && !pipe_opt && kn->kind >= FMCMC_KERNEL_ADAPT && m->p >= 1 && m->p <= 7 && kf == kn->k && kn->k <= SPEC_KA &&
+        A.kz == kn->k && m->n < (1ll << 29)) {
+      mfma_ad = 1;
+      mfma_ng = (m->p <= 3) ? 1 : 2;
+      mfma_ext = (mfma_ng == 1) ? MfmaAdShape<1>::NSR : MfmaAdShape<2>::NSR;
     }
   }
   A.spec_opt = pipe_opt;
@@ -708,7 +717,16 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
 #define MF_CASES16(KN, KV, GV) MF_CASES10(KN, KV, GV) MF_CASE(KN, KV, GV, 11) MF_CASE(KN, KV, GV, 12) MF_CASE(KN, KV, GV, 13) \
                                MF_CASE(KN, KV, GV, 14) MF_CASE(KN, KV, GV, 15) MF_CASE(KN, KV, GV, 16)
 #define MF_CASES17(KN, KV, GV) MF_CASE(KN, KV, GV, 17) MF_CASE(KN, KV, GV, 18) MF_CASE(KN, KV, GV, 19) MF_CASE(KN, KV, GV, 20)
-      if (mfma_ext) {
+      if (mfma_ad) {
+        g_kernel = "mfma-adaptive";
+        const size_t alds = mfma_ad_lds_bytes();
+#define MF_AD(GV, XV) do { if (kn->kind == FMCMC_KERNEL_ADAPT) hipLaunchKernelGGL((mh_sweep_mfma_ad<3, GV, XV>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); \
+                           else hipLaunchKernelGGL((mh_sweep_mfma_ad<4, GV, XV>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); } while (0)
+        if (mfma_ng == 1 && kn->k == 5) MF_AD(1, 5);
+        else if (mfma_ng == 1) MF_AD(1, 0);
+        else MF_AD(2, 0);
+#undef MF_AD
+      } else if (mfma_ext) {
         g_kernel = "mfma-streamed";
 #define MF_EXT(KV, GV, SV) do { if (big) hipLaunchKernelGGL((mh_sweep_mfma<KV, GV, SV, false, true, true>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A); \
                                 else hipLaunchKernelGGL((mh_sweep_mfma<KV, GV, SV, false, false, true>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A); } while (0)
@@ -815,10 +833,11 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
   } else
   if (resident && res_p == 1) { g_kernel = "resident"; LAUNCH_KIND(4, 1, 4); }
   else if (resident && res_p == 3) { g_kernel = "resident"; LAUNCH_KIND(4, 3, 20); }
-  else if (m->family == FMCMC_FAM_LOGISTIC && cw <= 4 && m->p <= 28 / cw - 1 &&
+  else if (m->family == FMCMC_FAM_LOGISTIC && cw <= 4 && lds + sizeof(double) * (LG_LDS_DOUBLES + 2) <= 160 * 1024 &&
            (kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE)) {
-    // logistic-only instantiations: the number of covariates is a compile-time constant of the evaluation loop and the
-    // coefficients of the CW chains live in SGPRs (mh_common.hpp), the g table in LDS
+    // logistic-only instantiations: the g table in LDS; up to 28 / cw - 1 covariates their number is a compile-time constant
+    // of the evaluation loop and the coefficients of the CW chains live in SGPRs (mh_common.hpp, logit_partials), beyond that
+    // the run-time loop (logit_partials_any) -- still with the table in LDS, which is what the all-family kernel lacks
     g_kernel = "streamed-logistic";
     const bool refl = kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE;
     lds += sizeof(double) * (LG_LDS_DOUBLES + 2);   // the table staged behind the chain blocks (16-byte aligned)

@@ -317,9 +317,30 @@ constexpr int SPEC_KA = 8;
 // KX > 0: the number of parameters is the compile-time constant KX (the statically unrolled loops then carry no `b < kf`
 // predicates and no dead iterations: at k = 5 the owner loop was 1800 instructions per step with KA = 8, and an owner
 // wave issues one instruction per ~6.5 cycles: the chain-step rate of C3 IS this instruction count); KX == 0: k <= 8.
-template <int KIND, int KX>
-__device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int myc, int cl, double* s_th1, double* s_par,
-                                                        unsigned* s_ready, unsigned* s_done, double* s_tr) {
+// How the owner meets the evaluation is a policy (round 4): SpecSync = mh_sweep_spec's LDS sequence words (the evaluation runs
+// in other waves, chain by chain); the MFMA kernel's owners (mh_mfma_ad.hpp) evaluate themselves and meet on barriers.
+//   total(v, prep): the canonical total of version v's evaluation of this chain (uniform); PREP_EARLY policies run prep() -- what
+//                   the decision needs and the evaluation does not enter -- inside it, in front of their wait
+//   publish(vn):    theta1 of version vn is in s_th1;   final(): behind the last decision (no proposal)
+struct SpecSync {
+  static constexpr bool PREP_EARLY = false;
+  unsigned* s_ready; unsigned* s_done; const double* s_tr; int myc;
+  template <class F> __device__ __forceinline__ double total(int v, F&&) const {
+    const int lane = threadIdx.x & 63;
+    while (lds_ld_u32(&s_done[myc]) < 8u * (unsigned)v) __builtin_amdgcn_s_sleep(1);
+    const double* src = s_tr + myc * (8 * PIPE_TRS) + lane;
+    const double v0 = src[0 * PIPE_TRS], v1 = src[1 * PIPE_TRS], v2 = src[2 * PIPE_TRS], v3 = src[3 * PIPE_TRS];
+    const double v4 = src[4 * PIPE_TRS], v5 = src[5 * PIPE_TRS], v6 = src[6 * PIPE_TRS], v7 = src[7 * PIPE_TRS];
+    return wave_xor_sum(((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7)));
+  }
+  __device__ __forceinline__ void publish(int vn) const {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store(&s_ready[myc], (unsigned)vn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  __device__ __forceinline__ void final() const {}
+};
+template <int KIND, int KX, class SYNC>
+__device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int myc, int cl, double* s_th1, SYNC& sync) {
   constexpr int KA = KX > 0 ? KX : SPEC_KA;
   const int lane = threadIdx.x & 63;
   const int k = KX > 0 ? KX : A.k, kf = k, kz = KX > 0 ? KX : A.kz;
@@ -407,7 +428,7 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
       pre_nrm2 = readlane_d(pre_Pj1, kf - 1);
     }
   };
-  prepare(1);
+  if (!SYNC::PREP_EARLY) prepare(1);
 #ifdef SPEC_STAMP   /* diagnostic build (tools/exp_spec.hip): s_memtime shares of the owner's phases */
   unsigned long long stt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stp = clk();
 #define SPEC_ST(i) do { const unsigned long long t_ = clk(); stt[i] += t_ - stp; stp = t_; } while (0)
@@ -416,12 +437,8 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
 #endif
 
   for (int v = 1; v <= nsteps; v++) {
-    while (lds_ld_u32(&s_done[myc]) < 8u * (unsigned)v) __builtin_amdgcn_s_sleep(1);
+    const double tot = sync.total(v, [&]() { prepare(v); });
     SPEC_ST(0);
-    const double* src = s_tr + myc * (8 * PIPE_TRS) + lane;
-    const double v0 = src[0 * PIPE_TRS], v1 = src[1 * PIPE_TRS], v2 = src[2 * PIPE_TRS], v3 = src[3 * PIPE_TRS];
-    const double v4 = src[4 * PIPE_TRS], v5 = src[5 * PIPE_TRS], v6 = src[6 * PIPE_TRS], v7 = src[7 * PIPE_TRS];
-    const double tot = wave_xor_sum(((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7)));
     const double h = 0.5 * tot;
     double f1;
     if (pre_ok && mfr_div_safe(h)) f1 = -pre_nt1 - div_finish(h, pre_ss, pre_rs);   // (finite: the guard has nothing to do)
@@ -554,8 +571,9 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
         }
         if (rl) s_th1[myc * PIPE_KMAX + lane] = th1;
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (lane == 0) __hip_atomic_store(&s_ready[myc], (unsigned)(v + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      sync.publish(v + 1);
+    } else {
+      sync.final();
     }
     SPEC_ST(5);
     if (st_row) {   // row v of ans / draws / logpost, off the compute waves' critical path
@@ -567,7 +585,7 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
       srow8 += 8;
     }
     SPEC_ST(6);
-    if (v < nsteps) prepare(v + 1);
+    if (!SYNC::PREP_EARLY && v < nsteps) prepare(v + 1);
     SPEC_ST(7);
   }
 #ifdef SPEC_STAMP
@@ -727,12 +745,13 @@ __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
   if constexpr (KIND == FMCMC_KERNEL_ADAPT || KIND == FMCMC_KERNEL_RAM) {
     bool nofixed = true;
     for (int j = 0; j < k; j++) nofixed = nofixed && (A.fixed[j] == 0);
+    SpecSync sync{s_ready, s_done, s_tr, myc};
     if (k == P + 2 && nofixed && A.kz == k && !(A.debug & 16))        // intercept + P covariates + sigma (C3: k = 5)
-      spec_owner_adaptive_reg<KIND, P + 2>(A, myc, cl, s_th1, s_par, s_ready, s_done, s_tr);
+      spec_owner_adaptive_reg<KIND, P + 2>(A, myc, cl, s_th1, sync);
     else if (k == P + 1 && nofixed && A.kz == k && !(A.debug & 16))   // no intercept
-      spec_owner_adaptive_reg<KIND, P + 1>(A, myc, cl, s_th1, s_par, s_ready, s_done, s_tr);
+      spec_owner_adaptive_reg<KIND, P + 1>(A, myc, cl, s_th1, sync);
     else if (k <= SPEC_KA && nofixed && !(A.debug & 16))
-      spec_owner_adaptive_reg<KIND, 0>(A, myc, cl, s_th1, s_par, s_ready, s_done, s_tr);
+      spec_owner_adaptive_reg<KIND, 0>(A, myc, cl, s_th1, sync);
     else
       spec_owner_adaptive<KIND>(A, myc, cl, s_th1, s_par, s_ready, s_done, s_tr, s_ad + myc * SPEC_ADS);
     return;

@@ -632,6 +632,22 @@ def test_mfma_kernel_beyond_its_operand_registers(E, O, n, p):
     assert abi.last_kernel() == "mfma-streamed"
 
 
+@pytest.mark.parametrize("n,p,intercept", [(10241, 3, True), (20000, 3, True), (12001, 3, False), (30000, 2, True), (5121, 5, True), (6500, 6, True), (9000, 4, False)])
+def test_adaptive_kernels_on_the_streamed_mfma_evaluation(E, O, n, p, intercept):
+    """mh_sweep_mfma_ad (round 4): kernel_adapt / kernel_ram beyond mh_sweep_spec's registers -- the streamed MFMA evaluation of
+    all four chains of a workgroup, then one step of the register-row adaptive owners between barriers.  k = 5 (the
+    compile-time owner) and the generic k <= 8 owner, with and without intercept, ragged last slot, continuation calls."""
+    from fmcmc_amd import _abi as abi
+    X, y = synth_linreg(n, p, 6100 + n + p)
+    k = p + 1 + (1 if intercept else 0)
+    init = jitter_init(([0.0] if intercept else []) + [0.0] * p + [float(np.std(y))], 6, 97 + p)
+    init[:, -1] = np.abs(init[:, -1])
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_ADAPT, k, init, nsteps=80, calls=2, warmup=20, intercept=intercept)
+    assert abi.last_kernel() == "mfma-adaptive"
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, k, init, nsteps=60, calls=2, intercept=intercept)
+    assert abi.last_kernel() == "mfma-adaptive"
+
+
 def test_small_shape_mfma_equals_wave_specialised_kernel(E, O, monkeypatch):
     """README-size data (p = 1, n ~ 1000): the MFMA kernel (default) and the wave-specialised VALU kernel it replaced there
     (knob mfma=0) give the oracle's bits, normal and reflective kernels."""
