@@ -842,16 +842,19 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
     const bool refl = kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE;
     lds += sizeof(double) * (LG_LDS_DOUBLES + 2);   // the table staged behind the chain blocks (16-byte aligned)
     // Observation-sharded form (mh_common.hpp, logit_shard): 256 workgroups of two canonical lanes each evaluate ALL chains
-    // of the launch, up to 256 x cw of them; more chains run as consecutive launches.  Cost model (us per step, fitted at
-    // C5: n = 1e5, p = 5): chain-sharded ~ n cw 2.6e-4 (its lookups scatter over the table: LDS-bound), sharded ~ 15 of
-    // hand-overs + chains n 6.8e-7.  Knob shard=1 forces it for every eligible shape (tests), shard=0 disables it.
+    // of the launch, up to 256 x cw of them; more chains run as consecutive launches.  Cost model (us per step, fitted to
+    // tools/shape_map.py at p = 5, 7, n = 1e4 .. 1e5, 1024 chains): both loops cost ~(p + 12) instructions per observation
+    // and chain; chain-sharded 4.5 + n cw (p + 12) 1.35e-5 with the coefficients in SGPRs (p <= 28 / cw - 1; 2.8e-5 on the
+    // run-time loop beyond that) -- its lookups scatter over the table: LDS-bound --, sharded 15 of hand-overs +
+    // chains n (p + 12) 3.5e-8.  Knob shard=1 forces it for every eligible shape (tests), shard=0 disables it.
     bool lshard = false;
     const long long nb_launch = 256;
     const long long ch_launch = (nblk > nb_launch) ? nb_launch * cw : (long long)run->nchains;
     const int nslots = (int)((m->n + NT - 1) / NT);
     if (K.shard != 0 && m->p >= 1 && m->p <= 8 && ncu == 256 && m->n >= 2 * NT && m->n < (1ll << 28)) {
-      const double est_chain = 2.6e-4 * (double)m->n * cw, est_shard = 15.0 + 6.8e-7 * (double)m->n * (double)ch_launch;
-      lshard = K.shard == 1 || est_shard < 0.9 * est_chain;
+      const double w = (double)m->n * (double)(m->p + 12);
+      const double est_chain = 4.5 + w * cw * ((m->p <= 28 / cw - 1) ? 1.35e-5 : 2.8e-5), est_shard = 15.0 + 3.5e-8 * w * (double)ch_launch;
+      lshard = K.shard == 1 || est_shard < 0.95 * est_chain;
     }
     const void* kfn = nullptr;
 #define LSK(CWV) (refl ? (const void*)mh_sweep_kernel<CWV, -1, 2, 2, FMCMC_FAM_LOGISTIC, 1> : (const void*)mh_sweep_kernel<CWV, -1, 2, 1, FMCMC_FAM_LOGISTIC, 1>)

@@ -18,6 +18,15 @@ r = E.sweep(gm, gk, st, nst, seed=1215, want_bits=False, check=False)
 torch.cuda.synchronize()
 print("kernel:", abi.last_kernel())
 d = r.status_theta.cpu().numpy()[::2] * 0.01          # us
+# a workgroup whose stamped wave never passed one of the stamps (a slot left at 0: the sweep ended first, or the wave is not
+# the stamped one in that workgroup) stays out of the statistics -- an unset stamp used to enter them as "0 us", i.e. as
+# minus the whole run time relative to the median publish
+cols = [24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 36, 37]
+ok = (d[:, cols] > 0).all(axis=1)
+print("workgroups with every stamp set: %d of %d" % (int(ok.sum()), d.shape[0]))
+d = d[ok]
+if d.shape[0] == 0:
+    raise SystemExit("no workgroup has all stamps: is FMCMC_AMD_LIB the -DFMCMC_STAMP build?")
 for g in (0, 1):
     pub300, x1seen, x2arr, x2arr5, x2seen, pub301 = d[:, 32 + g], d[:, 26 + 2 * g], d[:, 27 + 2 * g], d[:, 36 + g], d[:, 24 + 6 * g], d[:, 25 + 6 * g]
     t0 = np.median(pub300)
