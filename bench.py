@@ -438,7 +438,20 @@ def launch_ranks(args_list, n, backend):
     return worst if 0 <= worst < 256 else 1
 
 
+def install_segv_trace():
+    """FMCMC_SEGV_TRACE=1 (diagnosis): native backtrace on SIGSEGV (tools/segv_trace.c), e.g. for the crash of a rocprofv3-profiled
+    run inside an exit handler; FMCMC_SEGV_TRACE_FILE names the file it goes to (default stderr)."""
+    if os.environ.get("FMCMC_SEGV_TRACE") != "1":
+        return
+    import ctypes
+    so = os.path.join(ROOT, "tools", "exp_bin", "libsegv_trace.so")
+    if os.path.exists(so):
+        lib = ctypes.CDLL(so)
+        lib.fmcmc_segv_trace_install(os.environ.get("FMCMC_SEGV_TRACE_FILE", "").encode())
+
+
 def main():
+    install_segv_trace()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=0, help="timed steps (default: about 5 s of GPU time for the config: c2 240, c3 140, c4 20, c5 6)")

@@ -421,7 +421,9 @@ __device__ __forceinline__ void sh_store2(double* p, double v0, double v1) {
 __device__ __forceinline__ double sh_load(const double* p) {
   return __hip_atomic_load((sh_gptr_t)(unsigned long long)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ bool shard_barrier(unsigned* bar, unsigned epoch) {
+// fault: FMCMC_AMD_DEBUG=mode=512 (tests): workgroup 1 never arrives for epoch 3 and every spin gives up after ~25 ms instead
+// of ~1 s -- the way a lost hand-over is EXERCISED rather than only argued (status 5, "results invalid", no hang)
+__device__ __forceinline__ bool shard_barrier(unsigned* bar, unsigned epoch, bool fault = false) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_waitcnt(0);           // this thread's sc1 stores have been acknowledged
   __syncthreads();
@@ -430,16 +432,19 @@ __device__ __forceinline__ bool shard_barrier(unsigned* bar, unsigned epoch) {
     const unsigned ngroups = 8, gsize = gridDim.x / 8, g = blockIdx.x % ngroups;
     unsigned* top = bar + 8 * 32;
     unsigned* rel = bar + 9 * 32;
-    const unsigned old = __hip_atomic_fetch_add(&bar[g * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (old + 1 == epoch * gsize) {
-      const unsigned t = __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (t + 1 == epoch * ngroups)
-        for (unsigned q = 0; q < ngroups; q++) __hip_atomic_store(&rel[q * 32], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!(fault && blockIdx.x == 1 && epoch == 3)) {
+      const unsigned old = __hip_atomic_fetch_add(&bar[g * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old + 1 == epoch * gsize) {
+        const unsigned t = __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t + 1 == epoch * ngroups)
+          for (unsigned q = 0; q < ngroups; q++) __hip_atomic_store(&rel[q * 32], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     unsigned spins = 0;
+    const unsigned limit = fault ? 400000u : 20000000u;
     while (__hip_atomic_load(&rel[g * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > 20000000u) { ok = false; break; }
+      if (++spins > limit) { ok = false; break; }
     }
   }
   ok = !__syncthreads_or(ok ? 0 : 1);      // the verdict of thread 0, for every thread of the workgroup
@@ -796,7 +801,7 @@ __device__ __forceinline__ bool eval_sharded(const SweepArgs& A, double* const* 
   constexpr unsigned LOST = 0x80000000u;
   bool ok = true;
   FMH_STAMP(stp, 3);
-  if (!(A.debug & 32) && !(epoch & LOST)) { ok = shard_barrier(A.sh_bar, ++epoch); if (!ok) epoch |= LOST; }
+  if (!(A.debug & 32) && !(epoch & LOST)) { ok = shard_barrier(A.sh_bar, ++epoch, (A.debug & 512) != 0); if (!ok) epoch |= LOST; }
   FMH_STAMP(stp, 4);
   // 2. thread = chain: the slice's observations for that chain
   if constexpr (FAM == FMCMC_FAM_LOGISTIC) {
@@ -823,7 +828,7 @@ __device__ __forceinline__ bool eval_sharded(const SweepArgs& A, double* const* 
   else shard_columns<LPW, SH_MAXO>(sc);
   }
   FMH_STAMP(stp, 5);
-  if (!(A.debug & 32) && !(epoch & LOST)) { ok = shard_barrier(A.sh_bar, ++epoch); if (!ok) epoch |= LOST; }
+  if (!(A.debug & 32) && !(epoch & LOST)) { ok = shard_barrier(A.sh_bar, ++epoch, (A.debug & 512) != 0); if (!ok) epoch |= LOST; }
   FMH_STAMP(stp, 6);
   ok = !(epoch & LOST);
   // 3. thread = canonical lane: its partial of this workgroup's chains

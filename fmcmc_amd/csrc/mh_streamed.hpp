@@ -722,7 +722,11 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
     if (lane == 0) {
       A.f0[cl] = f0;
       A.accept_count[cl] = nacc;
-      if (status == FMCMC_CHAIN_OK) { A.status[cl] = FMCMC_CHAIN_OK; A.status_step[cl] = 0; }
+      // (a grid-wide hand-over of the observation-sharded evaluation was lost -- bit 31 of the epoch, eval_sharded --: EVERY chain
+      //  of the workgroup says so.  Until round 4 the OK of the line below overwrote the one status word eval_partials had set:
+      //  found by the forced fault of test_a_lost_hand_over_ends_in_status_5_not_in_a_hang)
+      if (sh_epoch & 0x80000000u) { A.status[cl] = FMCMC_CHAIN_SYNC_TIMEOUT; A.status_step[cl] = 0; }
+      else if (status == FMCMC_CHAIN_OK) { A.status[cl] = FMCMC_CHAIN_OK; A.status_step[cl] = 0; }
       if (mirror) { A.abs_iter[cl] = abs_iter; A.obs_arate[cl] = obs_arate; }
       if (adaptive) {
         A.abs_iter[cl] = abs_iter;

@@ -60,7 +60,7 @@ __device__ __forceinline__ void w2_lds_st(unsigned* p, unsigned v) {
 }
 // lane 0 of the calling wave polls its shard's replica of the top counter for `target` = shards that take part x epoch;
 // wave-uniform result; false: timed out (or the workgroup is already lost)
-__device__ __forceinline__ bool w2_wait(unsigned* bar, unsigned target, unsigned* s_lost) {
+__device__ __forceinline__ bool w2_wait(unsigned* bar, unsigned target, unsigned* s_lost, unsigned limit = 20000000u) {
   const unsigned g = blockIdx.x % 8;
   const unsigned epoch = target;
   unsigned* rel = bar + 9 * 32;
@@ -69,7 +69,7 @@ __device__ __forceinline__ bool w2_wait(unsigned* bar, unsigned target, unsigned
     unsigned spins = 0;
     while (__hip_atomic_load(&rel[g * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > 20000000u || w2_lds_ld(s_lost)) { ok = false; break; }
+      if (++spins > limit || w2_lds_ld(s_lost)) { ok = false; break; }
     }
   }
   // Acquire side of the hand-over FOR THE COMPILER: the payload is read with relaxed agent-scope (sc1) loads, which the
@@ -282,14 +282,14 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
         unsigned* X2 = A.sh_bar + (2 * g + 1) * W2_BARW;
         // the proposals of group g, version v, are complete: wave 2 polls, the other evaluators watch an LDS word it then sets
         if (wave == 2) {
-          const bool ok = w2_wait(X1, (unsigned)v * ((ng == 4) ? 4u : 8u), s_lost);   // (shards that own chains of the group)
+          const bool ok = w2_wait(X1, (unsigned)v * ((ng == 4) ? 4u : 8u), s_lost, (A.debug & 512) ? 400000u : 20000000u);   // (shards that own chains of the group)
           if (!ok) { if (lane == 0) w2_lds_st(s_lost, 1u); lost = true; }
           else if (lane == 0) w2_lds_st(&s_sync[g], (unsigned)v);
         } else {
           unsigned spins = 0;
           while (w2_lds_ld(&s_sync[g]) < (unsigned)v) {
             __builtin_amdgcn_s_sleep(1);
-            if (w2_lds_ld(s_lost) || ++spins > 40000000u) { lost = true; break; }
+            if (w2_lds_ld(s_lost) || ++spins > ((A.debug & 512) ? 800000u : 40000000u)) { lost = true; break; }
           }
           asm volatile("" ::: "memory");   // (compiler-level acquire of the LDS relay, as in w2_wait)
         }
@@ -380,7 +380,8 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
   auto publish = [&](unsigned epoch, bool store) {
     if (has && store && lane < nb) sh_store(&A.sh_th[(long long)lane * NCP + g * NH + (int)(cl / ng)], L.th1[lane]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) w2_arrive(X1, epoch);
+    // (mode=512, tests: workgroup 1 never announces version 3 of its group-0 proposals -- a lost hand-over, exercised)
+    if (lane == 0 && !((A.debug & 512) && blockIdx.x == 1 && epoch == 3 && g == 0)) w2_arrive(X1, epoch);
   };
   // row bookkeeping (R/mcmc.R:786-813), as in mh_sweep_kernel
   const int burnin = (int)A.burnin, thin = (int)A.thin;
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
     // (a wave without a chain waits and signals like the others: an arrival for version v + 1 must not come before every
     //  workgroup's arrival for version v)
     {
-      const bool ok = w2_wait(X2, (unsigned)v * 8u, s_lost);
+      const bool ok = w2_wait(X2, (unsigned)v * 8u, s_lost, (A.debug & 512) ? 400000u : 20000000u);
       if (!ok) { if (lane == 0) w2_lds_st(s_lost, 1u); lost = true; break; }
     }
     W2_OW_STAMP(0);

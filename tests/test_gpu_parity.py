@@ -708,6 +708,55 @@ def test_ram_families_in_the_dataflow_form(E, O, monkeypatch):
             assert abi.last_kernel() == "wide-dataflow"
 
 
+@pytest.mark.parametrize("form", ["logistic-sharded", "wide-sequential", "wide-dataflow"])
+def test_a_lost_hand_over_ends_in_status_5_not_in_a_hang(E, monkeypatch, form):
+    """The grid-wide hand-overs of the observation-sharded kernels, with a FAULT: knob mode=512 makes workgroup 1 skip ONE
+    arrival (epoch 3) and shortens every spin bound.  Every waiter must give up, every loop must run out and the grid must
+    drain: the call returns, chains carry status 5 (FMCMC_CHAIN_SYNC_TIMEOUT) and the host raises 'results invalid' instead
+    of handing out samples -- the path that had only ever been argued, not run."""
+    import time
+    import torch
+    from fmcmc_amd import _abi as abi
+    if torch.cuda.get_device_properties(0).multi_processor_count < 256:
+        pytest.skip("the sharded forms need all 256 CUs")
+    set_knob(monkeypatch, "shard", "1")
+    set_knob(monkeypatch, "mode", "512")
+    big = E.DBL_MAX
+    if form == "logistic-sharded":
+        rng = np.random.default_rng(3)
+        n, p, C = 3000, 3, 40
+        X = rng.standard_normal((n, p)); y = (rng.uniform(size=n) < 0.4).astype(np.float64)
+        gm = E.DeviceModel(abi.FAM_LOGISTIC, X, y, intercept=True, guard=False, prior_div=8.0)
+        k = p + 1
+        gk = E.KernelSpec(abi.KERNEL_NORMAL, k, np.zeros(k), np.full(k, 0.05), np.full(k, -big), np.full(k, big), np.zeros(k, np.uint8))
+        init = 0.1 * rng.standard_normal((C, k))
+    else:
+        set_knob(monkeypatch, "cw", "2")
+        set_knob(monkeypatch, "wide2", "1" if form == "wide-dataflow" else "0")
+        X, y = synth_linreg(1500, 20, 4242, beta=np.linspace(1.0, -1.0, 21))
+        k, C = 22, 512
+        gm = E.DeviceModel(abi.FAM_GAUSSIAN_LINREG, X, y)
+        gk = E.KernelSpec(abi.KERNEL_RAM, k, np.zeros(k), np.ones(k), np.full(k, -big), np.full(k, big), np.zeros(k, np.uint8))
+        init = jitter_init(list(np.linspace(1.0, -1.0, 21)) + [4.0], C, 6)
+        init[:, -1] = np.abs(init[:, -1])
+    st = E.ChainState(init, gk.kf)
+    t0 = time.time()
+    r = E.sweep(gm, gk, st, 40, seed=7, check=False)
+    torch.cuda.synchronize()
+    assert time.time() - t0 < 120.0
+    want = {"logistic-sharded": "logistic-sharded", "wide-sequential": "streamed-wide-sharded-mfma", "wide-dataflow": "wide-dataflow"}[form]
+    assert abi.last_kernel() == want
+    status = r.status.cpu().numpy()
+    assert (status == abi.CHAIN_SYNC_TIMEOUT).any() and set(np.unique(status)) <= {0, abi.CHAIN_SYNC_TIMEOUT}
+    with pytest.raises(RuntimeError, match="results of this call are invalid"):
+        E.raise_on_chain_error(r)
+    # the device is fine afterwards: the same call without the fault runs clean
+    set_knob(monkeypatch, "mode", "0")
+    r2 = E.sweep(gm, gk, E.ChainState(init, gk.kf), 40, seed=7, check=False)
+    torch.cuda.synchronize()
+    assert int(r2.status.abs().sum().item()) == 0
+
+
 @pytest.mark.parametrize("chains,cw,n,p,intercept", [
     (256, "1", 10000, 16, True),      # 256 workgroups x 2 canonical lanes, 20 slots: the full slice of 40 observations
     (128, "1", 4099, 21, True),       # 128 workgroups x 4 lanes, ragged last slot
