@@ -19,7 +19,8 @@ ABI_VERSION = 4
 RNG_PHILOX, RNG_FED = 0, 1
 OK, ERR_ARG, ERR_DEVICE, ERR_CHAIN, ERR_UNSUPPORTED = 0, 1, 2, 3, 4
 CHAIN_OK, CHAIN_NAN_LOGPOST, CHAIN_NAN_RATIO, CHAIN_NOT_PD, CHAIN_BAD_WINDOW, CHAIN_SYNC_TIMEOUT = 0, 1, 2, 3, 4, 5
-MAX_K = 64
+MAX_K = 128        # (FMCMC_MAX_K; every kernel / option up to MAX_K_WAVE, the joint simple kernels, kernel_adapt and kernel_ram beyond)
+MAX_K_WAVE = 64
 
 EXPORTS = ["fmcmc_abi_version", "fmcmc_last_error", "fmcmc_last_kernel", "fmcmc_device_count", "fmcmc_kept_rows",
            "fmcmc_validate", "fmcmc_mcmc_run_dev", "fmcmc_mcmc_run_host", "fmcmc_gelman_partial_len",

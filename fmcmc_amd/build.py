@@ -6,7 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = [os.path.join(HERE, "csrc", "mh_engine.hip"), os.path.join(HERE, "csrc", "gelman.hip")]
 DEPS = [os.path.join(ROOT, "include", f) for f in ("fmcmc_amd.h", "fmh_detmath.h", "fmh_philox.h")] + \
-       [os.path.join(HERE, "csrc", f) for f in ("mh_common.hpp", "mh_streamed.hpp", "mh_pipe.hpp", "mh_mfma.hpp", "mh_mfma_rep.hpp", "mh_spec.hpp", "mh_wide2.hpp", "mh_mfma_ad.hpp")] + \
+       [os.path.join(HERE, "csrc", f) for f in ("mh_common.hpp", "mh_streamed.hpp", "mh_pipe.hpp", "mh_mfma.hpp", "mh_mfma_rep.hpp", "mh_spec.hpp", "mh_wide2.hpp", "mh_mfma_ad.hpp", "mh_bigk.hpp")] + \
        [os.path.join(ROOT, "include", "fmh_logit_tab.h")]
 OUT = os.path.join(HERE, "lib", "libfmcmc_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -292,7 +292,7 @@ int64_t fmcmc_gelman_work_len(int64_t nchains, int32_t p) { return nchains * ((i
 int fmcmc_gelman_partial_dev(const double* samples, int64_t nchains, int32_t k, int64_t S, int64_t row0,
                              int64_t N, const int32_t* cols, int32_t p, const double* center,
                              double* work, double* partial, void* hip_stream) {
-  if (!samples || !cols || !work || !partial || p < 1 || p > FMCMC_MAX_K || nchains < 1 || N < 2 ||
+  if (!samples || !cols || !work || !partial || p < 1 || p > FMCMC_MAX_K_WAVE || nchains < 1 || N < 2 ||
       row0 < 0 || row0 + N > S)
     return FMCMC_ERR_ARG;
   hipStream_t st = (hipStream_t)hip_stream;
@@ -314,7 +314,7 @@ int fmcmc_gelman_partial_dev(const double* samples, int64_t nchains, int32_t k, 
 // Host finish. partial is the (all-reduced) vector; xbar sums are relative to `center`.
 // psrf[p] point estimates (coda's "Point est."), *mpsrf multivariate (NaN when p == 1).
 int fmcmc_gelman_finish(const double* P, int32_t p, int64_t N, double* psrf, double* mpsrf) {
-  if (!P || p < 1 || p > FMCMC_MAX_K || N < 2) return FMCMC_ERR_ARG;
+  if (!P || p < 1 || p > FMCMC_MAX_K_WAVE || N < 2) return FMCMC_ERR_ARG;
   const double m = P[0];
   if (m < 2) return FMCMC_ERR_ARG;
   const double* sx = P + 1;

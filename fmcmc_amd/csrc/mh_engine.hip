@@ -47,6 +47,7 @@
 #include "mh_spec.hpp"
 #include "mh_wide2.hpp"
 #include "mh_mfma_ad.hpp"
+#include "mh_bigk.hpp"
 
 namespace {
 
@@ -268,6 +269,16 @@ int fmcmc_validate(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_run
   if (kn->k < 1 || kn->k > FMCMC_MAX_K) {
     set_err("number of parameters k=%d outside [1, %d]", kn->k, FMCMC_MAX_K);
     return FMCMC_ERR_UNSUPPORTED;
+  }
+  if (kn->k > FMCMC_MAX_K_WAVE) {   // one workgroup per chain (mh_sweep_bigk): what it implements
+    const bool simple_joint = (kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE || kn->kind == FMCMC_KERNEL_UNIF || kn->kind == FMCMC_KERNEL_UNIF_REFLECTIVE) &&
+                              kn->scheme == FMCMC_SCHEME_JOINT;
+    const bool adapt_plain = kn->kind == FMCMC_KERNEL_ADAPT && kn->bw == 0 && kn->freq <= 1;
+    if (!(simple_joint || adapt_plain || kn->kind == FMCMC_KERNEL_RAM)) {
+      set_err("k = %d > %d parameters: supported are kernel_normal(_reflective) / kernel_unif(_reflective) with scheme = 'joint', "
+              "kernel_adapt(bw = 0, freq = 1) and kernel_ram", kn->k, FMCMC_MAX_K_WAVE);
+      return FMCMC_ERR_UNSUPPORTED;
+    }
   }
   int kexp = -1;
   switch (m->family) {
@@ -520,6 +531,19 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
       arch_ok = (hipGetDeviceProperties(&prop, dev) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) ? 1 : 0;
     }
     if (!arch_ok) { set_err("this library is built for gfx950 (MI355X); the current device is another architecture"); return FMCMC_ERR_DEVICE; }
+  }
+  // more parameters than a wavefront has lanes: one workgroup per chain (mh_bigk.hpp); fmcmc_validate has refused what it lacks
+  if (kn->k > FMCMC_MAX_K_WAVE) {
+    const size_t blds = sizeof(double) * bigk_lds_doubles(kn->k, kf, kn->kind);
+    if (blds > 160 * 1024) { set_err("LDS budget exceeded (k=%d)", kn->k); return FMCMC_ERR_UNSUPPORTED; }
+    hipError_t eb = hipFuncSetAttribute((const void*)mh_sweep_bigk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds);
+    if (eb == hipSuccess) {
+      g_kernel = "big-k";
+      hipLaunchKernelGGL(mh_sweep_bigk, dim3((unsigned)run->nchains), dim3(NT), blds, stream, A);
+      eb = hipGetLastError();
+    }
+    if (eb != hipSuccess) { set_err("HIP launch failed: %s", hipGetErrorString(eb)); return FMCMC_ERR_DEVICE; }
+    return FMCMC_OK;
   }
   // register-resident variant: Gaussian linreg whose data fits the VGPR budget of 512 threads
   int res_p = -1, res_opt = 0;

@@ -37,7 +37,12 @@ extern "C" {
 #endif
 
 #define FMCMC_ABI_VERSION 4
-#define FMCMC_MAX_K 64 /* parameters per chain supported by the device kernels */
+#define FMCMC_MAX_K 128 /* parameters per chain supported by the device kernels (R/kernel_ram.R:93-121, R/kernel_adapt.R:87-115: any k) */
+/* Up to FMCMC_MAX_K_WAVE parameters a chain's rows live in the lanes of one wavefront and every kernel, scheme and option is
+ * available; from there to FMCMC_MAX_K one workgroup serves a chain (mh_sweep_bigk): kernel_normal(_reflective) /
+ * kernel_unif(_reflective) with scheme = "joint", kernel_adapt(bw = 0, freq = 1), kernel_ram -- anything else, and
+ * fmcmc_gelman_partial_dev (the window covariance tiles), is refused above FMCMC_MAX_K_WAVE with FMCMC_ERR_UNSUPPORTED. */
+#define FMCMC_MAX_K_WAVE 64
 
 /* ---- log-posterior families: the `fun` argument of MCMC() (R/mcmc.R:327) ---------- */
 enum {

@@ -648,6 +648,49 @@ def test_adaptive_kernels_on_the_streamed_mfma_evaluation(E, O, n, p, intercept)
     assert abi.last_kernel() == "mfma-adaptive"
 
 
+@pytest.mark.parametrize("k", [65, 100, 128])
+@pytest.mark.parametrize("kind_name", ["ram", "adapt", "normal", "ram_bounded"])
+def test_more_parameters_than_a_wavefront_has_lanes(E, O, k, kind_name):
+    """64 < k <= 128 (round 4: FMCMC_MAX_K was 64; R/kernel_ram.R:93-121 and R/kernel_adapt.R:87-115 take any k, the authors'
+    benchmark is k = 100): mh_sweep_bigk, one workgroup per chain, packed triangular matrices -- the oracle's bits for
+    kernel_ram (product-form update, prefix sums over 128 rows), kernel_adapt (recursive covariance + Cholesky),
+    kernel_normal_reflective, bounded kernel_ram (second evaluation), two consecutive calls, a fixed parameter."""
+    from fmcmc_amd import _abi as abi
+    p = k - 2
+    n = 700 + k
+    X, y = synth_linreg(n, p, 8000 + k, beta=np.linspace(1.0, -1.0, p + 1), sigma=2.0)
+    init = jitter_init(list(np.linspace(1.0, -1.0, p + 1)) + [2.0], 3, 600 + k)
+    init[:, -1] = np.abs(init[:, -1])
+    fixed = [False] * k
+    fixed[3] = (k == 100)                       # one case with a fixed parameter (kf = k - 1)
+    if kind_name == "ram":
+        run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, k, init, nsteps=40, calls=2, fixed=fixed)
+    elif kind_name == "ram_bounded":
+        run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, k, init, nsteps=30, calls=2, lb=-1.5, ub=2.5, fixed=fixed)
+    elif kind_name == "adapt":
+        run_both(E, O, O.FAM_LINREG, X, y, O.K_ADAPT, k, init, nsteps=40, calls=2, warmup=10, fixed=fixed)
+    else:
+        run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL_REFLECTIVE, k, init, nsteps=50, burnin=4, thin=3, calls=2, scale=0.01,
+                 lb=-3.0, ub=4.0, fixed=fixed)
+    assert abi.last_kernel() == "big-k"
+
+
+def test_what_the_big_k_kernel_refuses(E, O):
+    """Above 64 parameters the single-parameter schemes, the mirror kernels and the windowed / strided kernel_adapt are
+    refused with a message (FMCMC_ERR_UNSUPPORTED), not mis-run."""
+    from fmcmc_amd import _abi as abi
+    k = 70
+    X, y = synth_linreg(500, k - 2, 5, beta=np.linspace(1.0, -1.0, k - 1))
+    gm = E.DeviceModel(abi.FAM_GAUSSIAN_LINREG, X, y)
+    big = E.DBL_MAX
+    z, o = np.zeros(k), np.ones(k)
+    for kw in (dict(kind=abi.KERNEL_NORMAL, scheme=abi.SCHEME_ORDERED), dict(kind=abi.KERNEL_NMIRROR), dict(kind=abi.KERNEL_ADAPT, bw=20, warmup=30)):
+        kind = kw.pop("kind")
+        gk = E.KernelSpec(kind, k, z, 0.01 * o, -big * o, big * o, np.zeros(k, np.uint8), **kw)
+        with pytest.raises(ValueError, match="k = 70 > 64 parameters"):
+            E.sweep(gm, gk, E.ChainState(np.tile(np.r_[np.zeros(k - 1), 2.0], (2, 1)), k), 20)
+
+
 def test_small_shape_mfma_equals_wave_specialised_kernel(E, O, monkeypatch):
     """README-size data (p = 1, n ~ 1000): the MFMA kernel (default) and the wave-specialised VALU kernel it replaced there
     (knob mfma=0) give the oracle's bits, normal and reflective kernels."""
