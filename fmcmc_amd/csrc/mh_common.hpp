@@ -332,25 +332,23 @@ __device__ __forceinline__ ChainLds chain_lds(double* base, int k, int kf, int k
 
 // ---- logistic family: g(|eta|) = log(2 cosh(eta / 2)) off the row-polynomial table (include/fmh_detmath.h, fmh_logit_g):
 // chain-vectorised twin of fmh_logit_g_scaled, the same operations in the same order for every element, so the same bits.
-// The table (2400 rows x 6 coefficients, 115 KB) is staged in LDS by the logistic-only instantiations as THREE arrays of
-// 16-byte coefficient PAIRS (c0 c1 | c2 c3 | c4 c5) read with three ds_read_b128 from one address + immediate offsets: 16-byte
+// The table (2400 rows x 6 coefficients, 115 KB) is staged in LDS by the logistic-only instantiations row by row (48 bytes:
+// c0 c1 | c2 c3 | c4 c5) and a row is read with three ds_read_b128 from ONE address, 48 j, + immediate offsets 0 / 16 / 32
+// (as three arrays of pairs the third array's offset, 76832, no longer fits the 16-bit offset field: one more vector add per
+// lookup): 16-byte
 // reads run at the full LDS rate (256 B/clk) with four waves per CU, 8-byte reads need four waves per SIMD for theirs
 // (MI355X_MICROARCH.md, LDS), and tools/probe_logit_grid.hip measured the 8-byte form a third slower.  What a lookup costs
 // beyond that is bank conflicts between the rows the lanes of one read hit: lanes = observations (the chain-sharded loops)
 // scatter over the table, ~2.9-way; lanes = chains of one observation (the observation-sharded loop, logit_shard) hit equal or
 // neighbouring rows, which neighbouring addresses serve without conflict.
 typedef double lg_v2d __attribute__((ext_vector_type(2)));
-constexpr int LG_STRIDE = FMH_LG_ROWS + 1;            // 16-byte elements from one pair array to the next
-constexpr int LG_LDS_DOUBLES = 3 * LG_STRIDE * 2;
+constexpr int LG_LDS_DOUBLES = FMH_LG_ROWS * 6;       // rows of 48 bytes, c0 .. c5, as in include/fmh_logit_tab.h
 __device__ __forceinline__ double* logit_table_align(double* p) {   // 16-byte aligned start inside [p, p + 2)
   return (double*)(((unsigned long long)p + 15ull) & ~15ull);
 }
 __device__ __forceinline__ void logit_stage_table(double* s_tab) {
   const double* t = fmh_lg_tab_();
-  for (int i = threadIdx.x; i < FMH_LG_ROWS * 6; i += blockDim.x) {
-    const int j = i / 6, c = i - 6 * j;
-    s_tab[((c >> 1) * LG_STRIDE + j) * 2 + (c & 1)] = t[i];
-  }
+  for (int i = threadIdx.x; i < FMH_LG_ROWS * 6; i += blockDim.x) s_tab[i] = t[i];
 }
 
 // LDSTAB is a COMPILE-TIME property (the logistic-only instantiations always stage the table; the all-family kernels read
@@ -368,7 +366,7 @@ __device__ __forceinline__ void logit_g_vec(const double (&us)[CW], double (&out
     s[c] = __builtin_amdgcn_fract(us[c]);
     unsigned j = (unsigned)us[c];                      // (saturating; NaN -> 0)
     j = (j < (unsigned)FMH_LG_ROWS) ? j : (unsigned)(FMH_LG_ROWS - 1);   // an element beyond the table is replaced below
-    if constexpr (LDSTAB) { p0[c] = ltab[j]; p1[c] = ltab[LG_STRIDE + j]; p2[c] = ltab[2 * LG_STRIDE + j]; }
+    if constexpr (LDSTAB) { p0[c] = ltab[3u * j]; p1[c] = ltab[3u * j + 1u]; p2[c] = ltab[3u * j + 2u]; }
     else { p0[c] = gtab[3u * j]; p1[c] = gtab[3u * j + 1u]; p2[c] = gtab[3u * j + 2u]; }
   }
 #pragma unroll
@@ -961,10 +959,10 @@ __device__ __attribute__((noinline)) void logit_partials(LogitEval a) {
       sv[c] = __builtin_amdgcn_fract(ue);
       unsigned int j = (unsigned int)ue;
       if (CHECKED) j = (j < (unsigned)FMH_LG_ROWS) ? j : (unsigned)(FMH_LG_ROWS - 1);
-      const ldsb_t row = (ldsb_t)(unsigned long long)(tabaddr + 16u * j);
+      const ldsb_t row = (ldsb_t)(unsigned long long)(tabaddr + 48u * j);
       p0[c] = *(lds2_t)(row);
-      p1[c] = *(lds2_t)(row + 16 * LG_STRIDE);
-      p2[c] = *(lds2_t)(row + 32 * LG_STRIDE);
+      p1[c] = *(lds2_t)(row + 16);
+      p2[c] = *(lds2_t)(row + 32);
     }
 #pragma unroll
     for (int c = 0; c < CW; c++) {
@@ -1146,12 +1144,11 @@ __device__ __attribute__((noinline)) void logit_shard(LogitShard c) {
     if (fast && npass > 0) {
       double xa[2][PL], xb[2][PL], sva[2][NCH], svb[2][NCH];
       lg_v2d pra[2][NCH][3], prb[2][NCH][3];
-      auto sload = [&](double (&x)[2][PL], int pass) {
-        const int pc = pass < npass ? pass : npass - 1;      // (beyond the end: a repeat that is not accumulated)
-#pragma unroll
+      auto sload = [&](double (&x)[2][PL], int pass) {         // (beyond the end: the next slice or the padding behind the last
+#pragma unroll                                                 //  one -- logit_build_slices -- read but never accumulated)
         for (int q = 0; q < 2; q++)
 #pragma unroll
-          for (int u = 0; u < PL; u++) x[q][u] = slice[(pc * 2 + q) * PL + u];
+          for (int u = 0; u < PL; u++) x[q][u] = slice[(pass * 2 + q) * PL + u];
       };
       auto front = [&](const double (&x)[2][PL], double (&sv)[2][NCH], lg_v2d (&pr)[2][NCH][3]) {   // 64 eta, reduction, lookups
         unsigned ad[2][NCH];
@@ -1164,7 +1161,7 @@ __device__ __attribute__((noinline)) void logit_shard(LogitShard c) {
             for (int u = 0; u < PL; u++) es = fmh_fma(x[q][u], bs[h][u], es);
             const double ue = __builtin_fabs(es);
             sv[q][h] = __builtin_amdgcn_fract(ue);
-            ad[q][h] = tabaddr + 16u * (unsigned)ue;
+            ad[q][h] = tabaddr + 48u * (unsigned)ue;      // (v_mad_u32_u24)
           }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1172,7 +1169,7 @@ __device__ __attribute__((noinline)) void logit_shard(LogitShard c) {
 #pragma unroll
           for (int h = 0; h < NCH; h++)
 #pragma unroll
-            for (int k = 0; k < 3; k++) pr[q][h][k] = *(lds2_t)((ldsb_t)(unsigned long long)ad[q][h] + 16 * LG_STRIDE * k);
+            for (int k = 0; k < 3; k++) pr[q][h][k] = *(lds2_t)((ldsb_t)(unsigned long long)ad[q][h] + 16 * k);
         __builtin_amdgcn_sched_barrier(0);
       };
       auto back = [&](const double (&sv)[2][NCH], const lg_v2d (&pr)[2][NCH][3]) {                     // polynomials

@@ -897,12 +897,14 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
     }
     if (lshard) {
       double* shw = nullptr;
-      const size_t nxs = (size_t)nb_launch * nslots * 2 * m->p, nth = ((size_t)kn->k * (ch_launch + SH_PAD) + 7) & ~(size_t)7,
+      // (+ 8 observations behind the last slice: the pipelined loop's scalar loads run up to three passes ahead without a clamp)
+      const size_t nxs = (size_t)nb_launch * nslots * 2 * m->p + 8 * (size_t)m->p, nth = ((size_t)kn->k * (ch_launch + SH_PAD) + 7) & ~(size_t)7,
                    npt = (size_t)(NT + SH_PAD) * ch_launch, nbar = 32 * 20 / 2;
       e = hipMallocAsync((void**)&shw, sizeof(double) * (nxs + nth + npt + nbar), stream);
       if (e != hipSuccess) { set_err("hipMallocAsync(sharded evaluation) failed: %s", hipGetErrorString(e)); return FMCMC_ERR_DEVICE; }
       shw_guard.p = shw; shw_guard.s = stream;
       double* thw = shw; double* ptw = thw + nth; unsigned* bar = (unsigned*)(ptw + npt); double* xs = ptw + npt + nbar;
+      (void)hipMemsetAsync(xs + (size_t)nb_launch * nslots * 2 * m->p, 0, sizeof(double) * 8 * (size_t)m->p, stream);
       hipLaunchKernelGGL(logit_build_slices, dim3((unsigned)nb_launch), dim3(256), 0, stream, m->X, (long long)m->n, m->p, nslots, xs);
       A.shard = 2; A.sh_nslots = nslots; A.sh_xs = xs; A.sh_ys = nullptr; A.sh_th = thw; A.sh_part = ptw; A.sh_bar = bar;
       g_kernel = "logistic-sharded";

@@ -24,6 +24,9 @@
 #ifndef NCH
 #define NCH 2              // chains per thread
 #endif
+#ifndef XMODE
+#define XMODE 0      // 0: covariates as scalar loads one pass ahead; 1: never reloaded (ablation); 2: two passes ahead; 3: from LDS
+#endif
 #ifndef SPREAD
 #define SPREAD 0.01        // sd of the chains' coefficients around the centre
 #endif
@@ -40,6 +43,10 @@ __global__ void __launch_bounds__(NT, 1) loop(const double* __restrict__ xs /*[2
                                                int nchains, const double* __restrict__ gtab, double* part /*[chains][512]*/, int reps) {
   extern __shared__ double s_tab[];
   for (int i = threadIdx.x; i < NPAIR * STRIDE * 2; i += NT) s_tab[i] = gtab[i];
+  double* s_x = s_tab + NPAIR * STRIDE * 2;          // XMODE 3: this workgroup's slice, [nobs][6] doubles (48 B per observation)
+#if XMODE == 3
+  for (int i = threadIdx.x; i < nobs * 6; i += NT) { const int o = i / 6, u = i - 6 * o; s_x[i] = (u < PL) ? xs[((size_t)blockIdx.x * nobs + o) * PL + u] : 0.0; }
+#endif
   __syncthreads();
   typedef __attribute__((address_space(3))) const v2d* lds2_t;
   typedef __attribute__((address_space(3))) const char* ldsb_t;
@@ -68,7 +75,8 @@ __global__ void __launch_bounds__(NT, 1) loop(const double* __restrict__ xs /*[2
       double xa[OB][PL], xb[OB][PL], sva[OB][NCH], svb[OB][NCH];
       v2d pra[OB][NCH][NPAIR], prb[OB][NCH][NPAIR];
       auto sload = [&](double (&x)[OB][PL], int pass) {
-        const int pc = pass < npass ? pass : npass - 1;
+        int pc = pass < npass ? pass : npass - 1;
+        if (XMODE == 4) pc &= 3;                                  // (ablation: the same four passes over and over -- always cache hits)
 #pragma unroll
         for (int b = 0; b < OB; b++)
 #pragma unroll
@@ -111,19 +119,83 @@ __global__ void __launch_bounds__(NT, 1) loop(const double* __restrict__ xs /*[2
           }
         __builtin_amdgcn_sched_barrier(0);
       };
+#if 0
+#define XMODE_UNUSED 0      // 0: covariates of pass p + 2 loaded one pass ahead (product); 1: never reloaded (timing ablation: what the
+#endif
+#if XMODE == 3
+      // covariates from LDS: uniform-address ds_read_b128 (a broadcast), ONE register set re-loaded in place the moment a pass's
+      // etas are formed; everything on lgkmcnt is then an LDS read, in order
+      const unsigned xaddr = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const double*)s_x;
+      auto xload = [&](double (&x)[OB][PL], int pass) {
+        const int pc = pass < npass ? pass : npass - 1;
+        const ldsb_t base = (ldsb_t)(unsigned long long)(xaddr + (unsigned)(pc * OB) * 48u);
+#pragma unroll
+        for (int b = 0; b < OB; b++) {
+          const v2d p0 = *(lds2_t)(base + 48 * b), p1 = *(lds2_t)(base + 48 * b + 16), p2 = *(lds2_t)(base + 48 * b + 32);
+          x[b][0] = p0.x; x[b][1] = p0.y; x[b][2] = p1.x; x[b][3] = p1.y; x[b][4] = p2.x;
+        }
+      };
+      auto front3 = [&](double (&x)[OB][PL], int nextpass, double (&sv)[OB][NCH], v2d (&pr)[OB][NCH][NPAIR]) {
+        unsigned ad[OB][NCH];
+#pragma unroll
+        for (int b = 0; b < OB; b++)
+#pragma unroll
+          for (int h = 0; h < NCH; h++) {
+            double eta = b0[h];
+#pragma unroll
+            for (int u = 0; u < PL; u++) eta = __builtin_fma(x[b][u], bs[h][u], eta);
+            const double ue = __builtin_fabs(eta);
+            sv[b][h] = __builtin_amdgcn_fract(ue);
+            ad[b][h] = tabaddr + 16u * (unsigned)ue;
+          }
+        __builtin_amdgcn_sched_barrier(0);
+        xload(x, nextpass);
+#pragma unroll
+        for (int b = 0; b < OB; b++)
+#pragma unroll
+          for (int h = 0; h < NCH; h++)
+#pragma unroll
+            for (int k = 0; k < NPAIR; k++) pr[b][h][k] = *(lds2_t)((ldsb_t)(unsigned long long)ad[b][h] + 16 * STRIDE * k);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      xload(xa, 0);
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      front3(xa, 1, sva, pra);
+      for (int p = 0; p < npass; p += 2) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        front3(xa, p + 2, svb, prb);              // pass p + 1
+        back(sva, pra);                           // pass p
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        front3(xa, p + 3, sva, pra);              // pass p + 2
+        if (p + 1 < npass) back(svb, prb);        // pass p + 1
+      }
+#elif XMODE == 2
+      double xc[OB][PL];
+      sload(xa, 0); sload(xb, 1); sload(xc, 2);
+      front(xa, sva, pra);
+      for (int p = 0; p < npass; p += 6) {       // (npass is a multiple of 2; the clamped repeats beyond the end are not accumulated)
+        __builtin_amdgcn_s_waitcnt(0xC07F); sload(xa, p + 3); front(xb, svb, prb); if (p + 0 < npass) back(sva, pra);
+        __builtin_amdgcn_s_waitcnt(0xC07F); sload(xb, p + 4); front(xc, sva, pra); if (p + 1 < npass) back(svb, prb);
+        __builtin_amdgcn_s_waitcnt(0xC07F); sload(xc, p + 5); front(xa, svb, prb); if (p + 2 < npass) back(sva, pra);
+        __builtin_amdgcn_s_waitcnt(0xC07F); sload(xa, p + 6); front(xb, sva, pra); if (p + 3 < npass) back(svb, prb);
+        __builtin_amdgcn_s_waitcnt(0xC07F); sload(xb, p + 7); front(xc, svb, prb); if (p + 4 < npass) back(sva, pra);
+        __builtin_amdgcn_s_waitcnt(0xC07F); sload(xc, p + 8); front(xa, sva, pra); if (p + 5 < npass) back(svb, prb);
+      }
+#else
       sload(xa, 0);
       sload(xb, 1);
       front(xa, sva, pra);                        // pass 0's lookups in flight
       for (int p = 0; p < npass; p += 2) {
         __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0): pass p's coefficients, pass p + 1's covariates
-        sload(xa, p + 2);
+        if (XMODE == 0 || XMODE == 4) sload(xa, p + 2);
         front(xb, svb, prb);                      // pass p + 1 (beyond the end: a clamped repeat, not accumulated)
         back(sva, pra);                           // pass p
         __builtin_amdgcn_s_waitcnt(0xC07F);
-        sload(xb, p + 3);
+        if (XMODE == 0 || XMODE == 4) sload(xb, p + 3);
         front(xa, sva, pra);                      // pass p + 2
         if (p + 1 < npass) back(svb, prb);        // pass p + 1
       }
+#endif
       __builtin_amdgcn_s_waitcnt(0xC07F);
 #pragma unroll
       for (int h = 0; h < NCH; h++) {
@@ -185,7 +257,7 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(dxs, xs.data(), xs.size() * 8, hipMemcpyHostToDevice));
   CK(hipMemcpy(db, beta.data(), beta.size() * 8, hipMemcpyHostToDevice));
   CK(hipMemcpy(dt, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
-  const size_t lds = tab.size() * 8;
+  const size_t lds = tab.size() * 8 + (XMODE == 3 ? (size_t)nobs * 6 * 8 : 0);
   CK(hipFuncSetAttribute((const void*)loop, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   float best = 1e30f;
