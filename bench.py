@@ -333,7 +333,7 @@ def run_config(cfg, chains, iters, steps, warmup, world, rank, dev, dist, torch,
     # the library's DEFAULT path of the same sweep (no materialised stream handed in: the library fills its own per step
     # window, mh_engine.hip launch_sweep), timed beside the fed form the steps above used: what a plain MCMC() call gets
     default_ms = None
-    if cfg.name in ("c2", "c3"):
+    if cfg.name in ("c2", "c3") and not getattr(cfg, "no_default_path", False):
         nd = max(2, min(steps, 12))
         d0, d1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         outs_d = None
@@ -462,6 +462,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true", help="headline invocation only: skip the short C3 / C4 / C5 sweeps reported under `configs`")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for N > 1 (nccl = RCCL; gloo moves the tensors through the host: tests on one GPU)")
+    ap.add_argument("--no-default-path", action="store_true", help="skip the extra leg that times the library's default path (profiling passes: keeps the sweep kernel's launches uniform)")
     ap.add_argument("--any-kernel", action="store_true", help="diagnosis: do not insist on the kernel the config is tuned for (FMCMC_AMD_DEBUG knobs)")
     ap.add_argument("--traffic-from", default=None, help="JSON of a PMC pass of this same command (hbm_bytes_per_launch)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -470,6 +471,7 @@ def main():
     args = ap.parse_args()
     cfg = Config(args.config)
     cfg.any_kernel = args.any_kernel
+    cfg.no_default_path = args.no_default_path
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ:

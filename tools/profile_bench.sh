@@ -15,7 +15,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 rm -rf $OUT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $GRAFT_REPO_ROOT/bench.py --config $CFG --steps 3 --warmup 1 --no-cpu-baseline --no-extra-configs"
+CMD="python3 $GRAFT_REPO_ROOT/bench.py --config $CFG --steps 3 --warmup 1 --no-cpu-baseline --no-extra-configs --no-default-path"
 pass() {   # pass <name> <rocprofv3 options...>
   local name=$1; shift
   rm -rf $OUT/$name
@@ -42,7 +42,7 @@ try:
 except OSError:
     pass
 summary = {"config": cfg, "tag": tag, "head": head,
-           "command": "bench.py --config %s --steps 3 --warmup 1 --no-cpu-baseline --no-extra-configs" % cfg}
+           "command": "bench.py --config %s --steps 3 --warmup 1 --no-cpu-baseline --no-extra-configs --no-default-path" % cfg}
 ks = sorted(glob.glob(out + "/kt/**/*kernel_stats.csv", recursive=True))
 assert len(ks) <= 1, "more than one kernel_stats.csv in a fresh pass directory: %s" % ks
 sweep_name, sweep_avg = None, None
