@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FMCMC_ABI_VERSION 4
+#define FMCMC_ABI_VERSION 5
 #define FMCMC_MAX_K 128 /* parameters per chain supported by the device kernels (R/kernel_ram.R:93-121, R/kernel_adapt.R:87-115: any k) */
 /* Up to FMCMC_MAX_K_WAVE parameters a chain's rows live in the lanes of one wavefront and every kernel, scheme and option is
  * available; from there to FMCMC_MAX_K one workgroup serves a chain (mh_sweep_bigk): kernel_normal(_reflective) /

@@ -22,11 +22,13 @@ FIELDS = {"TotalSGPRs": "sgprs", "VGPRs": "vgprs", "AGPRs": "agprs", "ScratchSiz
           "Occupancy [waves/SIMD]": "occupancy_waves_per_simd", "SGPRs Spill": "sgpr_spills", "VGPRs Spill": "vgpr_spills",
           "LDS Size [bytes/block]": "static_lds_bytes"}
 # the kernels the four GPU configs of BASELINE.md section 4 run on (bench.py fails if the dispatcher picks another one)
-PRODUCT = [("C2 headline", r"mh_sweep_mfma<1, 1, 20, false, false>"), ("C2 shape, > 4 GiB of samples", r"mh_sweep_mfma<1, 1, 20, false, true>"),
+PRODUCT = [("C2 headline", r"mh_sweep_mfma<1, 1, 20, false, false, false>"), ("C2 shape, > 4 GiB of samples", r"mh_sweep_mfma<1, 1, 20, false, true, false>"),
            ("C3", r"mh_sweep_spec<3, 20, 3>"),
            ("C3' kernel_ram k=5", r"mh_sweep_spec<3, 20, 4>"), ("C4", r"mh_sweep_wide2<4, 3>"),
            ("C4 slice product", r"shard_columns_mfma<2, 3, 12>"),
-           ("C5", r"mh_sweep_kernel<4, -1, 0, 2, 2, 1>"), ("rng stream", r"rng_fill_kernel"),
+           ("C5 (observation-sharded)", r"mh_sweep_kernel<4, -1, 2, 2, 2, 1>"), ("C5 shape, chain-sharded form", r"mh_sweep_kernel<4, -1, 0, 2, 2, 1>"),
+           ("n > 10240, normal kernels", r"mh_sweep_mfma<1, 1, 16, false, false, true>"), ("n > 10240, kernel_adapt k = 5", r"mh_sweep_mfma_ad<3, 1, 5>"),
+           ("64 < k <= 128", r"mh_sweep_bigk"), ("rng stream", r"rng_fill_kernel"),
            ("Gelman window covariance", r"gelman_chain_mfma"), ("Gelman chain sum", r"gelman_sum_kernel")]
 
 
@@ -60,7 +62,8 @@ def collect(extra_flags=()):
 # real (noinline) device functions that carry the hot loops of a product kernel: the remark pass reports kernels only, so
 # their registers and spill code are read off the ISA (-S): highest VGPR named, scratch instructions, and v_readlane /
 # v_writelane (SGPR spill traffic) inside their innermost hot loop (the largest backward-branch body below 400 instructions)
-DEVICE_FUNCS = [("C5 observation loop", "logit_partials<4, 5>"), ("C4 slice product", "shard_columns_mfma<2, 3, 12>"),
+DEVICE_FUNCS = [("C5 observation loop (observation-sharded)", "logit_shard<5, 2>"), ("C5 shape, chain-sharded observation loop", "logit_partials<4, 5>"),
+                ("C4 slice product", "shard_columns_mfma<2, 3, 12>"),
                 ("C4 factor update + proposal", "w2_ram_update_propose")]
 
 
