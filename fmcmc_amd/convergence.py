@@ -65,7 +65,26 @@ class convergence_gelman:
             center.copy_(samples[0, cols_d.long(), row0])
         if distributed:
             dist.all_reduce(center, op=dist.ReduceOp.SUM, group=group)
-        if Cn > 0:
+        if Cn > 0 and p > abi.MAX_K_WAVE:
+            # more free parameters than the MFMA window reduction tiles (64): the same per-chain statistics -- window mean relative
+            # to the centre, window covariance -- and their sums over the chains with torch on the device (64 < k <= 128 is the
+            # big-k kernel's territory: one chain per workgroup, speed is not the point there)
+            X = samples[:, cols_d.long(), row0:row0 + N] - center[None, :, None]
+            xbm = X.mean(dim=2)
+            Xc = X - xbm[:, :, None]
+            Sc = Xc @ Xc.transpose(1, 2) / float(N - 1)
+            s2 = Sc.diagonal(dim1=1, dim2=2)
+            partial[0] = float(Cn)
+            o = 1
+            for blk in (xbm.sum(0), (xbm[:, :, None] * xbm[:, None, :]).sum(0).reshape(-1), Sc.sum(0).reshape(-1), s2.sum(0), (s2 * s2).sum(0),
+                        (s2 * xbm).sum(0), (s2 * xbm * xbm).sum(0)):
+                partial[o:o + blk.numel()] = blk
+                o += blk.numel()
+            if self.check_invariant:
+                xb = xbm + center
+                partial[plen] = float(N) * xb.sum()
+                partial[plen + 1] = ((N - 1.0) * s2 + float(N) * xb * xb).sum()
+        elif Cn > 0:
             work = torch.empty(int(L.fmcmc_gelman_work_len(Cn, p)), dtype=torch.float64, device=dev)
             with torch.cuda.device(dev):
                 rc = L.fmcmc_gelman_partial_dev(samples.data_ptr(), Cn, k, stride, row0, N, cols_d.data_ptr(), p,

@@ -314,7 +314,7 @@ int fmcmc_gelman_partial_dev(const double* samples, int64_t nchains, int32_t k, 
 // Host finish. partial is the (all-reduced) vector; xbar sums are relative to `center`.
 // psrf[p] point estimates (coda's "Point est."), *mpsrf multivariate (NaN when p == 1).
 int fmcmc_gelman_finish(const double* P, int32_t p, int64_t N, double* psrf, double* mpsrf) {
-  if (!P || p < 1 || p > FMCMC_MAX_K_WAVE || N < 2) return FMCMC_ERR_ARG;
+  if (!P || p < 1 || p > FMCMC_MAX_K || N < 2) return FMCMC_ERR_ARG;   // (the host finish is general in p)
   const double m = P[0];
   if (m < 2) return FMCMC_ERR_ARG;
   const double* sx = P + 1;

@@ -200,6 +200,18 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
       }
       const double cop = ic ? tj[0] : 0.0;                      // C = intercept of chain j
       double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      // (EXT) the first streamed slots are requested BEFORE the resident ones run: their L2 round trip hides under ~1200 cycles of MFMAs
+      typedef double mf_d4 __attribute__((ext_vector_type(4)));
+      constexpr int RD = (NG == 1) ? 4 : 2;                       // slots in flight per wave (register ring)
+      const int next = EXT ? A.mf_next : 0;
+      const mf_d4* sp = reinterpret_cast<const mf_d4*>(A.mf_stream) + ((long long)wave * next * NG) * 64 + lane;
+      mf_d4 ring[EXT ? RD : 1][NG];
+      if constexpr (EXT) {
+#pragma unroll
+        for (int r = 0; r < RD; r++)
+#pragma unroll
+          for (int q = 0; q < NG; q++) ring[r][q] = sp[(((r < next) ? r : next - 1) * NG + q) * 64];
+      }
       // batches of MB independent MFMA chains followed by their MB dependent FMAs: the result latency of one MFMA is
       // covered by issuing the next ones, and the batch shape (not the allocator's leftovers) bounds the live results
 #pragma unroll
@@ -231,15 +243,6 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
       }
       if constexpr (EXT) {
         // the streamed slots: operands of slot e, group q, for this lane = 4 doubles at ((wave next + e) NG + q) 64 + lane
-        typedef double mf_d4 __attribute__((ext_vector_type(4)));
-        constexpr int RD = (NG == 1) ? 4 : 2;                     // slots in flight per wave (register ring)
-        const int next = A.mf_next;
-        const mf_d4* sp = reinterpret_cast<const mf_d4*>(A.mf_stream) + ((long long)wave * next * NG) * 64 + lane;
-        mf_d4 ring[RD][NG];
-#pragma unroll
-        for (int r = 0; r < RD; r++)
-#pragma unroll
-          for (int q = 0; q < NG; q++) ring[r][q] = sp[(((r < next) ? r : next - 1) * NG + q) * 64];
         double cml[4];                                              // C operands of the LAST slot (padding: 0, see above)
 #pragma unroll
         for (int g = 0; g < 4; g++) cml[g] = ((vbits >> g) & 1u) ? cop : 0.0;

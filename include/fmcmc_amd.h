@@ -40,8 +40,9 @@ extern "C" {
 #define FMCMC_MAX_K 128 /* parameters per chain supported by the device kernels (R/kernel_ram.R:93-121, R/kernel_adapt.R:87-115: any k) */
 /* Up to FMCMC_MAX_K_WAVE parameters a chain's rows live in the lanes of one wavefront and every kernel, scheme and option is
  * available; from there to FMCMC_MAX_K one workgroup serves a chain (mh_sweep_bigk): kernel_normal(_reflective) /
- * kernel_unif(_reflective) with scheme = "joint", kernel_adapt(bw = 0, freq = 1), kernel_ram -- anything else, and
- * fmcmc_gelman_partial_dev (the window covariance tiles), is refused above FMCMC_MAX_K_WAVE with FMCMC_ERR_UNSUPPORTED. */
+ * kernel_unif(_reflective) with scheme = "joint", kernel_adapt(bw = 0, freq = 1), kernel_ram -- anything else is refused above FMCMC_MAX_K_WAVE with FMCMC_ERR_UNSUPPORTED;
+ * fmcmc_gelman_partial_dev (MFMA window tiles) takes p <= FMCMC_MAX_K_WAVE columns (above it the host side forms the same partial
+ * sums itself, fmcmc_amd/convergence.py), fmcmc_gelman_finish any p <= FMCMC_MAX_K. */
 #define FMCMC_MAX_K_WAVE 64
 
 /* ---- log-posterior families: the `fun` argument of MCMC() (R/mcmc.R:327) ---------- */

@@ -211,6 +211,25 @@ def test_mcmc_autostop_matches_the_oracle(E, O, readme_data):
     assert list(ans.iters) == list(ro.iters)
 
 
+def test_mcmc_with_more_than_64_parameters_and_the_gelman_checker(E, O):
+    """MCMC(..., kernel_ram(), conv_checker = convergence_gelman()) at k = 70 (round 4: FMCMC_MAX_K 128): the chains come from
+    mh_sweep_bigk, the checker's window statistics from the host-side torch path above 64 columns -- the R-hat history, the
+    stop bulk and the samples equal the oracle's (R/mcmc.R:841-1019, R/convergence.R:191-246)."""
+    import fmcmc_amd as f
+    from fmcmc_amd import _abi as abi
+    k = 70
+    X, y = synth_linreg(600, k - 2, 11, beta=np.linspace(1.0, -1.0, k - 1), sigma=2.0)
+    init = np.tile(np.r_[np.linspace(1.0, -1.0, k - 1), 2.0], (3, 1)) + 0.02 * np.random.default_rng(3).standard_normal((3, k))
+    init[:, -1] = np.abs(init[:, -1])
+    chk = f.convergence_gelman(100, threshold=1.5)
+    ans = f.MCMC(init, f.gaussian_linreg(X, y), 600, seed=7, nchains=3, kernel=f.kernel_ram(), conv_checker=chk)
+    assert abi.last_kernel() == "big-k"
+    ro = O.mcmc_with_conv_checker(O.Model(O.FAM_LINREG, X, y), O.Kernel(O.K_RAM, k), init, 600, 3, 100, seed=7, threshold=1.5)
+    assert [h[0] for h in chk.history] == [h[0] for h in ro.history] and len(chk.history) >= 1
+    assert np.allclose([h[1] for h in chk.history], [h[1] for h in ro.history], rtol=1e-7)
+    assert np.array_equal(_bits(ans.as_array()), _bits(ro.samples))
+
+
 def test_logistic_and_large_k_ram(E, O):
     """BASELINE configs 4 and 5 in miniature: kernel_ram at k = 50, logistic with reflective bounds."""
     from test_gpu_parity import run_both, jitter_init
