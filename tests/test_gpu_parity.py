@@ -675,6 +675,22 @@ def test_more_parameters_than_a_wavefront_has_lanes(E, O, k, kind_name):
     assert abi.last_kernel() == "big-k"
 
 
+def test_big_k_kernel_with_the_logistic_family(E, O):
+    """k = 70 logistic regression (69 covariates + intercept) on mh_sweep_bigk: the all-family evaluation with the g table read
+    from global memory, the scaled coefficient copies and the data-only sums, normal and RAM kernels."""
+    from fmcmc_amd import _abi as abi
+    rng = np.random.default_rng(70)
+    n, p = 900, 69
+    X = rng.standard_normal((n, p)) * 0.3
+    beta = rng.uniform(-0.5, 0.5, p + 1)
+    y = (rng.uniform(size=n) < 1 / (1 + np.exp(-(beta[0] + X @ beta[1:])))).astype(np.float64)
+    init = jitter_init(beta, 3, 71)
+    run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_NORMAL, p + 1, init, nsteps=40, calls=2, prior_div=8.0, scale=0.01)
+    assert abi.last_kernel() == "big-k"
+    run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_RAM, p + 1, init, nsteps=30, prior_div=8.0)
+    assert abi.last_kernel() == "big-k"
+
+
 def test_what_the_big_k_kernel_refuses(E, O):
     """Above 64 parameters the single-parameter schemes, the mirror kernels and the windowed / strided kernel_adapt are
     refused with a message (FMCMC_ERR_UNSUPPORTED), not mis-run."""

@@ -3,7 +3,8 @@
 # Runs the kernel-trace pass of tools/profile_bench.sh for C4 with tools/segv_trace.c installed (bench.py loads it when
 # FMCMC_SEGV_TRACE=1; the program itself stays directly after `--`), and, for comparison, the same command unprofiled.
 # Output: gpurun_out/c4_exit_trace.txt (frames), gpurun_out/c4_exit_trace.log (return codes).
-mkdir -p $GRAFT_REPO_ROOT/gpurun_out
+mkdir -p $GRAFT_REPO_ROOT/gpurun_out $GRAFT_REPO_ROOT/tools/exp_bin
+[ -f $GRAFT_REPO_ROOT/tools/exp_bin/libsegv_trace.so ] || gcc -shared -fPIC -O1 $GRAFT_REPO_ROOT/tools/segv_trace.c -o $GRAFT_REPO_ROOT/tools/exp_bin/libsegv_trace.so
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_c4_exit
 rm -rf $OUT; mkdir -p $OUT
 rm -f $GRAFT_REPO_ROOT/gpurun_out/c4_exit_trace.txt
