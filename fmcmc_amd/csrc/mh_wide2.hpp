@@ -527,7 +527,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
         const int i = v + 1;
         const double* zt = s_z + (slot * 2 + (i & 1)) * (kz + 1);
         if (KIND == FMCMC_KERNEL_RAM) {   // R/kernel_ram.R:123-126
-          const double s = do_update ? w2_ram_update_propose((lds_dptr_t)SG, (lds_dptr_t)CF, (lds_dptr_t)zt, LD, kf)
+          const double s = (do_update && !(A.debug & 1024)) ? w2_ram_update_propose((lds_dptr_t)SG, (lds_dptr_t)CF, (lds_dptr_t)zt, LD, kf)   /* (1024: timing ablation, results invalid) */
                                      : w2_ram_propose((lds_dptr_t)SG, (lds_dptr_t)zt, LD, kf);
           if (lane < kf) {
             const int j = s_which[lane];
