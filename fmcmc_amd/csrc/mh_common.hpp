@@ -1144,11 +1144,14 @@ __device__ __attribute__((noinline)) void logit_shard(LogitShard c) {
     if (fast && npass > 0) {
       double xa[2][PL], xb[2][PL], sva[2][NCH], svb[2][NCH];
       lg_v2d pra[2][NCH][3], prb[2][NCH][3];
-      auto sload = [&](double (&x)[2][PL], int pass) {         // (beyond the end: the next slice or the padding behind the last
-#pragma unroll                                                 //  one -- logit_build_slices -- read but never accumulated)
+      // (a pass's covariates by a RUNNING pointer + immediate offsets: indexed by the pass number every load group cost a sign
+      //  extension, a shift and a 64-bit add of scalar instructions, and every instruction of any kind is ~4.5 cycles of the SIMD;
+      //  beyond the end the loads read the next slice or the padding behind the last one -- logit_build_slices -- never accumulated)
+      auto sload = [&](double (&x)[2][PL], cptr_t base) {
+#pragma unroll
         for (int q = 0; q < 2; q++)
 #pragma unroll
-          for (int u = 0; u < PL; u++) x[q][u] = slice[(pass * 2 + q) * PL + u];
+          for (int u = 0; u < PL; u++) x[q][u] = base[q * PL + u];
       };
       auto front = [&](const double (&x)[2][PL], double (&sv)[2][NCH], lg_v2d (&pr)[2][NCH][3]) {   // 64 eta, reduction, lookups
         unsigned ad[2][NCH];
@@ -1161,7 +1164,7 @@ __device__ __attribute__((noinline)) void logit_shard(LogitShard c) {
             for (int u = 0; u < PL; u++) es = fmh_fma(x[q][u], bs[h][u], es);
             const double ue = __builtin_fabs(es);
             sv[q][h] = __builtin_amdgcn_fract(ue);
-            ad[q][h] = tabaddr + 48u * (unsigned)ue;      // (v_mad_u32_u24)
+            ad[q][h] = __umul24((unsigned)ue, 48u) + tabaddr;   // (v_mad_u32_u24: one instruction; the plain product became a 64-bit mad)
           }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1186,18 +1189,20 @@ __device__ __attribute__((noinline)) void logit_shard(LogitShard c) {
           }
         __builtin_amdgcn_sched_barrier(0);
       };
-      sload(xa, 0);
-      sload(xb, 1);
+      cptr_t xp = slice;                          // covariates of pass ps
+      sload(xa, xp);
+      sload(xb, xp + 2 * PL);
       front(xa, sva, pra);                        // pass 0's lookups in flight
       for (int ps = 0; ps < npass; ps += 2) {
         __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0): pass ps's coefficients, pass ps + 1's covariates
-        sload(xa, ps + 2);
+        sload(xa, xp + 4 * PL);
         front(xb, svb, prb);                      // pass ps + 1
         back(sva, pra);                           // pass ps
         __builtin_amdgcn_s_waitcnt(0xC07F);
-        sload(xb, ps + 3);
+        sload(xb, xp + 6 * PL);
         front(xa, sva, pra);                      // pass ps + 2
         if (ps + 1 < npass) back(svb, prb);       // pass ps + 1
+        xp += 4 * PL;
       }
       __builtin_amdgcn_s_waitcnt(0xC07F);
     } else {
