@@ -34,7 +34,10 @@ constexpr int G = 1 << GLOG2;
 constexpr int NROWS = UMAXX2 * G / 2;
 constexpr int STRIDE = NROWS + 1;
 constexpr int NPAIR = (DEG + 2) / 2;
-constexpr int NT = 512, PL = 5;
+#ifndef NTHREADS
+#define NTHREADS 512      // 1024: sixteen waves per CU (four per SIMD), one chain per thread
+#endif
+constexpr int NT = NTHREADS, PL = 5;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 typedef double v2d __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ double s_of(double v) { return v; }
@@ -102,7 +105,9 @@ __global__ void __launch_bounds__(NT, 1) loop(const double* __restrict__ xs /*[2
           for (int h = 0; h < NCH; h++)
 #pragma unroll
             for (int k = 0; k < NPAIR; k++) pr[b][h][k] = *(lds2_t)((ldsb_t)(unsigned long long)ad[b][h] + 16 * STRIDE * k);
+#ifndef ILV
         __builtin_amdgcn_sched_barrier(0);
+#endif
       };
       auto back = [&](const double (&sv)[OB][NCH], const v2d (&pr)[OB][NCH][NPAIR]) {                     // polynomials
 #pragma unroll
@@ -117,6 +122,10 @@ __global__ void __launch_bounds__(NT, 1) loop(const double* __restrict__ xs /*[2
             for (int k = DEG - 1; k >= 0; k--) q = __builtin_fma(sv[b][h], q, co[k]);
             if (b & 1) a1[h] += q; else a0[h] += q;
           }
+#ifdef ILV   // the lookups of the next pass (issued by front() just before) interleaved with this pass's polynomials: 1 read per ILV VALU
+#pragma unroll
+        for (int i = 0; i < OB * NCH * NPAIR; i++) { __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, ILV, 0); }
+#endif
         __builtin_amdgcn_sched_barrier(0);
       };
 #if 0

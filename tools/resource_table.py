@@ -25,7 +25,7 @@ FIELDS = {"TotalSGPRs": "sgprs", "VGPRs": "vgprs", "AGPRs": "agprs", "ScratchSiz
 PRODUCT = [("C2 headline", r"mh_sweep_mfma<1, 1, 20, false, false, false>"), ("C2 shape, > 4 GiB of samples", r"mh_sweep_mfma<1, 1, 20, false, true, false>"),
            ("C3", r"mh_sweep_spec<3, 20, 3>"),
            ("C3' kernel_ram k=5", r"mh_sweep_spec<3, 20, 4>"), ("C4", r"mh_sweep_wide2<4, 3>"),
-           ("C4 slice product", r"shard_columns_mfma<2, 3, 12>"),
+           
            ("C5 (observation-sharded)", r"mh_sweep_kernel<4, -1, 2, 2, 2, 1>"), ("C5 shape, chain-sharded form", r"mh_sweep_kernel<4, -1, 0, 2, 2, 1>"),
            ("n > 10240, normal kernels", r"mh_sweep_mfma<1, 1, 16, false, false, true>"), ("n > 10240, kernel_adapt k = 5", r"mh_sweep_mfma_ad<3, 1, 5>"),
            ("64 < k <= 128", r"mh_sweep_bigk"), ("rng stream", r"rng_fill_kernel"),
@@ -63,7 +63,7 @@ def collect(extra_flags=()):
 # their registers and spill code are read off the ISA (-S): highest VGPR named, scratch instructions, and v_readlane /
 # v_writelane (SGPR spill traffic) inside their innermost hot loop (the largest backward-branch body below 400 instructions)
 DEVICE_FUNCS = [("C5 observation loop (observation-sharded)", "logit_shard<5, 2>"), ("C5 shape, chain-sharded observation loop", "logit_partials<4, 5>"),
-                ("C4 slice product", "shard_columns_mfma<2, 3, 12>"),
+                ("C4 slice product (form T10)", "shard_columns_mfma<2, 3, 12, true>"),
                 ("C4 factor update + proposal", "w2_ram_update_propose")]
 
 
@@ -103,7 +103,37 @@ def isa_functions(extra_flags=()):
                         "scratch_instructions": cnt(ins, "scratch_"), "hot_loop_instructions": len(best or []),
                         "hot_loop_fp64": cnt(best or [], "_f64"), "hot_loop_mfma": cnt(best or [], "v_mfma"),
                         "hot_loop_scratch": cnt(best or [], "scratch_"), "hot_loop_readlane_writelane": cnt(best or [], "v_readlane|v_writelane")})
-    return out
+    # where a product kernel's scratch IS: the remark pass reports a kernel's worst-case stack over everything it can call; what
+    # matters is which scratch instructions sit on the path a config executes -- the kernel body (by enclosing loop) and each callee
+    calls = []
+    dem = dict(zip(names, demangle(names)))
+    for role, pat in PRODUCT:
+        for mangled in names:
+            if pat not in dem[mangled]:
+                continue
+            body = funcs[mangled]
+            ins = [(i, x) for i, x in enumerate(body) if x.startswith("\t") and not x.strip().startswith((";", "."))]
+            if not any("s_endpgm" in x for _, x in ins):
+                continue                     # (device functions are listed as callees)
+            labels = {m.group(1): i for i, l in enumerate(body) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+            loops = []
+            for i, l in enumerate(body):
+                m = re.search(r"s_(?:cbranch_\w+|branch)\s+(\.LBB\d+_\d+)", l)
+                if m and m.group(1) in labels and labels[m.group(1)] < i:
+                    loops.append((labels[m.group(1)], i))
+            sc = [i for i, x in ins if "scratch_" in x]
+            in_loop = sum(1 for i in sc if any(a <= i <= b for a, b in loops))
+            cal = []
+            for l in body:
+                m = re.search(r"(_Z\w+)@(?:rel32|gotpcrel32)", l)
+                if m and m.group(1) in funcs and m.group(1) not in [c[0] for c in cal]:
+                    cb = [x for x in funcs[m.group(1)] if x.startswith("\t") and not x.strip().startswith((";", "."))]
+                    if cb:
+                        cal.append((m.group(1), dem[m.group(1)], len(cb), sum(1 for x in cb if "scratch_" in x)))
+            calls.append({"role": role, "kernel": dem[mangled], "instructions": len(ins), "scratch_instructions": len(sc),
+                          "scratch_instructions_inside_a_loop": in_loop,
+                          "callees": [{"name": c[1], "instructions": c[2], "scratch_instructions": c[3]} for c in cal]})
+    return out, calls
 
 
 def main():
@@ -113,8 +143,8 @@ def main():
     args = ap.parse_args()
     rows, secs = collect(args.flags.split())
     head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
-    fns = isa_functions(args.flags.split())
-    rec = {"head": head, "flags": B.FLAGS + args.flags.split(), "device_compile_seconds": round(secs, 1), "kernels": rows, "device_functions": fns,
+    fns, calls = isa_functions(args.flags.split())
+    rec = {"head": head, "flags": B.FLAGS + args.flags.split(), "device_compile_seconds": round(secs, 1), "kernels": rows, "device_functions": fns, "scratch_by_path": calls,
            "n_kernels": len(rows), "n_with_scratch": sum(1 for r in rows if r.get("scratch_bytes_per_lane", 0))}
     json.dump(rec, open(os.path.join(ROOT, "profiles", "%s_resources.json" % args.tag), "w"), indent=1)
     cols = ["vgprs", "agprs", "sgprs", "scratch_bytes_per_lane", "vgpr_spills", "sgpr_spills", "occupancy_waves_per_simd"]
@@ -133,6 +163,15 @@ def main():
     for f in fns:
         md.append("| %s | `%s` | %d | %d | %d | %d | %d | %d | %d |\n" % (f["role"], f["name"], f["highest_vgpr"], f["scratch_instructions"],
                   f["hot_loop_instructions"], f["hot_loop_fp64"], f["hot_loop_mfma"], f["hot_loop_scratch"], f["hot_loop_readlane_writelane"]))
+    md.append("\n## Where a product kernel's scratch is (read off the ISA)\n\nThe table above gives a kernel's WORST-CASE stack over everything it can "
+              "call; these are the `scratch_*` instructions of the kernel body and of each real (noinline) function it calls -- a config executes "
+              "the body and ONE of the callee instantiations.\n\n| role | kernel / callee | instructions | `scratch_*` | of them inside a loop |\n|---|---|---|---|---|\n")
+    for c in calls:
+        if not c["callees"] and not c["scratch_instructions"]:
+            continue
+        md.append("| %s | `%s` | %d | %d | %d |\n" % (c["role"], c["kernel"], c["instructions"], c["scratch_instructions"], c["scratch_instructions_inside_a_loop"]))
+        for f in c["callees"]:
+            md.append("| | calls `%s` | %d | %d | |\n" % (f["name"], f["instructions"], f["scratch_instructions"]))
     md.append("\n## Every kernel with scratch\n\n" + hdr)
     for r in sorted(rows, key=lambda r: -int(r.get("scratch_bytes_per_lane", 0) or 0)):
         if r.get("scratch_bytes_per_lane", 0):
