@@ -1355,6 +1355,113 @@ def test_randomised_option_cases(E, O, case):
              seed=int(rng.integers(1, 10**6)), chain_base=int(rng.choice([0, 3, 4096])), calls=calls, **kw, **opts)
 
 
+@pytest.mark.parametrize("case", range(int(os.environ.get("FMCMC_TEST_RANDOM_CASES3", "64"))))   # soak: 2000 passed
+def test_randomised_round4_regions(E, O, monkeypatch, case):
+    """Third randomised sweep, over the regions round 4 opened and the first two never draw: (A) linreg beyond the operand
+    registers of the MFMA kernel (10,240 < n <= 45,000 at p <= 3, 5,120 < n at p <= 7: mfma-streamed / mfma-adaptive), (B) 64 < k
+    <= 128 (big-k), (C) logistic regression on the observation-sharded evaluation at ragged n, p <= 8, chain counts around 512,
+    (D) the wave-specialised kernel at any n <= 10,240 with p <= 7 -- each with random kernels, bounds, fixed masks, burn-in,
+    thinning and one or two calls.  Whatever kernel the dispatcher picks: the oracle's bits."""
+    from fmcmc_amd import _abi as abi
+    rng = np.random.default_rng(8640000 + case)
+    region = "ABCD"[case % 4]
+    intercept = bool(rng.integers(0, 4))            # mostly with an intercept
+    calls = int(rng.integers(1, 3))
+    fam = "logistic" if region == "C" else "linreg"
+    if region == "A":
+        p = int(rng.choice([1, 2, 3, 3, 4, 5, 7]))
+        n = int(rng.integers(10241, 45001)) if p <= 3 else int(rng.integers(5121 if p <= 5 else 4097, 20001))
+        chains = int(rng.choice([1, 4, 5, 9]))
+        kind_name = str(rng.choice(["normal", "reflective", "unif", "adapt", "ram"]))
+    elif region == "B":
+        k_ = int(rng.integers(65, 129))
+        p = k_ - 1 - int(intercept)
+        n = int(rng.integers(200, 2500))
+        chains = int(rng.choice([1, 2, 3, 5]))
+        kind_name = str(rng.choice(["normal", "reflective", "unif", "adapt", "ram"]))
+    elif region == "C":
+        p = int(rng.integers(1, 9))
+        n = int(rng.integers(1024, 24001))
+        chains = int(rng.choice([3, 8, 130, 511, 513, 600]))
+        kind_name = str(rng.choice(["normal", "reflective"]))
+        set_knob(monkeypatch, "shard", str(rng.choice(["1", "1", "0"])))
+    else:
+        p = int(rng.integers(1, 8))
+        n = int(rng.integers(513, 10241 if p <= 3 else (5121 if p <= 5 else 4097)))
+        chains = int(rng.choice([1, 3, 4, 6, 13]))
+        kind_name = str(rng.choice(["adapt", "ram", "normal"]))
+    k = p + int(intercept) + (1 if fam == "linreg" else 0)
+    nsteps = int(max(7, min(60, 1.5e8 / (chains * n * max(p, 1) * 2 * calls))))
+    beta = rng.uniform(-1.0, 1.0, p + 1) * (0.3 if region == "B" else 1.0)
+    X = rng.standard_normal((n, p)) * (0.4 if region == "B" else 1.0)
+    if fam == "linreg":
+        y = (beta[0] if intercept else 0.0) + X @ beta[1:] + 1.5 * rng.standard_normal(n)
+        base = list(beta[(0 if intercept else 1):]) + [1.5]
+        famc, kw = O.FAM_LINREG, dict(intercept=intercept, guard=bool(rng.integers(0, 4)))
+        lb, ub = [-30.0] * (k - 1) + [0.2], 30.0
+    else:
+        eta = (beta[0] if intercept else 0.0) + X @ beta[1:]
+        y = (rng.uniform(size=n) < 1 / (1 + np.exp(-eta))).astype(np.float64)
+        base = list(beta[(0 if intercept else 1):])
+        famc, kw = O.FAM_LOGISTIC, dict(intercept=intercept, prior_div=float(rng.choice([0.0, 8.0])))
+        lb, ub = [-5.0] * k, 5.0
+    init = jitter_init(base, chains, 21 + case)
+    if fam == "linreg":
+        init[:, -1] = np.abs(init[:, -1]) + 0.3
+    fixed = np.zeros(k, bool)
+    if k > 3 and rng.random() < 0.35:
+        fixed[rng.choice(k - 1, size=int(rng.integers(1, 3)), replace=False)] = True
+    opts = dict(fixed=fixed)
+    if kind_name in ("normal", "reflective"):
+        kind = O.K_NORMAL if kind_name == "normal" else O.K_NORMAL_REFLECTIVE
+        opts.update(scale=rng.uniform(0.002, 0.02, k))
+        if kind_name == "reflective":
+            opts.update(lb=lb, ub=ub)
+    elif kind_name == "unif":
+        kind = O.K_UNIF_REFLECTIVE if case % 8 >= 4 else O.K_UNIF
+        opts.update(min_=-0.01, max_=0.012)
+        if kind == O.K_UNIF_REFLECTIVE:
+            opts.update(lb=lb, ub=ub)
+    elif kind_name == "adapt":
+        kind = O.K_ADAPT
+        opts.update(warmup=int(rng.integers(2, 10)), eps=float(rng.choice([1e-4, 1e-6])))
+        if region != "B" and rng.random() < 0.3:
+            opts["freq"] = 2
+        if rng.random() < 0.3:
+            opts["until"] = float(nsteps // 2)
+        if rng.random() < 0.4:
+            opts.update(lb=lb, ub=ub)
+    else:
+        kind = O.K_RAM
+        opts.update(arate=float(rng.choice([0.234, 0.4])), warmup=int(rng.choice([0, 0, 3])))
+        if rng.random() < 0.3:
+            opts["constr"] = (np.abs(np.subtract.outer(np.arange(k), np.arange(k))) <= 2).astype(float)
+        if rng.random() < 0.35:
+            opts.update(lb=lb, ub=ub)
+    burnin = int(rng.integers(0, 3))
+    thin = int(rng.choice([1, 1, 2, 3]))
+    if burnin + thin > nsteps - 1:
+        burnin, thin = 0, 1
+    run_both(E, O, famc, X, y, kind, k, init, nsteps=nsteps, burnin=burnin, thin=thin, seed=int(rng.integers(1, 10**6)),
+             chain_base=int(rng.choice([0, 7, 4096])), calls=calls, **kw, **opts)
+    _R4_PICKED.setdefault(region, set()).add(abi.last_kernel())
+
+
+_R4_PICKED = {}
+
+
+def test_randomised_round4_regions_reached_their_kernels():
+    """(runs after the cases above) the regions were drawn to reach the round-4 kernels -- say which ones they did reach"""
+    import torch
+    if not _R4_PICKED or torch.cuda.get_device_properties(0).multi_processor_count < 256:
+        pytest.skip("cases not run in this process / not a 256-CU device")
+    if int(os.environ.get("FMCMC_TEST_RANDOM_CASES3", "64")) >= 64:
+        assert {"mfma-streamed", "mfma-adaptive"} <= _R4_PICKED["A"], _R4_PICKED
+        assert _R4_PICKED["B"] == {"big-k"}, _R4_PICKED
+        assert "logistic-sharded" in _R4_PICKED["C"], _R4_PICKED
+        assert "spec" in _R4_PICKED["D"], _R4_PICKED
+
+
 @pytest.mark.parametrize("kind_name", ["normal", "ram"])
 def test_sharded_evaluation_in_consecutive_launches(E, O, monkeypatch, kind_name):
     """More than 512 chains per GPU on a wide model: the sweep runs as consecutive cooperative launches of 512 chains
