@@ -1097,8 +1097,13 @@ struct LogitShard {
   int pad_;
 };
 static_assert(sizeof(LogitShard) == 64, "LogitShard must stay at 16 dwords");
-template <int PL, int NCH>
+// OB = 2: a pass is one slot, the two observations of the slice's two canonical lanes (p <= 8); OB = 1: a pass is ONE observation,
+// even passes the lower lane's, odd passes the upper lane's -- the covariates of two passes then fit the scalar registers up to
+// p = 16 (round 4: tools/dispatch_audit.py found logistic models with more than 8 covariates on the run-time chain-sharded loop,
+// 5x the time per step of p = 8).  Either way a canonical lane's terms are added in slot order: the same bits.
+template <int PL, int NCH, int OB = 2>
 __device__ __attribute__((noinline)) void logit_shard(LogitShard c) {
+  static_assert(OB == 1 || OB == 2, "one or two observations per pass");
   typedef const double __attribute__((address_space(4))) * cptr_t;
   typedef __attribute__((address_space(3))) const char* ldsb_t;
   typedef __attribute__((address_space(3))) const lg_v2d* lds2_t;
@@ -1142,21 +1147,21 @@ __device__ __attribute__((noinline)) void logit_shard(LogitShard c) {
       return g1[0];
     };
     if (fast && npass > 0) {
-      double xa[2][PL], xb[2][PL], sva[2][NCH], svb[2][NCH];
-      lg_v2d pra[2][NCH][3], prb[2][NCH][3];
+      double xa[OB][PL], xb[OB][PL], sva[OB][NCH], svb[OB][NCH];
+      lg_v2d pra[OB][NCH][3], prb[OB][NCH][3];
       // (a pass's covariates by a RUNNING pointer + immediate offsets: indexed by the pass number every load group cost a sign
       //  extension, a shift and a 64-bit add of scalar instructions, and every instruction of any kind is ~4.5 cycles of the SIMD;
       //  beyond the end the loads read the next slice or the padding behind the last one -- logit_build_slices -- never accumulated)
-      auto sload = [&](double (&x)[2][PL], cptr_t base) {
+      auto sload = [&](double (&x)[OB][PL], cptr_t base) {
 #pragma unroll
-        for (int q = 0; q < 2; q++)
+        for (int q = 0; q < OB; q++)
 #pragma unroll
           for (int u = 0; u < PL; u++) x[q][u] = base[q * PL + u];
       };
-      auto front = [&](const double (&x)[2][PL], double (&sv)[2][NCH], lg_v2d (&pr)[2][NCH][3]) {   // 64 eta, reduction, lookups
-        unsigned ad[2][NCH];
+      auto front = [&](const double (&x)[OB][PL], double (&sv)[OB][NCH], lg_v2d (&pr)[OB][NCH][3]) {   // 64 eta, reduction, lookups
+        unsigned ad[OB][NCH];
 #pragma unroll
-        for (int q = 0; q < 2; q++)
+        for (int q = 0; q < OB; q++)
 #pragma unroll
           for (int h = 0; h < NCH; h++) {
             double es = b0[h];
@@ -1168,16 +1173,16 @@ __device__ __attribute__((noinline)) void logit_shard(LogitShard c) {
           }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int q = 0; q < 2; q++)
+        for (int q = 0; q < OB; q++)
 #pragma unroll
           for (int h = 0; h < NCH; h++)
 #pragma unroll
             for (int k = 0; k < 3; k++) pr[q][h][k] = *(lds2_t)((ldsb_t)(unsigned long long)ad[q][h] + 16 * k);
         __builtin_amdgcn_sched_barrier(0);
       };
-      auto back = [&](const double (&sv)[2][NCH], const lg_v2d (&pr)[2][NCH][3]) {                     // polynomials
+      auto back = [&](const double (&sv)[OB][NCH], const lg_v2d (&pr)[OB][NCH][3], const int upper /* OB == 1: the pass's lane */) {   // polynomials
 #pragma unroll
-        for (int q = 0; q < 2; q++)
+        for (int q = 0; q < OB; q++)
 #pragma unroll
           for (int h = 0; h < NCH; h++) {
             double v = fmh_fma(sv[q][h], pr[q][h][2].y, pr[q][h][2].x);
@@ -1185,24 +1190,25 @@ __device__ __attribute__((noinline)) void logit_shard(LogitShard c) {
             v = fmh_fma(sv[q][h], v, pr[q][h][1].x);
             v = fmh_fma(sv[q][h], v, pr[q][h][0].y);
             v = fmh_fma(sv[q][h], v, pr[q][h][0].x);
-            if (q) a1[h] = a1[h] + v; else a0[h] = a0[h] + v;
+            if (OB == 2 ? q : upper) a1[h] = a1[h] + v; else a0[h] = a0[h] + v;
           }
         __builtin_amdgcn_sched_barrier(0);
       };
       cptr_t xp = slice;                          // covariates of pass ps
+      const int nps = npass * (2 / OB);           // passes in which the pipelined loop runs (OB == 1: two per slot)
       sload(xa, xp);
-      sload(xb, xp + 2 * PL);
+      sload(xb, xp + OB * PL);
       front(xa, sva, pra);                        // pass 0's lookups in flight
-      for (int ps = 0; ps < npass; ps += 2) {
+      for (int ps = 0; ps < nps; ps += 2) {
         __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0): pass ps's coefficients, pass ps + 1's covariates
-        sload(xa, xp + 4 * PL);
+        sload(xa, xp + 2 * OB * PL);
         front(xb, svb, prb);                      // pass ps + 1
-        back(sva, pra);                           // pass ps
+        back(sva, pra, 0);                        // pass ps
         __builtin_amdgcn_s_waitcnt(0xC07F);
-        sload(xb, xp + 6 * PL);
+        sload(xb, xp + 3 * OB * PL);
         front(xa, sva, pra);                      // pass ps + 2
-        if (ps + 1 < npass) back(svb, prb);       // pass ps + 1
-        xp += 4 * PL;
+        if (ps + 1 < nps) back(svb, prb, 1);      // pass ps + 1
+        xp += 2 * OB * PL;
       }
       __builtin_amdgcn_s_waitcnt(0xC07F);
     } else {
@@ -1241,7 +1247,10 @@ __device__ __forceinline__ void eval_sharded_logit_step(const SweepArgs& A, cons
 #define LG_CASE(P_) case P_: if (two) logit_shard<P_, 2>(ls); else logit_shard<P_, 1>(ls); break;
     LG_CASE(1) LG_CASE(2) LG_CASE(3) LG_CASE(4) LG_CASE(5) LG_CASE(6) LG_CASE(7) LG_CASE(8)
 #undef LG_CASE
-    default: break;                    // (the host takes this form for 1 <= p <= 8 only)
+#define LG_CASE(P_) case P_: if (two) logit_shard<P_, 2, 1>(ls); else logit_shard<P_, 1, 1>(ls); break;
+    LG_CASE(9) LG_CASE(10) LG_CASE(11) LG_CASE(12) LG_CASE(13) LG_CASE(14) LG_CASE(15) LG_CASE(16)
+#undef LG_CASE
+    default: break;                    // (the host takes this form for 1 <= p <= 16 only)
   }
 }
 

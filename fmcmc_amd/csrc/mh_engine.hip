@@ -418,7 +418,8 @@ static Knobs read_knobs() {
   return K;
 }
 static bool shard_mfma_enabled(const Knobs& K) { return K.shard_mfma != 0; }
-static int wide_sharded_lanes(const Knobs& K, const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_run* run, int ram_bounded, int ncu, long long nb) {
+static int wide_sharded_lanes(const Knobs& K, const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_run* run, int ram_bounded, int ncu, long long nb,
+                              int cw_now = 2 /* chains per workgroup the call would run with on the chain-sharded / general kernel */) {
   if (K.shard == 0) return 0;
   if (m->family != FMCMC_FAM_GAUSSIAN_LINREG || m->p < 16) return 0;
   if (kn->kind != FMCMC_KERNEL_RAM && kn->kind != FMCMC_KERNEL_NORMAL && kn->kind != FMCMC_KERNEL_NORMAL_REFLECTIVE) return 0;
@@ -434,15 +435,32 @@ static int wide_sharded_lanes(const Knobs& K, const fmcmc_model* m, const fmcmc_
                   run->nsteps < 30000000;   /* barrier epochs (2 per step) x workgroups per group stay below 2^32 */
   if (!ok) return 0;
   if (K.shard != 1) {
-    const double walked = (cached ? 1.0 : 2.1) * ((lpw * nslots <= SH_MAXO / 2) ? SH_MAXO / 2 : SH_MAXO);
-    const double est_chain = 4.0 + (double)m->n * (double)m->p * 8.0 / 65000.0;
-    const double est_shard = 14.0 + 0.0085 * (double)m->p * walked + (kn->kind == FMCMC_KERNEL_RAM ? 6.0 : 0.0);
-    if (!(est_shard < est_chain)) return 0;
+    // us per step, refitted to tools/dispatch_audit.py (profiles/r04_dispatch_audit.md: p = 16 .. 60, n = 1e3 .. 1e4, 64 .. 2048
+    // chains): the chain-sharded kernel streams the data set per workgroup and pays kernel_ram's owner phase (~0.15 us per
+    // parameter) in the open; the sharded forms cost ~9 us of hand-overs plus a slice product that grows with the chains of a
+    // launch -- on the matrix cores p (0.08 + 0.00475 slice observations) per 512 chains -- and hide the RAM owners in the
+    // dataflow form (more than 256 chains), pay ~0.17 us per parameter in the sequential one
+    const bool ram = kn->kind == FMCMC_KERNEL_RAM;
+    // (with four / eight chains per workgroup -- more than 512 / 1024 chains -- the data stream is shared by more chains but a
+    //  step takes 1.1x / 2.4x as long (and the owners of a workgroup queue), and the workgroups run in rounds; the sharded sweep runs as consecutive launches)
+    const double rounds = (double)((run->nchains + (long long)cw_now * ncu - 1) / ((long long)cw_now * ncu));
+    const double launches = (double)((run->nchains + per_launch - 1) / per_launch);
+    const double est_chain = (4.0 + (double)m->n * (double)m->p * 8.0 / 65000.0 * (cw_now >= 8 ? 2.4 : (cw_now == 4 ? 1.1 : 1.0)) +
+                              (ram ? 0.075 * (double)kn->k * (double)(cw_now < 2 ? 2 : cw_now) : 0.0)) * rounds;
+    const double frac = (double)(run->nchains < per_launch ? run->nchains : per_launch) / 512.0;
+    double est_shard;
+    if (shard_mfma_enabled(K) && m->p <= 4 * SHM_KBMAX)
+      est_shard = 9.3 + frac * (3.2 + (double)m->p * (0.08 + 0.00475 * (double)(lpw * nslots))) + ((ram && run->nchains <= 256) ? 0.17 * (double)kn->k : 0.0);
+    else {
+      const double walked = (cached ? 1.0 : 2.1) * ((lpw * nslots <= SH_MAXO / 2) ? SH_MAXO / 2 : SH_MAXO);
+      est_shard = 14.0 + 0.0085 * (double)m->p * walked + (ram ? 6.0 : 0.0);
+    }
+    if (!(est_shard * launches < 0.95 * est_chain)) return 0;
   }
   return lpw;
 }
-static bool wide_sharded_pays(const Knobs& K, const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_run* run, int ram_bounded, int ncu, long long nb) {
-  return wide_sharded_lanes(K, m, kn, run, ram_bounded, ncu, nb) > 0;
+static bool wide_sharded_pays(const Knobs& K, const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_run* run, int ram_bounded, int ncu, long long nb, int cw_now) {
+  return wide_sharded_lanes(K, m, kn, run, ram_bounded, ncu, nb, cw_now) > 0;
 }
 
 // stream-ordered scratch that is released on EVERY way out of launch_sweep
@@ -559,6 +577,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
   const bool resident = res_p >= 0;
   // chains per workgroup: fill the CUs first, then stack chains on a workgroup
   int cw = 1;
+  bool wide_switched = false;   // two chains per workgroup BECAUSE the observation-sharded sweep pays: the decision stands below
   if (resident) {
     cw = 4;
   } else {
@@ -568,7 +587,11 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
     // consecutive observation-sharded launches of 2 x CUs chains each (below) when that pays off
     // (measured at k = 50, n = 10k: 1024 chains 63.8 us per step instead of 71.6 with four chains per workgroup; at 2048
     //  chains the general kernel with eight chains per workgroup is level, 123 vs 128, and keeps the sweep)
-    else if (cw == 4 && wide_sharded_pays(K, m, kn, run, ram_bounded, ncu, (long long)ncu)) cw = 2;
+    else if (cw >= 4 && wide_sharded_pays(K, m, kn, run, ram_bounded, ncu, (long long)ncu, cw)) { cw = 2; wide_switched = true; }
+    // the logistic-only instantiations (table in LDS; observation-sharded form) exist for up to four chains per workgroup: more
+    // than 1024 chains run as more workgroups / consecutive sharded launches there, not on the all-family kernel with eight
+    // chains per workgroup (tools/dispatch_audit.py: 4096 chains, n = 1e5, p = 5 took 1244 us per step, 4.7x four launches)
+    else if (cw > 4 && m->family == FMCMC_FAM_LOGISTIC && (kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE)) cw = 4;
   }
   int tb = 32;
   while (tb > 1 && sweep_lds_bytes(kn->k, kf, kn->kind, cw, tb, A.kz, resident) > 60 * 1024) tb >>= 1;
@@ -636,7 +659,9 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
     }
     // kernel_adapt / kernel_ram beyond mh_sweep_spec's registers: the same streamed MFMA evaluation with the register-row
     // adaptive owners between barriers (mh_mfma_ad.hpp); no fixed parameter, k <= 8
-    if (K.mfma != 0 && !pipe_opt && kn->kind >= FMCMC_KERNEL_ADAPT && m->p >= 1 && m->p <= 7 && kf == kn->k && kn->k <= SPEC_KA &&
+    // (k = 9 -- seven covariates, intercept and sigma -- as a compile-time row count: tools/dispatch_audit.py found these calls on
+    //  the general kernel, 7x the time of the normal kernels at the same shape)
+    if (K.mfma != 0 && !pipe_opt && kn->kind >= FMCMC_KERNEL_ADAPT && m->p >= 1 && m->p <= 7 && kf == kn->k && (kn->k <= SPEC_KA || kn->k == 9) &&
         A.kz == kn->k && m->n < (1ll << 29)) {
       mfma_ad = 1;
       mfma_ng = (m->p <= 3) ? 1 : 2;
@@ -748,6 +773,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
                            else hipLaunchKernelGGL((mh_sweep_mfma_ad<4, GV, XV>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); } while (0)
         if (mfma_ng == 1 && kn->k == 5) MF_AD(1, 5);
         else if (mfma_ng == 1) MF_AD(1, 0);
+        else if (kn->k == 9) MF_AD(2, 9);
         else MF_AD(2, 0);
 #undef MF_AD
       } else if (mfma_ext) {
@@ -866,18 +892,25 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
     const bool refl = kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE;
     lds += sizeof(double) * (LG_LDS_DOUBLES + 2);   // the table staged behind the chain blocks (16-byte aligned)
     // Observation-sharded form (mh_common.hpp, logit_shard): 256 workgroups of two canonical lanes each evaluate ALL chains
-    // of the launch, up to 256 x cw of them; more chains run as consecutive launches.  Cost model (us per step, fitted to
-    // tools/shape_map.py at p = 5, 7, n = 1e4 .. 1e5, 1024 chains): both loops cost ~(p + 12) instructions per observation
-    // and chain; chain-sharded 4.5 + n cw (p + 12) 1.35e-5 with the coefficients in SGPRs (p <= 28 / cw - 1; 2.8e-5 on the
-    // run-time loop beyond that) -- its lookups scatter over the table: LDS-bound --, sharded 15 of hand-overs +
-    // chains n (p + 12) 3.5e-8.  Knob shard=1 forces it for every eligible shape (tests), shard=0 disables it.
+    // of the launch, up to 256 x cw of them; more chains run as consecutive launches.  Cost model (us per step): the
+    // chain-sharded loop costs ~(p + 12) instructions per observation and chain, 4.5 + n cw (p + 12) 1.35e-5 with the
+    // coefficients in SGPRs (p <= 28 / cw - 1; 2.8e-5 on the run-time loop beyond that) -- its lookups scatter over the table:
+    // LDS-bound -- but never less than one pass of the workgroup over the data set at ~90 GB/s; the sharded form ~10 us of
+    // hand-overs + n (p + 10.3) 1.78e-5 per 512 chains of a launch.  Knob shard=1 forces it for every eligible shape (tests),
+    // shard=0 disables it.
     bool lshard = false;
     const long long nb_launch = 256;
     const long long ch_launch = (nblk > nb_launch) ? nb_launch * cw : (long long)run->nchains;
     const int nslots = (int)((m->n + NT - 1) / NT);
-    if (K.shard != 0 && m->p >= 1 && m->p <= 8 && ncu == 256 && m->n >= 2 * NT && m->n < (1ll << 28)) {
+    if (K.shard != 0 && m->p >= 1 && m->p <= 16 && ncu == 256 && m->n >= 2 * NT && m->n < (1ll << 28)) {
+      // (refitted to tools/dispatch_audit.py, profiles/r04_dispatch_audit.md: n = 2e3 .. 1e5, p = 2, 5, 8, 64 .. 4096 chains)
       const double w = (double)m->n * (double)(m->p + 12);
-      const double est_chain = 4.5 + w * cw * ((m->p <= 28 / cw - 1) ? 1.35e-5 : 2.8e-5), est_shard = 15.0 + 3.5e-8 * w * (double)ch_launch;
+      const double stream_us = (double)m->n * (double)(m->p + 1) * 8.0 / 9.0e4;      // a workgroup's pass over the data set at ~90 GB/s
+      const double loop_us = w * cw * ((m->p <= 28 / cw - 1) ? 1.35e-5 : 2.8e-5);
+      const double rounds = (double)((nblk + ncu - 1) / ncu), launches = (double)((run->nchains + ch_launch - 1) / ch_launch);
+      const double est_chain = (4.5 + (loop_us > stream_us ? loop_us : stream_us)) * rounds;
+      const double passes = (double)((ch_launch + NT - 1) / NT);                       // chains per thread of the sharded loop
+      const double est_shard = (10.3 + 2.2 * (passes - 1.0) + 1.78e-5 * (double)m->n * ((double)m->p + 10.3) * passes) * launches;
       lshard = K.shard == 1 || est_shard < 0.95 * est_chain;
     }
     const void* kfn = nullptr;
@@ -966,7 +999,9 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
     //  up to 512 chains run as one launch of 256 workgroups, exactly 128 workgroups keep 4 lanes each when n allows)
     const long long nb_launch = (nblk == 128 && 4 * nslots <= SH_MAXO) ? 128 : 256;
     const long long ch_launch = (nblk > nb_launch) ? nb_launch * cw : (long long)run->nchains;
-    const int lpw = wide_sharded_lanes(K, m, kn, run, ram_bounded, ncu, nb_launch);
+    Knobs Kw = K;
+    if (wide_switched && K.shard != 0) Kw.shard = 1;
+    const int lpw = wide_sharded_lanes(Kw, m, kn, run, ram_bounded, ncu, nb_launch);
     bool shard = lpw > 0;
     // the sharded evaluation is its own instantiation (OPT = lanes per workgroup): sharing one with the streamed loop
     // cost 200-300 spilled registers in BOTH paths

@@ -514,17 +514,19 @@ def test_logistic_specialised_loops(E, O, monkeypatch, cw, p, intercept):
              scale=0.3, lb=-2.0, ub=2.0, intercept=intercept)
 
 
-@pytest.mark.parametrize("p,intercept,C", [(1, True, 5), (3, False, 9), (5, True, 7), (8, True, 3), (5, True, 600), (2, True, 513)])
+@pytest.mark.parametrize("p,intercept,C", [(1, True, 5), (3, False, 9), (5, True, 7), (8, True, 3), (5, True, 600), (2, True, 513),
+                                           (9, True, 5), (12, False, 520), (16, True, 4), (13, True, 700), (11, False, 9)])
 def test_logistic_observation_sharded(E, O, monkeypatch, p, intercept, C):
     """The observation-sharded logistic evaluation (logit_shard, knob shard=1 forces it at these sizes): 256 workgroups of two
     canonical lanes each evaluate ALL chains, thread = chain -- one chain per thread up to 512 chains, two side by side
-    above --, hand-pipelined fast loop and the checked form (large |eta|: beyond the table's 2400 rows), ragged n (a last
+    above; two observations per pass up to p = 8, one from p = 9 to 16 --, hand-pipelined fast loop and the checked form
+    (large |eta|: beyond the table's 2400 rows), ragged n (a last
     slot that only some lanes hold), chain counts that leave workgroups without chains, two consecutive calls."""
     from fmcmc_amd import _abi as abi
     set_knob(monkeypatch, "shard", "1")
     rng = np.random.default_rng(900 + 10 * p + C)
     n = 512 * 3 + 37 * p + 1                                              # odd: the last slot holds lanes 0 .. 37 p only
-    X = rng.standard_normal((n, p)) * (12.0 if p == 3 else 1.0)           # p = 3: |eta| up to ~60, off the table
+    X = rng.standard_normal((n, p)) * (12.0 if p in (3, 11) else 1.0)     # p = 3, 11: |eta| up to ~60, off the table
     k = p + (1 if intercept else 0)
     beta = rng.uniform(-1.5, 1.5, k)
     eta = (beta[0] if intercept else 0.0) + X @ beta[(1 if intercept else 0):]
@@ -632,7 +634,7 @@ def test_mfma_kernel_beyond_its_operand_registers(E, O, n, p):
     assert abi.last_kernel() == "mfma-streamed"
 
 
-@pytest.mark.parametrize("n,p,intercept", [(10241, 3, True), (20000, 3, True), (12001, 3, False), (30000, 2, True), (5121, 5, True), (6500, 6, True), (9000, 4, False)])
+@pytest.mark.parametrize("n,p,intercept", [(10241, 3, True), (20000, 3, True), (12001, 3, False), (30000, 2, True), (5121, 5, True), (6500, 6, True), (9000, 4, False), (6000, 7, True), (8200, 7, False)])
 def test_adaptive_kernels_on_the_streamed_mfma_evaluation(E, O, n, p, intercept):
     """mh_sweep_mfma_ad (round 4): kernel_adapt / kernel_ram beyond mh_sweep_spec's registers -- the streamed MFMA evaluation of
     all four chains of a workgroup, then one step of the register-row adaptive owners between barriers.  k = 5 (the
@@ -1380,7 +1382,7 @@ def test_randomised_round4_regions(E, O, monkeypatch, case):
         chains = int(rng.choice([1, 2, 3, 5]))
         kind_name = str(rng.choice(["normal", "reflective", "unif", "adapt", "ram"]))
     elif region == "C":
-        p = int(rng.integers(1, 9))
+        p = int(rng.integers(1, 17))
         n = int(rng.integers(1024, 24001))
         chains = int(rng.choice([3, 8, 130, 511, 513, 600]))
         kind_name = str(rng.choice(["normal", "reflective"]))
