@@ -591,7 +591,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
     // the logistic-only instantiations (table in LDS; observation-sharded form) exist for up to four chains per workgroup: more
     // than 1024 chains run as more workgroups / consecutive sharded launches there, not on the all-family kernel with eight
     // chains per workgroup (tools/dispatch_audit.py: 4096 chains, n = 1e5, p = 5 took 1244 us per step, 4.7x four launches)
-    else if (cw > 4 && m->family == FMCMC_FAM_LOGISTIC && (kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE)) cw = 4;
+    else if (cw > 4 && m->family == FMCMC_FAM_LOGISTIC && kn->kind >= FMCMC_KERNEL_NORMAL && kn->kind <= FMCMC_KERNEL_RAM) cw = 4;
   }
   int tb = 32;
   while (tb > 1 && sweep_lds_bytes(kn->k, kf, kn->kind, cw, tb, A.kz, resident) > 60 * 1024) tb >>= 1;
@@ -883,13 +883,16 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
   } else
   if (resident && res_p == 1) { g_kernel = "resident"; LAUNCH_KIND(4, 1, 4); }
   else if (resident && res_p == 3) { g_kernel = "resident"; LAUNCH_KIND(4, 3, 20); }
-  else if (m->family == FMCMC_FAM_LOGISTIC && cw <= 4 && lds + sizeof(double) * (LG_LDS_DOUBLES + 2) <= 160 * 1024 &&
-           (kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE)) {
+  else if (!force && m->family == FMCMC_FAM_LOGISTIC && cw <= 4 && lds + sizeof(double) * (LG_LDS_DOUBLES + 2) <= 160 * 1024 &&
+           (kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE || kn->kind == FMCMC_KERNEL_ADAPT ||
+            kn->kind == FMCMC_KERNEL_RAM)) {
+    // (round 4: kernel_adapt / kernel_ram too -- the workflow vignette's own model is a logistic regression under kernel_adapt;
+    //  tools/option_audit.py found them on the all-family kernel at 3.9x the time per step of the normal kernels)
     // logistic-only instantiations: the g table in LDS; up to 28 / cw - 1 covariates their number is a compile-time constant
     // of the evaluation loop and the coefficients of the CW chains live in SGPRs (mh_common.hpp, logit_partials), beyond that
     // the run-time loop (logit_partials_any) -- still with the table in LDS, which is what the all-family kernel lacks
     g_kernel = "streamed-logistic";
-    const bool refl = kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE;
+    const int lkv = kn->kind;   // 1 .. 4
     lds += sizeof(double) * (LG_LDS_DOUBLES + 2);   // the table staged behind the chain blocks (16-byte aligned)
     // Observation-sharded form (mh_common.hpp, logit_shard): 256 workgroups of two canonical lanes each evaluate ALL chains
     // of the launch, up to 256 x cw of them; more chains run as consecutive launches.  Cost model (us per step): the
@@ -902,7 +905,10 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
     const long long nb_launch = 256;
     const long long ch_launch = (nblk > nb_launch) ? nb_launch * cw : (long long)run->nchains;
     const int nslots = (int)((m->n + NT - 1) / NT);
-    if (K.shard != 0 && m->p >= 1 && m->p <= 16 && ncu == 256 && m->n >= 2 * NT && m->n < (1ll << 28)) {
+    // (not the bounded kernel_ram: its second evaluation of a step runs only in the workgroups where a proposal was reflected
+    //  -- the grid-wide evaluation needs every workgroup in every hand-over)
+    if (K.shard != 0 && m->p >= 1 && m->p <= 16 && ncu == 256 && m->n >= 2 * NT && m->n < (1ll << 28) &&
+        !(kn->kind == FMCMC_KERNEL_RAM && ram_bounded)) {
       // (refitted to tools/dispatch_audit.py, profiles/r04_dispatch_audit.md: n = 2e3 .. 1e5, p = 2, 5, 8, 64 .. 4096 chains)
       const double w = (double)m->n * (double)(m->p + 12);
       const double stream_us = (double)m->n * (double)(m->p + 1) * 8.0 / 9.0e4;      // a workgroup's pass over the data set at ~90 GB/s
@@ -914,7 +920,8 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
       lshard = K.shard == 1 || est_shard < 0.95 * est_chain;
     }
     const void* kfn = nullptr;
-#define LSK(CWV) (refl ? (const void*)mh_sweep_kernel<CWV, -1, 2, 2, FMCMC_FAM_LOGISTIC, 1> : (const void*)mh_sweep_kernel<CWV, -1, 2, 1, FMCMC_FAM_LOGISTIC, 1>)
+#define LSK(CWV) (lkv == 1 ? (const void*)mh_sweep_kernel<CWV, -1, 2, 1, FMCMC_FAM_LOGISTIC, 1> : lkv == 2 ? (const void*)mh_sweep_kernel<CWV, -1, 2, 2, FMCMC_FAM_LOGISTIC, 1> \
+                : lkv == 3 ? (const void*)mh_sweep_kernel<CWV, -1, 2, 3, FMCMC_FAM_LOGISTIC, 1> : (const void*)mh_sweep_kernel<CWV, -1, 2, 4, FMCMC_FAM_LOGISTIC, 1>)
     if (lshard) kfn = (cw == 1) ? LSK(1) : (cw == 2) ? LSK(2) : LSK(4);
 #undef LSK
     if (lshard) {
@@ -971,11 +978,14 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
       if (e == hipSuccess)                                                                                             \
         hipLaunchKernelGGL((mh_sweep_kernel<CWV, -1, 0, KV, FMCMC_FAM_LOGISTIC, MB>), dim3((unsigned)nblk), dim3(NT), lds, stream, A); \
     } while (0)
+#define LAUNCH_LOGIT_K(CWV) do { if (lkv == 1) LAUNCH_LOGIT(CWV, 1, 1); else if (lkv == 2) LAUNCH_LOGIT(CWV, 2, 1); \
+                                 else if (lkv == 3) LAUNCH_LOGIT(CWV, 3, 1); else LAUNCH_LOGIT(CWV, 4, 1); } while (0)
     switch (cw) {
-      case 1: if (refl) LAUNCH_LOGIT(1, 2, 1); else LAUNCH_LOGIT(1, 1, 1); break;
-      case 2: if (refl) LAUNCH_LOGIT(2, 2, 1); else LAUNCH_LOGIT(2, 1, 1); break;
-      default: if (refl) LAUNCH_LOGIT(4, 2, 1); else LAUNCH_LOGIT(4, 1, 1); break;
+      case 1: LAUNCH_LOGIT_K(1); break;
+      case 2: LAUNCH_LOGIT_K(2); break;
+      default: LAUNCH_LOGIT_K(4); break;
     }
+#undef LAUNCH_LOGIT_K
 #undef LAUNCH_LOGIT
     }
   }

@@ -724,10 +724,43 @@ def test_small_shape_mfma_equals_wave_specialised_kernel(E, O, monkeypatch):
     assert _bits_equal(out[0][0], out[1][0]) and _bits_equal(out[0][1], out[1][1])
 
 
+@pytest.mark.parametrize("form", ["chain-sharded", "observation-sharded"])
+@pytest.mark.parametrize("kind_name", ["adapt", "adapt_window", "ram", "ram_bounded", "ram_constr"])
+def test_logistic_adaptive_kernels_on_the_logistic_kernels(E, O, monkeypatch, kind_name, form):
+    """kernel_adapt / kernel_ram on a logistic model (the workflow vignette's own combination) run on the logistic-only
+    instantiations since round 4 -- g table in LDS, both the chain-sharded loop and the observation-sharded evaluation (the
+    bounded kernel_ram on the chain-sharded one only) -- with 6 and 520 chains, two calls: the oracle's bits."""
+    from fmcmc_amd import _abi as abi
+    set_knob(monkeypatch, "shard", "1" if form == "observation-sharded" else "0")
+    rng = np.random.default_rng(177)
+    n, p = 2100, 4
+    X = rng.standard_normal((n, p))
+    beta = np.array([-0.5, 1.0, -1.0, 0.5, 0.25])
+    y = (rng.uniform(size=n) < 1 / (1 + np.exp(-(beta[0] + X @ beta[1:])))).astype(np.float64)
+    for chains, steps in ((6, 70), (520, 16)):
+        init = jitter_init(beta, chains, 19)
+        kw = dict(nsteps=steps, calls=2, prior_div=8.0)
+        if kind_name == "adapt":
+            run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_ADAPT, 5, init, warmup=8, **kw)
+        elif kind_name == "adapt_window":
+            run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_ADAPT, 5, init, warmup=8, bw=6, Sd=0.7, freq=2, lb=-3.0, ub=3.0, **kw)
+        elif kind_name == "ram":
+            run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_RAM, 5, init, **kw)
+        elif kind_name == "ram_bounded":
+            run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_RAM, 5, init, lb=-1.2, ub=1.2, **kw)
+        else:
+            run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_RAM, 5, init, freq=2,
+                     constr=(np.abs(np.subtract.outer(np.arange(5), np.arange(5))) <= 1).astype(float), **kw)
+        # (the bounded kernel_ram evaluates a second time only where a proposal was reflected: chain-sharded form only)
+        assert abi.last_kernel() == ("logistic-sharded" if form == "observation-sharded" and kind_name != "ram_bounded" else "streamed-logistic")
+
+
 @pytest.mark.parametrize("kind_name", ["adapt", "ram", "normal_ordered"])
-def test_logistic_on_the_general_kernel(E, O, kind_name):
-    """Logistic model with the kernels that stay on the all-family streamed kernel (adaptive kernels, single-parameter
-    schemes): its softplus reads the tables from global memory instead of LDS -- same bits as the oracle."""
+def test_logistic_on_the_general_kernel(E, O, monkeypatch, kind_name):
+    """Logistic model on the all-family streamed kernel (knob streamed=1; until round 4 the adaptive kernels ran there): its g
+    table is read from global memory instead of LDS -- same bits as the oracle."""
+    from fmcmc_amd import _abi as abi
+    set_knob(monkeypatch, "streamed", "1")
     rng = np.random.default_rng(77)
     n, p = 1300, 3
     X = rng.standard_normal((n, p))
@@ -740,6 +773,7 @@ def test_logistic_on_the_general_kernel(E, O, kind_name):
         run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_RAM, 4, init, nsteps=120, calls=2, prior_div=8.0)
     else:
         run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_NORMAL, 4, init, nsteps=150, prior_div=8.0, scale=0.1, scheme="ordered")
+    assert abi.last_kernel() == "streamed"
 
 
 SHARDED = ("streamed-wide-sharded-mfma", "wide-dataflow")     # the sequential and the dataflow form of the observation-sharded sweep
