@@ -626,7 +626,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
   AsyncScratch mfs_guard;
   if (!force && !nopipe && m->family == FMCMC_FAM_GAUSSIAN_LINREG &&
       (kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE ||
-       (((kn->kind == FMCMC_KERNEL_ADAPT && !adapt_hist) || (kn->kind == FMCMC_KERNEL_RAM && !ram_bounded && !kn->constr)) && !nospec)) &&
+       (((kn->kind == FMCMC_KERNEL_ADAPT && !adapt_hist) || (kn->kind == FMCMC_KERNEL_RAM && !kn->constr)) && !nospec)) &&
       (kn->scheme == FMCMC_SCHEME_JOINT || kn->kind >= FMCMC_KERNEL_ADAPT) && kn->k <= PIPE_KMAX &&
       // Sizes (round 3: rows and variates are addressed as 64-bit chain base + 32-bit offset, and a long call of the normal /
       // uniform kernels runs as step windows with a bounded stream, so a call no longer leaves these kernels at 4 GiB of
@@ -641,7 +641,9 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
     {
       const long long nsl = (m->n + NT - 1) / NT, nsl2 = (nsl + 1) & ~1ll;
       const int optmax = (m->p >= 1 && m->p <= 3) ? 20 : (m->p <= 5 ? 10 : (m->p <= 7 ? 8 : 0));
-      if (m->p >= 1 && nsl2 <= optmax && kn->kind >= FMCMC_KERNEL_ADAPT) pipe_opt = (int)nsl2;
+      // (the bounded kernel_ram decides on f of the REFLECTED proposal: a second evaluation in the steps in which the reflection
+      //  moved something -- the barrier-synchronised owners of mh_sweep_mfma_ad ask for it, this kernel's pipelined ones cannot)
+      if (m->p >= 1 && nsl2 <= optmax && kn->kind >= FMCMC_KERNEL_ADAPT && !(kn->kind == FMCMC_KERNEL_RAM && ram_bounded)) pipe_opt = (int)nsl2;
       // (normal / uniform kernels run on the MFMA kernel; knob mfma=0 keeps them here for the two shapes they were tuned at)
       if (m->p == 3 && nsl == 20 && kn->kind < FMCMC_KERNEL_ADAPT) pipe_opt = 20;
       if (m->p == 1 && nsl == 2 && kn->kind < FMCMC_KERNEL_ADAPT) pipe_opt = 2;
@@ -663,10 +665,14 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
     //  the general kernel, 7x the time of the normal kernels at the same shape)
     if (K.mfma != 0 && !pipe_opt && kn->kind >= FMCMC_KERNEL_ADAPT && m->p >= 1 && m->p <= 7 && kf == kn->k && (kn->k <= SPEC_KA || kn->k == 9) &&
         A.kz == kn->k && m->n < (1ll << 29)) {
-      mfma_ad = 1;
-      mfma_ng = (m->p <= 3) ? 1 : 2;
-      mfma_ext = (mfma_ng == 1) ? MfmaAdShape<1>::NSR : MfmaAdShape<2>::NSR;
+      const int ng = (m->p <= 3) ? 1 : 2, nsr = (ng == 1) ? MfmaAdShape<1>::NSR : MfmaAdShape<2>::NSR;
+      if (m->n > (long long)NT * nsr) {    // (its resident slots are all full: the bounded kernel_ram comes here from any n)
+        mfma_ad = 1;
+        mfma_ng = ng;
+        mfma_ext = nsr;
+      }
     }
+    if (kn->kind == FMCMC_KERNEL_RAM && ram_bounded && !mfma_ad) pipe_opt = 0, mfma_ng = 0;   // (general kernel)
   }
   A.spec_opt = pipe_opt;
   if (pipe_opt || mfma_ng) {
@@ -770,6 +776,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
         g_kernel = "mfma-adaptive";
         const size_t alds = mfma_ad_lds_bytes();
 #define MF_AD(GV, XV) do { if (kn->kind == FMCMC_KERNEL_ADAPT) hipLaunchKernelGGL((mh_sweep_mfma_ad<3, GV, XV>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); \
+                           else if (ram_bounded) hipLaunchKernelGGL((mh_sweep_mfma_ad<4, GV, XV, true>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); \
                            else hipLaunchKernelGGL((mh_sweep_mfma_ad<4, GV, XV>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); } while (0)
         if (mfma_ng == 1 && kn->k == 5) MF_AD(1, 5);
         else if (mfma_ng == 1) MF_AD(1, 0);

@@ -22,21 +22,43 @@ struct MfmaAdShape {
 template <class EV>
 struct MfmaAdSync {
   static constexpr bool PREP_EARLY = true;
-  EV& ev; const double* s_fold; int myc;
-  template <class F> __device__ __forceinline__ double total(int, F&& prep) const {
-    ev();
-    prep();                                     // the sigma-only half of the closed form, in the slack before the barrier
-    lds_barrier();
+  EV& ev; const double* s_fold; int myc; unsigned* s_need;
+  __device__ __forceinline__ double fold() const {
     double wsum = s_fold[myc * NW + (threadIdx.x & 7)];
     wsum = wsum + dpp_d<0xB1>(wsum);            // canonical levels 64, 128, 256 over the eight wave sums
     wsum = wsum + dpp_d<0x4E>(wsum);
     return wsum + dpp_d<0x141>(wsum);
   }
+  // bounded kernel_ram (spec_owner_adaptive_reg<.., BND>): one more barrier per step tells the workgroup whether any of its
+  // chains' proposals was moved by the reflection; if so all eight waves evaluate the four (republished) proposals once more
+  template <class W> __device__ __forceinline__ bool second(bool need, W&& republish, double& tot2) const {
+    if (need && (threadIdx.x & 63) == 0) lds_st_u32(s_need, 1u);
+    lds_barrier();
+    const bool again = __builtin_amdgcn_readfirstlane((int)lds_ld_u32(s_need)) != 0;
+    if (!again) return false;
+    republish();
+    lds_barrier();                              // (every wave has read the flag; the proposals are in place)
+    if (threadIdx.x == 0) lds_st_u32(s_need, 0u);
+    ev();
+    lds_barrier();
+    tot2 = fold();
+    return true;
+  }
+  __device__ __forceinline__ void second_idle() const {
+    double t;
+    (void)second(false, []() {}, t);
+  }
+  template <class F> __device__ __forceinline__ double total(int, F&& prep) const {
+    ev();
+    prep();                                     // the sigma-only half of the closed form, in the slack before the barrier
+    lds_barrier();
+    return fold();
+  }
   __device__ __forceinline__ void publish(int) const { lds_barrier(); }
   __device__ __forceinline__ void final() const { lds_barrier(); }
 };
 
-template <int KIND, int NG, int KX>
+template <int KIND, int NG, int KX, bool BND = false>
 __global__ __launch_bounds__(NT) void mh_sweep_mfma_ad(const SweepArgs A) {
   constexpr int CW = 4, NS = MfmaAdShape<NG>::NSR, RD = MfmaAdShape<NG>::RD, TN = NS * 4, MB = 12;
   static_assert(TN % MB == 0, "batches of MB pairs");
@@ -46,6 +68,8 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma_ad(const SweepArgs A) {
   const int k = A.k;
   double* s_th1 = smem;                            // [CW][PIPE_KMAX]
   double* s_fold = s_th1 + CW * PIPE_KMAX;         // [CW][NW] per-wave sums of every chain (canonical levels 1..32 done)
+  unsigned* s_need = reinterpret_cast<unsigned*>(s_fold + CW * NW);   // BND: "a reflection moved a proposal of this workgroup in this step"
+  if (tid == 0) lds_st_u32(s_need, 0u);
   const long long cg0 = (long long)blockIdx.x * CW;
   const int ncw = (int)((A.nchains - cg0 < CW) ? (A.nchains - cg0) : CW);
   const int nsteps = (int)A.nsteps, ic = A.intercept, P = A.p, next = A.mf_next;
@@ -161,15 +185,20 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma_ad(const SweepArgs A) {
   };
 
   const int myc = wave;
-  if (myc >= ncw) {                               // waves without a chain: evaluate, meet the two barriers of every step
-    for (int v = 1; v <= nsteps; v++) { evaluate(); lds_barrier(); lds_barrier(); }
+  MfmaAdSync<decltype(evaluate)> sync{evaluate, s_fold, myc < ncw ? myc : 0, s_need};
+  if (myc >= ncw) {                               // waves without a chain: evaluate, meet the barriers of every step
+    for (int v = 1; v <= nsteps; v++) {
+      evaluate();
+      lds_barrier();
+      if constexpr (BND) sync.second_idle();
+      lds_barrier();
+    }
     return;
   }
   const int cl = __builtin_amdgcn_readfirstlane((int)cg0 + myc);
-  MfmaAdSync<decltype(evaluate)> sync{evaluate, s_fold, myc};
-  spec_owner_adaptive_reg<KIND, KX>(A, myc, cl, s_th1, sync);
+  spec_owner_adaptive_reg<KIND, KX, decltype(sync), BND>(A, myc, cl, s_th1, sync);
 }
 
-size_t mfma_ad_lds_bytes() { return sizeof(double) * ((size_t)4 * PIPE_KMAX + 4 * NW); }
+size_t mfma_ad_lds_bytes() { return sizeof(double) * ((size_t)4 * PIPE_KMAX + 4 * NW + 1); }
 
 }  // namespace

@@ -29,6 +29,10 @@ __device__ __forceinline__ unsigned lds_ld_u32(const unsigned* p) {
   return v;
 }
 
+__device__ __forceinline__ void lds_st_u32(unsigned* p, unsigned v) {   // (completed by the s_waitcnt of the next lds_barrier)
+  asm volatile("ds_write_b32 %0, %1" : : "v"((unsigned)(size_t)p), "v"(v) : "memory");
+}
+
 __device__ __forceinline__ double lds_ld_f64(const double* p) {   // ordered after a preceding flag poll
   double v;
   asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(size_t)p) : "memory");
@@ -339,8 +343,13 @@ struct SpecSync {
   }
   __device__ __forceinline__ void final() const {}
 };
-template <int KIND, int KX, class SYNC>
+// BND (kernel_ram with bounds, R/kernel_ram.R:123-157 + R/mcmc.R:749-753): the adaptation takes f of the proposal as drawn, the
+// decision f of the REFLECTED proposal -- a second evaluation, needed only in the steps in which a reflection moved something.  The
+// policy decides it for its workgroup: second(need, republish, tot2) -> true when a second evaluation ran (tot2: its total for this
+// chain), second_idle() for an owner that has nothing to ask in this step but must keep in step (MfmaAdSync; SpecSync has neither).
+template <int KIND, int KX, class SYNC, bool BND = false>
 __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int myc, int cl, double* s_th1, SYNC& sync) {
+  static_assert(!BND || KIND == FMCMC_KERNEL_RAM, "BND is the bounded kernel_ram");
   constexpr int KA = KX > 0 ? KX : SPEC_KA;
   const int lane = threadIdx.x & 63;
   const int k = KX > 0 ? KX : A.k, kf = k, kz = KX > 0 ? KX : A.kz;
@@ -445,13 +454,16 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
     else f1 = logpost_of(tot, readlane_d(th1, k - 1));
     bool st_row = false;
     double st_th0 = 0.0;
-    const double st_dr = th1;
+    double st_dr = th1;
     SPEC_ST(1);
     if (v == 1) {
       f0 = f1;
       run_sum = th0;
       if (1 > burnin) { thin_ctr += 1; if (thin_ctr == thin) { thin_ctr = 0; st_row = true; st_th0 = th0; } }
-    } else if (status == FMCMC_CHAIN_OK) {
+      if constexpr (BND) sync.second_idle();
+    } else if (status != FMCMC_CHAIN_OK) {
+      if constexpr (BND) sync.second_idle();
+    } else {
       const int i = v;
       if (KIND == FMCMC_KERNEL_RAM) {   // adaptation with f(theta1) of the pending proposal (R/kernel_ram.R:129-152)
         if (ram_gate) {
@@ -479,6 +491,15 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
           }
         }
         abs_iter += 1;
+        if constexpr (BND) {
+          const double th1r = reflect1(th1, lb_l, ub_l);
+          const bool moved = __any(rl && !(th1r == th1));
+          th1 = th1r;
+          st_dr = th1r;                               // (the row of draws is the proposal the kernel returns: reflected)
+          double tot2 = 0.0;
+          const bool again = sync.second(moved, [&]() { if (rl) s_th1[myc * PIPE_KMAX + lane] = th1; }, tot2);
+          if (again && moved) f1 = logpost_of(tot2, readlane_d(th1, k - 1));   // (not moved: the same vector, the same f)
+        }
       }
       if (fmh_isnan(f1)) status = FMCMC_CHAIN_NAN_LOGPOST;
       const double ratio = f1 - f0;

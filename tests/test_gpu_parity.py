@@ -634,7 +634,7 @@ def test_mfma_kernel_beyond_its_operand_registers(E, O, n, p):
     assert abi.last_kernel() == "mfma-streamed"
 
 
-@pytest.mark.parametrize("n,p,intercept", [(10241, 3, True), (20000, 3, True), (12001, 3, False), (30000, 2, True), (5121, 5, True), (6500, 6, True), (9000, 4, False), (6000, 7, True), (8200, 7, False)])
+@pytest.mark.parametrize("n,p,intercept", [(10241, 3, True), (20000, 3, True), (12001, 3, False), (30000, 2, True), (5121, 5, True), (6500, 6, True), (9000, 4, False), (6000, 7, True), (8200, 7, False), (7000, 3, True), (10000, 3, True), (3100, 5, True)])
 def test_adaptive_kernels_on_the_streamed_mfma_evaluation(E, O, n, p, intercept):
     """mh_sweep_mfma_ad (round 4): kernel_adapt / kernel_ram beyond mh_sweep_spec's registers -- the streamed MFMA evaluation of
     all four chains of a workgroup, then one step of the register-row adaptive owners between barriers.  k = 5 (the
@@ -644,9 +644,17 @@ def test_adaptive_kernels_on_the_streamed_mfma_evaluation(E, O, n, p, intercept)
     k = p + 1 + (1 if intercept else 0)
     init = jitter_init(([0.0] if intercept else []) + [0.0] * p + [float(np.std(y))], 6, 97 + p)
     init[:, -1] = np.abs(init[:, -1])
+    unbounded = "spec" if n <= (10240 if p <= 3 else (5120 if p <= 5 else 4096)) else "mfma-adaptive"   # (the bounded kernel_ram comes here from any n)
     run_both(E, O, O.FAM_LINREG, X, y, O.K_ADAPT, k, init, nsteps=80, calls=2, warmup=20, intercept=intercept)
-    assert abi.last_kernel() == "mfma-adaptive"
+    assert abi.last_kernel() == unbounded
     run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, k, init, nsteps=60, calls=2, intercept=intercept)
+    assert abi.last_kernel() == unbounded
+    # kernel_ram with bounds (the advanced-features vignette's kernel_ram(lb = c(NA, NA, NA, .001))): the decision takes f of the
+    # REFLECTED proposal -- a second evaluation of the workgroup's four chains in the steps in which a reflection moved one
+    rb, ro = run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, k, init, nsteps=70, calls=2, intercept=intercept,
+                      lb=[-0.25] * (k - 1) + [0.3], ub=[0.25] * (k - 1) + [float(np.std(y)) + 0.2])
+    assert abi.last_kernel() == "mfma-adaptive" and ro.accept_count.sum() > 0
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, k, init, nsteps=40, intercept=intercept, lb=[-50.0] * (k - 1) + [0.001], ub=50.0)   # (never reflects)
     assert abi.last_kernel() == "mfma-adaptive"
 
 
