@@ -655,6 +655,11 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
       // beyond the operand registers: 16 (8) slots resident, the rest streamed from an operand-order copy every step (EXT)
       else if (m->p <= 3 && m->n < (1ll << 29)) { mfma_ng = 1; mfma_ext = 16; }
       else if (m->p <= 7 && m->n < (1ll << 29)) { mfma_ng = 2; mfma_ext = 8; }
+      // 8 .. 15 covariates (k <= 16): three / four operand groups per observation slot, four / three slots resident (one for short
+      // data), the rest streamed -- tools/dispatch_audit.py found these models on the general kernel at 0.10 of the fp64 peak where
+      // p = 7 runs at 0.44
+      else if (m->p <= 11 && m->n > NT && m->n < (1ll << 29)) { mfma_ng = 3; mfma_ext = (m->n > (long long)NT * 4) ? 4 : 1; }
+      else if (m->p <= 15 && m->n > NT && m->n < (1ll << 29)) { mfma_ng = 4; mfma_ext = (m->n > (long long)NT * 3) ? 3 : 1; }
       // (the wave-specialised VALU kernel, which overlaps owners and evaluation, used to win at its small shape
       //  (p = 1, n ~ 1000); since the instruction diet of the owner phase the MFMA kernel is 1.2-1.35x ahead there too:
       //  tools/bench_small.py.  Knob mfma=0 still selects it.)
@@ -788,7 +793,11 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
 #define MF_EXT(KV, GV, SV) do { if (big) hipLaunchKernelGGL((mh_sweep_mfma<KV, GV, SV, false, true, true>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A); \
                                 else hipLaunchKernelGGL((mh_sweep_mfma<KV, GV, SV, false, false, true>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A); } while (0)
         if (mfma_ng == 1) { if (kv == 1) MF_EXT(1, 1, 16); else MF_EXT(2, 1, 16); }
-        else { if (kv == 1) MF_EXT(1, 2, 8); else MF_EXT(2, 2, 8); }
+        else if (mfma_ng == 2) { if (kv == 1) MF_EXT(1, 2, 8); else MF_EXT(2, 2, 8); }
+        else if (mfma_ng == 3 && mfma_ext == 4) { if (kv == 1) MF_EXT(1, 3, 4); else MF_EXT(2, 3, 4); }
+        else if (mfma_ng == 3) { if (kv == 1) MF_EXT(1, 3, 1); else MF_EXT(2, 3, 1); }
+        else if (mfma_ext == 3) { if (kv == 1) MF_EXT(1, 4, 3); else MF_EXT(2, 4, 3); }
+        else { if (kv == 1) MF_EXT(1, 4, 1); else MF_EXT(2, 4, 1); }
 #undef MF_EXT
       } else if (false) {
 #ifdef FMCMC_AB   /* the stamped (DBG) instantiations: tools/stamp_mfma.py against an -DFMCMC_AB build */

@@ -634,6 +634,27 @@ def test_mfma_kernel_beyond_its_operand_registers(E, O, n, p):
     assert abi.last_kernel() == "mfma-streamed"
 
 
+@pytest.mark.parametrize("n,p,intercept", [(513, 8, True), (2048, 9, True), (2049, 11, False), (3000, 10, True), (10000, 11, True), (700, 12, True),
+                                           (1536, 13, True), (1537, 14, True), (6000, 14, False), (10001, 15, False), (12345, 12, True), (4097, 8, False)])
+def test_mfma_kernel_with_eight_to_fifteen_covariates(E, O, n, p, intercept):
+    """8 <= p <= 15 (k <= 16) on mh_sweep_mfma<.., EXT> with three / four operand groups per slot (round 4: these models ran on the
+    general kernel, 4x the time per flop of p = 7): four / three slots resident, or one for short data, the rest streamed; ragged
+    last slots, the slot-count edges, with and without intercept, normal / reflective / uniform kernels, a fixed parameter."""
+    from fmcmc_amd import _abi as abi
+    X, y = synth_linreg(n, p, 5300 + n + p, beta=np.linspace(0.8, -0.8, p + 1))
+    k = p + 1 + (1 if intercept else 0)
+    init = jitter_init(([0.0] if intercept else []) + [0.0] * p + [float(np.std(y))], 5, 96 + p)
+    init[:, -1] = np.abs(init[:, -1])
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, k, init, nsteps=60, burnin=3, thin=2, calls=2, scale=0.02, intercept=intercept)
+    assert abi.last_kernel() == "mfma-streamed"
+    fixed = [False] * k
+    fixed[2] = True
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL_REFLECTIVE, k, init, nsteps=50, scale=0.3, lb=-6.0, ub=9.0, intercept=intercept, fixed=fixed)
+    assert abi.last_kernel() == "mfma-streamed"
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_UNIF, k, init, nsteps=40, min_=-0.02, max_=0.03, intercept=intercept)
+    assert abi.last_kernel() == "mfma-streamed"
+
+
 @pytest.mark.parametrize("n,p,intercept", [(10241, 3, True), (20000, 3, True), (12001, 3, False), (30000, 2, True), (5121, 5, True), (6500, 6, True), (9000, 4, False), (6000, 7, True), (8200, 7, False), (7000, 3, True), (10000, 3, True), (3100, 5, True)])
 def test_adaptive_kernels_on_the_streamed_mfma_evaluation(E, O, n, p, intercept):
     """mh_sweep_mfma_ad (round 4): kernel_adapt / kernel_ram beyond mh_sweep_spec's registers -- the streamed MFMA evaluation of
@@ -1413,8 +1434,8 @@ def test_randomised_round4_regions(E, O, monkeypatch, case):
     calls = int(rng.integers(1, 3))
     fam = "logistic" if region == "C" else "linreg"
     if region == "A":
-        p = int(rng.choice([1, 2, 3, 3, 4, 5, 7]))
-        n = int(rng.integers(10241, 45001)) if p <= 3 else int(rng.integers(5121 if p <= 5 else 4097, 20001))
+        p = int(rng.choice([1, 2, 3, 3, 4, 5, 7, 8, 10, 13, 14]))
+        n = int(rng.integers(10241, 45001)) if p <= 3 else (int(rng.integers(5121 if p <= 5 else 4097, 20001)) if p <= 7 else int(rng.integers(513, 12001)))
         chains = int(rng.choice([1, 4, 5, 9]))
         kind_name = str(rng.choice(["normal", "reflective", "unif", "adapt", "ram"]))
     elif region == "B":
