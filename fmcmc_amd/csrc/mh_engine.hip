@@ -442,10 +442,10 @@ static int wide_sharded_lanes(const Knobs& K, const fmcmc_model* m, const fmcmc_
     // dataflow form (more than 256 chains), pay ~0.17 us per parameter in the sequential one
     const bool ram = kn->kind == FMCMC_KERNEL_RAM;
     // (with four / eight chains per workgroup -- more than 512 / 1024 chains -- the data stream is shared by more chains but a
-    //  step takes 1.1x / 2.4x as long (and the owners of a workgroup queue), and the workgroups run in rounds; the sharded sweep runs as consecutive launches)
+    //  step takes 1.3x / 2.4x as long (and the owners of a workgroup queue), and the workgroups run in rounds; the sharded sweep runs as consecutive launches)
     const double rounds = (double)((run->nchains + (long long)cw_now * ncu - 1) / ((long long)cw_now * ncu));
     const double launches = (double)((run->nchains + per_launch - 1) / per_launch);
-    const double est_chain = (4.0 + (double)m->n * (double)m->p * 8.0 / 65000.0 * (cw_now >= 8 ? 2.4 : (cw_now == 4 ? 1.1 : 1.0)) +
+    const double est_chain = (4.0 + (double)m->n * (double)m->p * 8.0 / 65000.0 * (cw_now >= 8 ? 2.4 : (cw_now == 4 ? 1.3 : 1.0)) +
                               (ram ? 0.075 * (double)kn->k * (double)(cw_now < 2 ? 2 : cw_now) : 0.0)) * rounds;
     const double frac = (double)(run->nchains < per_launch ? run->nchains : per_launch) / 512.0;
     double est_shard;
@@ -668,11 +668,13 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
     // adaptive owners between barriers (mh_mfma_ad.hpp); no fixed parameter, k <= 8
     // (k = 9 -- seven covariates, intercept and sigma -- as a compile-time row count: tools/dispatch_audit.py found these calls on
     //  the general kernel, 7x the time of the normal kernels at the same shape)
-    if (K.mfma != 0 && !pipe_opt && kn->kind >= FMCMC_KERNEL_ADAPT && m->p >= 1 && m->p <= 7 && kf == kn->k && (kn->k <= SPEC_KA || kn->k == 9) &&
-        A.kz == kn->k && m->n < (1ll << 29)) {
-      const int ng = (m->p <= 3) ? 1 : 2, nsr = (ng == 1) ? MfmaAdShape<1>::NSR : MfmaAdShape<2>::NSR;
-      if (m->n > (long long)NT * nsr) {    // (its resident slots are all full: the bounded kernel_ram comes here from any n)
-        mfma_ad = 1;
+    // (mfma_ad == 2: the owners with their matrices in LDS -- 8 .. 15 covariates, or a fixed parameter; not the bounded kernel_ram)
+    if (K.mfma != 0 && !pipe_opt && kn->kind >= FMCMC_KERNEL_ADAPT && m->p >= 1 && m->p <= 15 && m->n < (1ll << 29)) {
+      const bool reg_owner = m->p <= 7 && kf == kn->k && (kn->k <= SPEC_KA || kn->k == 9) && A.kz == kn->k;
+      const int ng = (m->p <= 3) ? 1 : (m->p <= 7 ? 2 : (m->p <= 11 ? 3 : 4));
+      const int nsr = (ng == 1) ? MfmaAdShape<1>::NSR : (ng == 2 ? MfmaAdShape<2>::NSR : MfmaAdShape<3>::NSR);
+      if (m->n > (long long)NT * nsr && (reg_owner || !(kn->kind == FMCMC_KERNEL_RAM && ram_bounded))) {   // (its resident slots are all full)
+        mfma_ad = reg_owner ? 1 : 2;
         mfma_ng = ng;
         mfma_ext = nsr;
       }
@@ -779,14 +781,18 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
 #define MF_CASES17(KN, KV, GV) MF_CASE(KN, KV, GV, 17) MF_CASE(KN, KV, GV, 18) MF_CASE(KN, KV, GV, 19) MF_CASE(KN, KV, GV, 20)
       if (mfma_ad) {
         g_kernel = "mfma-adaptive";
-        const size_t alds = mfma_ad_lds_bytes();
+        const size_t alds = mfma_ad_lds_bytes(mfma_ad == 2);
 #define MF_AD(GV, XV) do { if (kn->kind == FMCMC_KERNEL_ADAPT) hipLaunchKernelGGL((mh_sweep_mfma_ad<3, GV, XV>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); \
                            else if (ram_bounded) hipLaunchKernelGGL((mh_sweep_mfma_ad<4, GV, XV, true>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); \
                            else hipLaunchKernelGGL((mh_sweep_mfma_ad<4, GV, XV>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); } while (0)
-        if (mfma_ng == 1 && kn->k == 5) MF_AD(1, 5);
+#define MF_ADL(GV) do { if (kn->kind == FMCMC_KERNEL_ADAPT) hipLaunchKernelGGL((mh_sweep_mfma_ad<3, GV, -1>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); \
+                        else hipLaunchKernelGGL((mh_sweep_mfma_ad<4, GV, -1>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); } while (0)
+        if (mfma_ad == 2) { if (mfma_ng == 1) MF_ADL(1); else if (mfma_ng == 2) MF_ADL(2); else if (mfma_ng == 3) MF_ADL(3); else MF_ADL(4); }
+        else if (mfma_ng == 1 && kn->k == 5) MF_AD(1, 5);
         else if (mfma_ng == 1) MF_AD(1, 0);
         else if (kn->k == 9) MF_AD(2, 9);
         else MF_AD(2, 0);
+#undef MF_ADL
 #undef MF_AD
       } else if (mfma_ext) {
         g_kernel = "mfma-streamed";

@@ -14,7 +14,7 @@ namespace {
 // costs the normal kernels on mh_sweep_mfma; below them mh_sweep_spec, which overlaps owners and evaluation, stays the kernel.
 template <int NG>
 struct MfmaAdShape {
-  static constexpr int NSR = (NG == 1) ? 12 : 6;    // resident slots (operand registers: 4 NSR NG doubles per lane)
+  static constexpr int NSR = (NG == 1) ? 12 : (NG == 2 ? 6 : 3);    // resident slots (operand registers: 4 NSR NG doubles per lane)
   static constexpr int RD = (NG == 1) ? 4 : 2;      // streamed slots in flight per wave
 };
 
@@ -62,6 +62,7 @@ template <int KIND, int NG, int KX, bool BND = false>
 __global__ __launch_bounds__(NT) void mh_sweep_mfma_ad(const SweepArgs A) {
   constexpr int CW = 4, NS = MfmaAdShape<NG>::NSR, RD = MfmaAdShape<NG>::RD, TN = NS * 4, MB = 12;
   static_assert(TN % MB == 0, "batches of MB pairs");
+  static_assert(KX >= 0 || !BND, "the bounded kernel_ram has the register-row owner only");
   extern __shared__ double smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -69,7 +70,16 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma_ad(const SweepArgs A) {
   double* s_th1 = smem;                            // [CW][PIPE_KMAX]
   double* s_fold = s_th1 + CW * PIPE_KMAX;         // [CW][NW] per-wave sums of every chain (canonical levels 1..32 done)
   unsigned* s_need = reinterpret_cast<unsigned*>(s_fold + CW * NW);   // BND: "a reflection moved a proposal of this workgroup in this step"
+  double* s_par = s_fold + CW * NW + 1;            // KX < 0: [4][PIPE_KMAX] mu | scale | lb | ub, then [CW][SPEC_ADS] the owners' matrices
+  double* s_ad = s_par + 4 * PIPE_KMAX;
   if (tid == 0) lds_st_u32(s_need, 0u);
+  if (KX < 0 && tid < PIPE_KMAX) {
+    const bool in = tid < A.k;
+    s_par[0 * PIPE_KMAX + tid] = in ? A.mu[tid] : 0.0;
+    s_par[1 * PIPE_KMAX + tid] = in ? A.scale[tid] : 0.0;
+    s_par[2 * PIPE_KMAX + tid] = in ? A.lb[tid] : 0.0;
+    s_par[3 * PIPE_KMAX + tid] = in ? A.ub[tid] : 0.0;
+  }
   const long long cg0 = (long long)blockIdx.x * CW;
   const int ncw = (int)((A.nchains - cg0 < CW) ? (A.nchains - cg0) : CW);
   const int nsteps = (int)A.nsteps, ic = A.intercept, P = A.p, next = A.mf_next;
@@ -196,9 +206,12 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma_ad(const SweepArgs A) {
     return;
   }
   const int cl = __builtin_amdgcn_readfirstlane((int)cg0 + myc);
-  spec_owner_adaptive_reg<KIND, KX, decltype(sync), BND>(A, myc, cl, s_th1, sync);
+  // KX < 0: the owners with their matrices in LDS (spec_owner_adaptive: any k <= 16, fixed parameters) -- 8 .. 15 covariates, or a
+  // fixed parameter, beyond the wave-specialised kernel's range
+  if constexpr (KX < 0) spec_owner_adaptive<KIND>(A, myc, cl, s_th1, s_par, sync, s_ad + myc * SPEC_ADS);
+  else spec_owner_adaptive_reg<KIND, KX, decltype(sync), BND>(A, myc, cl, s_th1, sync);
 }
 
-size_t mfma_ad_lds_bytes() { return sizeof(double) * ((size_t)4 * PIPE_KMAX + 4 * NW + 1); }
+size_t mfma_ad_lds_bytes(bool lds_owner) { return sizeof(double) * ((size_t)4 * PIPE_KMAX + 4 * NW + 1 + (lds_owner ? 4 * PIPE_KMAX + 4 * SPEC_ADS : 0)); }
 
 }  // namespace

@@ -47,9 +47,9 @@ constexpr int SPEC_ADS = 7 * PIPE_KMAX + 2 * PIPE_KMAX * SPEC_ALD;  // doubles o
 // Owner role of the specialised kernel for kernel_adapt (R/kernel_adapt.R:117-180) and kernel_ram
 // (R/kernel_ram.R:123-158, unbounded parameters): same wave-collective arithmetic as mh_sweep_kernel (lanes = rows
 // of Sigma / S, twin of the oracle's propose_adapt / propose_ram), state in LDS, variates from the HBM stream.
-template <int KIND>
-__device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc, int cl, double* s_th1, double* s_par,
-                                                    unsigned* s_ready, unsigned* s_done, double* s_tr, double* ad) {
+template <int KIND, class SYNC>   // SYNC: how the owner meets the evaluation (SpecSync below / MfmaAdSync, mh_mfma_ad.hpp)
+__device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc, int cl, double* s_th1, const double* s_par,
+                                                    SYNC& sync, double* ad) {
   const int lane = threadIdx.x & 63;
   const int k = A.k, kz = A.kz, nsteps = (int)A.nsteps, burnin = (int)A.burnin, thin = (int)A.thin;
   constexpr int LD = SPEC_ALD;
@@ -112,11 +112,7 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
   };
 
   for (int v = 1; v <= nsteps; v++) {
-    while (lds_ld_u32(&s_done[myc]) < 8u * (unsigned)v) __builtin_amdgcn_s_sleep(1);
-    const double* src = s_tr + myc * (8 * PIPE_TRS) + lane;
-    const double v0 = src[0 * PIPE_TRS], v1 = src[1 * PIPE_TRS], v2 = src[2 * PIPE_TRS], v3 = src[3 * PIPE_TRS];
-    const double v4 = src[4 * PIPE_TRS], v5 = src[5 * PIPE_TRS], v6 = src[6 * PIPE_TRS], v7 = src[7 * PIPE_TRS];
-    const double tot = wave_xor_sum(((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7)));
+    const double tot = sync.total(v, []() {});
     const double f1 = finish_logpost(A, th1, tot);
     bool keep_row = false, st_row = false;
     double st_th0 = 0.0, st_dr = 0.0;
@@ -280,8 +276,9 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
         wave_sync_lds();
         if (lane < k) s_th1[myc * PIPE_KMAX + lane] = th1[lane];
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (lane == 0) __hip_atomic_store(&s_ready[myc], (unsigned)(v + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      sync.publish(v + 1);
+    } else {
+      sync.final();
     }
     if (st_row) {   // row v of ans / draws / logpost, off the compute waves' critical path
       if (lane < k) {
@@ -775,7 +772,7 @@ __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
     else if (k <= SPEC_KA && nofixed && !(A.debug & 16))
       spec_owner_adaptive_reg<KIND, 0>(A, myc, cl, s_th1, sync);
     else
-      spec_owner_adaptive<KIND>(A, myc, cl, s_th1, s_par, s_ready, s_done, s_tr, s_ad + myc * SPEC_ADS);
+      spec_owner_adaptive<KIND>(A, myc, cl, s_th1, s_par, sync, s_ad + myc * SPEC_ADS);
     return;
   }
   const bool plane = (lane < k);

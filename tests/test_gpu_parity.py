@@ -679,6 +679,31 @@ def test_adaptive_kernels_on_the_streamed_mfma_evaluation(E, O, n, p, intercept)
     assert abi.last_kernel() == "mfma-adaptive"
 
 
+@pytest.mark.parametrize("n,p,intercept,fix", [(3000, 9, True, False), (10000, 11, True, False), (2049, 12, False, False), (1537, 13, True, True),
+                                               (6000, 14, True, False), (12000, 3, True, True), (6000, 6, True, True), (20000, 8, False, True)])
+def test_adaptive_kernels_with_their_matrices_in_lds_on_the_streamed_mfma_evaluation(E, O, n, p, intercept, fix):
+    """mh_sweep_mfma_ad<KIND, NG, -1> (round 4): kernel_adapt / kernel_ram with 8 .. 15 covariates (k <= 16), or with a fixed
+    parameter beyond the wave-specialised kernel's range -- the owners that keep their matrices in LDS (spec_owner_adaptive, any
+    k <= 16) between the barriers of the streamed MFMA evaluation, three / four operand groups per slot.  These calls ran on the
+    general kernel (tools/dispatch_audit.py: 22 .. 55 us per step at n = 1e4)."""
+    from fmcmc_amd import _abi as abi
+    X, y = synth_linreg(n, p, 6400 + n + p, beta=np.linspace(0.7, -0.7, p + 1))
+    k = p + 1 + (1 if intercept else 0)
+    init = jitter_init(([0.0] if intercept else []) + [0.0] * p + [float(np.std(y))], 6, 98 + p)
+    init[:, -1] = np.abs(init[:, -1])
+    fixed = [False] * k
+    if fix:
+        fixed[1] = True
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_ADAPT, k, init, nsteps=70, calls=2, warmup=15, intercept=intercept, fixed=fixed)
+    assert abi.last_kernel() == "mfma-adaptive"
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_ADAPT, k, init, nsteps=50, warmup=10, intercept=intercept, fixed=fixed, lb=-4.0, ub=9.0, until=30.0)
+    assert abi.last_kernel() == "mfma-adaptive"
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, k, init, nsteps=60, calls=2, intercept=intercept, fixed=fixed, burnin=2, thin=3)
+    assert abi.last_kernel() == "mfma-adaptive"
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, k, init, nsteps=40, intercept=intercept, fixed=fixed, ram_qfun=1, warmup=4, freq=2)
+    assert abi.last_kernel() == "mfma-adaptive"
+
+
 @pytest.mark.parametrize("k", [65, 100, 128])
 @pytest.mark.parametrize("kind_name", ["ram", "adapt", "normal", "ram_bounded"])
 def test_more_parameters_than_a_wavefront_has_lanes(E, O, k, kind_name):
