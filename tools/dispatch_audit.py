@@ -1,5 +1,5 @@
 """Dispatch audit (profiles/r04_dispatch_audit.md): does the dispatcher pick the fastest kernel it has?  For a grid of shapes
-(Gaussian linreg narrow and wide, logistic) x chain counts x kernel_* every sweep is timed on the dispatcher's own choice and
+(Gaussian linreg p = 1 .. 14 and wide, logistic) x chain counts x kernel_* every sweep is timed on the dispatcher's own choice and
 on the alternatives the diagnosis knobs can force (FMCMC_AMD_DEBUG, read once per call: mfma=0, spec=0, streamed=1, shard=0|1,
 wide2=0, shard_mfma=0); a row is flagged when an alternative beats the default by more than 5 %.
   python tools/dispatch_audit.py [out.md] [--quick] [--only=narrow,wide,logistic]      (on the GPU box; HIP events around the sweep, best of 3)"""
@@ -93,7 +93,7 @@ if QUICK:
     grid_wide = [(5000, 48, 512)]
     grid_logit = [(30000, 5, 1024)]
 else:
-    grid_narrow = [(n, p, c) for n in (300, 1000, 3000, 6000, 10000, 10241, 15000, 30000) for p in (1, 3, 5, 7) for c in (64, 1024, 4096)]
+    grid_narrow = [(n, p, c) for n in (300, 1000, 3000, 6000, 10000, 10241, 15000, 30000) for p in (1, 3, 5, 7, 10, 14) for c in (64, 1024, 4096)]
     grid_wide = [(n, p, c) for n in (1000, 5000, 10000, 20000) for p in (16, 30, 48, 60) for c in (64, 512, 2048)]
     grid_logit = [(n, p, c) for n in (2000, 10000, 30000, 100000) for p in (2, 5, 8, 12) for c in (64, 512, 1024, 4096)]
 for n, p, c in (grid_narrow if "narrow" in ONLY else []):
