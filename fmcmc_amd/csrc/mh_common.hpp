@@ -565,8 +565,10 @@ __device__ __attribute__((noinline)) void shard_columns(ShardCols c) {
 // 16 kk + 4 blk + i wants row 4 r + i of the tile whatever blk is, so the third tile's region holds, per K-block, the 32
 // doubles [kk][i][r] (one ds_read_b128 per lane and K-block) instead of 64.  Matrix-core time per tile: 12 x (2 x 64 + 2 x 16.7)
 // = 1936 cycles against 2304.
-constexpr int SHM_T = 12;                       // D values per lane and N-tile (3 M-tiles x 4 registers)
-constexpr int SHM_HDR = 32 + SHM_T * 64;        // doubles in front of the A tiles
+constexpr int SHM_T = 24;                       // D values per lane and N-tile at most (6 M-tiles x 4 registers; 3 until round 4: n <= 10,240)
+// doubles in front of the A tiles of a block with nmt M-tiles: 32 of validity bits, then y in D layout for its 4 nmt values per lane
+// (never less than the three-tile header of rounds 2-3, so that the tuned forms keep their addresses)
+__host__ __device__ constexpr int shm_hdr(int nmt) { return 32 + (nmt < 3 ? 12 : 4 * nmt) * 64; }
 constexpr int SHM_KBMAX = 16;                   // K-blocks of 4 columns: p <= 64
 constexpr int SHM_T10_FULL = 7;                 // form T10: values 0..6 of every lane group are observations (checked by the host)
 typedef double d4_t __attribute__((ext_vector_type(4)));
@@ -607,12 +609,13 @@ __device__ __attribute__((noinline)) void shard_columns_mfma(ShardMfma c) {
   double ya[SHM_T];
 #pragma unroll
   for (int t = 0; t < NTV; t++) ya[t] = blk[32 + 64 * t + lane];
-  const ldsc_t xa = blk + SHM_HDR + lane;       // tile (mt, kb) at xa[(mt KB + kb) 64]
+  constexpr int HDR = shm_hdr(NMT);
+  const ldsc_t xa = blk + HDR + lane;           // tile (mt, kb) at xa[(mt KB + kb) 64]
   const int kk = lane >> 4, j = lane & 15;
   typedef double d2_t __attribute__((ext_vector_type(2)));
   typedef __attribute__((address_space(3))) const d2_t* ldsc2_t;
   // (T10) rows 4 r + i of the third tile, r = 0, 1, for column kk of K-block kb: xa4[kb * 32]
-  const ldsc2_t xa4 = (ldsc2_t)(blk + SHM_HDR + 2 * KB * 64 + 2 * (4 * kk + (lane & 3)));
+  const ldsc2_t xa4 = (ldsc2_t)(blk + HDR + 2 * KB * 64 + 2 * (4 * kk + (lane & 3)));
   const int ntiles_all = (NC + 15) >> 4;
   // (the wave's share: tfirst, tfirst + tstep, ..., at most tcount of them)
   const int ntiles = (tcount > 0 && tfirst + tcount * tstep < ntiles_all) ? tfirst + (tcount - 1) * tstep + 1 : ntiles_all;
@@ -818,6 +821,9 @@ __device__ __forceinline__ bool eval_sharded(const SweepArgs& A, double* const* 
     const bool kb12 = ((p + 3) >> 2) == 12;   // (config C4's width gets the instantiation with a compile-time K-block count)
     if (A.sh_nmt == 1) shard_columns_mfma<LPW, 1>(sm);
     else if (A.sh_nmt == 2) shard_columns_mfma<LPW, 2>(sm);
+    else if (A.sh_nmt == 4) shard_columns_mfma<LPW, 4>(sm);      // (slices of 41 .. 96 observations: 10,240 < n <= 24,576 at 256 workgroups)
+    else if (A.sh_nmt == 5) shard_columns_mfma<LPW, 5>(sm);
+    else if (A.sh_nmt == 6) shard_columns_mfma<LPW, 6>(sm);
     else if (kb12 && A.sh_t10) shard_columns_mfma<LPW, 3, 12, true>(sm);
     else if (kb12) shard_columns_mfma<LPW, 3, 12>(sm);
     else shard_columns_mfma<LPW, 3>(sm);

@@ -157,12 +157,12 @@ __global__ void shard_build_slices(const double* X, const double* y, long long n
 }
 
 // the same slices in fp64-MFMA operand layout (mh_common.hpp, shard_columns_mfma): per workgroup a block of
-// SHM_HDR + nmt KB 64 doubles = validity bits | y in D layout | A tiles [mt][kb][lane]
+// shm_hdr(nmt) + nmt KB 64 doubles = validity bits | y in D layout | A tiles [mt][kb][lane]
 // t10: the third M-tile in the layout of the two 4x4x4 MFMAs that compute its 8 live rows, per K-block 32 doubles [kk][i][r]
 // = row 4 r + i of the tile (value t = 8 + r of lane group i), column 4 kb + kk; the other 32 doubles of the K-block stay 0
 __global__ void shard_build_mfma(const double* X, const double* y, long long n, int p, int lpw, int nslots, int nmt, int t10,
                                  double* out, int blk_doubles) {
-  const int b = blockIdx.x, KB = (p + 3) >> 2, H = 4 / lpw, spg = (nslots + H - 1) / H;
+  const int b = blockIdx.x, KB = (p + 3) >> 2, H = 4 / lpw, spg = (nslots + H - 1) / H, HDR = shm_hdr(nmt);
   double* o = out + (long long)b * blk_doubles;
   auto obs_of = [&](int g, int t) -> long long {   // observation at D position (lane group g, value t), -1: none
     const int q = g / H, h = g % H;
@@ -183,12 +183,12 @@ __global__ void shard_build_mfma(const double* X, const double* y, long long n, 
       }
       ((unsigned*)o)[2 * idx] = w[0];
       ((unsigned*)o)[2 * idx + 1] = w[1];
-    } else if (idx < SHM_HDR) {
+    } else if (idx < HDR) {
       const int t = (idx - 32) >> 6, lane = (idx - 32) & 63;
       const long long i = obs_of(lane >> 4, t);
       o[idx] = i >= 0 ? y[i] : 0.0;
     } else {
-      const int e = idx - SHM_HDR, lane = e & 63, kb = (e >> 6) % KB, mt = (e >> 6) / KB;
+      const int e = idx - HDR, lane = e & 63, kb = (e >> 6) % KB, mt = (e >> 6) / KB;
       if (t10 && mt == 2) {
         const int kk4 = lane >> 3, i4 = (lane >> 1) & 3, r4 = lane & 1, col4 = 4 * kb + kk4;
         const long long i = lane < 32 ? obs_of(i4, 8 + r4) : -1;
@@ -430,7 +430,10 @@ static int wide_sharded_lanes(const Knobs& K, const fmcmc_model* m, const fmcmc_
   // normal kernels (k = 64, n = 10k: 57 us per step against 78); kernel_ram stays chain-sharded there, its owner phase
   // dominates at that width and runs slower in the sharded instantiation (121 against 108).
   const bool cached = shard_mfma_enabled(K) || (size_t)m->p * SH_MAXO * sizeof(double) <= 15872;   // (the MFMA form keeps the slice in LDS)
-  const bool ok = lpw > 0 && !(kn->kind == FMCMC_KERNEL_RAM && (ram_bounded || !cached)) && lpw * nslots <= SH_MAXO && nb <= ncu &&
+  // (a slice holds up to SH_MAXO = 40 observations in the scalar / register form, up to 4 SHM_T = 96 -- six M-tiles -- in LDS for the
+  //  matrix-core form: n <= 24,576 at 256 workgroups)
+  const bool mf_ok = shard_mfma_enabled(K) && m->p <= 4 * SHM_KBMAX;
+  const bool ok = lpw > 0 && !(kn->kind == FMCMC_KERNEL_RAM && (ram_bounded || !cached)) && lpw * nslots <= (mf_ok ? 4 * SHM_T : SH_MAXO) && nb <= ncu &&
                   (long long)m->p * SH_MAXO * nb < (1ll << 28) && (long long)(m->p + 1) * (per_launch + SH_PAD) < (1ll << 31) &&
                   run->nsteps < 30000000;   /* barrier epochs (2 per step) x workgroups per group stay below 2^32 */
   if (!ok) return 0;
@@ -449,8 +452,14 @@ static int wide_sharded_lanes(const Knobs& K, const fmcmc_model* m, const fmcmc_
                               (ram ? 0.075 * (double)kn->k * (double)(cw_now < 2 ? 2 : cw_now) : 0.0)) * rounds;
     const double frac = (double)(run->nchains < per_launch ? run->nchains : per_launch) / 512.0;
     double est_shard;
-    if (shard_mfma_enabled(K) && m->p <= 4 * SHM_KBMAX)
-      est_shard = 9.3 + frac * (3.2 + (double)m->p * (0.08 + 0.00475 * (double)(lpw * nslots))) + ((ram && run->nchains <= 256) ? 0.17 * (double)kn->k : 0.0);
+    if (shard_mfma_enabled(K) && m->p <= 4 * SHM_KBMAX) {
+      // (more than three M-tiles: the run-time K-block loop, +5 us; kernel_ram's owners are hidden by the dataflow form only -- more
+      //  than 256 chains, at most three M-tiles --, else ~0.17 us per parameter for few chains, ~0.3 in full launches)
+      const bool tall = lpw * nslots > SH_MAXO;
+      const bool hidden = ram && run->nchains > 256 && !tall;
+      est_shard = 9.3 + (tall ? 5.0 : 0.0) + frac * (3.2 + (double)m->p * (0.08 + 0.00475 * (double)(lpw * nslots))) +
+                  ((ram && !hidden) ? (run->nchains <= 256 ? 0.17 : 0.3) * (double)kn->k : 0.0);
+    }
     else {
       const double walked = (cached ? 1.0 : 2.1) * ((lpw * nslots <= SH_MAXO / 2) ? SH_MAXO / 2 : SH_MAXO);
       est_shard = 14.0 + 0.0085 * (double)m->p * walked + (ram ? 6.0 : 0.0);
@@ -1049,7 +1058,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
     const size_t lds_plain = lds;   // what the chain-sharded kernel needs, should the sharded forms below not launch
     // the slice product on the matrix cores (shard_columns_mfma): the slice lives in LDS behind the chain blocks
     const int mf_spg = shard ? (nslots + 4 / lpw - 1) / (4 / lpw) : 0, nmt = (mf_spg + 3) / 4;
-    const int mblk = SHM_HDR + nmt * ((m->p + 3) / 4) * 64;
+    const int mblk = shm_hdr(nmt) + nmt * ((m->p + 3) / 4) * 64;
     // (three M-tiles of which the third holds values 8, 9 only, at the width with a compile-time K-block count -- config C4:
     //  its 8 rows go through two 4x4x4 MFMAs per K-block instead of a 16x16x4 that is half padding; knob t10=0: off)
     //  (the form reads values 0 .. SHM_T10_FULL - 1 of every lane group without a mask: slots spg h + t <= nslots - 2 are full)
@@ -1058,6 +1067,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
     bool mfma_form = shard && shard_mfma_enabled(K) && m->p <= 4 * SHM_KBMAX && mf_spg <= SHM_T &&
                      lds + sizeof(double) * (size_t)(mblk + 1) <= 160 * 1024;
     if (mfma_form) lds += sizeof(double) * (size_t)(mblk + 1);
+    if (shard && !mfma_form && lpw * nslots > SH_MAXO) shard = false;      // (more than 40 observations per slice: the matrix-core form or none)
     if (shard) g_kernel = mfma_form ? "streamed-wide-sharded-mfma" : "streamed-wide-sharded";
     // the dataflow form (mh_wide2.hpp): owner and evaluator waves decoupled, two chain groups half a step out of phase.
     // It pays where the owners have real work to hide -- kernel_ram: 35.8 -> 27.9 us per step at C4 -- and costs the normal

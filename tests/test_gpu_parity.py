@@ -857,6 +857,36 @@ def test_ram_families_in_the_dataflow_form(E, O, monkeypatch):
             assert abi.last_kernel() == "wide-dataflow"
 
 
+@pytest.mark.parametrize("n,p,chains,intercept", [(10241, 20, 6, True), (12289, 33, 40, True), (16385, 17, 5, False), (20480, 48, 9, True),
+                                                  (20481, 16, 300, True), (24576, 60, 7, True), (23000, 21, 513, True)])
+def test_observation_sharded_slices_beyond_forty_observations(E, O, monkeypatch, n, p, chains, intercept):
+    """Wide linear models with 10,240 < n <= 24,576 (round 4): the slice of a workgroup -- 41 .. 96 observations -- as four to six
+    M-tiles of the matrix-core slice product (it was three: tools/dispatch_audit.py found p = 48, n = 2e4 on the chain-sharded
+    kernel at 6.4x the time per step of n = 1e4).  The tile-count edges, ragged last slots, few and many chains (consecutive
+    launches above 512), kernel_normal, kernel_normal_reflective and kernel_ram (sequential form), two calls: the oracle's bits."""
+    import torch
+    from fmcmc_amd import _abi as abi
+    set_knob(monkeypatch, "shard", "1")
+    rng = np.random.default_rng(n + p)
+    beta = rng.uniform(-1.0, 1.0, p + 1)
+    X = rng.standard_normal((n, p))
+    y = (beta[0] if intercept else 0.0) + X @ beta[1:] + 2.0 * rng.standard_normal(n)
+    k = p + 1 + (1 if intercept else 0)
+    init = jitter_init(list(beta[(0 if intercept else 1):]) + [2.0], chains, 5 + p)
+    init[:, -1] = np.abs(init[:, -1]) + 0.1
+    steps = int(max(6, min(30, 1.2e8 / (chains * n * p * 2))))
+    full = torch.cuda.get_device_properties(0).multi_processor_count >= 256
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, k, init, nsteps=steps, calls=2, scale=0.004, intercept=intercept)
+    if full:
+        assert abi.last_kernel() == "streamed-wide-sharded-mfma"
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL_REFLECTIVE, k, init, nsteps=steps, burnin=1, thin=2, scale=0.05, lb=-1.2, ub=2.6, intercept=intercept)
+    if full:
+        assert abi.last_kernel() == "streamed-wide-sharded-mfma"
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, k, init, nsteps=steps, calls=2, intercept=intercept)
+    if full:
+        assert abi.last_kernel() == "streamed-wide-sharded-mfma"
+
+
 @pytest.mark.parametrize("form", ["logistic-sharded", "wide-sequential", "wide-dataflow"])
 def test_a_lost_hand_over_ends_in_status_5_not_in_a_hang(E, monkeypatch, form):
     """The grid-wide hand-overs of the observation-sharded kernels, with a FAULT: knob mode=512 makes workgroup 1 skip ONE

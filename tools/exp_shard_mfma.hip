@@ -37,7 +37,7 @@ namespace {
 __global__ __launch_bounds__(EXP_NT) void bench(const double* th, double* part, double* out, int reps, int mode, int p, int nchains) {
   extern __shared__ double smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int KB = (p + 3) >> 2, mblk = SHM_HDR + 3 * KB * 64;
+  const int KB = (p + 3) >> 2, mblk = shm_hdr(3) + 3 * KB * 64;
   for (int i = tid; i < mblk; i += NT) smem[i] = (i < 32) ? 0.0 : 1e-3 * (double)((i * 2654435761u) >> 20);
   if (tid < 64) ((unsigned*)smem)[tid] = 0xfffu;
   __syncthreads();
@@ -99,7 +99,7 @@ int main() {
   std::vector<double> h(nth);
   for (size_t i = 0; i < nth; i++) h[i] = 1e-3 * (double)(i % 977);
   CK(hipMemcpy(th, h.data(), nth * 8, hipMemcpyHostToDevice));
-  const int KB = (p + 3) / 4; const size_t lds = sizeof(double) * (SHM_HDR + 3 * KB * 64);
+  const int KB = (p + 3) / 4; const size_t lds = sizeof(double) * (shm_hdr(3) + 3 * KB * 64);
   for (int mode = 0; mode < 9; mode++) {
 #ifndef EXP_W12
     if (mode >= 7) break;
