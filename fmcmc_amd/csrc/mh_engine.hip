@@ -480,10 +480,16 @@ struct AsyncScratch {
 };
 
 // kernel->fixed etc. are DEVICE pointers here; kf and bounds info come via `kf`/`ram_bounded`.
-static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const fmcmc_run* run,
+static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, const fmcmc_run* run,
                         fmcmc_state* st, fmcmc_out* out, int kf, int ram_bounded, hipStream_t stream) {
   SweepArgs A;
   memset(&A, 0, sizeof(A));
+  // iid Normal(mu, sigma) IS the Gaussian linear model with an intercept and no covariate -- the same canonical arithmetic in
+  // every kernel and in the oracle (fmcmc_oracle.c: pp = 0, icc = 1) -- so it takes that model's fast paths instead of the
+  // all-family kernel (tools/option_audit.py)
+  fmcmc_model m_norm = *m_in;
+  if (m_norm.family == FMCMC_FAM_IID_NORMAL) { m_norm.family = FMCMC_FAM_GAUSSIAN_LINREG; m_norm.p = 0; m_norm.intercept = 1; }
+  const fmcmc_model* m = &m_norm;
   AsyncScratch hist_guard, ws_guard, shw_guard, wc_guard;
   // the uniform kernels ARE the normal kernels with mu = min., scale = max. - min. and U(0,1) variates
   fmcmc_kernel ke = *kn_in;
@@ -678,7 +684,7 @@ static int launch_sweep(const fmcmc_model* m, const fmcmc_kernel* kn_in, const f
     // (k = 9 -- seven covariates, intercept and sigma -- as a compile-time row count: tools/dispatch_audit.py found these calls on
     //  the general kernel, 7x the time of the normal kernels at the same shape)
     // (mfma_ad == 2: the owners with their matrices in LDS -- 8 .. 15 covariates, or a fixed parameter; not the bounded kernel_ram)
-    if (K.mfma != 0 && !pipe_opt && kn->kind >= FMCMC_KERNEL_ADAPT && m->p >= 1 && m->p <= 15 && m->n < (1ll << 29)) {
+    if (K.mfma != 0 && !pipe_opt && kn->kind >= FMCMC_KERNEL_ADAPT && m->p >= 0 && m->p <= 15 && m->n < (1ll << 29)) {   // (p = 0: iid Normal)
       const bool reg_owner = m->p <= 7 && kf == kn->k && (kn->k <= SPEC_KA || kn->k == 9) && A.kz == kn->k;
       const int ng = (m->p <= 3) ? 1 : (m->p <= 7 ? 2 : (m->p <= 11 ? 3 : 4));
       const int nsr = (ng == 1) ? MfmaAdShape<1>::NSR : (ng == 2 ? MfmaAdShape<2>::NSR : MfmaAdShape<3>::NSR);

@@ -202,6 +202,26 @@ def test_iid_normal(E, O):
              guard=False, scale=0.1, lb=0.0, ub=10.0)
 
 
+def test_iid_normal_on_the_linear_model_kernels(E, O):
+    """FAM_IID_NORMAL is the Gaussian linear model with an intercept and no covariate, in the oracle and in every kernel: since
+    round 4 it takes that model's fast paths (normal / uniform kernels on the MFMA kernels, the adaptive ones on the streamed MFMA
+    evaluation beyond 6,144 observations) instead of the all-family kernel."""
+    from fmcmc_amd import _abi as abi
+    rng = np.random.default_rng(12)
+    for n, want_n, want_a in ((700, "mfma", "streamed"), (9000, "mfma", "mfma-adaptive"), (20001, "mfma-streamed", "mfma-adaptive")):
+        y = 1.5 + 2.0 * rng.standard_normal(n)
+        init = jitter_init([1.0, 2.0], 7, 5)
+        init[:, -1] = np.abs(init[:, -1]) + 0.1
+        run_both(E, O, O.FAM_IID_NORMAL, None, y, O.K_NORMAL, 2, init, nsteps=90, burnin=4, thin=3, calls=2, scale=0.03)
+        assert abi.last_kernel() == want_n
+        run_both(E, O, O.FAM_IID_NORMAL, None, y, O.K_UNIF_REFLECTIVE, 2, init, nsteps=60, min_=-0.04, max_=0.05, lb=[-40.0, 0.05], ub=40.0)
+        assert abi.last_kernel() == want_n
+        run_both(E, O, O.FAM_IID_NORMAL, None, y, O.K_ADAPT, 2, init, nsteps=80, calls=2, warmup=10)
+        assert abi.last_kernel() == want_a
+        run_both(E, O, O.FAM_IID_NORMAL, None, y, O.K_RAM, 2, init, nsteps=80, calls=2, lb=[-40.0, 0.05], ub=40.0)
+        assert abi.last_kernel() == want_a
+
+
 def test_nan_logpost_is_reported(E, O):
     """README.md:356-361 ll without the guard: sigma < 0 -> NaN -> 'fun(par) is undefined'."""
     X, y = synth_linreg(300, 1, 2)
