@@ -670,11 +670,11 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
       // beyond the operand registers: 16 (8) slots resident, the rest streamed from an operand-order copy every step (EXT)
       else if (m->p <= 3 && m->n < (1ll << 29)) { mfma_ng = 1; mfma_ext = 16; }
       else if (m->p <= 7 && m->n < (1ll << 29)) { mfma_ng = 2; mfma_ext = 8; }
-      // 8 .. 15 covariates (k <= 16): three / four operand groups per observation slot, four / three slots resident (one for short
+      // 8 .. 15 covariates (k <= 16): three / four operand groups per observation slot, four / two slots resident (one for short
       // data), the rest streamed -- tools/dispatch_audit.py found these models on the general kernel at 0.10 of the fp64 peak where
       // p = 7 runs at 0.44
       else if (m->p <= 11 && m->n > NT && m->n < (1ll << 29)) { mfma_ng = 3; mfma_ext = (m->n > (long long)NT * 4) ? 4 : 1; }
-      else if (m->p <= 15 && m->n > NT && m->n < (1ll << 29)) { mfma_ng = 4; mfma_ext = (m->n > (long long)NT * 3) ? 3 : 1; }
+      else if (m->p <= 15 && m->n > NT && m->n < (1ll << 29)) { mfma_ng = 4; mfma_ext = (m->n > (long long)NT * 2) ? 2 : 1; }
       // (the wave-specialised VALU kernel, which overlaps owners and evaluation, used to win at its small shape
       //  (p = 1, n ~ 1000); since the instruction diet of the owner phase the MFMA kernel is 1.2-1.35x ahead there too:
       //  tools/bench_small.py.  Knob mfma=0 still selects it.)
@@ -817,7 +817,7 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
         else if (mfma_ng == 2) { if (kv == 1) MF_EXT(1, 2, 8); else MF_EXT(2, 2, 8); }
         else if (mfma_ng == 3 && mfma_ext == 4) { if (kv == 1) MF_EXT(1, 3, 4); else MF_EXT(2, 3, 4); }
         else if (mfma_ng == 3) { if (kv == 1) MF_EXT(1, 3, 1); else MF_EXT(2, 3, 1); }
-        else if (mfma_ext == 3) { if (kv == 1) MF_EXT(1, 4, 3); else MF_EXT(2, 4, 3); }
+        else if (mfma_ext == 2) { if (kv == 1) MF_EXT(1, 4, 2); else MF_EXT(2, 4, 2); }
         else { if (kv == 1) MF_EXT(1, 4, 1); else MF_EXT(2, 4, 1); }
 #undef MF_EXT
       } else if (false) {

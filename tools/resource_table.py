@@ -27,7 +27,10 @@ PRODUCT = [("C2 headline", r"mh_sweep_mfma<1, 1, 20, false, false, false>"), ("C
            ("C3' kernel_ram k=5", r"mh_sweep_spec<3, 20, 4>"), ("C4", r"mh_sweep_wide2<4, 3>"),
            
            ("C5 (observation-sharded)", r"mh_sweep_kernel<4, -1, 2, 2, 2, 1>"), ("C5 shape, chain-sharded form", r"mh_sweep_kernel<4, -1, 0, 2, 2, 1>"),
-           ("n > 10240, normal kernels", r"mh_sweep_mfma<1, 1, 16, false, false, true>"), ("n > 10240, kernel_adapt k = 5", r"mh_sweep_mfma_ad<3, 1, 5>"),
+           ("n > 10240, normal kernels", r"mh_sweep_mfma<1, 1, 16, false, false, true>"), ("8 <= p <= 11, normal kernels", r"mh_sweep_mfma<1, 3, 4, false, false, true>"),
+           ("12 <= p <= 15, normal kernels", r"mh_sweep_mfma<1, 4, 3, false, false, true>"),
+           ("n > 10240, kernel_adapt k = 5", r"mh_sweep_mfma_ad<3, 1, 5, false>"), ("bounded kernel_ram k = 5", r"mh_sweep_mfma_ad<4, 1, 5, true>"),
+           ("kernel_adapt, 8 <= p <= 11 (owners' matrices in LDS)", r"mh_sweep_mfma_ad<3, 3, -1, false>"),
            ("64 < k <= 128", r"mh_sweep_bigk"), ("rng stream", r"rng_fill_kernel"),
            ("Gelman window covariance", r"gelman_chain_mfma"), ("Gelman chain sum", r"gelman_sum_kernel")]
 
@@ -62,7 +65,7 @@ def collect(extra_flags=()):
 # real (noinline) device functions that carry the hot loops of a product kernel: the remark pass reports kernels only, so
 # their registers and spill code are read off the ISA (-S): highest VGPR named, scratch instructions, and v_readlane /
 # v_writelane (SGPR spill traffic) inside their innermost hot loop (the largest backward-branch body below 400 instructions)
-DEVICE_FUNCS = [("C5 observation loop (observation-sharded)", "logit_shard<5, 2>"), ("C5 shape, chain-sharded observation loop", "logit_partials<4, 5>"),
+DEVICE_FUNCS = [("C5 observation loop (observation-sharded)", "logit_shard<5, 2, 2>"), ("logistic p = 12 (one observation per pass)", "logit_shard<12, 2, 1>"), ("C5 shape, chain-sharded observation loop", "logit_partials<4, 5>"),
                 ("C4 slice product (form T10)", "shard_columns_mfma<2, 3, 12, true>"),
                 ("C4 factor update + proposal", "w2_ram_update_propose")]
 
