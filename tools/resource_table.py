@@ -28,7 +28,7 @@ PRODUCT = [("C2 headline", r"mh_sweep_mfma<1, 1, 20, false, false, false>"), ("C
            
            ("C5 (observation-sharded)", r"mh_sweep_kernel<4, -1, 2, 2, 2, 1>"), ("C5 shape, chain-sharded form", r"mh_sweep_kernel<4, -1, 0, 2, 2, 1>"),
            ("n > 10240, normal kernels", r"mh_sweep_mfma<1, 1, 16, false, false, true>"), ("8 <= p <= 11, normal kernels", r"mh_sweep_mfma<1, 3, 4, false, false, true>"),
-           ("12 <= p <= 15, normal kernels", r"mh_sweep_mfma<1, 4, 3, false, false, true>"),
+           ("12 <= p <= 15, normal kernels", r"mh_sweep_mfma<1, 4, 2, false, false, true>"),
            ("n > 10240, kernel_adapt k = 5", r"mh_sweep_mfma_ad<3, 1, 5, false>"), ("bounded kernel_ram k = 5", r"mh_sweep_mfma_ad<4, 1, 5, true>"),
            ("kernel_adapt, 8 <= p <= 11 (owners' matrices in LDS)", r"mh_sweep_mfma_ad<3, 3, -1, false>"),
            ("64 < k <= 128", r"mh_sweep_bigk"), ("rng stream", r"rng_fill_kernel"),
