@@ -1495,7 +1495,7 @@ def test_randomised_option_cases(E, O, case):
              seed=int(rng.integers(1, 10**6)), chain_base=int(rng.choice([0, 3, 4096])), calls=calls, **kw, **opts)
 
 
-@pytest.mark.parametrize("case", range(int(os.environ.get("FMCMC_TEST_RANDOM_CASES3", "64"))))   # soak: 2000 passed
+@pytest.mark.parametrize("case", range(int(os.environ.get("FMCMC_TEST_RANDOM_CASES3", "64"))))   # soak: 4000 passed (final code of round 4)
 def test_randomised_round4_regions(E, O, monkeypatch, case):
     """Third randomised sweep, over the regions round 4 opened and the first two never draw: (A) linreg beyond the operand
     registers of the MFMA kernel (10,240 < n <= 45,000 at p <= 3, 5,120 < n at p <= 7: mfma-streamed / mfma-adaptive), (B) 64 < k
