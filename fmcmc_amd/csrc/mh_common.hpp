@@ -95,6 +95,8 @@ struct SweepArgs {
   const double* sh_mfma;     // [G][sh_mblk] the slices once more, in fp64-MFMA operand layout (shard_columns_mfma), or NULL
   int sh_mblk, sh_nmt;       // doubles per workgroup block; M-tiles of 16 observations per slice (1..3)
   int sh_t10;                // 1: the third M-tile holds 8 rows only and is laid out for two 4x4x4 MFMAs (shard_columns_mfma, T10)
+  int sh_long;               // 1: the LONG-DATA form (shard_long): few chains, slices of thousands of observations; sh_xs = [G][p + 1][2 nslots]
+  int sh_lcg;                //    chains whose residuals fit the workgroup's LDS block (sh_mblk doubles) at a time
   // out
   double* samples;
   double* logpost;
@@ -781,6 +783,85 @@ __device__ __attribute__((noinline)) void shard_columns_mfma(ShardMfma c) {
 #undef SHM_LOAD_B
 #undef SHM_PIN
 
+// ---- LONG-DATA form of the sharded evaluation (round 4; tools/dispatch_audit.py: four chains are ONE workgroup on the chain-sharded
+// kernels -- n = 1e5 observations took 34 us per step on one CU, 255 CUs idle).  Workgroup b owns the canonical lanes 2b, 2b + 1 as
+// in the other sharded forms, but its slice is long (n / 256 observations) and the chains are few: (a) all 512 threads compute the
+// residuals r = y - (b0 + x b) of the slice for a group of chains -- the fma chain over the columns in the canonical order -- into
+// LDS; (b) ONE thread per (chain, canonical lane) walks its residuals in slot order, acc = fma(r, r, acc): the canonical lane sum is
+// a sequential chain, ~8 cycles per slot whatever is done, and that walk IS the evaluation time (n = 1e6: 1953 slots, ~7 us).
+struct ShardLong {
+  const double* xs;      // this workgroup's slice [p + 1][nobs]: columns, then y; observation o = 2 slot + q (0 beyond n)
+  const double* th;      // [k][ncp] proposals of all chains
+  double* part;          // [NC][NT + SH_PAD] lane partials
+  long long n;
+  unsigned lds;          // LDS address of the residual block [lcg][2][shard_long_row(nslots)] + [lcg][16] coefficients
+  int NC, ncp, p, ic, nslots, lane0, lcg;
+};
+static_assert(sizeof(ShardLong) <= 64, "ShardLong must travel in registers (16 dwords)");
+// slots of a (chain, canonical lane) row of the residual block: nslots rounded up to the walk's block of 16, plus one block the
+// walk's prefetch may touch
+__host__ __device__ constexpr int shard_long_row(int nslots) { return ((nslots + 15) & ~15) + 16; }
+__device__ __attribute__((noinline)) void shard_long(ShardLong c) {
+  typedef __attribute__((address_space(3))) double* ldsd_t;
+  typedef double d2_t __attribute__((ext_vector_type(2)));
+  const int tid = threadIdx.x;
+  const int NC = rfl_i(c.NC), NCP = rfl_i(c.ncp), p = rfl_i(c.p), ic = rfl_i(c.ic), nslots = rfl_i(c.nslots), lane0 = rfl_i(c.lane0), lcg = rfl_i(c.lcg);
+  const long long n = (long long)rfl_u64((unsigned long long)c.n);
+  const double* xs = (const double*)rfl_u64((unsigned long long)c.xs);
+  const double* thg = (const double*)rfl_u64((unsigned long long)c.th);
+  double* part = (double*)rfl_u64((unsigned long long)c.part);
+  const int nobs = 2 * nslots, nb = ic + p, NSP = shard_long_row(nslots), nwalk = NSP - 16;
+  double* s_r = (double*)(ldsd_t)(unsigned long long)(unsigned)rfl_i((int)c.lds);   // [lcg][2][NSP] residuals, a row per (chain, lane)
+  double* s_b = s_r + (long long)lcg * 2 * NSP;                                       // [lcg][16] coefficients of the group's chains
+  for (int c0 = 0; c0 < NC; c0 += lcg) {
+    const int ncg = (NC - c0 < lcg) ? NC - c0 : lcg;
+    for (int idx = tid; idx < ncg * nb; idx += NT) {
+      const int cc = idx / nb, j = idx - cc * nb;
+      s_b[cc * 16 + j] = sh_load(thg + ((unsigned int)(j * NCP) + (unsigned int)(c0 + cc)));
+    }
+    lds_barrier();
+    // (a) residuals of the slice, every thread a stride of its observations; slots beyond the data (and the padding of a row up to
+    //     the walk's block) hold 0: fma(0, 0, acc) == acc exactly, so the walk below needs no tail
+    for (int o = tid; o < 2 * nwalk; o += NT) {
+      const long long i = (long long)NT * (o >> 1) + lane0 + (o & 1);
+      const bool valid = o < nobs && i < n;
+      const int oc = o < nobs ? o : nobs - 1;
+      double x[15];
+#pragma unroll
+      for (int j = 0; j < 15; j++) x[j] = (j < p) ? xs[(long long)j * nobs + oc] : 0.0;
+      const double yv = xs[(long long)p * nobs + oc];
+      double* dst = s_r + (long long)(o & 1) * NSP + (o >> 1);
+      for (int cc = 0; cc < ncg; cc++) {
+        const double* bj = s_b + cc * 16;
+        double m = ic ? bj[0] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 15; j++) if (j < p) m = fmh_fma(x[j], bj[ic + j], m);
+        dst[(long long)cc * 2 * NSP] = valid ? yv - m : 0.0;
+      }
+    }
+    lds_barrier();
+    // (b) the canonical lane sum: ONE thread per (chain, lane) walks its row in slot order -- blocks of 16 slots, the next block's
+    //     eight ds_read_b128 in flight under this block's sixteen dependent FMAs
+    if (tid < 2 * ncg) {
+      const d2_t* rp = reinterpret_cast<const d2_t*>(s_r + (long long)tid * NSP);   // (row cc * 2 + q == tid)
+      d2_t cur[8], nxt[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) cur[u] = rp[u];
+      double acc = 0.0;
+      for (int sl = 0; sl < nwalk; sl += 16) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) nxt[u] = rp[(sl >> 1) + 8 + u];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { acc = fmh_fma(cur[u].x, cur[u].x, acc); acc = fmh_fma(cur[u].y, cur[u].y, acc); }
+#pragma unroll
+        for (int u = 0; u < 8; u++) cur[u] = nxt[u];
+      }
+      sh_store(&part[(long long)(c0 + (tid >> 1)) * (NT + SH_PAD) + lane0 + (tid & 1)], acc);
+    }
+    lds_barrier();
+  }
+}
+
 // lane partials acc[c] of canonical lane `tid` for the CW chains of this workgroup, via the sharded evaluation
 // (the logistic family's step 2, logit_shard below, is reached through this forward-declared hook)
 template <int LPW>
@@ -807,6 +888,13 @@ __device__ __forceinline__ bool eval_sharded(const SweepArgs& A, double* const* 
   // 2. thread = chain: the slice's observations for that chain
   if constexpr (FAM == FMCMC_FAM_LOGISTIC) {
     eval_sharded_logit_step<LPW>(A, s_mblk);
+  } else if (A.sh_long) {
+    typedef __attribute__((address_space(3))) const double* ldsc_t;
+    ShardLong sl;
+    sl.xs = A.sh_xs + (long long)blockIdx.x * (p + 1) * 2 * A.sh_nslots;
+    sl.th = A.sh_th; sl.part = A.sh_part; sl.n = A.n; sl.lds = (unsigned)(unsigned long long)(ldsc_t)s_mblk;
+    sl.NC = NC; sl.ncp = NCP; sl.p = p; sl.ic = ic; sl.nslots = A.sh_nslots; sl.lane0 = (int)blockIdx.x * LPW; sl.lcg = A.sh_lcg;
+    shard_long(sl);
   } else {
   ShardCols sc;
   sc.xs = A.sh_xs + (long long)blockIdx.x * p * SH_MAXO;

@@ -141,6 +141,17 @@ __global__ void logit_build_slices(const double* X, long long n, int p, int nslo
   }
 }
 
+// the slices of the long-data form (mh_common.hpp, shard_long): per workgroup [p + 1][2 nslots], columns then y, observation
+// o = 2 slot + q <-> i = 512 slot + 2 b + q (0 beyond n): thread t of the workgroup reads element o = t, t + 512, .. of every column
+__global__ void long_build_slices(const double* X, const double* y, long long n, int p, int nslots, double* xs) {
+  const int b = blockIdx.x, nobs = 2 * nslots;
+  for (long long idx = threadIdx.x; idx < (long long)(p + 1) * nobs; idx += blockDim.x) {
+    const int j = (int)(idx / nobs), o = (int)(idx - (long long)j * nobs);
+    const long long i = (long long)NT * (o >> 1) + 2 * b + (o & 1);
+    xs[(long long)b * (p + 1) * nobs + idx] = (i < n) ? (j < p ? X[(long long)j * n + i] : y[i]) : 0.0;
+  }
+}
+
 // compact per-workgroup slices of X and y for the observation-sharded evaluation (mh_common.hpp, eval_sharded):
 // xs[(b p + j) SH_MAXO + o], ys[b SH_MAXO + o] with o = slot * LPW + q <-> observation b LPW + q + 512 slot (0 beyond n)
 __global__ void shard_build_slices(const double* X, const double* y, long long n, int p, int lpw, int nslots,
@@ -697,6 +708,61 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
     if (kn->kind == FMCMC_KERNEL_RAM && ram_bounded && !mfma_ad) pipe_opt = 0, mfma_ng = 0;   // (general kernel)
   }
   A.spec_opt = pipe_opt;
+  // ---- the LONG-DATA form (mh_common.hpp, shard_long): few chains on long data.  Up to four chains are one workgroup of the
+  // chain-sharded kernels, i.e. ONE compute unit walks the whole data set per step (n = 1e5, p = 3: 34 us per step, 255 CUs idle);
+  // here all 256 workgroups evaluate their 1/256 of the observations for every chain and the canonical lane sums cross the chip as
+  // in the other observation-sharded forms.
+  bool launched_long = false;
+  if (!force && K.shard != 0 && m->family == FMCMC_FAM_GAUSSIAN_LINREG && m->p <= 15 && cw == 1 && ncu == 256 && run->nchains <= 64 &&
+      (kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE || (kn->kind == FMCMC_KERNEL_RAM && !ram_bounded)) &&
+      m->n >= 8 * NT && m->n < (1ll << 31) && run->nsteps < 30000000) {
+    const int nslots = (int)((m->n + NT - 1) / NT), nobs = 2 * nslots;
+    const long long room = ((long long)150 * 1024 - (long long)lds) / 8 - 2;
+    const long long lrow = 2ll * shard_long_row(nslots) + 16;     // LDS doubles per chain of a group
+    long long lcg = room / lrow;
+    if (lcg > run->nchains) lcg = run->nchains;
+    // us per step, fitted on `tools/dispatch_audit.py --only=long` (profiles/r04_dispatch_audit.md): the chain-sharded kernels walk
+    // the data set in one workgroup whatever the chain count (up to 1024); the long form pays ~8 us of hand-overs, the walk of a
+    // lane's slots once per group of chains whose residuals fit the LDS, and per chain its residuals and its share of the exchange
+    const double pn = (double)m->n;
+    const double now_rate = (m->p <= 3) ? (pn <= 2e5 ? 3.3e-4 : 5.1e-4) : (m->p <= 7 ? 5.4e-4 : (m->p <= 11 ? 8.5e-4 : 1.17e-3));
+    const double est_now = (m->n <= (long long)NT * (m->p <= 3 ? 20 : (m->p <= 7 ? 10 : 0)) ? 2.2 : now_rate * pn) + (kn->kind == FMCMC_KERNEL_RAM ? 2.0 : 0.0);
+    const double groups = lcg >= 1 ? (double)((run->nchains + lcg - 1) / lcg) : 1e9;
+    const double est_long = 8.3 + groups * 1.6e-5 * pn + 0.5e-6 * pn * (double)(m->p + 1) +
+                            (double)run->nchains * (0.17 + 0.028 * (double)m->p + 1.2e-6 * pn) + (kn->kind == FMCMC_KERNEL_RAM ? 3.5 : 0.0);
+    const int kvl = kn->kind;
+    const void* kfn = (kvl == 1) ? (const void*)mh_sweep_kernel<1, -1, 2, 1, FMCMC_FAM_GAUSSIAN_LINREG>
+                    : (kvl == 2) ? (const void*)mh_sweep_kernel<1, -1, 2, 2, FMCMC_FAM_GAUSSIAN_LINREG>
+                                 : (const void*)mh_sweep_kernel<1, -1, 2, 4, FMCMC_FAM_GAUSSIAN_LINREG>;
+    bool go = lcg >= 1 && (K.shard == 1 || est_long < 0.9 * est_now);
+    const size_t llds = lds + sizeof(double) * (size_t)(lcg * lrow + 2);
+    if (go) {
+      int coop = 0, perCU = 0;
+      (void)hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev);
+      hipError_t el = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)llds);
+      if (el != hipSuccess || !coop || hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kfn, NT, llds) != hipSuccess || perCU < 1) go = false;
+    }
+    if (go) {
+      double* shw = nullptr;
+      const size_t nxs = (size_t)256 * (m->p + 1) * nobs, nth = ((size_t)kn->k * (run->nchains + SH_PAD) + 7) & ~(size_t)7,
+                   npt = (size_t)(NT + SH_PAD) * run->nchains, nbar = 32 * 20 / 2;
+      e = hipMallocAsync((void**)&shw, sizeof(double) * (nxs + nth + npt + nbar), stream);
+      if (e != hipSuccess) { set_err("hipMallocAsync(sharded evaluation) failed: %s", hipGetErrorString(e)); return FMCMC_ERR_DEVICE; }
+      shw_guard.p = shw; shw_guard.s = stream;
+      double* thw = shw; double* ptw = thw + nth; unsigned* bar = (unsigned*)(ptw + npt); double* xs = ptw + npt + nbar;
+      hipLaunchKernelGGL(long_build_slices, dim3(256), dim3(256), 0, stream, m->X, m->y, (long long)m->n, m->p, nslots, xs);
+      (void)hipMemsetAsync(bar, 0, sizeof(double) * nbar, stream);
+      SweepArgs W = A;
+      W.shard = 2; W.sh_nslots = nslots; W.sh_xs = xs; W.sh_ys = nullptr; W.sh_th = thw; W.sh_part = ptw; W.sh_bar = bar;
+      W.sh_long = 1; W.sh_lcg = (int)lcg; W.sh_mblk = (int)(lcg * lrow); W.tb = A.tb;
+      void* kargs[] = {(void*)&W};
+      e = hipLaunchCooperativeKernel(kfn, dim3(256), dim3(NT), kargs, (unsigned int)llds, stream);
+      if (e == hipSuccess) { launched_long = true; g_kernel = "long-sharded"; }
+      else { (void)hipGetLastError(); e = hipSuccess; }     // the runtime refused the cooperative launch: nothing ran, take the usual kernels
+    }
+  }
+  if (launched_long) {
+  } else
   if (pipe_opt || mfma_ng) {
     const size_t plds = pipe_opt ? pipe_lds_bytes(pipe_opt) : 0;
     const long long pblk = (run->nchains + 3) / 4;

@@ -185,6 +185,8 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
       const double* src = A.sh_mfma + (long long)blockIdx.x * A.sh_mblk;
       for (int i = tid; i < A.sh_mblk; i += NT) blk[i] = src[i];
       s_sptab = blk;
+    } else if (A.sh_long) {   // long-data form: the block holds the residuals of a group of chains (shard_long), nothing to stage
+      s_sptab = s_chains + CW * CHS + ((CW * CHS) & 1);
     }
   }
   const long long cg0 = (long long)blockIdx.x * CW;  // first local chain of this workgroup

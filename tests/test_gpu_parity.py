@@ -638,10 +638,11 @@ def test_wave_specialised_kernel_at_any_shape(E, O, n, p):
 
 
 @pytest.mark.parametrize("n,p", [(10241, 3), (12000, 3), (20000, 3), (20481, 2), (50001, 3), (5121, 5), (9000, 7), (12345, 4)])
-def test_mfma_kernel_beyond_its_operand_registers(E, O, n, p):
+def test_mfma_kernel_beyond_its_operand_registers(E, O, monkeypatch, n, p):
     """mh_sweep_mfma<.., EXT> (round 4): 16 (p <= 3) or 8 (p <= 7) observation slots resident, the rest streamed every step
     from the operand-order copy -- the shapes that fell to the general kernel at observation 10,241 / 5,121.  Ragged last
     slot, one and many streamed slots, normal and reflective kernels, two consecutive calls."""
+    set_knob(monkeypatch, "shard", "0")     # (few chains on long data would take the long-data form: test_few_chains_on_long_data)
     from fmcmc_amd import _abi as abi
     X, y = synth_linreg(n, p, 5200 + n + p)
     k = p + 2
@@ -656,10 +657,11 @@ def test_mfma_kernel_beyond_its_operand_registers(E, O, n, p):
 
 @pytest.mark.parametrize("n,p,intercept", [(513, 8, True), (2048, 9, True), (2049, 11, False), (3000, 10, True), (10000, 11, True), (700, 12, True),
                                            (1536, 13, True), (1537, 14, True), (6000, 14, False), (10001, 15, False), (12345, 12, True), (4097, 8, False)])
-def test_mfma_kernel_with_eight_to_fifteen_covariates(E, O, n, p, intercept):
+def test_mfma_kernel_with_eight_to_fifteen_covariates(E, O, monkeypatch, n, p, intercept):
     """8 <= p <= 15 (k <= 16) on mh_sweep_mfma<.., EXT> with three / four operand groups per slot (round 4: these models ran on the
     general kernel, 4x the time per flop of p = 7): four / three slots resident, or one for short data, the rest streamed; ragged
     last slots, the slot-count edges, with and without intercept, normal / reflective / uniform kernels, a fixed parameter."""
+    set_knob(monkeypatch, "shard", "0")     # (few chains on long data would take the long-data form: test_few_chains_on_long_data)
     from fmcmc_amd import _abi as abi
     X, y = synth_linreg(n, p, 5300 + n + p, beta=np.linspace(0.8, -0.8, p + 1))
     k = p + 1 + (1 if intercept else 0)
@@ -676,10 +678,11 @@ def test_mfma_kernel_with_eight_to_fifteen_covariates(E, O, n, p, intercept):
 
 
 @pytest.mark.parametrize("n,p,intercept", [(10241, 3, True), (20000, 3, True), (12001, 3, False), (30000, 2, True), (5121, 5, True), (6500, 6, True), (9000, 4, False), (6000, 7, True), (8200, 7, False), (7000, 3, True), (10000, 3, True), (3100, 5, True)])
-def test_adaptive_kernels_on_the_streamed_mfma_evaluation(E, O, n, p, intercept):
+def test_adaptive_kernels_on_the_streamed_mfma_evaluation(E, O, monkeypatch, n, p, intercept):
     """mh_sweep_mfma_ad (round 4): kernel_adapt / kernel_ram beyond mh_sweep_spec's registers -- the streamed MFMA evaluation of
     all four chains of a workgroup, then one step of the register-row adaptive owners between barriers.  k = 5 (the
     compile-time owner) and the generic k <= 8 owner, with and without intercept, ragged last slot, continuation calls."""
+    set_knob(monkeypatch, "shard", "0")     # (few chains on long data would take the long-data form: test_few_chains_on_long_data)
     from fmcmc_amd import _abi as abi
     X, y = synth_linreg(n, p, 6100 + n + p)
     k = p + 1 + (1 if intercept else 0)
@@ -701,11 +704,12 @@ def test_adaptive_kernels_on_the_streamed_mfma_evaluation(E, O, n, p, intercept)
 
 @pytest.mark.parametrize("n,p,intercept,fix", [(3000, 9, True, False), (10000, 11, True, False), (2049, 12, False, False), (1537, 13, True, True),
                                                (6000, 14, True, False), (12000, 3, True, True), (6000, 6, True, True), (20000, 8, False, True)])
-def test_adaptive_kernels_with_their_matrices_in_lds_on_the_streamed_mfma_evaluation(E, O, n, p, intercept, fix):
+def test_adaptive_kernels_with_their_matrices_in_lds_on_the_streamed_mfma_evaluation(E, O, monkeypatch, n, p, intercept, fix):
     """mh_sweep_mfma_ad<KIND, NG, -1> (round 4): kernel_adapt / kernel_ram with 8 .. 15 covariates (k <= 16), or with a fixed
     parameter beyond the wave-specialised kernel's range -- the owners that keep their matrices in LDS (spec_owner_adaptive, any
     k <= 16) between the barriers of the streamed MFMA evaluation, three / four operand groups per slot.  These calls ran on the
     general kernel (tools/dispatch_audit.py: 22 .. 55 us per step at n = 1e4)."""
+    set_knob(monkeypatch, "shard", "0")     # (few chains on long data would take the long-data form: test_few_chains_on_long_data)
     from fmcmc_amd import _abi as abi
     X, y = synth_linreg(n, p, 6400 + n + p, beta=np.linspace(0.7, -0.7, p + 1))
     k = p + 1 + (1 if intercept else 0)
@@ -905,6 +909,37 @@ def test_observation_sharded_slices_beyond_forty_observations(E, O, monkeypatch,
     run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, k, init, nsteps=steps, calls=2, intercept=intercept)
     if full:
         assert abi.last_kernel() == "streamed-wide-sharded-mfma"
+
+
+@pytest.mark.parametrize("n,p,chains,intercept", [(4096, 3, 1, True), (5001, 1, 3, True), (30000, 3, 4, True), (65537, 2, 2, False), (100000, 3, 4, True),
+                                                  (200001, 5, 1, True), (50000, 8, 5, True), (40000, 14, 2, True), (300000, 0, 3, True), (20000, 3, 40, True)])
+def test_few_chains_on_long_data(E, O, monkeypatch, n, p, chains, intercept):
+    """The long-data form of the observation-sharded evaluation (shard_long, round 4): up to 64 chains, every one of the 256
+    workgroups evaluates its 1/256 of the observations for all of them -- residuals into LDS by all threads, then one thread per
+    (chain, canonical lane) walks its slots in order -- instead of one workgroup walking the whole data set.  Forced by knob
+    shard=1 at the small sizes; ragged n, no intercept, p = 0 (iid Normal) .. 14, chain groups (40 chains at n = 20,000 need two LDS
+    passes... or one), kernel_normal, kernel_normal_reflective with an ordered scheme, kernel_ram, two calls: the oracle's bits."""
+    import torch
+    from fmcmc_amd import _abi as abi
+    if torch.cuda.get_device_properties(0).multi_processor_count < 256:
+        pytest.skip("the sharded forms need all 256 CUs")
+    set_knob(monkeypatch, "shard", "1")
+    rng = np.random.default_rng(n + 7 * p)
+    beta = rng.uniform(-1.0, 1.0, p + 1)
+    X = rng.standard_normal((n, p)) if p else None
+    y = (beta[0] if intercept else 0.0) + (X @ beta[1:] if p else 0.0) + 2.0 * rng.standard_normal(n)
+    k = p + 1 + (1 if intercept else 0)
+    init = jitter_init(list(beta[(0 if intercept else 1):]) + [2.0], chains, 9 + p)
+    init[:, -1] = np.abs(init[:, -1]) + 0.1
+    steps = int(max(8, min(40, 1.0e8 / (chains * n * max(p, 1) * 2))))
+    fam = O.FAM_LINREG if p else O.FAM_IID_NORMAL
+    kw = dict(intercept=intercept) if p else {}
+    run_both(E, O, fam, X, y, O.K_NORMAL, k, init, nsteps=steps, calls=2, scale=0.004, burnin=2, thin=2, **kw)
+    assert abi.last_kernel() == "long-sharded"
+    run_both(E, O, fam, X, y, O.K_NORMAL_REFLECTIVE, k, init, nsteps=steps, scale=0.05, lb=-1.2, ub=2.6, scheme="ordered", **kw)
+    assert abi.last_kernel() == "long-sharded"
+    run_both(E, O, fam, X, y, O.K_RAM, k, init, nsteps=steps, calls=2, **kw)
+    assert abi.last_kernel() == "long-sharded"
 
 
 @pytest.mark.parametrize("form", ["logistic-sharded", "wide-sequential", "wide-dataflow"])

@@ -2,7 +2,7 @@
 (Gaussian linreg p = 1 .. 14 and wide, logistic) x chain counts x kernel_* every sweep is timed on the dispatcher's own choice and
 on the alternatives the diagnosis knobs can force (FMCMC_AMD_DEBUG, read once per call: mfma=0, spec=0, streamed=1, shard=0|1,
 wide2=0, shard_mfma=0); a row is flagged when an alternative beats the default by more than 5 %.
-  python tools/dispatch_audit.py [out.md] [--quick] [--only=narrow,wide,logistic]      (on the GPU box; HIP events around the sweep, best of 3)"""
+  python tools/dispatch_audit.py [out.md] [--quick] [--only=narrow,wide,logistic,long]      (on the GPU box; HIP events around the sweep, best of 3)"""
 import os
 import sys
 import time
@@ -13,7 +13,7 @@ from fmcmc_amd import engine as E, _abi as abi  # noqa: E402
 
 QUICK = "--quick" in sys.argv
 ONLY = [a.split("=", 1)[1].split(",") for a in sys.argv if a.startswith("--only=")]
-ONLY = ONLY[0] if ONLY else ["narrow", "wide", "logistic"]      # --only=wide,logistic
+ONLY = ONLY[0] if ONLY else ["narrow", "wide", "logistic", "long"]      # --only=wide,logistic
 rows = []
 t_begin = time.time()
 
@@ -104,6 +104,12 @@ for n, p, c in (grid_wide if "wide" in ONLY else []):
     for kind, name in (KINDS[0], KINDS[2]):
         linreg(n, p, c, kind, name, WIDE_ALTS)
     print("wide", n, p, c, "%.0f s" % (time.time() - t_begin), flush=True)
+# few chains on long data (the long-data form, shard_long): default against shard=0 (the chain-sharded kernels) and shard=1 (forced)
+grid_long = [] if QUICK else [(n, p, c) for n in (20000, 50000, 100000, 300000, 1000000) for p in (3, 7, 12) for c in (1, 4, 16, 64)]
+for n, p, c in (grid_long if "long" in ONLY else []):
+    for kind, name in (KINDS[0], KINDS[2]):
+        linreg(n, p, c, kind, name, ["", "shard=0", "shard=1"])
+    print("long", n, p, c, "%.0f s" % (time.time() - t_begin), flush=True)
 for n, p, c in (grid_logit if "logistic" in ONLY else []):
     logistic(n, p, c, LOGIT_ALTS)
     print("logistic", n, p, c, "%.0f s" % (time.time() - t_begin), flush=True)
