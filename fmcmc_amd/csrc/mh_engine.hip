@@ -714,7 +714,8 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
   // in the other observation-sharded forms.
   bool launched_long = false;
   if (!force && K.shard != 0 && m->family == FMCMC_FAM_GAUSSIAN_LINREG && m->p <= 15 && cw == 1 && ncu == 256 && run->nchains <= 64 &&
-      (kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE || (kn->kind == FMCMC_KERNEL_RAM && !ram_bounded)) &&
+      (kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE || kn->kind == FMCMC_KERNEL_ADAPT ||
+       (kn->kind == FMCMC_KERNEL_RAM && !ram_bounded)) &&
       m->n >= 8 * NT && m->n < (1ll << 31) && run->nsteps < 30000000) {
     const int nslots = (int)((m->n + NT - 1) / NT), nobs = 2 * nslots;
     const long long room = ((long long)150 * 1024 - (long long)lds) / 8 - 2;
@@ -726,13 +727,14 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
     // lane's slots once per group of chains whose residuals fit the LDS, and per chain its residuals and its share of the exchange
     const double pn = (double)m->n;
     const double now_rate = (m->p <= 3) ? (pn <= 2e5 ? 3.3e-4 : 5.1e-4) : (m->p <= 7 ? 5.4e-4 : (m->p <= 11 ? 8.5e-4 : 1.17e-3));
-    const double est_now = (m->n <= (long long)NT * (m->p <= 3 ? 20 : (m->p <= 7 ? 10 : 0)) ? 2.2 : now_rate * pn) + (kn->kind == FMCMC_KERNEL_RAM ? 2.0 : 0.0);
+    const double est_now = (m->n <= (long long)NT * (m->p <= 3 ? 20 : (m->p <= 7 ? 10 : 0)) ? 2.2 : now_rate * pn) + (kn->kind >= FMCMC_KERNEL_ADAPT ? 2.0 : 0.0);
     const double groups = lcg >= 1 ? (double)((run->nchains + lcg - 1) / lcg) : 1e9;
     const double est_long = 8.3 + groups * 1.6e-5 * pn + 0.5e-6 * pn * (double)(m->p + 1) +
-                            (double)run->nchains * (0.17 + 0.028 * (double)m->p + 1.2e-6 * pn) + (kn->kind == FMCMC_KERNEL_RAM ? 3.5 : 0.0);
+                            (double)run->nchains * (0.17 + 0.028 * (double)m->p + 1.2e-6 * pn) + (kn->kind >= FMCMC_KERNEL_ADAPT ? 3.5 : 0.0);
     const int kvl = kn->kind;
     const void* kfn = (kvl == 1) ? (const void*)mh_sweep_kernel<1, -1, 2, 1, FMCMC_FAM_GAUSSIAN_LINREG>
                     : (kvl == 2) ? (const void*)mh_sweep_kernel<1, -1, 2, 2, FMCMC_FAM_GAUSSIAN_LINREG>
+                    : (kvl == 3) ? (const void*)mh_sweep_kernel<1, -1, 2, 3, FMCMC_FAM_GAUSSIAN_LINREG>
                                  : (const void*)mh_sweep_kernel<1, -1, 2, 4, FMCMC_FAM_GAUSSIAN_LINREG>;
     bool go = lcg >= 1 && (K.shard == 1 || est_long < 0.9 * est_now);
     const size_t llds = lds + sizeof(double) * (size_t)(lcg * lrow + 2);

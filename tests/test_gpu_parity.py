@@ -940,6 +940,8 @@ def test_few_chains_on_long_data(E, O, monkeypatch, n, p, chains, intercept):
     assert abi.last_kernel() == "long-sharded"
     run_both(E, O, fam, X, y, O.K_RAM, k, init, nsteps=steps, calls=2, **kw)
     assert abi.last_kernel() == "long-sharded"
+    run_both(E, O, fam, X, y, O.K_ADAPT, k, init, nsteps=steps, calls=2, warmup=3, lb=[-40.0] * (k - 1) + [0.05], ub=40.0, **kw)
+    assert abi.last_kernel() == "long-sharded"
 
 
 @pytest.mark.parametrize("form", ["logistic-sharded", "wide-sequential", "wide-dataflow"])

@@ -107,7 +107,7 @@ for n, p, c in (grid_wide if "wide" in ONLY else []):
 # few chains on long data (the long-data form, shard_long): default against shard=0 (the chain-sharded kernels) and shard=1 (forced)
 grid_long = [] if QUICK else [(n, p, c) for n in (20000, 50000, 100000, 300000, 1000000) for p in (3, 7, 12) for c in (1, 4, 16, 64)]
 for n, p, c in (grid_long if "long" in ONLY else []):
-    for kind, name in (KINDS[0], KINDS[2]):
+    for kind, name in KINDS:
         linreg(n, p, c, kind, name, ["", "shard=0", "shard=1"])
     print("long", n, p, c, "%.0f s" % (time.time() - t_begin), flush=True)
 for n, p, c in (grid_logit if "logistic" in ONLY else []):
