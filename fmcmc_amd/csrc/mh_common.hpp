@@ -793,31 +793,39 @@ struct ShardLong {
   const double* xs;      // this workgroup's slice [p + 1][nobs]: columns, then y; observation o = 2 slot + q (0 beyond n)
   const double* th;      // [k][ncp] proposals of all chains
   double* part;          // [NC][NT + SH_PAD] lane partials
-  long long n;
-  unsigned lds;          // LDS address of the residual block [lcg][2][shard_long_row(nslots)] + [lcg][16] coefficients
+  unsigned lds;          // LDS address of the term block [lcg][2][shard_long_row(nslots)] + [lcg][32] coefficients
+  unsigned tab;          // logistic: LDS address of the g table
+  int n;                 // observations (< 2^31: the host checks)
   int NC, ncp, p, ic, nslots, lane0, lcg;
 };
 static_assert(sizeof(ShardLong) <= 64, "ShardLong must travel in registers (16 dwords)");
 // slots of a (chain, canonical lane) row of the residual block: nslots rounded up to the walk's block of 16, plus one block the
 // walk's prefetch may touch
 __host__ __device__ constexpr int shard_long_row(int nslots) { return ((nslots + 15) & ~15) + 16; }
+// FAM: Gaussian linreg -- terms r = y - (b0 + x b), lane sum acc = fma(r, r, acc) -- or logistic -- terms g(|64 eta|) off the table
+// in LDS (the checked form of logit_shard's term: any |eta|), lane sum acc = acc + g; up to 16 covariates.
+template <int FAM>
 __device__ __attribute__((noinline)) void shard_long(ShardLong c) {
   typedef __attribute__((address_space(3))) double* ldsd_t;
   typedef double d2_t __attribute__((ext_vector_type(2)));
+  constexpr bool LG = FAM == FMCMC_FAM_LOGISTIC;
+  constexpr int PMAX = LG ? 16 : 15;
   const int tid = threadIdx.x;
   const int NC = rfl_i(c.NC), NCP = rfl_i(c.ncp), p = rfl_i(c.p), ic = rfl_i(c.ic), nslots = rfl_i(c.nslots), lane0 = rfl_i(c.lane0), lcg = rfl_i(c.lcg);
-  const long long n = (long long)rfl_u64((unsigned long long)c.n);
+  const long long n = (long long)rfl_i(c.n);
   const double* xs = (const double*)rfl_u64((unsigned long long)c.xs);
   const double* thg = (const double*)rfl_u64((unsigned long long)c.th);
   double* part = (double*)rfl_u64((unsigned long long)c.part);
+  const double* s_tab = (const double*)(ldsd_t)(unsigned long long)(unsigned)rfl_i((int)c.tab);
   const int nobs = 2 * nslots, nb = ic + p, NSP = shard_long_row(nslots), nwalk = NSP - 16;
   double* s_r = (double*)(ldsd_t)(unsigned long long)(unsigned)rfl_i((int)c.lds);   // [lcg][2][NSP] residuals, a row per (chain, lane)
-  double* s_b = s_r + (long long)lcg * 2 * NSP;                                       // [lcg][16] coefficients of the group's chains
+  double* s_b = s_r + (long long)lcg * 2 * NSP;                                       // [lcg][32] coefficients of the group's chains (logistic: times 64, exact)
   for (int c0 = 0; c0 < NC; c0 += lcg) {
     const int ncg = (NC - c0 < lcg) ? NC - c0 : lcg;
     for (int idx = tid; idx < ncg * nb; idx += NT) {
       const int cc = idx / nb, j = idx - cc * nb;
-      s_b[cc * 16 + j] = sh_load(thg + ((unsigned int)(j * NCP) + (unsigned int)(c0 + cc)));
+      const double bv = sh_load(thg + ((unsigned int)(j * NCP) + (unsigned int)(c0 + cc)));
+      s_b[cc * 32 + j] = LG ? bv * FMH_LG_SCALE : bv;
     }
     lds_barrier();
     // (a) residuals of the slice, every thread a stride of its observations; slots beyond the data (and the padding of a row up to
@@ -826,17 +834,26 @@ __device__ __attribute__((noinline)) void shard_long(ShardLong c) {
       const long long i = (long long)NT * (o >> 1) + lane0 + (o & 1);
       const bool valid = o < nobs && i < n;
       const int oc = o < nobs ? o : nobs - 1;
-      double x[15];
+      double x[PMAX];
 #pragma unroll
-      for (int j = 0; j < 15; j++) x[j] = (j < p) ? xs[(long long)j * nobs + oc] : 0.0;
-      const double yv = xs[(long long)p * nobs + oc];
+      for (int j = 0; j < PMAX; j++) x[j] = (j < p) ? xs[(long long)j * nobs + oc] : 0.0;
+      const double yv = LG ? 0.0 : xs[(long long)p * nobs + oc];
       double* dst = s_r + (long long)(o & 1) * NSP + (o >> 1);
       for (int cc = 0; cc < ncg; cc++) {
-        const double* bj = s_b + cc * 16;
+        const double* bj = s_b + cc * 32;
         double m = ic ? bj[0] : 0.0;
 #pragma unroll
-        for (int j = 0; j < 15; j++) if (j < p) m = fmh_fma(x[j], bj[ic + j], m);
-        dst[(long long)cc * 2 * NSP] = valid ? yv - m : 0.0;
+        for (int j = 0; j < PMAX; j++) if (j < p) m = fmh_fma(x[j], bj[ic + j], m);
+        double term;
+        if constexpr (LG) {
+          const double us1[1] = {__builtin_fabs(m)};
+          double g1[1];
+          logit_g_vec<1, true>(us1, g1, s_tab);
+          term = g1[0];
+        } else {
+          term = yv - m;
+        }
+        dst[(long long)cc * 2 * NSP] = valid ? term : 0.0;
       }
     }
     lds_barrier();
@@ -852,7 +869,10 @@ __device__ __attribute__((noinline)) void shard_long(ShardLong c) {
 #pragma unroll
         for (int u = 0; u < 8; u++) nxt[u] = rp[(sl >> 1) + 8 + u];
 #pragma unroll
-        for (int u = 0; u < 8; u++) { acc = fmh_fma(cur[u].x, cur[u].x, acc); acc = fmh_fma(cur[u].y, cur[u].y, acc); }
+        for (int u = 0; u < 8; u++) {
+          if constexpr (LG) { acc = acc + cur[u].x; acc = acc + cur[u].y; }      // (a slot without an observation adds +0: exact)
+          else { acc = fmh_fma(cur[u].x, cur[u].x, acc); acc = fmh_fma(cur[u].y, cur[u].y, acc); }
+        }
 #pragma unroll
         for (int u = 0; u < 8; u++) cur[u] = nxt[u];
       }
@@ -886,15 +906,19 @@ __device__ __forceinline__ bool eval_sharded(const SweepArgs& A, double* const* 
   if (!(A.debug & 32) && !(epoch & LOST)) { ok = shard_barrier(A.sh_bar, ++epoch, (A.debug & 512) != 0); if (!ok) epoch |= LOST; }
   FMH_STAMP(stp, 4);
   // 2. thread = chain: the slice's observations for that chain
-  if constexpr (FAM == FMCMC_FAM_LOGISTIC) {
-    eval_sharded_logit_step<LPW>(A, s_mblk);
-  } else if (A.sh_long) {
+  if (A.sh_long) {   // few chains on long data (both families)
     typedef __attribute__((address_space(3))) const double* ldsc_t;
+    constexpr bool LG = FAM == FMCMC_FAM_LOGISTIC;
     ShardLong sl;
     sl.xs = A.sh_xs + (long long)blockIdx.x * (p + 1) * 2 * A.sh_nslots;
-    sl.th = A.sh_th; sl.part = A.sh_part; sl.n = A.n; sl.lds = (unsigned)(unsigned long long)(ldsc_t)s_mblk;
+    sl.th = A.sh_th; sl.part = A.sh_part; sl.n = (int)A.n;
+    // (logistic: s_mblk is the g table; the term block sits behind it)
+    sl.tab = LG ? (unsigned)(unsigned long long)(ldsc_t)s_mblk : 0u;
+    sl.lds = (unsigned)(unsigned long long)(ldsc_t)(LG ? s_mblk + LG_LDS_DOUBLES + 2 : s_mblk);
     sl.NC = NC; sl.ncp = NCP; sl.p = p; sl.ic = ic; sl.nslots = A.sh_nslots; sl.lane0 = (int)blockIdx.x * LPW; sl.lcg = A.sh_lcg;
-    shard_long(sl);
+    shard_long<LG ? FMCMC_FAM_LOGISTIC : FMCMC_FAM_GAUSSIAN_LINREG>(sl);
+  } else if constexpr (FAM == FMCMC_FAM_LOGISTIC) {
+    eval_sharded_logit_step<LPW>(A, s_mblk);
   } else {
   ShardCols sc;
   sc.xs = A.sh_xs + (long long)blockIdx.x * p * SH_MAXO;

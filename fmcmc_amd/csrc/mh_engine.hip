@@ -711,57 +711,60 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
   // ---- the LONG-DATA form (mh_common.hpp, shard_long): few chains on long data.  Up to four chains are one workgroup of the
   // chain-sharded kernels, i.e. ONE compute unit walks the whole data set per step (n = 1e5, p = 3: 34 us per step, 255 CUs idle);
   // here all 256 workgroups evaluate their 1/256 of the observations for every chain and the canonical lane sums cross the chip as
-  // in the other observation-sharded forms.
+  // in the other observation-sharded forms.  try_long(kernel, its LDS bytes without the term block, what the call costs otherwise)
+  // launches it when the cost model -- or knob shard=1 -- says so; us per step, fitted on `tools/dispatch_audit.py --only=long`
+  // (profiles/r04_dispatch_audit.md): ~8 us of hand-overs, the walk of a lane's slots (1.6e-5 us per observation; sums of the
+  // logistic terms 1.0e-5) once per group of chains whose terms fit the LDS, and per chain its terms and its share of the exchange.
   bool launched_long = false;
-  if (!force && K.shard != 0 && m->family == FMCMC_FAM_GAUSSIAN_LINREG && m->p <= 15 && cw == 1 && ncu == 256 && run->nchains <= 64 &&
-      (kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE || kn->kind == FMCMC_KERNEL_ADAPT ||
-       (kn->kind == FMCMC_KERNEL_RAM && !ram_bounded)) &&
-      m->n >= 8 * NT && m->n < (1ll << 31) && run->nsteps < 30000000) {
+  auto try_long = [&](const void* kfn, size_t lds_base, double est_now, bool logistic) -> int {
+    if (force || K.shard == 0 || cw != 1 || ncu != 256 || run->nchains > 64 || m->n < 8 * NT || m->n >= (1ll << 31) || run->nsteps >= 30000000 ||
+        (kn->kind == FMCMC_KERNEL_RAM && ram_bounded) || kn->kind < FMCMC_KERNEL_NORMAL || kn->kind > FMCMC_KERNEL_RAM) return FMCMC_OK;
     const int nslots = (int)((m->n + NT - 1) / NT), nobs = 2 * nslots;
-    const long long room = ((long long)150 * 1024 - (long long)lds) / 8 - 2;
-    const long long lrow = 2ll * shard_long_row(nslots) + 16;     // LDS doubles per chain of a group
+    const long long room = ((long long)150 * 1024 - (long long)lds_base) / 8 - 2;
+    const long long lrow = 2ll * shard_long_row(nslots) + 32;     // LDS doubles per chain of a group
     long long lcg = room / lrow;
     if (lcg > run->nchains) lcg = run->nchains;
-    // us per step, fitted on `tools/dispatch_audit.py --only=long` (profiles/r04_dispatch_audit.md): the chain-sharded kernels walk
-    // the data set in one workgroup whatever the chain count (up to 1024); the long form pays ~8 us of hand-overs, the walk of a
-    // lane's slots once per group of chains whose residuals fit the LDS, and per chain its residuals and its share of the exchange
+    if (lcg < 1) return FMCMC_OK;
+    const double pn = (double)m->n;
+    const double groups = (double)((run->nchains + lcg - 1) / lcg);
+    const double est_long = 8.3 + groups * (logistic ? 1.0e-5 : 1.6e-5) * pn + (logistic ? 2.0e-6 : 0.5e-6) * pn * (double)(m->p + 1) +
+                            (double)run->nchains * (0.17 + 0.028 * (double)m->p + (logistic ? 3.0e-6 : 1.2e-6) * pn) +
+                            (kn->kind >= FMCMC_KERNEL_ADAPT ? 3.5 : 0.0);
+    if (!(K.shard == 1 || est_long < 0.9 * est_now)) return FMCMC_OK;
+    const size_t llds = lds_base + sizeof(double) * (size_t)(lcg * lrow + 2);
+    int coop = 0, perCU = 0;
+    (void)hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev);
+    hipError_t el = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)llds);
+    if (el != hipSuccess || !coop || hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kfn, NT, llds) != hipSuccess || perCU < 1) return FMCMC_OK;
+    double* shw = nullptr;
+    const size_t nxs = (size_t)256 * (m->p + 1) * nobs, nth = ((size_t)kn->k * (run->nchains + SH_PAD) + 7) & ~(size_t)7,
+                 npt = (size_t)(NT + SH_PAD) * run->nchains, nbar = 32 * 20 / 2;
+    hipError_t ea = hipMallocAsync((void**)&shw, sizeof(double) * (nxs + nth + npt + nbar), stream);
+    if (ea != hipSuccess) { set_err("hipMallocAsync(sharded evaluation) failed: %s", hipGetErrorString(ea)); return FMCMC_ERR_DEVICE; }
+    shw_guard.p = shw; shw_guard.s = stream;
+    double* thw = shw; double* ptw = thw + nth; unsigned* bar = (unsigned*)(ptw + npt); double* xs = ptw + npt + nbar;
+    hipLaunchKernelGGL(long_build_slices, dim3(256), dim3(256), 0, stream, m->X, m->y, (long long)m->n, m->p, nslots, xs);
+    (void)hipMemsetAsync(bar, 0, sizeof(double) * nbar, stream);
+    SweepArgs W = A;
+    W.shard = 2; W.sh_nslots = nslots; W.sh_xs = xs; W.sh_ys = nullptr; W.sh_th = thw; W.sh_part = ptw; W.sh_bar = bar;
+    W.sh_long = 1; W.sh_lcg = (int)lcg; W.sh_mblk = (int)(lcg * lrow);
+    void* kargs[] = {(void*)&W};
+    hipError_t ec = hipLaunchCooperativeKernel(kfn, dim3(256), dim3(NT), kargs, (unsigned int)llds, stream);
+    if (ec == hipSuccess) { launched_long = true; g_kernel = "long-sharded"; }
+    else (void)hipGetLastError();     // the runtime refused the cooperative launch: nothing ran, take the usual kernels
+    return FMCMC_OK;
+  };
+  if (m->family == FMCMC_FAM_GAUSSIAN_LINREG && m->p <= 15) {
     const double pn = (double)m->n;
     const double now_rate = (m->p <= 3) ? (pn <= 2e5 ? 3.3e-4 : 5.1e-4) : (m->p <= 7 ? 5.4e-4 : (m->p <= 11 ? 8.5e-4 : 1.17e-3));
     const double est_now = (m->n <= (long long)NT * (m->p <= 3 ? 20 : (m->p <= 7 ? 10 : 0)) ? 2.2 : now_rate * pn) + (kn->kind >= FMCMC_KERNEL_ADAPT ? 2.0 : 0.0);
-    const double groups = lcg >= 1 ? (double)((run->nchains + lcg - 1) / lcg) : 1e9;
-    const double est_long = 8.3 + groups * 1.6e-5 * pn + 0.5e-6 * pn * (double)(m->p + 1) +
-                            (double)run->nchains * (0.17 + 0.028 * (double)m->p + 1.2e-6 * pn) + (kn->kind >= FMCMC_KERNEL_ADAPT ? 3.5 : 0.0);
     const int kvl = kn->kind;
     const void* kfn = (kvl == 1) ? (const void*)mh_sweep_kernel<1, -1, 2, 1, FMCMC_FAM_GAUSSIAN_LINREG>
                     : (kvl == 2) ? (const void*)mh_sweep_kernel<1, -1, 2, 2, FMCMC_FAM_GAUSSIAN_LINREG>
                     : (kvl == 3) ? (const void*)mh_sweep_kernel<1, -1, 2, 3, FMCMC_FAM_GAUSSIAN_LINREG>
                                  : (const void*)mh_sweep_kernel<1, -1, 2, 4, FMCMC_FAM_GAUSSIAN_LINREG>;
-    bool go = lcg >= 1 && (K.shard == 1 || est_long < 0.9 * est_now);
-    const size_t llds = lds + sizeof(double) * (size_t)(lcg * lrow + 2);
-    if (go) {
-      int coop = 0, perCU = 0;
-      (void)hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev);
-      hipError_t el = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)llds);
-      if (el != hipSuccess || !coop || hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kfn, NT, llds) != hipSuccess || perCU < 1) go = false;
-    }
-    if (go) {
-      double* shw = nullptr;
-      const size_t nxs = (size_t)256 * (m->p + 1) * nobs, nth = ((size_t)kn->k * (run->nchains + SH_PAD) + 7) & ~(size_t)7,
-                   npt = (size_t)(NT + SH_PAD) * run->nchains, nbar = 32 * 20 / 2;
-      e = hipMallocAsync((void**)&shw, sizeof(double) * (nxs + nth + npt + nbar), stream);
-      if (e != hipSuccess) { set_err("hipMallocAsync(sharded evaluation) failed: %s", hipGetErrorString(e)); return FMCMC_ERR_DEVICE; }
-      shw_guard.p = shw; shw_guard.s = stream;
-      double* thw = shw; double* ptw = thw + nth; unsigned* bar = (unsigned*)(ptw + npt); double* xs = ptw + npt + nbar;
-      hipLaunchKernelGGL(long_build_slices, dim3(256), dim3(256), 0, stream, m->X, m->y, (long long)m->n, m->p, nslots, xs);
-      (void)hipMemsetAsync(bar, 0, sizeof(double) * nbar, stream);
-      SweepArgs W = A;
-      W.shard = 2; W.sh_nslots = nslots; W.sh_xs = xs; W.sh_ys = nullptr; W.sh_th = thw; W.sh_part = ptw; W.sh_bar = bar;
-      W.sh_long = 1; W.sh_lcg = (int)lcg; W.sh_mblk = (int)(lcg * lrow); W.tb = A.tb;
-      void* kargs[] = {(void*)&W};
-      e = hipLaunchCooperativeKernel(kfn, dim3(256), dim3(NT), kargs, (unsigned int)llds, stream);
-      if (e == hipSuccess) { launched_long = true; g_kernel = "long-sharded"; }
-      else { (void)hipGetLastError(); e = hipSuccess; }     // the runtime refused the cooperative launch: nothing ran, take the usual kernels
-    }
+    const int rcl = try_long(kfn, lds, est_now, false);
+    if (rcl != FMCMC_OK) return rcl;
   }
   if (launched_long) {
   } else
@@ -1007,6 +1010,19 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
     // hand-overs + n (p + 10.3) 1.78e-5 per 512 chains of a launch.  Knob shard=1 forces it for every eligible shape (tests),
     // shard=0 disables it.
     bool lshard = false;
+    // few chains: the long-data form (shard_long<LOGISTIC>) -- the sharded loop below keeps ONE thread per chain busy with its whole
+    // slice (n = 1e5, 1 .. 64 chains: 31 .. 36 us per step), the chain-sharded one walks the data set in one workgroup
+    if (m->p >= 1 && m->p <= 16) {
+      const double w1 = (double)m->n * (double)(m->p + 12), stream1 = (double)m->n * (double)(m->p + 1) * 8.0 / 9.0e4;
+      const double chain1 = 4.5 + ((w1 * 1.35e-5 > stream1) ? w1 * 1.35e-5 : stream1);
+      const double shard1 = 10.3 + 1.78e-5 * (double)m->n * ((double)m->p + 10.3);
+      const void* kfl = (lkv == 1) ? (const void*)mh_sweep_kernel<1, -1, 2, 1, FMCMC_FAM_LOGISTIC, 1> : (lkv == 2) ? (const void*)mh_sweep_kernel<1, -1, 2, 2, FMCMC_FAM_LOGISTIC, 1>
+                      : (lkv == 3) ? (const void*)mh_sweep_kernel<1, -1, 2, 3, FMCMC_FAM_LOGISTIC, 1> : (const void*)mh_sweep_kernel<1, -1, 2, 4, FMCMC_FAM_LOGISTIC, 1>;
+      const int rcl = try_long(kfl, lds, (chain1 < shard1 || m->p > 16) ? chain1 : shard1, true);
+      if (rcl != FMCMC_OK) return rcl;
+    }
+    if (launched_long) {
+    } else {
     const long long nb_launch = 256;
     const long long ch_launch = (nblk > nb_launch) ? nb_launch * cw : (long long)run->nchains;
     const int nslots = (int)((m->n + NT - 1) / NT);
@@ -1093,6 +1109,7 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
 #undef LAUNCH_LOGIT_K
 #undef LAUNCH_LOGIT
     }
+    }   // (not the long-data form)
   }
   else if (m->family == FMCMC_FAM_GAUSSIAN_LINREG && m->p >= 16 && cw <= 2 &&
            (kn->kind == FMCMC_KERNEL_RAM || kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE)) {

@@ -944,6 +944,38 @@ def test_few_chains_on_long_data(E, O, monkeypatch, n, p, chains, intercept):
     assert abi.last_kernel() == "long-sharded"
 
 
+@pytest.mark.parametrize("n,p,chains,intercept", [(4096, 3, 1, True), (9001, 1, 3, False), (30000, 5, 4, True), (65537, 8, 2, True), (100000, 5, 4, True),
+                                                  (200001, 2, 1, True), (40000, 12, 3, True), (25000, 16, 2, False), (20000, 5, 40, True)])
+def test_few_chains_on_long_data_logistic(E, O, monkeypatch, n, p, chains, intercept):
+    """The long-data form for the logistic family (shard_long<LOGISTIC>): the terms g(|eta|) of the slice into LDS by all threads
+    (the checked form: one column scaled by 12 puts |eta| beyond the table), then one thread per (chain, canonical lane) adds them in
+    slot order.  1 .. 40 chains (LDS groups), p up to 16, ragged n, all four proposal families, two calls: the oracle's bits."""
+    import torch
+    from fmcmc_amd import _abi as abi
+    if torch.cuda.get_device_properties(0).multi_processor_count < 256:
+        pytest.skip("the sharded forms need all 256 CUs")
+    set_knob(monkeypatch, "shard", "1")
+    rng = np.random.default_rng(3 * n + p)
+    X = rng.standard_normal((n, p))
+    if p == 8:
+        X[:, 0] *= 12.0
+    k = p + (1 if intercept else 0)
+    beta = rng.uniform(-1.0, 1.0, k)
+    eta = (beta[0] if intercept else 0.0) + X @ beta[(1 if intercept else 0):]
+    y = (rng.uniform(size=n) < 1 / (1 + np.exp(-eta))).astype(np.float64)
+    init = jitter_init(beta, chains, 50 + p)
+    steps = int(max(8, min(40, 6.0e7 / (chains * n * max(p, 1) * 2))))
+    kw = dict(intercept=intercept, prior_div=8.0)
+    run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_NORMAL, k, init, nsteps=steps, calls=2, scale=0.01, burnin=2, thin=2, **kw)
+    assert abi.last_kernel() == "long-sharded"
+    run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_NORMAL_REFLECTIVE, k, init, nsteps=steps, scale=0.1, lb=-1.5, ub=1.5, **kw)
+    assert abi.last_kernel() == "long-sharded"
+    run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_ADAPT, k, init, nsteps=steps, calls=2, warmup=3, **kw)
+    assert abi.last_kernel() == "long-sharded"
+    run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_RAM, k, init, nsteps=steps, **kw)
+    assert abi.last_kernel() == "long-sharded"
+
+
 @pytest.mark.parametrize("form", ["logistic-sharded", "wide-sequential", "wide-dataflow"])
 def test_a_lost_hand_over_ends_in_status_5_not_in_a_hang(E, monkeypatch, form):
     """The grid-wide hand-overs of the observation-sharded kernels, with a FAULT: knob mode=512 makes workgroup 1 skip ONE
