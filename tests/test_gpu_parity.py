@@ -976,7 +976,7 @@ def test_few_chains_on_long_data_logistic(E, O, monkeypatch, n, p, chains, inter
     assert abi.last_kernel() == "long-sharded"
 
 
-@pytest.mark.parametrize("form", ["logistic-sharded", "wide-sequential", "wide-dataflow"])
+@pytest.mark.parametrize("form", ["logistic-sharded", "wide-sequential", "wide-dataflow", "long-sharded"])
 def test_a_lost_hand_over_ends_in_status_5_not_in_a_hang(E, monkeypatch, form):
     """The grid-wide hand-overs of the observation-sharded kernels, with a FAULT: knob mode=512 makes workgroup 1 skip ONE
     arrival (epoch 3) and shortens every spin bound.  Every waiter must give up, every loop must run out and the grid must
@@ -998,6 +998,13 @@ def test_a_lost_hand_over_ends_in_status_5_not_in_a_hang(E, monkeypatch, form):
         k = p + 1
         gk = E.KernelSpec(abi.KERNEL_NORMAL, k, np.zeros(k), np.full(k, 0.05), np.full(k, -big), np.full(k, big), np.zeros(k, np.uint8))
         init = 0.1 * rng.standard_normal((C, k))
+    elif form == "long-sharded":
+        X, y = synth_linreg(30000, 3, 4243)
+        k, C = 5, 4
+        gm = E.DeviceModel(abi.FAM_GAUSSIAN_LINREG, X, y)
+        gk = E.KernelSpec(abi.KERNEL_NORMAL, k, np.zeros(k), np.full(k, 0.02), np.full(k, -big), np.full(k, big), np.zeros(k, np.uint8))
+        init = jitter_init([0.0] * 4 + [float(np.std(y))], C, 6)
+        init[:, -1] = np.abs(init[:, -1])
     else:
         set_knob(monkeypatch, "cw", "2")
         set_knob(monkeypatch, "wide2", "1" if form == "wide-dataflow" else "0")
@@ -1012,7 +1019,8 @@ def test_a_lost_hand_over_ends_in_status_5_not_in_a_hang(E, monkeypatch, form):
     r = E.sweep(gm, gk, st, 40, seed=7, check=False)
     torch.cuda.synchronize()
     assert time.time() - t0 < 120.0
-    want = {"logistic-sharded": "logistic-sharded", "wide-sequential": "streamed-wide-sharded-mfma", "wide-dataflow": "wide-dataflow"}[form]
+    want = {"logistic-sharded": "logistic-sharded", "wide-sequential": "streamed-wide-sharded-mfma", "wide-dataflow": "wide-dataflow",
+            "long-sharded": "long-sharded"}[form]
     assert abi.last_kernel() == want
     status = r.status.cpu().numpy()
     assert (status == abi.CHAIN_SYNC_TIMEOUT).any() and set(np.unique(status)) <= {0, abi.CHAIN_SYNC_TIMEOUT}
