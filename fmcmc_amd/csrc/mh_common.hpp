@@ -793,7 +793,7 @@ struct ShardLong {
   const double* xs;      // this workgroup's slice [p + 1][nobs]: columns, then y; observation o = 2 slot + q (0 beyond n)
   const double* th;      // [k][ncp] proposals of all chains
   double* part;          // [NC][NT + SH_PAD] lane partials
-  unsigned lds;          // LDS address of the term block [lcg][2][shard_long_row(nslots)] + [lcg][32] coefficients
+  unsigned lds;          // LDS address of the term block [lcg][2][shard_long_row(nslots)] + [lcg][SHL_BS] coefficients
   unsigned tab;          // logistic: LDS address of the g table
   int n;                 // observations (< 2^31: the host checks)
   int NC, ncp, p, ic, nslots, lane0, lcg;
@@ -804,12 +804,12 @@ static_assert(sizeof(ShardLong) <= 64, "ShardLong must travel in registers (16 d
 __host__ __device__ constexpr int shard_long_row(int nslots) { return ((nslots + 15) & ~15) + 16; }
 // FAM: Gaussian linreg -- terms r = y - (b0 + x b), lane sum acc = fma(r, r, acc) -- or logistic -- terms g(|64 eta|) off the table
 // in LDS (the checked form of logit_shard's term: any |eta|), lane sum acc = acc + g; up to 16 covariates.
-template <int FAM>
+constexpr int SHL_BS = 64;     // doubles per chain of the coefficient copies in LDS (k <= 64)
+template <int FAM, int PMAX /* columns held in registers per observation: 16, or 62 for wide linear models */>
 __device__ __attribute__((noinline)) void shard_long(ShardLong c) {
   typedef __attribute__((address_space(3))) double* ldsd_t;
   typedef double d2_t __attribute__((ext_vector_type(2)));
   constexpr bool LG = FAM == FMCMC_FAM_LOGISTIC;
-  constexpr int PMAX = LG ? 16 : 15;
   const int tid = threadIdx.x;
   const int NC = rfl_i(c.NC), NCP = rfl_i(c.ncp), p = rfl_i(c.p), ic = rfl_i(c.ic), nslots = rfl_i(c.nslots), lane0 = rfl_i(c.lane0), lcg = rfl_i(c.lcg);
   const long long n = (long long)rfl_i(c.n);
@@ -819,13 +819,13 @@ __device__ __attribute__((noinline)) void shard_long(ShardLong c) {
   const double* s_tab = (const double*)(ldsd_t)(unsigned long long)(unsigned)rfl_i((int)c.tab);
   const int nobs = 2 * nslots, nb = ic + p, NSP = shard_long_row(nslots), nwalk = NSP - 16;
   double* s_r = (double*)(ldsd_t)(unsigned long long)(unsigned)rfl_i((int)c.lds);   // [lcg][2][NSP] residuals, a row per (chain, lane)
-  double* s_b = s_r + (long long)lcg * 2 * NSP;                                       // [lcg][32] coefficients of the group's chains (logistic: times 64, exact)
+  double* s_b = s_r + (long long)lcg * 2 * NSP;                                       // [lcg][SHL_BS] coefficients of the group's chains (logistic: times 64, exact)
   for (int c0 = 0; c0 < NC; c0 += lcg) {
     const int ncg = (NC - c0 < lcg) ? NC - c0 : lcg;
     for (int idx = tid; idx < ncg * nb; idx += NT) {
       const int cc = idx / nb, j = idx - cc * nb;
       const double bv = sh_load(thg + ((unsigned int)(j * NCP) + (unsigned int)(c0 + cc)));
-      s_b[cc * 32 + j] = LG ? bv * FMH_LG_SCALE : bv;
+      s_b[cc * SHL_BS + j] = LG ? bv * FMH_LG_SCALE : bv;
     }
     lds_barrier();
     // (a) residuals of the slice, every thread a stride of its observations; slots beyond the data (and the padding of a row up to
@@ -840,7 +840,7 @@ __device__ __attribute__((noinline)) void shard_long(ShardLong c) {
       const double yv = LG ? 0.0 : xs[(long long)p * nobs + oc];
       double* dst = s_r + (long long)(o & 1) * NSP + (o >> 1);
       for (int cc = 0; cc < ncg; cc++) {
-        const double* bj = s_b + cc * 32;
+        const double* bj = s_b + cc * SHL_BS;
         double m = ic ? bj[0] : 0.0;
 #pragma unroll
         for (int j = 0; j < PMAX; j++) if (j < p) m = fmh_fma(x[j], bj[ic + j], m);
@@ -916,7 +916,9 @@ __device__ __forceinline__ bool eval_sharded(const SweepArgs& A, double* const* 
     sl.tab = LG ? (unsigned)(unsigned long long)(ldsc_t)s_mblk : 0u;
     sl.lds = (unsigned)(unsigned long long)(ldsc_t)(LG ? s_mblk + LG_LDS_DOUBLES + 2 : s_mblk);
     sl.NC = NC; sl.ncp = NCP; sl.p = p; sl.ic = ic; sl.nslots = A.sh_nslots; sl.lane0 = (int)blockIdx.x * LPW; sl.lcg = A.sh_lcg;
-    shard_long<LG ? FMCMC_FAM_LOGISTIC : FMCMC_FAM_GAUSSIAN_LINREG>(sl);
+    if constexpr (LG) shard_long<FMCMC_FAM_LOGISTIC, 16>(sl);
+    else if (p <= 16) shard_long<FMCMC_FAM_GAUSSIAN_LINREG, 16>(sl);
+    else shard_long<FMCMC_FAM_GAUSSIAN_LINREG, 62>(sl);      // (wide linear models beyond the slices of the matrix-core form)
   } else if constexpr (FAM == FMCMC_FAM_LOGISTIC) {
     eval_sharded_logit_step<LPW>(A, s_mblk);
   } else {

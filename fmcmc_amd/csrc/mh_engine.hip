@@ -721,7 +721,7 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
         (kn->kind == FMCMC_KERNEL_RAM && ram_bounded) || kn->kind < FMCMC_KERNEL_NORMAL || kn->kind > FMCMC_KERNEL_RAM) return FMCMC_OK;
     const int nslots = (int)((m->n + NT - 1) / NT), nobs = 2 * nslots;
     const long long room = ((long long)150 * 1024 - (long long)lds_base) / 8 - 2;
-    const long long lrow = 2ll * shard_long_row(nslots) + 32;     // LDS doubles per chain of a group
+    const long long lrow = 2ll * shard_long_row(nslots) + SHL_BS;     // LDS doubles per chain of a group
     long long lcg = room / lrow;
     if (lcg > run->nchains) lcg = run->nchains;
     if (lcg < 1) return FMCMC_OK;
@@ -754,10 +754,13 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
     else (void)hipGetLastError();     // the runtime refused the cooperative launch: nothing ran, take the usual kernels
     return FMCMC_OK;
   };
-  if (m->family == FMCMC_FAM_GAUSSIAN_LINREG && m->p <= 15) {
+  // (wide linear models, p >= 16: where the matrix-core slices end -- 96 observations per workgroup, n = 24,576 -- the chain-sharded
+  //  kernel is what is left: 4 + n p 8 / 65000 us per step)
+  if (m->family == FMCMC_FAM_GAUSSIAN_LINREG && (m->p <= 15 || (m->p <= 62 && m->n > (long long)NT * 2 * SHM_T))) {
     const double pn = (double)m->n;
     const double now_rate = (m->p <= 3) ? (pn <= 2e5 ? 3.3e-4 : 5.1e-4) : (m->p <= 7 ? 5.4e-4 : (m->p <= 11 ? 8.5e-4 : 1.17e-3));
-    const double est_now = (m->n <= (long long)NT * (m->p <= 3 ? 20 : (m->p <= 7 ? 10 : 0)) ? 2.2 : now_rate * pn) + (kn->kind >= FMCMC_KERNEL_ADAPT ? 2.0 : 0.0);
+    const double est_now = (m->p >= 16) ? 4.0 + pn * (double)m->p * 8.0 / 65000.0
+                         : (m->n <= (long long)NT * (m->p <= 3 ? 20 : (m->p <= 7 ? 10 : 0)) ? 2.2 : now_rate * pn) + (kn->kind >= FMCMC_KERNEL_ADAPT ? 2.0 : 0.0);
     const int kvl = kn->kind;
     const void* kfn = (kvl == 1) ? (const void*)mh_sweep_kernel<1, -1, 2, 1, FMCMC_FAM_GAUSSIAN_LINREG>
                     : (kvl == 2) ? (const void*)mh_sweep_kernel<1, -1, 2, 2, FMCMC_FAM_GAUSSIAN_LINREG>

@@ -912,12 +912,14 @@ def test_observation_sharded_slices_beyond_forty_observations(E, O, monkeypatch,
 
 
 @pytest.mark.parametrize("n,p,chains,intercept", [(4096, 3, 1, True), (5001, 1, 3, True), (30000, 3, 4, True), (65537, 2, 2, False), (100000, 3, 4, True),
-                                                  (200001, 5, 1, True), (50000, 8, 5, True), (40000, 14, 2, True), (300000, 0, 3, True), (20000, 3, 40, True)])
+                                                  (200001, 5, 1, True), (50000, 8, 5, True), (40000, 14, 2, True), (300000, 0, 3, True), (20000, 3, 40, True),
+                                                  (24577, 16, 3, True), (30000, 48, 2, True), (60001, 33, 1, False), (25000, 62, 4, True)])
 def test_few_chains_on_long_data(E, O, monkeypatch, n, p, chains, intercept):
     """The long-data form of the observation-sharded evaluation (shard_long, round 4): up to 64 chains, every one of the 256
     workgroups evaluates its 1/256 of the observations for all of them -- residuals into LDS by all threads, then one thread per
     (chain, canonical lane) walks its slots in order -- instead of one workgroup walking the whole data set.  Forced by knob
-    shard=1 at the small sizes; ragged n, no intercept, p = 0 (iid Normal) .. 14, chain groups (40 chains at n = 20,000 need two LDS
+    shard=1 at the small sizes; ragged n, no intercept, p = 0 (iid Normal) .. 14 and wide models (p = 16 .. 62) beyond the matrix-core
+    slices' 24,576 observations, chain groups (40 chains at n = 20,000 need two LDS
     passes... or one), kernel_normal, kernel_normal_reflective with an ordered scheme, kernel_ram, two calls: the oracle's bits."""
     import torch
     from fmcmc_amd import _abi as abi

@@ -110,6 +110,10 @@ for n, p, c in (grid_long if "long" in ONLY else []):
     for kind, name in KINDS:
         linreg(n, p, c, kind, name, ["", "shard=0", "shard=1"])
     print("long", n, p, c, "%.0f s" % (time.time() - t_begin), flush=True)
+for n, p, c in ([] if QUICK or "long" not in ONLY else [(n, p, c) for n in (30000, 100000) for p in (30, 48) for c in (1, 4, 64)]):
+    for kind, name in (KINDS[0], KINDS[2]):
+        linreg(n, p, c, kind, name, ["", "shard=0", "shard=1"])
+    print("long wide", n, p, c, "%.0f s" % (time.time() - t_begin), flush=True)
 grid_llong = [] if QUICK else [(n, p, c) for n in (20000, 100000, 1000000) for p in (5, 12) for c in (1, 4, 16, 64)]
 for n, p, c in (grid_llong if "long" in ONLY else []):
     logistic(n, p, c, ["", "shard=0", "shard=1"])
