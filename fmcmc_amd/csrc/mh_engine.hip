@@ -652,8 +652,9 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
   AsyncScratch mfs_guard;
   if (!force && !nopipe && m->family == FMCMC_FAM_GAUSSIAN_LINREG &&
       (kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE ||
-       (((kn->kind == FMCMC_KERNEL_ADAPT && !adapt_hist) || (kn->kind == FMCMC_KERNEL_RAM && !kn->constr)) && !nospec)) &&
-      (kn->scheme == FMCMC_SCHEME_JOINT || kn->kind >= FMCMC_KERNEL_ADAPT) && kn->k <= PIPE_KMAX &&
+       (((kn->kind == FMCMC_KERNEL_ADAPT && !adapt_hist) || (kn->kind == FMCMC_KERNEL_RAM && !kn->constr)) && !nospec) ||
+       (mirror && kn->scheme == FMCMC_SCHEME_JOINT && kf == kn->k && K.mfma != 0)) &&
+      (kn->scheme == FMCMC_SCHEME_JOINT || kn->kind == FMCMC_KERNEL_ADAPT || kn->kind == FMCMC_KERNEL_RAM) && kn->k <= PIPE_KMAX &&
       // Sizes (round 3: rows and variates are addressed as 64-bit chain base + 32-bit offset, and a long call of the normal /
       // uniform kernels runs as step windows with a bounded stream, so a call no longer leaves these kernels at 4 GiB of
       // samples or stream).  What is left: offsets inside one chain's blocks are 32 bits, and the adaptive kernels -- whose
@@ -669,7 +670,7 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
       const int optmax = (m->p >= 1 && m->p <= 3) ? 20 : (m->p <= 5 ? 10 : (m->p <= 7 ? 8 : 0));
       // (the bounded kernel_ram decides on f of the REFLECTED proposal: a second evaluation in the steps in which the reflection
       //  moved something -- the barrier-synchronised owners of mh_sweep_mfma_ad ask for it, this kernel's pipelined ones cannot)
-      if (m->p >= 1 && nsl2 <= optmax && kn->kind >= FMCMC_KERNEL_ADAPT && !(kn->kind == FMCMC_KERNEL_RAM && ram_bounded)) pipe_opt = (int)nsl2;
+      if (m->p >= 1 && nsl2 <= optmax && (kn->kind == FMCMC_KERNEL_ADAPT || kn->kind == FMCMC_KERNEL_RAM) && !(kn->kind == FMCMC_KERNEL_RAM && ram_bounded)) pipe_opt = (int)nsl2;
       // (normal / uniform kernels run on the MFMA kernel; knob mfma=0 keeps them here for the two shapes they were tuned at)
       if (m->p == 3 && nsl == 20 && kn->kind < FMCMC_KERNEL_ADAPT) pipe_opt = 20;
       if (m->p == 1 && nsl == 2 && kn->kind < FMCMC_KERNEL_ADAPT) pipe_opt = 2;
@@ -695,7 +696,7 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
     // (k = 9 -- seven covariates, intercept and sigma -- as a compile-time row count: tools/dispatch_audit.py found these calls on
     //  the general kernel, 7x the time of the normal kernels at the same shape)
     // (mfma_ad == 2: the owners with their matrices in LDS -- 8 .. 15 covariates, or a fixed parameter; not the bounded kernel_ram)
-    if (K.mfma != 0 && !pipe_opt && kn->kind >= FMCMC_KERNEL_ADAPT && m->p >= 0 && m->p <= 15 && m->n < (1ll << 29)) {   // (p = 0: iid Normal)
+    if (K.mfma != 0 && !pipe_opt && (kn->kind == FMCMC_KERNEL_ADAPT || kn->kind == FMCMC_KERNEL_RAM) && m->p >= 0 && m->p <= 15 && m->n < (1ll << 29)) {   // (p = 0: iid Normal)
       const bool reg_owner = m->p <= 7 && kf == kn->k && (kn->k <= SPEC_KA || kn->k == 9) && A.kz == kn->k;
       const int ng = (m->p <= 3) ? 1 : (m->p <= 7 ? 2 : (m->p <= 11 ? 3 : 4));
       const int nsr = (ng == 1) ? MfmaAdShape<1>::NSR : (ng == 2 ? MfmaAdShape<2>::NSR : MfmaAdShape<3>::NSR);
@@ -706,6 +707,13 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
       }
     }
     if (kn->kind == FMCMC_KERNEL_RAM && ram_bounded && !mfma_ad) pipe_opt = 0, mfma_ng = 0;   // (general kernel)
+    // the mirror kernels (joint scheme, no fixed parameter): their owner between the barriers of the same streamed MFMA evaluation
+    if (mirror) {
+      const int ng = (m->p <= 3) ? 1 : (m->p <= 7 ? 2 : (m->p <= 11 ? 3 : 4));
+      const int nsr = (ng == 1) ? MfmaAdShape<1>::NSR : (ng == 2 ? MfmaAdShape<2>::NSR : MfmaAdShape<3>::NSR);
+      pipe_opt = 0; mfma_ng = 0;
+      if (m->p <= 15 && m->n > (long long)NT * nsr && m->n < (1ll << 29)) { mfma_ad = 3; mfma_ng = ng; mfma_ext = nsr; }
+    }
   }
   A.spec_opt = pipe_opt;
   // ---- the LONG-DATA form (mh_common.hpp, shard_long): few chains on long data.  Up to four chains are one workgroup of the
@@ -876,7 +884,11 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
                            else hipLaunchKernelGGL((mh_sweep_mfma_ad<4, GV, XV>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); } while (0)
 #define MF_ADL(GV) do { if (kn->kind == FMCMC_KERNEL_ADAPT) hipLaunchKernelGGL((mh_sweep_mfma_ad<3, GV, -1>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); \
                         else hipLaunchKernelGGL((mh_sweep_mfma_ad<4, GV, -1>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); } while (0)
-        if (mfma_ad == 2) { if (mfma_ng == 1) MF_ADL(1); else if (mfma_ng == 2) MF_ADL(2); else if (mfma_ng == 3) MF_ADL(3); else MF_ADL(4); }
+#define MF_ADM(GV) do { if (kn->kind == FMCMC_KERNEL_NMIRROR) hipLaunchKernelGGL((mh_sweep_mfma_ad<FMCMC_KERNEL_NMIRROR, GV, -2>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); \
+                        else hipLaunchKernelGGL((mh_sweep_mfma_ad<FMCMC_KERNEL_UMIRROR, GV, -2>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); } while (0)
+        if (mfma_ad == 3) { if (mfma_ng == 1) MF_ADM(1); else if (mfma_ng == 2) MF_ADM(2); else if (mfma_ng == 3) MF_ADM(3); else MF_ADM(4); }
+        else if (mfma_ad == 2) { if (mfma_ng == 1) MF_ADL(1); else if (mfma_ng == 2) MF_ADL(2); else if (mfma_ng == 3) MF_ADL(3); else MF_ADL(4); }
+#undef MF_ADM
         else if (mfma_ng == 1 && kn->k == 5) MF_AD(1, 5);
         else if (mfma_ng == 1) MF_AD(1, 0);
         else if (kn->k == 9) MF_AD(2, 9);

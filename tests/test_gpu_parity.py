@@ -508,6 +508,26 @@ def test_mirror_kernels(E, O, kind_name, C, n, p, scheme, fixed):
     assert np.all(ro.state.abs_iter == 318)
 
 
+@pytest.mark.parametrize("kind_name", ["nmirror", "umirror"])
+@pytest.mark.parametrize("n,p,intercept", [(10000, 3, True), (6145, 1, True), (20001, 2, False), (5000, 5, True), (3073, 7, True), (4000, 9, True), (2000, 13, True)])
+def test_mirror_kernels_on_the_streamed_mfma_evaluation(E, O, monkeypatch, kind_name, n, p, intercept):
+    """kernel_nmirror / kernel_umirror with the joint scheme and no fixed parameter from 6,144 (3,072 / 1,536) observations on:
+    mh_sweep_mfma_ad<KIND, NG, -2>, their owner between the barriers of the streamed MFMA evaluation (round 4; the all-family
+    kernel took 17.8 us per step at C2's shape).  Warm-up mean, the one-off tan() rescaling, bounds, two calls with the state
+    carried: the oracle's bits."""
+    from fmcmc_amd import _abi as abi
+    set_knob(monkeypatch, "shard", "0")
+    X, y = synth_linreg(n, p, 93 + n, beta=np.linspace(0.6, -0.6, p + 1))
+    k = p + 1 + (1 if intercept else 0)
+    base = ([0.5] if intercept else []) + [0.5] * p + [float(np.std(y))]
+    init = jitter_init(base, 6, 8)
+    kind = O.K_NMIRROR if kind_name == "nmirror" else O.K_UMIRROR
+    rg, ro = run_both(E, O, O.FAM_LINREG, X, y, kind, k, init, nsteps=150, calls=2, mu=base, scale=0.15, warmup=110, nadapt=6,
+                      lb=[-30.0] * (k - 1) + [0.05], ub=30.0, intercept=intercept, burnin=3, thin=2)
+    assert abi.last_kernel() == "mfma-adaptive"
+    assert np.all(np.isfinite(ro.state.obs_arate)) and np.all(ro.state.abs_iter == 298)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # One-family instantiations of the streamed kernel: logistic (compile-time number of covariates, coefficients in SGPRs,
 # chain-vectorised softplus), wide linear models (observation blocking), and the adaptive owners with a compile-time k
