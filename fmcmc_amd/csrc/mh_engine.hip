@@ -704,6 +704,12 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
         mfma_ad = reg_owner ? 1 : 2;
         mfma_ng = ng;
         mfma_ext = nsr;
+      } else if (m->n > NT && ((reg_owner && kn->kind == FMCMC_KERNEL_RAM && ram_bounded) || (!reg_owner && !(kn->kind == FMCMC_KERNEL_RAM && ram_bounded)))) {
+        // short data (one slot resident, the rest streamed) for what the wave-specialised kernel does not take: the bounded
+        // kernel_ram, 8 .. 15 covariates
+        mfma_ad = reg_owner ? 1 : 2;
+        mfma_ng = ng;
+        mfma_ext = 1;
       }
     }
     if (kn->kind == FMCMC_KERNEL_RAM && ram_bounded && !mfma_ad) pipe_opt = 0, mfma_ng = 0;   // (general kernel)
@@ -712,7 +718,7 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
       const int ng = (m->p <= 3) ? 1 : (m->p <= 7 ? 2 : (m->p <= 11 ? 3 : 4));
       const int nsr = (ng == 1) ? MfmaAdShape<1>::NSR : (ng == 2 ? MfmaAdShape<2>::NSR : MfmaAdShape<3>::NSR);
       pipe_opt = 0; mfma_ng = 0;
-      if (m->p <= 15 && m->n > (long long)NT * nsr && m->n < (1ll << 29)) { mfma_ad = 3; mfma_ng = ng; mfma_ext = nsr; }
+      if (m->p <= 15 && m->n > NT && m->n < (1ll << 29)) { mfma_ad = 3; mfma_ng = ng; mfma_ext = (m->n > (long long)NT * nsr) ? nsr : 1; }
     }
   }
   A.spec_opt = pipe_opt;
@@ -879,12 +885,18 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
       if (mfma_ad) {
         g_kernel = "mfma-adaptive";
         const size_t alds = mfma_ad_lds_bytes(mfma_ad == 2);
+        const bool ad_short = mfma_ext == 1;    // (short data: one resident slot)
 #define MF_AD(GV, XV) do { if (kn->kind == FMCMC_KERNEL_ADAPT) hipLaunchKernelGGL((mh_sweep_mfma_ad<3, GV, XV>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); \
+                           else if (ram_bounded && ad_short) hipLaunchKernelGGL((mh_sweep_mfma_ad<4, GV, XV, true, 1>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); \
                            else if (ram_bounded) hipLaunchKernelGGL((mh_sweep_mfma_ad<4, GV, XV, true>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); \
                            else hipLaunchKernelGGL((mh_sweep_mfma_ad<4, GV, XV>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); } while (0)
-#define MF_ADL(GV) do { if (kn->kind == FMCMC_KERNEL_ADAPT) hipLaunchKernelGGL((mh_sweep_mfma_ad<3, GV, -1>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); \
+#define MF_ADL(GV) do { if (kn->kind == FMCMC_KERNEL_ADAPT && ad_short) hipLaunchKernelGGL((mh_sweep_mfma_ad<3, GV, -1, false, 1>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); \
+                        else if (kn->kind == FMCMC_KERNEL_ADAPT) hipLaunchKernelGGL((mh_sweep_mfma_ad<3, GV, -1>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); \
+                        else if (ad_short) hipLaunchKernelGGL((mh_sweep_mfma_ad<4, GV, -1, false, 1>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); \
                         else hipLaunchKernelGGL((mh_sweep_mfma_ad<4, GV, -1>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); } while (0)
-#define MF_ADM(GV) do { if (kn->kind == FMCMC_KERNEL_NMIRROR) hipLaunchKernelGGL((mh_sweep_mfma_ad<FMCMC_KERNEL_NMIRROR, GV, -2>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); \
+#define MF_ADM(GV) do { if (kn->kind == FMCMC_KERNEL_NMIRROR && ad_short) hipLaunchKernelGGL((mh_sweep_mfma_ad<FMCMC_KERNEL_NMIRROR, GV, -2, false, 1>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); \
+                        else if (kn->kind == FMCMC_KERNEL_NMIRROR) hipLaunchKernelGGL((mh_sweep_mfma_ad<FMCMC_KERNEL_NMIRROR, GV, -2>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); \
+                        else if (ad_short) hipLaunchKernelGGL((mh_sweep_mfma_ad<FMCMC_KERNEL_UMIRROR, GV, -2, false, 1>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); \
                         else hipLaunchKernelGGL((mh_sweep_mfma_ad<FMCMC_KERNEL_UMIRROR, GV, -2>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); } while (0)
         if (mfma_ad == 3) { if (mfma_ng == 1) MF_ADM(1); else if (mfma_ng == 2) MF_ADM(2); else if (mfma_ng == 3) MF_ADM(3); else MF_ADM(4); }
         else if (mfma_ad == 2) { if (mfma_ng == 1) MF_ADL(1); else if (mfma_ng == 2) MF_ADL(2); else if (mfma_ng == 3) MF_ADL(3); else MF_ADL(4); }

@@ -196,9 +196,10 @@ __device__ __forceinline__ void mfma_owner_mirror(const SweepArgs& A, int myc, i
   }
 }
 
-template <int KIND, int NG, int KX, bool BND = false>
+// NSV: resident slots -- MfmaAdShape<NG>::NSR, or 1 for short data (512 < n <= 512 NSR: everything else streamed)
+template <int KIND, int NG, int KX, bool BND = false, int NSV = MfmaAdShape<NG>::NSR>
 __global__ __launch_bounds__(NT) void mh_sweep_mfma_ad(const SweepArgs A) {
-  constexpr int CW = 4, NS = MfmaAdShape<NG>::NSR, RD = MfmaAdShape<NG>::RD, TN = NS * 4, MB = 12;
+  constexpr int CW = 4, NS = NSV, RD = MfmaAdShape<NG>::RD, TN = NS * 4, MB = TN < 12 ? TN : 12;
   static_assert(TN % MB == 0, "batches of MB pairs");
   static_assert(KX >= 0 || !BND, "the bounded kernel_ram has the register-row owner only");   // (KX = -1: matrices in LDS, -2: the mirror kernels' owner)
   extern __shared__ double smem[];

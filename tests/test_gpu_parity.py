@@ -509,9 +509,11 @@ def test_mirror_kernels(E, O, kind_name, C, n, p, scheme, fixed):
 
 
 @pytest.mark.parametrize("kind_name", ["nmirror", "umirror"])
-@pytest.mark.parametrize("n,p,intercept", [(10000, 3, True), (6145, 1, True), (20001, 2, False), (5000, 5, True), (3073, 7, True), (4000, 9, True), (2000, 13, True)])
+@pytest.mark.parametrize("n,p,intercept", [(10000, 3, True), (6145, 1, True), (20001, 2, False), (5000, 5, True), (3073, 7, True), (4000, 9, True), (2000, 13, True),
+                                           (1500, 3, True), (513, 2, True), (700, 9, True), (3072, 5, False)])
 def test_mirror_kernels_on_the_streamed_mfma_evaluation(E, O, monkeypatch, kind_name, n, p, intercept):
-    """kernel_nmirror / kernel_umirror with the joint scheme and no fixed parameter from 6,144 (3,072 / 1,536) observations on:
+    """kernel_nmirror / kernel_umirror with the joint scheme and no fixed parameter from 513 observations on (one resident slot for
+    short data):
     mh_sweep_mfma_ad<KIND, NG, -2>, their owner between the barriers of the streamed MFMA evaluation (round 4; the all-family
     kernel took 17.8 us per step at C2's shape).  Warm-up mean, the one-off tan() rescaling, bounds, two calls with the state
     carried: the oracle's bits."""
@@ -697,7 +699,7 @@ def test_mfma_kernel_with_eight_to_fifteen_covariates(E, O, monkeypatch, n, p, i
     assert abi.last_kernel() == "mfma-streamed"
 
 
-@pytest.mark.parametrize("n,p,intercept", [(10241, 3, True), (20000, 3, True), (12001, 3, False), (30000, 2, True), (5121, 5, True), (6500, 6, True), (9000, 4, False), (6000, 7, True), (8200, 7, False), (7000, 3, True), (10000, 3, True), (3100, 5, True)])
+@pytest.mark.parametrize("n,p,intercept", [(10241, 3, True), (20000, 3, True), (12001, 3, False), (30000, 2, True), (5121, 5, True), (6500, 6, True), (9000, 4, False), (6000, 7, True), (8200, 7, False), (7000, 3, True), (10000, 3, True), (3100, 5, True), (2000, 3, True), (700, 1, False), (1000, 6, True)])
 def test_adaptive_kernels_on_the_streamed_mfma_evaluation(E, O, monkeypatch, n, p, intercept):
     """mh_sweep_mfma_ad (round 4): kernel_adapt / kernel_ram beyond mh_sweep_spec's registers -- the streamed MFMA evaluation of
     all four chains of a workgroup, then one step of the register-row adaptive owners between barriers.  k = 5 (the
@@ -723,7 +725,8 @@ def test_adaptive_kernels_on_the_streamed_mfma_evaluation(E, O, monkeypatch, n, 
 
 
 @pytest.mark.parametrize("n,p,intercept,fix", [(3000, 9, True, False), (10000, 11, True, False), (2049, 12, False, False), (1537, 13, True, True),
-                                               (6000, 14, True, False), (12000, 3, True, True), (6000, 6, True, True), (20000, 8, False, True)])
+                                               (6000, 14, True, False), (12000, 3, True, True), (6000, 6, True, True), (20000, 8, False, True),
+                                               (900, 9, True, False), (1500, 13, True, False), (513, 8, False, True)])
 def test_adaptive_kernels_with_their_matrices_in_lds_on_the_streamed_mfma_evaluation(E, O, monkeypatch, n, p, intercept, fix):
     """mh_sweep_mfma_ad<KIND, NG, -1> (round 4): kernel_adapt / kernel_ram with 8 .. 15 covariates (k <= 16), or with a fixed
     parameter beyond the wave-specialised kernel's range -- the owners that keep their matrices in LDS (spec_owner_adaptive, any
