@@ -704,9 +704,9 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
         mfma_ad = reg_owner ? 1 : 2;
         mfma_ng = ng;
         mfma_ext = nsr;
-      } else if (m->n > NT && ((reg_owner && kn->kind == FMCMC_KERNEL_RAM && ram_bounded) || (!reg_owner && !(kn->kind == FMCMC_KERNEL_RAM && ram_bounded)))) {
+      } else if (m->n > NT && ((reg_owner && ((kn->kind == FMCMC_KERNEL_RAM && ram_bounded) || m->p == 0)) || (!reg_owner && !(kn->kind == FMCMC_KERNEL_RAM && ram_bounded)))) {
         // short data (one slot resident, the rest streamed) for what the wave-specialised kernel does not take: the bounded
-        // kernel_ram, 8 .. 15 covariates
+        // kernel_ram, 8 .. 15 covariates, no covariate at all (iid Normal)
         mfma_ad = reg_owner ? 1 : 2;
         mfma_ng = ng;
         mfma_ext = 1;
@@ -886,7 +886,9 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
         g_kernel = "mfma-adaptive";
         const size_t alds = mfma_ad_lds_bytes(mfma_ad == 2);
         const bool ad_short = mfma_ext == 1;    // (short data: one resident slot)
-#define MF_AD(GV, XV) do { if (kn->kind == FMCMC_KERNEL_ADAPT) hipLaunchKernelGGL((mh_sweep_mfma_ad<3, GV, XV>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); \
+#define MF_AD(GV, XV) do { if (kn->kind == FMCMC_KERNEL_ADAPT && ad_short && GV == 1 && XV == 0) hipLaunchKernelGGL((mh_sweep_mfma_ad<3, 1, 0, false, 1>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); \
+                           else if (kn->kind == FMCMC_KERNEL_ADAPT) hipLaunchKernelGGL((mh_sweep_mfma_ad<3, GV, XV>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); \
+                           else if (!ram_bounded && ad_short && GV == 1 && XV == 0) hipLaunchKernelGGL((mh_sweep_mfma_ad<4, 1, 0, false, 1>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); \
                            else if (ram_bounded && ad_short) hipLaunchKernelGGL((mh_sweep_mfma_ad<4, GV, XV, true, 1>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); \
                            else if (ram_bounded) hipLaunchKernelGGL((mh_sweep_mfma_ad<4, GV, XV, true>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); \
                            else hipLaunchKernelGGL((mh_sweep_mfma_ad<4, GV, XV>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); } while (0)

@@ -205,10 +205,10 @@ def test_iid_normal(E, O):
 def test_iid_normal_on_the_linear_model_kernels(E, O):
     """FAM_IID_NORMAL is the Gaussian linear model with an intercept and no covariate, in the oracle and in every kernel: since
     round 4 it takes that model's fast paths (normal / uniform kernels on the MFMA kernels, the adaptive ones on the streamed MFMA
-    evaluation beyond 6,144 observations) instead of the all-family kernel."""
+    evaluation from 513 observations on) instead of the all-family kernel."""
     from fmcmc_amd import _abi as abi
     rng = np.random.default_rng(12)
-    for n, want_n, want_a in ((700, "mfma", "streamed"), (9000, "mfma", "mfma-adaptive"), (20001, "mfma-streamed", "mfma-adaptive")):
+    for n, want_n, want_a in ((700, "mfma", "mfma-adaptive"), (9000, "mfma", "mfma-adaptive"), (20001, "mfma-streamed", "mfma-adaptive")):
         y = 1.5 + 2.0 * rng.standard_normal(n)
         init = jitter_init([1.0, 2.0], 7, 5)
         init[:, -1] = np.abs(init[:, -1]) + 0.1
