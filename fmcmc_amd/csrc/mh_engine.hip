@@ -704,7 +704,7 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
         mfma_ad = reg_owner ? 1 : 2;
         mfma_ng = ng;
         mfma_ext = nsr;
-      } else if (m->n > NT && ((reg_owner && ((kn->kind == FMCMC_KERNEL_RAM && ram_bounded) || m->p == 0)) || (!reg_owner && !(kn->kind == FMCMC_KERNEL_RAM && ram_bounded)))) {
+      } else if (m->n > NT && ((reg_owner && ((kn->kind == FMCMC_KERNEL_RAM && ram_bounded) || m->p == 0)) || (!reg_owner && !(kn->kind == FMCMC_KERNEL_RAM && ram_bounded) && run->nchains <= 2048 /* (beyond: level with the general kernel at eight chains per workgroup) */))) {
         // short data (one slot resident, the rest streamed) for what the wave-specialised kernel does not take: the bounded
         // kernel_ram, 8 .. 15 covariates, no covariate at all (iid Normal)
         mfma_ad = reg_owner ? 1 : 2;
