@@ -1597,19 +1597,20 @@ def test_randomised_option_cases(E, O, case):
              seed=int(rng.integers(1, 10**6)), chain_base=int(rng.choice([0, 3, 4096])), calls=calls, **kw, **opts)
 
 
-@pytest.mark.parametrize("case", range(int(os.environ.get("FMCMC_TEST_RANDOM_CASES3", "64"))))   # soak: 4000 passed (final code of round 4)
+@pytest.mark.parametrize("case", range(int(os.environ.get("FMCMC_TEST_RANDOM_CASES3", "64"))))   # soak: 4000 + 1500 (with region E) passed on the final code of round 4
 def test_randomised_round4_regions(E, O, monkeypatch, case):
     """Third randomised sweep, over the regions round 4 opened and the first two never draw: (A) linreg beyond the operand
     registers of the MFMA kernel (10,240 < n <= 45,000 at p <= 3, 5,120 < n at p <= 7: mfma-streamed / mfma-adaptive), (B) 64 < k
     <= 128 (big-k), (C) logistic regression on the observation-sharded evaluation at ragged n, p <= 8, chain counts around 512,
-    (D) the wave-specialised kernel at any n <= 10,240 with p <= 7 -- each with random kernels, bounds, fixed masks, burn-in,
+    (D) the wave-specialised kernel at any n <= 10,240 with p <= 7, (E) few chains on long data (the long-data form; linreg narrow
+    and wide, logistic) -- each with random kernels, bounds, fixed masks, burn-in,
     thinning and one or two calls.  Whatever kernel the dispatcher picks: the oracle's bits."""
     from fmcmc_amd import _abi as abi
     rng = np.random.default_rng(8640000 + case)
-    region = "ABCD"[case % 4]
+    region = "ABCDE"[case % 5]
     intercept = bool(rng.integers(0, 4))            # mostly with an intercept
     calls = int(rng.integers(1, 3))
-    fam = "logistic" if region == "C" else "linreg"
+    fam = "logistic" if region == "C" else "linreg"     # (region E draws its own)
     if region == "A":
         p = int(rng.choice([1, 2, 3, 3, 4, 5, 7, 8, 10, 13, 14]))
         n = int(rng.integers(10241, 45001)) if p <= 3 else (int(rng.integers(5121 if p <= 5 else 4097, 20001)) if p <= 7 else int(rng.integers(513, 12001)))
@@ -1627,6 +1628,19 @@ def test_randomised_round4_regions(E, O, monkeypatch, case):
         chains = int(rng.choice([3, 8, 130, 511, 513, 600]))
         kind_name = str(rng.choice(["normal", "reflective"]))
         set_knob(monkeypatch, "shard", str(rng.choice(["1", "1", "0"])))
+    elif region == "E":     # few chains on long data: the long-data form, linreg narrow / wide and logistic
+        fam = str(rng.choice(["linreg", "linreg", "logistic"]))
+        chains = int(rng.choice([1, 2, 4, 7]))
+        if fam == "logistic":
+            p = int(rng.integers(1, 17))
+            n = int(rng.integers(20000, 120001))
+        elif rng.random() < 0.3:
+            p = int(rng.integers(16, 41))
+            n = int(rng.integers(24577, 60001))
+        else:
+            p = int(rng.choice([1, 2, 3, 5, 8, 14]))
+            n = int(rng.integers(30000, 150001))
+        kind_name = str(rng.choice(["normal", "reflective", "adapt", "ram"]))
     else:
         p = int(rng.integers(1, 8))
         n = int(rng.integers(513, 10241 if p <= 3 else (5121 if p <= 5 else 4097)))
@@ -1702,6 +1716,7 @@ def test_randomised_round4_regions_reached_their_kernels():
         assert _R4_PICKED["B"] == {"big-k"}, _R4_PICKED
         assert "logistic-sharded" in _R4_PICKED["C"], _R4_PICKED
         assert "spec" in _R4_PICKED["D"], _R4_PICKED
+        assert "long-sharded" in _R4_PICKED["E"], _R4_PICKED
 
 
 @pytest.mark.parametrize("kind_name", ["normal", "ram"])
