@@ -347,6 +347,8 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma_ad(const SweepArgs A) {
   const int cl = __builtin_amdgcn_readfirstlane((int)cg0 + myc);
   // KX < 0: the owners with their matrices in LDS (spec_owner_adaptive: any k <= 16, fixed parameters) -- 8 .. 15 covariates, or a
   // fixed parameter, beyond the wave-specialised kernel's range
+  // (measured and dropped at the end of round 4: the register-row owner with rows of 16 -- level at 8 .. 11 covariates, 15.0 against
+  //  15.3 us per step at n = 1e4, and 1.3 - 1.7x SLOWER at 12 .. 15, where four operand groups leave the rows no registers)
   if constexpr (KIND == FMCMC_KERNEL_NMIRROR || KIND == FMCMC_KERNEL_UMIRROR) mfma_owner_mirror<KIND>(A, myc, cl, s_th1, sync);
   else if constexpr (KX < 0) spec_owner_adaptive<KIND>(A, myc, cl, s_th1, s_par, sync, s_ad + myc * SPEC_ADS);
   else spec_owner_adaptive_reg<KIND, KX, decltype(sync), BND>(A, myc, cl, s_th1, sync);
