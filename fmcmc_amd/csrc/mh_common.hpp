@@ -783,6 +783,26 @@ __device__ __attribute__((noinline)) void shard_columns_mfma(ShardMfma c) {
 #undef SHM_LOAD_B
 #undef SHM_PIN
 
+// The slice product with the K-block count a compile-time constant where one exists (two / three M-tiles of two canonical lanes per
+// workgroup, 4 .. 16 K-blocks: p = 13 .. 64): config C4's width had it since round 2 (12 K-blocks: 25.4 -> 20.1 us per step); at the
+// other widths a tile ran the run-time loop -- p = 30, n = 1e4, 512 chains: 21.0 -> 17.5 us per step with KBC = 8.
+template <int LPW, int NMT>
+__device__ __forceinline__ void shard_mfma_dispatch(const ShardMfma& sm, int KB, int t10) {
+  if constexpr (LPW == 2 && (NMT == 2 || NMT == 3)) {
+    if (NMT == 3 && KB == 12 && t10) { shard_columns_mfma<2, 3, 12, true>(sm); return; }
+    switch (KB) {
+#define SHM_KB(K_) case K_: shard_columns_mfma<2, NMT, K_>(sm); return;
+      SHM_KB(4) SHM_KB(5) SHM_KB(6) SHM_KB(7) SHM_KB(8) SHM_KB(9) SHM_KB(10) SHM_KB(11) SHM_KB(12) SHM_KB(13) SHM_KB(14) SHM_KB(15) SHM_KB(16)
+#undef SHM_KB
+      default: break;
+    }
+  } else if constexpr (NMT == 3) {
+    if (KB == 12 && t10) { shard_columns_mfma<LPW, 3, 12, true>(sm); return; }
+    if (KB == 12) { shard_columns_mfma<LPW, 3, 12>(sm); return; }
+  }
+  shard_columns_mfma<LPW, NMT>(sm);
+}
+
 // ---- LONG-DATA form of the sharded evaluation (round 4; tools/dispatch_audit.py: four chains are ONE workgroup on the chain-sharded
 // kernels -- n = 1e5 observations took 34 us per step on one CU, 255 CUs idle).  Workgroup b owns the canonical lanes 2b, 2b + 1 as
 // in the other sharded forms, but its slice is long (n / 256 observations) and the chains are few: (a) all 512 threads compute the
@@ -932,15 +952,13 @@ __device__ __forceinline__ bool eval_sharded(const SweepArgs& A, double* const* 
     sm.th = A.sh_th; sm.part = A.sh_part; sm.NC = NC; sm.p = p; sm.ic = ic; sm.lane0 = (int)blockIdx.x * LPW; sm.tcount = 0;
     sm.ncp = NCP; sm.cstride = 1; sm.coff = 0; sm.thoff = 0; sm.tfirst = (int)(threadIdx.x >> 6); sm.tstep = NW;   // all chains, N-tiles round robin
     sm.lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const double*)s_mblk;
-    const bool kb12 = ((p + 3) >> 2) == 12;   // (config C4's width gets the instantiation with a compile-time K-block count)
+    const int KB = (p + 3) >> 2;
     if (A.sh_nmt == 1) shard_columns_mfma<LPW, 1>(sm);
-    else if (A.sh_nmt == 2) shard_columns_mfma<LPW, 2>(sm);
+    else if (A.sh_nmt == 2) shard_mfma_dispatch<LPW, 2>(sm, KB, 0);
     else if (A.sh_nmt == 4) shard_columns_mfma<LPW, 4>(sm);      // (slices of 41 .. 96 observations: 10,240 < n <= 24,576 at 256 workgroups)
     else if (A.sh_nmt == 5) shard_columns_mfma<LPW, 5>(sm);
     else if (A.sh_nmt == 6) shard_columns_mfma<LPW, 6>(sm);
-    else if (kb12 && A.sh_t10) shard_columns_mfma<LPW, 3, 12, true>(sm);
-    else if (kb12) shard_columns_mfma<LPW, 3, 12>(sm);
-    else shard_columns_mfma<LPW, 3>(sm);
+    else shard_mfma_dispatch<LPW, 3>(sm, KB, A.sh_t10);
   } else
   if (A.sh_nslots * LPW <= SH_MAXO / 2) shard_columns<LPW, SH_MAXO / 2>(sc);   // half-empty slices: half the FMAs
   else shard_columns<LPW, SH_MAXO>(sc);

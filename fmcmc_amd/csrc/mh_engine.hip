@@ -460,7 +460,7 @@ static int wide_sharded_lanes(const Knobs& K, const fmcmc_model* m, const fmcmc_
     const double rounds = (double)((run->nchains + (long long)cw_now * ncu - 1) / ((long long)cw_now * ncu));
     const double launches = (double)((run->nchains + per_launch - 1) / per_launch);
     const double est_chain = (4.0 + (double)m->n * (double)m->p * 8.0 / 65000.0 * (cw_now >= 8 ? 2.4 : (cw_now == 4 ? 1.3 : 1.0)) +
-                              (ram ? 0.075 * (double)kn->k * (double)(cw_now < 2 ? 2 : cw_now) : 0.0)) * rounds;
+                              (ram ? (cw_now <= 2 ? 0.12 : 0.075 * (double)cw_now) * (double)kn->k : 0.0)) * rounds;
     const double frac = (double)(run->nchains < per_launch ? run->nchains : per_launch) / 512.0;
     double est_shard;
     if (shard_mfma_enabled(K) && m->p <= 4 * SHM_KBMAX) {
@@ -468,8 +468,14 @@ static int wide_sharded_lanes(const Knobs& K, const fmcmc_model* m, const fmcmc_
       //  than 256 chains, at most three M-tiles --, else ~0.17 us per parameter for few chains, ~0.3 in full launches)
       const bool tall = lpw * nslots > SH_MAXO;
       const bool hidden = ram && run->nchains > 256 && !tall;
-      est_shard = 9.3 + (tall ? 5.0 : 0.0) + frac * (3.2 + (double)m->p * (0.08 + 0.00475 * (double)(lpw * nslots))) +
+      // (refitted once more after the compile-time K-block counts of every width: 9.7 + p (0.083 + 0.004 slice observations) per 512
+      //  chains at up to three M-tiles; the dataflow form's kernel_ram runs ~2 us UNDER the normal kernels' sequential form)
+      est_shard = 9.3 + (tall ? 5.0 : 0.0) + frac * ((tall ? 3.2 : 0.4) + (double)m->p * ((tall ? 0.08 : 0.083) + (tall ? 0.00475 : 0.004) * (double)(lpw * nslots))) +
                   ((ram && !hidden) ? (run->nchains <= 256 ? 0.17 : 0.3) * (double)kn->k : 0.0);
+      if (hidden) {   // (what the dataflow form hides is at most a quarter of its slice product)
+        const double prod = frac * (0.4 + (double)m->p * (0.083 + 0.004 * (double)(lpw * nslots)));
+        est_shard -= (prod * 0.25 < 2.0 * frac) ? prod * 0.25 : 2.0 * frac;
+      }
     }
     else {
       const double walked = (cached ? 1.0 : 2.1) * ((lpw * nslots <= SH_MAXO / 2) ? SH_MAXO / 2 : SH_MAXO);

@@ -302,10 +302,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
         //  18.8 us per step against 18.5; the pairs drift apart by themselves)
         if (Ng > 0) {
           sm.NC = Ng; sm.coff = g; sm.thoff = g * NH;
-          if (NMT == 3 && ((p + 3) >> 2) == 12) {              // (C4's width: compile-time K-block count)
-            if (t10) shard_columns_mfma<2, NMT, (NMT == 3 ? 12 : 0), NMT == 3>(sm);   // (and its 10 values per lane group)
-            else shard_columns_mfma<2, NMT, (NMT == 3 ? 12 : 0)>(sm);
-          } else shard_columns_mfma<2, NMT>(sm);
+          shard_mfma_dispatch<2, NMT>(sm, (p + 3) >> 2, t10);    // (compile-time K-block counts; C4's width with its 10 values per lane group)
         }
         W2_EV_STAMP(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's partials have been acknowledged
