@@ -784,12 +784,14 @@ __device__ __attribute__((noinline)) void shard_columns_mfma(ShardMfma c) {
 #undef SHM_PIN
 
 // The slice product with the K-block count a compile-time constant where one exists (two / three M-tiles of two canonical lanes per
-// workgroup, 4 .. 16 K-blocks: p = 13 .. 64): config C4's width had it since round 2 (12 K-blocks: 25.4 -> 20.1 us per step); at the
+// workgroup -- up to six beyond n = 10,240 --, 4 .. 16 K-blocks: p = 13 .. 64): config C4's width had it since round 2 (12 K-blocks: 25.4 -> 20.1 us per step); at the
 // other widths a tile ran the run-time loop -- p = 30, n = 1e4, 512 chains: 21.0 -> 17.5 us per step with KBC = 8.
 template <int LPW, int NMT>
 __device__ __forceinline__ void shard_mfma_dispatch(const ShardMfma& sm, int KB, int t10) {
-  if constexpr (LPW == 2 && (NMT == 2 || NMT == 3)) {
+  if constexpr (LPW == 2 && NMT >= 2) {
     if (NMT == 3 && KB == 12 && t10) { shard_columns_mfma<2, 3, 12, true>(sm); return; }
+    // (four to six M-tiles: up to 12 K-blocks -- beyond, the unrolled tile spills: p = 60, n = 2e4, 64 chains 16.4 -> 25.6 us per step)
+    if (NMT <= 3 || KB <= 12)
     switch (KB) {
 #define SHM_KB(K_) case K_: shard_columns_mfma<2, NMT, K_>(sm); return;
       SHM_KB(4) SHM_KB(5) SHM_KB(6) SHM_KB(7) SHM_KB(8) SHM_KB(9) SHM_KB(10) SHM_KB(11) SHM_KB(12) SHM_KB(13) SHM_KB(14) SHM_KB(15) SHM_KB(16)
@@ -955,9 +957,9 @@ __device__ __forceinline__ bool eval_sharded(const SweepArgs& A, double* const* 
     const int KB = (p + 3) >> 2;
     if (A.sh_nmt == 1) shard_columns_mfma<LPW, 1>(sm);
     else if (A.sh_nmt == 2) shard_mfma_dispatch<LPW, 2>(sm, KB, 0);
-    else if (A.sh_nmt == 4) shard_columns_mfma<LPW, 4>(sm);      // (slices of 41 .. 96 observations: 10,240 < n <= 24,576 at 256 workgroups)
-    else if (A.sh_nmt == 5) shard_columns_mfma<LPW, 5>(sm);
-    else if (A.sh_nmt == 6) shard_columns_mfma<LPW, 6>(sm);
+    else if (A.sh_nmt == 4) shard_mfma_dispatch<LPW, 4>(sm, KB, 0);      // (slices of 41 .. 96 observations: 10,240 < n <= 24,576 at 256 workgroups)
+    else if (A.sh_nmt == 5) shard_mfma_dispatch<LPW, 5>(sm, KB, 0);
+    else if (A.sh_nmt == 6) shard_mfma_dispatch<LPW, 6>(sm, KB, 0);
     else shard_mfma_dispatch<LPW, 3>(sm, KB, A.sh_t10);
   } else
   if (A.sh_nslots * LPW <= SH_MAXO / 2) shard_columns<LPW, SH_MAXO / 2>(sc);   // half-empty slices: half the FMAs

@@ -468,9 +468,10 @@ static int wide_sharded_lanes(const Knobs& K, const fmcmc_model* m, const fmcmc_
       //  than 256 chains, at most three M-tiles --, else ~0.17 us per parameter for few chains, ~0.3 in full launches)
       const bool tall = lpw * nslots > SH_MAXO;
       const bool hidden = ram && run->nchains > 256 && !tall;
-      // (refitted once more after the compile-time K-block counts of every width: 9.7 + p (0.083 + 0.004 slice observations) per 512
+      // (refitted once more after the compile-time K-block counts of every width: ~10 of hand-overs, 0.4 + p (0.083 + 0.004 slice observations) per 512
       //  chains at up to three M-tiles; the dataflow form's kernel_ram runs ~2 us UNDER the normal kernels' sequential form)
-      est_shard = 9.3 + (tall ? 5.0 : 0.0) + frac * ((tall ? 3.2 : 0.4) + (double)m->p * ((tall ? 0.08 : 0.083) + (tall ? 0.00475 : 0.004) * (double)(lpw * nslots))) +
+      const bool tall_rt = tall && (m->p + 3) / 4 > 12;     // (tall slices beyond 12 K-blocks keep the run-time loop: ~5 us more)
+      est_shard = 10.2 + (tall_rt ? 5.0 : 0.0) + frac * ((tall ? 0.6 : 0.4) + (double)m->p * ((tall ? 0.08 : 0.083) + (tall ? 0.00475 : 0.004) * (double)(lpw * nslots))) +
                   ((ram && !hidden) ? (run->nchains <= 256 ? 0.17 : 0.3) * (double)kn->k : 0.0);
       if (hidden) {   // (what the dataflow form hides is at most a quarter of its slice product)
         const double prod = frac * (0.4 + (double)m->p * (0.083 + 0.004 * (double)(lpw * nslots)));
