@@ -1,41 +1,97 @@
-"""Builds the HIP engine in-tree: fmcmc_amd/lib/libfmcmc_amd.so (gfx950 only)."""
+"""Builds the HIP engine in-tree: fmcmc_amd/lib/libfmcmc_amd.so (gfx950 only).
+
+The library is several translation units (csrc/mh_engine.hip = C-ABI + kernel selection, csrc/k_*.hip = one kernel family
+each, csrc/gelman.hip) compiled in parallel into build/*.o and linked by hipcc; only the units whose sources changed are
+recompiled."""
+import concurrent.futures
+import glob
 import os
 import subprocess
+import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = [os.path.join(HERE, "csrc", "mh_engine.hip"), os.path.join(HERE, "csrc", "gelman.hip")]
-DEPS = [os.path.join(ROOT, "include", f) for f in ("fmcmc_amd.h", "fmh_detmath.h", "fmh_philox.h")] + \
-       [os.path.join(HERE, "csrc", f) for f in ("mh_common.hpp", "mh_streamed.hpp", "mh_pipe.hpp", "mh_mfma.hpp", "mh_mfma_rep.hpp", "mh_spec.hpp", "mh_wide2.hpp", "mh_mfma_ad.hpp", "mh_bigk.hpp")] + \
-       [os.path.join(ROOT, "include", "fmh_logit_tab.h")]
+CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libfmcmc_amd.so")
+OBJDIR = os.path.join(HERE, "build")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-Wno-unused-value", "-Wno-unused-result"]
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def deps():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hpp"))) + sorted(glob.glob(os.path.join(ROOT, "include", "*.h")))
+
+
+def unit_deps(src, _seen=None):
+    """the files a translation unit includes (quoted includes, followed recursively)"""
+    import re
+    seen = _seen if _seen is not None else set()
+    for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(src).read(), flags=re.M):
+        f = os.path.normpath(os.path.join(os.path.dirname(src), inc))
+        if os.path.exists(f) and f not in seen:
+            seen.add(f)
+            unit_deps(f, seen)
+    return seen
 
 
 def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    return any(os.path.exists(f) and os.path.getmtime(f) > t for f in SRC + DEPS)
+    return any(os.path.getmtime(f) > t for f in sources() + deps())
 
 
-def build(force=False, verbose=False, extra_flags=(), out=None):
-    """extra_flags / out: diagnostic variants next to the product library, loaded through FMCMC_AMD_LIB: -DFMCMC_STAMP ->
-    lib/libfmcmc_amd_stamp.so (tools/stamp_wide.py); -DFMCMC_AB -> lib/libfmcmc_amd_ab.so, which also carries the A/B partners
-    of the product kernels (mh_sweep_pipe, mh_sweep_mfmar, the stamped MFMA instantiations: knobs spec=0 / owners=0 / mode=8)."""
+def _compile(src, obj, flags, verbose):
+    cmd = [HIPCC] + flags + ["-c", src, "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    t0 = time.time()
+    subprocess.check_call(cmd)
+    return os.path.basename(src), time.time() - t0
+
+
+def build(force=False, verbose=False, extra_flags=(), out=None, jobs=None):
+    """extra_flags / out: diagnostic variants next to the product library, loaded through FMCMC_AMD_LIB (e.g. -DFMCMC_STAMP ->
+    lib/libfmcmc_amd_stamp.so, tools/stamp_wide.py); their objects go to build/<name of out>/.  Returns the library path;
+    build.last_times holds the compile seconds per translation unit of the last call."""
     out = out or OUT
     if not force and not extra_flags and not needs_build():
         return out
+    variant = "" if out == OUT else os.path.splitext(os.path.basename(out))[0]
+    objdir = os.path.join(OBJDIR, variant) if variant else OBJDIR
+    os.makedirs(objdir, exist_ok=True)
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    src = [s for s in SRC if os.path.exists(s)]
-    cmd = [HIPCC] + FLAGS + list(extra_flags) + src + ["-o", out]
+    flags = FLAGS + list(extra_flags)
+    todo, objs = [], []
+    for src in sources():
+        obj = os.path.join(objdir, os.path.splitext(os.path.basename(src))[0] + ".o")
+        objs.append(obj)
+        dep_t = max(os.path.getmtime(f) for f in [src] + sorted(unit_deps(src)))
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < dep_t:
+            todo.append((src, obj))
+    jobs = jobs or int(os.environ.get("FMCMC_BUILD_JOBS", "0")) or min(8, os.cpu_count() or 1)
+    t0 = time.time()
+    times = {}
+    with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as ex:
+        for name, dt in ex.map(lambda so: _compile(so[0], so[1], flags, verbose), todo):
+            times[name] = dt
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    times["_wall"] = time.time() - t0
+    build.last_times = times
+    if verbose:
+        print("compile seconds per unit:", {k: round(v, 1) for k, v in sorted(times.items())}, flush=True)
     return out
 
+
+build.last_times = {}
 
 if __name__ == "__main__":
     build(force=True, verbose=True)

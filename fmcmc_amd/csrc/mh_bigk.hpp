@@ -22,6 +22,7 @@ __host__ __device__ inline size_t bigk_lds_doubles(int k, int kf, int kind) {
          2 * (size_t)k /* th0, th1 */ + 8 * (size_t)kf /* vectors */ + 2 * (size_t)kf /* scan buffers */ + mats + 4;
 }
 
+#ifdef FMH_WITH_BIGK_KERNEL   /* compiled into k_wide2.hip only; the engine takes bigk_lds_doubles above */
 __global__ __launch_bounds__(NT) void mh_sweep_bigk(const SweepArgs A0) {
   SweepArgs A = A0;
   extern __shared__ double smem[];
@@ -346,5 +347,6 @@ __global__ __launch_bounds__(NT) void mh_sweep_bigk(const SweepArgs A0) {
     if (adapt && row) A.mean_prev[cl * kf + r] = vmp[r];
   }
 }
+#endif  // FMH_WITH_BIGK_KERNEL
 
 }  // namespace

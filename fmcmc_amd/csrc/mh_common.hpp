@@ -74,6 +74,7 @@ struct SweepArgs {
   const double* mf_stream;   // mh_sweep_mfma<.., EXT>: the observation slots beyond the operand registers, in operand order (mfma_build_stream)
   int mf_next;               //                          their number
   int spec_opt;              // mh_sweep_spec: observation slots per lane of this launch, rounded up to even (<= the instantiation's OPTMAX)
+  int spec_cw;               // mh_sweep_spec: chains per workgroup of this launch: 4, or 2 / 1 (the latency form for few chains per GPU)
   // state
   double* theta0;
   double* f0;

@@ -1,9 +1,11 @@
 // mh_engine.hip — gfx950 (MI355X) many-chain Metropolis-Hastings engine: the C-ABI (include/fmcmc_amd.h), validation,
-// kernel selection and launches.  The device code lives in the headers included below (one translation unit):
+// kernel selection and launches.  The sweep kernels are instantiated in the k_*.hip translation units (compiled in parallel,
+// fmcmc_amd/build.py) and reached through the look-ups of mh_kernels.hpp; their source is in the headers:
 //   mh_common.hpp  shared device helpers      mh_streamed.hpp  general kernel (all families / kernels / schemes)
-//   mh_pipe.hpp    RNG stream + pipelined VALU kernel   mh_mfma.hpp  fp64-MFMA kernel, owner waves (headline)
-//   mh_mfma_rep.hpp  fp64-MFMA kernel, replicated chain state   mh_spec.hpp  wave-specialised kernel
-//   mh_wide2.hpp  wide models: observation-sharded dataflow kernel (owner / evaluator waves, two chain groups)
+//   mh_rng.hpp     RNG stream kernel          mh_mfma.hpp      fp64-MFMA kernel, owner waves (headline)
+//   mh_spec.hpp    wave-specialised kernel (kernel_adapt / kernel_ram; the latency form for few chains)
+//   mh_wide2.hpp   wide models: observation-sharded dataflow kernel (owner / evaluator waves, two chain groups)
+//   mh_mfma_ad.hpp adaptive owners on the MFMA evaluation   mh_bigk.hpp  more than 64 parameters
 //
 // Replaces, for ALL chains of a call at once, the per-chain loop of the reference
 //   R/mcmc.R:720-838 (loop, accept, burn-in/thin)  x  R/kernel_normal.R / R/kernel_adapt.R /
@@ -22,28 +24,12 @@
 //   * RNG = Philox4x32-10 counter stream (include/fmh_philox.h) or host-fed variates.
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (explicit fma only).
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <string.h>
-#include <stdio.h>
-#include <stdarg.h>
-#include <stdlib.h>
-#include <math.h>
-#include <float.h>
+#define FMH_WITH_RNG_FILL
+#include "mh_tu.hpp"
 #include <vector>
-#include <type_traits>
-
-#include "../../include/fmcmc_amd.h"
-#include "../../include/fmh_detmath.h"
-#include "../../include/fmh_philox.h"
-
-#include "mh_common.hpp"
+// (host-side shape helpers of the kernel families -- LDS sizes, slot counts; their kernels are instantiated in the k_*.hip files)
 #include "mh_streamed.hpp"
-#include "mh_pipe.hpp"
 #include "mh_mfma.hpp"
-#ifdef FMCMC_AB   /* A/B partners of the product kernels (tools/, -DFMCMC_AB builds): not in libfmcmc_amd.so */
-#include "mh_mfma_rep.hpp"
-#endif
 #include "mh_spec.hpp"
 #include "mh_wide2.hpp"
 #include "mh_mfma_ad.hpp"
@@ -399,8 +385,8 @@ static SweepArgs chain_window(const SweepArgs& A, long long off, long long cnt, 
 // ---- diagnosis knobs: ONE environment variable, read once per call --------------------------------------------------------
 //   FMCMC_AMD_DEBUG="key=value,key=value"   (unset = product behaviour; nothing else in the environment is looked at)
 //   streamed=1   general streamed kernel for everything          cw=1|2|4|8  chains per workgroup of the streamed kernels
-//   pipe=0       no materialised-stream kernels (mfma/spec/pipe)  spec=0      mh_sweep_pipe instead of mh_sweep_spec
-//   mfma=0       VALU evaluation instead of the fp64-MFMA kernels owners=0|1  replicated-state / owner-wave MFMA kernel
+//   pipe=0       no materialised-stream kernels (mfma / spec)      lat=0|1|2|3 latency form of mh_sweep_spec: off / chains per workgroup
+//   mfma=0       VALU evaluation instead of the fp64-MFMA kernels
 //   shard=0|1    wide models: never / always (when eligible) observation-sharded; unset: cost model
 //   shard_mfma=0 VALU form of the sharded slice product           wide2=0|1   never / always (when eligible) the dataflow form
 //   groups=4     four chain groups in the dataflow form (default two)       tiles=0     even N-tile shares of its evaluator waves
@@ -409,14 +395,14 @@ static SweepArgs chain_window(const SweepArgs& A, long long off, long long cnt, 
 //   mode=<bits>  timing ablations and stamps (SweepArgs.debug)
 // The kernel a call ended up on is reported by fmcmc_last_kernel(); DESIGN.md section 5 has the shape -> kernel table.
 struct Knobs {
-  int streamed = -1, cw = -1, pipe = -1, spec = -1, mfma = -1, owners = -1, shard = -1, shard_mfma = -1, wide2 = -1, groups = -1, tiles = -1, t10 = -1, window = -1, mode = 0;
+  int streamed = -1, cw = -1, pipe = -1, lat = -1, mfma = -1, shard = -1, shard_mfma = -1, wide2 = -1, groups = -1, tiles = -1, t10 = -1, window = -1, mode = 0;
 };
 static Knobs read_knobs() {
   Knobs K;
   const char* e = getenv("FMCMC_AMD_DEBUG");
   if (!e) return K;
-  struct { const char* name; int* dst; } tab[] = {{"streamed", &K.streamed}, {"cw", &K.cw}, {"pipe", &K.pipe}, {"spec", &K.spec},
-      {"mfma", &K.mfma}, {"owners", &K.owners}, {"shard_mfma", &K.shard_mfma}, {"shard", &K.shard}, {"wide2", &K.wide2}, {"groups", &K.groups}, {"tiles", &K.tiles}, {"t10", &K.t10}, {"window", &K.window}, {"mode", &K.mode}};
+  struct { const char* name; int* dst; } tab[] = {{"streamed", &K.streamed}, {"cw", &K.cw}, {"pipe", &K.pipe}, {"lat", &K.lat},
+      {"mfma", &K.mfma}, {"shard_mfma", &K.shard_mfma}, {"shard", &K.shard}, {"wide2", &K.wide2}, {"groups", &K.groups}, {"tiles", &K.tiles}, {"t10", &K.t10}, {"window", &K.window}, {"mode", &K.mode}};
   while (*e) {
     const char* eq = strchr(e, '=');
     const char* end = strchr(e, ',');
@@ -496,6 +482,17 @@ struct AsyncScratch {
   hipStream_t s = nullptr;
   ~AsyncScratch() { if (p) (void)hipFreeAsync(p, s); }
 };
+
+// launch of a kernel handle (mh_kernels.hpp): every sweep kernel takes the launch's SweepArgs by value
+static hipError_t launch_k(const void* kfn, long long grid, int block, size_t lds, hipStream_t stream, const SweepArgs& A) {
+  if (!kfn) return hipErrorInvalidDeviceFunction;
+  if (lds > 48 * 1024) {
+    const hipError_t ea = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (ea != hipSuccess) return ea;
+  }
+  void* kargs[] = {(void*)&A};
+  return hipLaunchKernel(kfn, dim3((unsigned)grid), dim3((unsigned)block), kargs, lds, stream);
+}
 
 // kernel->fixed etc. are DEVICE pointers here; kf and bounds info come via `kf`/`ram_bounded`.
 static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, const fmcmc_run* run,
@@ -587,12 +584,9 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
   if (kn->k > FMCMC_MAX_K_WAVE) {
     const size_t blds = sizeof(double) * bigk_lds_doubles(kn->k, kf, kn->kind);
     if (blds > 160 * 1024) { set_err("LDS budget exceeded (k=%d)", kn->k); return FMCMC_ERR_UNSUPPORTED; }
-    hipError_t eb = hipFuncSetAttribute((const void*)mh_sweep_bigk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds);
-    if (eb == hipSuccess) {
-      g_kernel = "big-k";
-      hipLaunchKernelGGL(mh_sweep_bigk, dim3((unsigned)run->nchains), dim3(NT), blds, stream, A);
-      eb = hipGetLastError();
-    }
+    g_kernel = "big-k";
+    hipError_t eb = launch_k(fmh::k_bigk(), run->nchains, NT, blds, stream, A);
+    if (eb == hipSuccess) eb = hipGetLastError();
     if (eb != hipSuccess) { set_err("HIP launch failed: %s", hipGetErrorString(eb)); return FMCMC_ERR_DEVICE; }
     return FMCMC_OK;
   }
@@ -634,32 +628,13 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
   if (lds > 160 * 1024) { set_err("LDS budget exceeded (k=%d)", kn->k); return FMCMC_ERR_UNSUPPORTED; }
   const long long nblk = (run->nchains + cw - 1) / cw;
   hipError_t e = hipSuccess;
-#define LAUNCH(CWV, PV, OV, KV)                                                                      \
-  do {                                                                                               \
-    if (lds > 48 * 1024)                                                                             \
-      e = hipFuncSetAttribute((const void*)mh_sweep_kernel<CWV, PV, OV, KV>,                        \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
-    if (e == hipSuccess)                                                                             \
-      hipLaunchKernelGGL((mh_sweep_kernel<CWV, PV, OV, KV>), dim3((unsigned)nblk), dim3(NT), lds, stream, A); \
-  } while (0)
-#define LAUNCH_KIND(CWV, PV, OV)                                                                     \
-  switch (kn->kind) {                                                                                \
-    case FMCMC_KERNEL_NORMAL: LAUNCH(CWV, PV, OV, 1); break;                                         \
-    case FMCMC_KERNEL_NORMAL_REFLECTIVE: LAUNCH(CWV, PV, OV, 2); break;                              \
-    case FMCMC_KERNEL_ADAPT: LAUNCH(CWV, PV, OV, 3); break;                                          \
-    default: LAUNCH(CWV, PV, OV, 4); break;                                                          \
-  }
   // software-pipelined fast path: normal kernels, joint scheme, k <= 16, linreg data in registers
-#ifdef FMCMC_AB
-  const bool nopipe = K.pipe == 0, nospec = K.spec == 0;
-#else
-  const bool nopipe = K.pipe == 0, nospec = false;   // (spec=0 / owners=0 select kernels that only -DFMCMC_AB builds carry)
-#endif
-  int pipe_opt = 0, mfma_ng = 0, mfma_ad = 0, mfma_ext = 0;   // mfma_ext: resident slots of the EXT form (0: everything resident)
+  const bool nopipe = K.pipe == 0;
+  int pipe_opt = 0, mfma_ng = 0, mfma_ad = 0, mfma_ext = 0, spec_cw = 4;   // mfma_ext: resident slots of the EXT form (0: everything resident)
   AsyncScratch mfs_guard;
   if (!force && !nopipe && m->family == FMCMC_FAM_GAUSSIAN_LINREG &&
       (kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE ||
-       (((kn->kind == FMCMC_KERNEL_ADAPT && !adapt_hist) || (kn->kind == FMCMC_KERNEL_RAM && !kn->constr)) && !nospec) ||
+       ((kn->kind == FMCMC_KERNEL_ADAPT && !adapt_hist) || (kn->kind == FMCMC_KERNEL_RAM && !kn->constr)) ||
        (mirror && kn->scheme == FMCMC_SCHEME_JOINT && kf == kn->k && K.mfma != 0)) &&
       (kn->scheme == FMCMC_SCHEME_JOINT || kn->kind == FMCMC_KERNEL_ADAPT || kn->kind == FMCMC_KERNEL_RAM) && kn->k <= PIPE_KMAX &&
       // Sizes (round 3: rows and variates are addressed as 64-bit chain base + 32-bit offset, and a long call of the normal /
@@ -727,8 +702,25 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
       pipe_opt = 0; mfma_ng = 0;
       if (m->p <= 15 && m->n > NT && m->n < (1ll << 29)) { mfma_ad = 3; mfma_ng = ng; mfma_ext = (m->n > (long long)NT * nsr) ? nsr : 1; }
     }
+    // ---- the LATENCY form (round 5): fewer than four chains per compute unit.  The reference scales a FIXED number of chains
+    // over its workers (R/mcmc.R:536-641), and a sharded call leaves every GPU nchains / G of them: with four chains per
+    // workgroup a step of C2's shape costs the same 2 us at 64 chains and at 1024.  Here the wave-specialised kernel runs one,
+    // two or three chains per workgroup -- all eight compute waves on the chain(s) there are (an evaluation of n = 10,000 is
+    // 0.33 us of one CU's fp64 issue), no owner queued behind the evaluation of other chains -- for every shape its compute
+    // lanes hold in registers, the normal / uniform kernels included (with four chains per workgroup those stay on the MFMA
+    // kernel).  Same canonical lanes and tree: the bits do not depend on the form.  Knob lat=0: off; lat=1|2|3: forced.
+    if (K.lat != 0 && !mirror && (pipe_opt || (mfma_ng && !mfma_ext && !mfma_ad))) {
+      const long long per_cu = (run->nchains + ncu - 1) / ncu;
+      const int lcw = (K.lat >= 1 && K.lat <= 3) ? K.lat : (per_cu <= 3 ? (int)per_cu : 4);
+      const long long nsl2 = (((m->n + NT - 1) / NT) + 1) & ~1ll;
+      if (lcw < 4 && m->p >= 1 && nsl2 <= fmh::k_spec_optmax(m->p, kn->kind)) {
+        if (kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE) { pipe_opt = (int)nsl2; mfma_ng = 0; }
+        if (pipe_opt && !mfma_ng) spec_cw = lcw;
+      }
+    }
   }
   A.spec_opt = pipe_opt;
+  A.spec_cw = spec_cw;
   // ---- the LONG-DATA form (mh_common.hpp, shard_long): few chains on long data.  Up to four chains are one workgroup of the
   // chain-sharded kernels, i.e. ONE compute unit walks the whole data set per step (n = 1e5, p = 3: 34 us per step, 255 CUs idle);
   // here all 256 workgroups evaluate their 1/256 of the observations for every chain and the canonical lane sums cross the chip as
@@ -772,7 +764,11 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
     void* kargs[] = {(void*)&W};
     hipError_t ec = hipLaunchCooperativeKernel(kfn, dim3(256), dim3(NT), kargs, (unsigned int)llds, stream);
     if (ec == hipSuccess) { launched_long = true; g_kernel = "long-sharded"; }
-    else (void)hipGetLastError();     // the runtime refused the cooperative launch: nothing ran, take the usual kernels
+    else {                            // the runtime refused the cooperative launch: nothing ran, take the usual kernels
+      (void)hipGetLastError();
+      (void)hipFreeAsync(shw, stream);   // (the paths below put their own block into shw_guard)
+      shw_guard.p = nullptr;
+    }
     return FMCMC_OK;
   };
   // (wide linear models, p >= 16: where the matrix-core slices end -- 96 observations per workgroup, n = 24,576 -- the chain-sharded
@@ -782,19 +778,13 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
     const double now_rate = (m->p <= 3) ? (pn <= 2e5 ? 3.3e-4 : 5.1e-4) : (m->p <= 7 ? 5.4e-4 : (m->p <= 11 ? 8.5e-4 : 1.17e-3));
     const double est_now = (m->p >= 16) ? 4.0 + pn * (double)m->p * 8.0 / 65000.0
                          : (m->n <= (long long)NT * (m->p <= 3 ? 20 : (m->p <= 7 ? 10 : 0)) ? 2.2 : now_rate * pn) + (kn->kind >= FMCMC_KERNEL_ADAPT ? 2.0 : 0.0);
-    const int kvl = kn->kind;
-    const void* kfn = (kvl == 1) ? (const void*)mh_sweep_kernel<1, -1, 2, 1, FMCMC_FAM_GAUSSIAN_LINREG>
-                    : (kvl == 2) ? (const void*)mh_sweep_kernel<1, -1, 2, 2, FMCMC_FAM_GAUSSIAN_LINREG>
-                    : (kvl == 3) ? (const void*)mh_sweep_kernel<1, -1, 2, 3, FMCMC_FAM_GAUSSIAN_LINREG>
-                                 : (const void*)mh_sweep_kernel<1, -1, 2, 4, FMCMC_FAM_GAUSSIAN_LINREG>;
+    const void* kfn = fmh::k_wide(1, 2, kn->kind);       // (the long-data form: one chain per workgroup, every proposal kernel)
     const int rcl = try_long(kfn, lds, est_now, false);
     if (rcl != FMCMC_OK) return rcl;
   }
   if (launched_long) {
   } else
   if (pipe_opt || mfma_ng) {
-    const size_t plds = pipe_opt ? pipe_lds_bytes(pipe_opt) : 0;
-    const long long pblk = (run->nchains + 3) / 4;
     double* ws = nullptr;
     const double fill_df = (kn->kind == FMCMC_KERNEL_RAM) ? A.ram_df : (A.variate == 1 ? -1.0 : 0.0);
     // Step windows: the normal / uniform kernels with the library's own stream.  Window 0 is an ordinary launch of the call's
@@ -806,12 +796,7 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
     // 80 operand registers and one extra evaluation, so the buffer is as large as is reasonable, not cache-sized).  The Philox counter
     // is the ABSOLUTE step, so the variates, and with them every bit of the output, do not depend on the cut
     // (windows begin behind a step = 1 mod 32: the accept bitmap's words then line up).
-#ifdef FMCMC_AB
-    const bool ab_partner = (K.spec == 0 || K.owners == 0);   // (the A/B partner kernels know nothing of windows)
-#else
-    const bool ab_partner = false;
-#endif
-    const bool windowed = A.rng_mode == FMCMC_RNG_PHILOX && kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE && !ab_partner;
+    const bool windowed = A.rng_mode == FMCMC_RNG_PHILOX && kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE;
     long long win = run->nsteps;
     if (windowed) {
       const long long per_step = (long long)run->nchains * (A.kz + 1) * 8;
@@ -847,146 +832,36 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
       W.fed_z = ws + items;
       W.rng_mode = FMCMC_RNG_FED;
     };
-    auto launch_fast = [&](const SweepArgs& A) {   // (shadows the call's arguments: the launch macros below name `A`)
-#ifdef FMCMC_AB
-#define LAUNCH_PIPE(PV, OV, KV)                                                                        \
-    do {                                                                                               \
-      if (plds > 48 * 1024)                                                                            \
-        e = hipFuncSetAttribute((const void*)mh_sweep_pipe<PV, OV, KV>,                               \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);                \
-      if (e == hipSuccess)                                                                             \
-        hipLaunchKernelGGL((mh_sweep_pipe<PV, OV, KV>), dim3((unsigned)pblk), dim3(NT), plds, stream, A); \
-    } while (0)
-#endif
-    g_kernel = mfma_ng ? "mfma" : !nospec ? "spec" : "pipe";
-    if (mfma_ng) {
-      // Two MFMA kernels with identical results.  mh_sweep_mfma (owner waves) is the product path for every shape;
-      // mh_sweep_mfmar (chain state replicated in every wave, one barrier per step) was 2-10 % ahead below n = 8192
-      // until the owner phase of mh_sweep_mfma went through the same instruction diet, and is 1-7 % behind since
-      // (tools/bench_shapes_ab.py).  It is compiled into -DFMCMC_AB builds only (n > 8192, p <= 3, non-reflective
-      // kernels: knob owners=0, tools/exp_mfmar.hip), as the A/B partner and as a second implementation the parity tests
-      // compare when they run against such a build.
-      const int ns = (int)((m->n + NT - 1) / NT);   // observation slots of 512
-      const int kv = (kn->kind == FMCMC_KERNEL_NORMAL) ? 1 : 2;
-#ifdef FMCMC_AB
-      const bool owners = !(K.owners == 0 && kv == 1 && mfma_ng == 1 && ns > 16);
-      const size_t mlds = owners ? mfma_lds_bytes() : mfmar_lds_bytes();
-#else
-      const bool owners = true;
-      const size_t mlds = mfma_lds_bytes();
-#endif
-      if (!owners) g_kernel = "mfma-replicated";
-      const bool dbgk = (A.debug & 8) != 0 && mfma_ng == 1 && ns == 20; (void)dbgk;
-      // (offsets from the buffer bases stay 32 bits -- the cheaper form, see mh_sweep_mfma's BIG -- while the samples of all chains
-      //  and the stream of this launch stay below 4 GiB)
-      const bool big = (unsigned long long)A.nchains * kn->k * (unsigned long long)A.ldS * 8ull >= (1ull << 32) ||
-                       (unsigned long long)A.nchains * (unsigned long long)A.nsteps * (unsigned long long)A.kz * 8ull >= (1ull << 32);
-#define MF_CASE(KN, KV, GV, SV) case SV: if (big) hipLaunchKernelGGL((KN<KV, GV, SV, false, true>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A); \
-                                         else hipLaunchKernelGGL((KN<KV, GV, SV, false, false>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A); break;
-#define MF_CASE_AB(KN, KV, GV, SV) case SV: hipLaunchKernelGGL((KN<KV, GV, SV, false>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A); break;
-#define MF_CASES10(KN, KV, GV) MF_CASE(KN, KV, GV, 1) MF_CASE(KN, KV, GV, 2) MF_CASE(KN, KV, GV, 3) MF_CASE(KN, KV, GV, 4) MF_CASE(KN, KV, GV, 5) \
-                               MF_CASE(KN, KV, GV, 6) MF_CASE(KN, KV, GV, 7) MF_CASE(KN, KV, GV, 8) MF_CASE(KN, KV, GV, 9) MF_CASE(KN, KV, GV, 10)
-#define MF_CASES16(KN, KV, GV) MF_CASES10(KN, KV, GV) MF_CASE(KN, KV, GV, 11) MF_CASE(KN, KV, GV, 12) MF_CASE(KN, KV, GV, 13) \
-                               MF_CASE(KN, KV, GV, 14) MF_CASE(KN, KV, GV, 15) MF_CASE(KN, KV, GV, 16)
-#define MF_CASES17(KN, KV, GV) MF_CASE(KN, KV, GV, 17) MF_CASE(KN, KV, GV, 18) MF_CASE(KN, KV, GV, 19) MF_CASE(KN, KV, GV, 20)
-      if (mfma_ad) {
-        g_kernel = "mfma-adaptive";
-        const size_t alds = mfma_ad_lds_bytes(mfma_ad == 2);
-        const bool ad_short = mfma_ext == 1;    // (short data: one resident slot)
-#define MF_AD(GV, XV) do { if (kn->kind == FMCMC_KERNEL_ADAPT && ad_short && GV == 1 && XV == 0) hipLaunchKernelGGL((mh_sweep_mfma_ad<3, 1, 0, false, 1>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); \
-                           else if (kn->kind == FMCMC_KERNEL_ADAPT) hipLaunchKernelGGL((mh_sweep_mfma_ad<3, GV, XV>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); \
-                           else if (!ram_bounded && ad_short && GV == 1 && XV == 0) hipLaunchKernelGGL((mh_sweep_mfma_ad<4, 1, 0, false, 1>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); \
-                           else if (ram_bounded && ad_short) hipLaunchKernelGGL((mh_sweep_mfma_ad<4, GV, XV, true, 1>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); \
-                           else if (ram_bounded) hipLaunchKernelGGL((mh_sweep_mfma_ad<4, GV, XV, true>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); \
-                           else hipLaunchKernelGGL((mh_sweep_mfma_ad<4, GV, XV>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); } while (0)
-#define MF_ADL(GV) do { if (kn->kind == FMCMC_KERNEL_ADAPT && ad_short) hipLaunchKernelGGL((mh_sweep_mfma_ad<3, GV, -1, false, 1>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); \
-                        else if (kn->kind == FMCMC_KERNEL_ADAPT) hipLaunchKernelGGL((mh_sweep_mfma_ad<3, GV, -1>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); \
-                        else if (ad_short) hipLaunchKernelGGL((mh_sweep_mfma_ad<4, GV, -1, false, 1>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); \
-                        else hipLaunchKernelGGL((mh_sweep_mfma_ad<4, GV, -1>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); } while (0)
-#define MF_ADM(GV) do { if (kn->kind == FMCMC_KERNEL_NMIRROR && ad_short) hipLaunchKernelGGL((mh_sweep_mfma_ad<FMCMC_KERNEL_NMIRROR, GV, -2, false, 1>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); \
-                        else if (kn->kind == FMCMC_KERNEL_NMIRROR) hipLaunchKernelGGL((mh_sweep_mfma_ad<FMCMC_KERNEL_NMIRROR, GV, -2>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); \
-                        else if (ad_short) hipLaunchKernelGGL((mh_sweep_mfma_ad<FMCMC_KERNEL_UMIRROR, GV, -2, false, 1>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); \
-                        else hipLaunchKernelGGL((mh_sweep_mfma_ad<FMCMC_KERNEL_UMIRROR, GV, -2>), dim3((unsigned)pblk), dim3(NT), alds, stream, A); } while (0)
-        if (mfma_ad == 3) { if (mfma_ng == 1) MF_ADM(1); else if (mfma_ng == 2) MF_ADM(2); else if (mfma_ng == 3) MF_ADM(3); else MF_ADM(4); }
-        else if (mfma_ad == 2) { if (mfma_ng == 1) MF_ADL(1); else if (mfma_ng == 2) MF_ADL(2); else if (mfma_ng == 3) MF_ADL(3); else MF_ADL(4); }
-#undef MF_ADM
-        else if (mfma_ng == 1 && kn->k == 5) MF_AD(1, 5);
-        else if (mfma_ng == 1) MF_AD(1, 0);
-        else if (kn->k == 9) MF_AD(2, 9);
-        else MF_AD(2, 0);
-#undef MF_ADL
-#undef MF_AD
-      } else if (mfma_ext) {
-        g_kernel = "mfma-streamed";
-#define MF_EXT(KV, GV, SV) do { if (big) hipLaunchKernelGGL((mh_sweep_mfma<KV, GV, SV, false, true, true>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A); \
-                                else hipLaunchKernelGGL((mh_sweep_mfma<KV, GV, SV, false, false, true>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A); } while (0)
-        if (mfma_ng == 1) { if (kv == 1) MF_EXT(1, 1, 16); else MF_EXT(2, 1, 16); }
-        else if (mfma_ng == 2) { if (kv == 1) MF_EXT(1, 2, 8); else MF_EXT(2, 2, 8); }
-        else if (mfma_ng == 3 && mfma_ext == 4) { if (kv == 1) MF_EXT(1, 3, 4); else MF_EXT(2, 3, 4); }
-        else if (mfma_ng == 3) { if (kv == 1) MF_EXT(1, 3, 1); else MF_EXT(2, 3, 1); }
-        else if (mfma_ext == 2) { if (kv == 1) MF_EXT(1, 4, 2); else MF_EXT(2, 4, 2); }
-        else { if (kv == 1) MF_EXT(1, 4, 1); else MF_EXT(2, 4, 1); }
-#undef MF_EXT
-      } else if (false) {
-#ifdef FMCMC_AB   /* the stamped (DBG) instantiations: tools/stamp_mfma.py against an -DFMCMC_AB build */
-      } else if (dbgk && owners) {
-        if (kv == 1) hipLaunchKernelGGL((mh_sweep_mfma<1, 1, 20, true>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A);
-        else hipLaunchKernelGGL((mh_sweep_mfma<2, 1, 20, true>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A);
-      } else if (dbgk) {
-        hipLaunchKernelGGL((mh_sweep_mfmar<1, 1, 20, true>), dim3((unsigned)pblk), dim3(NT), mlds, stream, A);
-      } else if (!owners) {
-        switch (ns) { MF_CASE_AB(mh_sweep_mfmar, 1, 1, 17) MF_CASE_AB(mh_sweep_mfmar, 1, 1, 18) MF_CASE_AB(mh_sweep_mfmar, 1, 1, 19) MF_CASE_AB(mh_sweep_mfmar, 1, 1, 20) default: break; }
-#endif
-      } else if (mfma_ng == 2 && kv == 1) {
-        switch (ns) { MF_CASES10(mh_sweep_mfma, 1, 2) default: break; }
-      } else if (mfma_ng == 2) {
-        switch (ns) { MF_CASES10(mh_sweep_mfma, 2, 2) default: break; }
-      } else if (kv == 1) {
-        switch (ns) { MF_CASES16(mh_sweep_mfma, 1, 1) MF_CASES17(mh_sweep_mfma, 1, 1) default: break; }
-      } else {
-        switch (ns) { MF_CASES16(mh_sweep_mfma, 2, 1) MF_CASES17(mh_sweep_mfma, 2, 1) default: break; }
-      }
-#undef MF_CASES17
-#undef MF_CASES16
-#undef MF_CASES10
-#undef MF_CASE
-#undef MF_CASE_AB
-    } else
-    if (!nospec) {
-      const size_t slds = spec_lds_bytes(pipe_opt, kn->kind >= FMCMC_KERNEL_ADAPT);
-#define LAUNCH_SPEC(PV, OV, KV)                                                                        \
-      do {                                                                                             \
-        if (slds > 48 * 1024)                                                                          \
-          e = hipFuncSetAttribute((const void*)mh_sweep_spec<PV, OV, KV>,                             \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds);              \
-        if (e == hipSuccess)                                                                           \
-          hipLaunchKernelGGL((mh_sweep_spec<PV, OV, KV>), dim3((unsigned)pblk), dim3(SPEC_NT), slds, stream, A); \
-      } while (0)
-      if (kn->kind < FMCMC_KERNEL_ADAPT) {
-        if (m->p == 3) { if (kn->kind == FMCMC_KERNEL_NORMAL) LAUNCH_SPEC(3, 20, 1); else LAUNCH_SPEC(3, 20, 2); }
-        else { if (kn->kind == FMCMC_KERNEL_NORMAL) LAUNCH_SPEC(1, 20, 1); else LAUNCH_SPEC(1, 20, 2); }
-      } else {
-#define SPEC_AD(PV, OV) do { if (kn->kind == FMCMC_KERNEL_ADAPT) LAUNCH_SPEC(PV, OV, 3); else LAUNCH_SPEC(PV, OV, 4); } while (0)
-        switch (m->p) {
-          case 1: SPEC_AD(1, 20); break;
-          case 2: SPEC_AD(2, 20); break;
-          case 3: SPEC_AD(3, 20); break;
-          case 4: SPEC_AD(4, 10); break;
-          case 5: SPEC_AD(5, 10); break;
-          case 6: SPEC_AD(6, 8); break;
-          default: SPEC_AD(7, 8); break;
+    auto launch_fast = [&](const SweepArgs& A) {   // (shadows the call's arguments: one launch of the call, or one step window of it)
+      const long long pblk = (A.nchains + 3) / 4;
+      if (mfma_ng) {
+        // fp64-MFMA evaluation (mh_mfma.hpp), four chains per workgroup
+        const int ns = (int)((m->n + NT - 1) / NT);   // observation slots of 512
+        const int kv = (kn->kind == FMCMC_KERNEL_NORMAL) ? 1 : 2;
+        // (offsets from the buffer bases stay 32 bits -- the cheaper form, see mh_sweep_mfma's BIG -- while the samples of all chains
+        //  and the stream of this launch stay below 4 GiB)
+        const bool big = (unsigned long long)A.nchains * kn->k * (unsigned long long)A.ldS * 8ull >= (1ull << 32) ||
+                         (unsigned long long)A.nchains * (unsigned long long)A.nsteps * (unsigned long long)A.kz * 8ull >= (1ull << 32);
+        if (mfma_ad) {
+          // kernel_adapt / kernel_ram / mirror kernels: the adaptive owners between the barriers of the streamed evaluation (mh_mfma_ad.hpp)
+          g_kernel = "mfma-adaptive";
+          const bool ad_short = mfma_ext == 1;    // (short data: one resident slot)
+          const int kx = (mfma_ad == 3) ? -2 : (mfma_ad == 2) ? -1 : (mfma_ng == 1 ? (kn->k == 5 ? 5 : 0) : (kn->k == 9 ? 9 : 0));
+          const bool bnd = mfma_ad == 1 && kn->kind == FMCMC_KERNEL_RAM && ram_bounded;
+          e = launch_k(fmh::k_mfma_ad(kn->kind, mfma_ng, kx, bnd ? 1 : 0, ad_short ? 1 : 0), pblk, NT, mfma_ad_lds_bytes(mfma_ad == 2), stream, A);
+        } else if (mfma_ext) {
+          g_kernel = "mfma-streamed";
+          e = launch_k(fmh::k_mfma_ext(kv, mfma_ng, mfma_ext, big ? 1 : 0), pblk, NT, mfma_lds_bytes(), stream, A);
+        } else {
+          g_kernel = "mfma";
+          e = launch_k(fmh::k_mfma(kv, mfma_ng, ns, big ? 1 : 0), pblk, NT, mfma_lds_bytes(), stream, A);
         }
-#undef SPEC_AD
+      } else {
+        // the wave-specialised kernel (mh_spec.hpp): A.spec_cw chains per workgroup
+        g_kernel = A.spec_cw == 1 ? "spec-lat1" : A.spec_cw == 2 ? "spec-lat2" : A.spec_cw == 3 ? "spec-lat3" : "spec";
+        const long long sblk = (A.nchains + A.spec_cw - 1) / A.spec_cw;
+        e = launch_k(fmh::k_spec(m->p, kn->kind), sblk, SPEC_NT, spec_lds_bytes(pipe_opt, kn->kind >= FMCMC_KERNEL_ADAPT), stream, A);
       }
-#undef LAUNCH_SPEC
-    }
-#ifdef FMCMC_AB
-    else if (pipe_opt == 20 && kn->kind == FMCMC_KERNEL_NORMAL) LAUNCH_PIPE(3, 20, 1);
-    else if (pipe_opt == 20) LAUNCH_PIPE(3, 20, 2);
-    else if (kn->kind == FMCMC_KERNEL_NORMAL) LAUNCH_PIPE(1, 2, 1);
-    else LAUNCH_PIPE(1, 2, 2);
-#undef LAUNCH_PIPE
-#endif
     };   // launch_fast
     {
       SweepArgs W = A;
@@ -1025,8 +900,7 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
       }
     }
   } else
-  if (resident && res_p == 1) { g_kernel = "resident"; LAUNCH_KIND(4, 1, 4); }
-  else if (resident && res_p == 3) { g_kernel = "resident"; LAUNCH_KIND(4, 3, 20); }
+  if (resident) { g_kernel = "resident"; e = launch_k(fmh::k_resident(res_p, kn->kind), nblk, NT, lds, stream, A); }
   else if (!force && m->family == FMCMC_FAM_LOGISTIC && cw <= 4 && lds + sizeof(double) * (LG_LDS_DOUBLES + 2) <= 160 * 1024 &&
            (kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE || kn->kind == FMCMC_KERNEL_ADAPT ||
             kn->kind == FMCMC_KERNEL_RAM)) {
@@ -1052,8 +926,7 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
       const double w1 = (double)m->n * (double)(m->p + 12), stream1 = (double)m->n * (double)(m->p + 1) * 8.0 / 9.0e4;
       const double chain1 = 4.5 + ((w1 * 1.35e-5 > stream1) ? w1 * 1.35e-5 : stream1);
       const double shard1 = 10.3 + 1.78e-5 * (double)m->n * ((double)m->p + 10.3);
-      const void* kfl = (lkv == 1) ? (const void*)mh_sweep_kernel<1, -1, 2, 1, FMCMC_FAM_LOGISTIC, 1> : (lkv == 2) ? (const void*)mh_sweep_kernel<1, -1, 2, 2, FMCMC_FAM_LOGISTIC, 1>
-                      : (lkv == 3) ? (const void*)mh_sweep_kernel<1, -1, 2, 3, FMCMC_FAM_LOGISTIC, 1> : (const void*)mh_sweep_kernel<1, -1, 2, 4, FMCMC_FAM_LOGISTIC, 1>;
+      const void* kfl = fmh::k_logit(1, 1, lkv);
       const int rcl = try_long(kfl, lds, (chain1 < shard1 || m->p > 16) ? chain1 : shard1, true);
       if (rcl != FMCMC_OK) return rcl;
     }
@@ -1077,10 +950,7 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
       lshard = K.shard == 1 || est_shard < 0.95 * est_chain;
     }
     const void* kfn = nullptr;
-#define LSK(CWV) (lkv == 1 ? (const void*)mh_sweep_kernel<CWV, -1, 2, 1, FMCMC_FAM_LOGISTIC, 1> : lkv == 2 ? (const void*)mh_sweep_kernel<CWV, -1, 2, 2, FMCMC_FAM_LOGISTIC, 1> \
-                : lkv == 3 ? (const void*)mh_sweep_kernel<CWV, -1, 2, 3, FMCMC_FAM_LOGISTIC, 1> : (const void*)mh_sweep_kernel<CWV, -1, 2, 4, FMCMC_FAM_LOGISTIC, 1>)
-    if (lshard) kfn = (cw == 1) ? LSK(1) : (cw == 2) ? LSK(2) : LSK(4);
-#undef LSK
+    if (lshard) kfn = fmh::k_logit(cw <= 2 ? cw : 4, 1, lkv);
     if (lshard) {
       int coop = 0, perCU = 0;
       (void)hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev);
@@ -1127,23 +997,7 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
       }
     }
     if (!lshard) {
-#define LAUNCH_LOGIT(CWV, KV, MB)                                                                                      \
-    do {                                                                                                               \
-      if (lds > 48 * 1024)                                                                                             \
-        e = hipFuncSetAttribute((const void*)mh_sweep_kernel<CWV, -1, 0, KV, FMCMC_FAM_LOGISTIC, MB>,                  \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
-      if (e == hipSuccess)                                                                                             \
-        hipLaunchKernelGGL((mh_sweep_kernel<CWV, -1, 0, KV, FMCMC_FAM_LOGISTIC, MB>), dim3((unsigned)nblk), dim3(NT), lds, stream, A); \
-    } while (0)
-#define LAUNCH_LOGIT_K(CWV) do { if (lkv == 1) LAUNCH_LOGIT(CWV, 1, 1); else if (lkv == 2) LAUNCH_LOGIT(CWV, 2, 1); \
-                                 else if (lkv == 3) LAUNCH_LOGIT(CWV, 3, 1); else LAUNCH_LOGIT(CWV, 4, 1); } while (0)
-    switch (cw) {
-      case 1: LAUNCH_LOGIT_K(1); break;
-      case 2: LAUNCH_LOGIT_K(2); break;
-      default: LAUNCH_LOGIT_K(4); break;
-    }
-#undef LAUNCH_LOGIT_K
-#undef LAUNCH_LOGIT
+      e = launch_k(fmh::k_logit(cw <= 2 ? cw : 4, 0, lkv), nblk, NT, lds, stream, A);
     }
     }   // (not the long-data form)
   }
@@ -1151,14 +1005,6 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
            (kn->kind == FMCMC_KERNEL_RAM || kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE)) {
     // wide linear models (config C4: k = 50): one family and one proposal kernel compiled in, which leaves the streamed
     // evaluation the registers for 4 observations x 8 columns in flight per thread (mh_common.hpp)
-#define LAUNCH_WIDE(CWV, KV)                                                                                           \
-    do {                                                                                                               \
-      if (lds > 48 * 1024)                                                                                             \
-        e = hipFuncSetAttribute((const void*)mh_sweep_kernel<CWV, -1, 0, KV, FMCMC_FAM_GAUSSIAN_LINREG>,               \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
-      if (e == hipSuccess)                                                                                             \
-        hipLaunchKernelGGL((mh_sweep_kernel<CWV, -1, 0, KV, FMCMC_FAM_GAUSSIAN_LINREG>), dim3((unsigned)nblk), dim3(NT), lds, stream, A); \
-    } while (0)
     const int kv = kn->kind;   // 1, 2 or 4
     // Observation-sharded evaluation: one cooperative launch when the call has 128 or 256 workgroups, consecutive launches
     // of 256 workgroups when it has a multiple of that (more than 512 chains per GPU at two chains per workgroup)
@@ -1174,11 +1020,7 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
     // the sharded evaluation is its own instantiation (OPT = lanes per workgroup): sharing one with the streamed loop
     // cost 200-300 spilled registers in BOTH paths
     const void* kfn = nullptr;
-#define SHK(CWV, LV) ((kv == 1) ? (const void*)mh_sweep_kernel<CWV, -1, LV, 1, FMCMC_FAM_GAUSSIAN_LINREG>   \
-                    : (kv == 2) ? (const void*)mh_sweep_kernel<CWV, -1, LV, 2, FMCMC_FAM_GAUSSIAN_LINREG> \
-                                : (const void*)mh_sweep_kernel<CWV, -1, LV, 4, FMCMC_FAM_GAUSSIAN_LINREG>)
-    if (shard) kfn = (cw == 1) ? (lpw == 2 ? SHK(1, 2) : SHK(1, 4)) : (lpw == 2 ? SHK(2, 2) : SHK(2, 4));
-#undef SHK
+    if (shard) kfn = fmh::k_wide(cw, lpw, kv);
     if (A.debug & 256) fprintf(stderr, "fmcmc_amd: wide path nblk=%lld lpw=%d nslots=%d p=%d bounded=%d shard=%d\n", nblk, lpw, nslots, m->p, (int)ram_bounded, (int)shard);
     double* shw = nullptr;
     g_kernel = shard ? "streamed-wide-sharded" : "streamed-wide";
@@ -1209,9 +1051,7 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
               sizeof(double) * wide2_lds_doubles(kn->k, kf, kn->kind, A.kz, mblk) <= 160 * 1024;
     }
     if (wide2) {
-#define W2K(KV) ((nmt == 1) ? (const void*)mh_sweep_wide2<KV, 1> : (nmt == 2) ? (const void*)mh_sweep_wide2<KV, 2> : (const void*)mh_sweep_wide2<KV, 3>)
-      kfn = (kv == 1) ? W2K(1) : (kv == 2) ? W2K(2) : W2K(4);
-#undef W2K
+      kfn = fmh::k_wide2(kv, nmt);
       lds = sizeof(double) * wide2_lds_doubles(kn->k, kf, kn->kind, A.kz, mblk);
       g_kernel = "wide-dataflow";
       A.sh_ngrp = (K.groups == 4) ? 4 : 2;
@@ -1273,18 +1113,9 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
     }
     if (shard) {
     } else
-    if (cw == 1) { if (kv == 1) LAUNCH_WIDE(1, 1); else if (kv == 2) LAUNCH_WIDE(1, 2); else LAUNCH_WIDE(1, 4); }
-    else { if (kv == 1) LAUNCH_WIDE(2, 1); else if (kv == 2) LAUNCH_WIDE(2, 2); else LAUNCH_WIDE(2, 4); }
-#undef LAUNCH_WIDE
+    e = launch_k(fmh::k_wide(cw, 0, kv), nblk, NT, lds, stream, A);
   }
-  else { g_kernel = "streamed"; switch (cw) {
-    case 1: LAUNCH(1, -1, 0, 0); break;
-    case 2: LAUNCH(2, -1, 0, 0); break;
-    case 4: LAUNCH(4, -1, 0, 0); break;
-    default: LAUNCH(8, -1, 0, 0); break;
-  } }
-#undef LAUNCH_KIND
-#undef LAUNCH
+  else { g_kernel = "streamed"; e = launch_k(fmh::k_general(cw), nblk, NT, lds, stream, A); }
   if (e == hipSuccess) e = hipGetLastError();
   if (e != hipSuccess) { set_err("HIP launch failed: %s", hipGetErrorString(e)); return FMCMC_ERR_DEVICE; }
   return FMCMC_OK;

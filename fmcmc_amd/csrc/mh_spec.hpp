@@ -712,8 +712,12 @@ __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
   double* s_tr = s_par + 4 * PIPE_KMAX + CW;       // [CW][8][PIPE_TRS] lane partials, transposed
   double* s_y = s_tr + CW * 8 * PIPE_TRS;          // [OPT/2][NT][2] this workgroup's copy of y
   double* s_ad = s_y + OPT * NT;                   // KIND >= 3: [CW][SPEC_ADS] adaptive per-chain state
-  const long long cg0 = (long long)blockIdx.x * CW;
-  const int ncw = (int)((A.nchains - cg0 < CW) ? (A.nchains - cg0) : CW);
+  // chains of this workgroup: A.spec_cw = 4, or 2 / 1 in the LATENCY form (fewer than 4 x CUs chains per GPU: every chain gets
+  // more of a compute unit -- all eight compute waves evaluate the one or two chains there are, and an owner's turn-around
+  // is no longer queued behind the evaluation of three other chains; same canonical lanes, same tree, same bits)
+  const int cwl = A.spec_cw;
+  const long long cg0 = (long long)blockIdx.x * cwl;
+  const int ncw = (int)((A.nchains - cg0 < cwl) ? (A.nchains - cg0) : cwl);
   const int nsteps = (int)A.nsteps, burnin = (int)A.burnin, thin = (int)A.thin;
   const int ic = A.intercept;
   const bool dbg = (A.debug & 8) != 0;

@@ -22,15 +22,51 @@ def E():
     return engine
 
 
+@pytest.fixture(autouse=True)
+def _four_chains_per_workgroup(request, monkeypatch):
+    """The cases of this module reach the kernels of FULL launches (four chains per workgroup: mh_sweep_mfma, mh_sweep_spec) with
+    a handful of chains, so they switch the latency form off (knob lat=0).  It has its own tests (test_latency_form_*), and the
+    randomised sweeps and everything in test_gpu_api.py run on the dispatcher's own choice."""
+    if "latency" not in request.node.name and "randomised" not in request.node.name:
+        set_knob(monkeypatch, "lat", "0")
+
+
 def _bits_equal(a, b):
     a = np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
     b = np.ascontiguousarray(b, dtype=np.float64).view(np.uint64)
     return np.array_equal(a, b)
 
 
+class _Blocks:
+    """The oracle on `threads` host threads: consecutive blocks of chains, each an oracle call with its chain_base (ctypes
+    releases the GIL; chains never interact, R/mcmc.R:590-673), presented as ONE result / ONE state."""
+
+    def __init__(self, O, om, ok, initial, threads):
+        C_ = initial.shape[0]
+        nb = max(1, min(threads, C_))
+        edges = [C_ * b // nb for b in range(nb + 1)]
+        self.O, self.om, self.ok = O, om, ok
+        self.blocks = [(lo, hi, O.ChainState(initial[lo:hi], ok.kf)) for lo, hi in zip(edges[:-1], edges[1:]) if hi > lo]
+
+    def run(self, **kw):
+        from concurrent.futures import ThreadPoolExecutor
+        base = kw.pop("chain_base", 0)
+        with ThreadPoolExecutor(len(self.blocks)) as ex:
+            rs = list(ex.map(lambda b: self.O.run(self.om, self.ok, chain_base=base + b[0], state=b[2], **kw), self.blocks))
+        ro = type("R", (), {})()
+        for name in ("status", "accept_bits", "accept_count", "samples_cks", "draws_cks", "logpost"):
+            setattr(ro, name, np.concatenate([getattr(r, name) for r in rs], axis=0))
+        return ro
+
+    def __getattr__(self, name):     # the state arrays of all blocks
+        vals = [getattr(b[2], name) for b in self.blocks]
+        return None if vals[0] is None else np.concatenate(vals, axis=0)
+
+
 def run_both(E, O, fam, X, y, kind, k, initial, nsteps, burnin=0, thin=1, seed=1215, chain_base=0,
-             calls=1, intercept=True, guard=True, prior_div=0.0, **kw):
-    """Runs `calls` consecutive sweeps on GPU and oracle; asserts bit-equality after each."""
+             calls=1, intercept=True, guard=True, prior_div=0.0, threads=1, **kw):
+    """Runs `calls` consecutive sweeps on GPU and oracle; asserts bit-equality after each.  threads > 1: the oracle runs
+    blocks of chains on that many host threads (full-width configs)."""
     from fmcmc_amd import _abi as abi
     om = O.Model(fam, X, y, intercept=intercept, guard=guard, prior_div=prior_div)
     ok = O.Kernel(kind, k, **kw)
@@ -40,12 +76,16 @@ def run_both(E, O, fam, X, y, kind, k, initial, nsteps, burnin=0, thin=1, seed=1
                       scheme_seq=ok.scheme_seq, constr=ok.constr, nadapt=ok.nadapt, ram_qfun=ok.ram_qfun, ram_df=ok.ram_df,
                       ram_eta_exp=ok.ram_eta_exp)
     initial = np.ascontiguousarray(initial, dtype=np.float64)
-    ost = O.ChainState(initial, ok.kf)
+    blocks = _Blocks(O, om, ok, initial, threads) if threads > 1 else None
+    ost = blocks if blocks is not None else O.ChainState(initial, ok.kf)
     gst = E.ChainState(initial, ok.kf)
     res = None
     for _ in range(calls):
-        ro = O.run(om, ok, nsteps=nsteps, burnin=burnin, thin=thin, seed=seed, chain_base=chain_base,
-                   state=ost)
+        if blocks is not None:
+            ro = blocks.run(nsteps=nsteps, burnin=burnin, thin=thin, seed=seed, chain_base=chain_base)
+        else:
+            ro = O.run(om, ok, nsteps=nsteps, burnin=burnin, thin=thin, seed=seed, chain_base=chain_base,
+                       state=ost)
         rg = E.sweep(gm, gk, gst, nsteps, burnin=burnin, thin=thin, seed=seed, chain_base=chain_base,
                      check=False)
         import torch
@@ -296,40 +336,129 @@ def test_mfma_equals_valu_kernels(E, O, monkeypatch):
     b, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=80, scale=0.02)
     assert _bits_equal(a.samples.cpu().numpy(), b.samples.cpu().numpy())
     from fmcmc_amd import _abi as abi
-    assert abi.last_kernel() == "spec"
-    set_knob(monkeypatch, "spec", "0")     # the software-pipelined kernel: an A/B partner, in -DFMCMC_AB builds only
-    c, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=80, scale=0.02)
-    assert _bits_equal(a.samples.cpu().numpy(), c.samples.cpu().numpy())
-    assert abi.last_kernel() in ("pipe", "spec")
+    assert abi.last_kernel().startswith("spec")
 
 
 @pytest.mark.parametrize("n", [10000, 9000, 600])
-def test_mfma_replicated_equals_owner_kernel(E, O, monkeypatch, n):
-    """The two MFMA kernels (owner waves = the product path / chain state replicated in every wave, one barrier) give the
-    same bits as the oracle and as each other wherever both are compiled in (-DFMCMC_AB builds, n > 8192; elsewhere the
-    switch is a no-op and the test covers the product kernel on these cases),
-    incl. thinning, continuation, a fixed parameter, the uniform kernel and a chain that fails with a NaN (the rare-path
-    branch of either kernel)."""
+@pytest.mark.parametrize("lat", ["0", "-1"])
+def test_mfma_kernel_rare_paths(E, O, monkeypatch, n, lat):
+    """The MFMA kernel (four chains per workgroup, knob lat=0) and what the dispatcher takes for 7 chains by itself (the
+    latency form of the wave-specialised kernel): thinning, continuation, a fixed parameter, the uniform kernel and a chain
+    that fails with a NaN (the rare-path branch) -- the oracle's bits in both."""
+    from fmcmc_amd import _abi as abi
+    set_knob(monkeypatch, "lat", lat)          # (-1: the dispatcher's own choice)
     X, y = synth_linreg(n, 3, 31 + n)
     init = jitter_init([0, 0, 0, 0, float(np.std(y))], 7, 24)
     init[:, -1] = np.abs(init[:, -1])
     bad = init.copy()
     bad[:, -1] = 0.03                                     # sigma steps below zero within a few proposals of scale 1
-    out = {}
-    for force in ("1", "0"):
-        set_knob(monkeypatch, "owners", force)
-        a, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=150, burnin=11, thin=4, calls=2, scale=0.02)
-        b, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=90, scale=0.03, fixed=[False, False, True, False, False])
-        c, _ = run_both(E, O, O.FAM_LINREG, X, y, O.K_UNIF, 5, init, nsteps=90, min_=-0.03, max_=0.04)
-        d, ro = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, bad, nsteps=60, guard=False, scale=1.0)
-        assert (ro.status == 1).any()
-        out[force] = [r.samples.cpu().numpy() for r in (a, b, c)] + [d.status.cpu().numpy()]
-        if force == "0":   # (the replicated-state kernel is an A/B partner: -DFMCMC_AB builds carry it, the product library does not)
-            from fmcmc_amd import _abi as abi
-            assert abi.last_kernel() in ("mfma", "mfma-replicated")
-    for u, w in zip(out["1"][:3], out["0"][:3]):
-        assert _bits_equal(u, w)
-    assert np.array_equal(out["1"][3], out["0"][3])
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=150, burnin=11, thin=4, calls=2, scale=0.02)
+    assert abi.last_kernel() == ("mfma" if lat == "0" else "spec-lat1")
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=90, scale=0.03, fixed=[False, False, True, False, False])
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_UNIF, 5, init, nsteps=90, min_=-0.03, max_=0.04)
+    _, ro = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, bad, nsteps=60, guard=False, scale=1.0)
+    assert (ro.status == 1).any()
+    assert abi.last_kernel() == ("mfma" if lat == "0" else "spec-lat1")
+
+
+# ---- the LATENCY form (round 5): one, two or three chains per workgroup of the wave-specialised kernel
+@pytest.mark.parametrize("C", [3, 256, 257, 512, 513, 768, 769])
+@pytest.mark.parametrize("kind", ["normal", "reflective", "adapt", "ram"])
+def test_latency_form_equals_the_oracle(E, O, kind, C):
+    """Fewer than four chains per compute unit (R/mcmc.R:536-641 scales a FIXED number of chains over its workers, so a GPU
+    of a sharded call holds nchains / G): the dispatcher gives each workgroup ceil(C / 256) chains -- 1 up to 256 chains, 2 up
+    to 512, 3 up to 768, then the usual four.  C2 / C3's shape (n = 10,000, k = 5), every proposal family, the oracle's bits;
+    the chain counts sit on both sides of every switch (and leave a last workgroup partly filled)."""
+    from fmcmc_amd import _abi as abi
+    X, y = synth_linreg(10000, 3, 20260102)
+    init = jitter_init([0, 0, 0, 0, float(np.std(y))], C, 12)
+    init[:, -1] = np.abs(init[:, -1])
+    thr = 16
+    if kind == "normal":
+        run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=40, calls=2, scale=0.02, threads=thr)
+    elif kind == "reflective":
+        run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL_REFLECTIVE, 5, init, nsteps=40, burnin=3, thin=2, scale=0.3,
+                 lb=[-5, -5, -5, -5, 0.1], ub=[5, 5, 5, 5, 5.0], guard=False, threads=thr)
+    elif kind == "adapt":
+        run_both(E, O, O.FAM_LINREG, X, y, O.K_ADAPT, 5, init, nsteps=60, calls=2, warmup=20, threads=thr)
+    else:
+        run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, 5, init, nsteps=40, calls=2, threads=thr)
+    per_cu = (C + 255) // 256
+    fast4 = "mfma" if kind in ("normal", "reflective") else "spec"
+    assert abi.last_kernel() == ("spec-lat%d" % per_cu if per_cu < 4 else fast4)
+
+
+@pytest.mark.parametrize("lat", ["1", "2", "3"])
+@pytest.mark.parametrize("n,p", [(700, 1), (2000, 2), (5000, 4), (5120, 5), (3000, 6), (4096, 7), (10240, 3), (513, 3)])
+def test_latency_form_shapes(E, O, monkeypatch, lat, n, p):
+    """Every compute loop of the latency form (p = 1 .. 7 covariates, 2 .. 20 observation slots per lane, ragged last slots),
+    forced to 1 / 2 / 3 chains per workgroup (knob lat) for a chain count that leaves the last workgroup partly filled;
+    kernel_normal with thinning and a continuation, kernel_adapt."""
+    from fmcmc_amd import _abi as abi
+    set_knob(monkeypatch, "lat", lat)
+    X, y = synth_linreg(n, p, 4100 + n + p)
+    init = jitter_init([0.0] * (p + 1) + [float(np.std(y))], 7, 50 + p)
+    init[:, -1] = np.abs(init[:, -1])
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, p + 2, init, nsteps=70, burnin=4, thin=3, calls=2, scale=0.03)
+    assert abi.last_kernel() == "spec-lat" + lat
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_ADAPT, p + 2, init, nsteps=70, calls=2, warmup=15)
+    assert abi.last_kernel() == "spec-lat" + lat
+
+
+def test_latency_form_step_windows(E, O, monkeypatch):
+    """A long call of the normal kernels runs as step windows (bounded stream) in the latency form too: 96-step windows, the
+    bits of the oracle's one call."""
+    from fmcmc_amd import _abi as abi
+    set_knob(monkeypatch, "window", "96")
+    X, y = synth_linreg(3000, 3, 77)
+    init = jitter_init([0, 0, 0, 0, float(np.std(y))], 5, 3)
+    init[:, -1] = np.abs(init[:, -1])
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=333, burnin=40, thin=7, calls=2, scale=0.03)
+    assert abi.last_kernel() == "spec-lat1"
+
+
+# ---- BASELINE configs[1], [2] and [4] at EXACTLY their per-GPU width against the oracle (the oracle on 16 host threads)
+def test_c2_exact_shape_equals_the_oracle(E, O):
+    """configs[1]: 1024 chains x n = 10,000, k = 5, kernel_normal(scale = 0.02) -- the headline kernel (mh_sweep_mfma<1, 1, 20>,
+    256 workgroups of four chains), 48 steps, every output and the carried state, bit for bit."""
+    import bench
+    from fmcmc_amd import _abi as abi
+    cfg = bench.Config("c2")
+    X, y, init = cfg.workload(cfg.chains, 0)
+    assert X.shape == (10000, 3) and init.shape == (1024, 5)
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=48, seed=bench.CHAIN_SEED, scale=0.02, threads=16)
+    assert abi.last_kernel() == "mfma"
+
+
+def test_c3_exact_shape_equals_the_oracle(E, O):
+    """configs[2]: 1024 chains, kernel_adapt() with its default warmup = 500 (R/kernel_adapt.R:118-160), 720 steps: the
+    recursive mean / covariance, the Cholesky factor and the proposals of 220 adapting steps at full width, then a second
+    call of 64 steps that continues the adapted state -- every output, Sigma, the running mean, abs_iter, bit for bit."""
+    import bench
+    from fmcmc_amd import _abi as abi
+    cfg = bench.Config("c3")
+    X, y, init = cfg.workload(cfg.chains, 0)
+    rg, ro = run_both(E, O, O.FAM_LINREG, X, y, O.K_ADAPT, 5, init, nsteps=720, seed=bench.CHAIN_SEED, warmup=500, threads=16)
+    assert abi.last_kernel() == "spec"
+    st = rg.state if hasattr(rg, "state") else None
+    del rg, ro, st
+
+
+def test_c5_full_width_equals_the_oracle(E, O):
+    """configs[4] at its per-GPU width: 1024 chains, logistic n = 100,000, k = 6, kernel_normal_reflective(scale = .01, lb = -5,
+    ub = 5), thin 10 -- the observation-sharded form with TWO chains per thread (logit_shard<5, 2, 2>, the instantiation the
+    bench runs), 21 steps (two kept rows) and a continuation of 11, bit for bit."""
+    import bench
+    from fmcmc_amd import _abi as abi
+    cfg = bench.Config("c5")
+    X, y, init = cfg.workload(cfg.chains, 0)
+    assert X.shape == (100000, 5) and init.shape == (1024, 6)
+    run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_NORMAL_REFLECTIVE, 6, init, nsteps=21, thin=10, seed=bench.CHAIN_SEED,
+             prior_div=8.0, guard=False, scale=0.01, lb=-5.0, ub=5.0, threads=16)
+    assert abi.last_kernel() == "logistic-sharded"
+    run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_NORMAL_REFLECTIVE, 6, init, nsteps=11, thin=1, seed=bench.CHAIN_SEED,
+             prior_div=8.0, guard=False, scale=0.01, lb=-5.0, ub=5.0, threads=16)
+    assert abi.last_kernel() == "logistic-sharded"
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -1715,7 +1844,7 @@ def test_randomised_round4_regions_reached_their_kernels():
         assert {"mfma-streamed", "mfma-adaptive"} <= _R4_PICKED["A"], _R4_PICKED
         assert _R4_PICKED["B"] == {"big-k"}, _R4_PICKED
         assert "logistic-sharded" in _R4_PICKED["C"], _R4_PICKED
-        assert "spec" in _R4_PICKED["D"], _R4_PICKED
+        assert any(kn.startswith("spec") for kn in _R4_PICKED["D"]), _R4_PICKED
         assert "long-sharded" in _R4_PICKED["E"], _R4_PICKED
 
 
