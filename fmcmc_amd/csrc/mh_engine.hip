@@ -31,6 +31,7 @@
 #include "mh_streamed.hpp"
 #include "mh_mfma.hpp"
 #include "mh_spec.hpp"
+#include "mh_lat.hpp"
 #include "mh_wide2.hpp"
 #include "mh_mfma_ad.hpp"
 #include "mh_bigk.hpp"
@@ -630,7 +631,8 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
   hipError_t e = hipSuccess;
   // software-pipelined fast path: normal kernels, joint scheme, k <= 16, linreg data in registers
   const bool nopipe = K.pipe == 0;
-  int pipe_opt = 0, mfma_ng = 0, mfma_ad = 0, mfma_ext = 0, spec_cw = 4;   // mfma_ext: resident slots of the EXT form (0: everything resident)
+  int pipe_opt = 0, mfma_ng = 0, mfma_ad = 0, mfma_ext = 0, spec_cw = 4;
+  bool lat_normal = false;   // the normal / uniform kernels in the latency form (mh_sweep_lat)   // mfma_ext: resident slots of the EXT form (0: everything resident)
   AsyncScratch mfs_guard;
   if (!force && !nopipe && m->family == FMCMC_FAM_GAUSSIAN_LINREG &&
       (kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE ||
@@ -707,14 +709,15 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
     // workgroup a step of C2's shape costs the same 2 us at 64 chains and at 1024.  Here the wave-specialised kernel runs one,
     // two or three chains per workgroup -- all eight compute waves on the chain(s) there are (an evaluation of n = 10,000 is
     // 0.33 us of one CU's fp64 issue), no owner queued behind the evaluation of other chains -- for every shape its compute
-    // lanes hold in registers, the normal / uniform kernels included (with four chains per workgroup those stay on the MFMA
-    // kernel).  Same canonical lanes and tree: the bits do not depend on the form.  Knob lat=0: off; lat=1|2|3: forced.
+    // lanes hold in registers: kernel_adapt / kernel_ram on mh_sweep_spec (its owners no longer queue behind the evaluation of
+    // other chains), the normal / uniform kernels on mh_sweep_lat (mh_lat.hpp: chain state replicated in every wave, ONE barrier
+    // per step).  Same canonical lanes and tree: the bits do not depend on the form.  Knob lat=0: off; lat=1|2|3: forced.
     if (K.lat != 0 && !mirror && (pipe_opt || (mfma_ng && !mfma_ext && !mfma_ad))) {
       const long long per_cu = (run->nchains + ncu - 1) / ncu;
       const int lcw = (K.lat >= 1 && K.lat <= 3) ? K.lat : (per_cu <= 3 ? (int)per_cu : 4);
       const long long nsl2 = (((m->n + NT - 1) / NT) + 1) & ~1ll;
       if (lcw < 4 && m->p >= 1 && nsl2 <= fmh::k_spec_optmax(m->p, kn->kind)) {
-        if (kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE) { pipe_opt = (int)nsl2; mfma_ng = 0; }
+        if (kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE) { pipe_opt = (int)nsl2; mfma_ng = 0; lat_normal = true; }
         if (pipe_opt && !mfma_ng) spec_cw = lcw;
       }
     }
@@ -856,6 +859,10 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
           g_kernel = "mfma";
           e = launch_k(fmh::k_mfma(kv, mfma_ng, ns, big ? 1 : 0), pblk, NT, mfma_lds_bytes(), stream, A);
         }
+      } else if (lat_normal) {
+        // the latency form of the normal / uniform kernels (mh_lat.hpp): A.spec_cw = 1 .. 3 chains per workgroup
+        g_kernel = A.spec_cw == 1 ? "lat1" : A.spec_cw == 2 ? "lat2" : "lat3";
+        e = launch_k(fmh::k_lat(m->p, kn->kind), (A.nchains + A.spec_cw - 1) / A.spec_cw, NT, lat_lds_bytes(), stream, A);
       } else {
         // the wave-specialised kernel (mh_spec.hpp): A.spec_cw chains per workgroup
         g_kernel = A.spec_cw == 1 ? "spec-lat1" : A.spec_cw == 2 ? "spec-lat2" : A.spec_cw == 3 ? "spec-lat3" : "spec";

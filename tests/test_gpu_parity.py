@@ -353,12 +353,12 @@ def test_mfma_kernel_rare_paths(E, O, monkeypatch, n, lat):
     bad = init.copy()
     bad[:, -1] = 0.03                                     # sigma steps below zero within a few proposals of scale 1
     run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=150, burnin=11, thin=4, calls=2, scale=0.02)
-    assert abi.last_kernel() == ("mfma" if lat == "0" else "spec-lat1")
+    assert abi.last_kernel() == ("mfma" if lat == "0" else "lat1")
     run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=90, scale=0.03, fixed=[False, False, True, False, False])
     run_both(E, O, O.FAM_LINREG, X, y, O.K_UNIF, 5, init, nsteps=90, min_=-0.03, max_=0.04)
     _, ro = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, bad, nsteps=60, guard=False, scale=1.0)
     assert (ro.status == 1).any()
-    assert abi.last_kernel() == ("mfma" if lat == "0" else "spec-lat1")
+    assert abi.last_kernel() == ("mfma" if lat == "0" else "lat1")
 
 
 # ---- the LATENCY form (round 5): one, two or three chains per workgroup of the wave-specialised kernel
@@ -384,8 +384,8 @@ def test_latency_form_equals_the_oracle(E, O, kind, C):
     else:
         run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, 5, init, nsteps=40, calls=2, threads=thr)
     per_cu = (C + 255) // 256
-    fast4 = "mfma" if kind in ("normal", "reflective") else "spec"
-    assert abi.last_kernel() == ("spec-lat%d" % per_cu if per_cu < 4 else fast4)
+    simple = kind in ("normal", "reflective")
+    assert abi.last_kernel() == ((("lat%d" if simple else "spec-lat%d") % per_cu) if per_cu < 4 else ("mfma" if simple else "spec"))
 
 
 @pytest.mark.parametrize("lat", ["1", "2", "3"])
@@ -400,7 +400,10 @@ def test_latency_form_shapes(E, O, monkeypatch, lat, n, p):
     init = jitter_init([0.0] * (p + 1) + [float(np.std(y))], 7, 50 + p)
     init[:, -1] = np.abs(init[:, -1])
     run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, p + 2, init, nsteps=70, burnin=4, thin=3, calls=2, scale=0.03)
-    assert abi.last_kernel() == "spec-lat" + lat
+    assert abi.last_kernel() == "lat" + lat
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_UNIF_REFLECTIVE, p + 2, init, nsteps=50, min_=-0.04, max_=0.05,
+             lb=[-9.0] * (p + 1) + [0.05], ub=9.0, fixed=[False, True] + [False] * p)
+    assert abi.last_kernel() == "lat" + lat
     run_both(E, O, O.FAM_LINREG, X, y, O.K_ADAPT, p + 2, init, nsteps=70, calls=2, warmup=15)
     assert abi.last_kernel() == "spec-lat" + lat
 
@@ -414,7 +417,7 @@ def test_latency_form_step_windows(E, O, monkeypatch):
     init = jitter_init([0, 0, 0, 0, float(np.std(y))], 5, 3)
     init[:, -1] = np.abs(init[:, -1])
     run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, 5, init, nsteps=333, burnin=40, thin=7, calls=2, scale=0.03)
-    assert abi.last_kernel() == "spec-lat1"
+    assert abi.last_kernel() == "lat1"
 
 
 # ---- BASELINE configs[1], [2] and [4] at EXACTLY their per-GPU width against the oracle (the oracle on 16 host threads)
