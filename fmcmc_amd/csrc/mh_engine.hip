@@ -714,7 +714,11 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
     // per step).  Same canonical lanes and tree: the bits do not depend on the form.  Knob lat=0: off; lat=1|2|3: forced.
     if (K.lat != 0 && !mirror && (pipe_opt || (mfma_ng && !mfma_ext && !mfma_ad))) {
       const long long per_cu = (run->nchains + ncu - 1) / ncu;
-      const int lcw = (K.lat >= 1 && K.lat <= 3) ? K.lat : (per_cu <= 3 ? (int)per_cu : 4);
+      // (measured, tools/bench_lat_grid.sh: the normal kernels win with one chain per workgroup -- 0.60 .. 1.06 us per step against
+      //  0.98 .. 2.0 -- and win or tie with two; with three the MFMA kernel's four are faster.  kernel_adapt / kernel_ram gain up to 25 %
+      //  with one, 18 % with two, 6 % with three at n = 10,000 and are level at small n: their step is the owner's dependent chain.)
+      const int lmax = (kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE) ? 2 : 3;
+      const int lcw = (K.lat >= 1 && K.lat <= 3) ? K.lat : (per_cu <= lmax ? (int)per_cu : 4);
       const long long nsl2 = (((m->n + NT - 1) / NT) + 1) & ~1ll;
       if (lcw < 4 && m->p >= 1 && nsl2 <= fmh::k_spec_optmax(m->p, kn->kind)) {
         if (kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE) { pipe_opt = (int)nsl2; mfma_ng = 0; lat_normal = true; }

@@ -2,7 +2,8 @@
 strong-scaled call sees (1024 chains over G GPUs = 1024 / G each).  For every chain count the dispatcher's own choice and the
 four-chains-per-workgroup kernels (knob lat=0) side by side.
 
-  python tools/bench_chains.py [normal|adapt|ram] [steps] [chain counts ...]   -> one line per count + a JSON summary"""
+  python tools/bench_chains.py [normal|adapt|ram] [steps] [chain counts ...]   -> one line per count + a JSON summary
+  BENCH_N / BENCH_P in the environment: another shape (n observations, p covariates) instead of C2's"""
 import json
 import os
 import sys
@@ -18,18 +19,28 @@ kind = sys.argv[1] if len(sys.argv) > 1 else "normal"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4000
 counts = [int(a) for a in sys.argv[3:]] or [4, 64, 128, 256, 257, 384, 512, 513, 640, 768, 769, 1024]
 cfg = bench.Config({"normal": "c2", "adapt": "c3", "ram": "c3"}[kind])
-X, y, init = cfg.workload(max(counts), 0)
+if "BENCH_N" in os.environ:
+    cfg.n, cfg.p = int(os.environ["BENCH_N"]), int(os.environ.get("BENCH_P", "3"))
+    cfg.k = cfg.p + 2
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((cfg.n, cfg.p))
+    y = 1.0 + X @ np.linspace(1.0, -1.0, cfg.p) + 4.0 * rng.standard_normal(cfg.n)
+    init = np.concatenate([np.zeros(cfg.p + 1), [float(np.std(y))]])[None, :] + 0.05 * rng.standard_normal((max(counts), cfg.k))
+    init[:, -1] = np.abs(init[:, -1])
+else:
+    X, y, init = cfg.workload(max(counts), 0)
+K = cfg.k
 gm, gk = bench.device_objects(cfg, E, abi, X, y, "cuda:0")
 if kind == "ram":
     big = E.DBL_MAX
-    gk = E.KernelSpec(abi.KERNEL_RAM, 5, np.zeros(5), np.ones(5), np.full(5, -big), np.full(5, big), np.zeros(5, np.uint8))
+    gk = E.KernelSpec(abi.KERNEL_RAM, K, np.zeros(K), np.ones(K), np.full(K, -big), np.full(K, big), np.zeros(K, np.uint8))
 
 
 def us_per_step(C):
     init_d = torch.as_tensor(init[:C]).cuda()
     best = None
     for rep in range(3):
-        st = E.ChainState(init_d, 5)
+        st = E.ChainState(init_d, K)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         r = E.sweep(gm, gk, st, steps, seed=bench.CHAIN_SEED, want_logpost=True, want_draws=True, want_bits=False, check=False)
@@ -50,5 +61,5 @@ for C in counts:
     os.environ.pop("FMCMC_AMD_DEBUG", None)
     rows.append({"chains": C, "us_per_step": round(a, 3), "kernel": ka, "us_per_step_lat0": round(b, 3), "kernel_lat0": kb,
                  "samples_per_s": round(C / a * 1e6)})
-    print("%-6s chains %5d: %7.3f us/step on %-10s (four per workgroup: %7.3f on %s)  %.3e samples/s" % (kind, C, a, ka, b, kb, C / a * 1e6), flush=True)
+    print("%-6s n=%d p=%d chains %5d: %7.3f us/step on %-10s (four per workgroup: %7.3f on %s)  %.3e samples/s" % (kind, cfg.n, cfg.p, C, a, ka, b, kb, C / a * 1e6), flush=True)
 print(json.dumps({"kind": kind, "steps": steps, "rows": rows}))
