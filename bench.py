@@ -399,8 +399,17 @@ def roofline_block(res, traffic_from=None):
           "kernel_ms": kern_ms, "flops_per_sample": cfg.flops, "flops_note": cfg.flops_note,
           "hbm": {"achieved_GBps": out_bytes / (kern_ms * 1e-3) / 1e9, "peak_GBps": PEAK_HBM_GBS,
                   "algorithmic_bytes_per_step": out_bytes}}
+    # the whole step the caller pays for (C2 / C3: + rng_fill_kernel; C4: + the Gelman checks), beside the sweep kernel's own fraction
+    rl["frac_step"] = res["samples_per_step"] * cfg.flops / (res["ms_per_step"] * 1e-3) / 1e12 / PEAK_FP64_TFLOPS
+    launches = len(BULKS_OF(cfg, iters)) if cfg.name == "c4" else 1
+    rl["algorithmic_bytes_per_launch"] = out_bytes / launches
+    rl["traffic_ratio"] = (traffic / (out_bytes / launches)) if traffic else None
     rl.update(res["extra"])
     return rl
+
+
+def BULKS_OF(cfg, iters):
+    return [cfg.bulk] * (iters // cfg.bulk) + ([iters % cfg.bulk] if iters % cfg.bulk else [])
 
 
 def workload_text(res):
@@ -417,7 +426,7 @@ def launch_ranks(args_list, n, backend):
     re-executed in place: the parent only waits."""
     import socket
     import subprocess
-    with socket.socket() as s:
+    with socket.socket() as s:      # (a free port of this moment; the ranks' rendezvous has a timeout, see main)
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
@@ -428,9 +437,38 @@ def launch_ranks(args_list, n, backend):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + args_list, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0 = procs[0].communicate()[0] or ""
-    rcs = [p.wait() for p in procs]
-    sys.stdout.write(out0)
+    # every rank is watched: when one dies, the others (blocked in the rendezvous or in a collective until the backend's
+    # timeout) are ended at once, and nothing outlives this process
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read() or ""), daemon=True)
+    reader.start()
+    rcs = [None] * n
+    t_fail = None
+    try:
+        while any(rc is None for rc in rcs):
+            for r, pr in enumerate(procs):
+                if rcs[r] is None:
+                    rcs[r] = pr.poll()
+            if any(rc not in (None, 0) for rc in rcs):
+                t_fail = t_fail or time.time()
+                if time.time() - t_fail > 3.0:      # (grace: ranks that fail for the same reason report it themselves)
+                    break
+            time.sleep(0.05)
+    finally:
+        for r, pr in enumerate(procs):
+            if pr.poll() is None:
+                pr.terminate()
+        for r, pr in enumerate(procs):
+            try:
+                rc = pr.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                pr.kill()
+                rc = pr.wait()
+            if rcs[r] is None:
+                rcs[r] = rc if rc else (0 if all(x in (None, 0) for x in rcs) else -15)
+    reader.join(timeout=5)
+    sys.stdout.write("".join(out0))
     sys.stdout.flush()
     worst = max(rcs, key=abs) if any(rcs) else 0
     if worst:
@@ -497,13 +535,16 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+        tmo = datetime.timedelta(seconds=int(os.environ.get("FMCMC_BENCH_RDZV_TIMEOUT", "180")))   # (a rank that never arrives must not hang the others for the backend's default half hour)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=tmo)
 
     chains = args.chains or cfg.chains
     scaling = "weak"
+    strong_ok = world > 1 and cfg.name in ("c2", "c3") and not args.chains and cfg.chains % world == 0
     if args.scaling == "strong" and world > 1 and cfg.name in ("c2", "c3") and not args.chains:
         if cfg.chains % world:
             raise SystemExit("bench.py --scaling strong: %d chains do not divide over %d ranks" % (cfg.chains, world))
@@ -518,6 +559,27 @@ def main():
         ranks_seen = [None] * world
         dist.all_gather_object(ranks_seen, me)
     res = run_config(cfg, chains, iters, args.steps, args.warmup, world, rank, dev, dist, torch, E, abi)
+    # C2 / C3 on N > 1 GPUs: BOTH scalings in one invocation.  The reference scales a FIXED number of chains over its workers
+    # (R/mcmc.R:536-641), i.e. strong scaling -- 1024 / N chains per GPU, the latency form of the kernels below 1024 --, the
+    # contract's line is per-GPU work fixed (weak).  `value` / `scaling` are the leg --scaling names; `scalings` holds both.
+    scalings = {scaling: {"value": res["value"], "chains_per_gpu": chains, "total_chains": chains * world, "ms_per_step": res["ms_per_step"],
+                          "kernel": res["picked"]}}
+    if strong_ok:
+        other = "strong" if scaling == "weak" else "weak"
+        oc = cfg.chains // world if other == "strong" else cfg.chains
+        ores = run_config(cfg, oc, iters, max(3, args.steps // 4), 1, world, rank, dev, dist, torch, E, abi)
+        scalings[other] = {"value": ores["value"], "chains_per_gpu": oc, "total_chains": oc * world, "ms_per_step": ores["ms_per_step"],
+                           "kernel": ores["picked"], "steps": ores["steps"]}
+    # one GPU: what a GPU of a strong-scaled call of this config would see -- 1024 / G chains, measured HERE -- and the curve
+    # that follows from it (G x the samples/s of 1024 / G chains on one GPU: chains never interact, R/mcmc.R:590-673)
+    projection = None
+    if world == 1 and cfg.name in ("c2", "c3") and not args.chains and not args.iters and not args.no_extra_configs:
+        projection = {"note": "measured on this one GPU with 1024 / G chains; value_G = G x samples/s of that run (no data-path collective exists)",
+                      "1": {"chains_per_gpu": cfg.chains, "ms_per_step": res["ms_per_step"], "value": res["value"], "kernel": res["picked"]}}
+        for G in (2, 4, 8):
+            pr = run_config(cfg, cfg.chains // G, iters, max(3, args.steps // 8), 1, 1, 0, dev, dist, torch, E, abi)
+            projection[str(G)] = {"chains_per_gpu": cfg.chains // G, "ms_per_step": pr["ms_per_step"], "value": G * pr["value"],
+                                  "kernel": pr["picked"], "speedup_vs_1": G * pr["value"] / res["value"]}
 
     # the other GPU configs of BASELINE.md section 4 as short full-size sweeps, so that the driver's clock covers them too
     # (headline invocation on one GPU only; `--config cX` gives each its own full line, `--gpus N` its scaling)
@@ -531,7 +593,8 @@ def main():
             extras[name] = {"workload": workload_text(xr), "value": xr["value"], "unit": "MH samples/s", "steps": xr["steps"], "warmup": 1,
                             "ms_per_step": xr["ms_per_step"], "accept_rate": xr["accept_rate"], "kernel": rl["kernel"],
                             "kernel_ms": rl["kernel_ms"], "bound": rl["bound"], "achieved": rl["achieved"], "peak": rl["peak"],
-                            "frac": rl["frac"], "flops_per_sample": rl["flops_per_sample"], "traffic": rl["traffic"],
+                            "frac": rl["frac"], "frac_step": rl["frac_step"], "flops_per_sample": rl["flops_per_sample"], "traffic": rl["traffic"],
+                            "traffic_ratio": rl["traffic_ratio"], "algorithmic_bytes_per_launch": rl["algorithmic_bytes_per_launch"],
                             "traffic_source": rl["traffic_source"], "wall_s_incl_setup": None}
             for key in ("gelman_checks_ms_per_step", "rng_fill_kernel_ms", "default_path_ms_per_step"):
                 if key in rl:
@@ -541,6 +604,8 @@ def main():
     if rank == 0:
         metric = "MH samples/sec (chains x iters / s), 1024 chains, 5-param linreg n=10k" if cfg.name == "c2" else \
                  "MH samples/sec (chains x iters / s), config %s" % cfg.name.upper()
+        if world > 1 and scaling == "weak":   # (per-GPU work fixed: the job holds N x the config's chains)
+            metric += " [weak scaling: %d x %d chains]" % (world, chains)
         line = {
             "metric": metric,
             "value": res["value"], "unit": "MH samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -557,6 +622,10 @@ def main():
                        "all_reduce_calls_in_timed_steps": res["all_reduce_calls_in_timed_steps"]},
             "roofline": roofline_block(res, args.traffic_from),
         }
+        if world > 1:
+            line["scalings"] = scalings
+        if projection:
+            line["strong_scaling_projection"] = projection
         if extras:
             line["configs"] = extras
         if world == 1 and not args.no_cpu_baseline:

@@ -69,6 +69,7 @@ struct SweepArgs {
   // bits_stride the words per chain of the WHOLE call's bitmap, step_off what to add to a local step for status_step.
   int win_cont, thin_ctr0;
   long long bits_stride, step_off;
+  double* win_sum;           // kernel_adapt in step windows: [C][kf] the running sum of this call's rows (its first running mean), carried from window to window; or NULL
   const double* fed_logu;
   const double* fed_z;
   const double* mf_stream;   // mh_sweep_mfma<.., EXT>: the observation slots beyond the operand registers, in operand order (mfma_build_stream)

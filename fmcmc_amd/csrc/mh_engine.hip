@@ -369,7 +369,7 @@ static SweepArgs chain_window(const SweepArgs& A, long long off, long long cnt, 
   ADV(scheme_cols, ns); ADV(mirror_mu, k); ADV(mirror_scale, k); ADV(obs_arate, 1);
   ADV(hist, (long long)A.hist_rows * kf);
   ADV(fed_logu, ns); ADV(fed_z, ns * A.kz);
-  ADV(theta0, k); ADV(f0, 1); ADV(abs_iter, 1); ADV(Sigma, (long long)kf * kf); ADV(mean_prev, kf); ADV(have_mean, 1); ADV(nerrors, 1);
+  ADV(win_sum, kf); ADV(theta0, k); ADV(f0, 1); ADV(abs_iter, 1); ADV(Sigma, (long long)kf * kf); ADV(mean_prev, kf); ADV(have_mean, 1); ADV(nerrors, 1);
   ADV(samples, k * S); ADV(logpost, S); ADV(draws, k * S); ADV(accept_count, 1); ADV(accept_bits, words);
   ADV(status, 1); ADV(status_step, 1); ADV(status_theta, k);
 #undef ADV
@@ -639,14 +639,14 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
        ((kn->kind == FMCMC_KERNEL_ADAPT && !adapt_hist) || (kn->kind == FMCMC_KERNEL_RAM && !kn->constr)) ||
        (mirror && kn->scheme == FMCMC_SCHEME_JOINT && kf == kn->k && K.mfma != 0)) &&
       (kn->scheme == FMCMC_SCHEME_JOINT || kn->kind == FMCMC_KERNEL_ADAPT || kn->kind == FMCMC_KERNEL_RAM) && kn->k <= PIPE_KMAX &&
-      // Sizes (round 3: rows and variates are addressed as 64-bit chain base + 32-bit offset, and a long call of the normal /
-      // uniform kernels runs as step windows with a bounded stream, so a call no longer leaves these kernels at 4 GiB of
-      // samples or stream).  What is left: offsets inside one chain's blocks are 32 bits, and the adaptive kernels -- whose
-      // step-dependent rules make a window a different call -- materialise their whole stream, which is kept below 8 GiB.
+      // Sizes (round 3: rows and variates are addressed as 64-bit chain base + 32-bit offset, and a long call runs as step
+      // windows with a bounded stream, so a call no longer leaves these kernels at 4 GiB of samples or stream).  What is
+      // left: offsets inside one chain's blocks are 32 bits.
       (unsigned long long)run->nsteps * (unsigned long long)A.kz * 8ull < (1ull << 32) && run->nsteps < (1ll << 30) &&
       (unsigned long long)kn->k * (unsigned long long)A.ldS * 8ull < (1ull << 32) &&      /* 32-bit offsets inside ONE chain's block */
-      (kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE ||
-       (unsigned long long)run->nchains * (unsigned long long)run->nsteps * (unsigned long long)(A.kz + 1) * 8ull < (8ull << 30))) {
+      /* (round 5: kernel_adapt / kernel_ram run in step windows too -- their step-dependent rules read the CALL's step, see below;
+          what still materialises its whole stream, kept below 8 GiB: host-fed variates are the caller's, and the mirror kernels) */
+      (!mirror || (unsigned long long)run->nchains * (unsigned long long)run->nsteps * (unsigned long long)(A.kz + 1) * 8ull < (8ull << 30))) {
     // the wave-specialised kernel (mh_sweep_spec): x of a compute lane in VGPRs, the slot count an (even) run-time choice among
     // its compute loops: any n <= 10240 at p <= 3, n <= 5120 at p = 4, 5, n <= 4096 at p = 6, 7 (OPTMAX P doubles per lane)
     {
@@ -803,7 +803,12 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
     // 80 operand registers and one extra evaluation, so the buffer is as large as is reasonable, not cache-sized).  The Philox counter
     // is the ABSOLUTE step, so the variates, and with them every bit of the output, do not depend on the cut
     // (windows begin behind a step = 1 mod 32: the accept bitmap's words then line up).
-    const bool windowed = A.rng_mode == FMCMC_RNG_PHILOX && kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE;
+    // Round 5: kernel_adapt / kernel_ram too (R/kernel_adapt.R:118-133, R/kernel_ram.R:129-152 are ONE loop of any length).  What
+    // depends on the step -- `i > 2`, the mean of this call's rows before the first adaptation, eta(i, k), `i %% freq` -- reads
+    // the call's step (SweepArgs.step_off + the window's), the running sum of the rows travels from window to window
+    // (SweepArgs.win_sum), everything else (Sigma / S, the running mean, abs_iter) is the state the windows hand on anyway.
+    const bool windowed = A.rng_mode == FMCMC_RNG_PHILOX && !mirror &&
+                          (kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE || kn->kind == FMCMC_KERNEL_ADAPT || kn->kind == FMCMC_KERNEL_RAM);
     long long win = run->nsteps;
     if (windowed) {
       const long long per_step = (long long)run->nchains * (A.kz + 1) * 8;
@@ -878,21 +883,27 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
       SweepArgs W = A;
       W.nsteps = n0;
       W.bits_stride = (run->nsteps + 31) >> 5;
-      if (A.rng_mode == FMCMC_RNG_PHILOX) fill_stream(W, (long long)run->step_base);
-      launch_fast(W);
       const long long kept_all = A.S;
       long long* wcount = nullptr;                                          // accept counts of one continuation window
-      if (n0 < run->nsteps) {
-        e = hipMallocAsync((void**)&wcount, sizeof(long long) * (size_t)run->nchains, stream);
+      double* wsum = nullptr;
+      if (n0 < run->nsteps) {   // (window counts, and behind them kernel_adapt's running sums of the call's rows)
+        const size_t nsum = (kn->kind == FMCMC_KERNEL_ADAPT) ? (size_t)run->nchains * (size_t)kf : 0;
+        e = hipMallocAsync((void**)&wcount, sizeof(long long) * (size_t)run->nchains + sizeof(double) * nsum, stream);
         if (e != hipSuccess) { set_err("hipMallocAsync(window counts) failed: %s", hipGetErrorString(e)); return FMCMC_ERR_DEVICE; }
         wc_guard.p = wcount; wc_guard.s = stream;
+        if (nsum) wsum = reinterpret_cast<double*>(wcount + run->nchains);
       }
+      W.win_sum = wsum;
+      if (A.rng_mode == FMCMC_RNG_PHILOX) fill_stream(W, (long long)run->step_base);
+      launch_fast(W);
       for (long long s0 = n0; s0 < run->nsteps && e == hipSuccess; ) {     // continuation windows
         const long long w = (run->nsteps - s0 < win) ? run->nsteps - s0 : win;
         const long long rows_done = fmcmc_kept_rows(s0, run->burnin, run->thin);
         W = A;
         W.nsteps = w + 1;
         W.win_cont = 1;
+        W.fresh = 0;                 // (kernel state: what the window before wrote back)
+        W.win_sum = wsum;
         W.step_off = s0 - 1;
         W.burnin = (run->burnin - s0 + 1 > 1) ? run->burnin - s0 + 1 : 1;
         W.thin_ctr0 = (s0 > run->burnin) ? (int)((s0 - run->burnin) % run->thin) : 0;

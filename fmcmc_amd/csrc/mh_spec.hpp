@@ -70,7 +70,11 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
   const double* s_mu = s_par, *s_lb = s_par + 2 * PIPE_KMAX, *s_ub = s_par + 3 * PIPE_KMAX;
   double f0 = 0.0;
   long long abs_iter = 0;
-  int nacc = 0, status = FMCMC_CHAIN_OK, thin_ctr = 0, have_mean = 0, nerr = 0;
+  // (a continuation window of a long call -- launch_sweep, SweepArgs.win_cont -- takes over what the windows before it left:
+  //  chain status, thinning counter, the running sum of this call's rows; the step-dependent rules read the CALL's step
+  //  ioff + i: `i > 2`, the mean of the rows so far, eta(i, k), `i %% freq`)
+  int nacc = 0, status = A.win_cont ? A.status[cl] : FMCMC_CHAIN_OK, thin_ctr = A.thin_ctr0, have_mean = 0, nerr = 0;
+  const int ioff = (int)A.step_off;
   unsigned int bitword = 0;
   double* const Scur = SigA;
   if (lane < k) { double t = A.theta0[(long long)cl * k + lane]; th0[lane] = t; th1[lane] = t; }
@@ -107,7 +111,10 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
   double lu_nx = (nsteps >= 2) ? lu_row[1] : 0.0;
   bool ram_gate = false;   // gate of the PENDING proposal (evaluated when it was made)
   auto flush_bits = [&](int i) {
-    if (A.accept_bits && lane == 0) A.accept_bits[(long long)cl * ((nsteps + 31) >> 5) + ((i - 1) >> 5)] = bitword;
+    if (A.accept_bits && lane == 0) {   // (bits_stride: words per chain of the whole call's bitmap; the first word of a continuation window also holds the last bit of the window before it)
+      unsigned int* w = A.accept_bits + ((long long)cl * A.bits_stride + ((i - 1) >> 5));
+      *w = (A.win_cont && i <= 32) ? (*w | bitword) : bitword;
+    }
     bitword = 0;
   };
 
@@ -118,7 +125,7 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
     double st_th0 = 0.0, st_dr = 0.0;
     if (v == 1) {
       f0 = f1;
-      if (lane < kf) vrs[lane] = th0[which[lane]];
+      if (lane < kf) vrs[lane] = (A.win_cont && A.win_sum) ? A.win_sum[(long long)cl * kf + lane] : th0[which[lane]];
       keep_row = true;
     } else if (status == FMCMC_CHAIN_OK) {
       const int i = v;
@@ -127,7 +134,7 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
           double a_n = fmh_exp(f1 - f0);
           if (fmh_isnan(a_n)) a_n = 0.0;
           else if (a_n > 1.0) a_n = 1.0;
-          double eta = (double)kf * fmh_exp(A.ram_neg_exp * fmh_log((double)i));
+          double eta = (double)kf * fmh_exp(A.ram_neg_exp * fmh_log((double)(i + ioff)));
           if (eta > 1.0) eta = 1.0;
           // S <- S T in place (mh_common.hpp, ram_coef; twin of the oracle's ram_factor_update_canon)
           const double zl = (lane < kf) ? vz[lane] : 0.0;
@@ -159,7 +166,7 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
       const double ratio = f1 - f0;
       if (status == FMCMC_CHAIN_OK && fmh_isnan(ratio)) status = FMCMC_CHAIN_NAN_RATIO;
       if (status != FMCMC_CHAIN_OK) {
-        if (lane == 0) { A.status[cl] = status; A.status_step[cl] = i; }
+        if (lane == 0) { A.status[cl] = status; A.status_step[cl] = i + ioff; }
         if (lane < k) A.status_theta[(long long)cl * k + lane] = th1[lane];
         flush_bits(i);
       } else {
@@ -210,12 +217,12 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
         z_nx = (lane < kz) ? ld_z(v + 1 < nsteps ? v + 1 : nsteps - 1) : 0.0;
         wave_sync_lds();
         if (KIND == FMCMC_KERNEL_ADAPT) {
-          if (A.until > (double)abs_iter && abs_iter > A.warmup && i > 2) {
+          if (A.until > (double)abs_iter && abs_iter > A.warmup && i + ioff > 2) {
             const double t = (double)(abs_iter - 1);
             double x = 0, mp = 0, mt = 0;
             if (lane < kf) {
               x = th0[which[lane]];
-              mp = have_mean ? vmp[lane] : (vrs[lane] / (double)(i - 1));
+              mp = have_mean ? vmp[lane] : (vrs[lane] / (double)(i + ioff - 1));
               mt = (mp * t + x) / (t + 1);
               vv[lane] = x; vmp[lane] = mp; vmt[lane] = mt;
             }
@@ -249,7 +256,7 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
           }
           if (notpd) {
             status = FMCMC_CHAIN_NOT_PD;
-            if (lane == 0) { A.status[cl] = status; A.status_step[cl] = i; }
+            if (lane == 0) { A.status[cl] = status; A.status_step[cl] = i + ioff; }
             if (lane < k) A.status_theta[(long long)cl * k + lane] = th1[lane];
           } else {
             if (lane < k) th1[lane] = th0[lane];
@@ -271,7 +278,7 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
             const int j = which[lane];
             th1[j] = th0[j] + sacc;
           }
-          ram_gate = (A.until > (double)abs_iter && abs_iter > A.warmup && ((v + 1) % A.freq) == 0);
+          ram_gate = (A.until > (double)abs_iter && abs_iter > A.warmup && ((v + 1 + ioff) % A.freq) == 0);
         }
         wave_sync_lds();
         if (lane < k) s_th1[myc * PIPE_KMAX + lane] = th1[lane];
@@ -300,6 +307,7 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
     if (A.nerrors) A.nerrors[cl] = nerr;
     if (KIND == FMCMC_KERNEL_ADAPT) A.have_mean[cl] = have_mean;
   }
+  if (KIND == FMCMC_KERNEL_ADAPT && A.win_sum && lane < kf) A.win_sum[(long long)cl * kf + lane] = vrs[lane];
   const double* Sfin = (KIND == FMCMC_KERNEL_RAM) ? Scur : SigA;
   for (int e = lane; e < kf * kf; e += 64) {
     const int a = e / kf, b = e % kf;
@@ -365,7 +373,9 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
   double th0 = rl ? A.theta0[(long long)cl * k + lane] : 0.0, th1 = th0;
   double f0 = 0.0, mean_prev = 0.0, run_sum = 0.0, zcur = 0.0;
   long long abs_iter = 0;
-  int nacc = 0, status = FMCMC_CHAIN_OK, thin_ctr = 0, have_mean = 0, nerr = 0;
+  // (continuation windows of a long call: see spec_owner_adaptive)
+  int nacc = 0, status = A.win_cont ? A.status[cl] : FMCMC_CHAIN_OK, thin_ctr = A.thin_ctr0, have_mean = 0, nerr = 0;
+  const int ioff = (int)A.step_off;
   unsigned int bitword = 0;
   if (!A.fresh) {
     abs_iter = A.abs_iter[cl];
@@ -394,7 +404,10 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
   double lu_nx = (nsteps >= 2) ? lu_row[1] : 0.0;
   bool ram_gate = false;
   auto flush_bits = [&](int i) {
-    if (A.accept_bits && lane == 0) A.accept_bits[(long long)cl * ((nsteps + 31) >> 5) + ((i - 1) >> 5)] = bitword;
+    if (A.accept_bits && lane == 0) {
+      unsigned int* w = A.accept_bits + ((long long)cl * A.bits_stride + ((i - 1) >> 5));
+      *w = (A.win_cont && i <= 32) ? (*w | bitword) : bitword;
+    }
     bitword = 0;
   };
   auto logpost_of = [&](double tot, double sigma) -> double {   // Gaussian linreg closed form (same as the normal owners)
@@ -426,7 +439,7 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
     pre_ok = sg_fast && mfr_div_safe(pre_ss);
     pre_rs = div_recip(pre_ok ? pre_ss : 1.0);
     if (KIND == FMCMC_KERNEL_RAM && i >= 2) {
-      double eta = (double)kf * fmh_exp(A.ram_neg_exp * fmh_log((double)i));
+      double eta = (double)kf * fmh_exp(A.ram_neg_exp * fmh_log((double)(i + ioff)));
       if (eta > 1.0) eta = 1.0;
       pre_eta = eta;
       pre_Pj1 = lane_scan_row16(zcur * zcur);                // (zcur is 0 beyond the parameters)
@@ -455,7 +468,7 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
     SPEC_ST(1);
     if (v == 1) {
       f0 = f1;
-      run_sum = th0;
+      run_sum = (A.win_cont && A.win_sum && rl) ? A.win_sum[(long long)cl * kf + lane] : th0;
       if (1 > burnin) { thin_ctr += 1; if (thin_ctr == thin) { thin_ctr = 0; st_row = true; st_th0 = th0; } }
       if constexpr (BND) sync.second_idle();
     } else if (status != FMCMC_CHAIN_OK) {
@@ -502,7 +515,7 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
       const double ratio = f1 - f0;
       if (status == FMCMC_CHAIN_OK && fmh_isnan(ratio)) status = FMCMC_CHAIN_NAN_RATIO;
       if (status != FMCMC_CHAIN_OK) {
-        if (lane == 0) { A.status[cl] = status; A.status_step[cl] = i; }
+        if (lane == 0) { A.status[cl] = status; A.status_step[cl] = i + ioff; }
         if (rl) A.status_theta[(long long)cl * k + lane] = th1;
         flush_bits(i);
       } else {
@@ -527,10 +540,10 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
         zcur = z_nx;
         z_nx = rl ? ld_z(v + 1 < nsteps ? v + 1 : nsteps - 1) : 0.0;
         if (KIND == FMCMC_KERNEL_ADAPT) {
-          if (A.until > (double)abs_iter && abs_iter > A.warmup && i > 2 && !(A.debug & 4096)) {   // R/kernel_adapt.R:118-166 (4096: timing ablation)
+          if (A.until > (double)abs_iter && abs_iter > A.warmup && i + ioff > 2 && !(A.debug & 4096)) {   // R/kernel_adapt.R:118-166 (4096: timing ablation)
             const double t = (double)(abs_iter - 1);
             const double x = th0;
-            const double mp = have_mean ? mean_prev : (run_sum / (double)(i - 1));
+            const double mp = have_mean ? mean_prev : (run_sum / (double)(i + ioff - 1));
             const double mt = (mp * t + x) / (t + 1);
             const double c1 = (t - 1) / t, c2 = 1.0 / t;
 #pragma unroll
@@ -571,7 +584,7 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
           SPEC_ST(4);
           if (notpd) {
             status = FMCMC_CHAIN_NOT_PD;
-            if (lane == 0) { A.status[cl] = status; A.status_step[cl] = i; }
+            if (lane == 0) { A.status[cl] = status; A.status_step[cl] = i + ioff; }
             if (rl) A.status_theta[(long long)cl * k + lane] = th1;
           } else {
             double sacc = 0.0;
@@ -586,7 +599,7 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
           for (int b = KA - 1; b >= 0; b--)   // last column first; the partial sums are the G_ib of the factor update
             if (b < kf) { const double ub_ = readlane_d(zcur, b); Grow[b] = sacc; sacc = fmh_fma(Srow[b], ub_, sacc); }   // (+0 above the diagonal adds +0)
           th1 = th0 + sacc;
-          ram_gate = (A.until > (double)abs_iter && abs_iter > A.warmup && ((v + 1) % A.freq) == 0);
+          ram_gate = (A.until > (double)abs_iter && abs_iter > A.warmup && ((v + 1 + ioff) % A.freq) == 0);
         }
         if (rl) s_th1[myc * PIPE_KMAX + lane] = th1;
       }
@@ -626,6 +639,7 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
   for (int b = 0; b < KA; b++)
     if (rl && b < kf) A.Sigma[((long long)cl * kf + lane) * kf + b] = (b <= lane || KIND == FMCMC_KERNEL_ADAPT) ? Srow[b] : 0.0;
   if (KIND == FMCMC_KERNEL_ADAPT && rl) A.mean_prev[(long long)cl * kf + lane] = mean_prev;
+  if (KIND == FMCMC_KERNEL_ADAPT && A.win_sum && rl) A.win_sum[(long long)cl * kf + lane] = run_sum;
 }
 
 // The compute role of mh_sweep_spec for OPT (even) observation slots of P covariates per lane: one instantiation per slot count,

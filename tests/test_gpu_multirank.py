@@ -200,6 +200,13 @@ def test_bench_strong_scaling_divides_the_headline_chains():
     line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert line["scaling"] == "strong" and line["n_gpus"] == 2
     assert line["config"]["chains_per_gpu"] == 512 and line["config"]["chain_base_of_rank"] == [0, 512]
+    # both scalings in the one invocation: the strong leg on the latency form (two chains per workgroup), the weak leg on the
+    # kernel of full launches with 2 x 1024 chains in the job
+    sc = line["scalings"]
+    assert sc["strong"]["chains_per_gpu"] == 512 and sc["strong"]["total_chains"] == 1024 and sc["strong"]["kernel"] == ["lat2"]
+    assert sc["weak"]["chains_per_gpu"] == 1024 and sc["weak"]["total_chains"] == 2048 and sc["weak"]["kernel"] == ["mfma"]
+    assert sc["strong"]["value"] == line["value"] and sc["weak"]["value"] > 0
+    assert "weak scaling" not in line["metric"]
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=dict(env, WORLD_SIZE="2", RANK="0"),
                          capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "but the launcher started WORLD_SIZE=2" in bad.stderr

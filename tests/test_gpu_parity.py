@@ -1532,6 +1532,35 @@ def test_a_call_longer_than_4_gib_of_samples_stays_on_the_headline_kernel(E, mon
     assert long_us <= 1.10 * short_us, "%.3f us per step at 1.2e5 steps, %.3f at 1e4" % (long_us, short_us)
 
 
+@pytest.mark.parametrize("window", ["32", "96"])
+@pytest.mark.parametrize("kind", ["adapt", "ram"])
+@pytest.mark.parametrize("shape", ["spec", "spec-lds-owner", "mfma-adaptive", "spec-lat1"])
+def test_step_windows_of_the_adaptive_kernels(E, O, monkeypatch, kind, window, shape):
+    """Round 5: kernel_adapt / kernel_ram in step windows (they used to materialise the whole stream and leave for the general
+    kernel at 8 GiB).  R/kernel_adapt.R:118-133 and R/kernel_ram.R:129-152 are ONE loop: `i > 2`, the mean of the call's rows
+    before the first adaptation, eta(i, k) and `i %% freq` read the CALL's step, whatever the window.  Windows of 32 / 96 steps
+    cut calls of a few hundred steps 3 - 12 times: the oracle's bits -- warm-up ending inside a later window (so the first
+    running mean comes from the carried row sum), burn-in and thinning that do not divide the window, kernel_ram's freq = 3,
+    `until` inside a window, a second call continuing the first; register-row owners, the owners with their matrices in
+    LDS (a fixed parameter), the streamed MFMA evaluation (n = 12,001), one chain per workgroup."""
+    from fmcmc_amd import _abi as abi
+    set_knob(monkeypatch, "window", window)
+    if shape == "spec-lat1":
+        set_knob(monkeypatch, "lat", "1")
+    n = 12001 if shape == "mfma-adaptive" else 3000
+    X, y = synth_linreg(n, 3, 20260102)
+    init = jitter_init([0, 0, 0, 0, float(np.std(y))], 6, 31)
+    init[:, -1] = np.abs(init[:, -1])
+    kw = dict(fixed=[False, True, False, False, False]) if shape == "spec-lds-owner" else {}
+    if kind == "adapt":
+        run_both(E, O, O.FAM_LINREG, X, y, O.K_ADAPT, 5, init, nsteps=333, burnin=41, thin=7, calls=2, warmup=70, until=500.0, **kw)
+        run_both(E, O, O.FAM_LINREG, X, y, O.K_ADAPT, 5, init, nsteps=150, warmup=0, **kw)   # (adapting from step 3 of the call)
+    else:
+        run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, 5, init, nsteps=333, burnin=41, thin=7, calls=2, freq=3, warmup=50, **kw)
+        run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, 5, init, nsteps=150, **kw)
+    assert abi.last_kernel() == {"spec": "spec", "spec-lds-owner": "spec", "mfma-adaptive": "mfma-adaptive", "spec-lat1": "spec-lat1"}[shape]
+
+
 def test_full_size_headline_properties(E, monkeypatch):
     """BASELINE configs[1] at its full size (1024 chains x 10,000 iterations, n = 10,000, k = 5; the oracle would need
     minutes), through properties that do not depend on the size: (a) two shards of 512 chains with their chain_base give
