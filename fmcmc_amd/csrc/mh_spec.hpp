@@ -258,6 +258,7 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
             status = FMCMC_CHAIN_NOT_PD;
             if (lane == 0) { A.status[cl] = status; A.status_step[cl] = i + ioff; }
             if (lane < k) A.status_theta[(long long)cl * k + lane] = th1[lane];
+            if (((v - 1) & 31) != 31) flush_bits(v);   // (the accept bits of the steps decided so far; a full word has just been flushed)
           } else {
             if (lane < k) th1[lane] = th0[lane];
             wave_sync_lds();
@@ -586,6 +587,7 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
             status = FMCMC_CHAIN_NOT_PD;
             if (lane == 0) { A.status[cl] = status; A.status_step[cl] = i + ioff; }
             if (rl) A.status_theta[(long long)cl * k + lane] = th1;
+            if (((v - 1) & 31) != 31) flush_bits(v);   // (the accept bits of the steps decided so far; a full word has just been flushed)
           } else {
             double sacc = 0.0;
 #pragma unroll
