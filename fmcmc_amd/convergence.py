@@ -69,14 +69,27 @@ class convergence_gelman:
             # more free parameters than the MFMA window reduction tiles (64): the same per-chain statistics -- window mean relative
             # to the centre, window covariance -- and their sums over the chains with torch on the device (64 < k <= 128 is the
             # big-k kernel's territory: one chain per workgroup, speed is not the point there)
-            X = samples[:, cols_d.long(), row0:row0 + N] - center[None, :, None]
-            xbm = X.mean(dim=2)
-            Xc = X - xbm[:, :, None]
-            Sc = Xc @ Xc.transpose(1, 2) / float(N - 1)
-            s2 = Sc.diagonal(dim1=1, dim2=2)
+            # in blocks of chains, so that the gathered window, its centred copy and the products stay bounded (1024 chains x k = 100 x
+            # N = 5000 rows were three 4 GB tensors at once): per-chain statistics are independent, the sums over the chains add up
+            per_chain = 3 * p * N * 8
+            blk_c = max(1, min(Cn, (256 << 20) // max(per_chain, 1)))
+            xbm = torch.empty((Cn, p), dtype=torch.float64, device=dev)
+            s2 = torch.empty((Cn, p), dtype=torch.float64, device=dev)
+            sum_xx = torch.zeros((p, p), dtype=torch.float64, device=dev)
+            sum_S = torch.zeros((p, p), dtype=torch.float64, device=dev)
+            for c0 in range(0, Cn, blk_c):
+                X = samples[c0:c0 + blk_c][:, cols_d.long(), row0:row0 + N] - center[None, :, None]
+                xb_b = X.mean(dim=2)
+                X -= xb_b[:, :, None]
+                Sc = X @ X.transpose(1, 2) / float(N - 1)
+                xbm[c0:c0 + blk_c] = xb_b
+                s2[c0:c0 + blk_c] = Sc.diagonal(dim1=1, dim2=2)
+                sum_xx += (xb_b[:, :, None] * xb_b[:, None, :]).sum(0)
+                sum_S += Sc.sum(0)
+                del X, Sc
             partial[0] = float(Cn)
             o = 1
-            for blk in (xbm.sum(0), (xbm[:, :, None] * xbm[:, None, :]).sum(0).reshape(-1), Sc.sum(0).reshape(-1), s2.sum(0), (s2 * s2).sum(0),
+            for blk in (xbm.sum(0), sum_xx.reshape(-1), sum_S.reshape(-1), s2.sum(0), (s2 * s2).sum(0),
                         (s2 * xbm).sum(0), (s2 * xbm * xbm).sum(0)):
                 partial[o:o + blk.numel()] = blk
                 o += blk.numel()

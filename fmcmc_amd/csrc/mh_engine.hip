@@ -789,6 +789,22 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
     const int rcl = try_long(kfn, lds, est_now, false);
     if (rcl != FMCMC_OK) return rcl;
   }
+  // the operand-order copy of the observation slots beyond the registers (EXT / adaptive MFMA forms): 4 ng doubles per streamed
+  // observation -- for p = 1 several times the size of X.  When the device cannot give that memory the call still runs: on
+  // the general streamed kernel, which needs none
+  if (!launched_long && mfma_ng && mfma_ext) {
+    const int ns_all = (int)((m->n + NT - 1) / NT), next = ns_all - mfma_ext;
+    double* mfs = nullptr;
+    const size_t nd = (size_t)NW * next * mfma_ng * 64 * 4;
+    if (hipMallocAsync((void**)&mfs, sizeof(double) * nd, stream) != hipSuccess) {
+      (void)hipGetLastError();
+      mfma_ng = 0; mfma_ext = 0; mfma_ad = 0; pipe_opt = 0; lat_normal = false;
+    } else {
+      mfs_guard.p = mfs; mfs_guard.s = stream;
+      hipLaunchKernelGGL(mfma_build_stream, dim3(512), dim3(256), 0, stream, m->X, m->y, (long long)m->n, m->p, mfma_ng, mfma_ext, next, mfs);
+      A.mf_stream = mfs; A.mf_next = next;
+    }
+  }
   if (launched_long) {
   } else
   if (pipe_opt || mfma_ng) {
@@ -824,16 +840,6 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
       e = hipMallocAsync((void**)&ws, sizeof(double) * items * (size_t)(A.kz + 1), stream);
       if (e != hipSuccess) { set_err("hipMallocAsync(rng stream) failed: %s", hipGetErrorString(e)); return FMCMC_ERR_DEVICE; }
       ws_guard.p = ws; ws_guard.s = stream;
-    }
-    if (mfma_ng && mfma_ext) {
-      const int ns_all = (int)((m->n + NT - 1) / NT), next = ns_all - mfma_ext;
-      double* mfs = nullptr;
-      const size_t nd = (size_t)NW * next * mfma_ng * 64 * 4;
-      e = hipMallocAsync((void**)&mfs, sizeof(double) * nd, stream);
-      if (e != hipSuccess) { set_err("hipMallocAsync(operand stream) failed: %s", hipGetErrorString(e)); return FMCMC_ERR_DEVICE; }
-      mfs_guard.p = mfs; mfs_guard.s = stream;
-      hipLaunchKernelGGL(mfma_build_stream, dim3(512), dim3(256), 0, stream, m->X, m->y, (long long)m->n, m->p, mfma_ng, mfma_ext, next, mfs);
-      A.mf_stream = mfs; A.mf_next = next;
     }
     auto fill_stream = [&](SweepArgs& W, long long step_base_eff) {   // the stream of launch W, rows = W.nsteps
       const size_t items = (size_t)W.nchains * (size_t)W.nsteps;
@@ -1140,6 +1146,14 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
   else { g_kernel = "streamed"; e = launch_k(fmh::k_general(cw), nblk, NT, lds, stream, A); }
   if (e == hipSuccess) e = hipGetLastError();
   if (e != hipSuccess) { set_err("HIP launch failed: %s", hipGetErrorString(e)); return FMCMC_ERR_DEVICE; }
+  // timing ablations and stamps (knob mode=<bits>: 8 stamps in the draws buffer, 32 / 64 / 128 / 1024 parts of a step left out)
+  // produce INVALID samples: a call made with one of them says so in fmcmc_last_kernel(), so that its results cannot pass for
+  // a product run's
+  if (K.mode & (8 | 32 | 64 | 128 | 1024)) {
+    static thread_local char kbuf[96];
+    snprintf(kbuf, sizeof(kbuf), "invalid-results(mode=%d):%s", K.mode, g_kernel);
+    g_kernel = kbuf;
+  }
   return FMCMC_OK;
 }
 

@@ -541,7 +541,7 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
         zcur = z_nx;
         z_nx = rl ? ld_z(v + 1 < nsteps ? v + 1 : nsteps - 1) : 0.0;
         if (KIND == FMCMC_KERNEL_ADAPT) {
-          if (A.until > (double)abs_iter && abs_iter > A.warmup && i + ioff > 2 && !(A.debug & 4096)) {   // R/kernel_adapt.R:118-166 (4096: timing ablation)
+          if (A.until > (double)abs_iter && abs_iter > A.warmup && i + ioff > 2) {   // R/kernel_adapt.R:118-166
             const double t = (double)(abs_iter - 1);
             const double x = th0;
             const double mp = have_mean ? mean_prev : (run_sum / (double)(i + ioff - 1));
@@ -563,7 +563,6 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
           SPEC_ST(3);
           // left-looking Cholesky: column j, lane = row (twin of oracle chol_lower_canon)
           bool notpd = false;
-          if (!(A.debug & 2048))      // (2048: timing ablation -- no factorisation at all, results invalid: the ceiling of any cheaper factor)
 #pragma unroll
           for (int j = 0; j < KA; j++) {
             if (j < kf && !notpd) {

@@ -1481,7 +1481,7 @@ def test_a_call_longer_than_4_gib_of_samples_stays_on_the_headline_kernel(E, mon
     left mh_sweep_mfma for the general kernel at the 4 GiB limit of its 32-bit offsets and of its materialised RNG stream.
     Now: (a) it runs on "mfma"; (b) the size-independent properties of the 10^4-step test hold (rows follow the accept bits,
     counts are popcounts); (c) a 64-chain shard with the same chain ids equals the general kernel (knob streamed=1) bit for
-    bit; (d) the time per step is within 3 % of a 10^4-step call's (HIP events, best of three)."""
+    bit.  (The time per step against a 10^4-step call's: tests/test_gpu_perf_guard.py.)"""
     import torch
     from fmcmc_amd import _abi as abi
     import bench
@@ -1501,8 +1501,6 @@ def test_a_call_longer_than_4_gib_of_samples_stays_on_the_headline_kernel(E, mon
         torch.cuda.synchronize()
         return r, st, e0.elapsed_time(e1) * 1e3 / nsteps
 
-    short_us = min(timed(10000, want_bits=False)[2] for _ in range(3))
-    long_us = min(timed(iters, want_bits=False)[2] for _ in range(3))              # (the first one also loads the kernel's code)
     full, st_full, _ = timed(iters)
     assert abi.last_kernel() == "mfma"                                             # (a)
     assert full.samples.numel() * 8 > (4 << 30)
@@ -1526,10 +1524,7 @@ def test_a_call_longer_than_4_gib_of_samples_stays_on_the_headline_kernel(E, mon
         assert torch.equal(getattr(part, name), getattr(full, name)[448:512]), name
     assert torch.equal(st_part.theta0, st_full.theta0[448:512]) and torch.equal(st_part.f0, st_full.f0[448:512])
     del part
-    # (d) no cliff
-    # (a timing bound has no place beside bitwise assertions on a shared box: 10 % here only catches a fall to another
-    #  kernel class -- the general kernel is 2.5-6.5x slower; the 3 % figure of DESIGN 5.6 is tools/bench_long.py's)
-    assert long_us <= 1.10 * short_us, "%.3f us per step at 1.2e5 steps, %.3f at 1e4" % (long_us, short_us)
+    # ((d), the time per step of the long call against a 10^4-step call, lives in tests/test_gpu_perf_guard.py)
 
 
 @pytest.mark.parametrize("window", ["32", "96"])

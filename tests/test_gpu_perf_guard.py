@@ -59,3 +59,45 @@ def test_time_per_iteration_within_125_percent_of_the_record(name):
     assert name in rec, "no record for %s in profiles/perf_guard.json" % name
     limit = 1.25 * rec[name]["us_per_iteration"]
     assert us <= limit, "%s: %.2f us per MH iteration, the record is %.2f (limit %.2f)" % (name, us, rec[name]["us_per_iteration"], limit)
+
+
+@pytest.mark.parametrize("name,iters,kernel", [("c2", 120000, "mfma"), ("c3", 300000, "spec")])
+def test_a_long_call_costs_per_step_what_a_short_one_does(name, iters, kernel):
+    """No cliff with the length of a call: 1024 chains x 1.2e5 steps of kernel_normal (4.9 GB of samples) and 1024 chains x 3e5
+    steps of kernel_adapt (a stream of 14.7 GB if it were materialised whole: until round 5 such a call left mh_sweep_spec for
+    the general kernel at 8 GiB, ~6x the time per step) stay on their kernels, in step windows, within 3 % of the time per step
+    of a 10^4-step call (HIP events, best of three; rows and draws are not recorded for the adaptive call: thin = 100).
+    R/mcmc.R:749-783 is one loop of any length."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    if torch.cuda.get_device_properties(0).multi_processor_count < 256:
+        pytest.skip("a whole MI355X (256 CUs)")
+    sys.path.insert(0, ROOT)
+    import bench
+    from fmcmc_amd import engine as E, _abi as abi
+    cfg = bench.Config(name)
+    X, y, init = cfg.workload(cfg.chains, 0)
+    gm, gk = bench.device_objects(cfg, E, abi, X, y, torch.device("cuda", 0))
+    thin = 1 if name == "c2" else 100
+
+    def us_per_step(nsteps):
+        best = float("inf")
+        for _ in range(3):
+            st = E.ChainState(init, cfg.k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            r = E.sweep(gm, gk, st, nsteps, thin=thin, seed=bench.CHAIN_SEED, want_bits=False, want_draws=(name == "c2"), check=False)
+            e1.record()
+            torch.cuda.synchronize()
+            assert int(r.status.abs().sum().item()) == 0
+            del r
+            best = min(best, e0.elapsed_time(e1) * 1e3 / nsteps)
+        return best
+
+    short = us_per_step(10000)
+    assert abi.last_kernel() == kernel
+    long_ = us_per_step(iters)
+    assert abi.last_kernel() == kernel, "a call of %d steps left '%s' for '%s'" % (iters, kernel, abi.last_kernel())
+    assert long_ <= 1.03 * short, "%s: %.3f us per step at %d steps, %.3f at 1e4" % (name, long_, iters, short)

@@ -15,7 +15,7 @@ gk = E.KernelSpec(1, 5, np.zeros(5), np.full(5, .02), np.full(5, -E.DBL_MAX), np
 st = E.ChainState(init, 5)
 r = E.sweep(gm, gk, st, nsteps, want_draws=True, check=False)
 torch.cuda.synchronize()
-kn = abi.last_kernel()
+kn = abi.last_kernel().split(":")[-1]
 cw = int(kn[-1]) if kn.startswith("spec-lat") else 4
 nb = (C + cw - 1) // cw
 d = r.draws.reshape(-1)[: nb * 12 * 4].cpu().numpy().reshape(nb, 12, 4)
