@@ -240,18 +240,19 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
             have_mean = 1;
           }
           abs_iter += 1;
+          // root-free factor Sigma = L D L^T (twin of the oracle's ldl_lower_canon): L in the lower triangle of SigB, the numerators
+          // W_ib = L_ib D_b in its upper one (W_ib at [b][i]), D in vv (the x of the covariance update is done with)
           bool notpd = false;
           for (int j = 0; j < kf; j++) {
             double sacc = 0.0;
             if (lane >= j && lane < kf) {
               sacc = SigA[lane * LD + j];
-              for (int b = 0; b < j; b++) sacc = fmh_fma(-SigB[lane * LD + b], SigB[j * LD + b], sacc);
+              for (int b = 0; b < j; b++) sacc = fmh_fma(-SigB[lane * LD + b], SigB[b * LD + j], sacc);
             }
             double d = shfl_d(sacc, j);
             if (!(d > 0.0) || !fmh_isfinite(d)) { notpd = true; break; }
-            double ljj = fmh_sqrt(d);
-            if (lane == j) SigB[j * LD + j] = ljj;
-            else if (lane > j && lane < kf) SigB[lane * LD + j] = sacc / ljj;
+            if (lane == j) { SigB[j * LD + j] = 1.0; vv[j] = d; }
+            else if (lane > j && lane < kf) { SigB[lane * LD + j] = sacc / d; SigB[j * LD + lane] = sacc; }
             wave_sync_lds();
           }
           if (notpd) {
@@ -261,6 +262,7 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
             if (((v - 1) & 31) != 31) flush_bits(v);   // (the accept bits of the steps decided so far; a full word has just been flushed)
           } else {
             if (lane < k) th1[lane] = th0[lane];
+            if (lane < kf) vz[lane] = fmh_sqrt(vv[lane]) * vz[lane];    // u = sqrt(D) z
             wave_sync_lds();
             if (lane < kf) {
               double sacc = 0.0;
@@ -363,8 +365,11 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
   const bool rl = lane < k;                 // row lane == parameter lane (no fixed parameters)
   const int jl = rl ? lane : 0;
   const double mu_l = A.mu[jl], lb_l = A.lb[jl], ub_l = A.ub[jl];
-  double Srow[KA], Lrow[KA];                // Sigma (adapt) or S (ram) row `lane`; Cholesky factor row (adapt)
+  double Srow[KA], Lrow[KA];                // Sigma (adapt) or S (ram) row `lane`; row of the unit lower factor L (adapt)
+  double Wrow[KIND == FMCMC_KERNEL_ADAPT ? KA : 1];   // adapt: the numerators W_ib = L_ib D_b of the factor's row
   double (&Grow)[KA] = Lrow;                // ram: G_ib, the partial sums of the proposal's (S z)_lane chain
+#pragma unroll
+  for (int b = 0; b < (KIND == FMCMC_KERNEL_ADAPT ? KA : 1); b++) Wrow[b] = 0.0;
 #pragma unroll
   for (int b = 0; b < KA; b++) {
     Lrow[b] = 0.0;
@@ -561,23 +566,28 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
           }
           abs_iter += 1;
           SPEC_ST(3);
-          // left-looking Cholesky: column j, lane = row (twin of oracle chol_lower_canon)
+          // root-free factor Sigma = L D L^T, left-looking: column j, lane = row (twin of the oracle's ldl_lower_canon; round 5).  The
+          // Cholesky factor it replaces put a square root AND a division into every column's dependent chain (5 x ~27 of the
+          // owner's ~550 vector instructions at k = 5); here a column is its fma chain and one division, W = the numerators
+          // before the division stand in for L D in the sums, and sqrt(D) is one element-wise square root at proposal time.
           bool notpd = false;
+          double Dl = 0.0;                    // D_lane
 #pragma unroll
           for (int j = 0; j < KA; j++) {
             if (j < kf && !notpd) {
               double sacc = Srow[j];
 #pragma unroll
-              for (int b = 0; b < j; b++) sacc = fmh_fma(-Lrow[b], readlane_d(Lrow[b], j), sacc);
+              for (int b = 0; b < j; b++) sacc = fmh_fma(-Lrow[b], readlane_d(Wrow[KIND == FMCMC_KERNEL_ADAPT ? b : 0], j), sacc);
               const double d = readlane_d(sacc, j);
               if (!(d > 0.0) || !fmh_isfinite(d)) {
                 notpd = true;
               } else {
                 // selects, not exec-mask regions: every `if (lane ...)` costs three scalar instructions and a branch, and
                 // the owner's rate is its instruction count (rows above j keep their 0)
-                const double ljj = fmh_sqrt(d);
-                const double qj = sacc / ljj;
-                Lrow[j] = (lane == j) ? ljj : ((lane > j) ? qj : Lrow[j]);
+                const double qj = sacc / d;
+                Lrow[j] = (lane == j) ? 1.0 : ((lane > j) ? qj : Lrow[j]);
+                Wrow[KIND == FMCMC_KERNEL_ADAPT ? j : 0] = sacc;
+                Dl = (lane == j) ? d : Dl;
               }
             }
           }
@@ -588,10 +598,11 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
             if (rl) A.status_theta[(long long)cl * k + lane] = th1;
             if (((v - 1) & 31) != 31) flush_bits(v);   // (the accept bits of the steps decided so far; a full word has just been flushed)
           } else {
+            const double ul = fmh_sqrt(Dl) * zcur;    // (beyond the parameters: D = 0, z = 0)
             double sacc = 0.0;
 #pragma unroll
             for (int b = 0; b < KA; b++)   // (row `lane` of the factor is 0 beyond its diagonal and sacc starts at +0: the terms
-              if (b < kf) { const double zb = readlane_d(zcur, b); sacc = fmh_fma(Lrow[b], zb, sacc); }   // b > lane add +-0 exactly)
+              if (b < kf) { const double ub_ = readlane_d(ul, b); sacc = fmh_fma(Lrow[b], ub_, sacc); }   // b > lane add +-0 exactly)
             th1 = reflect1(th0 + (mu_l + sacc), lb_l, ub_l);
           }
         } else {  // RAM P1 (R/kernel_ram.R:123-126)

@@ -553,29 +553,30 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
           }
         }
         abs_iter += 1;
-        // left-looking Cholesky, lane = row (twin of oracle chol_lower_canon)
+        // root-free factor Sigma = L D L^T, left-looking, lane = row (twin of the oracle's ldl_lower_canon): L in the lower triangle of
+        // SigB, the numerators W_ib = L_ib D_b in its upper one (W_ib at [b][i]), D in vv
         bool notpd = false;
         for (int j = 0; j < kf && status == FMCMC_CHAIN_OK; j++) {
           double s = 0.0;
           if (lane >= j && lane < kf) {
             s = L.SigA[lane * LD + j];
-            for (int b = 0; b < j; b++) s = fmh_fma(-L.SigB[lane * LD + b], L.SigB[j * LD + b], s);
+            for (int b = 0; b < j; b++) s = fmh_fma(-L.SigB[lane * LD + b], L.SigB[b * LD + j], s);
           }
           double d = shfl_d(s, j);
           if (!(d > 0.0) || !fmh_isfinite(d)) { notpd = true; break; }
-          double ljj = fmh_sqrt(d);
-          if (lane == j) L.SigB[j * LD + j] = ljj;
-          else if (lane > j && lane < kf) L.SigB[lane * LD + j] = s / ljj;
+          if (lane == j) { L.SigB[j * LD + j] = 1.0; L.vv[j] = d; }
+          else if (lane > j && lane < kf) { L.SigB[lane * LD + j] = s / d; L.SigB[j * LD + lane] = s; }
           wave_sync_lds();
         }
         if (notpd) {
           status = FMCMC_CHAIN_NOT_PD;
         } else if (status == FMCMC_CHAIN_OK) {
           if (lane < k) L.th1[lane] = L.th0[lane];
+          if (lane < kf) L.vz[lane] = fmh_sqrt(L.vv[lane]) * zt[lane];    // u = sqrt(D) z
           wave_sync_lds();
           if (lane < kf) {
             double s = 0.0;
-            for (int b = 0; b <= lane; b++) s = fmh_fma(L.SigB[lane * LD + b], zt[b], s);
+            for (int b = 0; b <= lane; b++) s = fmh_fma(L.SigB[lane * LD + b], L.vz[b], s);
             int j = s_which[lane];
             double t = L.th0[j] + (s_mu[j] + s);
             L.th1[j] = reflect1(t, s_lb[j], s_ub[j]);

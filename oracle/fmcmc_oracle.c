@@ -351,6 +351,29 @@ static int chol_lower_canon(const double* A, double* L, int k) {
   }
   return 0;
 }
+/* Root-free factor Sigma = L D L^T (L unit lower, row-major; D the pivots), canonical op order -- the factor kernel_adapt's
+ * canonical proposal draws through for k <= 64 parameters since round 5 (theta1 = theta0 + mu + L sqrt(D) z: the same law as
+ * MASS::mvrnorm's eigen-factor and as the Cholesky factor it replaces, R/kernel_adapt.R:173-180).  W_ib = the numerator of
+ * L_ib before its division (= L_ib D_b up to rounding) is what the sums subtract, so a column costs one division and no
+ * square root; sqrt(D) is taken once, element-wise, at proposal time.  Returns 0 ok, 1 not positive definite. */
+static int ldl_lower_canon(const double* A, double* L, double* D, int k) {
+  static __thread double W[MAXK * MAXK];
+  for (int a = 0; a < k * k; a++) L[a] = 0.0;
+  for (int j = 0; j < k; j++) {
+    double d = A[j * k + j];
+    for (int b = 0; b < j; b++) d = fmh_fma(-L[j * k + b], W[j * k + b], d);
+    if (!(d > 0.0) || !fmh_isfinite(d)) return 1;
+    D[j] = d;
+    L[j * k + j] = 1.0;
+    for (int i = j + 1; i < k; i++) {
+      double s = A[i * k + j];
+      for (int b = 0; b < j; b++) s = fmh_fma(-L[i * k + b], W[j * k + b], s);
+      W[i * k + j] = s;
+      L[i * k + j] = s / d;
+    }
+  }
+  return 0;
+}
 /* plain (no fma) lower Cholesky for the R-faithful mode */
 static int chol_lower_plain(const double* A, double* L, int k) {
   for (int a = 0; a < k * k; a++) L[a] = 0.0;
@@ -638,11 +661,22 @@ static int propose_adapt(const ocfg* cfg, const fmcmc_kernel* kn, kstate* ks, in
     }
   } else {
     double L[MAXK * MAXK];
-    if (chol_lower_canon(ks->Sigma, L, kf)) return FMCMC_CHAIN_NOT_PD;
-    for (int a = 0; a < kf; a++) {
-      double s = 0.0;
-      for (int b = 0; b <= a; b++) s = fmh_fma(L[a * kf + b], z[b], s);
-      delta[a] = kn->mu[ks->which[a]] + s;
+    if (kn->k > 64) {   /* (more parameters than a wavefront has lanes: the one-workgroup-per-chain kernel keeps the Cholesky factor) */
+      if (chol_lower_canon(ks->Sigma, L, kf)) return FMCMC_CHAIN_NOT_PD;
+      for (int a = 0; a < kf; a++) {
+        double s = 0.0;
+        for (int b = 0; b <= a; b++) s = fmh_fma(L[a * kf + b], z[b], s);
+        delta[a] = kn->mu[ks->which[a]] + s;
+      }
+    } else {
+      double D[MAXK], u[MAXK];
+      if (ldl_lower_canon(ks->Sigma, L, D, kf)) return FMCMC_CHAIN_NOT_PD;
+      for (int a = 0; a < kf; a++) u[a] = fmh_sqrt(D[a]) * z[a];
+      for (int a = 0; a < kf; a++) {
+        double s = 0.0;
+        for (int b = 0; b <= a; b++) s = fmh_fma(L[a * kf + b], u[b], s);   /* (L_aa = 1) */
+        delta[a] = kn->mu[ks->which[a]] + s;
+      }
     }
   }
   for (int a = 0; a < kn->k; a++) theta1[a] = theta0[a];
