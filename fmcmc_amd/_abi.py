@@ -15,7 +15,7 @@ KERNEL_NMIRROR, KERNEL_UMIRROR = 7, 8
 MIRROR_KERNELS = (KERNEL_NMIRROR, KERNEL_UMIRROR)
 SIMPLE_KERNELS = (KERNEL_NORMAL, KERNEL_NORMAL_REFLECTIVE, KERNEL_UNIF, KERNEL_UNIF_REFLECTIVE) + MIRROR_KERNELS
 SCHEME_JOINT, SCHEME_ORDERED, SCHEME_RANDOM, SCHEME_EXPLICIT = 0, 1, 2, 3
-ABI_VERSION = 5
+ABI_VERSION = 6
 RNG_PHILOX, RNG_FED = 0, 1
 OK, ERR_ARG, ERR_DEVICE, ERR_CHAIN, ERR_UNSUPPORTED = 0, 1, 2, 3, 4
 CHAIN_OK, CHAIN_NAN_LOGPOST, CHAIN_NAN_RATIO, CHAIN_NOT_PD, CHAIN_BAD_WINDOW, CHAIN_SYNC_TIMEOUT = 0, 1, 2, 3, 4, 5

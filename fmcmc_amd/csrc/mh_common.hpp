@@ -43,7 +43,7 @@ struct SweepArgs {
   int nadapt;                // mirror kernels: abs_iter of the one-off scale adaptation
   double* mirror_mu;         // [C][k] in/out
   double* mirror_scale;      // [C][k] in/out
-  double* obs_arate;         // [C] out (in when continuing)
+  double* obs_arate;         // [C][k] out (in when continuing)
   int bw;                    // adapt: window (0 = recursive)
   int hist_rows;             // adapt with bw > 0 / freq > 1: rows of the ring below (max(freq, bw - 1)), else 0
   double Sd;                 // adapt, bw > 0

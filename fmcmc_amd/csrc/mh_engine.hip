@@ -366,7 +366,7 @@ static SweepArgs chain_window(const SweepArgs& A, long long off, long long cnt, 
   const long long k = A.k, S = A.ldS, ns = A.nsteps, words = (A.nsteps + 31) >> 5;
   W.nchains = cnt; W.chain_base = A.chain_base + off;
 #define ADV(f, stride) if (W.f) W.f += off * (stride)
-  ADV(scheme_cols, ns); ADV(mirror_mu, k); ADV(mirror_scale, k); ADV(obs_arate, 1);
+  ADV(scheme_cols, ns); ADV(mirror_mu, k); ADV(mirror_scale, k); ADV(obs_arate, k);
   ADV(hist, (long long)A.hist_rows * kf);
   ADV(fed_logu, ns); ADV(fed_z, ns * A.kz);
   ADV(win_sum, kf); ADV(theta0, k); ADV(f0, 1); ADV(abs_iter, 1); ADV(Sigma, (long long)kf * kf); ADV(mean_prev, kf); ADV(have_mean, 1); ADV(nerrors, 1);
@@ -1294,7 +1294,7 @@ int fmcmc_mcmc_run_host(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcm
     UP(ds.abs_iter, st->fresh ? nullptr : st->abs_iter, sizeof(int64_t) * (size_t)C);
     UP(ds.mirror_mu, st->fresh ? nullptr : st->mirror_mu, sizeof(double) * (size_t)C * k);
     UP(ds.mirror_scale, st->fresh ? nullptr : st->mirror_scale, sizeof(double) * (size_t)C * k);
-    UP(ds.obs_arate, st->fresh ? nullptr : st->obs_arate, sizeof(double) * (size_t)C);
+    UP(ds.obs_arate, st->fresh ? nullptr : st->obs_arate, sizeof(double) * (size_t)C * k);
   }
   if (adaptive) {
     UP(ds.abs_iter, st->fresh ? nullptr : st->abs_iter, sizeof(int64_t) * (size_t)C);
@@ -1324,7 +1324,7 @@ int fmcmc_mcmc_run_host(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcm
     DOWN(st->abs_iter, ds.abs_iter, sizeof(int64_t) * (size_t)C);
     DOWN(st->mirror_mu, ds.mirror_mu, sizeof(double) * (size_t)C * k);
     DOWN(st->mirror_scale, ds.mirror_scale, sizeof(double) * (size_t)C * k);
-    DOWN(st->obs_arate, ds.obs_arate, sizeof(double) * (size_t)C);
+    DOWN(st->obs_arate, ds.obs_arate, sizeof(double) * (size_t)C * k);
   }
   if (adaptive) {
     DOWN(st->abs_iter, ds.abs_iter, sizeof(int64_t) * (size_t)C);

@@ -73,9 +73,9 @@ __device__ __forceinline__ void mfma_owner_mirror(const SweepArgs& A, int myc, i
   double th0 = rl ? A.theta0[(long long)cl * k + lane] : 0.0, th1 = th0;
   double mmu = rl ? (A.fresh ? A.mu[jl] : A.mirror_mu[(long long)cl * k + jl]) : 0.0;
   double msc = rl ? (A.fresh ? A.scale[jl] : A.mirror_scale[(long long)cl * k + jl]) : 0.0;
-  double f0 = 0.0, obs_arate = fmh_nan();
+  double f0 = 0.0, obs_arate = fmh_nan(), th_prev = 0.0;   // (obs_arate: lane = parameter -- R's turns into a k-vector through warm-up; th_prev: ans[i-2, ])
   long long abs_iter = 0, nzero = 0;
-  if (!A.fresh) { abs_iter = A.abs_iter[cl]; obs_arate = A.obs_arate[cl]; }
+  if (!A.fresh) { abs_iter = A.abs_iter[cl]; obs_arate = A.obs_arate[(long long)cl * k + jl]; }
   int nacc = 0, status = FMCMC_CHAIN_OK, thin_ctr = 0;
   unsigned int bitword = 0;
   char* const s_base = reinterpret_cast<char*>(A.samples) + ((long long)cl * k) * A.ldS * 8;
@@ -128,6 +128,7 @@ __device__ __forceinline__ void mfma_owner_mirror(const SweepArgs& A, int myc, i
         const double lu = lu_nx;
         lu_nx = lu_row[v < nsteps ? v : nsteps - 1];
         bool moved = false;
+        th_prev = th0;                          // (row i - 1, the row before the one decided now)
         if (lu < ratio) {
           const double d = th1 - th0;           // rowSums(diff(ans)^2) of the row about to be stored: the sequential sum of the oracle
           double sq = 0.0;
@@ -155,6 +156,10 @@ __device__ __forceinline__ void mfma_owner_mirror(const SweepArgs& A, int myc, i
           const double num = fmh_tan_0_halfpi(1.5707963267948966 * obs_arate);
           const double den = fmh_tan_0_halfpi(1.5707963267948966 * A.arate);
           msc = msc * num / den;
+        } else if (abs_iter > A.nadapt && abs_iter <= A.warmup) {
+          // obs_arate <<- mean_recursive(as.double(ans[i-1, ] != ans[i-2, ]), obs_arate, abs_iter), element-wise (R/kernel_mirror.R:108-118,
+          // :246-253); the first proposal of a call has no ans[i-2, ]: numeric(0) in R, NaN here (twin of the oracle's propose_mirror)
+          obs_arate = (i < 3) ? fmh_nan() : (obs_arate * (double)abs_iter + ((th0 != th_prev) ? 1.0 : 0.0)) / ((double)abs_iter + 1);
         }
         double t;
         if (KIND == FMCMC_KERNEL_NMIRROR) {
@@ -186,13 +191,13 @@ __device__ __forceinline__ void mfma_owner_mirror(const SweepArgs& A, int myc, i
     A.theta0[(long long)cl * k + lane] = th0;
     A.mirror_mu[(long long)cl * k + lane] = mmu;
     A.mirror_scale[(long long)cl * k + lane] = msc;
+    A.obs_arate[(long long)cl * k + lane] = obs_arate;
   }
   if (lane == 0) {
     A.f0[cl] = f0;
     A.accept_count[cl] = nacc;
     if (status == FMCMC_CHAIN_OK) { A.status[cl] = FMCMC_CHAIN_OK; A.status_step[cl] = 0; }
     A.abs_iter[cl] = abs_iter;
-    A.obs_arate[cl] = obs_arate;
   }
 }
 

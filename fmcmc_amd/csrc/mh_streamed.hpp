@@ -285,7 +285,8 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
   int have_mean = 0, nerr = 0, status = FMCMC_CHAIN_OK;
   unsigned int bitword = 0;
   const bool mirror = (A.kind == FMCMC_KERNEL_NMIRROR || A.kind == FMCMC_KERNEL_UMIRROR);
-  double obs_arate = fmh_nan();   // mirror kernels
+  double obs_arate = fmh_nan();   // mirror kernels: lane = parameter (R's obs_arate turns into a k-vector through warm-up); th_prev: ans[i-2, ]
+  double th_prev = 0.0;
   long long nzero = 0;            // rows 2..i-1 of this call equal to their predecessor (rowSums(diff(ans)^2) == 0)
   double* const Scur = L.SigA;   // ram: the factor S
 
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
         L.mmu[lane] = A.fresh ? A.mu[lane] : A.mirror_mu[cl * k + lane];
         L.msc[lane] = A.fresh ? A.scale[lane] : A.mirror_scale[cl * k + lane];
       }
-      if (!A.fresh) { abs_iter = A.abs_iter[cl]; obs_arate = A.obs_arate[cl]; }
+      if (!A.fresh) { abs_iter = A.abs_iter[cl]; obs_arate = A.obs_arate[cl * k + (lane < k ? lane : 0)]; }
     }
     if (adaptive) {
       if (A.fresh) {
@@ -450,6 +451,11 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
           const double num = fmh_tan_0_halfpi(1.5707963267948966 * obs_arate);
           const double den = fmh_tan_0_halfpi(1.5707963267948966 * A.arate);
           if (lane < k) L.msc[lane] = L.msc[lane] * num / den;
+        } else if (abs_iter > A.nadapt && abs_iter <= A.warmup) {
+          // obs_arate <<- mean_recursive(as.double(ans[i-1, ] != ans[i-2, ]), obs_arate, abs_iter), element-wise (R/kernel_mirror.R:108-118);
+          // the first proposal of a call has no ans[i-2, ]: numeric(0) in R, NaN here (twin of the oracle's propose_mirror)
+          const double xt = (lane < k && L.th0[lane] != th_prev) ? 1.0 : 0.0;
+          obs_arate = (i < 3) ? fmh_nan() : (obs_arate * (double)abs_iter + xt) / ((double)abs_iter + 1);
         }
         if (lane < k) L.th1[lane] = L.th0[lane];
         wave_sync_lds();
@@ -689,6 +695,7 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
       } else {
         const double lu = s_lu[myc * TB + tt];
         bool moved = false;
+        if (mirror && lane < k) th_prev = L.th0[lane];     // (row i - 1, the row before the one decided now)
         if (lu < ratio) {
           if (mirror) {   // rowSums(diff(ans)^2) of the row about to be stored (sequential sum, as in the oracle)
             double sq = 0.0;
@@ -730,7 +737,7 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
       //  found by the forced fault of test_a_lost_hand_over_ends_in_status_5_not_in_a_hang)
       if (sh_epoch & 0x80000000u) { A.status[cl] = FMCMC_CHAIN_SYNC_TIMEOUT; A.status_step[cl] = 0; }
       else if (status == FMCMC_CHAIN_OK) { A.status[cl] = FMCMC_CHAIN_OK; A.status_step[cl] = 0; }
-      if (mirror) { A.abs_iter[cl] = abs_iter; A.obs_arate[cl] = obs_arate; }
+      if (mirror) A.abs_iter[cl] = abs_iter;
       if (adaptive) {
         A.abs_iter[cl] = abs_iter;
         if (A.nerrors) A.nerrors[cl] = nerr;
@@ -740,6 +747,7 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
     if (mirror && lane < k) {
       A.mirror_mu[cl * k + lane] = L.mmu[lane];
       A.mirror_scale[cl * k + lane] = L.msc[lane];
+      A.obs_arate[cl * k + lane] = obs_arate;
     }
     if (adaptive) {
       wave_sync_lds();

@@ -134,7 +134,7 @@ class ChainState:
         k = self.theta0.shape[1]
         self.mirror_mu = torch.zeros(Cn, k, dtype=torch.float64, **z)      # mirror kernels: adapted mean / scale
         self.mirror_scale = torch.zeros(Cn, k, dtype=torch.float64, **z)
-        self.obs_arate = torch.full((Cn,), float("nan"), dtype=torch.float64, **z)
+        self.obs_arate = torch.full((Cn, k), float("nan"), dtype=torch.float64, **z)   # (R's obs_arate: a k-vector after warm-up updates)
         self.fresh = 1
         self.step_base = 0
 

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FMCMC_ABI_VERSION 5
+#define FMCMC_ABI_VERSION 6
 #define FMCMC_MAX_K 128 /* parameters per chain supported by the device kernels (R/kernel_ram.R:93-121, R/kernel_adapt.R:87-115: any k) */
 /* Up to FMCMC_MAX_K_WAVE parameters a chain's rows live in the lanes of one wavefront and every kernel, scheme and option is
  * available; from there to FMCMC_MAX_K one workgroup serves a chain (mh_sweep_bigk): kernel_normal(_reflective) /
@@ -177,8 +177,10 @@ typedef struct fmcmc_state {
    * the plan of the kernel's first call -- written here when non-NULL.  FED mode: read from here (the caller
    * replays R's sample()).  [C][nsteps] int32, or NULL. */
   int32_t* scheme_cols;
-  /* mirror kernels: the adapted mean and scale of every chain, [C][k] each, and the observed acceptance rate the one-off
-   * adaptation used, [C] (NaN before it happened); fresh == 1: initialised from kernel->mu / kernel->scale. */
+  /* mirror kernels: the adapted mean and scale of every chain, [C][k] each, and obs_arate, [C][k] (ABI 6; was [C]): NaN before
+   * the one-off adaptation, the observed acceptance rate it used in all k entries after it, then -- through the rest of the
+   * warm-up -- R's element-wise running mean of (ans[i-1, ] != ans[i-2, ]) (R/kernel_mirror.R:108-118,:246-253: the closure's
+   * scalar turns into a k-vector there).  fresh == 1: mu / scale initialised from kernel->mu / kernel->scale. */
   double* mirror_mu;
   double* mirror_scale;
   double* obs_arate;

@@ -465,7 +465,8 @@ typedef struct {
   const int32_t* cols;         /* scheme = "random": plan of this chain, entry i-1 = column of loop step i */
   const double* hist;          /* adapt with bw > 0 / freq > 1: env$ans[, which.] of THIS call, row r at hist + (r-1)*kf */
   double mmu[MAXK], msc[MAXK]; /* mirror kernels: adapted mean / scale (all k parameters) */
-  double obs_arate;
+  double obs_arate[MAXK];      /* R's obs_arate: a scalar (all k entries equal) after the one-off adaptation, element-wise afterwards */
+  double prev_row[MAXK];       /* ans[i - 2, ] of this call (the row before theta0) */
   int64_t nzero;               /* rows r = 2..i-1 of this call with sum(diff(ans)[r-1, ]^2) == 0 */
 } kstate;
 
@@ -532,16 +533,23 @@ static void propose_mirror(const ocfg* cfg, const fmcmc_kernel* kn, kstate* ks, 
   if (a_it == kn->nadapt) {
     /* obs_arate <<- 1 - mean(rowSums(diff(ans[1:(i-1), ])^2) == 0) :103-107 (mean of zero rows is NaN);
      * scale <<- scale * tan(pi/2 obs_arate) / tan(pi/2 arate) :121-127 */
-    ks->obs_arate = 1.0 - (double)ks->nzero / (double)(i - 2);
+    const double oa = 1.0 - (double)ks->nzero / (double)(i - 2);
+    for (int a = 0; a < k; a++) ks->obs_arate[a] = oa;
     double num, den;
     if (cfg->math_mode == ORACLE_MATH_R) {
-      num = tan(M_PI / 2.0 * ks->obs_arate);
+      num = tan(M_PI / 2.0 * oa);
       den = tan(M_PI / 2.0 * kn->arate);
     } else {
-      num = fmh_tan_0_halfpi(1.5707963267948966 * ks->obs_arate);
+      num = fmh_tan_0_halfpi(1.5707963267948966 * oa);
       den = fmh_tan_0_halfpi(1.5707963267948966 * kn->arate);
     }
     for (int a = 0; a < k; a++) ks->msc[a] = ks->msc[a] * num / den;
+  } else if (a_it > kn->nadapt && a_it <= kn->warmup) {
+    /* obs_arate <<- mean_recursive(as.double(ans[i-1, ] != ans[i-2, ]), obs_arate, abs_iter) :108-118, :246-253 -- element-wise over the
+     * k parameters: (obs t + X_t) / (t + 1) (R/recursive.R:124-127).  At the first proposal of a call (i = 2) ans[i-2, ] is ans[0, ]:
+     * zero rows, the comparison and with it obs_arate become numeric(0) in R and stay so; here: NaN in every entry (NaN t + X = NaN) */
+    for (int a = 0; a < k; a++)
+      ks->obs_arate[a] = (i < 3) ? NAN : (ks->obs_arate[a] * (double)a_it + ((theta0[a] != ks->prev_row[a]) ? 1.0 : 0.0)) / ((double)a_it + 1);
   }
   for (int a = 0; a < k; a++) theta1[a] = theta0[a];
   int upd[MAXK], nupd = 0;
@@ -896,10 +904,10 @@ int fmcmc_oracle_run(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_r
       ks.nzero = 0;
       if (st->fresh) {
         for (int a = 0; a < k; a++) { ks.mmu[a] = kn->mu[a]; ks.msc[a] = kn->scale[a]; }
-        ks.obs_arate = NAN;
+        for (int a = 0; a < k; a++) ks.obs_arate[a] = NAN;
       } else {
         for (int a = 0; a < k; a++) { ks.mmu[a] = st->mirror_mu[c * k + a]; ks.msc[a] = st->mirror_scale[c * k + a]; }
-        ks.obs_arate = st->obs_arate[c];
+        for (int a = 0; a < k; a++) ks.obs_arate[a] = st->obs_arate[c * k + a];
         ks.abs_iter = st->abs_iter[c];
       }
     }
@@ -993,11 +1001,13 @@ int fmcmc_oracle_run(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_r
             moved = (sq != 0.0);
           }
         }
+        if (mirror) for (int a = 0; a < k; a++) ks.prev_row[a] = theta0[a];
         for (int a = 0; a < k; a++) theta0[a] = theta1[a];
         f0 = f1;
         nacc++;
         if (bits) bits[(i - 1) >> 5] |= (1u << ((i - 1) & 31));
       }
+      else if (mirror) for (int a = 0; a < k; a++) ks.prev_row[a] = theta0[a];   /* (rejected: rows i - 1 and i are the same) */
       STORE_ROW(i, theta0, theta1, f1);
       if (mirror && !moved) ks.nzero += 1;
       if (hist) for (int a = 0; a < kf; a++) hist[(i - 1) * kf + a] = theta0[ks.which[a]]; /* row i */
@@ -1012,7 +1022,7 @@ int fmcmc_oracle_run(const fmcmc_model* m, const fmcmc_kernel* kn, const fmcmc_r
     st->f0[c] = f0;
     if (mirror) {
       for (int a = 0; a < k; a++) { st->mirror_mu[c * k + a] = ks.mmu[a]; st->mirror_scale[c * k + a] = ks.msc[a]; }
-      st->obs_arate[c] = ks.obs_arate;
+      for (int a = 0; a < k; a++) st->obs_arate[c * k + a] = ks.obs_arate[a];
       st->abs_iter[c] = ks.abs_iter;
     }
     if (kn->kind == FMCMC_KERNEL_ADAPT || kn->kind == FMCMC_KERNEL_RAM) {

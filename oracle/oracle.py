@@ -311,7 +311,7 @@ class ChainState:
         self.nerrors = np.zeros(Cn, dtype=np.int32)
         self.scheme_cols = None   # [C][nsteps] int32 plan of scheme = "random" (set by run())
         self.mirror_mu, self.mirror_scale = np.zeros((Cn, k)), np.zeros((Cn, k))
-        self.obs_arate = np.full(Cn, np.nan)
+        self.obs_arate = np.full((Cn, k), np.nan)
         self.fresh = 1
         self.step_base = 0
 

@@ -156,7 +156,9 @@ kernel_state <- function(kernels, spec, initial) {
     if (spec$kind %in% c(7L, 8L)) {
       st$mirror_mu    <- as.double(vapply(kernels, function(e) as.double(e$mu), rep(0, k)))
       st$mirror_scale <- as.double(vapply(kernels, function(e) as.double(e$scale), rep(0, k)))
-      st$obs_arate    <- as.double(vapply(kernels, function(e) if (is.null(e$obs_arate)) NA_real_ else e$obs_arate, 0))
+      # (the closure's obs_arate: NULL before the one-off adaptation, a scalar after it, a k-vector -- or numeric(0) -- once the
+      #  warm-up's element-wise mean_recursive has touched it, R/kernel_mirror.R:108-118; the engine keeps k entries, NA = none)
+      st$obs_arate    <- as.double(vapply(kernels, function(e) if (length(e$obs_arate) == 0L) rep(NA_real_, k) else rep_len(as.double(e$obs_arate), k), rep(0, k)))
     }
     if (spec$scheme == 2L)                                  # the plan is made ONCE per kernel object (R/kernel.R:106-113)
       st$scheme_cols <- as.integer(vapply(kernels, function(e) as.integer(max.col(e$update_sequence, "first") - 1L),
@@ -188,7 +190,7 @@ kernel_write_back <- function(kernels, spec, res, nsteps) {
       e$update_sequence <- us
       e$k <- sum(us[1L, ])                                     # k <<- sum(update_sequence[1, ]) (R/kernel_normal.R:61)
       if (spec$kind %in% c(7L, 8L)) {
-        e$mu <- s$mirror_mu[, c]; e$scale <- s$mirror_scale[, c]; e$obs_arate <- s$obs_arate[c]; e$abs_iter <- s$abs_iter[c]
+        e$mu <- s$mirror_mu[, c]; e$scale <- s$mirror_scale[, c]; e$obs_arate <- if (all(is.na(s$obs_arate[, c]))) NULL else s$obs_arate[, c]; e$abs_iter <- s$abs_iter[c]
       }
     } else {
       e$k <- kf; e$which. <- w; e$lb <- spec$lb; e$ub <- spec$ub

@@ -187,7 +187,7 @@ static void fill_run(SEXP run, const fmcmc_kernel* k, fmcmc_run* r) {
  * state = list(theta0 (k x C: t(initial)), fresh, and -- when fresh = FALSE -- abs_iter (double[C]), Sigma (kf x kf x C, each
  *              slice the TRANSPOSE of R's matrix: the ABI is row-major), mean_prev (kf x C), have_mean (int[C]),
  *              nerrors (int[C]); scheme_cols (nsteps x C int) for a continued / fed "random" scheme;
- *              mirror_mu, mirror_scale (k x C), obs_arate (C) for the mirror kernels)
+ *              mirror_mu, mirror_scale, obs_arate (k x C) for the mirror kernels)
  * returns list(samples, logpost, draws, accept_count, status, status_step, status_theta, state = list(...same fields...),
  *              kernel_name) */
 SEXP C_fmcmc_amd_run(SEXP model, SEXP kernel, SEXP run, SEXP state) {
@@ -219,7 +219,7 @@ SEXP C_fmcmc_amd_run(SEXP model, SEXP kernel, SEXP run, SEXP state) {
   SEXP nerrors = PROTECT(allocVector(INTSXP, C)); np++;
   SEXP mirror_mu = PROTECT(allocMatrix(REALSXP, (int)K, (int)C)); np++;
   SEXP mirror_scale = PROTECT(allocMatrix(REALSXP, (int)K, (int)C)); np++;
-  SEXP obs_arate = PROTECT(allocVector(REALSXP, C)); np++;
+  SEXP obs_arate = PROTECT(allocMatrix(REALSXP, (int)K, (int)C)); np++;
   int64_t* abs64 = (int64_t*)R_alloc((size_t)C, sizeof(int64_t));
   memset(REAL(f0), 0, sizeof(double) * (size_t)C);
   memset(REAL(Sigma), 0, sizeof(double) * (size_t)(kf * kf * C));
@@ -228,7 +228,8 @@ SEXP C_fmcmc_amd_run(SEXP model, SEXP kernel, SEXP run, SEXP state) {
   memset(INTEGER(nerrors), 0, sizeof(int) * (size_t)C);
   memset(REAL(mirror_mu), 0, sizeof(double) * (size_t)(K * C));
   memset(REAL(mirror_scale), 0, sizeof(double) * (size_t)(K * C));
-  for (R_xlen_t c = 0; c < C; c++) { abs64[c] = 0; REAL(obs_arate)[c] = NA_REAL; }
+  for (R_xlen_t c = 0; c < C; c++) abs64[c] = 0;
+  for (R_xlen_t e = 0; e < K * C; e++) REAL(obs_arate)[e] = NA_REAL;
   if (!fresh) {
     const double* a = el_real(state, "abs_iter", C, adaptive || mirror);
     if (a) for (R_xlen_t c = 0; c < C; c++) abs64[c] = (int64_t)a[c];
@@ -243,7 +244,7 @@ SEXP C_fmcmc_amd_run(SEXP model, SEXP kernel, SEXP run, SEXP state) {
     if (mirror) {
       memcpy(REAL(mirror_mu), el_real(state, "mirror_mu", K * C, 1), sizeof(double) * (size_t)(K * C));
       memcpy(REAL(mirror_scale), el_real(state, "mirror_scale", K * C, 1), sizeof(double) * (size_t)(K * C));
-      memcpy(REAL(obs_arate), el_real(state, "obs_arate", C, 1), sizeof(double) * (size_t)C);
+      memcpy(REAL(obs_arate), el_real(state, "obs_arate", K * C, 1), sizeof(double) * (size_t)(K * C));
     }
   }
   s.theta0 = REAL(theta0); s.f0 = REAL(f0); s.abs_iter = abs64; s.Sigma = REAL(Sigma); s.mean_prev = REAL(mean_prev);

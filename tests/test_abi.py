@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported(abi):
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
     assert set(abi.EXPORTS) <= set(names)
-    assert L.fmcmc_abi_version() == abi.ABI_VERSION == 5
+    assert L.fmcmc_abi_version() == abi.ABI_VERSION == 6
 
 
 def test_struct_layouts_match_the_oracle_binding(abi, O):

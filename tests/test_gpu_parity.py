@@ -107,7 +107,8 @@ def run_both(E, O, fam, X, y, kind, k, initial, nsteps, burnin=0, thin=1, seed=1
             assert np.array_equal(gst.abs_iter.cpu().numpy(), ost.abs_iter)
             assert _bits_equal(gst.mirror_mu.cpu().numpy(), ost.mirror_mu), "mirror mu"
             assert _bits_equal(gst.mirror_scale.cpu().numpy(), ost.mirror_scale), "mirror scale"
-            assert _bits_equal(gst.obs_arate.cpu().numpy(), ost.obs_arate), "obs_arate"
+            ga, oa = gst.obs_arate.cpu().numpy(), ost.obs_arate          # (NaN = R's NULL / numeric(0): payloads are not part of the spec)
+            assert np.array_equal(np.isnan(ga), np.isnan(oa)) and _bits_equal(np.nan_to_num(ga, nan=-1.0), np.nan_to_num(oa, nan=-1.0)), "obs_arate"
         if ok.scheme == O.SCHEME_RANDOM:
             assert np.array_equal(gst.scheme_cols.cpu().numpy()[:, 1:nsteps], ost.scheme_cols[:, 1:nsteps]), "update plan"
         if kind == O.K_ADAPT:
@@ -635,9 +636,37 @@ def test_mirror_kernels(E, O, kind_name, C, n, p, scheme, fixed):
     kind = O.K_NMIRROR if kind_name == "nmirror" else O.K_UMIRROR
     rg, ro = run_both(E, O, O.FAM_LINREG, X, y, kind, k, init, nsteps=160, calls=2, mu=base, scale=0.15, warmup=120, nadapt=6,
                       lb=[-30.0] * (p + 1) + [0.05], ub=30.0, scheme=scheme, fixed=fixed)
-    q = ro.state.obs_arate
-    assert np.all(np.isfinite(q)) and np.allclose(q * 6, np.round(q * 6))          # multiples of 1 / nadapt
+    q = ro.state.obs_arate                                  # [C][k]: the one-off rate, then R's element-wise running mean through warm-up
+    assert q.shape == (C, k) and np.all(np.isfinite(q)) and np.all((q >= 0) & (q <= 1))
+    fx = np.asarray(fixed if fixed is not False else [False] * k, dtype=bool)
+    if fx.any():                                            # (a fixed parameter never moves: its entry only decays from the one-off rate)
+        assert np.all(q[:, fx] <= q[:, ~fx].max(axis=1, keepdims=True) + 1e-12)
     assert np.all(ro.state.abs_iter == 318)
+
+
+@pytest.mark.parametrize("kind_name", ["nmirror", "umirror"])
+@pytest.mark.parametrize("n", [800, 10000])
+def test_mirror_obs_arate_through_warmup_and_across_calls(E, O, kind_name, n):
+    """R/kernel_mirror.R:108-118, :246-253: after the one-off adaptation obs_arate keeps being updated through the warm-up --
+    mean_recursive(as.double(ans[i-1, ] != ans[i-2, ]), obs_arate, abs_iter), element-wise: the closure's scalar turns into a
+    k-vector -- and that is the kernel state a second call continues (R/kernel.R:405-422 writes it back).  (a) one call that ends
+    inside the warm-up: k distinct running means; (b) a second call continuing INSIDE the warm-up: its first proposal (i = 2)
+    has no ans[i-2, ] -- numeric(0) in R, which every later update keeps: NaN in every entry here; (c) a chain whose warm-up
+    ends in the first call keeps its vector through the second.  General kernel (n = 800) and the MFMA owner (n = 10,000),
+    the oracle's bits (inside run_both: outputs, mu, scale, obs_arate, abs_iter)."""
+    X, y = synth_linreg(n, 2, 91 + n)
+    k = 4
+    base = [0.5, 0.5, 0.5, float(np.std(y))]
+    init = jitter_init(base, 5, 8)
+    kind = O.K_NMIRROR if kind_name == "nmirror" else O.K_UMIRROR
+    common = dict(mu=base, scale=0.15, nadapt=6, lb=[-30.0] * 3 + [0.05], ub=30.0)
+    rg, ro = run_both(E, O, O.FAM_LINREG, X, y, kind, k, init, nsteps=90, warmup=400, **common)              # (a)
+    q = ro.state.obs_arate
+    assert np.all(np.isfinite(q)) and np.all((q > 0) & (q < 1)) and len({tuple(r) for r in q.round(12)}) > 1
+    rg, ro = run_both(E, O, O.FAM_LINREG, X, y, kind, k, init, nsteps=90, calls=2, warmup=400, **common)     # (b)
+    assert np.all(np.isnan(ro.state.obs_arate)) and np.all(ro.state.abs_iter == 178)
+    rg, ro = run_both(E, O, O.FAM_LINREG, X, y, kind, k, init, nsteps=90, calls=2, warmup=60, **common)      # (c)
+    assert np.all(np.isfinite(ro.state.obs_arate))
 
 
 @pytest.mark.parametrize("kind_name", ["nmirror", "umirror"])

@@ -320,6 +320,8 @@ def test_mirror_kernels_replay_R_semantics(O, kind_name):
             d = np.diff(np.array(ans), axis=0)
             obs = 1.0 - np.mean((d ** 2).sum(axis=1) == 0.0)
             scale = scale * np.tan(np.pi / 2.0 * obs) / np.tan(np.pi / 2.0 * 0.4)
+        elif 4 < a <= 30:     # obs_arate <<- mean_recursive(as.double(ans[i-1, ] != ans[i-2, ]), obs_arate, abs_iter): a k-vector from here on
+            obs = (obs * a + (ans[-1] != ans[-2]).astype(float)) / (a + 1)
         if kind == O.K_NMIRROR:
             th1 = (2 * mu - th0) + scale * g.rnorm(2)
         else:
@@ -335,7 +337,7 @@ def test_mirror_kernels_replay_R_semantics(O, kind_name):
         ans.append(th0.copy())
         assert np.array_equal(r.samples[0, i - 1], th0)
     assert np.allclose(r.state.mirror_mu[0], mu, rtol=1e-13) and np.allclose(r.state.mirror_scale[0], scale, rtol=1e-13)
-    assert abs(r.state.obs_arate[0] - obs) < 1e-15 and r.state.abs_iter[0] == 79
+    assert np.shape(obs) == (2,) and np.allclose(r.state.obs_arate[0], obs, rtol=0, atol=1e-15) and r.state.abs_iter[0] == 79
 
 
 def test_mirror_kernels_sample_the_posterior(O):
