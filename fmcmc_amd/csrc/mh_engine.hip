@@ -1003,6 +1003,27 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
       hipLaunchKernelGGL(logit_build_slices, dim3((unsigned)nb_launch), dim3(256), 0, stream, m->X, (long long)m->n, m->p, nslots, xs);
       A.shard = 2; A.sh_nslots = nslots; A.sh_xs = xs; A.sh_ys = nullptr; A.sh_th = thw; A.sh_part = ptw; A.sh_bar = bar;
       g_kernel = "logistic-sharded";
+      // Round 5: the canonical stream of the call materialised in front of the sweep (rng_fill_kernel), where it fits 1 GiB, instead
+      // of being drawn inside the cooperative kernel: there the draws of a tile of steps -- Philox, AS241 with its ~50 constants
+      // reloaded from scratch -- sit between two grid-wide hand-overs with 255 workgroups waiting (C5: 1.4 us of a 66 us step,
+      // tools/bench_c5_fed.py).  The same variates, the same bits.
+      SweepArgs A_own = A;
+      const unsigned long long stream_bytes = (unsigned long long)run->nchains * (unsigned long long)run->nsteps * (unsigned long long)(A.kz + 1) * 8ull;
+      if (A.rng_mode == FMCMC_RNG_PHILOX && stream_bytes <= (1ull << 30) &&
+          (kn->kind >= FMCMC_KERNEL_ADAPT || kn->scheme == FMCMC_SCHEME_JOINT)) {
+        double* wsl = nullptr;
+        if (hipMallocAsync((void**)&wsl, (size_t)stream_bytes, stream) == hipSuccess) {
+          ws_guard.p = wsl; ws_guard.s = stream;
+          const size_t items = (size_t)run->nchains * (size_t)run->nsteps;
+          const double fill_df = (kn->kind == FMCMC_KERNEL_RAM) ? A.ram_df : (A.variate == 1 ? -1.0 : 0.0);
+          hipLaunchKernelGGL(rng_fill_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream,
+                             (unsigned long long)run->seed, (long long)run->step_base, (long long)run->chain_base,
+                             (long long)run->nchains, (long long)run->nsteps, A.kz, fill_df, wsl, wsl + items);
+          A.fed_logu = wsl; A.fed_z = wsl + items; A.rng_mode = FMCMC_RNG_FED;
+        } else {
+          (void)hipGetLastError();
+        }
+      }
       long long done = 0;
       for (; done < run->nchains && e == hipSuccess; done += ch_launch) {   // (the slices and tables serve every launch)
         SweepArgs W = chain_window(A, done, (run->nchains - done < ch_launch) ? run->nchains - done : ch_launch, kf);
@@ -1021,6 +1042,7 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
         e = hipSuccess;
         lshard = false;
         g_kernel = "streamed-logistic";
+        A = A_own;
         A.shard = 0; A.sh_xs = nullptr; A.sh_th = nullptr; A.sh_part = nullptr; A.sh_bar = nullptr;
       }
     }
