@@ -714,11 +714,29 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
     // per step).  Same canonical lanes and tree: the bits do not depend on the form.  Knob lat=0: off; lat=1|2|3: forced.
     if (K.lat != 0 && !mirror && (pipe_opt || (mfma_ng && !mfma_ext && !mfma_ad))) {
       const long long per_cu = (run->nchains + ncu - 1) / ncu;
-      // (measured, tools/bench_lat_grid.sh: the normal kernels win with one chain per workgroup -- 0.60 .. 1.06 us per step against
-      //  0.98 .. 2.0 -- and win or tie with two; with three the MFMA kernel's four are faster.  kernel_adapt / kernel_ram gain up to 25 %
-      //  with one, 18 % with two, 6 % with three at n = 10,000 and are level at small n: their step is the owner's dependent chain.)
-      const int lmax = (kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE) ? 2 : 3;
-      const int lcw = (K.lat >= 1 && K.lat <= 3) ? K.lat : (per_cu <= lmax ? (int)per_cu : 4);
+      // kernel_adapt / kernel_ram (mh_sweep_spec) gain up to 25 % with one chain per workgroup, 18 % with two, 6 % with three at
+      // n = 10,000 and are level at small n -- their step is the owner's dependent chain --: one to three, always.  The normal
+      // kernels by a cost model (us per step, fitted to tools/bench_lat_grid.sh and `tools/dispatch_audit.py --only=few`,
+      // profiles/r05_dispatch_audit_few.md): mh_sweep_lat costs ~0.45 us of fold, barrier and decision plus, per chain of the
+      // workgroup, its evaluation (n (p + 2) fp64 instructions at ~4.7 cycles over four SIMDs; shorter lanes of p >= 4 run
+      // at a lower rate) or -- short data -- its coefficient broadcast and tree; the MFMA kernel's four chains cost ~0.8 us
+      // + 0.06 us per operand group and observation slot.  n = 10,000, p = 3: 1.03 | 1.62 | 2.15 us with 1 | 2 | 3 chains
+      // against 2.0; p = 1: three chains still win (1.54 against 2.07); p = 7, n = 1000: two lose (1.22 against 1.13).
+      int lcw_auto = 4;
+      if (per_cu <= 3) {
+        if (kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE) {
+          const double w = (double)m->n * (double)(m->p + 2), rate = (m->p <= 3) ? 9.2e-6 : 1.25e-5;
+          const double per_chain = (0.10 + rate * w > 0.18 + 0.025 * (double)m->p) ? 0.10 + rate * w : 0.18 + 0.025 * (double)m->p;
+          const double t_lat = 0.45 + (double)per_cu * per_chain;
+          const double ns = (double)((m->n + NT - 1) / NT), ng = (m->p <= 3) ? 1.0 : 2.0;
+          const double t_floor = 0.98 + 0.10 * (ng - 1.0);
+          const double t_mfma = (0.80 + 0.06 * ng * ns > t_floor) ? 0.80 + 0.06 * ng * ns : t_floor;
+          if (t_lat < t_mfma) lcw_auto = (int)per_cu;
+        } else {
+          lcw_auto = (int)per_cu;
+        }
+      }
+      const int lcw = (K.lat >= 1 && K.lat <= 3) ? K.lat : lcw_auto;
       const long long nsl2 = (((m->n + NT - 1) / NT) + 1) & ~1ll;
       if (lcw < 4 && m->p >= 1 && nsl2 <= fmh::k_spec_optmax(m->p, kn->kind)) {
         if (kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE) { pipe_opt = (int)nsl2; mfma_ng = 0; lat_normal = true; }

@@ -1,8 +1,8 @@
 """Dispatch audit (profiles/r04_dispatch_audit.md): does the dispatcher pick the fastest kernel it has?  For a grid of shapes
 (Gaussian linreg p = 1 .. 14 and wide, logistic) x chain counts x kernel_* every sweep is timed on the dispatcher's own choice and
-on the alternatives the diagnosis knobs can force (FMCMC_AMD_DEBUG, read once per call: mfma=0, spec=0, streamed=1, shard=0|1,
+on the alternatives the diagnosis knobs can force (FMCMC_AMD_DEBUG, read once per call: mfma=0, lat=0|1|2|3, streamed=1, shard=0|1,
 wide2=0, shard_mfma=0); a row is flagged when an alternative beats the default by more than 5 %.
-  python tools/dispatch_audit.py [out.md] [--quick] [--only=narrow,wide,logistic,long]      (on the GPU box; HIP events around the sweep, best of 3)"""
+  python tools/dispatch_audit.py [out.md] [--quick] [--only=narrow,few,wide,logistic,long]      (on the GPU box; HIP events around the sweep, best of 3)"""
 import os
 import sys
 import time
@@ -13,7 +13,7 @@ from fmcmc_amd import engine as E, _abi as abi  # noqa: E402
 
 QUICK = "--quick" in sys.argv
 ONLY = [a.split("=", 1)[1].split(",") for a in sys.argv if a.startswith("--only=")]
-ONLY = ONLY[0] if ONLY else ["narrow", "wide", "logistic", "long"]      # --only=wide,logistic
+ONLY = ONLY[0] if ONLY else ["narrow", "few", "wide", "logistic", "long"]      # --only=wide,logistic
 rows = []
 t_begin = time.time()
 
@@ -85,7 +85,10 @@ def logistic(n, p, chains, alts):
 
 
 KINDS = ((abi.KERNEL_NORMAL, "normal"), (abi.KERNEL_ADAPT, "adapt"), (abi.KERNEL_RAM, "ram"))
-NARROW_ALTS = ["", "mfma=0", "mfma=0,spec=0", "streamed=1"]
+NARROW_ALTS = ["", "mfma=0", "streamed=1"]
+# few chains per GPU (round 5: the latency form): the dispatcher's choice against the four-chains-per-workgroup kernels (lat=0) and
+# against every forced number of chains per workgroup
+FEW_ALTS = ["", "lat=0", "lat=1", "lat=2", "lat=3", "streamed=1"]
 WIDE_ALTS = ["", "shard=0", "shard=1", "shard=1,wide2=0", "shard=1,shard_mfma=0"]
 LOGIT_ALTS = ["", "shard=0", "shard=1"]
 if QUICK:
@@ -100,6 +103,12 @@ for n, p, c in (grid_narrow if "narrow" in ONLY else []):
     for kind, name in KINDS:
         linreg(n, p, c, kind, name, NARROW_ALTS)
     print("narrow", n, p, c, "%.0f s" % (time.time() - t_begin), flush=True)
+grid_few = [] if QUICK else [(n, p, c) for n in (1000, 3000, 6000, 10000) for p in (1, 3, 5, 7) for c in (4, 128, 256, 512, 768)
+                             if not (p >= 4 and n > 5120) and not (p >= 6 and n > 4096)]
+for n, p, c in (grid_few if "few" in ONLY else []):
+    for kind, name in KINDS:
+        linreg(n, p, c, kind, name, FEW_ALTS)
+    print("few", n, p, c, "%.0f s" % (time.time() - t_begin), flush=True)
 for n, p, c in (grid_wide if "wide" in ONLY else []):
     for kind, name in (KINDS[0], KINDS[2]):
         linreg(n, p, c, kind, name, WIDE_ALTS)
