@@ -22,7 +22,8 @@ FIELDS = {"TotalSGPRs": "sgprs", "VGPRs": "vgprs", "AGPRs": "agprs", "ScratchSiz
           "Occupancy [waves/SIMD]": "occupancy_waves_per_simd", "SGPRs Spill": "sgpr_spills", "VGPRs Spill": "vgpr_spills",
           "LDS Size [bytes/block]": "static_lds_bytes"}
 # the kernels the four GPU configs of BASELINE.md section 4 run on (bench.py fails if the dispatcher picks another one)
-PRODUCT = [("C2 headline", r"mh_sweep_mfma<1, 1, 20, false, false, false>"), ("C2 shape, > 4 GiB of samples", r"mh_sweep_mfma<1, 1, 20, false, true, false>"),
+PRODUCT = [("C2 headline", r"mh_sweep_mfma<1, 1, 20, false, false, false>"),
+           ("C2 shape, 256 chains or fewer per GPU (latency form)", r"mh_sweep_lat<1, 3, 20>"), ("C2 shape, > 4 GiB of samples", r"mh_sweep_mfma<1, 1, 20, false, true, false>"),
            ("C3", r"mh_sweep_spec<3, 20, 3>"),
            ("C3' kernel_ram k=5", r"mh_sweep_spec<3, 20, 4>"), ("C4", r"mh_sweep_wide2<4, 3>"),
            
@@ -40,13 +41,35 @@ def demangle(names):
     return [re.sub(r"\(anonymous namespace\)::", "", s).split("(")[0].replace("void ", "") for s in out.splitlines()]
 
 
+def _one_unit(src, extra_flags):
+    """remarks and ISA of one translation unit (the product's own flags + --cuda-device-only)"""
+    base = [B.HIPCC] + list(B.FLAGS) + list(extra_flags) + ["--cuda-device-only"]
+    t0 = time.time()
+    err = subprocess.run(base + ["-c", "-Rpass-analysis=kernel-resource-usage", src, "-o", "/dev/null"], capture_output=True, text=True).stderr
+    secs = time.time() - t0
+    asm = "/tmp/fmcmc_amd_%s.s" % os.path.splitext(os.path.basename(src))[0]
+    subprocess.run(base + ["-S", src, "-o", asm], capture_output=True, text=True)
+    return src, err, secs, asm
+
+
+_UNITS = None
+
+
+def units(extra_flags=()):
+    global _UNITS
+    if _UNITS is None:
+        from concurrent.futures import ThreadPoolExecutor
+        t0 = time.time()
+        with ThreadPoolExecutor(min(8, os.cpu_count() or 1)) as ex:
+            res = list(ex.map(lambda s_: _one_unit(s_, extra_flags), B.sources()))
+        _UNITS = (res, time.time() - t0)
+    return _UNITS
+
+
 def collect(extra_flags=()):
     rows = []
-    t0 = time.time()
-    for src in B.SRC:
-        cmd = [B.HIPCC] + [f for f in B.FLAGS if f != "-shared"] + list(extra_flags) + \
-              ["--cuda-device-only", "-c", "-Rpass-analysis=kernel-resource-usage", src, "-o", "/dev/null"]
-        err = subprocess.run(cmd, capture_output=True, text=True).stderr
+    res, wall = units(extra_flags)
+    for src, err, secs, _asm in res:
         cur = None
         for line in err.splitlines():
             m = re.search(r"remark: Function Name: (\S+)", line)
@@ -59,7 +82,8 @@ def collect(extra_flags=()):
                 cur[FIELDS[m.group(1)]] = int(m.group(2)) if m.group(2).isdigit() else m.group(2)
     for r, d in zip(rows, demangle([r["mangled"] for r in rows])):
         r["name"] = d
-    return rows, time.time() - t0
+    return rows, {"wall_8_jobs": round(wall, 1), "sum_of_units": round(sum(u[2] for u in res), 1),
+                  "per_unit": {os.path.basename(u[0]): round(u[2], 1) for u in res}}
 
 
 # real (noinline) device functions that carry the hot loops of a product kernel: the remark pass reports kernels only, so
@@ -72,19 +96,21 @@ DEVICE_FUNCS = [("C5 observation loop (observation-sharded)", "logit_shard<5, 2,
 
 def isa_functions(extra_flags=()):
     out = []
-    src = B.SRC[0]
-    asm = "/tmp/fmcmc_amd_engine.s"
-    cmd = [B.HIPCC] + [f for f in B.FLAGS if f != "-shared"] + list(extra_flags) + ["--cuda-device-only", "-S", src, "-o", asm]
-    subprocess.run(cmd, capture_output=True, text=True)
     funcs, cur = {}, None
-    for line in open(asm):
-        m = re.match(r"^(_Z\w+):", line)
-        if m:
-            cur = m.group(1); funcs[cur] = []
-        elif cur is not None:
-            funcs[cur].append(line.rstrip("\n"))
-            if line.startswith(".Lfunc_end"):
-                cur = None
+    for _src, _err, _secs, asm in units(extra_flags)[0]:
+        cur = None
+        for line in open(asm):
+            m = re.match(r"^(_Z\w+):", line)
+            if m:
+                cur = m.group(1)
+                if cur in funcs:          # (the same noinline helper in several translation units: the first one stands for all)
+                    cur = None
+                else:
+                    funcs[cur] = []
+            elif cur is not None:
+                funcs[cur].append(line.rstrip("\n"))
+                if line.startswith(".Lfunc_end"):
+                    cur = None
     names = list(funcs)
     for role, pat in DEVICE_FUNCS:
         for mangled, dem in zip(names, demangle(names)):
@@ -147,15 +173,16 @@ def main():
     rows, secs = collect(args.flags.split())
     head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
     fns, calls = isa_functions(args.flags.split())
-    rec = {"head": head, "flags": B.FLAGS + args.flags.split(), "device_compile_seconds": round(secs, 1), "kernels": rows, "device_functions": fns, "scratch_by_path": calls,
+    rec = {"head": head, "flags": B.FLAGS + args.flags.split(), "device_compile_seconds": secs, "kernels": rows, "device_functions": fns, "scratch_by_path": calls,
            "n_kernels": len(rows), "n_with_scratch": sum(1 for r in rows if r.get("scratch_bytes_per_lane", 0))}
     json.dump(rec, open(os.path.join(ROOT, "profiles", "%s_resources.json" % args.tag), "w"), indent=1)
     cols = ["vgprs", "agprs", "sgprs", "scratch_bytes_per_lane", "vgpr_spills", "sgpr_spills", "occupancy_waves_per_simd"]
     hdr = "| role | kernel | VGPRs | AGPRs | SGPRs | scratch B/lane | VGPR spills | SGPR spills | waves/SIMD |\n|---|---|---|---|---|---|---|---|---|\n"
     md = ["# Kernel resources (%s, commit %s)\n" % (args.tag, head),
           "`python tools/resource_table.py --tag %s`: hipcc `-Rpass-analysis=kernel-resource-usage` on the product's own "
-          "command line; %d kernels / device functions in the code object, %d of them with scratch; device compile %.0f s.\n"
-          % (args.tag, len(rows), rec["n_with_scratch"], secs),
+          "command line, one pass per translation unit; %d kernels in the code objects, %d of them with scratch.  Device compile (remark pass, "
+          "8 jobs): %.0f s wall, %.0f s summed over the units (%s); `python -m fmcmc_amd.build` (full compile + link, 8 jobs) takes about a minute.\n"
+          % (args.tag, len(rows), rec["n_with_scratch"], secs["wall_8_jobs"], secs["sum_of_units"], ", ".join("%s %.0f" % kv for kv in sorted(secs["per_unit"].items()))),
           "## Product kernels of the GPU configs\n", hdr]
     for role, pat in PRODUCT:
         for r in rows:
