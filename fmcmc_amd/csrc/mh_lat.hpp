@@ -135,29 +135,51 @@ __device__ __forceinline__ void lat_steps(const SweepArgs& A, double* smem) {
     lu_nx = lu_row[vn < nsteps ? vn : nsteps - 1];
     z_nx = z_lane[(long long)(vn + 1 < nsteps ? vn + 1 : nsteps - 1) * kz];
   };
-  // ---- the sigma-only half of the closed form of theta1, in two pieces (branch-free: the lanes without a result write to a sink)
-  auto prepare_log = [&](int vn) {       // -> buffer vn & 1: n (log sigma + ln sqrt 2 pi), and whether sigma is positive, finite, normal
-    const double sigma = shfl_d(th1, (lane & 48) + k - 1);
-    const unsigned sg_hi = (unsigned)(fmh_d2u(sigma) >> 32);
-    const bool sg_fast = (sg_hi - 0x00100000u) < 0x7fe00000u;
-    const double sg = sg_fast ? sigma : 1.0;
-    const double t1 = fmh_log_pn(sg) + FMH_K(FMH_LN_SQRT_2PI);           // same bits as fmh_log(sigma) on this range
-    const double nt1 = dn * t1;
-    const double v = (jj == 0) ? nt1 : (sg_fast ? 1.0 : 0.0);
-    double* dst = (jj < 2) ? s_prep + (vn & 1) * 16 + jj * LAT_ROWS + row : s_sink + lane;
-    *dst = v;
-  };
-  auto prepare_recip = [&](int vn) {     // -> buffer vn & 1: sigma^2 and its reciprocal for div_finish (0: take the plain division)
-    const double sigma = shfl_d(th1, (lane & 48) + k - 1);
-    const unsigned sg_hi = (unsigned)(fmh_d2u(sigma) >> 32);
-    const bool sg_fast = (sg_hi - 0x00100000u) < 0x7fe00000u;
-    const double sg = sg_fast ? sigma : 1.0;
-    const double ss = sg * sg;
-    const bool ok = sg_fast && mfr_div_safe(ss);
-    const double rs = div_recip(ok ? ss : 1.0);
-    const double v = (jj == 2) ? ss : (ok ? rs : 0.0);
-    double* dst = (jj == 2 || jj == 3) ? s_prep + (vn & 1) * 16 + jj * LAT_ROWS + row : s_sink + lane;
-    *dst = v;
+  // ---- the duties of waves 1 .. 3 in STAGES, run between the slot groups of the first chain's evaluation (stage g in front of group g:
+  // the same basic block, in this order in the source -- left to itself the scheduler kept a duty's dependent chain in front of the
+  // evaluation, ~450 cycles of latency that the barrier then waited for).  Branch-free: lanes without a result write to a sink.
+  //   wave 1: n (log sigma + ln sqrt 2 pi) of theta1 (fmh_log_pn in its pieces: the same operations, the same bits)
+  //   wave 2: both candidates of the next proposal and the log-uniform of the pending decision
+  //   wave 3: sigma^2 and its reciprocal for div_finish (0: take the plain division)
+  double dt_f = 0.0, dt_s = 0.0, dt_R = 0.0, dt_sg = 1.0;
+  int dt_k = 0;
+  bool dt_fast = false;
+  auto duty_stage = [&](int g, int vn) {     // vn: the version under evaluation (buffer vn & 1)
+    if constexpr (ROLE == LAT_LOG) {
+      if (g == 0) {
+        const double sigma = shfl_d(th1, (lane & 48) + k - 1);
+        const unsigned sg_hi = (unsigned)(fmh_d2u(sigma) >> 32);
+        dt_fast = (sg_hi - 0x00100000u) < 0x7fe00000u;                    // positive, finite, normal
+        dt_sg = dt_fast ? sigma : 1.0;
+        dt_f = fmh_log_split_pn_(dt_sg, &dt_k);
+      } else if (g == 1) {
+        dt_s = fmh_log_s_(dt_f);
+      } else if (g == 2) {
+        dt_R = fmh_log_R_(dt_s);
+      } else if (g == 3) {
+        const double t1 = fmh_log_fin_(dt_f, dt_k, 0.0, dt_s, dt_R) + FMH_K(FMH_LN_SQRT_2PI);   // = fmh_log(sigma) + ln sqrt 2 pi
+        const double nt1 = dn * t1;
+        const double v = (jj == 0) ? nt1 : (dt_fast ? 1.0 : 0.0);
+        double* dst = (jj < 2) ? s_prep + (vn & 1) * 16 + jj * LAT_ROWS + row : s_sink + lane;
+        *dst = v;
+      }
+    } else if constexpr (ROLE == LAT_RECIP) {
+      if (g == 0) {
+        const double sigma = shfl_d(th1, (lane & 48) + k - 1);
+        const unsigned sg_hi = (unsigned)(fmh_d2u(sigma) >> 32);
+        dt_fast = (sg_hi - 0x00100000u) < 0x7fe00000u;
+        dt_sg = dt_fast ? sigma : 1.0;
+      } else if (g == 1) {
+        const double ss = dt_sg * dt_sg;
+        const bool ok = dt_fast && mfr_div_safe(ss);
+        const double rs = div_recip(ok ? ss : 1.0);
+        const double v = (jj == 2) ? ss : (ok ? rs : 0.0);
+        double* dst = (jj == 2 || jj == 3) ? s_prep + (vn & 1) * 16 + jj * LAT_ROWS + row : s_sink + lane;
+        *dst = v;
+      }
+    } else if constexpr (ROLE == LAT_CANDS) {
+      if (g == 0 && vn >= 2) candidates(vn);   // (version 1's come from the prologue; behind the last step they go nowhere)
+    }
   };
   auto logpost_of = [&](double tot, double sigma) -> double {
     double f;
@@ -174,9 +196,10 @@ __device__ __forceinline__ void lat_steps(const SweepArgs& A, double* smem) {
     return f;
   };
   // one chain's lane partial: the canonical fma chains of this lane's OPT observations, four slots in flight
-  auto eval_chain = [&](int c) -> double {
+  auto eval_chain = [&](int c, auto&& stage) -> double {
     const int l0 = 16 * c;
-    double m00 = ic ? readlane_d(th1, l0) : 0.0;
+    double m00 = readlane_d(th1, l0);              // (a select, not a branch: the duty waves' preparation shares this basic block)
+    m00 = ic ? m00 : 0.0;
     double b0[P > 0 ? P : 1];
 #pragma unroll
     for (int j = 0; j < P; j++) b0[j] = readlane_d(th1, l0 + ic + j);
@@ -185,9 +208,10 @@ __device__ __forceinline__ void lat_steps(const SweepArgs& A, double* smem) {
 #pragma unroll
     for (int j = 0; j < P; j++) asm volatile("" : "+v"(b0[j]));
     double a0 = 0.0;
-    constexpr int G = 4;
+    constexpr int G = 4, NGR = (OPT + G - 1) / G;
 #pragma unroll
     for (int s0 = 0; s0 < OPT; s0 += G) {
+      stage(s0 / G);
       double m[G];
 #pragma unroll
       for (int u = 0; u < G; u++) m[u] = m00;
@@ -209,8 +233,11 @@ __device__ __forceinline__ void lat_steps(const SweepArgs& A, double* smem) {
         }
       }
     }
+#pragma unroll
+    for (int g = NGR; g < 4; g++) stage(g);     // (fewer slot groups than stages: the rest behind the loop)
     return a0;
   };
+  auto no_stage = [](int) {};
 
   // ---- prologue: what barrier 1 hands over
   if constexpr (ROLE == LAT_CANDS) {
@@ -225,13 +252,11 @@ __device__ __forceinline__ void lat_steps(const SweepArgs& A, double* smem) {
     const int par = v & 1;
     // ================= evaluation of version v of every chain, levels 1..32 of the tree =================
     // (the logarithm / the reciprocal of theta1's sigma ride in the same basic block as the first chain's evaluation)
-    if constexpr (ROLE == LAT_LOG) prepare_log(v);
-    if constexpr (ROLE == LAT_RECIP) prepare_recip(v);
     // (the tree of chain c - 1 runs in the same basic block as the evaluation of chain c: its six dependent levels hide
     //  under the next chain's fma chains; only the last chain's tree is exposed.  Lanes without a result write to a sink.)
-    double a_prev = eval_chain(0);
+    double a_prev = eval_chain(0, [&](int g) { duty_stage(g, v); });
     for (int c = 1; c < ncw; c++) {
-      const double a_cur = eval_chain(c);
+      const double a_cur = eval_chain(c, no_stage);
       const double fs = wave_xor_sum(a_prev);
       double* dst = (lane == 0) ? s_fold + (par * LAT_ROWS + (c - 1)) * NW + wave : s_sink + lane;
       *dst = fs;
@@ -293,9 +318,6 @@ __device__ __forceinline__ void lat_steps(const SweepArgs& A, double* smem) {
     f0 = acc ? f1 : f0;
     th1 = (status != FMCMC_CHAIN_OK) ? th1 : (acc ? cand_a : cand_r);   // (a failed chain keeps its theta1)
     // ---- the duties, in the shadow of the next evaluation (four different SIMDs)
-    if constexpr (ROLE == LAT_CANDS) {
-      if (v < nsteps) candidates(v + 1);
-    }
     if constexpr (ROLE == LAT_KEEPER) {
       nacc += acc ? 1 : 0;
       bitword |= (acc ? 1u : 0u) << ((v - 1) & 31);

@@ -73,23 +73,31 @@ FMH_HD double fmh_nan(void) { return fmh_u2d(0x7ff8000000000000ull); }
 
 /* Core of log: given u = 2^k * m exactly (m in [sqrt(1/2), sqrt(2)), f = m-1) and a small
  * additive correction `extra` (0 for log, c/u for log1p), return log(u) + extra. */
-FMH_HD double fmh_log_core_(double f, int k, double extra) {
+/* (three pieces, so that a kernel can schedule them between other work -- mh_lat.hpp; composed, exactly the function below) */
+FMH_HD double fmh_log_s_(double f) { return f / (2.0 + f); }
+FMH_HD double fmh_log_R_(double s) {
   const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
                Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
                Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
                Lg7 = 1.479819860511658591e-01;
-  double s = f / (2.0 + f);
   double z = s * s;
   double w = z * z;
   double t1 = w * fmh_fma(w, fmh_fma(w, FMH_K(Lg6), FMH_K(Lg4)), FMH_K(Lg2));
   double t2 = z * fmh_fma(w, fmh_fma(w, fmh_fma(w, FMH_K(Lg7), FMH_K(Lg5)), FMH_K(Lg3)), FMH_K(Lg1));
-  double R = t2 + t1;
+  return t2 + t1;
+}
+FMH_HD double fmh_log_fin_(double f, int k, double extra, double s, double R) {
   double hfsq = 0.5 * f * f;
   double dk = (double)k;
   /* log = k*ln2_hi - ((hfsq - (s*(hfsq+R) + (k*ln2_lo + extra))) - f) */
   double lo = fmh_fma(dk, FMH_K(FMH_LN2_LO), extra);
   double inner = fmh_fma(s, hfsq + R, lo);
   return dk * FMH_K(FMH_LN2_HI) - ((hfsq - inner) - f);
+}
+FMH_HD double fmh_log_core_(double f, int k, double extra) {
+  const double s = fmh_log_s_(f);
+  const double R = fmh_log_R_(s);
+  return fmh_log_fin_(f, k, extra, s, R);
 }
 
 /* Split a positive finite normal/subnormal x into k and m = x / 2^k with
@@ -125,7 +133,8 @@ FMH_HD double fmh_log(double x) {
 
 /* fmh_log for a POSITIVE, FINITE, NORMAL argument (the caller checks): same bits as fmh_log(x), but
  * straight-line code, so a scheduler can overlap it with independent work. */
-FMH_HD double fmh_log_pn(double x) {
+/* its range reduction: x = 2^k m, m in [sqrt(1/2), sqrt(2)); returns f = m - 1 (exact) */
+FMH_HD double fmh_log_split_pn_(double x, int* kout) {
   uint64_t ux = fmh_d2u(x);
   uint32_t hx = (uint32_t)(ux >> 32);
   int k = (int)(hx >> 20) - 1023;
@@ -133,7 +142,13 @@ FMH_HD double fmh_log_pn(double x) {
   uint32_t i = (hx + 0x95f64u) & 0x100000u;
   uint64_t um = ((uint64_t)(hx | (i ^ 0x3ff00000u)) << 32) | (ux & 0xffffffffull);
   k += (int)(i >> 20);
-  return fmh_log_core_(fmh_u2d(um) - 1.0, k, 0.0);
+  *kout = k;
+  return fmh_u2d(um) - 1.0;
+}
+FMH_HD double fmh_log_pn(double x) {
+  int k;
+  const double f = fmh_log_split_pn_(x, &k);
+  return fmh_log_core_(f, k, 0.0);
 }
 
 FMH_HD double fmh_log1p(double x) {
