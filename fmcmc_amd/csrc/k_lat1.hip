@@ -5,6 +5,7 @@
 namespace fmh {
 FMH_HIDDEN const void* k_lat_kv1(int p) {
   switch (p) {
+    case 0: return (const void*)mh_sweep_lat<1, 0, 20>;     // (iid Normal: the linear model with an intercept and no covariate)
     case 1: return (const void*)mh_sweep_lat<1, 1, 20>;
     case 2: return (const void*)mh_sweep_lat<1, 2, 20>;
     case 3: return (const void*)mh_sweep_lat<1, 3, 20>;

@@ -6,7 +6,7 @@
 namespace fmh {
 int k_spec_optmax(int p, int kind) {
   (void)kind;   // (the compute role is the same for every proposal kernel: OPTMAX P doubles of x per lane)
-  return (p >= 1 && p <= 3) ? 20 : (p <= 5 ? 10 : (p <= 7 ? 8 : 0));
+  return (p >= 0 && p <= 3) ? 20 : (p <= 5 ? 10 : (p <= 7 ? 8 : 0));
 }
 FMH_HIDDEN const void* k_spec_normal(int p, int kind) {
 #define SPEC_N(PV, OV) ((kind == 1) ? (const void*)mh_sweep_spec<PV, OV, 1> : (const void*)mh_sweep_spec<PV, OV, 2>)

@@ -738,7 +738,8 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
       }
       const int lcw = (K.lat >= 1 && K.lat <= 3) ? K.lat : lcw_auto;
       const long long nsl2 = (((m->n + NT - 1) / NT) + 1) & ~1ll;
-      if (lcw < 4 && m->p >= 1 && nsl2 <= fmh::k_spec_optmax(m->p, kn->kind)) {
+      // (the normal kernels' latency form also takes p = 0 -- the iid Normal family --; mh_sweep_spec's compute lanes need a covariate)
+      if (lcw < 4 && (m->p >= 1 || kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE) && nsl2 <= fmh::k_spec_optmax(m->p, kn->kind)) {
         if (kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE) { pipe_opt = (int)nsl2; mfma_ng = 0; lat_normal = true; }
         if (pipe_opt && !mfma_ng) spec_cw = lcw;
       }
@@ -800,7 +801,7 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
   //  kernel is what is left: 4 + n p 8 / 65000 us per step)
   if (m->family == FMCMC_FAM_GAUSSIAN_LINREG && (m->p <= 15 || (m->p <= 62 && m->n > (long long)NT * 2 * SHM_T))) {
     const double pn = (double)m->n;
-    const double now_rate = (m->p <= 3) ? (pn <= 2e5 ? 3.3e-4 : 5.1e-4) : (m->p <= 7 ? 5.4e-4 : (m->p <= 11 ? 8.5e-4 : 1.17e-3));
+    const double now_rate = (m->p <= 3) ? (pn <= 2e5 ? 3.3e-4 : 5.1e-4) : (m->p <= 7 ? 4.9e-4 /* (round 5 audit: n = 2e4, p = 7, one chain: 9.75 us on the streamed MFMA kernel, the long-data form 10.6) */ : (m->p <= 11 ? 8.5e-4 : 1.17e-3));
     const double est_now = (m->p >= 16) ? 4.0 + pn * (double)m->p * 8.0 / 65000.0
                          : (m->n <= (long long)NT * (m->p <= 3 ? 20 : (m->p <= 7 ? 10 : 0)) ? 2.2 : now_rate * pn) + (kn->kind >= FMCMC_KERNEL_ADAPT ? 2.0 : 0.0);
     const void* kfn = fmh::k_wide(1, 2, kn->kind);       // (the long-data form: one chain per workgroup, every proposal kernel)

@@ -409,6 +409,21 @@ def test_latency_form_shapes(E, O, monkeypatch, lat, n, p):
     assert abi.last_kernel() == "spec-lat" + lat
 
 
+def test_latency_form_iid_normal(E, O):
+    """The iid Normal family (R/mcmc.R:141-144's example) is the linear model with an intercept and no covariate: with a handful
+    of chains it runs on the latency form too (mh_sweep_lat<KIND, 0, 20>), every slot count, the reflective and uniform kernels."""
+    from fmcmc_amd import _abi as abi
+    rng = np.random.default_rng(12)
+    for n in (700, 5000, 10240):
+        y = 1.5 + 2.0 * rng.standard_normal(n)
+        init = jitter_init([1.0, 2.0], 7, 5)
+        init[:, -1] = np.abs(init[:, -1]) + 0.1
+        run_both(E, O, O.FAM_IID_NORMAL, None, y, O.K_NORMAL, 2, init, nsteps=90, burnin=4, thin=3, calls=2, scale=0.03)
+        assert abi.last_kernel() == "lat1"
+        run_both(E, O, O.FAM_IID_NORMAL, None, y, O.K_UNIF_REFLECTIVE, 2, init, nsteps=60, min_=-0.04, max_=0.05, lb=[-40.0, 0.05], ub=40.0)
+        assert abi.last_kernel() == "lat1"
+
+
 def test_latency_form_step_windows(E, O, monkeypatch):
     """A long call of the normal kernels runs as step windows (bounded stream) in the latency form too: 96-step windows, the
     bits of the oracle's one call."""

@@ -12,7 +12,9 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REC = os.path.join(ROOT, "profiles", "perf_guard.json")
-SHORT = {"c2": 2000, "c3": 2000, "c4": 300, "c5": 150}      # MH iterations of the short run (chains: the config's per-GPU share)
+SHORT = {"c2": 2000, "c3": 2000, "c4": 300, "c5": 150,     # MH iterations of the short run (chains: the config's per-GPU share)
+         "c2@256": 4000, "c2@512": 4000, "c3@256": 3000}   # the latency form: a GPU's share of a 4- / 2-GPU strong-scaled call
+EXPECT = {"c2@256": "lat1", "c2@512": "lat2", "c3@256": "spec-lat1"}
 
 
 def _measure(name):
@@ -20,8 +22,9 @@ def _measure(name):
     sys.path.insert(0, ROOT)
     import bench
     from fmcmc_amd import engine as E, _abi as abi
-    cfg = bench.Config(name)
-    X, y, init = cfg.workload(cfg.chains, 0)
+    cfg = bench.Config(name.split("@")[0])
+    chains = int(name.split("@")[1]) if "@" in name else cfg.chains
+    X, y, init = cfg.workload(chains, 0)
     gm, gk = bench.device_objects(cfg, E, abi, X, y, torch.device("cuda", 0))
     iters = SHORT[name]
     best = float("inf")
@@ -35,10 +38,10 @@ def _measure(name):
         torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) * 1e3 / iters)
     assert int(r.status.abs().sum().item()) == 0
-    return best, abi.last_kernel(), cfg.expect_kernel
+    return best, abi.last_kernel(), EXPECT.get(name, cfg.expect_kernel)
 
 
-@pytest.mark.parametrize("name", ["c2", "c3", "c4", "c5"])
+@pytest.mark.parametrize("name", ["c2", "c3", "c4", "c5", "c2@256", "c2@512", "c3@256"])
 def test_time_per_iteration_within_125_percent_of_the_record(name):
     import torch
     if not torch.cuda.is_available():
