@@ -155,6 +155,33 @@ __device__ __forceinline__ double dpp_d(double v) {
   hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, true);
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
+// Lane N of the caller's 16-lane row in every lane of that row: ONE v_mov_b64_dpp row_newbcast.  (v_readlane_b32 twice gives
+// a scalar pair whose fp64 consumers issue at ~6 cycles instead of ~4.5, and wait states between the two.)  N is an immediate:
+// loops over rows go through static_for.
+template <int N>
+__device__ __forceinline__ double row_bcast(double v) {
+  long long u = __double_as_longlong(v);
+  u = __builtin_amdgcn_update_dpp(u, u, 0x150 + N, 0xf, 0xf, true);
+  return __longlong_as_double(u);
+}
+// acc + bcast_N(bsrc) * other (NEG: acc - ...) as ONE instruction, v_fmac_f64 with the row broadcast as its DPP control -- a fused
+// multiply-add like fmh_fma, the same bits.  (s_nop 1: a VGPR written by the VALU instruction in front needs two wait states before
+// a DPP read, and the compiler's hazard recogniser does not look into inline assembly.)
+template <int N, bool NEG = false>
+__device__ __forceinline__ double fmac_row_bcast(double acc, double bsrc, double other) {
+  if constexpr (NEG)
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bsrc), "v"(other), "n"(N));
+  else
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bsrc), "v"(other), "n"(N));
+  return acc;
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {   // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>), in this order
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>());
+  }
+}
 __device__ __forceinline__ double wave_xor_sum(double v) {
   v = v + dpp_d<0xB1>(v);   // quad_perm [1,0,3,2]  : xor 1
   v = v + dpp_d<0x4E>(v);   // quad_perm [2,3,0,1]  : xor 2

@@ -496,13 +496,13 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
             if (__any(rl && !okl)) {
               nerr += 1;
             } else {
-#pragma unroll
-              for (int j = 0; j < KA; j++) {
+              static_for<KA>([&](auto j_) {
+                constexpr int j = decltype(j_)::value;
                 if (j < kf) {
-                  const double dj = readlane_d(dl, j), kj = readlane_d(kl, j);
+                  const double dj = row_bcast<j>(dl), kj = row_bcast<j>(kl);
                   Srow[j] = fmh_fma(Grow[j], kj, Srow[j] * dj);    // (G_ij kept by the proposal; +0 above the diagonal stays +0)
                 }
-              }
+              });
             }
           }
         }
@@ -552,15 +552,15 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
             const double mp = have_mean ? mean_prev : (run_sum / (double)(i + ioff - 1));
             const double mt = (mp * t + x) / (t + 1);
             const double c1 = (t - 1) / t, c2 = 1.0 / t;
-#pragma unroll
-            for (int b = 0; b < KA; b++) {
+            static_for<KA>([&](auto b_) {
+              constexpr int b = decltype(b_)::value;
               if (b < kf) {
-                const double mpb = readlane_d(mp, b), mtb = readlane_d(mt, b), xb = readlane_d(x, b);
+                const double mpb = row_bcast<b>(mp), mtb = row_bcast<b>(mt), xb = row_bcast<b>(x);
                 const double ik = (b == lane) ? 1.0 * A.eps : 0.0;
                 const double inner = t * (mp * mpb) - (t + 1) * (mt * mtb) + x * xb + 1e-5 * ik;
                 Srow[b] = c1 * Srow[b] + c2 * inner;
               }
-            }
+            });
             mean_prev = mt;
             have_mean = 1;
           }
@@ -572,12 +572,14 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
           // before the division stand in for L D in the sums, and sqrt(D) is one element-wise square root at proposal time.
           bool notpd = false;
           double Dl = 0.0;                    // D_lane
-#pragma unroll
-          for (int j = 0; j < KA; j++) {
+          static_for<KA>([&](auto j_) {
+            constexpr int j = decltype(j_)::value;
             if (j < kf && !notpd) {
               double sacc = Srow[j];
-#pragma unroll
-              for (int b = 0; b < j; b++) sacc = fmh_fma(-Lrow[b], readlane_d(Wrow[KIND == FMCMC_KERNEL_ADAPT ? b : 0], j), sacc);
+              static_for<j>([&](auto b_) {
+                constexpr int b = decltype(b_)::value;
+                sacc = fmac_row_bcast<j, true>(sacc, Wrow[KIND == FMCMC_KERNEL_ADAPT ? b : 0], Lrow[b]);   // fma(-L_lane,b, W_jb, sacc)
+              });
               const double d = readlane_d(sacc, j);
               if (!(d > 0.0) || !fmh_isfinite(d)) {
                 notpd = true;
@@ -590,7 +592,7 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
                 Dl = (lane == j) ? d : Dl;
               }
             }
-          }
+          });
           SPEC_ST(4);
           if (notpd) {
             status = FMCMC_CHAIN_NOT_PD;
@@ -600,16 +602,18 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
           } else {
             const double ul = fmh_sqrt(Dl) * zcur;    // (beyond the parameters: D = 0, z = 0)
             double sacc = 0.0;
-#pragma unroll
-            for (int b = 0; b < KA; b++)   // (row `lane` of the factor is 0 beyond its diagonal and sacc starts at +0: the terms
-              if (b < kf) { const double ub_ = readlane_d(ul, b); sacc = fmh_fma(Lrow[b], ub_, sacc); }   // b > lane add +-0 exactly)
+            static_for<KA>([&](auto b_) {   // (row `lane` of the factor is 0 beyond its diagonal and sacc starts at +0: the terms
+              constexpr int b = decltype(b_)::value;
+              if (b < kf) sacc = fmac_row_bcast<b>(sacc, ul, Lrow[b]);   // b > lane add +-0 exactly)
+            });
             th1 = reflect1(th0 + (mu_l + sacc), lb_l, ub_l);
           }
         } else {  // RAM P1 (R/kernel_ram.R:123-126)
           double sacc = 0.0;
-#pragma unroll
-          for (int b = KA - 1; b >= 0; b--)   // last column first; the partial sums are the G_ib of the factor update
-            if (b < kf) { const double ub_ = readlane_d(zcur, b); Grow[b] = sacc; sacc = fmh_fma(Srow[b], ub_, sacc); }   // (+0 above the diagonal adds +0)
+          static_for<KA>([&](auto r_) {   // last column first; the partial sums are the G_ib of the factor update
+            constexpr int b = KA - 1 - decltype(r_)::value;
+            if (b < kf) { Grow[b] = sacc; sacc = fmac_row_bcast<b>(sacc, zcur, Srow[b]); }   // (+0 above the diagonal adds +0)
+          });
           th1 = th0 + sacc;
           ram_gate = (A.until > (double)abs_iter && abs_iter > A.warmup && ((v + 1 + ioff) % A.freq) == 0);
         }
