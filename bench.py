@@ -77,7 +77,7 @@ class Config:
             self.chains, self.iters, self.thin = 1024, 5000, 10
             self.family = "logistic"
             self.kernel_name = "kernel_normal_reflective(scale=0.01, lb=-5, ub=5), thin 10"
-            self.expect_kernel = "logistic-sharded"
+            self.expect_kernel = "logistic-shadow"
             self.flops = self.n * (2 * self.p + 8)          # exp and log1p counted as 1 flop each
             self.flops_note = "SURVEY 8(d): n (2 x 5 + 8) = 1.8e6 per sample, transcendentals counted as one flop each"
             self.bulk = None
@@ -218,7 +218,7 @@ def cpu_baseline(cfg, seconds_budget=24.0):
             "single_thread": single}
 
 
-KERNEL_FN = {"mfma": "mh_sweep_mfma", "wide-dataflow": "mh_sweep_wide2", "spec": "mh_sweep_spec", "streamed-logistic": "mh_sweep_kernel", "logistic-sharded": "mh_sweep_kernel"}
+KERNEL_FN = {"mfma": "mh_sweep_mfma", "wide-dataflow": "mh_sweep_wide2", "spec": "mh_sweep_spec", "streamed-logistic": "mh_sweep_kernel", "logistic-shadow": "mh_sweep_logit2", "logistic-sharded": "mh_sweep_kernel"}
 # what the dominant kernel of a config is bound by: C2 / C4 evaluate on the matrix cores, C3 / C5 on the fp64 VALU.  Either
 # way the peak is the ONE fp64 datapath of MI355X (fp64 matrix peak == fp64 vector peak, 78.6 TFLOP/s).
 BOUND = {"c2": "mfma", "c3": "valu", "c4": "mfma", "c5": "valu"}

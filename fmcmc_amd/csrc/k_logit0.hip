@@ -10,5 +10,6 @@ FMH_HIDDEN const void* k_logit_0(int cw, int kind) {
 #undef LK
 }
 FMH_HIDDEN const void* k_logit_1(int cw, int kind);
-const void* k_logit(int cw, int sharded, int kind) { return sharded ? k_logit_1(cw, kind) : k_logit_0(cw, kind); }
+FMH_HIDDEN const void* k_logit_2(int cw, int kind);
+const void* k_logit(int cw, int sharded, int kind) { return sharded == 2 ? k_logit_2(cw, kind) : sharded ? k_logit_1(cw, kind) : k_logit_0(cw, kind); }
 }  // namespace fmh

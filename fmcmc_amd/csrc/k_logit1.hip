@@ -1,4 +1,5 @@
-// k_logit1.hip -- logistic-only instantiations of mh_sweep_kernel (mh_streamed.hpp), g table in LDS: the observation-sharded form (logit_shard) and the long-data form
+// k_logit1.hip -- logistic-only instantiations of mh_sweep_kernel (mh_streamed.hpp), g table in LDS: the observation-sharded form (logit_shard) and the long-data form,
+// variates drawn in the kernel (calls whose stream is not materialised: more than 1 GiB of it, single-parameter schemes)
 #include "mh_tu.hpp"
 #include "mh_streamed.hpp"
 

@@ -236,7 +236,10 @@ __device__ __forceinline__ unsigned long long stamp_clk() {
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
   return t;
 }
-#define FMH_STAMP(S, i) do { if ((S) && (threadIdx.x >> 6) == 0) { const unsigned long long t_ = stamp_clk(); (S)->acc[i] += t_ - (S)->prev; (S)->prev = t_; } } while (0)
+#ifndef FMCMC_STAMP_WAVE
+#define FMCMC_STAMP_WAVE 0     /* -1: every wave stamps (tools/stamp_c5.py reads all eight) */
+#endif
+#define FMH_STAMP(S, i) do { if ((S) && (FMCMC_STAMP_WAVE < 0 || (int)(threadIdx.x >> 6) == FMCMC_STAMP_WAVE)) { const unsigned long long t_ = stamp_clk(); (S)->acc[i] += t_ - (S)->prev; (S)->prev = t_; } } while (0)
 #else
 #define FMH_STAMP(S, i) do { } while (0)
 #endif
@@ -1263,7 +1266,7 @@ struct LogitShard {
   unsigned tab;          // LDS address of the table
   int NC, ncp, ic, lane0;
   int nv0, nv1;          // slots of canonical lane lane0 / lane0 + 1 that hold an observation (nv1 <= nv0 <= nslots)
-  int pad_;
+  int turn;              // thousandths of its passes for which the younger wave of a SIMD holds the issue priority
 };
 static_assert(sizeof(LogitShard) == 64, "LogitShard must stay at 16 dwords");
 // OB = 2: a pass is one slot, the two observations of the slice's two canonical lanes (p <= 8); OB = 1: a pass is ONE observation,
@@ -1368,17 +1371,34 @@ __device__ __attribute__((noinline)) void logit_shard(LogitShard c) {
       sload(xa, xp);
       sload(xb, xp + OB * PL);
       front(xa, sva, pra);                        // pass 0's lookups in flight
-      for (int ps = 0; ps < nps; ps += 2) {
-        __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0): pass ps's coefficients, pass ps + 1's covariates
-        sload(xa, xp + 2 * OB * PL);
-        front(xb, svb, prb);                      // pass ps + 1
-        back(sva, pra, 0);                        // pass ps
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        sload(xb, xp + 3 * OB * PL);
-        front(xa, sva, pra);                      // pass ps + 2
-        if (ps + 1 < nps) back(svb, prb, 1);      // pass ps + 1
-        xp += 2 * OB * PL;
+      // ISSUE PRIORITY IN TWO TURNS (round 5).  The arbiter of a SIMD serves its OLDEST ready wave first: of the two waves of a SIMD
+      // (w and w + 4) the older one ran this loop at the pace of a wave that has the SIMD to itself and was done after 38.9 us, the
+      // younger one filled the gaps and then ran its last 17 us ALONE (stamps of all eight waves, tools/stamp_c5.py: 38.9 / 55.7 us)
+      // -- and one wave alone issues at ~0.64 of the rate of two.  Now the YOUNGER wave holds priority 1 for the first `turn`
+      // thousandths of its passes and drops to 0 for the rest: first it is the one that runs ahead, then the older one, and the two
+      // finish together.  (Priority alternating pass by pass was measured too: 68.3 us per step against 61.1 without.)
+      // (two copies of the loop, the priority changed between them: a compare and a branch around s_setprio inside the loop split
+      //  its basic block and cost 4.7 us per step)
+      const int nturn = ((rfl_i(tid >> 6) >= NW / 2) ? (int)(((long long)nps * rfl_i(c.turn)) / 1000) : 0) & ~1;
+      auto passes = [&](const int from, const int to) {
+        for (int ps = from; ps < to; ps += 2) {
+          __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0): pass ps's coefficients, pass ps + 1's covariates
+          sload(xa, xp + 2 * OB * PL);
+          front(xb, svb, prb);                      // pass ps + 1
+          back(sva, pra, 0);                        // pass ps
+          __builtin_amdgcn_s_waitcnt(0xC07F);
+          sload(xb, xp + 3 * OB * PL);
+          front(xa, sva, pra);                      // pass ps + 2
+          if (ps + 1 < nps) back(svb, prb, 1);      // pass ps + 1
+          xp += 2 * OB * PL;
+        }
+      };
+      if (nturn > 0) {
+        __builtin_amdgcn_s_setprio(1);
+        passes(0, nturn);
+        __builtin_amdgcn_s_setprio(0);
       }
+      passes(nturn, nps);
       __builtin_amdgcn_s_waitcnt(0xC07F);
     } else {
       for (int ps = 0; ps < npass; ps++) {
@@ -1410,7 +1430,7 @@ __device__ __forceinline__ void eval_sharded_logit_step(const SweepArgs& A, cons
   ls.NC = (int)A.nchains; ls.ncp = (int)A.nchains + SH_PAD; ls.ic = A.intercept; ls.lane0 = lane0;
   // slots of lane l that hold an observation: i = 512 slot + l < n
   auto nvalid = [&](int l) -> int { const long long v = (A.n - l + NT - 1) / NT; return (int)(v < 0 ? 0 : (v > nslots ? nslots : v)); };
-  ls.nv0 = nvalid(lane0); ls.nv1 = nvalid(lane0 + 1); ls.pad_ = 0;
+  ls.nv0 = nvalid(lane0); ls.nv1 = nvalid(lane0 + 1); ls.turn = A.sh_t10;   // (sh_t10: this family's use of the field)
   const bool two = A.nchains > NT;     // (uniform) more than 512 chains in the launch: two chains per thread side by side
   switch (A.p) {
 #define LG_CASE(P_) case P_: if (two) logit_shard<P_, 2>(ls); else logit_shard<P_, 1>(ls); break;

@@ -1012,8 +1012,11 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
     if (lshard) {
       double* shw = nullptr;
       // (+ 8 observations behind the last slice: the pipelined loop's scalar loads run up to three passes ahead without a clamp)
-      const size_t nxs = (size_t)nb_launch * nslots * 2 * m->p + 8 * (size_t)m->p, nth = ((size_t)kn->k * (ch_launch + SH_PAD) + 7) & ~(size_t)7,
-                   npt = (size_t)(NT + SH_PAD) * ch_launch, nbar = 32 * 20 / 2;
+      // (mh_sweep_logit2 holds four chains per workgroup whatever cw says: tables for the larger of the two launch widths)
+      const long long ch_shadow = (run->nchains < 4 * nb_launch) ? (long long)run->nchains : 4 * nb_launch;
+      const long long ch_tab = (ch_shadow > ch_launch) ? ch_shadow : ch_launch;
+      const size_t nxs = (size_t)nb_launch * nslots * 2 * m->p + 8 * (size_t)m->p, nth = ((size_t)kn->k * (ch_tab + SH_PAD) + 7) & ~(size_t)7,
+                   npt = (size_t)(NT + SH_PAD) * ch_tab, nbar = 32 * 20 / 2;
       e = hipMallocAsync((void**)&shw, sizeof(double) * (nxs + nth + npt + nbar), stream);
       if (e != hipSuccess) { set_err("hipMallocAsync(sharded evaluation) failed: %s", hipGetErrorString(e)); return FMCMC_ERR_DEVICE; }
       shw_guard.p = shw; shw_guard.s = stream;
@@ -1021,6 +1024,7 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
       (void)hipMemsetAsync(xs + (size_t)nb_launch * nslots * 2 * m->p, 0, sizeof(double) * 8 * (size_t)m->p, stream);
       hipLaunchKernelGGL(logit_build_slices, dim3((unsigned)nb_launch), dim3(256), 0, stream, m->X, (long long)m->n, m->p, nslots, xs);
       A.shard = 2; A.sh_nslots = nslots; A.sh_xs = xs; A.sh_ys = nullptr; A.sh_th = thw; A.sh_part = ptw; A.sh_bar = bar;
+      A.sh_t10 = (K.t10 >= 0) ? K.t10 : 640;   // (logit_shard: the younger wave's turn at the issue priority, thousandths of its passes)
       g_kernel = "logistic-sharded";
       // Round 5: the canonical stream of the call materialised in front of the sweep (rng_fill_kernel), where it fits 1 GiB, instead
       // of being drawn inside the cooperative kernel: there the draws of a tile of steps -- Philox, AS241 with its ~50 constants
@@ -1043,16 +1047,39 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
           (void)hipGetLastError();
         }
       }
+      // (variates from a stream, the library's or the caller's: the instantiation without the generators in its body)
+      const void* kfr = kfn;
+      size_t lds_run = lds;
+      long long ch_run = ch_launch;
+      if (A.rng_mode == FMCMC_RNG_FED) {
+        const void* kf2 = fmh::k_logit(cw <= 2 ? cw : 4, 2, lkv);
+        if (kf2 && hipFuncSetAttribute(kf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) kfr = kf2;
+        else (void)hipGetLastError();
+        // the normal / uniform proposal kernels, joint scheme, no fixed parameter: mh_sweep_logit2 (mh_logit2.hpp) -- four chains per
+        // workgroup whatever cw says, the owners' work in the shadow of the hand-overs (knob wide2=0: off)
+        const void* kf3 = (K.wide2 != 0 && kn->scheme == FMCMC_SCHEME_JOINT && kf == kn->k && A.kz == kn->k) ? fmh::k_logit2(lkv) : nullptr;
+        if (kf3) {
+          const size_t lds3 = fmh::k_logit2_lds(kn->k);
+          int per3 = 0;
+          if (hipFuncSetAttribute(kf3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3) == hipSuccess &&
+              hipOccupancyMaxActiveBlocksPerMultiprocessor(&per3, kf3, NT, lds3) == hipSuccess && (long long)per3 * ncu >= nb_launch) {
+            kfr = kf3; lds_run = lds3; ch_run = ch_shadow;
+            g_kernel = "logistic-shadow";
+          } else {
+            (void)hipGetLastError();
+          }
+        }
+      }
       long long done = 0;
-      for (; done < run->nchains && e == hipSuccess; done += ch_launch) {   // (the slices and tables serve every launch)
-        SweepArgs W = chain_window(A, done, (run->nchains - done < ch_launch) ? run->nchains - done : ch_launch, kf);
+      for (; done < run->nchains && e == hipSuccess; done += ch_run) {   // (the slices and tables serve every launch)
+        SweepArgs W = chain_window(A, done, (run->nchains - done < ch_run) ? run->nchains - done : ch_run, kf);
         (void)hipMemsetAsync(bar, 0, sizeof(double) * nbar, stream);
         void* kargs[] = {(void*)&W};
-        e = hipLaunchCooperativeKernel(kfn, dim3((unsigned)nb_launch), dim3(NT), kargs, (unsigned int)lds, stream);
+        e = hipLaunchCooperativeKernel(kfr, dim3((unsigned)nb_launch), dim3(NT), kargs, (unsigned int)lds_run, stream);
       }
-      if (e != hipSuccess && done > ch_launch) {    // a LATER window failed: the chains of the earlier windows have run
+      if (e != hipSuccess && done > ch_run) {    // a LATER window failed: the chains of the earlier windows have run
         set_err("HIP launch of chain window %lld failed (%s): the state of the first %lld chains is already advanced, the results of this call are invalid",
-                (long long)(done / ch_launch), hipGetErrorString(e), (long long)(done - ch_launch));
+                (long long)(done / ch_run), hipGetErrorString(e), (long long)(done - ch_run));
         (void)hipGetLastError();
         return FMCMC_ERR_DEVICE;
       }

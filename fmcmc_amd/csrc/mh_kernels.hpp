@@ -13,8 +13,11 @@ FMH_HIDDEN const void* k_resident(int p, int kind);
 // k_wide.hip: wide linear models mh_sweep_kernel<CW, -1, LPW, KIND, LINREG>: cw = 1, 2; lpw = 0 (chain-sharded), 2, 4 (observation-
 //             sharded, cooperative); kind = 1, 2, 4 -- and the long-data form <1, -1, 2, KIND, LINREG>, kind 1..4
 FMH_HIDDEN const void* k_wide(int cw, int lpw, int kind);
-// k_logit*.hip: logistic-only instantiations mh_sweep_kernel<CW, -1, OPT, KIND, LOGISTIC, 1>: cw = 1, 2, 4; sharded = 0 | 1 (OPT = 0 | 2)
+// k_logit*.hip: logistic-only instantiations mh_sweep_kernel<CW, -1, OPT, KIND, LOGISTIC, 1>: cw = 1, 2, 4; sharded = 0 | 1 | 2 (OPT = 0 | 2 | 2; 2: variates from a materialised stream only)
 FMH_HIDDEN const void* k_logit(int cw, int sharded, int kind);
+// k_logit3.hip: mh_sweep_logit2<KIND> (kind 1, 2): the observation-sharded sweep with the owners in the shadow of the hand-overs
+FMH_HIDDEN const void* k_logit2(int kind);
+FMH_HIDDEN size_t k_logit2_lds(int k);
 // k_mfma*.hip: mh_sweep_mfma<KV, NG, NS, false, BIG>, and the streamed-operand form <KV, NG, NSRES, false, BIG, true>
 FMH_HIDDEN const void* k_mfma(int kv, int ng, int ns, int big);
 FMH_HIDDEN const void* k_mfma_ext(int kv, int ng, int nsres, int big);

@@ -130,10 +130,13 @@ __device__ __attribute__((noinline)) double ram_update_propose_rows(lds_dptr_t S
   return s;
 }
 
-template <int CW, int P, int OPT, int KIND, int FAM = 0, int MINB = 1>
+// FEDONLY: an instantiation for calls whose variates come from a materialised stream (the observation-sharded logistic sweep since
+// round 5): no Philox, no AS241 with its ~50 constants in the kernel body -- they were what its step loop kept in scratch.
+template <int CW, int P, int OPT, int KIND, int FAM = 0, int MINB = 1, bool FEDONLY = false>
 __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) {
   constexpr bool RESIDENT = (P >= 0);
   SweepArgs A = A0;
+  const bool fed = FEDONLY ? true : (A0.rng_mode == FMCMC_RNG_FED);
   if constexpr (KIND > 0) A.kind = KIND;
   extern __shared__ double smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -369,10 +372,10 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
       const unsigned int st = (unsigned int)(A.step_base + ii);
       double v;
       if (a == kz) {
-        v = (A.rng_mode == FMCMC_RNG_FED) ? A.fed_logu[clc * A.nsteps + (ii - 1)] : fmh_log_accept_u(A.seed, st, cg);
+        v = (fed) ? A.fed_logu[clc * A.nsteps + (ii - 1)] : fmh_log_accept_u(A.seed, st, cg);
         s_lu[c * TB + t] = v;
       } else {
-        if (A.rng_mode == FMCMC_RNG_FED) v = A.fed_z[(clc * A.nsteps + (ii - 1)) * kz + a];
+        if (fed) v = A.fed_z[(clc * A.nsteps + (ii - 1)) * kz + a];
         else if (A.kind == FMCMC_KERNEL_RAM && A.ram_df > 0.0) v = fmh_student_t(A.seed, st, cg, (unsigned int)a, A.ram_df);
         else if (A.variate == 1) v = fmh_unif(A.seed, st, cg, (unsigned int)a);
         else v = fmh_normal(A.seed, st, cg, (unsigned int)a);
@@ -424,7 +427,7 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
         } else if (A.scheme == FMCMC_SCHEME_EXPLICIT) {
           col = A.scheme_seq[(i - 1) % A.scheme_len];
         } else if (A.scheme == FMCMC_SCHEME_RANDOM) {
-          if (A.rng_mode == FMCMC_RNG_FED) {
+          if (fed) {
             col = A.scheme_cols[cl * A.nsteps + (i - 1)];
           } else {
             // sample(which(!fixed), nsteps, TRUE)[i]; a single free parameter at position j makes R sample from 1:j
@@ -466,7 +469,7 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
         } else if (A.scheme == FMCMC_SCHEME_EXPLICIT) {
           col = A.scheme_seq[(i - 1) % A.scheme_len];
         } else if (A.scheme == FMCMC_SCHEME_RANDOM) {
-          if (A.rng_mode == FMCMC_RNG_FED) {
+          if (fed) {
             col = A.scheme_cols[cl * A.nsteps + (i - 1)];
           } else {
             const unsigned int npool = (kf == 1) ? (unsigned int)(s_which[0] + 1) : (unsigned int)kf;
@@ -724,6 +727,12 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
   }
 #ifdef FMCMC_STAMP
   if (wave == 0 && owner && lane < 16 && k >= 16) A.status_theta[cl * k + lane] = (double)stamps.acc[lane];
+  // (narrow models: over the first 16 kept rows of the chain's first parameter -- the stamped build's results are not results)
+  if (FMCMC_STAMP_WAVE >= 0 && wave == 0 && owner && lane < 16 && k < 16 && A.ldS >= 16) { __builtin_amdgcn_s_waitcnt(0); A.samples[(cl * k) * A.ldS + lane] = (double)stamps.acc[lane]; }
+  if (FMCMC_STAMP_WAVE < 0 && lane < 16 && A.ldS >= 128) {   // every wave: rows 16 w .. 16 w + 15 of the workgroup's first chain
+    __syncthreads();
+    A.samples[(cg0 * k) * A.ldS + 16 * wave + lane] = (double)stamps.acc[lane];
+  }
 #endif
 
   // ---- write state back

@@ -463,7 +463,7 @@ def test_c3_exact_shape_equals_the_oracle(E, O):
     del rg, ro, st
 
 
-def test_c5_full_width_equals_the_oracle(E, O):
+def test_c5_full_width_equals_the_oracle(E, O, monkeypatch):
     """configs[4] at its per-GPU width: 1024 chains, logistic n = 100,000, k = 6, kernel_normal_reflective(scale = .01, lb = -5,
     ub = 5), thin 10 -- the observation-sharded form with TWO chains per thread (logit_shard<5, 2, 2>, the instantiation the
     bench runs), 21 steps (two kept rows) and a continuation of 11, bit for bit."""
@@ -474,8 +474,12 @@ def test_c5_full_width_equals_the_oracle(E, O):
     assert X.shape == (100000, 5) and init.shape == (1024, 6)
     run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_NORMAL_REFLECTIVE, 6, init, nsteps=21, thin=10, seed=bench.CHAIN_SEED,
              prior_div=8.0, guard=False, scale=0.01, lb=-5.0, ub=5.0, threads=16)
-    assert abi.last_kernel() == "logistic-sharded"
+    assert abi.last_kernel() == "logistic-shadow"        # (round 5: the owners in the shadow of the hand-overs, mh_sweep_logit2)
     run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_NORMAL_REFLECTIVE, 6, init, nsteps=11, thin=1, seed=bench.CHAIN_SEED,
+             prior_div=8.0, guard=False, scale=0.01, lb=-5.0, ub=5.0, threads=16)
+    assert abi.last_kernel() == "logistic-shadow"
+    set_knob(monkeypatch, "wide2", "0")                  # the same call on the general kernel's observation-sharded form
+    run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_NORMAL_REFLECTIVE, 6, init, nsteps=11, thin=2, seed=bench.CHAIN_SEED,
              prior_div=8.0, guard=False, scale=0.01, lb=-5.0, ub=5.0, threads=16)
     assert abi.last_kernel() == "logistic-sharded"
 
@@ -753,6 +757,13 @@ def test_logistic_observation_sharded(E, O, monkeypatch, p, intercept, C):
     steps = 24 if C > 100 else 60
     run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_NORMAL, k, init, nsteps=steps, burnin=5, thin=2, calls=2,
              prior_div=8.0, scale=0.04, intercept=intercept)
+    assert abi.last_kernel() == "logistic-shadow"
+    run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_NORMAL_REFLECTIVE, k, init, nsteps=steps, prior_div=0.0,
+             scale=0.3, lb=-2.0, ub=2.0, intercept=intercept)
+    assert abi.last_kernel() == "logistic-shadow"
+    set_knob(monkeypatch, "wide2", "0")                  # (the general kernel's observation-sharded form, variates from the stream)
+    run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_NORMAL, k, init, nsteps=steps, burnin=5, thin=2, calls=2,
+             prior_div=8.0, scale=0.04, intercept=intercept)
     assert abi.last_kernel() == "logistic-sharded"
     run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_NORMAL_REFLECTIVE, k, init, nsteps=steps, prior_div=0.0,
              scale=0.3, lb=-2.0, ub=2.0, intercept=intercept)
@@ -781,7 +792,7 @@ def test_c5_exact_shape_equals_the_oracle(E, O, monkeypatch, n, form):
     for thin, steps in ((10, 31), (1, 12)):
         run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_NORMAL_REFLECTIVE, 6, init, nsteps=steps, thin=thin, prior_div=8.0,
                  guard=False, scale=0.01, lb=-5.0, ub=5.0)
-        assert abi.last_kernel() == ("logistic-sharded" if form == "observation-sharded" else "streamed-logistic")
+        assert abi.last_kernel() == ("logistic-shadow" if form == "observation-sharded" else "streamed-logistic")
 
 
 @pytest.mark.parametrize("cw", ["1", "2"])
@@ -1220,7 +1231,7 @@ def test_a_lost_hand_over_ends_in_status_5_not_in_a_hang(E, monkeypatch, form):
     r = E.sweep(gm, gk, st, 40, seed=7, check=False)
     torch.cuda.synchronize()
     assert time.time() - t0 < 120.0
-    want = {"logistic-sharded": "logistic-sharded", "wide-sequential": "streamed-wide-sharded-mfma", "wide-dataflow": "wide-dataflow",
+    want = {"logistic-sharded": "logistic-shadow", "wide-sequential": "streamed-wide-sharded-mfma", "wide-dataflow": "wide-dataflow",
             "long-sharded": "long-sharded"}[form]
     assert abi.last_kernel() == want
     status = r.status.cpu().numpy()
@@ -1676,7 +1687,7 @@ def test_full_size_logistic_and_wide_properties(E, monkeypatch):
         return r, st
 
     full, _ = run5(0, C5, 10)
-    assert abi.last_kernel() == "logistic-sharded"
+    assert abi.last_kernel() == "logistic-shadow"
     assert full.samples.shape[-1] == steps5 // 10
     assert bool((full.samples.abs() <= 5.0).all())
     part, _ = run5(256, 768, 10)
@@ -1914,7 +1925,7 @@ def test_randomised_round4_regions_reached_their_kernels():
     if int(os.environ.get("FMCMC_TEST_RANDOM_CASES3", "64")) >= 64:
         assert {"mfma-streamed", "mfma-adaptive"} <= _R4_PICKED["A"], _R4_PICKED
         assert _R4_PICKED["B"] == {"big-k"}, _R4_PICKED
-        assert "logistic-sharded" in _R4_PICKED["C"], _R4_PICKED
+        assert {"logistic-sharded", "logistic-shadow"} & _R4_PICKED["C"], _R4_PICKED
         assert any(kn.startswith("spec") for kn in _R4_PICKED["D"]), _R4_PICKED
         assert "long-sharded" in _R4_PICKED["E"], _R4_PICKED
 
