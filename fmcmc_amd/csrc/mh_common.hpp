@@ -377,12 +377,22 @@ __device__ __forceinline__ ChainLds chain_lds(double* base, int k, int kf, int k
 // neighbouring rows, which neighbouring addresses serve without conflict.
 typedef double lg_v2d __attribute__((ext_vector_type(2)));
 constexpr int LG_LDS_DOUBLES = FMH_LG_ROWS * 6;       // rows of 48 bytes, c0 .. c5, as in include/fmh_logit_tab.h
+constexpr int LG_LDS_TAIL = 2 + 6;                     // doubles allocated behind them: alignment slack + 12 control words (logit_shard's issue-priority turns)
 __device__ __forceinline__ double* logit_table_align(double* p) {   // 16-byte aligned start inside [p, p + 2)
   return (double*)(((unsigned long long)p + 15ull) & ~15ull);
 }
 __device__ __forceinline__ void logit_stage_table(double* s_tab) {
   const double* t = fmh_lg_tab_();
   for (int i = threadIdx.x; i < FMH_LG_ROWS * 6; i += blockDim.x) s_tab[i] = t[i];
+}
+__device__ __forceinline__ unsigned cycle_stamp32() {   // low word of the shader clock
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  return (unsigned)t;
+}
+// the 12 control words behind the table (LG_LDS_TAIL), for the launches that call logit_shard: "not set yet"
+__device__ __forceinline__ void logit_reset_turns(double* s_tab) {
+  if (threadIdx.x < 12) reinterpret_cast<unsigned*>(s_tab + LG_LDS_DOUBLES)[threadIdx.x] = 0xFFFFFFFFu;
 }
 
 // LDSTAB is a COMPILE-TIME property (the logistic-only instantiations always stage the table; the all-family kernels read
@@ -1374,12 +1384,35 @@ __device__ __attribute__((noinline)) void logit_shard(LogitShard c) {
       // ISSUE PRIORITY IN TWO TURNS (round 5).  The arbiter of a SIMD serves its OLDEST ready wave first: of the two waves of a SIMD
       // (w and w + 4) the older one ran this loop at the pace of a wave that has the SIMD to itself and was done after 38.9 us, the
       // younger one filled the gaps and then ran its last 17 us ALONE (stamps of all eight waves, tools/stamp_c5.py: 38.9 / 55.7 us)
-      // -- and one wave alone issues at ~0.64 of the rate of two.  Now the YOUNGER wave holds priority 1 for the first `turn`
-      // thousandths of its passes and drops to 0 for the rest: first it is the one that runs ahead, then the older one, and the two
-      // finish together.  (Priority alternating pass by pass was measured too: 68.3 us per step against 61.1 without.)
-      // (two copies of the loop, the priority changed between them: a compare and a branch around s_setprio inside the loop split
-      //  its basic block and cost 4.7 us per step)
-      const int nturn = ((rfl_i(tid >> 6) >= NW / 2) ? (int)(((long long)nps * rfl_i(c.turn)) / 1000) : 0) & ~1;
+      // -- and one wave alone issues at ~0.64 of the rate of two.  Now the YOUNGER wave holds priority 1 for its first `nturn`
+      // passes and drops to 0 for the rest: first it is the one that runs ahead, then the older one, and the two finish together.
+      // nturn REGULATES ITSELF: both waves leave their finishing time (s_memtime) in LDS, and at its next call the younger one
+      // moves its turn by (its time - the partner's + bias) / 512 cycles, at most 8 passes -- the balance point depends on p, on
+      // the chains per thread and on the clock, and a fixed fraction that was right for config C5 (0.72) was wrong by 2 % at 0.675.
+      // Measured at C5 (tools/bench_c5_turn.sh, us per step): no turn 61.2; fixed 0.64 / 0.72: 59.9 / 58.9; regulated with the
+      // younger wave meant to finish 0 / 2048 / 4096 / 6144 / 8192 cycles BEFORE its partner: 59.8 / 59.2 / 58.9 / 59.1 / 59.3.
+      // c.turn = thousandths to start from + 10000 (stay there) + 100000 x (bias / 256 cycles).
+      // Timing only: no result depends on it.  (Priority alternating pass by pass was measured too: 68.3 us per step against 61.1;
+      // a compare and a branch around s_setprio inside the loop split its basic block: two copies of the loop instead.)
+      typedef __attribute__((address_space(3))) unsigned* ldsu_t;
+      const int wv = rfl_i(tid >> 6), simd = wv & 3;
+      const bool young = wv >= NW / 2;
+      const ldsu_t ctl = (ldsu_t)(unsigned long long)(tabaddr + (unsigned)(LG_LDS_DOUBLES * 8));   // [4] nturn | [4] end of the older | [4] of the younger wave
+      const int tset = rfl_i(c.turn);                      // thousandths of the passes to start from (+ 10000: and to stay at)
+      int nturn = 0;
+      if (young) {
+        int cur = rfl_i((int)ctl[simd]);
+        if (cur < 0 || cur > nps) cur = (int)(((long long)nps * (tset % 10000)) / 1000);
+        else if ((tset % 100000) < 10000) {
+          const int diff = rfl_i((int)(ctl[8 + simd] - ctl[4 + simd])) + 256 * (tset / 100000);      // > 0: this wave was later than it is meant to be
+          int step = diff / 512;
+          step = step > 8 ? 8 : (step < -8 ? -8 : step);
+          cur += step;
+          cur = cur < 0 ? 0 : (cur > nps ? nps : cur);
+        }
+        if ((tid & 63) == 0) ctl[simd] = (unsigned)cur;
+        nturn = cur & ~1;
+      }
       auto passes = [&](const int from, const int to) {
         for (int ps = from; ps < to; ps += 2) {
           __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0): pass ps's coefficients, pass ps + 1's covariates
@@ -1400,6 +1433,7 @@ __device__ __attribute__((noinline)) void logit_shard(LogitShard c) {
       }
       passes(nturn, nps);
       __builtin_amdgcn_s_waitcnt(0xC07F);
+      if ((tid & 63) == 0) ctl[(young ? 8 : 4) + simd] = cycle_stamp32();
     } else {
       for (int ps = 0; ps < npass; ps++) {
 #pragma unroll

@@ -948,7 +948,7 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
     }
   } else
   if (resident) { g_kernel = "resident"; e = launch_k(fmh::k_resident(res_p, kn->kind), nblk, NT, lds, stream, A); }
-  else if (!force && m->family == FMCMC_FAM_LOGISTIC && cw <= 4 && lds + sizeof(double) * (LG_LDS_DOUBLES + 2) <= 160 * 1024 &&
+  else if (!force && m->family == FMCMC_FAM_LOGISTIC && cw <= 4 && lds + sizeof(double) * (LG_LDS_DOUBLES + LG_LDS_TAIL) <= 160 * 1024 &&
            (kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE || kn->kind == FMCMC_KERNEL_ADAPT ||
             kn->kind == FMCMC_KERNEL_RAM)) {
     // (round 4: kernel_adapt / kernel_ram too -- the workflow vignette's own model is a logistic regression under kernel_adapt;
@@ -958,7 +958,7 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
     // the run-time loop (logit_partials_any) -- still with the table in LDS, which is what the all-family kernel lacks
     g_kernel = "streamed-logistic";
     const int lkv = kn->kind;   // 1 .. 4
-    lds += sizeof(double) * (LG_LDS_DOUBLES + 2);   // the table staged behind the chain blocks (16-byte aligned)
+    lds += sizeof(double) * (LG_LDS_DOUBLES + LG_LDS_TAIL);   // the table staged behind the chain blocks (16-byte aligned), logit_shard's control words
     // Observation-sharded form (mh_common.hpp, logit_shard): 256 workgroups of two canonical lanes each evaluate ALL chains
     // of the launch, up to 256 x cw of them; more chains run as consecutive launches.  Cost model (us per step): the
     // chain-sharded loop costs ~(p + 12) instructions per observation and chain, 4.5 + n cw (p + 12) 1.35e-5 with the
@@ -988,12 +988,18 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
         !(kn->kind == FMCMC_KERNEL_RAM && ram_bounded)) {
       // (refitted to tools/dispatch_audit.py, profiles/r04_dispatch_audit.md: n = 2e3 .. 1e5, p = 2, 5, 8, 64 .. 4096 chains)
       const double w = (double)m->n * (double)(m->p + 12);
-      const double stream_us = (double)m->n * (double)(m->p + 1) * 8.0 / 9.0e4;      // a workgroup's pass over the data set at ~90 GB/s
+      const double stream_us = (double)m->n * ((double)m->p + 0.5) * 8.0 / 9.0e4;      // a workgroup's pass over the data set (X only: the term does not read y) at ~90 GB/s
       const double loop_us = w * cw * ((m->p <= 28 / cw - 1) ? 1.35e-5 : 2.8e-5);
       const double rounds = (double)((nblk + ncu - 1) / ncu), launches = (double)((run->nchains + ch_launch - 1) / ch_launch);
       const double est_chain = (4.5 + (loop_us > stream_us ? loop_us : stream_us)) * rounds;
       const double passes = (double)((ch_launch + NT - 1) / NT);                       // chains per thread of the sharded loop
-      const double est_shard = (10.3 + 2.2 * (passes - 1.0) + 1.78e-5 * (double)m->n * ((double)m->p + 10.3) * passes) * launches;
+      // (round 5: the issue-priority turns of logit_shard, and for the normal / uniform kernels mh_sweep_logit2 -- four chains per
+      //  workgroup whatever cw says --: 5 .. 15 % off every row of profiles/r05_dispatch_audit_logistic.md)
+      const bool shadow_ok = K.wide2 != 0 && kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE && kn->scheme == FMCMC_SCHEME_JOINT && kf == kn->k;
+      const double launches_s = shadow_ok ? (double)((run->nchains + 4 * nb_launch - 1) / (4 * nb_launch)) : launches;
+      const double passes_s = shadow_ok ? (double)(((run->nchains < 4 * nb_launch ? run->nchains : 4 * nb_launch) + NT - 1) / NT) : passes;
+      const double est_shard = ((shadow_ok ? 8.5 : 10.0) + 2.2 * (passes_s - 1.0) +
+                                (shadow_ok ? 1.62e-5 : 1.72e-5) * (double)m->n * ((double)m->p + 10.3) * passes_s) * launches_s;
       lshard = K.shard == 1 || est_shard < 0.95 * est_chain;
     }
     const void* kfn = nullptr;
@@ -1024,7 +1030,7 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
       (void)hipMemsetAsync(xs + (size_t)nb_launch * nslots * 2 * m->p, 0, sizeof(double) * 8 * (size_t)m->p, stream);
       hipLaunchKernelGGL(logit_build_slices, dim3((unsigned)nb_launch), dim3(256), 0, stream, m->X, (long long)m->n, m->p, nslots, xs);
       A.shard = 2; A.sh_nslots = nslots; A.sh_xs = xs; A.sh_ys = nullptr; A.sh_th = thw; A.sh_part = ptw; A.sh_bar = bar;
-      A.sh_t10 = (K.t10 >= 0) ? K.t10 : 640;   // (logit_shard: the younger wave's turn at the issue priority, thousandths of its passes)
+      A.sh_t10 = (K.t10 >= 0) ? K.t10 : 1600700;   // (logit_shard's issue-priority turn: starts at 0.700 of the younger wave's passes, regulated towards a lead of 16 x 256 cycles; knob t10)
       g_kernel = "logistic-sharded";
       // Round 5: the canonical stream of the call materialised in front of the sweep (rng_fill_kernel), where it fits 1 GiB, instead
       // of being drawn inside the cooperative kernel: there the draws of a tile of steps -- Philox, AS241 with its ~50 constants

@@ -82,6 +82,7 @@ __global__ __launch_bounds__(NT, 1) void mh_sweep_logit2(const SweepArgs A) {
     s_hs[tid] = (A.lg_hs && tid < nb) ? A.lg_hs[tid] : 0.0;
   }
   logit_stage_table(s_tab);
+  logit_reset_turns(s_tab);
   __syncthreads();
 
   const long long cg0 = (long long)blockIdx.x * LG2_CW;
@@ -234,6 +235,6 @@ __global__ __launch_bounds__(NT, 1) void mh_sweep_logit2(const SweepArgs A) {
   }
 }
 
-size_t logit2_lds_bytes(int k) { return sizeof(double) * (size_t)(5 * k + NW * LG2_CW + 2 + LG_LDS_DOUBLES); }
+size_t logit2_lds_bytes(int k) { return sizeof(double) * (size_t)(5 * k + NW * LG2_CW + LG_LDS_TAIL + LG_LDS_DOUBLES); }
 
 }  // namespace

@@ -180,6 +180,7 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
   if constexpr (FAM == FMCMC_FAM_LOGISTIC) {
     double* tabs = logit_table_align(s_chains + CW * CHS);    // 16-byte aligned pairs
     logit_stage_table(tabs);
+    if constexpr (P < 0 && OPT == 2) logit_reset_turns(tabs);     // (the observation-sharded form: logit_shard's control words)
     s_sptab = tabs;
   }
   if constexpr (FAM == FMCMC_FAM_GAUSSIAN_LINREG && P < 0 && OPT > 0) {
