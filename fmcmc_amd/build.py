@@ -74,6 +74,15 @@ def build(force=False, verbose=False, extra_flags=(), out=None, jobs=None):
         dep_t = max(os.path.getmtime(f) for f in [src] + sorted(unit_deps(src)))
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < dep_t:
             todo.append((src, obj))
+    # (longest first: the units that instantiate the most kernels decide the wall time when they start last)
+    HEAVY = ("k_wide.", "k_lat1b", "k_lat2b", "k_lat1a", "k_lat2a", "k_lat1c", "k_lat2c", "k_logit1", "k_spec_a", "k_mfma_ad", "k_logit2", "k_mfma2", "k_mfma1", "k_general")
+    def cost(so):
+        b = os.path.basename(so[0])
+        for i, h in enumerate(HEAVY):
+            if b.startswith(h):
+                return i
+        return len(HEAVY)
+    todo.sort(key=cost)
     jobs = jobs or int(os.environ.get("FMCMC_BUILD_JOBS", "0")) or min(8, os.cpu_count() or 1)
     t0 = time.time()
     times = {}
