@@ -434,8 +434,14 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
   // sigma^2 and the reciprocal half of the division (div_recip / div_finish: bit for bit the plain quotient in the safe
   // range, anything else takes logpost_of) -- and for kernel_ram eta(i, k) and the prefix sums of z^2.
   double pre_nt1 = 0.0, pre_ss = 1.0, pre_rs = 1.0, pre_eta = 0.0, pre_Pj = 0.0, pre_Pj1 = 0.0, pre_nrm2 = 1.0;
+  double pre_c1 = 0.0, pre_c2 = 0.0;   // kernel_adapt: (t - 1) / t and 1 / t of the NEXT covariance update (t = abs_iter - 1: the step's own)
   bool pre_ok = false;
   auto prepare = [&](int i) {   // i: loop step whose proposal is pending (1: the initial state)
+    if (KIND == FMCMC_KERNEL_ADAPT) {
+      const double t = uniform_d((double)(abs_iter - 1));
+      pre_c1 = (t - 1) / t;
+      pre_c2 = 1.0 / t;
+    }
     const double sigma = readlane_d(th1, k - 1);
     const unsigned sg_hi = (unsigned)(fmh_d2u(sigma) >> 32);
     const bool sg_fast = (sg_hi - 0x00100000u) < 0x7fe00000u;            // positive, finite, normal
@@ -551,7 +557,7 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
             const double x = th0;
             const double mp = have_mean ? mean_prev : (run_sum / (double)(i + ioff - 1));
             const double mt = (mp * t + x) / (t + 1);
-            const double c1 = (t - 1) / t, c2 = 1.0 / t;
+            const double c1 = pre_c1, c2 = pre_c2;       // (prepared while this wave waited for the partials: two divisions off the pass)
             static_for<KA>([&](auto b_) {
               constexpr int b = decltype(b_)::value;
               if (b < kf) {
@@ -574,14 +580,18 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
           double Dl = 0.0;                    // D_lane
           static_for<KA>([&](auto j_) {
             constexpr int j = decltype(j_)::value;
-            if (j < kf && !notpd) {
+            // (a compile-time row count: NO branch per column -- a pivot that fails marks the factor, the columns behind it compute
+            //  values nobody reads; every `if (!notpd)` was a scalar branch with its exec bookkeeping in the owner's dependent pass)
+            if (j < kf && (KX > 0 || !notpd)) {
               double sacc = Srow[j];
               static_for<j>([&](auto b_) {
                 constexpr int b = decltype(b_)::value;
                 sacc = fmac_row_bcast<j, true>(sacc, Wrow[KIND == FMCMC_KERNEL_ADAPT ? b : 0], Lrow[b]);   // fma(-L_lane,b, W_jb, sacc)
               });
               const double d = readlane_d(sacc, j);
-              if (!(d > 0.0) || !fmh_isfinite(d)) {
+              const bool badp = !(d > 0.0) || !fmh_isfinite(d);
+              if (KX > 0) notpd = notpd || badp;
+              if (KX <= 0 && badp) {
                 notpd = true;
               } else {
                 // selects, not exec-mask regions: every `if (lane ...)` costs three scalar instructions and a branch, and
