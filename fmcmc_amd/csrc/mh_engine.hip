@@ -393,6 +393,9 @@ static SweepArgs chain_window(const SweepArgs& A, long long off, long long cnt, 
 //   groups=4     four chain groups in the dataflow form (default two)       tiles=0     even N-tile shares of its evaluator waves
 //   window=N     step-window length of the stream-fed kernels (multiple of 32; default: ~256 MiB of stream per window)
 //   t10=0        the sharded slice product's third M-tile as a 16x16x4 tile even where 8 of its rows are padding
+//   (logistic family, observation-sharded form: wide2=0 keeps the normal / uniform kernels off mh_sweep_logit2; t10=<turn> is where
+//    the younger wave's turn at the issue priority starts, in thousandths of its passes, + 10000: and stays, + 100000 x lead / 256
+//    cycles it is regulated towards -- logit_shard, mh_common.hpp; timing only)
 //   mode=<bits>  timing ablations and stamps (SweepArgs.debug)
 // The kernel a call ended up on is reported by fmcmc_last_kernel(); DESIGN.md section 5 has the shape -> kernel table.
 struct Knobs {

@@ -770,6 +770,38 @@ def test_logistic_observation_sharded(E, O, monkeypatch, p, intercept, C):
     assert abi.last_kernel() == "logistic-sharded"
 
 
+def test_logit_shard_priority_turns_change_no_bit(E, monkeypatch):
+    """logit_shard gives the younger wave of every SIMD the issue priority for the first part of its passes and regulates where that
+    turn ends from the two waves' finishing times (round 5): TIMING only.  The same call with no turn, with a fixed early and a fixed
+    late turn and with the regulated one: identical samples, log-posteriors and states, on both observation-sharded kernels."""
+    import torch
+    from fmcmc_amd import _abi as abi
+    if torch.cuda.get_device_properties(0).multi_processor_count < 256:
+        pytest.skip("the sharded forms need all 256 CUs")
+    set_knob(monkeypatch, "shard", "1")
+    rng = np.random.default_rng(811)
+    n, p, C = 512 * 9 + 77, 4, 700
+    X = rng.standard_normal((n, p)); y = (rng.uniform(size=n) < 0.45).astype(np.float64)
+    k = p + 1
+    big = E.DBL_MAX
+    gm = E.DeviceModel(abi.FAM_LOGISTIC, X, y, intercept=True, guard=False, prior_div=8.0)
+    init = 0.1 * rng.standard_normal((C, k))
+    for kind, want in ((abi.KERNEL_NORMAL, "logistic-shadow"), (abi.KERNEL_ADAPT, "logistic-sharded")):
+        gk = (E.KernelSpec(kind, k, np.zeros(k), np.full(k, 0.05), np.full(k, -big), np.full(k, big), np.zeros(k, np.uint8)) if kind == abi.KERNEL_NORMAL
+              else E.KernelSpec(kind, k, np.zeros(k), np.ones(k), np.full(k, -big), np.full(k, big), np.zeros(k, np.uint8), warmup=10))
+        ref = None
+        for turn in ("0", "10250", "10900", "-1"):
+            set_knob(monkeypatch, "t10", turn)
+            st = E.ChainState(init, gk.kf)
+            r = E.sweep(gm, gk, st, 60, seed=77)
+            assert abi.last_kernel() == want
+            got = (r.samples.clone(), r.logpost.clone(), st.theta0.clone(), st.Sigma.clone())
+            if ref is None:
+                ref = got
+            else:
+                assert all(torch.equal(a, b) for a, b in zip(ref, got)), (want, turn)
+
+
 @pytest.mark.parametrize("n", [100000, 99841, 100351])
 @pytest.mark.parametrize("form", ["chain-sharded", "observation-sharded"])
 def test_c5_exact_shape_equals_the_oracle(E, O, monkeypatch, n, form):
