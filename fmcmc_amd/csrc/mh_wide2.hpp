@@ -271,7 +271,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
 #define W2_EVENT(cond, idx) do { if ((cond) && lane == 0 && k >= 48 && (long long)blockIdx.x * 2 < A.nchains) \
     A.status_theta[(long long)blockIdx.x * 2 * k + (idx)] = (double)__builtin_amdgcn_s_memrealtime(); } while (0)
     unsigned long long ev_acc[4] = {0, 0, 0, 0}, ev_prev = stamp_clk();
-#define W2_EV_STAMP(i) do { if (wave == 2) { const unsigned long long t_ = stamp_clk(); ev_acc[i] += t_ - ev_prev; ev_prev = t_; } } while (0)
+#define W2_EV_STAMP(i) do { if (wave == 2 || FMCMC_STAMP_WAVE < 0) { const unsigned long long t_ = stamp_clk(); ev_acc[i] += t_ - ev_prev; ev_prev = t_; } } while (0)
 #else
 #define W2_EV_STAMP(i) do { } while (0)
 #define W2_EVENT(cond, idx) do { } while (0)
@@ -319,6 +319,9 @@ __global__ __launch_bounds__(NT) void mh_sweep_wide2(const SweepArgs A0) {
 #ifdef FMCMC_STAMP
     if (wave == 2 && lane < 4 && k >= 32 && (long long)blockIdx.x * 2 < A.nchains)
       A.status_theta[(long long)blockIdx.x * 2 * k + 16 + lane] = (double)ev_acc[lane];
+    // (-DFMCMC_STAMP_WAVE=-1: every evaluator wave, four words each behind wave 2's)
+    if (FMCMC_STAMP_WAVE < 0 && wave > 2 && lane < 4 && k >= 44 && (long long)blockIdx.x * 2 < A.nchains)
+      A.status_theta[(long long)blockIdx.x * 2 * k + 16 + 4 * (wave - 2) + lane] = (double)ev_acc[lane];
 #endif
     return;
   }

@@ -28,3 +28,8 @@ for i, nm in enumerate(["wait for partials", "gather + log-posterior", "adapt (r
 print("evaluator wave 2 (us per step = both groups)")
 for i, nm in enumerate(["wait for proposals", "slice product (MFMA)", "drain stores", "arrive"]):
     print("  %-26s %7.2f %7.2f" % (nm, np.median(ev[:, i]) / tps, ev[:, i].max() / tps))
+if os.environ.get("STAMP_ALL", "0") == "1":      # the build with -DFMCMC_STAMP_WAVE=-1: every evaluator wave (2 .. 7; SIMD = wave % 4)
+    print("all evaluator waves (us per step: wait for proposals | slice product | drain | arrive)")
+    for w in range(2, 8):
+        e = d[:, 16 + 4 * (w - 2):20 + 4 * (w - 2)]
+        print("  wave %d (SIMD %d): %7.2f %7.2f %7.2f %7.2f" % ((w, w % 4) + tuple(np.median(e[:, i]) / tps for i in range(4))))
