@@ -544,8 +544,8 @@ def main():
 
     chains = args.chains or cfg.chains
     scaling = "weak"
-    strong_ok = world > 1 and cfg.name in ("c2", "c3") and not args.chains and cfg.chains % world == 0
-    if args.scaling == "strong" and world > 1 and cfg.name in ("c2", "c3") and not args.chains:
+    strong_ok = world > 1 and not args.chains and cfg.chains % world == 0
+    if args.scaling == "strong" and world > 1 and not args.chains:
         if cfg.chains % world:
             raise SystemExit("bench.py --scaling strong: %d chains do not divide over %d ranks" % (cfg.chains, world))
         chains, scaling = cfg.chains // world, "strong"
@@ -559,7 +559,7 @@ def main():
         ranks_seen = [None] * world
         dist.all_gather_object(ranks_seen, me)
     res = run_config(cfg, chains, iters, args.steps, args.warmup, world, rank, dev, dist, torch, E, abi)
-    # C2 / C3 on N > 1 GPUs: BOTH scalings in one invocation.  The reference scales a FIXED number of chains over its workers
+    # N > 1 GPUs: BOTH scalings in one invocation (every config since round 5).  The reference scales a FIXED number of chains over its workers
     # (R/mcmc.R:536-641), i.e. strong scaling -- 1024 / N chains per GPU, the latency form of the kernels below 1024 --, the
     # contract's line is per-GPU work fixed (weak).  `value` / `scaling` are the leg --scaling names; `scalings` holds both.
     scalings = {scaling: {"value": res["value"], "chains_per_gpu": chains, "total_chains": chains * world, "ms_per_step": res["ms_per_step"],
@@ -573,8 +573,10 @@ def main():
     # one GPU: what a GPU of a strong-scaled call of this config would see -- 1024 / G chains, measured HERE -- and the curve
     # that follows from it (G x the samples/s of 1024 / G chains on one GPU: chains never interact, R/mcmc.R:590-673)
     projection = None
-    if world == 1 and cfg.name in ("c2", "c3") and not args.chains and not args.iters and not args.no_extra_configs:
-        projection = {"note": "measured on this one GPU with 1024 / G chains; value_G = G x samples/s of that run (no data-path collective exists)",
+    if world == 1 and not args.chains and not args.iters and not args.no_extra_configs:
+        projection = {"note": "measured on this one GPU with %d / G chains; value_G = G x samples/s of that run (%s)" %
+                              (cfg.chains, "the all-reduce of a Gelman check, 1 + 5p + 2p^2 doubles per 1000 iterations, not included" if cfg.name == "c4"
+                               else "no data-path collective exists"),
                       "1": {"chains_per_gpu": cfg.chains, "ms_per_step": res["ms_per_step"], "value": res["value"], "kernel": res["picked"]}}
         for G in (2, 4, 8):
             pr = run_config(cfg, cfg.chains // G, iters, max(3, args.steps // 8), 1, 1, 0, dev, dist, torch, E, abi)

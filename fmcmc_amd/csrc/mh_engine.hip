@@ -457,7 +457,9 @@ static int wide_sharded_lanes(const Knobs& K, const fmcmc_model* m, const fmcmc_
       // (more than three M-tiles: the run-time K-block loop, +5 us; kernel_ram's owners are hidden by the dataflow form only -- more
       //  than 256 chains, at most three M-tiles --, else ~0.17 us per parameter for few chains, ~0.3 in full launches)
       const bool tall = lpw * nslots > SH_MAXO;
-      const bool hidden = ram && run->nchains > 256 && !tall;
+      // (round 5: the dataflow form for 256 chains and fewer too -- two chains per workgroup, half of the workgroups without chains:
+      //  C4's shape at 256 / 128 / 64 chains 15.0 / 14.7 / 12.7 us per step against 20.6 / 18.0 / 17.1 on the sequential form)
+      const bool hidden = ram && !tall && !kn->constr && K.wide2 != 0 && (run->nchains > 256 || cw_now == 2);
       // (refitted once more after the compile-time K-block counts of every width: ~10 of hand-overs, 0.4 + p (0.083 + 0.004 slice observations) per 512
       //  chains at up to three M-tiles; the dataflow form's kernel_ram runs ~2 us UNDER the normal kernels' sequential form)
       const bool tall_rt = tall && (m->p + 3) / 4 > 12;     // (tall slices beyond 12 K-blocks keep the run-time loop: ~5 us more)
@@ -619,6 +621,19 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
     // (measured at k = 50, n = 10k: 1024 chains 63.8 us per step instead of 71.6 with four chains per workgroup; at 2048
     //  chains the general kernel with eight chains per workgroup is level, 123 vs 128, and keeps the sweep)
     else if (cw >= 4 && wide_sharded_pays(K, m, kn, run, ram_bounded, ncu, (long long)ncu, cw)) { cw = 2; wide_switched = true; }
+    // kernel_ram on a wide model with ONE chain per CU or fewer: two per workgroup all the same, so that the sweep is eligible for the
+    // dataflow form (mh_wide2.hpp: two chain groups half a step out of phase; workgroups without chains evaluate like the others)
+    else if (cw == 1 && ncu == 256 && K.wide2 != 0 && m->family == FMCMC_FAM_GAUSSIAN_LINREG && m->p >= 16 && m->p <= 4 * SHM_KBMAX &&
+             kn->kind == FMCMC_KERNEL_RAM && !ram_bounded && !kn->constr && shard_mfma_enabled(K) &&
+             2 * ((m->n + NT - 1) / NT) <= SH_MAXO && run->nchains >= 2 &&
+             !((run->nchains + 1) / 2 == 128 && 4 * ((m->n + NT - 1) / NT) <= SH_MAXO) &&      /* (exactly 128 workgroups of four lanes: the sequential form's own shape) */
+             (m->n + NT - 1) / NT >= 6 &&      /* (short data: the chain-sharded sweep is ahead -- p = 30, n = 1000, 64 chains: 9.7 against 11.6 us) */
+             [&]() {                           /* (the dataflow form's LDS: two owners' factor and partial sums + the slice block -- k = 62 does not fit) */
+               const int nsl = (int)((m->n + NT - 1) / NT), spg = (nsl + 1) / 2, nmt_ = (spg + 3) / 4;
+               const int mblk_ = shm_hdr(nmt_) + nmt_ * ((m->p + 3) / 4) * 64;
+               return nmt_ >= 1 && nmt_ <= 3 && sizeof(double) * wide2_lds_doubles(kn->k, kf, kn->kind, A.kz, mblk_) <= 160 * 1024;
+             }() &&
+             wide_sharded_pays(K, m, kn, run, ram_bounded, ncu, (long long)ncu, 2)) { cw = 2; wide_switched = true; }
     // the logistic-only instantiations (table in LDS; observation-sharded form) exist for up to four chains per workgroup: more
     // than 1024 chains run as more workgroups / consecutive sharded launches there, not on the all-family kernel with eight
     // chains per workgroup (tools/dispatch_audit.py: 4096 chains, n = 1e5, p = 5 took 1244 us per step, 4.7x four launches)
@@ -1120,7 +1135,7 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
     const long long ch_launch = (nblk > nb_launch) ? nb_launch * cw : (long long)run->nchains;
     Knobs Kw = K;
     if (wide_switched && K.shard != 0) Kw.shard = 1;
-    const int lpw = wide_sharded_lanes(Kw, m, kn, run, ram_bounded, ncu, nb_launch);
+    const int lpw = wide_sharded_lanes(Kw, m, kn, run, ram_bounded, ncu, nb_launch, cw);
     bool shard = lpw > 0;
     // the sharded evaluation is its own instantiation (OPT = lanes per workgroup): sharing one with the streamed loop
     // cost 200-300 spilled registers in BOTH paths

@@ -1109,6 +1109,21 @@ def wide_form(request, monkeypatch):
     return "dataflow" if request.param == "dataflow4" else request.param
 
 
+@pytest.mark.parametrize("chains", [2, 3, 37, 256])
+def test_dataflow_form_with_few_chains(E, O, chains):
+    """kernel_ram on a wide model with one chain per CU or fewer (round 5): the dispatcher itself -- no knob -- puts two chains on a
+    workgroup so that the sweep runs in the dataflow form (half of the workgroups, or nearly all of them, hold no chain and
+    evaluate like the others): C4's shape at 256 chains 20.6 -> 15.0 us per step.  The oracle's bits, two calls."""
+    import torch
+    from fmcmc_amd import _abi as abi
+    X, y = synth_linreg(6000, 20, 4747, beta=np.linspace(1.0, -1.0, 21))
+    init = jitter_init(list(np.linspace(1.0, -1.0, 21)) + [4.0], chains, 8)
+    init[:, -1] = np.abs(init[:, -1])
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, 22, init, nsteps=26, calls=2, burnin=3, thin=2)
+    if torch.cuda.get_device_properties(0).multi_processor_count >= 256:
+        assert abi.last_kernel() == "wide-dataflow"
+
+
 def test_ram_families_in_the_dataflow_form(E, O, monkeypatch):
     """kernel_ram's qfun / eta families through mh_sweep_wide2 (its owners draw the variates themselves)."""
     import torch
