@@ -393,20 +393,21 @@ static SweepArgs chain_window(const SweepArgs& A, long long off, long long cnt, 
 //   groups=4     four chain groups in the dataflow form (default two)       tiles=0     even N-tile shares of its evaluator waves
 //   window=N     step-window length of the stream-fed kernels (multiple of 32; default: ~256 MiB of stream per window)
 //   t10=0        the sharded slice product's third M-tile as a 16x16x4 tile even where 8 of its rows are padding
-//   (logistic family, observation-sharded form: wide2=0 keeps the normal / uniform kernels off mh_sweep_logit2; t10=<turn> is where
-//    the younger wave's turn at the issue priority starts, in thousandths of its passes, + 10000: and stays, + 100000 x lead / 256
-//    cycles it is regulated towards -- logit_shard, mh_common.hpp; timing only)
+//   shadow=0     logistic, observation-sharded: the normal / uniform kernels on the general kernel's form, not on mh_sweep_logit2
+//   turn=<t>     logit_shard's issue-priority turn (timing only): thousandths of the younger wave's passes it starts from, + 10000: and
+//                stays at, + 100000 x (lead in units of 256 cycles it is regulated towards); turn=0: no turn
 //   mode=<bits>  timing ablations and stamps (SweepArgs.debug)
 // The kernel a call ended up on is reported by fmcmc_last_kernel(); DESIGN.md section 5 has the shape -> kernel table.
 struct Knobs {
   int streamed = -1, cw = -1, pipe = -1, lat = -1, mfma = -1, shard = -1, shard_mfma = -1, wide2 = -1, groups = -1, tiles = -1, t10 = -1, window = -1, mode = 0;
+  int shadow = -1, turn = -1;
 };
 static Knobs read_knobs() {
   Knobs K;
   const char* e = getenv("FMCMC_AMD_DEBUG");
   if (!e) return K;
   struct { const char* name; int* dst; } tab[] = {{"streamed", &K.streamed}, {"cw", &K.cw}, {"pipe", &K.pipe}, {"lat", &K.lat},
-      {"mfma", &K.mfma}, {"shard_mfma", &K.shard_mfma}, {"shard", &K.shard}, {"wide2", &K.wide2}, {"groups", &K.groups}, {"tiles", &K.tiles}, {"t10", &K.t10}, {"window", &K.window}, {"mode", &K.mode}};
+      {"mfma", &K.mfma}, {"shard_mfma", &K.shard_mfma}, {"shard", &K.shard}, {"wide2", &K.wide2}, {"groups", &K.groups}, {"tiles", &K.tiles}, {"t10", &K.t10}, {"window", &K.window}, {"mode", &K.mode}, {"shadow", &K.shadow}, {"turn", &K.turn}};
   while (*e) {
     const char* eq = strchr(e, '=');
     const char* end = strchr(e, ',');
@@ -1013,7 +1014,7 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
       const double passes = (double)((ch_launch + NT - 1) / NT);                       // chains per thread of the sharded loop
       // (round 5: the issue-priority turns of logit_shard, and for the normal / uniform kernels mh_sweep_logit2 -- four chains per
       //  workgroup whatever cw says --: 5 .. 15 % off every row of profiles/r05_dispatch_audit_logistic.md)
-      const bool shadow_ok = K.wide2 != 0 && kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE && kn->scheme == FMCMC_SCHEME_JOINT && kf == kn->k;
+      const bool shadow_ok = K.shadow != 0 && kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE && kn->scheme == FMCMC_SCHEME_JOINT && kf == kn->k;
       const double launches_s = shadow_ok ? (double)((run->nchains + 4 * nb_launch - 1) / (4 * nb_launch)) : launches;
       const double passes_s = shadow_ok ? (double)(((run->nchains < 4 * nb_launch ? run->nchains : 4 * nb_launch) + NT - 1) / NT) : passes;
       const double est_shard = ((shadow_ok ? 8.5 : 10.0) + 2.2 * (passes_s - 1.0) +
@@ -1048,7 +1049,7 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
       (void)hipMemsetAsync(xs + (size_t)nb_launch * nslots * 2 * m->p, 0, sizeof(double) * 8 * (size_t)m->p, stream);
       hipLaunchKernelGGL(logit_build_slices, dim3((unsigned)nb_launch), dim3(256), 0, stream, m->X, (long long)m->n, m->p, nslots, xs);
       A.shard = 2; A.sh_nslots = nslots; A.sh_xs = xs; A.sh_ys = nullptr; A.sh_th = thw; A.sh_part = ptw; A.sh_bar = bar;
-      A.sh_t10 = (K.t10 >= 0) ? K.t10 : 1600700;   // (logit_shard's issue-priority turn: starts at 0.700 of the younger wave's passes, regulated towards a lead of 16 x 256 cycles; knob t10)
+      A.sh_t10 = (K.turn >= 0) ? K.turn : 1600700;   // (logit_shard's issue-priority turn: starts at 0.700 of the younger wave's passes, regulated towards a lead of 16 x 256 cycles; knob turn)
       g_kernel = "logistic-sharded";
       // Round 5: the canonical stream of the call materialised in front of the sweep (rng_fill_kernel), where it fits 1 GiB, instead
       // of being drawn inside the cooperative kernel: there the draws of a tile of steps -- Philox, AS241 with its ~50 constants
@@ -1080,8 +1081,8 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
         if (kf2 && hipFuncSetAttribute(kf2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) kfr = kf2;
         else (void)hipGetLastError();
         // the normal / uniform proposal kernels, joint scheme, no fixed parameter: mh_sweep_logit2 (mh_logit2.hpp) -- four chains per
-        // workgroup whatever cw says, the owners' work in the shadow of the hand-overs (knob wide2=0: off)
-        const void* kf3 = (K.wide2 != 0 && kn->scheme == FMCMC_SCHEME_JOINT && kf == kn->k && A.kz == kn->k) ? fmh::k_logit2(lkv) : nullptr;
+        // workgroup whatever cw says, the owners' work in the shadow of the hand-overs (knob shadow=0: off)
+        const void* kf3 = (K.shadow != 0 && kn->scheme == FMCMC_SCHEME_JOINT && kf == kn->k && A.kz == kn->k) ? fmh::k_logit2(lkv) : nullptr;
         if (kf3) {
           const size_t lds3 = fmh::k_logit2_lds(kn->k);
           int per3 = 0;

@@ -478,7 +478,7 @@ def test_c5_full_width_equals_the_oracle(E, O, monkeypatch):
     run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_NORMAL_REFLECTIVE, 6, init, nsteps=11, thin=1, seed=bench.CHAIN_SEED,
              prior_div=8.0, guard=False, scale=0.01, lb=-5.0, ub=5.0, threads=16)
     assert abi.last_kernel() == "logistic-shadow"
-    set_knob(monkeypatch, "wide2", "0")                  # the same call on the general kernel's observation-sharded form
+    set_knob(monkeypatch, "shadow", "0")                 # the same call on the general kernel's observation-sharded form
     run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_NORMAL_REFLECTIVE, 6, init, nsteps=11, thin=2, seed=bench.CHAIN_SEED,
              prior_div=8.0, guard=False, scale=0.01, lb=-5.0, ub=5.0, threads=16)
     assert abi.last_kernel() == "logistic-sharded"
@@ -761,7 +761,7 @@ def test_logistic_observation_sharded(E, O, monkeypatch, p, intercept, C):
     run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_NORMAL_REFLECTIVE, k, init, nsteps=steps, prior_div=0.0,
              scale=0.3, lb=-2.0, ub=2.0, intercept=intercept)
     assert abi.last_kernel() == "logistic-shadow"
-    set_knob(monkeypatch, "wide2", "0")                  # (the general kernel's observation-sharded form, variates from the stream)
+    set_knob(monkeypatch, "shadow", "0")                 # (the general kernel's observation-sharded form, variates from the stream)
     run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_NORMAL, k, init, nsteps=steps, burnin=5, thin=2, calls=2,
              prior_div=8.0, scale=0.04, intercept=intercept)
     assert abi.last_kernel() == "logistic-sharded"
@@ -791,7 +791,7 @@ def test_logit_shard_priority_turns_change_no_bit(E, monkeypatch):
               else E.KernelSpec(kind, k, np.zeros(k), np.ones(k), np.full(k, -big), np.full(k, big), np.zeros(k, np.uint8), warmup=10))
         ref = None
         for turn in ("0", "10250", "10900", "-1"):
-            set_knob(monkeypatch, "t10", turn)
+            set_knob(monkeypatch, "turn", turn)
             st = E.ChainState(init, gk.kf)
             r = E.sweep(gm, gk, st, 60, seed=77)
             assert abi.last_kernel() == want

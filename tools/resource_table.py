@@ -28,7 +28,7 @@ PRODUCT = [("C2 headline", r"mh_sweep_mfma<1, 1, 20, false, false, false>"),
            ("C3' kernel_ram k=5", r"mh_sweep_spec<3, 20, 4>"), ("C4", r"mh_sweep_wide2<4, 3>"),
            
            ("C5 (observation-sharded, owners in the hand-overs' shadow)", r"mh_sweep_logit2<2>"),
-           ("C5 shape on the general kernel's observation-sharded form (stream-fed: knob wide2=0, kernel_adapt / kernel_ram)", r"mh_sweep_kernel<4, -1, 2, 2, 2, 1, true>"),
+           ("C5 shape on the general kernel's observation-sharded form (stream-fed: knob shadow=0, kernel_adapt / kernel_ram)", r"mh_sweep_kernel<4, -1, 2, 2, 2, 1, true>"),
            ("the same with in-kernel variates (streams beyond 1 GiB)", r"mh_sweep_kernel<4, -1, 2, 2, 2, 1, false>"),
            ("C5 shape, chain-sharded form", r"mh_sweep_kernel<4, -1, 0, 2, 2, 1, false>"),
            ("n > 10240, normal kernels", r"mh_sweep_mfma<1, 1, 16, false, false, true>"), ("8 <= p <= 11, normal kernels", r"mh_sweep_mfma<1, 3, 4, false, false, true>"),
