@@ -1,0 +1,27 @@
+// k_spec_l1.hip -- mh_sweep_spec<P, OPTMAX, KIND, LOGISTIC> (mh_spec.hpp): the wave-specialised sweep for the logistic family (round 5), the normal / uniform kernels
+#include "mh_tu.hpp"
+#include "mh_spec.hpp"
+
+namespace fmh {
+FMH_HIDDEN const void* k_spec_logit_n(int p, int kind) {
+#define SPEC_L(PV, OV) ((kind == 1) ? (const void*)mh_sweep_spec<PV, OV, 1, FMCMC_FAM_LOGISTIC> : (const void*)mh_sweep_spec<PV, OV, 2, FMCMC_FAM_LOGISTIC>)
+  switch (p) {
+    case 1: return SPEC_L(1, 20);
+    case 2: return SPEC_L(2, 20);
+    case 3: return SPEC_L(3, 20);
+    case 4: return SPEC_L(4, 10);
+    case 5: return SPEC_L(5, 10);
+    case 6: return SPEC_L(6, 8);
+    case 7: return SPEC_L(7, 8);
+    default: return nullptr;
+  }
+#undef SPEC_L
+}
+FMH_HIDDEN const void* k_spec_logit_a(int p, int kind);
+FMH_HIDDEN const void* k_spec_logit(int p, int kind) {
+  if (kind == FMCMC_KERNEL_NORMAL || kind == FMCMC_KERNEL_NORMAL_REFLECTIVE) return k_spec_logit_n(p, kind);
+  if (kind == FMCMC_KERNEL_ADAPT || kind == FMCMC_KERNEL_RAM) return k_spec_logit_a(p, kind);
+  return nullptr;
+}
+FMH_HIDDEN size_t k_spec_logit_lds(int adaptive) { return spec_logit_lds_bytes(adaptive != 0); }
+}  // namespace fmh

@@ -394,20 +394,21 @@ static SweepArgs chain_window(const SweepArgs& A, long long off, long long cnt, 
 //   window=N     step-window length of the stream-fed kernels (multiple of 32; default: ~256 MiB of stream per window)
 //   t10=0        the sharded slice product's third M-tile as a 16x16x4 tile even where 8 of its rows are padding
 //   shadow=0     logistic, observation-sharded: the normal / uniform kernels on the general kernel's form, not on mh_sweep_logit2
+//   speclogit=0  logistic family: not on the wave-specialised kernel (mh_sweep_spec<.., LOGISTIC>)
 //   turn=<t>     logit_shard's issue-priority turn (timing only): thousandths of the younger wave's passes it starts from, + 10000: and
 //                stays at, + 100000 x (lead in units of 256 cycles it is regulated towards); turn=0: no turn
 //   mode=<bits>  timing ablations and stamps (SweepArgs.debug)
 // The kernel a call ended up on is reported by fmcmc_last_kernel(); DESIGN.md section 5 has the shape -> kernel table.
 struct Knobs {
   int streamed = -1, cw = -1, pipe = -1, lat = -1, mfma = -1, shard = -1, shard_mfma = -1, wide2 = -1, groups = -1, tiles = -1, t10 = -1, window = -1, mode = 0;
-  int shadow = -1, turn = -1;
+  int shadow = -1, turn = -1, speclogit = -1;
 };
 static Knobs read_knobs() {
   Knobs K;
   const char* e = getenv("FMCMC_AMD_DEBUG");
   if (!e) return K;
   struct { const char* name; int* dst; } tab[] = {{"streamed", &K.streamed}, {"cw", &K.cw}, {"pipe", &K.pipe}, {"lat", &K.lat},
-      {"mfma", &K.mfma}, {"shard_mfma", &K.shard_mfma}, {"shard", &K.shard}, {"wide2", &K.wide2}, {"groups", &K.groups}, {"tiles", &K.tiles}, {"t10", &K.t10}, {"window", &K.window}, {"mode", &K.mode}, {"shadow", &K.shadow}, {"turn", &K.turn}};
+      {"mfma", &K.mfma}, {"shard_mfma", &K.shard_mfma}, {"shard", &K.shard}, {"wide2", &K.wide2}, {"groups", &K.groups}, {"tiles", &K.tiles}, {"t10", &K.t10}, {"window", &K.window}, {"mode", &K.mode}, {"shadow", &K.shadow}, {"turn", &K.turn}, {"speclogit", &K.speclogit}};
   while (*e) {
     const char* eq = strchr(e, '=');
     const char* end = strchr(e, ',');
@@ -764,6 +765,24 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
       }
     }
   }
+  // ---- the logistic family on the wave-specialised kernel (round 5; mh_spec.hpp, FAM = LOGISTIC): data in the compute lanes'
+  // registers, g table in LDS, the register owners.  The workflow vignette's own model (mcmc::logit: 100 observations, k = 5) ran
+  // on the general kernel at 2.6 / 5.9 us per step (kernel_normal / kernel_adapt).  Knob speclogit=0: off.
+  bool spec_logit = false;
+  if (!force && !nopipe && K.speclogit != 0 && K.shard < 0 && m->family == FMCMC_FAM_LOGISTIC && !mirror && m->p >= 1 && m->p <= 7 &&
+      kn->k == m->p + (m->intercept ? 1 : 0) && kf == kn->k && A.kz == kn->k &&
+      (((kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE) && kn->scheme == FMCMC_SCHEME_JOINT) ||
+       (kn->kind == FMCMC_KERNEL_ADAPT && !adapt_hist) || (kn->kind == FMCMC_KERNEL_RAM && !kn->constr && !ram_bounded)) &&
+      (unsigned long long)run->nsteps * (unsigned long long)A.kz * 8ull < (1ull << 32) && run->nsteps < (1ll << 30) &&
+      (unsigned long long)kn->k * (unsigned long long)A.ldS * 8ull < (1ull << 32)) {
+    const long long nsl2 = (((m->n + NT - 1) / NT) + 1) & ~1ll;
+    if (nsl2 <= fmh::k_spec_optmax(m->p, kn->kind) && fmh::k_spec_logit(m->p, kn->kind)) {
+      pipe_opt = (int)nsl2;
+      spec_logit = true;
+      const long long per_cu = (run->nchains + ncu - 1) / ncu;
+      spec_cw = (K.lat >= 1 && K.lat <= 3) ? K.lat : ((K.lat != 0 && per_cu <= 3) ? (int)per_cu : 4);
+    }
+  }
   A.spec_opt = pipe_opt;
   A.spec_cw = spec_cw;
   // ---- the LONG-DATA form (mh_common.hpp, shard_long): few chains on long data.  Up to four chains are one workgroup of the
@@ -918,9 +937,14 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
         e = launch_k(fmh::k_lat(m->p, kn->kind), (A.nchains + A.spec_cw - 1) / A.spec_cw, NT, lat_lds_bytes(), stream, A);
       } else {
         // the wave-specialised kernel (mh_spec.hpp): A.spec_cw chains per workgroup
-        g_kernel = A.spec_cw == 1 ? "spec-lat1" : A.spec_cw == 2 ? "spec-lat2" : A.spec_cw == 3 ? "spec-lat3" : "spec";
         const long long sblk = (A.nchains + A.spec_cw - 1) / A.spec_cw;
+        if (spec_logit) {
+          g_kernel = A.spec_cw == 1 ? "spec-logit-lat1" : A.spec_cw == 2 ? "spec-logit-lat2" : A.spec_cw == 3 ? "spec-logit-lat3" : "spec-logit";
+          e = launch_k(fmh::k_spec_logit(m->p, kn->kind), sblk, SPEC_NT, fmh::k_spec_logit_lds(kn->kind >= FMCMC_KERNEL_ADAPT ? 1 : 0), stream, A);
+        } else {
+        g_kernel = A.spec_cw == 1 ? "spec-lat1" : A.spec_cw == 2 ? "spec-lat2" : A.spec_cw == 3 ? "spec-lat3" : "spec";
         e = launch_k(fmh::k_spec(m->p, kn->kind), sblk, SPEC_NT, spec_lds_bytes(pipe_opt, kn->kind >= FMCMC_KERNEL_ADAPT), stream, A);
+        }
       }
     };   // launch_fast
     {

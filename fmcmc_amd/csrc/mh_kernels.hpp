@@ -27,6 +27,9 @@ FMH_HIDDEN const void* k_mfma_ad(int kind, int ng, int kx, int bnd, int shrt);
 // k_spec.hip: mh_sweep_spec<P, OPTMAX, KIND>
 FMH_HIDDEN const void* k_spec(int p, int kind);
 FMH_HIDDEN int k_spec_optmax(int p, int kind);
+// k_spec_l*.hip: mh_sweep_spec<P, OPTMAX, KIND, LOGISTIC>: p = 1 .. 7, kind 1 .. 4
+FMH_HIDDEN const void* k_spec_logit(int p, int kind);
+FMH_HIDDEN size_t k_spec_logit_lds(int adaptive);
 // k_lat*.hip: mh_sweep_lat<KIND, P, OPTMAX> (kind 1, 2; p = 1 .. 7; the slot counts of k_spec_optmax)
 FMH_HIDDEN const void* k_lat(int p, int kind);
 // k_wide2.hip: mh_sweep_wide2<KIND, NMT> (kind 1, 2, 4; nmt 1..3) and mh_sweep_bigk

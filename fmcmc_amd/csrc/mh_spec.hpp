@@ -355,9 +355,11 @@ struct SpecSync {
 // decision f of the REFLECTED proposal -- a second evaluation, needed only in the steps in which a reflection moved something.  The
 // policy decides it for its workgroup: second(need, republish, tot2) -> true when a second evaluation ran (tot2: its total for this
 // chain), second_idle() for an owner that has nothing to ask in this step but must keep in step (MfmaAdSync; SpecSync has neither).
-template <int KIND, int KX, class SYNC, bool BND = false>
+template <int KIND, int KX, class SYNC, bool BND = false, int FAM = FMCMC_FAM_GAUSSIAN_LINREG>
 __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int myc, int cl, double* s_th1, SYNC& sync) {
   static_assert(!BND || KIND == FMCMC_KERNEL_RAM, "BND is the bounded kernel_ram");
+  constexpr bool LG = FAM == FMCMC_FAM_LOGISTIC;
+  static_assert(!(LG && BND), "the logistic family runs the unbounded kernel_ram here");
   constexpr int KA = KX > 0 ? KX : SPEC_KA;
   const int lane = threadIdx.x & 63;
   const int k = KX > 0 ? KX : A.k, kf = k, kz = KX > 0 ? KX : A.kz;
@@ -435,12 +437,34 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
   // range, anything else takes logpost_of) -- and for kernel_ram eta(i, k) and the prefix sums of z^2.
   double pre_nt1 = 0.0, pre_ss = 1.0, pre_rs = 1.0, pre_eta = 0.0, pre_Pj = 0.0, pre_Pj1 = 0.0, pre_nrm2 = 1.0;
   double pre_c1 = 0.0, pre_c2 = 0.0;   // kernel_adapt: (t - 1) / t and 1 / t of the NEXT covariance update (t = abs_iter - 1: the step's own)
+  double pre_lin = 0.0, pre_pri = 0.0; // logistic: sum_j b_j hs_j and sum_j b_j^2 / prior_div of the pending proposal
+  const int nbl = A.intercept + A.p;
+  const double hs_l = (LG && lane < nbl && A.lg_hs) ? A.lg_hs[lane] : 0.0;
   bool pre_ok = false;
   auto prepare = [&](int i) {   // i: loop step whose proposal is pending (1: the initial state)
     if (KIND == FMCMC_KERNEL_ADAPT) {
       const double t = uniform_d((double)(abs_iter - 1));
       pre_c1 = (t - 1) / t;
       pre_c2 = 1.0 / t;
+    }
+    if constexpr (LG) {   // (finish_logpost<LOGISTIC>: the same fma chains, the same bits; no sigma in this family)
+      double lin = 0.0, ss = 0.0;
+      for (int j = 0; j < nbl; j++) {
+        const double bj = readlane_d(th1, j);
+        lin = fmh_fma(bj, readlane_d(hs_l, j), lin);
+        ss = fmh_fma(bj, bj, ss);
+      }
+      pre_lin = lin;
+      pre_pri = (A.prior_div != 0.0) ? ss / A.prior_div : 0.0;
+      if (KIND == FMCMC_KERNEL_RAM && i >= 2) {
+        double eta = (double)kf * fmh_exp(A.ram_neg_exp * fmh_log((double)(i + ioff)));
+        if (eta > 1.0) eta = 1.0;
+        pre_eta = eta;
+        pre_Pj1 = lane_scan_row16(zcur * zcur);
+        pre_Pj = dpp_d<0x111>(pre_Pj1);
+        pre_nrm2 = readlane_d(pre_Pj1, kf - 1);
+      }
+      return;
     }
     const double sigma = readlane_d(th1, k - 1);
     const unsigned sg_hi = (unsigned)(fmh_d2u(sigma) >> 32);
@@ -472,7 +496,11 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
     SPEC_ST(0);
     const double h = 0.5 * tot;
     double f1;
-    if (pre_ok && mfr_div_safe(h)) f1 = -pre_nt1 - div_finish(h, pre_ss, pre_rs);   // (finite: the guard has nothing to do)
+    if constexpr (LG) {
+      f1 = pre_lin - tot;
+      if (A.prior_div != 0.0) f1 = f1 - pre_pri;
+      if (A.guard && !fmh_isfinite(f1)) f1 = -fmh_inf();
+    } else if (pre_ok && mfr_div_safe(h)) f1 = -pre_nt1 - div_finish(h, pre_ss, pre_rs);   // (finite: the guard has nothing to do)
     else f1 = logpost_of(tot, readlane_d(th1, k - 1));
     bool st_row = false;
     double st_th0 = 0.0;
@@ -734,10 +762,72 @@ __device__ __forceinline__ void spec_compute(const SweepArgs& A, const double* s
     }
 }
 
+// The compute role for the LOGISTIC family (round 5: the workflow vignette's own model -- mcmc::logit, 100 observations -- ran on the
+// general kernel at 2.6 / 5.9 us per step, kernel_normal / kernel_adapt): a lane's OPT observations in VGPRs as above, per observation
+// 64 eta as the fma chain over the scaled coefficients and g(|eta|) off the table in LDS (logit_g_vec: the oracle's fmh_logit_g_scaled),
+// added in slot order; the linear part sum_j b_j hs_j and the prior term never enter a loop (the owners form them).  y is not read.
+template <int P, int OPT>
+__device__ __forceinline__ void spec_compute_logit(const SweepArgs& A, const double* s_tab, const double* s_th1, unsigned* s_ready, unsigned* s_done,
+                                                   double* s_tr, int ncw, int nsteps, int ic, int wave, int tid, int lane) {
+    double xr[OPT][P > 0 ? P : 1];
+    double wlast = 1.0, wprev = 1.0;
+#pragma unroll
+    for (int s = 0; s < OPT; s++) {
+      const long long i = (long long)tid + (long long)NT * s;
+      const bool valid = i < A.n;
+#pragma unroll
+      for (int j = 0; j < P; j++) xr[s][j] = valid ? A.X[(long long)j * A.n + i] : 0.0;
+      if (s == OPT - 1) wlast = valid ? 1.0 : 0.0;
+      if (s == OPT - 2) wprev = valid ? 1.0 : 0.0;
+    }
+    const int tr_slot = (tid & 7) * PIPE_TRS + (tid >> 3);
+    for (int v = 1; v <= nsteps; v++) {
+      for (int c = 0; c < ncw; c++) {
+        while (lds_ld_u32(&s_ready[c]) < (unsigned)v) __builtin_amdgcn_s_sleep(1);
+        const double* t0 = s_th1 + c * PIPE_KMAX;
+        const double m00 = ic ? t0[0] * FMH_LG_SCALE : 0.0;      // (times 64: exact)
+        double b0[P > 0 ? P : 1];
+#pragma unroll
+        for (int j = 0; j < P; j++) b0[j] = t0[ic + j] * FMH_LG_SCALE;
+        double a0 = 0.0;
+        constexpr int G = 4;
+#pragma unroll
+        for (int s0 = 0; s0 < OPT; s0 += G) {
+          constexpr int GG = G;
+          double us[GG], gv[GG];
+#pragma unroll
+          for (int u = 0; u < GG; u++) {
+            double es = m00;
+            if (s0 + u < OPT) {
+#pragma unroll
+              for (int j = 0; j < P; j++) es = fmh_fma(xr[s0 + u][j], b0[j], es);
+            }
+            us[u] = __builtin_fabs(es);
+          }
+          logit_g_vec<GG, true>(us, gv, s_tab);
+#pragma unroll
+          for (int u = 0; u < GG; u++) {
+            const int s = s0 + u;
+            if (s < OPT) {
+              if (s == OPT - 1) a0 = a0 + gv[u] * wlast;        // (g * 1 == g; a slot without an observation adds +0)
+              else if (s == OPT - 2) a0 = a0 + gv[u] * wprev;
+              else a0 = a0 + gv[u];
+            }
+          }
+        }
+        s_tr[c * (8 * PIPE_TRS) + tr_slot] = a0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // partials landed before the arrival is visible
+        if (lane == 0) __hip_atomic_fetch_add(&s_done[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+}
+
 // OPTMAX: the most observation slots a compute lane holds (x in VGPRs: OPTMAX P doubles); the launch's (even) slot count
-// A.spec_opt <= OPTMAX selects the compute loop.
-template <int P, int OPTMAX, int KIND>
+// A.spec_opt <= OPTMAX selects the compute loop.  FAM: the Gaussian linear model, or (round 5) the logistic one -- the g table in LDS
+// where the linear model keeps y, the closed form sum_j b_j hs_j - total - prior in the owners.
+template <int P, int OPTMAX, int KIND, int FAM = FMCMC_FAM_GAUSSIAN_LINREG>
 __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
+  constexpr bool LG = FAM == FMCMC_FAM_LOGISTIC;
   constexpr int CW = 4;
   static_assert(OPTMAX % 2 == 0, "slot counts are even (y is read back in pairs)");
   const int OPT = A.spec_opt;                      // (uniform) even, 2 .. OPTMAX
@@ -750,8 +840,9 @@ __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
   unsigned* s_ready = (unsigned*)(s_par + 4 * PIPE_KMAX);  // [CW] version of theta1[c] that is published
   unsigned* s_done = s_ready + CW;                         // [CW] partial arrivals (8 per version)
   double* s_tr = s_par + 4 * PIPE_KMAX + CW;       // [CW][8][PIPE_TRS] lane partials, transposed
-  double* s_y = s_tr + CW * 8 * PIPE_TRS;          // [OPT/2][NT][2] this workgroup's copy of y
-  double* s_ad = s_y + OPT * NT;                   // KIND >= 3: [CW][SPEC_ADS] adaptive per-chain state
+  double* s_y = s_tr + CW * 8 * PIPE_TRS;          // [OPT/2][NT][2] this workgroup's copy of y (logistic: the g table, 16-byte aligned)
+  double* s_ad = s_y + (LG ? LG_LDS_DOUBLES + 2 : OPT * NT);   // KIND >= 3: [CW][SPEC_ADS] adaptive per-chain state
+  double* const s_tab = LG ? logit_table_align(s_y) : nullptr;
   // chains of this workgroup: A.spec_cw = 4, or 2 / 1 in the LATENCY form (fewer than 4 x CUs chains per GPU: every chain gets
   // more of a compute unit -- all eight compute waves evaluate the one or two chains there are, and an owner's turn-around
   // is no longer queued behind the evaluation of three other chains; same canonical lanes, same tree, same bits)
@@ -763,10 +854,14 @@ __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
   const bool dbg = (A.debug & 8) != 0;
 
   // ---- cooperative set-up (all 12 waves): y -> LDS, kernel constants, initial theta1, flags
-  for (int e = tid; e < OPT * NT; e += SPEC_NT) {
-    const int s = e / NT, t = e - s * NT;
-    const long long i = (long long)t + (long long)NT * s;
-    s_y[((s >> 1) * NT + t) * 2 + (s & 1)] = (i < A.n) ? A.y[i] : 0.0;
+  if constexpr (LG) {
+    logit_stage_table(s_tab);
+  } else {
+    for (int e = tid; e < OPT * NT; e += SPEC_NT) {
+      const int s = e / NT, t = e - s * NT;
+      const long long i = (long long)t + (long long)NT * s;
+      s_y[((s >> 1) * NT + t) * 2 + (s & 1)] = (i < A.n) ? A.y[i] : 0.0;
+    }
   }
   if (tid < k) {
     s_par[0 * PIPE_KMAX + tid] = A.mu[tid];
@@ -784,7 +879,8 @@ __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
   if (wave < SPEC_NCW) {
     // =========================== COMPUTE ROLE ===========================
     switch (OPT) {
-#define SPEC_CC(O_) case O_: if constexpr (O_ <= OPTMAX) spec_compute<P, O_>(A, s_y, s_th1, s_ready, s_done, s_tr, ncw, nsteps, ic, dbg, wave, tid, lane); break;
+#define SPEC_CC(O_) case O_: if constexpr (O_ <= OPTMAX) { if constexpr (LG) spec_compute_logit<P, O_>(A, s_tab, s_th1, s_ready, s_done, s_tr, ncw, nsteps, ic, wave, tid, lane); \
+                                                            else spec_compute<P, O_>(A, s_y, s_th1, s_ready, s_done, s_tr, ncw, nsteps, ic, dbg, wave, tid, lane); } break;
       SPEC_CC(2) SPEC_CC(4) SPEC_CC(6) SPEC_CC(8) SPEC_CC(10) SPEC_CC(12) SPEC_CC(14) SPEC_CC(16) SPEC_CC(18) SPEC_CC(20)
 #undef SPEC_CC
       default: break;
@@ -809,6 +905,11 @@ __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
     bool nofixed = true;
     for (int j = 0; j < k; j++) nofixed = nofixed && (A.fixed[j] == 0);
     SpecSync sync{s_ready, s_done, s_tr, myc};
+    if constexpr (LG) {   // (the host takes this kernel for k = P + intercept, no fixed parameter: the register owner)
+      if (k == P + 1) spec_owner_adaptive_reg<KIND, P + 1, SpecSync, false, FMCMC_FAM_LOGISTIC>(A, myc, cl, s_th1, sync);
+      else spec_owner_adaptive_reg<KIND, (P > 0 ? P : 1), SpecSync, false, FMCMC_FAM_LOGISTIC>(A, myc, cl, s_th1, sync);
+      return;
+    }
     if (k == P + 2 && nofixed && A.kz == k && !(A.debug & 16))        // intercept + P covariates + sigma (C3: k = 5)
       spec_owner_adaptive_reg<KIND, P + 2>(A, myc, cl, s_th1, sync);
     else if (k == P + 1 && nofixed && A.kz == k && !(A.debug & 16))   // no intercept
@@ -872,8 +973,22 @@ __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
     bitword = 0;
   };
 
+  // logistic: sum_j b_j hs_j and the prior term of the pending proposal, formed while the compute waves evaluate it
+  const int nbl = A.intercept + A.p;
+  const double hs_l = (LG && lane < nbl && A.lg_hs) ? A.lg_hs[lane] : 0.0;
+  double lin1 = 0.0, pri1 = 0.0;
   unsigned long long tw = 0, tp = 0, tst = 0;
   for (int v = 1; v <= nsteps; v++) {
+    if constexpr (LG) {   // (finish_logpost<LOGISTIC>: the same fma chains, the same bits)
+      double lin = 0.0, ss = 0.0;
+      for (int j = 0; j < nbl; j++) {
+        const double bj = readlane_d(th1, j);
+        lin = fmh_fma(bj, readlane_d(hs_l, j), lin);
+        ss = fmh_fma(bj, bj, ss);
+      }
+      lin1 = lin;
+      pri1 = (A.prior_div != 0.0) ? ss / A.prior_div : 0.0;
+    }
     // ---- wait for the 8 compute waves' partials of version v
     unsigned long long t_a = dbg ? clk() : 0;
     while (lds_ld_u32(&s_done[myc]) < 8u * (unsigned)v) __builtin_amdgcn_s_sleep(1);
@@ -882,8 +997,14 @@ __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
     const double v0 = src[0 * PIPE_TRS], v1 = src[1 * PIPE_TRS], v2 = src[2 * PIPE_TRS], v3 = src[3 * PIPE_TRS];
     const double v4 = src[4 * PIPE_TRS], v5 = src[5 * PIPE_TRS], v6 = src[6 * PIPE_TRS], v7 = src[7 * PIPE_TRS];
     const double tot = wave_xor_sum(((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7)));
-    const double sigma = readlane_d(th1, k - 1);
-    const double f1 = logpost_of(tot, sigma);
+    double f1;
+    if constexpr (LG) {
+      f1 = lin1 - tot;
+      if (A.prior_div != 0.0) f1 = f1 - pri1;
+      if (A.guard && !fmh_isfinite(f1)) f1 = -fmh_inf();
+    } else {
+      f1 = logpost_of(tot, readlane_d(th1, k - 1));
+    }
     const double th1_eval = th1;
     bool keep_row = false;
     if (v == 1) {                       // row 1: f0 = f(initial)
@@ -954,6 +1075,9 @@ __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
   }
 }
 
+size_t spec_logit_lds_bytes(bool adaptive) {
+  return sizeof(double) * ((size_t)8 * PIPE_KMAX + 4 + 4 * 8 * PIPE_TRS + (size_t)(LG_LDS_DOUBLES + 2) + (adaptive ? 4 * SPEC_ADS : 0));
+}
 size_t spec_lds_bytes(int opt, bool adaptive) {
   return sizeof(double) * ((size_t)8 * PIPE_KMAX + 4 + 4 * 8 * PIPE_TRS + (size_t)opt * NT + (adaptive ? 4 * SPEC_ADS : 0));
 }

@@ -770,6 +770,35 @@ def test_logistic_observation_sharded(E, O, monkeypatch, p, intercept, C):
     assert abi.last_kernel() == "logistic-sharded"
 
 
+@pytest.mark.parametrize("n,p,intercept", [(100, 4, True), (1000, 2, False), (5000, 5, True), (4096, 7, True), (10240, 3, True), (513, 1, True)])
+@pytest.mark.parametrize("chains", [2, 5, 600, 1100])
+def test_logistic_on_the_wave_specialised_kernel(E, O, n, p, intercept, chains):
+    """Round 5: the logistic family on mh_sweep_spec (data in the compute lanes' registers, g table in LDS, register owners) -- the
+    workflow vignette's own model, mcmc::logit's 100 observations and four covariates, first (vignettes/workflow-with-fmcmc.Rmd:22-60:
+    kernel_normal, then kernel_adapt(freq = 1, warmup = 500)).  All four proposal kernels, one to four chains per workgroup, ragged n,
+    with and without intercept, two calls: the oracle's bits."""
+    from fmcmc_amd import _abi as abi
+    if n * chains > 3_000_000:
+        pytest.skip("oracle time")
+    rng = np.random.default_rng(1000 * p + n + chains)
+    X = rng.standard_normal((n, p))
+    beta = np.linspace(0.6, -0.6, p + 1)
+    eta = (beta[0] if intercept else 0.0) + X @ beta[1:]
+    y = (rng.uniform(size=n) < 1 / (1 + np.exp(-eta))).astype(np.float64)
+    k = p + (1 if intercept else 0)
+    init = jitter_init(list(beta[(0 if intercept else 1):]), chains, 17 + p)
+    steps = 60 if chains < 100 else 20
+    kw = dict(nsteps=steps, calls=2, prior_div=8.0, intercept=intercept)
+    run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_NORMAL, k, init, scale=0.1, burnin=3, thin=2, **kw)
+    assert abi.last_kernel().startswith("spec-logit"), abi.last_kernel()
+    run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_NORMAL_REFLECTIVE, k, init, scale=0.3, lb=-0.7, ub=0.9, **dict(kw, prior_div=0.0))
+    assert abi.last_kernel().startswith("spec-logit")
+    run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_ADAPT, k, init, warmup=6, **kw)
+    assert abi.last_kernel().startswith("spec-logit")
+    run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_RAM, k, init, **kw)
+    assert abi.last_kernel().startswith("spec-logit")
+
+
 def test_logit_shard_priority_turns_change_no_bit(E, monkeypatch):
     """logit_shard gives the younger wave of every SIMD the issue priority for the first part of its passes and regulates where that
     turn ends from the two waves' finishing times (round 5): TIMING only.  The same call with no turn, with a fixed early and a fixed
