@@ -799,6 +799,37 @@ def test_logistic_on_the_wave_specialised_kernel(E, O, n, p, intercept, chains):
     assert abi.last_kernel().startswith("spec-logit")
 
 
+@pytest.mark.parametrize("form", ["shadow", "spec"])
+def test_logistic_round5_kernels_edge_cases(E, O, monkeypatch, form):
+    """mh_sweep_logit2 ("logistic-shadow", forced by shard=1) and the logistic family on mh_sweep_spec ("spec-logit") at the edges: two
+    and three steps, a burn-in that leaves one row, a thinning interval one short of the call, one chain, chain counts that leave the last
+    workgroup ragged, 1025 chains (two launches of the sharded form), a continuation of a call, and chains whose log-posterior is NaN
+    from the start (status 1 / 2 with the step and the vector): the oracle's bits."""
+    import torch
+    from fmcmc_amd import _abi as abi
+    if torch.cuda.get_device_properties(0).multi_processor_count < 256:
+        pytest.skip("the sharded form needs all 256 CUs")
+    if form == "shadow":
+        set_knob(monkeypatch, "shard", "1")
+    want = "logistic-shadow" if form == "shadow" else "spec-logit"
+    rng = np.random.default_rng(5150)
+    n, p = 1500, 3
+    X = rng.standard_normal((n, p)); beta = np.array([0.3, 0.7, -0.6, 0.4])
+    y = (rng.uniform(size=n) < 1 / (1 + np.exp(-(beta[0] + X @ beta[1:])))).astype(np.float64)
+    k = p + 1
+    for chains, kw in ((1, dict(nsteps=2)), (3, dict(nsteps=3)), (5, dict(nsteps=40, burnin=39)), (7, dict(nsteps=33, thin=32)),
+                       (9, dict(nsteps=65, burnin=1, thin=3, calls=3)), (1025, dict(nsteps=12, thin=5))):
+        init = jitter_init(list(beta), chains, 3 + chains)
+        run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_NORMAL_REFLECTIVE, k, init, scale=0.2, lb=-1.0, ub=1.0, prior_div=8.0, guard=False, **kw)
+        assert abi.last_kernel().startswith(want), (abi.last_kernel(), chains)
+    # NaN from the start (an initial vector with a NaN coefficient): the chain stops at its first decision, the others run on
+    init = jitter_init(list(beta), 6, 11)
+    init[2, 1] = np.nan
+    init[4, 0] = np.inf          # (inf - inf in the ratio)
+    run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_NORMAL, k, init, nsteps=20, scale=0.1, prior_div=0.0, guard=False)
+    assert abi.last_kernel().startswith(want)
+
+
 def test_logit_shard_priority_turns_change_no_bit(E, monkeypatch):
     """logit_shard gives the younger wave of every SIMD the issue priority for the first part of its passes and regulates where that
     turn ends from the two waves' finishing times (round 5): TIMING only.  The same call with no turn, with a fixed early and a fixed
