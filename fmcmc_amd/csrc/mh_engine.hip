@@ -781,6 +781,13 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
       spec_logit = true;
       const long long per_cu = (run->nchains + ncu - 1) / ncu;
       spec_cw = (K.lat >= 1 && K.lat <= 3) ? K.lat : ((K.lat != 0 && per_cu <= 3) ? (int)per_cu : 4);
+      // the normal / uniform kernels with fewer than four chains per CU: the latency form (mh_sweep_lat<.., LOGISTIC>: replicated decision)
+      // (measured, tools/bench_small_logit.py and the pair of forms at 256 / 512 / 768 chains: the replicated decision wins up to ~3,000
+      //  observations at any count -- 0.85 / 1.18 / 1.59 us against 1.25 / 1.34 / 1.78 at n = 1000 -- and up to ~6,000 with one chain
+      //  per workgroup, 1.66 against 2.15 at n = 5000; beyond, the lookups' LDS time is the step and the owners' overlap pays:
+      //  n = 10,000: 6.4 against 4.8 at 512 chains.  Knob speclogit=2: never.)
+      if (spec_cw < 4 && K.speclogit != 2 && kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE && fmh::k_lat_logit(m->p, kn->kind) &&
+          nsl2 <= (spec_cw == 1 ? 12 : 6)) lat_normal = true;
     }
   }
   A.spec_opt = pipe_opt;
@@ -933,8 +940,13 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
         }
       } else if (lat_normal) {
         // the latency form of the normal / uniform kernels (mh_lat.hpp): A.spec_cw = 1 .. 3 chains per workgroup
+        if (spec_logit) {
+          g_kernel = A.spec_cw == 1 ? "lat-logit1" : A.spec_cw == 2 ? "lat-logit2" : "lat-logit3";
+          e = launch_k(fmh::k_lat_logit(m->p, kn->kind), (A.nchains + A.spec_cw - 1) / A.spec_cw, NT, fmh::k_lat_logit_lds(), stream, A);
+        } else {
         g_kernel = A.spec_cw == 1 ? "lat1" : A.spec_cw == 2 ? "lat2" : "lat3";
         e = launch_k(fmh::k_lat(m->p, kn->kind), (A.nchains + A.spec_cw - 1) / A.spec_cw, NT, lat_lds_bytes(), stream, A);
+        }
       } else {
         // the wave-specialised kernel (mh_spec.hpp): A.spec_cw chains per workgroup
         const long long sblk = (A.nchains + A.spec_cw - 1) / A.spec_cw;

@@ -32,6 +32,9 @@ FMH_HIDDEN const void* k_spec_logit(int p, int kind);
 FMH_HIDDEN size_t k_spec_logit_lds(int adaptive);
 // k_lat*.hip: mh_sweep_lat<KIND, P, OPTMAX> (kind 1, 2; p = 1 .. 7; the slot counts of k_spec_optmax)
 FMH_HIDDEN const void* k_lat(int p, int kind);
+// k_lat_l*.hip: mh_sweep_lat<KIND, P, OPTMAX, LOGISTIC> (kind 1, 2; p = 1 .. 7)
+FMH_HIDDEN const void* k_lat_logit(int p, int kind);
+FMH_HIDDEN size_t k_lat_logit_lds();
 // k_wide2.hip: mh_sweep_wide2<KIND, NMT> (kind 1, 2, 4; nmt 1..3) and mh_sweep_bigk
 FMH_HIDDEN const void* k_wide2(int kind, int nmt);
 FMH_HIDDEN const void* k_bigk();

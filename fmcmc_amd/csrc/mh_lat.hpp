@@ -41,8 +41,12 @@ constexpr int LAT_LDS_DOUBLES = LAT_SINK + 64;
 
 enum { LAT_GENERIC = 0, LAT_KEEPER = 1, LAT_LOG = 2, LAT_CANDS = 3, LAT_RECIP = 4 };
 
-template <int KIND, int P, int OPT, int ROLE>
+template <int KIND, int P, int OPT, int ROLE, int FAM = FMCMC_FAM_GAUSSIAN_LINREG>
 __device__ __forceinline__ void lat_steps(const SweepArgs& A, double* smem) {
+  // FAM = LOGISTIC (round 5): the same form for the logistic family -- per observation 64 eta from the scaled coefficients and
+  // g(|eta|) off the table in LDS (behind this kernel's block), added in slot order; y is not read; wave 1's duty is sum_j b_j hs_j and
+  // the prior term instead of the logarithm, wave 3 has none; the decision is lin - total - prior.
+  constexpr bool LG = FAM == FMCMC_FAM_LOGISTIC;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int k = A.k, kz = A.kz, ic = A.intercept;
@@ -66,7 +70,7 @@ __device__ __forceinline__ void lat_steps(const SweepArgs& A, double* smem) {
     const bool valid = i < A.n;
 #pragma unroll
     for (int j = 0; j < P; j++) xr[s][j] = valid ? A.X[(long long)j * A.n + i] : 0.0;
-    yr[s] = valid ? A.y[i] : 0.0;
+    yr[s] = (valid && !LG) ? A.y[i] : 0.0;
     if (s == OPT - 1) wlast = valid ? 1.0 : 0.0;
     if (s == OPT - 2) wprev = valid ? 1.0 : 0.0;
   }
@@ -144,7 +148,34 @@ __device__ __forceinline__ void lat_steps(const SweepArgs& A, double* smem) {
   double dt_f = 0.0, dt_s = 0.0, dt_R = 0.0, dt_sg = 1.0;
   int dt_k = 0;
   bool dt_fast = false;
+  const double* const s_tab = LG ? logit_table_align(smem + LAT_LDS_DOUBLES) : nullptr;
+  const int nbl = A.intercept + A.p;
+  const double hs_l = (LG && jj < nbl && A.lg_hs) ? A.lg_hs[jj] : 0.0;       // lane 16 c + j: the data-only sum of parameter j
   auto duty_stage = [&](int g, int vn) {     // vn: the version under evaluation (buffer vn & 1)
+    if constexpr (LG) {
+      if constexpr (ROLE == LAT_LOG) {
+        if (g == 0) {   // sum_j b_j hs_j and sum_j b_j^2 of every row's chain (finish_logpost<LOGISTIC>: the same fma chains)
+          double lin = 0.0, ss = 0.0;
+          static_for<16>([&](auto j_) {
+            constexpr int j = decltype(j_)::value;
+            if (j < nbl) {
+              const double bj = row_bcast<j>(th1);
+              lin = fmh_fma(bj, row_bcast<j>(hs_l), lin);
+              ss = fmh_fma(bj, bj, ss);
+            }
+          });
+          dt_f = lin; dt_s = ss;
+        } else if (g == 1) {
+          const double pri = (A.prior_div != 0.0) ? dt_s / A.prior_div : 0.0;
+          const double v = (jj == 0) ? dt_f : pri;
+          double* dst = (jj == 0) ? s_prep + (vn & 1) * 16 + 0 * LAT_ROWS + row : (jj == 2 ? s_prep + (vn & 1) * 16 + 2 * LAT_ROWS + row : s_sink + lane);
+          *dst = v;
+        }
+      } else if constexpr (ROLE == LAT_CANDS) {
+        if (g == 0 && vn >= 2) candidates(vn);
+      }
+      return;
+    }
     if constexpr (ROLE == LAT_LOG) {
       if (g == 0) {
         const double sigma = shfl_d(th1, (lane & 48) + k - 1);
@@ -203,6 +234,11 @@ __device__ __forceinline__ void lat_steps(const SweepArgs& A, double* smem) {
     double b0[P > 0 ? P : 1];
 #pragma unroll
     for (int j = 0; j < P; j++) b0[j] = readlane_d(th1, l0 + ic + j);
+    if constexpr (LG) {      // (the table's argument is 64 eta: coefficients times 64, exact)
+      m00 = m00 * FMH_LG_SCALE;
+#pragma unroll
+      for (int j = 0; j < P; j++) b0[j] = b0[j] * FMH_LG_SCALE;
+    }
     // (uniform values kept in VGPRs: an fp64 fma with a scalar operand issues at 6 cycles where all-VGPR ones take 4.5)
     asm volatile("" : "+v"(m00));
 #pragma unroll
@@ -220,6 +256,21 @@ __device__ __forceinline__ void lat_steps(const SweepArgs& A, double* smem) {
 #pragma unroll
         for (int u = 0; u < G; u++)
           if (s0 + u < OPT) m[u] = fmh_fma(xr[s0 + u][j], b0[j], m[u]);
+      if constexpr (LG) {
+        double us[G], gv[G];
+#pragma unroll
+        for (int u = 0; u < G; u++) us[u] = __builtin_fabs(m[u]);
+        logit_g_vec<G, true>(us, gv, s_tab);
+#pragma unroll
+        for (int u = 0; u < G; u++) {
+          const int s = s0 + u;
+          if (s < OPT) {
+            if (s == OPT - 1) a0 = a0 + gv[u] * wlast;       // (g * 1 == g; a slot without an observation adds +0)
+            else if (s == OPT - 2) a0 = a0 + gv[u] * wprev;
+            else a0 = a0 + gv[u];
+          }
+        }
+      } else {
 #pragma unroll
       for (int u = 0; u < G; u++)
         if (s0 + u < OPT) m[u] = yr[s0 + u] - m[u];
@@ -231,6 +282,7 @@ __device__ __forceinline__ void lat_steps(const SweepArgs& A, double* smem) {
           else if (s == OPT - 2) a0 = fmh_fma(m[u] * wprev, m[u], a0);   // (r * 1 == r: the same bits where the slot is full)
           else a0 = fmh_fma(m[u], m[u], a0);
         }
+      }
       }
     }
 #pragma unroll
@@ -278,17 +330,26 @@ __device__ __forceinline__ void lat_steps(const SweepArgs& A, double* smem) {
     wsum = wsum + dpp_d<0x4E>(wsum);                          // level 128: quad_perm [2,3,0,1]
     const double tot = wsum + dpp_d<0x141>(wsum);             // level 256: row_half_mirror (quads are uniform)
     const double h = 0.5 * tot;
-    double f1 = -nt1 - div_finish(h, ss, rs);
+    double f1;
+    if constexpr (LG) {          // nt1 = sum_j b_j hs_j, ss = the prior term (wave 1's duty)
+      f1 = nt1 - tot;
+      if (A.prior_div != 0.0) f1 = f1 - ss;
+      if (A.guard && !fmh_isfinite(f1)) f1 = -fmh_inf();
+    } else {
+      f1 = -nt1 - div_finish(h, ss, rs);
+    }
     const double th1_eval = th1;
     const double ratio_f = f1 - f0;
-    const bool rare = rowact && ((v == 1) || (status != FMCMC_CHAIN_OK) || (rs == 0.0) || !mfr_div_safe(h) || fmh_isnan(ratio_f));
+    const bool rare = rowact && ((v == 1) || (status != FMCMC_CHAIN_OK) || (!LG && ((rs == 0.0) || !mfr_div_safe(h))) || fmh_isnan(ratio_f));
     bool keep_row = true, acc = false;
     if (__builtin_expect(!__any(rare), 1)) {
       acc = lu < ratio_f;
     } else {
       const double sigma = shfl_d(th1, (lane & 48) + k - 1);
       keep_row = false;
-      if (sgf != 0.0) {
+      if constexpr (LG) {
+        (void)sigma;                                  // (f1 is what it is: the closed form has no special cases)
+      } else if (sgf != 0.0) {
         f1 = -nt1 - h / ss;
         if (A.guard && !fmh_isfinite(f1)) f1 = -fmh_inf();
       } else {
@@ -348,21 +409,22 @@ __device__ __forceinline__ void lat_steps(const SweepArgs& A, double* smem) {
   }
 }
 
-template <int KIND, int P, int OPT>
+template <int KIND, int P, int OPT, int FAM = FMCMC_FAM_GAUSSIAN_LINREG>
 __device__ __forceinline__ void lat_roles(const SweepArgs& A, double* smem) {
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  if (wave == 0) lat_steps<KIND, P, OPT, LAT_KEEPER>(A, smem);
-  else if (wave == 1) lat_steps<KIND, P, OPT, LAT_LOG>(A, smem);
-  else if (wave == 2) lat_steps<KIND, P, OPT, LAT_CANDS>(A, smem);
-  else if (wave == 3) lat_steps<KIND, P, OPT, LAT_RECIP>(A, smem);
-  else lat_steps<KIND, P, OPT, LAT_GENERIC>(A, smem);
+  if (wave == 0) lat_steps<KIND, P, OPT, LAT_KEEPER, FAM>(A, smem);
+  else if (wave == 1) lat_steps<KIND, P, OPT, LAT_LOG, FAM>(A, smem);
+  else if (wave == 2) lat_steps<KIND, P, OPT, LAT_CANDS, FAM>(A, smem);
+  else if (wave == 3 && FAM != FMCMC_FAM_LOGISTIC) lat_steps<KIND, P, OPT, LAT_RECIP, FAM>(A, smem);
+  else lat_steps<KIND, P, OPT, LAT_GENERIC, FAM>(A, smem);
 }
 
 // OPTMAX: the most observation slots a lane holds ((P + 1) OPTMAX doubles of x and y in VGPRs); the launch's (even) slot count
 // A.spec_opt <= OPTMAX selects the step loop.
-template <int KIND, int P, int OPTMAX>
+template <int KIND, int P, int OPTMAX, int FAM = FMCMC_FAM_GAUSSIAN_LINREG>
 __global__ __launch_bounds__(NT) void mh_sweep_lat(const SweepArgs A) {
   extern __shared__ double smem[];
+  if constexpr (FAM == FMCMC_FAM_LOGISTIC) logit_stage_table(logit_table_align(smem + LAT_LDS_DOUBLES));
   if (threadIdx.x < 64) {   // kernel constants of the candidate wave: mu, scale, lb, ub
     const int f = threadIdx.x >> 4, j = threadIdx.x & 15;
     const double* src = f == 0 ? A.mu : f == 1 ? A.scale : f == 2 ? A.lb : A.ub;
@@ -370,7 +432,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_lat(const SweepArgs A) {
   }
   __syncthreads();
   switch (A.spec_opt) {
-#define LAT_CC(O_) case O_: if constexpr (O_ <= OPTMAX) lat_roles<KIND, P, O_>(A, smem); break;
+#define LAT_CC(O_) case O_: if constexpr (O_ <= OPTMAX) lat_roles<KIND, P, O_, FAM>(A, smem); break;
     LAT_CC(2) LAT_CC(4) LAT_CC(6) LAT_CC(8) LAT_CC(10) LAT_CC(12) LAT_CC(14) LAT_CC(16) LAT_CC(18) LAT_CC(20)
 #undef LAT_CC
     default: break;
@@ -378,5 +440,6 @@ __global__ __launch_bounds__(NT) void mh_sweep_lat(const SweepArgs A) {
 }
 
 size_t lat_lds_bytes() { return sizeof(double) * (size_t)LAT_LDS_DOUBLES; }
+size_t lat_logit_lds_bytes() { return sizeof(double) * (size_t)(LAT_LDS_DOUBLES + 2 + LG_LDS_DOUBLES); }
 
 }  // namespace

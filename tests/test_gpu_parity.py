@@ -772,7 +772,7 @@ def test_logistic_observation_sharded(E, O, monkeypatch, p, intercept, C):
 
 @pytest.mark.parametrize("n,p,intercept", [(100, 4, True), (1000, 2, False), (5000, 5, True), (4096, 7, True), (10240, 3, True), (513, 1, True)])
 @pytest.mark.parametrize("chains", [2, 5, 600, 1100])
-def test_logistic_on_the_wave_specialised_kernel(E, O, n, p, intercept, chains):
+def test_logistic_on_the_wave_specialised_kernel_and_its_latency_forms(E, O, monkeypatch, n, p, intercept, chains):
     """Round 5: the logistic family on mh_sweep_spec (data in the compute lanes' registers, g table in LDS, register owners) -- the
     workflow vignette's own model, mcmc::logit's 100 observations and four covariates, first (vignettes/workflow-with-fmcmc.Rmd:22-60:
     kernel_normal, then kernel_adapt(freq = 1, warmup = 500)).  All four proposal kernels, one to four chains per workgroup, ragged n,
@@ -789,10 +789,18 @@ def test_logistic_on_the_wave_specialised_kernel(E, O, n, p, intercept, chains):
     init = jitter_init(list(beta[(0 if intercept else 1):]), chains, 17 + p)
     steps = 60 if chains < 100 else 20
     kw = dict(nsteps=steps, calls=2, prior_div=8.0, intercept=intercept)
+    # (the normal kernels with fewer than four chains per CU on short data: the latency form, mh_sweep_lat<.., LOGISTIC>)
+    lat = chains <= 768 and n <= (6144 if chains <= 256 else 3072)
     run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_NORMAL, k, init, scale=0.1, burnin=3, thin=2, **kw)
-    assert abi.last_kernel().startswith("spec-logit"), abi.last_kernel()
+    assert abi.last_kernel().startswith("lat-logit" if lat else "spec-logit"), abi.last_kernel()
     run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_NORMAL_REFLECTIVE, k, init, scale=0.3, lb=-0.7, ub=0.9, **dict(kw, prior_div=0.0))
-    assert abi.last_kernel().startswith("spec-logit")
+    assert abi.last_kernel().startswith("lat-logit" if lat else "spec-logit"), abi.last_kernel()
+    if lat:     # the same calls on the wave-specialised kernel (knob speclogit=2: no latency form)
+        set_knob(monkeypatch, "speclogit", "2")
+        run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_NORMAL, k, init, scale=0.1, burnin=3, thin=2, **kw)
+        assert abi.last_kernel().startswith("spec-logit"), abi.last_kernel()
+        run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_NORMAL_REFLECTIVE, k, init, scale=0.3, lb=-0.7, ub=0.9, **dict(kw, prior_div=0.0))
+        assert abi.last_kernel().startswith("spec-logit")
     run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_ADAPT, k, init, warmup=6, **kw)
     assert abi.last_kernel().startswith("spec-logit")
     run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_RAM, k, init, **kw)
@@ -811,7 +819,7 @@ def test_logistic_round5_kernels_edge_cases(E, O, monkeypatch, form):
         pytest.skip("the sharded form needs all 256 CUs")
     if form == "shadow":
         set_knob(monkeypatch, "shard", "1")
-    want = "logistic-shadow" if form == "shadow" else "spec-logit"
+    want = "logistic-shadow" if form == "shadow" else ("spec-logit", "lat-logit")
     rng = np.random.default_rng(5150)
     n, p = 1500, 3
     X = rng.standard_normal((n, p)); beta = np.array([0.3, 0.7, -0.6, 0.4])
