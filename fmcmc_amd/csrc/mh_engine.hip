@@ -1118,9 +1118,14 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
         else (void)hipGetLastError();
         // the normal / uniform proposal kernels, joint scheme, no fixed parameter: mh_sweep_logit2 (mh_logit2.hpp) -- four chains per
         // workgroup whatever cw says, the owners' work in the shadow of the hand-overs (knob shadow=0: off)
-        const void* kf3 = (K.shadow != 0 && kn->scheme == FMCMC_SCHEME_JOINT && kf == kn->k && A.kz == kn->k) ? fmh::k_logit2(lkv) : nullptr;
+        // (kernel_adapt / kernel_ram with up to eight parameters, none fixed, no window / constraint / bound: the same sweep with the
+        //  register owner of mh_spec.hpp, mh_sweep_logit2a)
+        const bool adaptive3 = (kn->kind == FMCMC_KERNEL_ADAPT && !adapt_hist) || (kn->kind == FMCMC_KERNEL_RAM && !kn->constr && !ram_bounded);
+        const void* kf3 = (K.shadow == 0 || kf != kn->k || A.kz != kn->k) ? nullptr
+                        : (kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE ? (kn->scheme == FMCMC_SCHEME_JOINT ? fmh::k_logit2(lkv) : nullptr)
+                           : ((adaptive3 && kn->k <= SPEC_KA && kn->k <= PIPE_KMAX) ? fmh::k_logit2a(lkv) : nullptr));
         if (kf3) {
-          const size_t lds3 = fmh::k_logit2_lds(kn->k);
+          const size_t lds3 = (kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE) ? fmh::k_logit2_lds(kn->k) : fmh::k_logit2a_lds();
           int per3 = 0;
           if (hipFuncSetAttribute(kf3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3) == hipSuccess &&
               hipOccupancyMaxActiveBlocksPerMultiprocessor(&per3, kf3, NT, lds3) == hipSuccess && (long long)per3 * ncu >= nb_launch) {
@@ -1134,6 +1139,7 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
       long long done = 0;
       for (; done < run->nchains && e == hipSuccess; done += ch_run) {   // (the slices and tables serve every launch)
         SweepArgs W = chain_window(A, done, (run->nchains - done < ch_run) ? run->nchains - done : ch_run, kf);
+        W.bits_stride = (run->nsteps + 31) >> 5;       // (the owners of mh_spec.hpp address the accept bitmap through it)
         (void)hipMemsetAsync(bar, 0, sizeof(double) * nbar, stream);
         void* kargs[] = {(void*)&W};
         e = hipLaunchCooperativeKernel(kfr, dim3((unsigned)nb_launch), dim3(NT), kargs, (unsigned int)lds_run, stream);

@@ -18,6 +18,8 @@ FMH_HIDDEN const void* k_logit(int cw, int sharded, int kind);
 // k_logit3.hip: mh_sweep_logit2<KIND> (kind 1, 2): the observation-sharded sweep with the owners in the shadow of the hand-overs
 FMH_HIDDEN const void* k_logit2(int kind);
 FMH_HIDDEN size_t k_logit2_lds(int k);
+FMH_HIDDEN const void* k_logit2a(int kind);     // mh_sweep_logit2a<KIND> (kind 3, 4; k <= 8, no fixed parameter, unbounded kernel_ram)
+FMH_HIDDEN size_t k_logit2a_lds();
 // k_mfma*.hip: mh_sweep_mfma<KV, NG, NS, false, BIG>, and the streamed-operand form <KV, NG, NSRES, false, BIG, true>
 FMH_HIDDEN const void* k_mfma(int kv, int ng, int ns, int big);
 FMH_HIDDEN const void* k_mfma_ext(int kv, int ng, int nsres, int big);

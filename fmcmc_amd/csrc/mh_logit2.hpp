@@ -235,6 +235,91 @@ __global__ __launch_bounds__(NT, 1) void mh_sweep_logit2(const SweepArgs A) {
   }
 }
 
+// ---- kernel_adapt / kernel_ram on the same sweep: the register owner of mh_spec.hpp (spec_owner_adaptive_reg<.., LOGISTIC>) meets the
+// evaluation through Logit2Sync -- total() IS the collective part of a step (hand-over 1 with the owner's preparation in its shadow,
+// logit_shard, hand-over 2, gather and tree), the waves that own nothing run the same calls in a loop of their own.
+template <class COLL>
+struct Logit2Sync {
+  static constexpr bool PREP_EARLY = true;
+  COLL& coll; const double* s_part; const double* s_th1; const SweepArgs& A; int myc; long long cl; int ncp;
+  template <class F> __device__ __forceinline__ double total(int, F&& prep) const {
+    coll(prep);
+    const int c = myc;
+    const double w0 = s_part[0 * LG2_CW + c], w1 = s_part[1 * LG2_CW + c], w2 = s_part[2 * LG2_CW + c], w3 = s_part[3 * LG2_CW + c];
+    const double w4 = s_part[4 * LG2_CW + c], w5 = s_part[5 * LG2_CW + c], w6 = s_part[6 * LG2_CW + c], w7 = s_part[7 * LG2_CW + c];
+    return ((w0 + w1) + (w2 + w3)) + ((w4 + w5) + (w6 + w7));  // levels 64, 128, 256
+  }
+  __device__ __forceinline__ void publish(int) const {       // (the owner has just written its proposal to s_th1: this lane's own element)
+    const int lane = threadIdx.x & 63;
+    if (lane < A.k) sh_store(&A.sh_th[(long long)lane * ncp + cl], s_th1[myc * PIPE_KMAX + lane]);
+  }
+  __device__ __forceinline__ void final() const {}
+};
+
+template <int KIND>
+__global__ __launch_bounds__(NT, 1) void mh_sweep_logit2a(const SweepArgs A) {
+  static_assert(KIND == FMCMC_KERNEL_ADAPT || KIND == FMCMC_KERNEL_RAM, "the adaptive proposal kernels");
+  extern __shared__ double smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int k = A.k;
+  const int nsteps = (int)A.nsteps;
+  double* s_th1 = smem;                                // [LG2_CW][PIPE_KMAX] the owners' proposals (spec_owner_adaptive_reg writes them here)
+  double* s_part = s_th1 + LG2_CW * PIPE_KMAX;         // [NW][LG2_CW]
+  double* s_tab = logit_table_align(s_part + NW * LG2_CW);
+  logit_stage_table(s_tab);
+  logit_reset_turns(s_tab);
+  const long long cg0 = (long long)blockIdx.x * LG2_CW;
+  const int ncw = (int)((A.nchains - cg0 < LG2_CW) ? (A.nchains - cg0 < 0 ? 0 : A.nchains - cg0) : LG2_CW);
+  const bool owner = wave < ncw;
+  const long long cl = cg0 + (owner ? wave : 0);
+  const int NCP = (int)A.nchains + SH_PAD;
+  const bool fault = (A.debug & 512) != 0;
+  constexpr unsigned LOST = 0x80000000u;
+  unsigned epoch = 0;
+  if (owner && lane < k) {                             // the initial state is the first "proposal"
+    const double t = A.theta0[cl * k + lane];
+    s_th1[wave * PIPE_KMAX + lane] = t;
+    sh_store(&A.sh_th[(long long)lane * NCP + cl], t);
+  }
+  __syncthreads();
+  // the collective part of a step; `prep` runs between the arrival and the wait of hand-over 1 (owners: what the decision needs and
+  // the evaluation does not enter)
+  auto coll = [&](auto&& prep) {
+    const bool sync_on = !(A.debug & 32) && !(epoch & LOST);
+    if (sync_on) lg2_arrive(A.sh_bar, ++epoch, fault); else __syncthreads();
+    prep();
+    if (sync_on) { if (!lg2_wait(A.sh_bar, epoch, fault)) epoch |= LOST; }
+    eval_sharded_logit_step<2>(A, s_tab);
+    const bool sync2 = !(A.debug & 32) && !(epoch & LOST);
+    if (sync2) {
+      lg2_arrive(A.sh_bar, ++epoch, fault);
+      if (!lg2_wait(A.sh_bar, epoch, fault)) epoch |= LOST;
+    } else {
+      __syncthreads();
+    }
+    double acc[LG2_CW];
+#pragma unroll
+    for (int c = 0; c < LG2_CW; c++)
+      acc[c] = (c < ncw && !(A.debug & 128)) ? sh_load(A.sh_part + ((unsigned int)(cg0 + c) * (unsigned int)(NT + SH_PAD) + (unsigned int)tid)) : 1.0;
+#pragma unroll
+    for (int c = 0; c < LG2_CW; c++) {
+      const double w = wave_xor_sum(acc[c]);
+      if (lane == 0) s_part[wave * LG2_CW + c] = w;
+    }
+    lds_barrier();
+  };
+  if (owner) {
+    Logit2Sync<decltype(coll)> sync{coll, s_part, s_th1, A, wave, cl, NCP};
+    spec_owner_adaptive_reg<KIND, 0, decltype(sync), false, FMCMC_FAM_LOGISTIC>(A, wave, (int)cl, s_th1, sync);
+    if ((epoch & LOST) && lane == 0) { A.status[cl] = FMCMC_CHAIN_SYNC_TIMEOUT; A.status_step[cl] = 0; }
+  } else {
+    for (int v = 1; v <= nsteps; v++) coll([]() {});
+  }
+}
+
+size_t logit2a_lds_bytes() { return sizeof(double) * (size_t)(LG2_CW * PIPE_KMAX + NW * LG2_CW + LG_LDS_TAIL + LG_LDS_DOUBLES); }
+
 size_t logit2_lds_bytes(int k) { return sizeof(double) * (size_t)(5 * k + NW * LG2_CW + LG_LDS_TAIL + LG_LDS_DOUBLES); }
 
 }  // namespace

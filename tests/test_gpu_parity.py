@@ -854,7 +854,8 @@ def test_logit_shard_priority_turns_change_no_bit(E, monkeypatch):
     big = E.DBL_MAX
     gm = E.DeviceModel(abi.FAM_LOGISTIC, X, y, intercept=True, guard=False, prior_div=8.0)
     init = 0.1 * rng.standard_normal((C, k))
-    for kind, want in ((abi.KERNEL_NORMAL, "logistic-shadow"), (abi.KERNEL_ADAPT, "logistic-sharded")):
+    for kind, want in ((abi.KERNEL_NORMAL, "logistic-shadow"), (abi.KERNEL_ADAPT, "logistic-shadow"), (abi.KERNEL_ADAPT, "logistic-sharded")):
+        set_knob(monkeypatch, "shadow", "0" if want == "logistic-sharded" else "-1")       # (the general kernel's sharded form too)
         gk = (E.KernelSpec(kind, k, np.zeros(k), np.full(k, 0.05), np.full(k, -big), np.full(k, big), np.zeros(k, np.uint8)) if kind == abi.KERNEL_NORMAL
               else E.KernelSpec(kind, k, np.zeros(k), np.ones(k), np.full(k, -big), np.full(k, big), np.zeros(k, np.uint8), warmup=10))
         ref = None
@@ -1140,7 +1141,9 @@ def test_logistic_adaptive_kernels_on_the_logistic_kernels(E, O, monkeypatch, ki
             run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_RAM, 5, init, freq=2,
                      constr=(np.abs(np.subtract.outer(np.arange(5), np.arange(5))) <= 1).astype(float), **kw)
         # (the bounded kernel_ram evaluates a second time only where a proposal was reflected: chain-sharded form only)
-        assert abi.last_kernel() == ("logistic-sharded" if form == "observation-sharded" and kind_name != "ram_bounded" else "streamed-logistic")
+        # (round 5: plain kernel_adapt / kernel_ram with up to eight parameters run the sweep with the register owner, mh_sweep_logit2a)
+        sharded = "logistic-shadow" if kind_name in ("adapt", "ram") else "logistic-sharded"
+        assert abi.last_kernel() == (sharded if form == "observation-sharded" and kind_name != "ram_bounded" else "streamed-logistic")
 
 
 @pytest.mark.parametrize("kind_name", ["adapt", "ram", "normal_ordered"])
