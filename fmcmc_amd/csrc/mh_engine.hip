@@ -652,11 +652,22 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
   // software-pipelined fast path: normal kernels, joint scheme, k <= 16, linreg data in registers
   const bool nopipe = K.pipe == 0;
   int pipe_opt = 0, mfma_ng = 0, mfma_ad = 0, mfma_ext = 0, spec_cw = 4;
+  // kernel_adapt(freq = 2 .. 8, bw = 0) on the register owner of mh_sweep_spec (round 5: the last `freq` rows of a chain in an LDS ring;
+  // tools/option_audit.py had it on the general kernel at 14.7 us per step where freq = 1 takes 3.3): no fixed parameter, k <= 8, and a
+  // call that is ONE step window (the ring does not travel between windows)
+  bool adapt_ring = false;
+  if (kn->kind == FMCMC_KERNEL_ADAPT && kn->bw == 0 && kn->freq >= 2 && kn->freq <= SPEC_FREQMAX && kf == kn->k && A.kz == kn->k && kn->k <= SPEC_KA) {
+    const long long per_step = (long long)run->nchains * (A.kz + 1) * 8;
+    long long win = ((256ll << 20) / (per_step > 0 ? per_step : 1)) & ~31ll;
+    if (win < 32) win = 32;
+    if (K.window >= 32) win = (long long)K.window & ~31ll;
+    adapt_ring = run->nsteps <= win + 1 || run->rng_mode != FMCMC_RNG_PHILOX;
+  }
   bool lat_normal = false;   // the normal / uniform kernels in the latency form (mh_sweep_lat)   // mfma_ext: resident slots of the EXT form (0: everything resident)
   AsyncScratch mfs_guard;
   if (!force && !nopipe && m->family == FMCMC_FAM_GAUSSIAN_LINREG &&
       (kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE ||
-       ((kn->kind == FMCMC_KERNEL_ADAPT && !adapt_hist) || (kn->kind == FMCMC_KERNEL_RAM && !kn->constr)) ||
+       ((kn->kind == FMCMC_KERNEL_ADAPT && (!adapt_hist || adapt_ring)) || (kn->kind == FMCMC_KERNEL_RAM && !kn->constr)) ||
        (mirror && kn->scheme == FMCMC_SCHEME_JOINT && kf == kn->k && K.mfma != 0)) &&
       (kn->scheme == FMCMC_SCHEME_JOINT || kn->kind == FMCMC_KERNEL_ADAPT || kn->kind == FMCMC_KERNEL_RAM) && kn->k <= PIPE_KMAX &&
       // Sizes (round 3: rows and variates are addressed as 64-bit chain base + 32-bit offset, and a long call runs as step
@@ -700,7 +711,7 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
     // (k = 9 -- seven covariates, intercept and sigma -- as a compile-time row count: tools/dispatch_audit.py found these calls on
     //  the general kernel, 7x the time of the normal kernels at the same shape)
     // (mfma_ad == 2: the owners with their matrices in LDS -- 8 .. 15 covariates, or a fixed parameter; not the bounded kernel_ram)
-    if (K.mfma != 0 && !pipe_opt && (kn->kind == FMCMC_KERNEL_ADAPT || kn->kind == FMCMC_KERNEL_RAM) && m->p >= 0 && m->p <= 15 && m->n < (1ll << 29)) {   // (p = 0: iid Normal)
+    if (K.mfma != 0 && !pipe_opt && !adapt_hist && (kn->kind == FMCMC_KERNEL_ADAPT || kn->kind == FMCMC_KERNEL_RAM) && m->p >= 0 && m->p <= 15 && m->n < (1ll << 29)) {   // (p = 0: iid Normal)
       const bool reg_owner = m->p <= 7 && kf == kn->k && (kn->k <= SPEC_KA || kn->k == 9) && A.kz == kn->k;
       const int ng = (m->p <= 3) ? 1 : (m->p <= 7 ? 2 : (m->p <= 11 ? 3 : 4));
       const int nsr = (ng == 1) ? MfmaAdShape<1>::NSR : (ng == 2 ? MfmaAdShape<2>::NSR : MfmaAdShape<3>::NSR);
@@ -772,7 +783,7 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
   if (!force && !nopipe && K.speclogit != 0 && K.shard < 0 && m->family == FMCMC_FAM_LOGISTIC && !mirror && m->p >= 1 && m->p <= 7 &&
       kn->k == m->p + (m->intercept ? 1 : 0) && kf == kn->k && A.kz == kn->k &&
       (((kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE) && kn->scheme == FMCMC_SCHEME_JOINT) ||
-       (kn->kind == FMCMC_KERNEL_ADAPT && !adapt_hist) || (kn->kind == FMCMC_KERNEL_RAM && !kn->constr && !ram_bounded)) &&
+       (kn->kind == FMCMC_KERNEL_ADAPT && (!adapt_hist || adapt_ring)) || (kn->kind == FMCMC_KERNEL_RAM && !kn->constr && !ram_bounded)) &&
       (unsigned long long)run->nsteps * (unsigned long long)A.kz * 8ull < (1ull << 32) && run->nsteps < (1ll << 30) &&
       (unsigned long long)kn->k * (unsigned long long)A.ldS * 8ull < (1ull << 32)) {
     const long long nsl2 = (((m->n + NT - 1) / NT) + 1) & ~1ll;

@@ -355,8 +355,10 @@ struct SpecSync {
 // decision f of the REFLECTED proposal -- a second evaluation, needed only in the steps in which a reflection moved something.  The
 // policy decides it for its workgroup: second(need, republish, tot2) -> true when a second evaluation ran (tot2: its total for this
 // chain), second_idle() for an owner that has nothing to ask in this step but must keep in step (MfmaAdSync; SpecSync has neither).
+constexpr int SPEC_FREQMAX = 8;    // kernel_adapt(freq = 2 .. 8, bw = 0) on the register owner: the last `freq` rows of the chain in an LDS ring
 template <int KIND, int KX, class SYNC, bool BND = false, int FAM = FMCMC_FAM_GAUSSIAN_LINREG>
-__device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int myc, int cl, double* s_th1, SYNC& sync) {
+__device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int myc, int cl, double* s_th1, SYNC& sync,
+                                                        double* ring = nullptr /* LDS [SPEC_FREQMAX][PIPE_KMAX]; needed for freq > 1 */) {
   static_assert(!BND || KIND == FMCMC_KERNEL_RAM, "BND is the bounded kernel_ram");
   constexpr bool LG = FAM == FMCMC_FAM_LOGISTIC;
   static_assert(!(LG && BND), "the logistic family runs the unbounded kernel_ram here");
@@ -380,6 +382,7 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
   }
   double th0 = rl ? A.theta0[(long long)cl * k + lane] : 0.0, th1 = th0;
   double f0 = 0.0, mean_prev = 0.0, run_sum = 0.0, zcur = 0.0;
+  double Dl = 0.0;                          // adapt: D_lane of the factor (kept between the steps that form it)
   long long abs_iter = 0;
   // (continuation windows of a long call: see spec_owner_adaptive)
   int nacc = 0, status = A.win_cont ? A.status[cl] : FMCMC_CHAIN_OK, thin_ctr = A.thin_ctr0, have_mean = 0, nerr = 0;
@@ -573,30 +576,43 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
       }
     }
     SPEC_ST(2);
+    // kernel_adapt(freq > 1): row v of the chain into the ring (rows (i - freq) .. (i - 1) are folded in together at step i)
+    const int afreq = (KIND == FMCMC_KERNEL_ADAPT) ? A.freq : 1;
+    if (KIND == FMCMC_KERNEL_ADAPT && afreq > 1 && ring && rl) ring[(v & (SPEC_FREQMAX - 1)) * PIPE_KMAX + lane] = th0;
     // ---- proposal of loop step i = v + 1
     if (v < nsteps) {
       if (status == FMCMC_CHAIN_OK) {
         const int i = v + 1;
         zcur = z_nx;
         z_nx = rl ? ld_z(v + 1 < nsteps ? v + 1 : nsteps - 1) : 0.0;
+        bool sig_dirty = (afreq == 1) || v == 1;         // (freq > 1: the factor is formed again only when Sigma has moved)
         if (KIND == FMCMC_KERNEL_ADAPT) {
-          if (A.until > (double)abs_iter && abs_iter > A.warmup && i + ioff > 2) {   // R/kernel_adapt.R:118-166
-            const double t = (double)(abs_iter - 1);
-            const double x = th0;
-            const double mp = have_mean ? mean_prev : (run_sum / (double)(i + ioff - 1));
-            const double mt = (mp * t + x) / (t + 1);
-            const double c1 = pre_c1, c2 = pre_c2;       // (prepared while this wave waited for the partials: two divisions off the pass)
-            static_for<KA>([&](auto b_) {
-              constexpr int b = decltype(b_)::value;
-              if (b < kf) {
-                const double mpb = row_bcast<b>(mp), mtb = row_bcast<b>(mt), xb = row_bcast<b>(x);
-                const double ik = (b == lane) ? 1.0 * A.eps : 0.0;
-                const double inner = t * (mp * mpb) - (t + 1) * (mt * mtb) + x * xb + 1e-5 * ik;
-                Srow[b] = c1 * Srow[b] + c2 * inner;
+          if (A.until > (double)abs_iter && abs_iter > A.warmup && i + ioff > 2 && (afreq == 1 || ((i + ioff) % afreq) == 0)) {   // R/kernel_adapt.R:118-166
+            if (afreq > 1 && i - afreq < 1) {
+              status = FMCMC_CHAIN_BAD_WINDOW;           // R: ans[0:(i-1), ] has fewer than freq rows, `[, , freq]` is out of bounds
+            } else {
+              // rows (i - freq):(i - 1) folded in one by one, t = abs_iter - freq + (row - 1) (R/recursive.R:79-108,:129-136)
+              for (int jr = 0; jr < afreq; jr++) {
+                const double t = (double)(abs_iter - afreq + jr);
+                const double x = (afreq == 1) ? th0 : (rl ? ring[((i - afreq + jr) & (SPEC_FREQMAX - 1)) * PIPE_KMAX + lane] : 0.0);
+                const double mp = have_mean ? mean_prev : (run_sum / (double)(i + ioff - 1));
+                const double mt = (mp * t + x) / (t + 1);
+                // (freq = 1: the two step-only quotients were prepared while this wave waited for the partials)
+                const double c1 = (afreq == 1) ? pre_c1 : (t - 1) / t, c2 = (afreq == 1) ? pre_c2 : 1.0 / t;
+                static_for<KA>([&](auto b_) {
+                  constexpr int b = decltype(b_)::value;
+                  if (b < kf) {
+                    const double mpb = row_bcast<b>(mp), mtb = row_bcast<b>(mt), xb = row_bcast<b>(x);
+                    const double ik = (b == lane) ? 1.0 * A.eps : 0.0;
+                    const double inner = t * (mp * mpb) - (t + 1) * (mt * mtb) + x * xb + 1e-5 * ik;
+                    Srow[b] = c1 * Srow[b] + c2 * inner;
+                  }
+                });
+                mean_prev = mt;
+                have_mean = 1;
               }
-            });
-            mean_prev = mt;
-            have_mean = 1;
+              sig_dirty = true;
+            }
           }
           abs_iter += 1;
           SPEC_ST(3);
@@ -605,7 +621,8 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
           // owner's ~550 vector instructions at k = 5); here a column is its fma chain and one division, W = the numerators
           // before the division stand in for L D in the sums, and sqrt(D) is one element-wise square root at proposal time.
           bool notpd = false;
-          double Dl = 0.0;                    // D_lane
+          if (status == FMCMC_CHAIN_OK && sig_dirty) {
+          Dl = 0.0;
           static_for<KA>([&](auto j_) {
             constexpr int j = decltype(j_)::value;
             // (a compile-time row count: NO branch per column -- a pivot that fails marks the factor, the columns behind it compute
@@ -631,9 +648,10 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
               }
             }
           });
+          }
           SPEC_ST(4);
-          if (notpd) {
-            status = FMCMC_CHAIN_NOT_PD;
+          if (notpd || status != FMCMC_CHAIN_OK) {
+            if (notpd) status = FMCMC_CHAIN_NOT_PD;
             if (lane == 0) { A.status[cl] = status; A.status_step[cl] = i + ioff; }
             if (rl) A.status_theta[(long long)cl * k + lane] = th1;
             if (((v - 1) & 31) != 31) flush_bits(v);   // (the accept bits of the steps decided so far; a full word has just been flushed)
@@ -906,16 +924,16 @@ __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
     for (int j = 0; j < k; j++) nofixed = nofixed && (A.fixed[j] == 0);
     SpecSync sync{s_ready, s_done, s_tr, myc};
     if constexpr (LG) {   // (the host takes this kernel for k = P + intercept, no fixed parameter: the register owner)
-      if (k == P + 1) spec_owner_adaptive_reg<KIND, P + 1, SpecSync, false, FMCMC_FAM_LOGISTIC>(A, myc, cl, s_th1, sync);
-      else spec_owner_adaptive_reg<KIND, (P > 0 ? P : 1), SpecSync, false, FMCMC_FAM_LOGISTIC>(A, myc, cl, s_th1, sync);
+      if (k == P + 1) spec_owner_adaptive_reg<KIND, P + 1, SpecSync, false, FMCMC_FAM_LOGISTIC>(A, myc, cl, s_th1, sync, s_ad + myc * SPEC_ADS);
+      else spec_owner_adaptive_reg<KIND, (P > 0 ? P : 1), SpecSync, false, FMCMC_FAM_LOGISTIC>(A, myc, cl, s_th1, sync, s_ad + myc * SPEC_ADS);
       return;
     }
     if (k == P + 2 && nofixed && A.kz == k && !(A.debug & 16))        // intercept + P covariates + sigma (C3: k = 5)
-      spec_owner_adaptive_reg<KIND, P + 2>(A, myc, cl, s_th1, sync);
+      spec_owner_adaptive_reg<KIND, P + 2>(A, myc, cl, s_th1, sync, s_ad + myc * SPEC_ADS);
     else if (k == P + 1 && nofixed && A.kz == k && !(A.debug & 16))   // no intercept
-      spec_owner_adaptive_reg<KIND, P + 1>(A, myc, cl, s_th1, sync);
+      spec_owner_adaptive_reg<KIND, P + 1>(A, myc, cl, s_th1, sync, s_ad + myc * SPEC_ADS);
     else if (k <= SPEC_KA && nofixed && !(A.debug & 16))
-      spec_owner_adaptive_reg<KIND, 0>(A, myc, cl, s_th1, sync);
+      spec_owner_adaptive_reg<KIND, 0>(A, myc, cl, s_th1, sync, s_ad + myc * SPEC_ADS);
     else
       spec_owner_adaptive<KIND>(A, myc, cl, s_th1, s_par, sync, s_ad + myc * SPEC_ADS);
     return;

@@ -500,7 +500,10 @@ __global__ __launch_bounds__(NT, MINB) void mh_sweep_kernel(const SweepArgs A0) 
         if (A.until > (double)abs_iter && abs_iter > A.warmup && i > 2 && (i % A.freq) == 0) {
           const int H = A.hist_rows;
           double* ring = A.hist + (long long)cl * H * kf;
-          if (H > 0) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");   // the ring rows were stored by other lanes of this wave
+          // the ring rows were stored by other lanes of THIS wave: their stores acknowledged (s_waitcnt vmcnt(0)) is all it takes -- the
+          // agent-scope fence that stood here wrote back and invalidated the XCD's caches at every adaptation (option audit:
+          // kernel_adapt(freq = 2) at 14.7 us per step against 3.3 for freq = 1)
+          if (H > 0) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
           if (A.bw > 0) {
             // windowed AM: Sigma <<- Sd * (cov(ans[(i - bw + 1):(i - 1), which.]) + Ik) :120-125 (twin of the oracle's canonical cov)
             const int N = A.bw - 1;

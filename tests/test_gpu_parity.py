@@ -625,6 +625,9 @@ def test_adapt_window_and_stride(E, O, C, n, p, bw, freq, warmup):
     init = jitter_init([0.0] * (p + 1) + [float(np.std(y))], C, 2)
     rg, ro = run_both(E, O, O.FAM_LINREG, X, y, O.K_ADAPT, k, init, nsteps=180, bw=bw, freq=freq, warmup=warmup, Sd=0.8)
     assert np.all(ro.status == 0) and ro.accept_count.min() > 0
+    from fmcmc_amd import _abi as abi
+    if bw == 0 and 2 <= freq <= 8 and 1 <= p <= 7 and n <= 512 * (20 if p <= 3 else 10 if p <= 5 else 8):
+        assert abi.last_kernel() == "spec"      # (round 5: the last `freq` rows in an LDS ring of the register owner)
     if bw > 0 or freq > 2:
         om, ok = O.Model(O.FAM_LINREG, X, y), O.Kernel(O.K_ADAPT, k, bw=bw, freq=freq, warmup=warmup, Sd=0.8)
         gm = E.DeviceModel(O.FAM_LINREG, X, y)
@@ -639,6 +642,26 @@ def test_adapt_window_and_stride(E, O, C, n, p, bw, freq, warmup):
         assert np.array_equal(r2g.status_step.cpu().numpy(), r2o.status_step)
         with pytest.raises(RuntimeError, match="subscript out of bounds"):
             E.raise_on_chain_error(r2g)
+
+
+@pytest.mark.parametrize("freq,warmup", [(2, 0), (4, 9), (8, 30), (7, 3)])
+@pytest.mark.parametrize("chains", [3, 700])
+def test_adapt_stride_on_the_register_owner_and_its_latency_forms(E, O, freq, warmup, chains):
+    """kernel_adapt(freq = 2 .. 8) (R/kernel_adapt.R:127-160: the last `freq` rows folded in together every freq-th step) on
+    mh_sweep_spec's register owner -- LDS ring of the chain's last rows, the factor formed again only when Sigma has moved -- for the
+    linear and the logistic model, one to three chains per workgroup and two calls (the second one's first update asks for rows
+    that precede the call where freq allows it: status 4, as the reference's subscript error): the oracle's bits."""
+    from fmcmc_amd import _abi as abi
+    X, y = synth_linreg(2100, 3, 77 + freq)
+    init = jitter_init([0.0] * 4 + [float(np.std(y))], chains, 5)
+    steps = 90 if chains < 100 else 40
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_ADAPT, 5, init, nsteps=steps, freq=freq, warmup=warmup, calls=2)
+    assert abi.last_kernel().startswith("spec"), abi.last_kernel()
+    rng = np.random.default_rng(freq)
+    Xl = rng.standard_normal((900, 2)); yl = (rng.uniform(size=900) < 0.4).astype(np.float64)
+    initl = 0.1 * rng.standard_normal((chains, 3))
+    run_both(E, O, O.FAM_LOGISTIC, Xl, yl, O.K_ADAPT, 3, initl, nsteps=steps, freq=freq, warmup=warmup, calls=2, prior_div=8.0)
+    assert abi.last_kernel().startswith("spec-logit"), abi.last_kernel()
 
 
 @pytest.mark.parametrize("kind_name", ["nmirror", "umirror"])
