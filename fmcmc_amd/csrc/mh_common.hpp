@@ -69,6 +69,7 @@ struct SweepArgs {
   // bits_stride the words per chain of the WHOLE call's bitmap, step_off what to add to a local step for status_step.
   int win_cont, thin_ctr0;
   long long bits_stride, step_off;
+  long long nsteps_call;     // loop steps of the WHOLE call (row stride of scheme_cols, the plan of scheme = "random"; nsteps is a window's)
   double* win_sum;           // kernel_adapt in step windows: [C][kf] the running sum of this call's rows (its first running mean), carried from window to window; or NULL
   const double* fed_logu;
   const double* fed_z;

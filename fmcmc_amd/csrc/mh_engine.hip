@@ -664,12 +664,17 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
     adapt_ring = run->nsteps <= win + 1 || run->rng_mode != FMCMC_RNG_PHILOX;
   }
   bool lat_normal = false;   // the normal / uniform kernels in the latency form (mh_sweep_lat)   // mfma_ext: resident slots of the EXT form (0: everything resident)
+  // single-parameter schemes of the normal / uniform kernels ("ordered", an explicit sequence, "random"): on mh_sweep_lat's candidate
+  // wave (round 5: they ran on the general kernel, 2.9 us per step at the README's size where the joint scheme takes 0.63), one to FOUR
+  // chains per workgroup; "random" draws its plan in the kernel and hands it back (a caller-fed plan stays general)
+  const bool single_lat = (kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE) && kn->scheme != FMCMC_SCHEME_JOINT &&
+                          K.lat != 0 && (kn->scheme != FMCMC_SCHEME_RANDOM || run->rng_mode == FMCMC_RNG_PHILOX);
   AsyncScratch mfs_guard;
   if (!force && !nopipe && m->family == FMCMC_FAM_GAUSSIAN_LINREG &&
       (kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE ||
        ((kn->kind == FMCMC_KERNEL_ADAPT && (!adapt_hist || adapt_ring)) || (kn->kind == FMCMC_KERNEL_RAM && !kn->constr)) ||
        (mirror && kn->scheme == FMCMC_SCHEME_JOINT && kf == kn->k && K.mfma != 0)) &&
-      (kn->scheme == FMCMC_SCHEME_JOINT || kn->kind == FMCMC_KERNEL_ADAPT || kn->kind == FMCMC_KERNEL_RAM) && kn->k <= PIPE_KMAX &&
+      (kn->scheme == FMCMC_SCHEME_JOINT || kn->kind == FMCMC_KERNEL_ADAPT || kn->kind == FMCMC_KERNEL_RAM || single_lat) && kn->k <= PIPE_KMAX &&
       // Sizes (round 3: rows and variates are addressed as 64-bit chain base + 32-bit offset, and a long call runs as step
       // windows with a bounded stream, so a call no longer leaves these kernels at 4 GiB of samples or stream).  What is
       // left: offsets inside one chain's blocks are 32 bits.
@@ -687,8 +692,8 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
       //  moved something -- the barrier-synchronised owners of mh_sweep_mfma_ad ask for it, this kernel's pipelined ones cannot)
       if (m->p >= 1 && nsl2 <= optmax && (kn->kind == FMCMC_KERNEL_ADAPT || kn->kind == FMCMC_KERNEL_RAM) && !(kn->kind == FMCMC_KERNEL_RAM && ram_bounded)) pipe_opt = (int)nsl2;
       // (normal / uniform kernels run on the MFMA kernel; knob mfma=0 keeps them here for the two shapes they were tuned at)
-      if (m->p == 3 && nsl == 20 && kn->kind < FMCMC_KERNEL_ADAPT) pipe_opt = 20;
-      if (m->p == 1 && nsl == 2 && kn->kind < FMCMC_KERNEL_ADAPT) pipe_opt = 2;
+      if (m->p == 3 && nsl == 20 && kn->kind < FMCMC_KERNEL_ADAPT && kn->scheme == FMCMC_SCHEME_JOINT) pipe_opt = 20;
+      if (m->p == 1 && nsl == 2 && kn->kind < FMCMC_KERNEL_ADAPT && kn->scheme == FMCMC_SCHEME_JOINT) pipe_opt = 2;
     }
     // fp64-MFMA evaluation: general in n and p up to what 80 operand registers per lane hold (normal / uniform kernels)
     if (K.mfma != 0 && kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE && kn->scheme == FMCMC_SCHEME_JOINT) {
@@ -743,6 +748,13 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
     // lanes hold in registers: kernel_adapt / kernel_ram on mh_sweep_spec (its owners no longer queue behind the evaluation of
     // other chains), the normal / uniform kernels on mh_sweep_lat (mh_lat.hpp: chain state replicated in every wave, ONE barrier
     // per step).  Same canonical lanes and tree: the bits do not depend on the form.  Knob lat=0: off; lat=1|2|3: forced.
+    if (single_lat && !mirror) {
+      const long long per_cu = (run->nchains + ncu - 1) / ncu, nsl2 = (((m->n + NT - 1) / NT) + 1) & ~1ll;
+      if (per_cu <= 4 && m->p >= 0 && m->p <= 7 && nsl2 <= fmh::k_spec_optmax(m->p, kn->kind) && fmh::k_lat(m->p, kn->kind)) {
+        pipe_opt = (int)nsl2; mfma_ng = 0; lat_normal = true;
+        spec_cw = (K.lat >= 1 && K.lat <= 3) ? K.lat : (int)per_cu;
+      }
+    } else
     if (K.lat != 0 && !mirror && (pipe_opt || (mfma_ng && !mfma_ext && !mfma_ad))) {
       const long long per_cu = (run->nchains + ncu - 1) / ncu;
       // kernel_adapt / kernel_ram (mh_sweep_spec) gain up to 25 % with one chain per workgroup, 18 % with two, 6 % with three at
@@ -803,6 +815,7 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
   }
   A.spec_opt = pipe_opt;
   A.spec_cw = spec_cw;
+  A.nsteps_call = run->nsteps;
   // ---- the LONG-DATA form (mh_common.hpp, shard_long): few chains on long data.  Up to four chains are one workgroup of the
   // chain-sharded kernels, i.e. ONE compute unit walks the whole data set per step (n = 1e5, p = 3: 34 us per step, 255 CUs idle);
   // here all 256 workgroups evaluate their 1/256 of the observations for every chain and the canonical lane sums cross the chip as
@@ -955,7 +968,7 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
           g_kernel = A.spec_cw == 1 ? "lat-logit1" : A.spec_cw == 2 ? "lat-logit2" : "lat-logit3";
           e = launch_k(fmh::k_lat_logit(m->p, kn->kind), (A.nchains + A.spec_cw - 1) / A.spec_cw, NT, fmh::k_lat_logit_lds(), stream, A);
         } else {
-        g_kernel = A.spec_cw == 1 ? "lat1" : A.spec_cw == 2 ? "lat2" : "lat3";
+        g_kernel = A.spec_cw == 1 ? "lat1" : A.spec_cw == 2 ? "lat2" : A.spec_cw == 3 ? "lat3" : "lat4";
         e = launch_k(fmh::k_lat(m->p, kn->kind), (A.nchains + A.spec_cw - 1) / A.spec_cw, NT, lat_lds_bytes(), stream, A);
         }
       } else {

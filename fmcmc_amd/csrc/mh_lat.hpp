@@ -111,9 +111,13 @@ __device__ __forceinline__ void lat_steps(const SweepArgs& A, double* smem) {
   const double* z_lane = nullptr; const double* lu_row = nullptr;
   bool fixed_l = false;
   double z_nx = 0.0, lu_nx = 0.0;
+  // single-parameter schemes (round 5; R/kernel.R:66-133 plan_update_sequence: "ordered", an explicit sequence, "random"): ONE
+  // parameter moves per step with the step's one variate -- the lane whose parameter it is takes dz, the others keep theirs.
+  const int scheme = A.scheme;
+  int zrank = 0, kfree = 0, first_free = 0;             // rank of this lane's parameter among the free ones; their number; the first of them
   if constexpr (ROLE == LAT_CANDS) {
-    int zidx = 0;
-    for (int j = 0; j < jl; j++) zidx += A.fixed[j] ? 0 : 1;
+    for (int j = k - 1; j >= 0; j--) { const int fr = A.fixed[j] ? 0 : 1; kfree += fr; if (j < jl) zrank += fr; if (fr) first_free = j; }
+    int zidx = zrank;
     if (zidx > kz - 1) zidx = kz > 0 ? kz - 1 : 0;   // lanes without a variate of their own read a valid neighbour (value unused)
     z_lane = A.fed_z + (cl * nsteps) * kz + zidx;
     lu_row = A.fed_logu + cl * nsteps;
@@ -122,15 +126,31 @@ __device__ __forceinline__ void lat_steps(const SweepArgs& A, double* smem) {
   auto candidates = [&](int vn) {    // candidates of version vn + 1 and the log-uniform of decision vn -> buffer vn & 1
     const double dz = s_par[0 * 16 + jj] + s_par[1 * 16 + jj] * z_nx;
     double ca = th1 + dz, cr = th0 + dz;
+    bool keep = fixed_l;                                // this lane's parameter does not move in this step
+    if (scheme != FMCMC_SCHEME_JOINT) {
+      const long long ic = (long long)vn + 1 + A.step_off;            // the CALL's loop step of the proposal
+      bool upd;
+      if (scheme == FMCMC_SCHEME_ORDERED) {
+        upd = !fixed_l && zrank == (int)((ic - 1) % kfree);
+      } else if (scheme == FMCMC_SCHEME_EXPLICIT) {
+        upd = jj == A.scheme_seq[(ic - 1) % A.scheme_len];
+      } else {   // sample(which(!fixed), nsteps, TRUE)[i]; a single free parameter at position j makes R sample from 1:j
+        const unsigned int pool = (kfree == 1) ? (unsigned int)(first_free + 1) : (unsigned int)kfree;
+        const unsigned int idx = fmh_scheme_index(A.seed, (unsigned int)ic, (unsigned int)(A.chain_base + cl), pool);
+        upd = (kfree == 1) ? (jj == (int)idx) : (!fixed_l && zrank == (int)idx);
+        if (upd && act && A.scheme_cols && vn + 1 <= nsteps) A.scheme_cols[cl * A.nsteps_call + (ic - 1)] = jj;   // the plan, handed back
+      }
+      keep = !upd;
+    }
     if (KIND == FMCMC_KERNEL_NORMAL_REFLECTIVE) {
-      if (act && !fixed_l) {
+      if (act && !keep) {
         const double lb_l = s_par[2 * 16 + jj], ub_l = s_par[3 * 16 + jj];
         ca = reflect1(ca, lb_l, ub_l);
         cr = reflect1(cr, lb_l, ub_l);
       }
     }
-    ca = fixed_l ? th1 : ca;
-    cr = fixed_l ? th0 : cr;
+    ca = keep ? th1 : ca;
+    cr = keep ? th0 : cr;
     double* cb = s_cand + (vn & 1) * 128;
     cb[lane] = ca;
     cb[64 + lane] = cr;

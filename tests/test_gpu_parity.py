@@ -525,6 +525,35 @@ def test_update_schemes(E, O, scheme, kind_name):
             assert np.all(ro.draws_cks[:, others, i - 1] == ro.samples_cks[:, others, i - 2])
 
 
+@pytest.mark.parametrize("scheme", ["ordered", "random", [5, 1, 3, 2, 4]])
+@pytest.mark.parametrize("chains,n,p", [(2, 1000, 3), (300, 1700, 2), (700, 600, 1), (1000, 2048, 3)])
+def test_update_schemes_on_the_latency_form(E, O, scheme, chains, n, p):
+    """Round 5: the single-parameter schemes of the normal / uniform kernels (R/kernel.R:66-133) on mh_sweep_lat's candidate wave -- one
+    to FOUR chains per workgroup; "random" draws its plan in the kernel (Philox, the call's loop step) and hands it back.  Unbounded and
+    reflective kernel, a fixed parameter, two calls with thinning: the oracle's bits and the oracle's plan."""
+    from fmcmc_amd import _abi as abi
+    X, y = synth_linreg(n, p, 600 + n)
+    k = p + 2
+    if isinstance(scheme, list):
+        scheme = [c for c in scheme if c <= k]
+    init = jitter_init([0.0] * (p + 1) + [float(np.std(y))], chains, 9)
+    steps = 120 if chains < 100 else 40
+    want = "lat%d" % min(4, (chains + 255) // 256)
+    rg, ro = run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, k, init, nsteps=steps, calls=2, burnin=3, thin=2, scale=0.05, scheme=scheme)
+    assert abi.last_kernel() == want, abi.last_kernel()
+    lb = [-9.0] * (k - 1) + [0.5]
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL_REFLECTIVE, k, init, nsteps=steps, scale=0.3, lb=lb, ub=9.0, scheme=scheme)
+    assert abi.last_kernel() == want
+    if not isinstance(scheme, list):
+        fixed = [False, True] + [False] * (k - 2)
+        run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, k, init, nsteps=steps, scale=0.05, fixed=fixed, scheme=scheme)
+        assert abi.last_kernel() == want
+    if scheme == "random":   # a single free parameter at position j: R samples from 1:j
+        fixed = [True] * k; fixed[k - 2] = False
+        run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, k, init, nsteps=steps, scale=0.05, fixed=fixed, scheme=scheme)
+        assert abi.last_kernel() == want
+
+
 def test_update_schemes_with_fixed_parameters(E, O):
     X, y = synth_linreg(900, 3, 5)
     init = jitter_init([0, 0, 0, 0, 4.0], 4, 3)

@@ -9,7 +9,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from fmcmc_amd import engine as E, _abi as abi  # noqa: E402
 
-C = 1024
+C = int(os.environ.get("OA_CHAINS", "1024"))      # (OA_CHAINS / OA_N: the same audit at another size, e.g. the README's: 2 chains, n = 1000)
 rows = []
 
 
@@ -47,7 +47,7 @@ def run(label, gm, k, init, kind, **kw):
 
 
 rng = np.random.default_rng(5)
-n, p = 10000, 3
+n, p = int(os.environ.get("OA_N", "10000")), 3
 X = rng.standard_normal((n, p)); y = 1.0 + X @ np.linspace(1, -1, p) + 4 * rng.standard_normal(n)
 k = p + 2
 init = np.array([0.0] * (p + 1) + [y.std()])[None, :] + 0.05 * rng.standard_normal((C, k)); init[:, -1] = np.abs(init[:, -1])
@@ -55,7 +55,7 @@ gm = E.DeviceModel(abi.FAM_GAUSSIAN_LINREG, X, y)
 big = E.DBL_MAX
 lbs = np.array([-big, -big, -big, -big, 0.001]); ubs = np.full(k, big)
 fx = np.zeros(k, np.uint8); fx[1] = 1
-L = "linreg n=1e4 p=3: "
+L = "linreg n=%g p=3, %d chains: " % (n, C) if (n, C) != (10000, 1024) else "linreg n=1e4 p=3: "
 run(L + "kernel_normal()", gm, k, init, abi.KERNEL_NORMAL)
 run(L + "kernel_normal(fixed = one)", gm, k, init, abi.KERNEL_NORMAL, fixed=fx)
 run(L + "kernel_normal(scheme = 'ordered')", gm, k, init, abi.KERNEL_NORMAL, scheme=abi.SCHEME_ORDERED)
