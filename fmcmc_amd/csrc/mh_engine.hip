@@ -792,17 +792,27 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
   // registers, g table in LDS, the register owners.  The workflow vignette's own model (mcmc::logit: 100 observations, k = 5) ran
   // on the general kernel at 2.6 / 5.9 us per step (kernel_normal / kernel_adapt).  Knob speclogit=0: off.
   bool spec_logit = false;
+  // (a fixed parameter under the normal / uniform kernels: the latency form's candidate wave handles it, the owners of mh_sweep_spec do not)
+  const bool lg_lat_fixed = kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE && kn->kind >= FMCMC_KERNEL_NORMAL && kn->scheme == FMCMC_SCHEME_JOINT &&
+                            kf != kn->k && K.lat != 0 && K.speclogit != 2;
   if (!force && !nopipe && K.speclogit != 0 && K.shard < 0 && m->family == FMCMC_FAM_LOGISTIC && !mirror && m->p >= 1 && m->p <= 7 &&
-      kn->k == m->p + (m->intercept ? 1 : 0) && kf == kn->k && A.kz == kn->k &&
-      (((kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE) && kn->scheme == FMCMC_SCHEME_JOINT) ||
+      kn->k == m->p + (m->intercept ? 1 : 0) && ((kf == kn->k && A.kz == kn->k) || single_lat || (lg_lat_fixed && kf >= 1)) &&
+      (((kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE) && (kn->scheme == FMCMC_SCHEME_JOINT || single_lat)) ||
        (kn->kind == FMCMC_KERNEL_ADAPT && (!adapt_hist || adapt_ring)) || (kn->kind == FMCMC_KERNEL_RAM && !kn->constr && !ram_bounded)) &&
       (unsigned long long)run->nsteps * (unsigned long long)A.kz * 8ull < (1ull << 32) && run->nsteps < (1ll << 30) &&
       (unsigned long long)kn->k * (unsigned long long)A.ldS * 8ull < (1ull << 32)) {
     const long long nsl2 = (((m->n + NT - 1) / NT) + 1) & ~1ll;
+    const long long per_cu = (run->nchains + ncu - 1) / ncu;
+    if ((kn->scheme != FMCMC_SCHEME_JOINT || lg_lat_fixed) && kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE) {
+      // single-parameter schemes: the latency form's candidate wave, one to four chains per workgroup (as for the linear model above)
+      if (per_cu <= 4 && nsl2 <= (lg_lat_fixed ? 12 : fmh::k_spec_optmax(m->p, kn->kind)) && fmh::k_lat_logit(m->p, kn->kind)) {
+        pipe_opt = (int)nsl2; spec_logit = true; lat_normal = true;
+        spec_cw = (K.lat >= 1 && K.lat <= 3) ? K.lat : (int)per_cu;
+      }
+    } else
     if (nsl2 <= fmh::k_spec_optmax(m->p, kn->kind) && fmh::k_spec_logit(m->p, kn->kind)) {
       pipe_opt = (int)nsl2;
       spec_logit = true;
-      const long long per_cu = (run->nchains + ncu - 1) / ncu;
       spec_cw = (K.lat >= 1 && K.lat <= 3) ? K.lat : ((K.lat != 0 && per_cu <= 3) ? (int)per_cu : 4);
       // the normal / uniform kernels with fewer than four chains per CU: the latency form (mh_sweep_lat<.., LOGISTIC>: replicated decision)
       // (measured, tools/bench_small_logit.py and the pair of forms at 256 / 512 / 768 chains: the replicated decision wins up to ~3,000
@@ -965,7 +975,7 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
       } else if (lat_normal) {
         // the latency form of the normal / uniform kernels (mh_lat.hpp): A.spec_cw = 1 .. 3 chains per workgroup
         if (spec_logit) {
-          g_kernel = A.spec_cw == 1 ? "lat-logit1" : A.spec_cw == 2 ? "lat-logit2" : "lat-logit3";
+          g_kernel = A.spec_cw == 1 ? "lat-logit1" : A.spec_cw == 2 ? "lat-logit2" : A.spec_cw == 3 ? "lat-logit3" : "lat-logit4";
           e = launch_k(fmh::k_lat_logit(m->p, kn->kind), (A.nchains + A.spec_cw - 1) / A.spec_cw, NT, fmh::k_lat_logit_lds(), stream, A);
         } else {
         g_kernel = A.spec_cw == 1 ? "lat1" : A.spec_cw == 2 ? "lat2" : A.spec_cw == 3 ? "lat3" : "lat4";

@@ -552,6 +552,23 @@ def test_update_schemes_on_the_latency_form(E, O, scheme, chains, n, p):
         fixed = [True] * k; fixed[k - 2] = False
         run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, k, init, nsteps=steps, scale=0.05, fixed=fixed, scheme=scheme)
         assert abi.last_kernel() == want
+    # the logistic family: the same candidate wave on mh_sweep_lat<.., LOGISTIC>
+    rng = np.random.default_rng(n + p)
+    yl = (rng.uniform(size=n) < 1 / (1 + np.exp(-(0.3 + X @ np.linspace(0.5, -0.5, p))))).astype(np.float64)
+    kl = p + 1
+    if isinstance(scheme, list):
+        scheme = [c for c in scheme if c <= kl]
+    il = jitter_init([0.1] * kl, chains, 4)
+    run_both(E, O, O.FAM_LOGISTIC, X, yl, O.K_NORMAL, kl, il, nsteps=steps, calls=2, burnin=3, thin=2, scale=0.1, prior_div=8.0, scheme=scheme)
+    assert abi.last_kernel() == want.replace("lat", "lat-logit"), abi.last_kernel()
+    run_both(E, O, O.FAM_LOGISTIC, X, yl, O.K_NORMAL_REFLECTIVE, kl, il, nsteps=steps, scale=0.3, lb=-0.7, ub=0.9, scheme=scheme)
+    assert abi.last_kernel() == want.replace("lat", "lat-logit")
+    if not isinstance(scheme, list):   # a fixed parameter, under the scheme and under the joint update
+        fixed = [False, True] + [False] * (kl - 2)
+        run_both(E, O, O.FAM_LOGISTIC, X, yl, O.K_NORMAL, kl, il, nsteps=steps, scale=0.1, prior_div=8.0, fixed=fixed, scheme=scheme)
+        assert abi.last_kernel() == want.replace("lat", "lat-logit")
+        run_both(E, O, O.FAM_LOGISTIC, X, yl, O.K_NORMAL, kl, il, nsteps=steps, scale=0.1, fixed=fixed)
+        assert abi.last_kernel() == want.replace("lat", "lat-logit")
 
 
 def test_update_schemes_with_fixed_parameters(E, O):
