@@ -395,20 +395,21 @@ static SweepArgs chain_window(const SweepArgs& A, long long off, long long cnt, 
 //   t10=0        the sharded slice product's third M-tile as a 16x16x4 tile even where 8 of its rows are padding
 //   shadow=0     logistic, observation-sharded: the normal / uniform kernels on the general kernel's form, not on mh_sweep_logit2
 //   speclogit=0  logistic family: not on the wave-specialised kernel (mh_sweep_spec<.., LOGISTIC>)
+//   specbnd=0    the bounded kernel_ram: not on the wave-specialised kernel (SpecSyncB)
 //   turn=<t>     logit_shard's issue-priority turn (timing only): thousandths of the younger wave's passes it starts from, + 10000: and
 //                stays at, + 100000 x (lead in units of 256 cycles it is regulated towards); turn=0: no turn
 //   mode=<bits>  timing ablations and stamps (SweepArgs.debug)
 // The kernel a call ended up on is reported by fmcmc_last_kernel(); DESIGN.md section 5 has the shape -> kernel table.
 struct Knobs {
   int streamed = -1, cw = -1, pipe = -1, lat = -1, mfma = -1, shard = -1, shard_mfma = -1, wide2 = -1, groups = -1, tiles = -1, t10 = -1, window = -1, mode = 0;
-  int shadow = -1, turn = -1, speclogit = -1;
+  int shadow = -1, turn = -1, speclogit = -1, specbnd = -1;
 };
 static Knobs read_knobs() {
   Knobs K;
   const char* e = getenv("FMCMC_AMD_DEBUG");
   if (!e) return K;
   struct { const char* name; int* dst; } tab[] = {{"streamed", &K.streamed}, {"cw", &K.cw}, {"pipe", &K.pipe}, {"lat", &K.lat},
-      {"mfma", &K.mfma}, {"shard_mfma", &K.shard_mfma}, {"shard", &K.shard}, {"wide2", &K.wide2}, {"groups", &K.groups}, {"tiles", &K.tiles}, {"t10", &K.t10}, {"window", &K.window}, {"mode", &K.mode}, {"shadow", &K.shadow}, {"turn", &K.turn}, {"speclogit", &K.speclogit}};
+      {"mfma", &K.mfma}, {"shard_mfma", &K.shard_mfma}, {"shard", &K.shard}, {"wide2", &K.wide2}, {"groups", &K.groups}, {"tiles", &K.tiles}, {"t10", &K.t10}, {"window", &K.window}, {"mode", &K.mode}, {"shadow", &K.shadow}, {"turn", &K.turn}, {"speclogit", &K.speclogit}, {"specbnd", &K.specbnd}};
   while (*e) {
     const char* eq = strchr(e, '=');
     const char* end = strchr(e, ',');
@@ -689,8 +690,10 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
       const long long nsl = (m->n + NT - 1) / NT, nsl2 = (nsl + 1) & ~1ll;
       const int optmax = (m->p >= 1 && m->p <= 3) ? 20 : (m->p <= 5 ? 10 : (m->p <= 7 ? 8 : 0));
       // (the bounded kernel_ram decides on f of the REFLECTED proposal: a second evaluation in the steps in which the reflection
-      //  moved something -- the barrier-synchronised owners of mh_sweep_mfma_ad ask for it, this kernel's pipelined ones cannot)
-      if (m->p >= 1 && nsl2 <= optmax && (kn->kind == FMCMC_KERNEL_ADAPT || kn->kind == FMCMC_KERNEL_RAM) && !(kn->kind == FMCMC_KERNEL_RAM && ram_bounded)) pipe_opt = (int)nsl2;
+      //  moved something -- the barrier-synchronised owners of mh_sweep_mfma_ad ask for it between barriers, this kernel's register
+      //  owners through a second evaluation slot per step (round 5, SpecSyncB: k <= 8, no fixed parameter; knob specbnd=0: off))
+      const bool bnd_ok = K.specbnd != 0 && kf == kn->k && kn->k <= SPEC_KA && A.kz == kn->k && !kn->constr;
+      if (m->p >= 1 && nsl2 <= optmax && (kn->kind == FMCMC_KERNEL_ADAPT || kn->kind == FMCMC_KERNEL_RAM) && (!(kn->kind == FMCMC_KERNEL_RAM && ram_bounded) || bnd_ok)) pipe_opt = (int)nsl2;
       // (normal / uniform kernels run on the MFMA kernel; knob mfma=0 keeps them here for the two shapes they were tuned at)
       if (m->p == 3 && nsl == 20 && kn->kind < FMCMC_KERNEL_ADAPT && kn->scheme == FMCMC_SCHEME_JOINT) pipe_opt = 20;
       if (m->p == 1 && nsl == 2 && kn->kind < FMCMC_KERNEL_ADAPT && kn->scheme == FMCMC_SCHEME_JOINT) pipe_opt = 2;
@@ -732,7 +735,7 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
         mfma_ext = 1;
       }
     }
-    if (kn->kind == FMCMC_KERNEL_RAM && ram_bounded && !mfma_ad) pipe_opt = 0, mfma_ng = 0;   // (general kernel)
+    if (kn->kind == FMCMC_KERNEL_RAM && ram_bounded && !mfma_ad && !pipe_opt) mfma_ng = 0;   // (general kernel)
     // the mirror kernels (joint scheme, no fixed parameter): their owner between the barriers of the same streamed MFMA evaluation
     if (mirror) {
       const int ng = (m->p <= 3) ? 1 : (m->p <= 7 ? 2 : (m->p <= 11 ? 3 : 4));

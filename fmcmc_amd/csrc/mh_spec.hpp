@@ -351,6 +351,43 @@ struct SpecSync {
   }
   __device__ __forceinline__ void final() const {}
 };
+// The bounded kernel_ram on this kernel (round 5; it ran on the barrier-synchronised MFMA kernel, or -- up to 512 observations -- on
+// the general one: 5.4 us per step at the README's size where the unbounded kernel takes 2.1): evaluations are REQUESTS, numbered per
+// chain -- s_ready[c] = requests published, s_done[c] = 8 x requests served --; a step asks once, and once more when the reflection
+// moved its proposal; the compute waves serve whatever request a chain has next (spec_compute<.., BNDC>) until the owner's final().
+// A step without a reflection costs what the unbounded kernel's costs.
+constexpr unsigned SPEC_FINAL = 0xFFFFFFFFu;
+struct SpecSyncB {
+  static constexpr bool PREP_EARLY = false;
+  unsigned* s_ready; unsigned* s_done; const double* s_tr; int myc;
+  mutable unsigned nreq = 1u;          // (request 1: the initial vector, published by the kernel's set-up)
+  __device__ __forceinline__ double served() const {
+    const int lane = threadIdx.x & 63;
+    while (lds_ld_u32(&s_done[myc]) < 8u * nreq) __builtin_amdgcn_s_sleep(1);
+    const double* src = s_tr + myc * (8 * PIPE_TRS) + lane;
+    const double v0 = src[0 * PIPE_TRS], v1 = src[1 * PIPE_TRS], v2 = src[2 * PIPE_TRS], v3 = src[3 * PIPE_TRS];
+    const double v4 = src[4 * PIPE_TRS], v5 = src[5 * PIPE_TRS], v6 = src[6 * PIPE_TRS], v7 = src[7 * PIPE_TRS];
+    return wave_xor_sum(((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7)));
+  }
+  __device__ __forceinline__ void ask() const {
+    nreq += 1u;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store(&s_ready[myc], nreq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  template <class F> __device__ __forceinline__ double total(int, F&&) const { return served(); }
+  template <class W> __device__ __forceinline__ bool second(bool need, W&& republish, double& tot2) const {
+    if (!need) return false;
+    republish();
+    ask();
+    tot2 = served();
+    return true;
+  }
+  __device__ __forceinline__ void second_idle() const {}
+  __device__ __forceinline__ void publish(int) const { ask(); }
+  __device__ __forceinline__ void final() const {
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store(&s_ready[myc], SPEC_FINAL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+};
 // BND (kernel_ram with bounds, R/kernel_ram.R:123-157 + R/mcmc.R:749-753): the adaptation takes f of the proposal as drawn, the
 // decision f of the REFLECTED proposal -- a second evaluation, needed only in the steps in which a reflection moved something.  The
 // policy decides it for its workgroup: second(need, republish, tot2) -> true when a second evaluation ran (tot2: its total for this
@@ -717,9 +754,10 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
 // The compute role of mh_sweep_spec for OPT (even) observation slots of P covariates per lane: one instantiation per slot count,
 // selected at run time by the kernel (round 4: the kernel used to exist for n in (9728, 10240] at p = 3 and (512, 1024] at p = 1
 // only, every other shape fell to the general kernel).
-template <int P, int OPT>
+template <int P, int OPT, bool BNDC = false>
 __device__ __forceinline__ void spec_compute(const SweepArgs& A, const double* s_y, const double* s_th1, unsigned* s_ready, unsigned* s_done,
-                                             double* s_tr, int ncw, int nsteps, int ic, bool dbg, int wave, int tid, int lane) {
+                                             double* s_tr, int ncw, int nsteps, int ic, bool dbg, int wave, int tid, int lane,
+                                             const unsigned* = nullptr) {
     double xr[OPT][P > 0 ? P : 1];
     double wlast = 1.0, wprev = 1.0;   // validity of this lane's observation in the last two slots (an odd slot count leaves the last one empty)
 #pragma unroll
@@ -734,10 +772,22 @@ __device__ __forceinline__ void spec_compute(const SweepArgs& A, const double* s
     const int tr_slot = (tid & 7) * PIPE_TRS + (tid >> 3);
     const double2* yp = reinterpret_cast<const double2*>(s_y) + tid;
     unsigned long long tw = 0, te = 0;
-    for (int v = 1; v <= nsteps; v++) {
+    // (BNDC, the bounded kernel_ram: numbered requests per chain, SpecSyncB -- a round serves the next request of every live chain)
+    unsigned srv0 = 0u, srv1 = 0u, srv2 = 0u, srv3 = 0u;
+    unsigned live = BNDC ? ((1u << ncw) - 1u) : 0u;
+    for (int v = 1; BNDC ? (live != 0u) : (v <= nsteps); v++) {
       for (int c = 0; c < ncw; c++) {
         unsigned long long t_a = dbg ? clk() : 0;
-        while (lds_ld_u32(&s_ready[c]) < (unsigned)v) __builtin_amdgcn_s_sleep(1);
+        if constexpr (BNDC) {
+          if (!((live >> c) & 1u)) continue;
+          const unsigned mine = c == 0 ? srv0 : (c == 1 ? srv1 : (c == 2 ? srv2 : srv3));
+          unsigned w;
+          while ((w = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_ld_u32(&s_ready[c]))) <= mine) __builtin_amdgcn_s_sleep(1);
+          if (w == SPEC_FINAL) { live &= ~(1u << c); continue; }
+          srv0 += (c == 0) ? 1u : 0u; srv1 += (c == 1) ? 1u : 0u; srv2 += (c == 2) ? 1u : 0u; srv3 += (c == 3) ? 1u : 0u;
+        } else {
+          while (lds_ld_u32(&s_ready[c]) < (unsigned)v) __builtin_amdgcn_s_sleep(1);
+        }
         unsigned long long t_b = dbg ? clk() : 0;
         const double* t0 = s_th1 + c * PIPE_KMAX;
         const double m00 = ic ? t0[0] : 0.0;
@@ -861,6 +911,7 @@ __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
   double* s_y = s_tr + CW * 8 * PIPE_TRS;          // [OPT/2][NT][2] this workgroup's copy of y (logistic: the g table, 16-byte aligned)
   double* s_ad = s_y + (LG ? LG_LDS_DOUBLES + 2 : OPT * NT);   // KIND >= 3: [CW][SPEC_ADS] adaptive per-chain state
   double* const s_tab = LG ? logit_table_align(s_y) : nullptr;
+  const bool s_need = KIND == FMCMC_KERNEL_RAM && !LG && A.ram_bounded;   // the bounded kernel_ram: numbered requests (SpecSyncB)
   // chains of this workgroup: A.spec_cw = 4, or 2 / 1 in the LATENCY form (fewer than 4 x CUs chains per GPU: every chain gets
   // more of a compute unit -- all eight compute waves evaluate the one or two chains there are, and an owner's turn-around
   // is no longer queued behind the evaluation of three other chains; same canonical lanes, same tree, same bits)
@@ -898,6 +949,7 @@ __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
     // =========================== COMPUTE ROLE ===========================
     switch (OPT) {
 #define SPEC_CC(O_) case O_: if constexpr (O_ <= OPTMAX) { if constexpr (LG) spec_compute_logit<P, O_>(A, s_tab, s_th1, s_ready, s_done, s_tr, ncw, nsteps, ic, wave, tid, lane); \
+                                                            else if (KIND == FMCMC_KERNEL_RAM && s_need) { if constexpr (KIND == FMCMC_KERNEL_RAM) spec_compute<P, O_, true>(A, s_y, s_th1, s_ready, s_done, s_tr, ncw, nsteps, ic, dbg, wave, tid, lane); } \
                                                             else spec_compute<P, O_>(A, s_y, s_th1, s_ready, s_done, s_tr, ncw, nsteps, ic, dbg, wave, tid, lane); } break;
       SPEC_CC(2) SPEC_CC(4) SPEC_CC(6) SPEC_CC(8) SPEC_CC(10) SPEC_CC(12) SPEC_CC(14) SPEC_CC(16) SPEC_CC(18) SPEC_CC(20)
 #undef SPEC_CC
@@ -927,6 +979,14 @@ __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
       if (k == P + 1) spec_owner_adaptive_reg<KIND, P + 1, SpecSync, false, FMCMC_FAM_LOGISTIC>(A, myc, cl, s_th1, sync, s_ad + myc * SPEC_ADS);
       else spec_owner_adaptive_reg<KIND, (P > 0 ? P : 1), SpecSync, false, FMCMC_FAM_LOGISTIC>(A, myc, cl, s_th1, sync, s_ad + myc * SPEC_ADS);
       return;
+    }
+    if constexpr (KIND == FMCMC_KERNEL_RAM) {
+      if (s_need) {   // the bounded kernel_ram (the host takes this kernel for k <= 8, no fixed parameter)
+        SpecSyncB syncb{s_ready, s_done, s_tr, myc};
+        if (k == P + 2) spec_owner_adaptive_reg<KIND, P + 2, SpecSyncB, true>(A, myc, cl, s_th1, syncb);
+        else spec_owner_adaptive_reg<KIND, 0, SpecSyncB, true>(A, myc, cl, s_th1, syncb);
+        return;
+      }
     }
     if (k == P + 2 && nofixed && A.kz == k && !(A.debug & 16))        // intercept + P covariates + sigma (C3: k = 5)
       spec_owner_adaptive_reg<KIND, P + 2>(A, myc, cl, s_th1, sync, s_ad + myc * SPEC_ADS);

@@ -1076,9 +1076,41 @@ def test_adaptive_kernels_on_the_streamed_mfma_evaluation(E, O, monkeypatch, n, 
     # REFLECTED proposal -- a second evaluation of the workgroup's four chains in the steps in which a reflection moved one
     rb, ro = run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, k, init, nsteps=70, calls=2, intercept=intercept,
                       lb=[-0.25] * (k - 1) + [0.3], ub=[0.25] * (k - 1) + [float(np.std(y)) + 0.2])
+    assert abi.last_kernel() == unbounded and ro.accept_count.sum() > 0      # (round 5: within mh_sweep_spec's registers, there)
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, k, init, nsteps=40, intercept=intercept, lb=[-50.0] * (k - 1) + [0.001], ub=50.0)   # (never reflects)
+    assert abi.last_kernel() == unbounded
+    set_knob(monkeypatch, "specbnd", "0")
+    rb, ro = run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, k, init, nsteps=70, calls=2, intercept=intercept,
+                      lb=[-0.25] * (k - 1) + [0.3], ub=[0.25] * (k - 1) + [float(np.std(y)) + 0.2])
     assert abi.last_kernel() == "mfma-adaptive" and ro.accept_count.sum() > 0
     run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, k, init, nsteps=40, intercept=intercept, lb=[-50.0] * (k - 1) + [0.001], ub=50.0)   # (never reflects)
     assert abi.last_kernel() == "mfma-adaptive"
+
+
+@pytest.mark.parametrize("chains,n,p,intercept", [(1, 100, 3, True), (5, 100, 3, True), (300, 1000, 2, True), (700, 3000, 3, False),
+                                                  (1001, 777, 5, True), (1030, 100, 6, False), (6, 4000, 7, False)])
+def test_bounded_kernel_ram_on_the_wave_specialised_kernel_and_its_latency_forms(E, O, monkeypatch, chains, n, p, intercept):
+    """Round 5: kernel_ram with bounds (R/kernel_ram.R:123-157 + R/mcmc.R:749-753; the advanced-features vignette's
+    kernel_ram(lb = c(NA, NA, NA, .001))) on mh_sweep_spec's register owners -- two evaluation slots per step, the second one taken only
+    when the reflection moved the proposal (SpecSyncB).  Tight bounds (most steps reflect), the vignette's kind of bound (hardly ever), one
+    to four chains per workgroup, a ragged last workgroup, two calls with burn-in and thinning, step windows: the oracle's bits."""
+    from fmcmc_amd import _abi as abi
+    X, y = synth_linreg(n, p, 7300 + n + p)
+    k = p + 1 + (1 if intercept else 0)
+    init = jitter_init(([0.0] if intercept else []) + [0.0] * p + [float(np.std(y))], chains, 41 + p)
+    init[:, -1] = np.abs(init[:, -1])
+    steps = 90 if chains < 100 else 30
+    want = "spec" if chains > 768 else "spec-lat%d" % ((chains + 255) // 256)
+    tight = dict(lb=[-0.25] * (k - 1) + [0.3], ub=[0.25] * (k - 1) + [float(np.std(y)) + 0.2])
+    init_t = np.clip(init, np.array(tight["lb"]) + 0.01, np.array(tight["ub"]) - 0.01)
+    rg, ro = run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, k, init_t, nsteps=steps, calls=2, burnin=3, thin=2, intercept=intercept, **tight)
+    assert abi.last_kernel() == want, abi.last_kernel()
+    assert ro.accept_count.sum() > 0
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, k, init, nsteps=steps, intercept=intercept, lb=[-50.0] * (k - 1) + [0.001], ub=50.0, freq=2, warmup=3)
+    assert abi.last_kernel() == want
+    set_knob(monkeypatch, "window", "16")
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, k, init_t, nsteps=steps, calls=2, intercept=intercept, **tight)
+    assert abi.last_kernel() == want
 
 
 @pytest.mark.parametrize("n,p,intercept,fix", [(3000, 9, True, False), (10000, 11, True, False), (2049, 12, False, False), (1537, 13, True, True),
