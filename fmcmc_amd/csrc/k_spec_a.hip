@@ -5,8 +5,10 @@
 
 namespace fmh {
 FMH_HIDDEN const void* k_spec_normal(int p, int kind);
+FMH_HIDDEN const void* k_spec_mirror(int p, int kind);
 const void* k_spec(int p, int kind) {
   if (kind == FMCMC_KERNEL_NORMAL || kind == FMCMC_KERNEL_NORMAL_REFLECTIVE) return k_spec_normal(p, kind);
+  if (kind == FMCMC_KERNEL_NMIRROR || kind == FMCMC_KERNEL_UMIRROR) return k_spec_mirror(p, kind);
   if (kind != FMCMC_KERNEL_ADAPT && kind != FMCMC_KERNEL_RAM) return nullptr;
 #define SPEC_AD(PV, OV) ((kind == 3) ? (const void*)mh_sweep_spec<PV, OV, 3> : (const void*)mh_sweep_spec<PV, OV, 4>)
   switch (p) {

@@ -396,20 +396,21 @@ static SweepArgs chain_window(const SweepArgs& A, long long off, long long cnt, 
 //   shadow=0     logistic, observation-sharded: the normal / uniform kernels on the general kernel's form, not on mh_sweep_logit2
 //   speclogit=0  logistic family: not on the wave-specialised kernel (mh_sweep_spec<.., LOGISTIC>)
 //   specbnd=0    the bounded kernel_ram: not on the wave-specialised kernel (SpecSyncB)
+//   specmirror=0 the mirror kernels: not on the wave-specialised kernel
 //   turn=<t>     logit_shard's issue-priority turn (timing only): thousandths of the younger wave's passes it starts from, + 10000: and
 //                stays at, + 100000 x (lead in units of 256 cycles it is regulated towards); turn=0: no turn
 //   mode=<bits>  timing ablations and stamps (SweepArgs.debug)
 // The kernel a call ended up on is reported by fmcmc_last_kernel(); DESIGN.md section 5 has the shape -> kernel table.
 struct Knobs {
   int streamed = -1, cw = -1, pipe = -1, lat = -1, mfma = -1, shard = -1, shard_mfma = -1, wide2 = -1, groups = -1, tiles = -1, t10 = -1, window = -1, mode = 0;
-  int shadow = -1, turn = -1, speclogit = -1, specbnd = -1;
+  int shadow = -1, turn = -1, speclogit = -1, specbnd = -1, specmirror = -1;
 };
 static Knobs read_knobs() {
   Knobs K;
   const char* e = getenv("FMCMC_AMD_DEBUG");
   if (!e) return K;
   struct { const char* name; int* dst; } tab[] = {{"streamed", &K.streamed}, {"cw", &K.cw}, {"pipe", &K.pipe}, {"lat", &K.lat},
-      {"mfma", &K.mfma}, {"shard_mfma", &K.shard_mfma}, {"shard", &K.shard}, {"wide2", &K.wide2}, {"groups", &K.groups}, {"tiles", &K.tiles}, {"t10", &K.t10}, {"window", &K.window}, {"mode", &K.mode}, {"shadow", &K.shadow}, {"turn", &K.turn}, {"speclogit", &K.speclogit}, {"specbnd", &K.specbnd}};
+      {"mfma", &K.mfma}, {"shard_mfma", &K.shard_mfma}, {"shard", &K.shard}, {"wide2", &K.wide2}, {"groups", &K.groups}, {"tiles", &K.tiles}, {"t10", &K.t10}, {"window", &K.window}, {"mode", &K.mode}, {"shadow", &K.shadow}, {"turn", &K.turn}, {"speclogit", &K.speclogit}, {"specbnd", &K.specbnd}, {"specmirror", &K.specmirror}};
   while (*e) {
     const char* eq = strchr(e, '=');
     const char* end = strchr(e, ',');
@@ -741,6 +742,11 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
       const int ng = (m->p <= 3) ? 1 : (m->p <= 7 ? 2 : (m->p <= 11 ? 3 : 4));
       const int nsr = (ng == 1) ? MfmaAdShape<1>::NSR : (ng == 2 ? MfmaAdShape<2>::NSR : MfmaAdShape<3>::NSR);
       pipe_opt = 0; mfma_ng = 0;
+      // (round 5: within mh_sweep_spec's registers their owner runs there -- beside the evaluation instead of between barriers, and in
+      //  the latency forms; up to 512 observations they ran on the general kernel.  Knob specmirror=0: off)
+      const long long nsl2 = (((m->n + NT - 1) / NT) + 1) & ~1ll;
+      if (K.specmirror != 0 && m->p >= 1 && m->p <= 7 && nsl2 <= fmh::k_spec_optmax(m->p, kn->kind) && fmh::k_spec(m->p, kn->kind)) pipe_opt = (int)nsl2;
+      else
       if (m->p <= 15 && m->n > NT && m->n < (1ll << 29)) { mfma_ad = 3; mfma_ng = ng; mfma_ext = (m->n > (long long)NT * nsr) ? nsr : 1; }
     }
     // ---- the LATENCY form (round 5): fewer than four chains per compute unit.  The reference scales a FIXED number of chains
@@ -758,7 +764,7 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
         spec_cw = (K.lat >= 1 && K.lat <= 3) ? K.lat : (int)per_cu;
       }
     } else
-    if (K.lat != 0 && !mirror && (pipe_opt || (mfma_ng && !mfma_ext && !mfma_ad))) {
+    if (K.lat != 0 && (!mirror || pipe_opt) && (pipe_opt || (mfma_ng && !mfma_ext && !mfma_ad))) {
       const long long per_cu = (run->nchains + ncu - 1) / ncu;
       // kernel_adapt / kernel_ram (mh_sweep_spec) gain up to 25 % with one chain per workgroup, 18 % with two, 6 % with three at
       // n = 10,000 and are level at small n -- their step is the owner's dependent chain --: one to three, always.  The normal
@@ -992,7 +998,7 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
           e = launch_k(fmh::k_spec_logit(m->p, kn->kind), sblk, SPEC_NT, fmh::k_spec_logit_lds(kn->kind >= FMCMC_KERNEL_ADAPT ? 1 : 0), stream, A);
         } else {
         g_kernel = A.spec_cw == 1 ? "spec-lat1" : A.spec_cw == 2 ? "spec-lat2" : A.spec_cw == 3 ? "spec-lat3" : "spec";
-        e = launch_k(fmh::k_spec(m->p, kn->kind), sblk, SPEC_NT, spec_lds_bytes(pipe_opt, kn->kind >= FMCMC_KERNEL_ADAPT), stream, A);
+        e = launch_k(fmh::k_spec(m->p, kn->kind), sblk, SPEC_NT, spec_lds_bytes(pipe_opt, kn->kind == FMCMC_KERNEL_ADAPT || kn->kind == FMCMC_KERNEL_RAM), stream, A);
         }
       }
     };   // launch_fast

@@ -751,6 +751,149 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
   if (KIND == FMCMC_KERNEL_ADAPT && A.win_sum && rl) A.win_sum[(long long)cl * kf + lane] = run_sum;
 }
 
+// The mirror kernels' owner (kernel_nmirror / kernel_umirror, R/kernel_mirror.R:66-131, :203-262; twin of the general kernel's
+// mirror branch, mh_streamed.hpp, and of the oracle's propose_mirror): joint scheme, no fixed parameter, lane = parameter with
+// theta, the running mean mu and the scale in registers.  Until round 4 these kernels ran on the all-family kernel only
+// (tools/option_audit.py: 17.8 us per step at C2's shape).
+template <int KIND, class SYNC>
+__device__ __forceinline__ void mfma_owner_mirror(const SweepArgs& A, int myc, int cl, double* s_th1, SYNC& sync) {
+  const int lane = threadIdx.x & 63;
+  const int k = A.k, kz = A.kz;
+  const int nsteps = (int)A.nsteps, burnin = (int)A.burnin, thin = (int)A.thin;
+  const bool rl = lane < k;
+  const int jl = rl ? lane : 0;
+  const double lb_l = A.lb[jl], ub_l = A.ub[jl];
+  double th0 = rl ? A.theta0[(long long)cl * k + lane] : 0.0, th1 = th0;
+  double mmu = rl ? (A.fresh ? A.mu[jl] : A.mirror_mu[(long long)cl * k + jl]) : 0.0;
+  double msc = rl ? (A.fresh ? A.scale[jl] : A.mirror_scale[(long long)cl * k + jl]) : 0.0;
+  double f0 = 0.0, obs_arate = fmh_nan(), th_prev = 0.0;   // (obs_arate: lane = parameter -- R's turns into a k-vector through warm-up; th_prev: ans[i-2, ])
+  long long abs_iter = 0, nzero = 0;
+  if (!A.fresh) { abs_iter = A.abs_iter[cl]; obs_arate = A.obs_arate[(long long)cl * k + jl]; }
+  int nacc = 0, status = FMCMC_CHAIN_OK, thin_ctr = 0;
+  unsigned int bitword = 0;
+  char* const s_base = reinterpret_cast<char*>(A.samples) + ((long long)cl * k) * A.ldS * 8;
+  char* const d_base = A.draws ? reinterpret_cast<char*>(A.draws) + ((long long)cl * k) * A.ldS * 8 : nullptr;
+  char* const l_base = A.logpost ? reinterpret_cast<char*>(A.logpost) + (long long)cl * A.ldS * 8 : nullptr;
+  const unsigned int lane_off = (unsigned int)((long long)jl * A.ldS * 8);
+  unsigned int srow8 = 0;
+  const char* const z_base = reinterpret_cast<const char*>(A.fed_z) + ((long long)cl * nsteps) * kz * 8;
+  const unsigned int z_lane = (unsigned int)(jl) * 8u;
+  const double* const lu_row = A.fed_logu + (long long)cl * nsteps;
+  const double dn = uniform_d((double)A.n);
+  auto ld_z = [&](int row) -> double { return *reinterpret_cast<const double*>(z_base + (z_lane + (unsigned int)row * (unsigned int)(kz * 8))); };
+  double z_nx = (rl && nsteps >= 2) ? ld_z(1) : 0.0;
+  double lu_nx = (nsteps >= 2) ? lu_row[1] : 0.0;
+  auto flush_bits = [&](int i) {
+    if (A.accept_bits && lane == 0) A.accept_bits[(long long)cl * ((nsteps + 31) >> 5) + ((i - 1) >> 5)] = bitword;
+    bitword = 0;
+  };
+  auto logpost_of = [&](double tot, double sigma) -> double {   // Gaussian linreg closed form (as the other owners')
+    double f;
+    if (sigma < 0.0 || fmh_isnan(sigma)) f = fmh_nan();
+    else if (sigma == 0.0) f = -fmh_inf();
+    else {
+      double t1 = fmh_log(sigma) + FMH_K(FMH_LN_SQRT_2PI);
+      double q = (0.5 * tot) / (sigma * sigma);
+      f = -(dn * t1) - q;
+    }
+    if (A.guard && !fmh_isfinite(f)) f = -fmh_inf();
+    return f;
+  };
+  for (int v = 1; v <= nsteps; v++) {
+    const double tot = sync.total(v, []() {});
+    const double f1 = logpost_of(tot, readlane_d(th1, k - 1));
+    bool st_row = false;
+    double st_th0 = 0.0;
+    const double st_dr = th1;
+    if (v == 1) {
+      f0 = f1;
+      if (1 > burnin) { thin_ctr += 1; if (thin_ctr == thin) { thin_ctr = 0; st_row = true; st_th0 = th0; } }
+    } else if (status == FMCMC_CHAIN_OK) {
+      const int i = v;
+      if (fmh_isnan(f1)) status = FMCMC_CHAIN_NAN_LOGPOST;
+      const double ratio = f1 - f0;
+      if (status == FMCMC_CHAIN_OK && fmh_isnan(ratio)) status = FMCMC_CHAIN_NAN_RATIO;
+      if (status != FMCMC_CHAIN_OK) {
+        if (lane == 0) { A.status[cl] = status; A.status_step[cl] = i; }
+        if (rl) A.status_theta[(long long)cl * k + lane] = th1;
+        flush_bits(i);
+      } else {
+        const double lu = lu_nx;
+        lu_nx = lu_row[v < nsteps ? v : nsteps - 1];
+        bool moved = false;
+        th_prev = th0;                          // (row i - 1, the row before the one decided now)
+        if (lu < ratio) {
+          const double d = th1 - th0;           // rowSums(diff(ans)^2) of the row about to be stored: the sequential sum of the oracle
+          double sq = 0.0;
+          for (int a = 0; a < k; a++) { const double da = readlane_d(d, a); sq = sq + da * da; }
+          moved = (sq != 0.0);
+          th0 = th1;
+          f0 = f1;
+          nacc += 1;
+          bitword |= (1u << ((i - 1) & 31));
+        }
+        if (!moved) nzero += 1;
+        if (i > burnin) { thin_ctr += 1; if (thin_ctr == thin) { thin_ctr = 0; st_row = true; st_th0 = th0; } }
+        if (((i - 1) & 31) == 31 || i == nsteps) flush_bits(i);
+      }
+    }
+    // ---- proposal of loop step i = v + 1
+    if (v < nsteps) {
+      if (status == FMCMC_CHAIN_OK) {
+        const int i = v + 1;
+        const double z = z_nx;
+        z_nx = rl ? ld_z(v + 1 < nsteps ? v + 1 : nsteps - 1) : 0.0;
+        if (abs_iter >= 1 && abs_iter <= A.warmup) mmu = (mmu * (double)abs_iter + th0) / ((double)abs_iter + 1);   // mean_recursive(ans[i-1, ], mu, abs_iter)
+        if (abs_iter == A.nadapt) {   // the one-off scale adaptation (the closure reads its argument `nadapt`)
+          obs_arate = 1.0 - (double)nzero / (double)(i - 2);
+          const double num = fmh_tan_0_halfpi(1.5707963267948966 * obs_arate);
+          const double den = fmh_tan_0_halfpi(1.5707963267948966 * A.arate);
+          msc = msc * num / den;
+        } else if (abs_iter > A.nadapt && abs_iter <= A.warmup) {
+          // obs_arate <<- mean_recursive(as.double(ans[i-1, ] != ans[i-2, ]), obs_arate, abs_iter), element-wise (R/kernel_mirror.R:108-118,
+          // :246-253); the first proposal of a call has no ans[i-2, ]: numeric(0) in R, NaN here (twin of the oracle's propose_mirror)
+          obs_arate = (i < 3) ? fmh_nan() : (obs_arate * (double)abs_iter + ((th0 != th_prev) ? 1.0 : 0.0)) / ((double)abs_iter + 1);
+        }
+        double t;
+        if (KIND == FMCMC_KERNEL_NMIRROR) {
+          t = (2.0 * mmu - th0) + msc * z;
+        } else {   // runif(k, 2 mu - theta -+ sqrt3 scale)
+          const double sqrt3 = fmh_sqrt(3.0);
+          const double c = 2.0 * mmu - th0;
+          const double lo = c - sqrt3 * msc, hi = c + sqrt3 * msc;
+          t = lo + (hi - lo) * z;
+        }
+        th1 = reflect1(t, lb_l, ub_l);
+        abs_iter += 1;
+        if (rl) s_th1[myc * PIPE_KMAX + lane] = th1;
+      }
+      sync.publish(v + 1);
+    } else {
+      sync.final();
+    }
+    if (st_row) {
+      if (rl) {
+        *reinterpret_cast<double*>(s_base + (lane_off + srow8)) = st_th0;
+        if (d_base) *reinterpret_cast<double*>(d_base + (lane_off + srow8)) = st_dr;
+      }
+      if (l_base && lane == 0) *reinterpret_cast<double*>(l_base + srow8) = f1;
+      srow8 += 8;
+    }
+  }
+  if (rl) {
+    A.theta0[(long long)cl * k + lane] = th0;
+    A.mirror_mu[(long long)cl * k + lane] = mmu;
+    A.mirror_scale[(long long)cl * k + lane] = msc;
+    A.obs_arate[(long long)cl * k + lane] = obs_arate;
+  }
+  if (lane == 0) {
+    A.f0[cl] = f0;
+    A.accept_count[cl] = nacc;
+    if (status == FMCMC_CHAIN_OK) { A.status[cl] = FMCMC_CHAIN_OK; A.status_step[cl] = 0; }
+    A.abs_iter[cl] = abs_iter;
+  }
+}
+
 // The compute role of mh_sweep_spec for OPT (even) observation slots of P covariates per lane: one instantiation per slot count,
 // selected at run time by the kernel (round 4: the kernel used to exist for n in (9728, 10240] at p = 3 and (512, 1024] at p = 1
 // only, every other shape fell to the general kernel).
@@ -971,6 +1114,11 @@ __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
 #endif
   if (SPEC_OWNER_PRIO > 0) __builtin_amdgcn_s_setprio(SPEC_OWNER_PRIO);
   const int cl = __builtin_amdgcn_readfirstlane((int)cg0 + myc);
+  if constexpr (KIND == FMCMC_KERNEL_NMIRROR || KIND == FMCMC_KERNEL_UMIRROR) {   // (joint scheme, no fixed parameter: the host's conditions)
+    SpecSync sync{s_ready, s_done, s_tr, myc};
+    mfma_owner_mirror<KIND>(A, myc, cl, s_th1, sync);
+    return;
+  }
   if constexpr (KIND == FMCMC_KERNEL_ADAPT || KIND == FMCMC_KERNEL_RAM) {
     bool nofixed = true;
     for (int j = 0; j < k; j++) nofixed = nofixed && (A.fixed[j] == 0);

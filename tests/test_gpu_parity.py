@@ -775,8 +775,36 @@ def test_mirror_kernels_on_the_streamed_mfma_evaluation(E, O, monkeypatch, kind_
     kind = O.K_NMIRROR if kind_name == "nmirror" else O.K_UMIRROR
     rg, ro = run_both(E, O, O.FAM_LINREG, X, y, kind, k, init, nsteps=150, calls=2, mu=base, scale=0.15, warmup=110, nadapt=6,
                       lb=[-30.0] * (k - 1) + [0.05], ub=30.0, intercept=intercept, burnin=3, thin=2)
-    assert abi.last_kernel() == "mfma-adaptive"
+    in_spec = p <= 7 and n <= 512 * (20 if p <= 3 else (10 if p <= 5 else 8))     # (round 5: there their owner runs on mh_sweep_spec)
+    assert abi.last_kernel() == ("spec" if in_spec else "mfma-adaptive")
     assert np.all(np.isfinite(ro.state.obs_arate)) and np.all(ro.state.abs_iter == 298)
+    if in_spec:
+        set_knob(monkeypatch, "specmirror", "0")
+        rg, ro = run_both(E, O, O.FAM_LINREG, X, y, kind, k, init, nsteps=150, calls=2, mu=base, scale=0.15, warmup=110, nadapt=6,
+                          lb=[-30.0] * (k - 1) + [0.05], ub=30.0, intercept=intercept, burnin=3, thin=2)
+        assert abi.last_kernel() == "mfma-adaptive"
+
+
+@pytest.mark.parametrize("kind_name", ["nmirror", "umirror"])
+@pytest.mark.parametrize("chains,n,p,intercept", [(1, 100, 3, True), (2, 1000, 3, True), (300, 100, 4, True), (700, 2500, 1, False),
+                                                  (1001, 512, 7, True), (1030, 4096, 6, False), (5, 10240, 2, True)])
+def test_mirror_kernels_on_the_wave_specialised_kernel_and_its_latency_forms(E, O, kind_name, chains, n, p, intercept):
+    """Round 5: kernel_nmirror / kernel_umirror (R/kernel_mirror.R:66-131, :203-262; joint scheme, no fixed parameter) within
+    mh_sweep_spec's registers -- their owner beside the evaluation on the kernel's LDS sequence words instead of between the barriers of
+    the streamed MFMA evaluation, one to four chains per workgroup (up to 512 observations they ran on the general kernel: 2.7 us per
+    step at the README's size).  Warm-up mean, the one-off tan() rescaling, the running rate, bounds, burn-in and thinning, two calls with
+    the state carried, a ragged last workgroup: the oracle's bits (outputs, mu, scale, obs_arate, abs_iter)."""
+    from fmcmc_amd import _abi as abi
+    X, y = synth_linreg(n, p, 9300 + n + p, beta=np.linspace(0.6, -0.6, p + 1))
+    k = p + 1 + (1 if intercept else 0)
+    base = ([0.5] if intercept else []) + [0.5] * p + [float(np.std(y))]
+    init = jitter_init(base, chains, 8)
+    kind = O.K_NMIRROR if kind_name == "nmirror" else O.K_UMIRROR
+    steps = 150 if chains < 100 else 40
+    rg, ro = run_both(E, O, O.FAM_LINREG, X, y, kind, k, init, nsteps=steps, calls=2, mu=base, scale=0.15, warmup=steps - 40 + 10, nadapt=6,
+                      lb=[-30.0] * (k - 1) + [0.05], ub=30.0, intercept=intercept, burnin=3, thin=2)
+    assert abi.last_kernel() == ("spec" if chains > 768 else "spec-lat%d" % ((chains + 255) // 256)), abi.last_kernel()
+    assert np.all(ro.state.abs_iter == 2 * steps - 2)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
