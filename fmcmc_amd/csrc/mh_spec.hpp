@@ -799,9 +799,32 @@ __device__ __forceinline__ void mfma_owner_mirror(const SweepArgs& A, int myc, i
     if (A.guard && !fmh_isfinite(f)) f = -fmh_inf();
     return f;
   };
+  // What a step needs and the evaluation does not enter, formed while the owner waits for the total (round 5, as the register owner's
+  // prepare()): the sigma-only half of the closed form with the reciprocal of sigma^2 (div_finish: bit for bit the division), and the
+  // reciprocal of abs_iter + 1, the denominator of the two running means of the proposal.
+  double pre_nt1 = 0.0, pre_ss = 1.0, pre_rs = 1.0, pre_den = 1.0, pre_rd = 1.0;
+  bool pre_ok = false;
+  auto prepare = [&]() {
+    const double sigma = readlane_d(th1, k - 1);
+    const unsigned sg_hi = (unsigned)(fmh_d2u(sigma) >> 32);
+    const bool sg_fast = (sg_hi - 0x00100000u) < 0x7fe00000u;            // positive, finite, normal
+    const double sg = sg_fast ? sigma : 1.0;
+    pre_nt1 = dn * (fmh_log(sg) + FMH_K(FMH_LN_SQRT_2PI));
+    pre_ss = sg * sg;
+    pre_ok = sg_fast && mfr_div_safe(pre_ss);
+    pre_rs = div_recip(pre_ok ? pre_ss : 1.0);
+    pre_den = (double)abs_iter + 1;
+    pre_rd = div_recip(pre_den);
+  };
+  auto over_den = [&](double num) -> double {   // num / (abs_iter + 1)
+    if (__all(!rl || mfr_div_safe(num))) return div_finish(num, pre_den, pre_rd);
+    return num / pre_den;
+  };
+  if (!SYNC::PREP_EARLY) prepare();
   for (int v = 1; v <= nsteps; v++) {
-    const double tot = sync.total(v, []() {});
-    const double f1 = logpost_of(tot, readlane_d(th1, k - 1));
+    const double tot = sync.total(v, [&]() { prepare(); });
+    const double hq = 0.5 * tot;
+    const double f1 = (pre_ok && mfr_div_safe(hq)) ? (-pre_nt1 - div_finish(hq, pre_ss, pre_rs)) : logpost_of(tot, readlane_d(th1, k - 1));
     bool st_row = false;
     double st_th0 = 0.0;
     const double st_dr = th1;
@@ -823,10 +846,8 @@ __device__ __forceinline__ void mfma_owner_mirror(const SweepArgs& A, int myc, i
         bool moved = false;
         th_prev = th0;                          // (row i - 1, the row before the one decided now)
         if (lu < ratio) {
-          const double d = th1 - th0;           // rowSums(diff(ans)^2) of the row about to be stored: the sequential sum of the oracle
-          double sq = 0.0;
-          for (int a = 0; a < k; a++) { const double da = readlane_d(d, a); sq = sq + da * da; }
-          moved = (sq != 0.0);
+          const double d = th1 - th0;           // rowSums(diff(ans)^2) != 0 of the row about to be stored: a sum of squares is 0 exactly
+          moved = __any(rl && (d * d != 0.0));  // when every term is (a NaN term makes it NaN: != 0 either way)
           th0 = th1;
           f0 = f1;
           nacc += 1;
@@ -843,7 +864,7 @@ __device__ __forceinline__ void mfma_owner_mirror(const SweepArgs& A, int myc, i
         const int i = v + 1;
         const double z = z_nx;
         z_nx = rl ? ld_z(v + 1 < nsteps ? v + 1 : nsteps - 1) : 0.0;
-        if (abs_iter >= 1 && abs_iter <= A.warmup) mmu = (mmu * (double)abs_iter + th0) / ((double)abs_iter + 1);   // mean_recursive(ans[i-1, ], mu, abs_iter)
+        if (abs_iter >= 1 && abs_iter <= A.warmup) mmu = over_den(mmu * (double)abs_iter + th0);   // mean_recursive(ans[i-1, ], mu, abs_iter)
         if (abs_iter == A.nadapt) {   // the one-off scale adaptation (the closure reads its argument `nadapt`)
           obs_arate = 1.0 - (double)nzero / (double)(i - 2);
           const double num = fmh_tan_0_halfpi(1.5707963267948966 * obs_arate);
@@ -852,7 +873,7 @@ __device__ __forceinline__ void mfma_owner_mirror(const SweepArgs& A, int myc, i
         } else if (abs_iter > A.nadapt && abs_iter <= A.warmup) {
           // obs_arate <<- mean_recursive(as.double(ans[i-1, ] != ans[i-2, ]), obs_arate, abs_iter), element-wise (R/kernel_mirror.R:108-118,
           // :246-253); the first proposal of a call has no ans[i-2, ]: numeric(0) in R, NaN here (twin of the oracle's propose_mirror)
-          obs_arate = (i < 3) ? fmh_nan() : (obs_arate * (double)abs_iter + ((th0 != th_prev) ? 1.0 : 0.0)) / ((double)abs_iter + 1);
+          obs_arate = (i < 3) ? fmh_nan() : over_den(obs_arate * (double)abs_iter + ((th0 != th_prev) ? 1.0 : 0.0));
         }
         double t;
         if (KIND == FMCMC_KERNEL_NMIRROR) {
@@ -879,6 +900,7 @@ __device__ __forceinline__ void mfma_owner_mirror(const SweepArgs& A, int myc, i
       if (l_base && lane == 0) *reinterpret_cast<double*>(l_base + srow8) = f1;
       srow8 += 8;
     }
+    if (!SYNC::PREP_EARLY && v < nsteps) prepare();
   }
   if (rl) {
     A.theta0[(long long)cl * k + lane] = th0;
