@@ -12,6 +12,7 @@ const void* k_spec(int p, int kind) {
   if (kind != FMCMC_KERNEL_ADAPT && kind != FMCMC_KERNEL_RAM) return nullptr;
 #define SPEC_AD(PV, OV) ((kind == 3) ? (const void*)mh_sweep_spec<PV, OV, 3> : (const void*)mh_sweep_spec<PV, OV, 4>)
   switch (p) {
+    case 0: return SPEC_AD(0, 20);   // (no covariate: the iid Normal family)
     case 1: return SPEC_AD(1, 20);
     case 2: return SPEC_AD(2, 20);
     case 3: return SPEC_AD(3, 20);

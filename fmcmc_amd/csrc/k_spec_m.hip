@@ -8,6 +8,7 @@ FMH_HIDDEN const void* k_spec_mirror(int p, int kind) {
   if (kind != FMCMC_KERNEL_NMIRROR && kind != FMCMC_KERNEL_UMIRROR) return nullptr;
 #define SPEC_M(PV, OV) ((kind == FMCMC_KERNEL_NMIRROR) ? (const void*)mh_sweep_spec<PV, OV, FMCMC_KERNEL_NMIRROR> : (const void*)mh_sweep_spec<PV, OV, FMCMC_KERNEL_UMIRROR>)
   switch (p) {
+    case 0: return SPEC_M(0, 20);   // (no covariate: the iid Normal family)
     case 1: return SPEC_M(1, 20);
     case 2: return SPEC_M(2, 20);
     case 3: return SPEC_M(3, 20);

@@ -397,20 +397,21 @@ static SweepArgs chain_window(const SweepArgs& A, long long off, long long cnt, 
 //   speclogit=0  logistic family: not on the wave-specialised kernel (mh_sweep_spec<.., LOGISTIC>)
 //   specbnd=0    the bounded kernel_ram: not on the wave-specialised kernel (SpecSyncB)
 //   specmirror=0 the mirror kernels: not on the wave-specialised kernel
+//   specp0=0     models without a covariate (iid Normal): adaptive / mirror kernels not on the wave-specialised kernel
 //   turn=<t>     logit_shard's issue-priority turn (timing only): thousandths of the younger wave's passes it starts from, + 10000: and
 //                stays at, + 100000 x (lead in units of 256 cycles it is regulated towards); turn=0: no turn
 //   mode=<bits>  timing ablations and stamps (SweepArgs.debug)
 // The kernel a call ended up on is reported by fmcmc_last_kernel(); DESIGN.md section 5 has the shape -> kernel table.
 struct Knobs {
   int streamed = -1, cw = -1, pipe = -1, lat = -1, mfma = -1, shard = -1, shard_mfma = -1, wide2 = -1, groups = -1, tiles = -1, t10 = -1, window = -1, mode = 0;
-  int shadow = -1, turn = -1, speclogit = -1, specbnd = -1, specmirror = -1;
+  int shadow = -1, turn = -1, speclogit = -1, specbnd = -1, specmirror = -1, specp0 = -1;
 };
 static Knobs read_knobs() {
   Knobs K;
   const char* e = getenv("FMCMC_AMD_DEBUG");
   if (!e) return K;
   struct { const char* name; int* dst; } tab[] = {{"streamed", &K.streamed}, {"cw", &K.cw}, {"pipe", &K.pipe}, {"lat", &K.lat},
-      {"mfma", &K.mfma}, {"shard_mfma", &K.shard_mfma}, {"shard", &K.shard}, {"wide2", &K.wide2}, {"groups", &K.groups}, {"tiles", &K.tiles}, {"t10", &K.t10}, {"window", &K.window}, {"mode", &K.mode}, {"shadow", &K.shadow}, {"turn", &K.turn}, {"speclogit", &K.speclogit}, {"specbnd", &K.specbnd}, {"specmirror", &K.specmirror}};
+      {"mfma", &K.mfma}, {"shard_mfma", &K.shard_mfma}, {"shard", &K.shard}, {"wide2", &K.wide2}, {"groups", &K.groups}, {"tiles", &K.tiles}, {"t10", &K.t10}, {"window", &K.window}, {"mode", &K.mode}, {"shadow", &K.shadow}, {"turn", &K.turn}, {"speclogit", &K.speclogit}, {"specbnd", &K.specbnd}, {"specmirror", &K.specmirror}, {"specp0", &K.specp0}};
   while (*e) {
     const char* eq = strchr(e, '=');
     const char* end = strchr(e, ',');
@@ -689,12 +690,13 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
     // its compute loops: any n <= 10240 at p <= 3, n <= 5120 at p = 4, 5, n <= 4096 at p = 6, 7 (OPTMAX P doubles per lane)
     {
       const long long nsl = (m->n + NT - 1) / NT, nsl2 = (nsl + 1) & ~1ll;
-      const int optmax = (m->p >= 1 && m->p <= 3) ? 20 : (m->p <= 5 ? 10 : (m->p <= 7 ? 8 : 0));
+      const int optmax = (m->p >= 0 && m->p <= 3) ? 20 : (m->p <= 5 ? 10 : (m->p <= 7 ? 8 : 0));
       // (the bounded kernel_ram decides on f of the REFLECTED proposal: a second evaluation in the steps in which the reflection
       //  moved something -- the barrier-synchronised owners of mh_sweep_mfma_ad ask for it between barriers, this kernel's register
       //  owners through a second evaluation slot per step (round 5, SpecSyncB: k <= 8, no fixed parameter; knob specbnd=0: off))
       const bool bnd_ok = K.specbnd != 0 && kf == kn->k && kn->k <= SPEC_KA && A.kz == kn->k && !kn->constr;
-      if (m->p >= 1 && nsl2 <= optmax && (kn->kind == FMCMC_KERNEL_ADAPT || kn->kind == FMCMC_KERNEL_RAM) && (!(kn->kind == FMCMC_KERNEL_RAM && ram_bounded) || bnd_ok)) pipe_opt = (int)nsl2;
+      // (round 5: no covariate at all -- the iid Normal family, intercept + sigma -- too: the compute lanes then hold no x)
+      if ((m->p >= 1 || (m->p == 0 && m->intercept && K.specp0 != 0)) && nsl2 <= optmax && (kn->kind == FMCMC_KERNEL_ADAPT || kn->kind == FMCMC_KERNEL_RAM) && (!(kn->kind == FMCMC_KERNEL_RAM && ram_bounded) || bnd_ok)) pipe_opt = (int)nsl2;
       // (normal / uniform kernels run on the MFMA kernel; knob mfma=0 keeps them here for the two shapes they were tuned at)
       if (m->p == 3 && nsl == 20 && kn->kind < FMCMC_KERNEL_ADAPT && kn->scheme == FMCMC_SCHEME_JOINT) pipe_opt = 20;
       if (m->p == 1 && nsl == 2 && kn->kind < FMCMC_KERNEL_ADAPT && kn->scheme == FMCMC_SCHEME_JOINT) pipe_opt = 2;
@@ -745,7 +747,7 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
       // (round 5: within mh_sweep_spec's registers their owner runs there -- beside the evaluation instead of between barriers, and in
       //  the latency forms; up to 512 observations they ran on the general kernel.  Knob specmirror=0: off)
       const long long nsl2 = (((m->n + NT - 1) / NT) + 1) & ~1ll;
-      if (K.specmirror != 0 && m->p >= 1 && m->p <= 7 && nsl2 <= fmh::k_spec_optmax(m->p, kn->kind) && fmh::k_spec(m->p, kn->kind)) pipe_opt = (int)nsl2;
+      if (K.specmirror != 0 && (m->p >= 1 || (m->p == 0 && m->intercept && K.specp0 != 0)) && m->p <= 7 && nsl2 <= fmh::k_spec_optmax(m->p, kn->kind) && fmh::k_spec(m->p, kn->kind)) pipe_opt = (int)nsl2;
       else
       if (m->p <= 15 && m->n > NT && m->n < (1ll << 29)) { mfma_ad = 3; mfma_ng = ng; mfma_ext = (m->n > (long long)NT * nsr) ? nsr : 1; }
     }
@@ -790,8 +792,8 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
       }
       const int lcw = (K.lat >= 1 && K.lat <= 3) ? K.lat : lcw_auto;
       const long long nsl2 = (((m->n + NT - 1) / NT) + 1) & ~1ll;
-      // (the normal kernels' latency form also takes p = 0 -- the iid Normal family --; mh_sweep_spec's compute lanes need a covariate)
-      if (lcw < 4 && (m->p >= 1 || kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE) && nsl2 <= fmh::k_spec_optmax(m->p, kn->kind)) {
+      // (p = 0 -- the iid Normal family -- included: the compute lanes then hold no x)
+      if (lcw < 4 && nsl2 <= fmh::k_spec_optmax(m->p, kn->kind)) {
         if (kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE) { pipe_opt = (int)nsl2; mfma_ng = 0; lat_normal = true; }
         if (pipe_opt && !mfma_ng) spec_cw = lcw;
       }
@@ -807,8 +809,8 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
   if (!force && !nopipe && K.speclogit != 0 && K.shard < 0 && m->family == FMCMC_FAM_LOGISTIC && !mirror && m->p >= 1 && m->p <= 7 &&
       kn->k == m->p + (m->intercept ? 1 : 0) && ((kf == kn->k && A.kz == kn->k) || single_lat || (lg_lat_fixed && kf >= 1)) &&
       (((kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE) && (kn->scheme == FMCMC_SCHEME_JOINT || single_lat)) ||
-       (kn->kind == FMCMC_KERNEL_ADAPT && (!adapt_hist || adapt_ring)) || (kn->kind == FMCMC_KERNEL_RAM && !kn->constr && !ram_bounded)) &&
-      (unsigned long long)run->nsteps * (unsigned long long)A.kz * 8ull < (1ull << 32) && run->nsteps < (1ll << 30) &&
+       (kn->kind == FMCMC_KERNEL_ADAPT && (!adapt_hist || adapt_ring)) || (kn->kind == FMCMC_KERNEL_RAM && !kn->constr && (!ram_bounded || K.specbnd != 0))) &&
+      (unsigned long long)run->nsteps * (unsigned long long)A.kz * 8ull < (1ull << 32) && run->nsteps < (1ll << 28) &&
       (unsigned long long)kn->k * (unsigned long long)A.ldS * 8ull < (1ull << 32)) {
     const long long nsl2 = (((m->n + NT - 1) / NT) + 1) & ~1ll;
     const long long per_cu = (run->nchains + ncu - 1) / ncu;

@@ -398,7 +398,6 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
                                                         double* ring = nullptr /* LDS [SPEC_FREQMAX][PIPE_KMAX]; needed for freq > 1 */) {
   static_assert(!BND || KIND == FMCMC_KERNEL_RAM, "BND is the bounded kernel_ram");
   constexpr bool LG = FAM == FMCMC_FAM_LOGISTIC;
-  static_assert(!(LG && BND), "the logistic family runs the unbounded kernel_ram here");
   constexpr int KA = KX > 0 ? KX : SPEC_KA;
   const int lane = threadIdx.x & 63;
   const int k = KX > 0 ? KX : A.k, kf = k, kz = KX > 0 ? KX : A.kz;
@@ -588,7 +587,21 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
           st_dr = th1r;                               // (the row of draws is the proposal the kernel returns: reflected)
           double tot2 = 0.0;
           const bool again = sync.second(moved, [&]() { if (rl) s_th1[myc * PIPE_KMAX + lane] = th1; }, tot2);
-          if (again && moved) f1 = logpost_of(tot2, readlane_d(th1, k - 1));   // (not moved: the same vector, the same f)
+          if (again && moved) {                       // (not moved: the same vector, the same f)
+            if constexpr (LG) {                       // (the linear part and the prior term of the REFLECTED proposal: prepare()'s chains)
+              double lin = 0.0, ss = 0.0;
+              for (int j = 0; j < nbl; j++) {
+                const double bj = readlane_d(th1, j);
+                lin = fmh_fma(bj, readlane_d(hs_l, j), lin);
+                ss = fmh_fma(bj, bj, ss);
+              }
+              f1 = lin - tot2;
+              if (A.prior_div != 0.0) f1 = f1 - ss / A.prior_div;
+              if (A.guard && !fmh_isfinite(f1)) f1 = -fmh_inf();
+            } else {
+              f1 = logpost_of(tot2, readlane_d(th1, k - 1));
+            }
+          }
         }
       }
       if (fmh_isnan(f1)) status = FMCMC_CHAIN_NAN_LOGPOST;
@@ -999,7 +1012,7 @@ __device__ __forceinline__ void spec_compute(const SweepArgs& A, const double* s
 // general kernel at 2.6 / 5.9 us per step, kernel_normal / kernel_adapt): a lane's OPT observations in VGPRs as above, per observation
 // 64 eta as the fma chain over the scaled coefficients and g(|eta|) off the table in LDS (logit_g_vec: the oracle's fmh_logit_g_scaled),
 // added in slot order; the linear part sum_j b_j hs_j and the prior term never enter a loop (the owners form them).  y is not read.
-template <int P, int OPT>
+template <int P, int OPT, bool BNDC = false>
 __device__ __forceinline__ void spec_compute_logit(const SweepArgs& A, const double* s_tab, const double* s_th1, unsigned* s_ready, unsigned* s_done,
                                                    double* s_tr, int ncw, int nsteps, int ic, int wave, int tid, int lane) {
     double xr[OPT][P > 0 ? P : 1];
@@ -1014,9 +1027,20 @@ __device__ __forceinline__ void spec_compute_logit(const SweepArgs& A, const dou
       if (s == OPT - 2) wprev = valid ? 1.0 : 0.0;
     }
     const int tr_slot = (tid & 7) * PIPE_TRS + (tid >> 3);
-    for (int v = 1; v <= nsteps; v++) {
+    unsigned srv0 = 0u, srv1 = 0u, srv2 = 0u, srv3 = 0u;         // (BNDC, the bounded kernel_ram: numbered requests per chain, as spec_compute)
+    unsigned live = BNDC ? ((1u << ncw) - 1u) : 0u;
+    for (int v = 1; BNDC ? (live != 0u) : (v <= nsteps); v++) {
       for (int c = 0; c < ncw; c++) {
-        while (lds_ld_u32(&s_ready[c]) < (unsigned)v) __builtin_amdgcn_s_sleep(1);
+        if constexpr (BNDC) {
+          if (!((live >> c) & 1u)) continue;
+          const unsigned mine = c == 0 ? srv0 : (c == 1 ? srv1 : (c == 2 ? srv2 : srv3));
+          unsigned w;
+          while ((w = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_ld_u32(&s_ready[c]))) <= mine) __builtin_amdgcn_s_sleep(1);
+          if (w == SPEC_FINAL) { live &= ~(1u << c); continue; }
+          srv0 += (c == 0) ? 1u : 0u; srv1 += (c == 1) ? 1u : 0u; srv2 += (c == 2) ? 1u : 0u; srv3 += (c == 3) ? 1u : 0u;
+        } else {
+          while (lds_ld_u32(&s_ready[c]) < (unsigned)v) __builtin_amdgcn_s_sleep(1);
+        }
         const double* t0 = s_th1 + c * PIPE_KMAX;
         const double m00 = ic ? t0[0] * FMH_LG_SCALE : 0.0;      // (times 64: exact)
         double b0[P > 0 ? P : 1];
@@ -1076,7 +1100,7 @@ __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
   double* s_y = s_tr + CW * 8 * PIPE_TRS;          // [OPT/2][NT][2] this workgroup's copy of y (logistic: the g table, 16-byte aligned)
   double* s_ad = s_y + (LG ? LG_LDS_DOUBLES + 2 : OPT * NT);   // KIND >= 3: [CW][SPEC_ADS] adaptive per-chain state
   double* const s_tab = LG ? logit_table_align(s_y) : nullptr;
-  const bool s_need = KIND == FMCMC_KERNEL_RAM && !LG && A.ram_bounded;   // the bounded kernel_ram: numbered requests (SpecSyncB)
+  const bool s_need = KIND == FMCMC_KERNEL_RAM && A.ram_bounded;   // the bounded kernel_ram: numbered requests (SpecSyncB)
   // chains of this workgroup: A.spec_cw = 4, or 2 / 1 in the LATENCY form (fewer than 4 x CUs chains per GPU: every chain gets
   // more of a compute unit -- all eight compute waves evaluate the one or two chains there are, and an owner's turn-around
   // is no longer queued behind the evaluation of three other chains; same canonical lanes, same tree, same bits)
@@ -1113,7 +1137,8 @@ __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
   if (wave < SPEC_NCW) {
     // =========================== COMPUTE ROLE ===========================
     switch (OPT) {
-#define SPEC_CC(O_) case O_: if constexpr (O_ <= OPTMAX) { if constexpr (LG) spec_compute_logit<P, O_>(A, s_tab, s_th1, s_ready, s_done, s_tr, ncw, nsteps, ic, wave, tid, lane); \
+#define SPEC_CC(O_) case O_: if constexpr (O_ <= OPTMAX) { if constexpr (LG) { if (KIND == FMCMC_KERNEL_RAM && s_need) { if constexpr (KIND == FMCMC_KERNEL_RAM) spec_compute_logit<P, O_, true>(A, s_tab, s_th1, s_ready, s_done, s_tr, ncw, nsteps, ic, wave, tid, lane); } \
+                                                                             else spec_compute_logit<P, O_>(A, s_tab, s_th1, s_ready, s_done, s_tr, ncw, nsteps, ic, wave, tid, lane); } \
                                                             else if (KIND == FMCMC_KERNEL_RAM && s_need) { if constexpr (KIND == FMCMC_KERNEL_RAM) spec_compute<P, O_, true>(A, s_y, s_th1, s_ready, s_done, s_tr, ncw, nsteps, ic, dbg, wave, tid, lane); } \
                                                             else spec_compute<P, O_>(A, s_y, s_th1, s_ready, s_done, s_tr, ncw, nsteps, ic, dbg, wave, tid, lane); } break;
       SPEC_CC(2) SPEC_CC(4) SPEC_CC(6) SPEC_CC(8) SPEC_CC(10) SPEC_CC(12) SPEC_CC(14) SPEC_CC(16) SPEC_CC(18) SPEC_CC(20)
@@ -1146,6 +1171,14 @@ __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
     for (int j = 0; j < k; j++) nofixed = nofixed && (A.fixed[j] == 0);
     SpecSync sync{s_ready, s_done, s_tr, myc};
     if constexpr (LG) {   // (the host takes this kernel for k = P + intercept, no fixed parameter: the register owner)
+      if constexpr (KIND == FMCMC_KERNEL_RAM) {
+        if (s_need) {
+          SpecSyncB syncb{s_ready, s_done, s_tr, myc};
+          if (k == P + 1) spec_owner_adaptive_reg<KIND, P + 1, SpecSyncB, true, FMCMC_FAM_LOGISTIC>(A, myc, cl, s_th1, syncb);
+          else spec_owner_adaptive_reg<KIND, (P > 0 ? P : 1), SpecSyncB, true, FMCMC_FAM_LOGISTIC>(A, myc, cl, s_th1, syncb);
+          return;
+        }
+      }
       if (k == P + 1) spec_owner_adaptive_reg<KIND, P + 1, SpecSync, false, FMCMC_FAM_LOGISTIC>(A, myc, cl, s_th1, sync, s_ad + myc * SPEC_ADS);
       else spec_owner_adaptive_reg<KIND, (P > 0 ? P : 1), SpecSync, false, FMCMC_FAM_LOGISTIC>(A, myc, cl, s_th1, sync, s_ad + myc * SPEC_ADS);
       return;

@@ -243,13 +243,14 @@ def test_iid_normal(E, O):
              guard=False, scale=0.1, lb=0.0, ub=10.0)
 
 
-def test_iid_normal_on_the_linear_model_kernels(E, O):
+def test_iid_normal_on_the_linear_model_kernels(E, O, monkeypatch):
     """FAM_IID_NORMAL is the Gaussian linear model with an intercept and no covariate, in the oracle and in every kernel: since
     round 4 it takes that model's fast paths (normal / uniform kernels on the MFMA kernels, the adaptive ones on the streamed MFMA
-    evaluation from 513 observations on) instead of the all-family kernel."""
+    evaluation from 513 observations on) instead of the all-family kernel; since round 5 the adaptive and the mirror kernels run on the
+    wave-specialised kernel up to 10,240 observations (compute lanes without an x; from one observation on)."""
     from fmcmc_amd import _abi as abi
     rng = np.random.default_rng(12)
-    for n, want_n, want_a in ((700, "mfma", "mfma-adaptive"), (9000, "mfma", "mfma-adaptive"), (20001, "mfma-streamed", "mfma-adaptive")):
+    for n, want_n, want_a in ((60, "mfma", "spec"), (700, "mfma", "spec"), (9000, "mfma", "spec"), (20001, "mfma-streamed", "mfma-adaptive")):
         y = 1.5 + 2.0 * rng.standard_normal(n)
         init = jitter_init([1.0, 2.0], 7, 5)
         init[:, -1] = np.abs(init[:, -1]) + 0.1
@@ -261,6 +262,15 @@ def test_iid_normal_on_the_linear_model_kernels(E, O):
         assert abi.last_kernel() == want_a
         run_both(E, O, O.FAM_IID_NORMAL, None, y, O.K_RAM, 2, init, nsteps=80, calls=2, lb=[-40.0, 0.05], ub=40.0)
         assert abi.last_kernel() == want_a
+        run_both(E, O, O.FAM_IID_NORMAL, None, y, O.K_RAM, 2, init, nsteps=80, burnin=2, thin=3)
+        assert abi.last_kernel() == want_a
+        run_both(E, O, O.FAM_IID_NORMAL, None, y, O.K_NMIRROR, 2, init, nsteps=120, calls=2, mu=[1.0, 2.0], scale=0.15, warmup=90, nadapt=6, lb=[-30.0, 0.05], ub=30.0)
+        assert abi.last_kernel() == want_a
+        if want_a == "spec" and n > 512:     # (knob specp0=0: the round-4 route)
+            set_knob(monkeypatch, "specp0", "0")
+            run_both(E, O, O.FAM_IID_NORMAL, None, y, O.K_ADAPT, 2, init, nsteps=80, calls=2, warmup=10)
+            assert abi.last_kernel() == "mfma-adaptive"
+            set_knob(monkeypatch, "specp0", "1")
 
 
 def test_nan_logpost_is_reported(E, O):
@@ -902,6 +912,9 @@ def test_logistic_on_the_wave_specialised_kernel_and_its_latency_forms(E, O, mon
     assert abi.last_kernel().startswith("spec-logit")
     run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_RAM, k, init, **kw)
     assert abi.last_kernel().startswith("spec-logit")
+    # the bounded kernel_ram: a second evaluation request in the steps in which the reflection moved the proposal (SpecSyncB)
+    rg, ro = run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_RAM, k, np.clip(init, -0.65, 0.85), lb=-0.7, ub=0.9, **kw)
+    assert abi.last_kernel().startswith("spec-logit") and ro.accept_count.sum() > 0
 
 
 @pytest.mark.parametrize("form", ["shadow", "spec"])
