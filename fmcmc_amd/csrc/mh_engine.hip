@@ -997,10 +997,10 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
         const long long sblk = (A.nchains + A.spec_cw - 1) / A.spec_cw;
         if (spec_logit) {
           g_kernel = A.spec_cw == 1 ? "spec-logit-lat1" : A.spec_cw == 2 ? "spec-logit-lat2" : A.spec_cw == 3 ? "spec-logit-lat3" : "spec-logit";
-          e = launch_k(fmh::k_spec_logit(m->p, kn->kind), sblk, SPEC_NT, fmh::k_spec_logit_lds(kn->kind >= FMCMC_KERNEL_ADAPT ? 1 : 0), stream, A);
+          e = launch_k((kn->kind == FMCMC_KERNEL_ADAPT && kn->freq > 1) ? fmh::k_spec_ring(m->p, 1) : fmh::k_spec_logit(m->p, kn->kind), sblk, SPEC_NT, fmh::k_spec_logit_lds(kn->kind >= FMCMC_KERNEL_ADAPT ? 1 : 0), stream, A);
         } else {
         g_kernel = A.spec_cw == 1 ? "spec-lat1" : A.spec_cw == 2 ? "spec-lat2" : A.spec_cw == 3 ? "spec-lat3" : "spec";
-        e = launch_k(fmh::k_spec(m->p, kn->kind), sblk, SPEC_NT, spec_lds_bytes(pipe_opt, kn->kind == FMCMC_KERNEL_ADAPT || kn->kind == FMCMC_KERNEL_RAM), stream, A);
+        e = launch_k((kn->kind == FMCMC_KERNEL_ADAPT && kn->freq > 1 && adapt_ring) ? fmh::k_spec_ring(m->p, 0) : fmh::k_spec(m->p, kn->kind), sblk, SPEC_NT, spec_lds_bytes(pipe_opt, kn->kind == FMCMC_KERNEL_ADAPT || kn->kind == FMCMC_KERNEL_RAM), stream, A);
         }
       }
     };   // launch_fast

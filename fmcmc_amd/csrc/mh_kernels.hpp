@@ -28,6 +28,7 @@ FMH_HIDDEN const void* k_mfma_ext(int kv, int ng, int nsres, int big);
 FMH_HIDDEN const void* k_mfma_ad(int kind, int ng, int kx, int bnd, int shrt);
 // k_spec.hip: mh_sweep_spec<P, OPTMAX, KIND>
 FMH_HIDDEN const void* k_spec(int p, int kind);
+FMH_HIDDEN const void* k_spec_ring(int p, int logistic);   // k_spec_r.hip: kernel_adapt(freq = 2 .. 8)
 FMH_HIDDEN int k_spec_optmax(int p, int kind);
 // k_spec_l*.hip: mh_sweep_spec<P, OPTMAX, KIND, LOGISTIC>: p = 1 .. 7, kind 1 .. 4
 FMH_HIDDEN const void* k_spec_logit(int p, int kind);

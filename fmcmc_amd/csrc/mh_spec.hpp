@@ -393,7 +393,10 @@ struct SpecSyncB {
 // policy decides it for its workgroup: second(need, republish, tot2) -> true when a second evaluation ran (tot2: its total for this
 // chain), second_idle() for an owner that has nothing to ask in this step but must keep in step (MfmaAdSync; SpecSync has neither).
 constexpr int SPEC_FREQMAX = 8;    // kernel_adapt(freq = 2 .. 8, bw = 0) on the register owner: the last `freq` rows of the chain in an LDS ring
-template <int KIND, int KX, class SYNC, bool BND = false, int FAM = FMCMC_FAM_GAUSSIAN_LINREG>
+// RING: kernel_adapt(freq > 1) -- a template parameter because the run-time stride (its modulo, the fold loop, the quotients it cannot
+// prepare) in the one owner cost kernel_adapt(freq = 1) 15 % in the latency form at n = 10,000 (2.20 -> 2.55 us per step, found by the
+// perf guard's record at the end of round 5; `tools/ab_lib.py`)
+template <int KIND, int KX, class SYNC, bool BND = false, int FAM = FMCMC_FAM_GAUSSIAN_LINREG, bool RING = false>
 __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int myc, int cl, double* s_th1, SYNC& sync,
                                                         double* ring = nullptr /* LDS [SPEC_FREQMAX][PIPE_KMAX]; needed for freq > 1 */) {
   static_assert(!BND || KIND == FMCMC_KERNEL_RAM, "BND is the bounded kernel_ram");
@@ -627,7 +630,7 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
     }
     SPEC_ST(2);
     // kernel_adapt(freq > 1): row v of the chain into the ring (rows (i - freq) .. (i - 1) are folded in together at step i)
-    const int afreq = (KIND == FMCMC_KERNEL_ADAPT) ? A.freq : 1;
+    const int afreq = (KIND == FMCMC_KERNEL_ADAPT && RING) ? A.freq : 1;
     if (KIND == FMCMC_KERNEL_ADAPT && afreq > 1 && ring && rl) ring[(v & (SPEC_FREQMAX - 1)) * PIPE_KMAX + lane] = th0;
     // ---- proposal of loop step i = v + 1
     if (v < nsteps) {
@@ -1082,8 +1085,11 @@ __device__ __forceinline__ void spec_compute_logit(const SweepArgs& A, const dou
 // OPTMAX: the most observation slots a compute lane holds (x in VGPRs: OPTMAX P doubles); the launch's (even) slot count
 // A.spec_opt <= OPTMAX selects the compute loop.  FAM: the Gaussian linear model, or (round 5) the logistic one -- the g table in LDS
 // where the linear model keeps y, the closed form sum_j b_j hs_j - total - prior in the owners.
-template <int P, int OPTMAX, int KIND, int FAM = FMCMC_FAM_GAUSSIAN_LINREG>
+// RING: kernel_adapt(freq = 2 .. 8) -- its own kernel (k_spec_r.hip): as one more owner inside the freq = 1 kernel it cost that
+// kernel's owner loop scalar-register spills (kernel_adapt in the latency form at n = 10,000: 2.20 -> 2.33 us per step).
+template <int P, int OPTMAX, int KIND, int FAM = FMCMC_FAM_GAUSSIAN_LINREG, bool RING = false>
 __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
+  static_assert(!RING || KIND == FMCMC_KERNEL_ADAPT, "RING is kernel_adapt(freq > 1)");
   constexpr bool LG = FAM == FMCMC_FAM_LOGISTIC;
   constexpr int CW = 4;
   static_assert(OPTMAX % 2 == 0, "slot counts are even (y is read back in pairs)");
@@ -1179,8 +1185,12 @@ __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
           return;
         }
       }
-      if (k == P + 1) spec_owner_adaptive_reg<KIND, P + 1, SpecSync, false, FMCMC_FAM_LOGISTIC>(A, myc, cl, s_th1, sync, s_ad + myc * SPEC_ADS);
-      else spec_owner_adaptive_reg<KIND, (P > 0 ? P : 1), SpecSync, false, FMCMC_FAM_LOGISTIC>(A, myc, cl, s_th1, sync, s_ad + myc * SPEC_ADS);
+      if constexpr (RING) {   // (the stride: the generic-width owner with the ring of the chain's last rows)
+        spec_owner_adaptive_reg<KIND, 0, SpecSync, false, FMCMC_FAM_LOGISTIC, true>(A, myc, cl, s_th1, sync, s_ad + myc * SPEC_ADS);
+        return;
+      }
+      if (k == P + 1) spec_owner_adaptive_reg<KIND, P + 1, SpecSync, false, FMCMC_FAM_LOGISTIC>(A, myc, cl, s_th1, sync);
+      else spec_owner_adaptive_reg<KIND, (P > 0 ? P : 1), SpecSync, false, FMCMC_FAM_LOGISTIC>(A, myc, cl, s_th1, sync);
       return;
     }
     if constexpr (KIND == FMCMC_KERNEL_RAM) {
@@ -1191,12 +1201,16 @@ __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
         return;
       }
     }
+    if constexpr (RING) {   // (the stride: the generic-width owner with the ring of the chain's last rows; k <= 8, none fixed: the host's conditions)
+      spec_owner_adaptive_reg<KIND, 0, SpecSync, false, FMCMC_FAM_GAUSSIAN_LINREG, true>(A, myc, cl, s_th1, sync, s_ad + myc * SPEC_ADS);
+      return;
+    }
     if (k == P + 2 && nofixed && A.kz == k && !(A.debug & 16))        // intercept + P covariates + sigma (C3: k = 5)
-      spec_owner_adaptive_reg<KIND, P + 2>(A, myc, cl, s_th1, sync, s_ad + myc * SPEC_ADS);
+      spec_owner_adaptive_reg<KIND, P + 2>(A, myc, cl, s_th1, sync);
     else if (k == P + 1 && nofixed && A.kz == k && !(A.debug & 16))   // no intercept
-      spec_owner_adaptive_reg<KIND, P + 1>(A, myc, cl, s_th1, sync, s_ad + myc * SPEC_ADS);
+      spec_owner_adaptive_reg<KIND, P + 1>(A, myc, cl, s_th1, sync);
     else if (k <= SPEC_KA && nofixed && !(A.debug & 16))
-      spec_owner_adaptive_reg<KIND, 0>(A, myc, cl, s_th1, sync, s_ad + myc * SPEC_ADS);
+      spec_owner_adaptive_reg<KIND, 0>(A, myc, cl, s_th1, sync);
     else
       spec_owner_adaptive<KIND>(A, myc, cl, s_th1, s_par, sync, s_ad + myc * SPEC_ADS);
     return;
