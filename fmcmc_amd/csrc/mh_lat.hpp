@@ -37,9 +37,10 @@ constexpr int LAT_LU = LAT_PREP + 2 * 4 * LAT_ROWS;      // [2][LAT_ROWS]     lo
 constexpr int LAT_CAND = LAT_LU + 2 * LAT_ROWS;          // [2][2][64]        next proposal if accepted / if rejected, lane-wise
 constexpr int LAT_PAR = LAT_CAND + 2 * 2 * 64;           // [4][16]           mu, scale, lb, ub
 constexpr int LAT_SINK = LAT_PAR + 64;                   // [64]              where the lanes without a result write
-constexpr int LAT_LDS_DOUBLES = LAT_SINK + 64;
+constexpr int LAT_PLAN = LAT_SINK + 64;                  // [66] ints         single-parameter schemes: a lane's rank among the free parameters, their number, the first
+constexpr int LAT_LDS_DOUBLES = LAT_PLAN + 34;
 
-enum { LAT_GENERIC = 0, LAT_KEEPER = 1, LAT_LOG = 2, LAT_CANDS = 3, LAT_RECIP = 4 };
+enum { LAT_GENERIC = 0, LAT_KEEPER = 1, LAT_LOG = 2, LAT_CANDS = 3, LAT_RECIP = 4, LAT_CANDS_S = 5 /* the candidate wave under a single-parameter scheme */ };
 
 template <int KIND, int P, int OPT, int ROLE, int FAM = FMCMC_FAM_GAUSSIAN_LINREG>
 __device__ __forceinline__ void lat_steps(const SweepArgs& A, double* smem) {
@@ -47,6 +48,7 @@ __device__ __forceinline__ void lat_steps(const SweepArgs& A, double* smem) {
   // g(|eta|) off the table in LDS (behind this kernel's block), added in slot order; y is not read; wave 1's duty is sum_j b_j hs_j and
   // the prior term instead of the logarithm, wave 3 has none; the decision is lin - total - prior.
   constexpr bool LG = FAM == FMCMC_FAM_LOGISTIC;
+  constexpr bool CANDS = ROLE == LAT_CANDS || ROLE == LAT_CANDS_S;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int k = A.k, kz = A.kz, ic = A.intercept;
@@ -113,22 +115,30 @@ __device__ __forceinline__ void lat_steps(const SweepArgs& A, double* smem) {
   double z_nx = 0.0, lu_nx = 0.0;
   // single-parameter schemes (round 5; R/kernel.R:66-133 plan_update_sequence: "ordered", an explicit sequence, "random"): ONE
   // parameter moves per step with the step's one variate -- the lane whose parameter it is takes dz, the others keep theirs.
+  // (what a plan needs -- a lane's rank among the free parameters, their number, the first of them -- waits in LDS: three more values
+  //  carried through the loop cost the JOINT scheme its registers, 7 % in the logistic latency form)
   const int scheme = A.scheme;
-  int zrank = 0, kfree = 0, first_free = 0;             // rank of this lane's parameter among the free ones; their number; the first of them
-  if constexpr (ROLE == LAT_CANDS) {
+  int* const s_plan = reinterpret_cast<int*>(smem + LAT_PLAN);
+  if constexpr (CANDS) {
+    int zrank = 0, kfree = 0, first_free = 0;
     for (int j = k - 1; j >= 0; j--) { const int fr = A.fixed[j] ? 0 : 1; kfree += fr; if (j < jl) zrank += fr; if (fr) first_free = j; }
+    s_plan[lane] = zrank;
+    if (lane == 0) { s_plan[64] = kfree; s_plan[65] = first_free; }
     int zidx = zrank;
     if (zidx > kz - 1) zidx = kz > 0 ? kz - 1 : 0;   // lanes without a variate of their own read a valid neighbour (value unused)
     z_lane = A.fed_z + (cl * nsteps) * kz + zidx;
     lu_row = A.fed_logu + cl * nsteps;
     fixed_l = A.fixed[jl] != 0;
   }
-  auto candidates = [&](int vn) {    // candidates of version vn + 1 and the log-uniform of decision vn -> buffer vn & 1
-    const double dz = s_par[0 * 16 + jj] + s_par[1 * 16 + jj] * z_nx;
-    double ca = th1 + dz, cr = th0 + dz;
+  // (the plan of a step -- which lane moves -- is formed at the TOP of the step, outside the basic block in which candidates() rides
+  //  beside the first chain's evaluation: its branches inside that block cost the joint scheme 6 % in the logistic latency form)
+  bool keep_plan = false;
+  auto plan = [&](int vn) {
     bool keep = fixed_l;                                // this lane's parameter does not move in this step
-    if (scheme != FMCMC_SCHEME_JOINT) {
+    if constexpr (ROLE == LAT_CANDS_S) {
       const long long ic = (long long)vn + 1 + A.step_off;            // the CALL's loop step of the proposal
+      const int zrank = s_plan[lane];
+      const int kfree = __builtin_amdgcn_readfirstlane(s_plan[64]), first_free = __builtin_amdgcn_readfirstlane(s_plan[65]);
       bool upd;
       if (scheme == FMCMC_SCHEME_ORDERED) {
         upd = !fixed_l && zrank == (int)((ic - 1) % kfree);
@@ -142,6 +152,12 @@ __device__ __forceinline__ void lat_steps(const SweepArgs& A, double* smem) {
       }
       keep = !upd;
     }
+    keep_plan = keep;
+  };
+  auto candidates = [&](int vn) {    // candidates of version vn + 1 and the log-uniform of decision vn -> buffer vn & 1
+    const double dz = s_par[0 * 16 + jj] + s_par[1 * 16 + jj] * z_nx;
+    double ca = th1 + dz, cr = th0 + dz;
+    const bool keep = (ROLE == LAT_CANDS_S) ? keep_plan : fixed_l;
     if (KIND == FMCMC_KERNEL_NORMAL_REFLECTIVE) {
       if (act && !keep) {
         const double lb_l = s_par[2 * 16 + jj], ub_l = s_par[3 * 16 + jj];
@@ -191,7 +207,7 @@ __device__ __forceinline__ void lat_steps(const SweepArgs& A, double* smem) {
           double* dst = (jj == 0) ? s_prep + (vn & 1) * 16 + 0 * LAT_ROWS + row : (jj == 2 ? s_prep + (vn & 1) * 16 + 2 * LAT_ROWS + row : s_sink + lane);
           *dst = v;
         }
-      } else if constexpr (ROLE == LAT_CANDS) {
+      } else if constexpr (CANDS) {
         if (g == 0 && vn >= 2) candidates(vn);
       }
       return;
@@ -228,7 +244,7 @@ __device__ __forceinline__ void lat_steps(const SweepArgs& A, double* smem) {
         double* dst = (jj == 2 || jj == 3) ? s_prep + (vn & 1) * 16 + jj * LAT_ROWS + row : s_sink + lane;
         *dst = v;
       }
-    } else if constexpr (ROLE == LAT_CANDS) {
+    } else if constexpr (CANDS) {
       if (g == 0 && vn >= 2) candidates(vn);   // (version 1's come from the prologue; behind the last step they go nowhere)
     }
   };
@@ -312,16 +328,18 @@ __device__ __forceinline__ void lat_steps(const SweepArgs& A, double* smem) {
   auto no_stage = [](int) {};
 
   // ---- prologue: what barrier 1 hands over
-  if constexpr (ROLE == LAT_CANDS) {
+  if constexpr (CANDS) {
     z_nx = z_lane[(long long)(nsteps >= 2 ? 1 : 0) * kz];   // row 1: the variates of loop step 2
     lu_nx = lu_row[nsteps >= 2 ? 1 : 0];
     // (version 1 decides nothing: both candidates of version 2 are theta0 + dz; the refills inside fetch lu_row[1] -- the
     //  log-uniform of decision 2 -- and row 2)
+    if constexpr (ROLE == LAT_CANDS_S) plan(1);
     candidates(1);
   }
 
   for (int v = 1; v <= nsteps; v++) {
     const int par = v & 1;
+    if constexpr (ROLE == LAT_CANDS_S) plan(v);
     // ================= evaluation of version v of every chain, levels 1..32 of the tree =================
     // (the logarithm / the reciprocal of theta1's sigma ride in the same basic block as the first chain's evaluation)
     // (the tree of chain c - 1 runs in the same basic block as the evaluation of chain c: its six dependent levels hide
@@ -434,7 +452,10 @@ __device__ __forceinline__ void lat_roles(const SweepArgs& A, double* smem) {
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (wave == 0) lat_steps<KIND, P, OPT, LAT_KEEPER, FAM>(A, smem);
   else if (wave == 1) lat_steps<KIND, P, OPT, LAT_LOG, FAM>(A, smem);
-  else if (wave == 2) lat_steps<KIND, P, OPT, LAT_CANDS, FAM>(A, smem);
+  else if (wave == 2) {   // (the scheme's plan in a loop of its own: inside the joint scheme's it cost that scheme registers -- 7 % of a step)
+    if (A.scheme != FMCMC_SCHEME_JOINT) lat_steps<KIND, P, OPT, LAT_CANDS_S, FAM>(A, smem);
+    else lat_steps<KIND, P, OPT, LAT_CANDS, FAM>(A, smem);
+  }
   else if (wave == 3 && FAM != FMCMC_FAM_LOGISTIC) lat_steps<KIND, P, OPT, LAT_RECIP, FAM>(A, smem);
   else lat_steps<KIND, P, OPT, LAT_GENERIC, FAM>(A, smem);
 }
