@@ -694,7 +694,7 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
       // (the bounded kernel_ram decides on f of the REFLECTED proposal: a second evaluation in the steps in which the reflection
       //  moved something -- the barrier-synchronised owners of mh_sweep_mfma_ad ask for it between barriers, this kernel's register
       //  owners through a second evaluation slot per step (round 5, SpecSyncB: k <= 8, no fixed parameter; knob specbnd=0: off))
-      const bool bnd_ok = K.specbnd != 0 && kf == kn->k && kn->k <= SPEC_KA && A.kz == kn->k && !kn->constr;
+      const bool bnd_ok = K.specbnd != 0 && kf == kn->k && (kn->k <= SPEC_KA || (kn->k == 9 && m->p == 7)) && A.kz == kn->k && !kn->constr;   // (k = 9: the compile-time owner of p = 7)
       // (round 5: no covariate at all -- the iid Normal family, intercept + sigma -- too: the compute lanes then hold no x)
       if ((m->p >= 1 || (m->p == 0 && m->intercept && K.specp0 != 0)) && nsl2 <= optmax && (kn->kind == FMCMC_KERNEL_ADAPT || kn->kind == FMCMC_KERNEL_RAM) && (!(kn->kind == FMCMC_KERNEL_RAM && ram_bounded) || bnd_ok)) pipe_opt = (int)nsl2;
       // (normal / uniform kernels run on the MFMA kernel; knob mfma=0 keeps them here for the two shapes they were tuned at)

@@ -1129,7 +1129,7 @@ def test_adaptive_kernels_on_the_streamed_mfma_evaluation(E, O, monkeypatch, n, 
 
 
 @pytest.mark.parametrize("chains,n,p,intercept", [(1, 100, 3, True), (5, 100, 3, True), (300, 1000, 2, True), (700, 3000, 3, False),
-                                                  (1001, 777, 5, True), (1030, 100, 6, False), (6, 4000, 7, False)])
+                                                  (1001, 777, 5, True), (1030, 100, 6, False), (6, 4000, 7, False), (260, 3500, 7, True)])
 def test_bounded_kernel_ram_on_the_wave_specialised_kernel_and_its_latency_forms(E, O, monkeypatch, chains, n, p, intercept):
     """Round 5: kernel_ram with bounds (R/kernel_ram.R:123-157 + R/mcmc.R:749-753; the advanced-features vignette's
     kernel_ram(lb = c(NA, NA, NA, .001))) on mh_sweep_spec's register owners -- two evaluation slots per step, the second one taken only
