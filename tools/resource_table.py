@@ -24,8 +24,8 @@ FIELDS = {"TotalSGPRs": "sgprs", "VGPRs": "vgprs", "AGPRs": "agprs", "ScratchSiz
 # the kernels the four GPU configs of BASELINE.md section 4 run on (bench.py fails if the dispatcher picks another one)
 PRODUCT = [("C2 headline", r"mh_sweep_mfma<1, 1, 20, false, false, false>"),
            ("C2 shape, 256 chains or fewer per GPU (latency form)", r"mh_sweep_lat<1, 3, 20>"), ("C2 shape, > 4 GiB of samples", r"mh_sweep_mfma<1, 1, 20, false, true, false>"),
-           ("C3", r"mh_sweep_spec<3, 20, 3>"),
-           ("C3' kernel_ram k=5", r"mh_sweep_spec<3, 20, 4>"), ("C4", r"mh_sweep_wide2<4, 3>"),
+           ("C3", r"mh_sweep_spec<3, 20, 3, 1, false>"),
+           ("C3' kernel_ram k=5", r"mh_sweep_spec<3, 20, 4, 1, false>"), ("C4", r"mh_sweep_wide2<4, 3>"),
            
            ("C5 (observation-sharded, owners in the hand-overs' shadow)", r"mh_sweep_logit2<2>"),
            ("C5 shape on the general kernel's observation-sharded form (stream-fed: knob shadow=0, kernel_adapt / kernel_ram)", r"mh_sweep_kernel<4, -1, 2, 2, 2, 1, true>"),
