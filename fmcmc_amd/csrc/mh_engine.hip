@@ -397,6 +397,7 @@ static SweepArgs chain_window(const SweepArgs& A, long long off, long long cnt, 
 //   speclogit=0  logistic family: not on the wave-specialised kernel (mh_sweep_spec<.., LOGISTIC>)
 //   specbnd=0    the bounded kernel_ram: not on the wave-specialised kernel (SpecSyncB)
 //   specmirror=0 the mirror kernels: not on the wave-specialised kernel
+//   tinymfma=0   the streamed MFMA forms (8 .. 15 covariates, mirror / adaptive kernels) only from 513 observations on
 //   specp0=0     models without a covariate (iid Normal): adaptive / mirror kernels not on the wave-specialised kernel
 //   turn=<t>     logit_shard's issue-priority turn (timing only): thousandths of the younger wave's passes it starts from, + 10000: and
 //                stays at, + 100000 x (lead in units of 256 cycles it is regulated towards); turn=0: no turn
@@ -404,14 +405,14 @@ static SweepArgs chain_window(const SweepArgs& A, long long off, long long cnt, 
 // The kernel a call ended up on is reported by fmcmc_last_kernel(); DESIGN.md section 5 has the shape -> kernel table.
 struct Knobs {
   int streamed = -1, cw = -1, pipe = -1, lat = -1, mfma = -1, shard = -1, shard_mfma = -1, wide2 = -1, groups = -1, tiles = -1, t10 = -1, window = -1, mode = 0;
-  int shadow = -1, turn = -1, speclogit = -1, specbnd = -1, specmirror = -1, specp0 = -1;
+  int shadow = -1, turn = -1, speclogit = -1, specbnd = -1, specmirror = -1, specp0 = -1, tinymfma = -1;
 };
 static Knobs read_knobs() {
   Knobs K;
   const char* e = getenv("FMCMC_AMD_DEBUG");
   if (!e) return K;
   struct { const char* name; int* dst; } tab[] = {{"streamed", &K.streamed}, {"cw", &K.cw}, {"pipe", &K.pipe}, {"lat", &K.lat},
-      {"mfma", &K.mfma}, {"shard_mfma", &K.shard_mfma}, {"shard", &K.shard}, {"wide2", &K.wide2}, {"groups", &K.groups}, {"tiles", &K.tiles}, {"t10", &K.t10}, {"window", &K.window}, {"mode", &K.mode}, {"shadow", &K.shadow}, {"turn", &K.turn}, {"speclogit", &K.speclogit}, {"specbnd", &K.specbnd}, {"specmirror", &K.specmirror}, {"specp0", &K.specp0}};
+      {"mfma", &K.mfma}, {"shard_mfma", &K.shard_mfma}, {"shard", &K.shard}, {"wide2", &K.wide2}, {"groups", &K.groups}, {"tiles", &K.tiles}, {"t10", &K.t10}, {"window", &K.window}, {"mode", &K.mode}, {"shadow", &K.shadow}, {"turn", &K.turn}, {"speclogit", &K.speclogit}, {"specbnd", &K.specbnd}, {"specmirror", &K.specmirror}, {"specp0", &K.specp0}, {"tinymfma", &K.tinymfma}};
   while (*e) {
     const char* eq = strchr(e, '=');
     const char* end = strchr(e, ',');
@@ -701,6 +702,9 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
       if (m->p == 3 && nsl == 20 && kn->kind < FMCMC_KERNEL_ADAPT && kn->scheme == FMCMC_SCHEME_JOINT) pipe_opt = 20;
       if (m->p == 1 && nsl == 2 && kn->kind < FMCMC_KERNEL_ADAPT && kn->scheme == FMCMC_SCHEME_JOINT) pipe_opt = 2;
     }
+    // (round 5: the streamed forms from ONE observation on -- up to 512 the one resident slot is the last, nothing is streamed; models with
+    //  8 .. 15 covariates on small data ran on the general kernel, 2.4 - 5 / 9 - 26 us per step.  Knob tinymfma=0: from 513 on, as before)
+    const long long nt_min = (K.tinymfma != 0) ? 0 : (long long)NT;
     // fp64-MFMA evaluation: general in n and p up to what 80 operand registers per lane hold (normal / uniform kernels)
     if (K.mfma != 0 && kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE && kn->scheme == FMCMC_SCHEME_JOINT) {
       if (m->p <= 3 && m->n <= (long long)NT * 20) mfma_ng = 1;
@@ -711,8 +715,8 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
       // 8 .. 15 covariates (k <= 16): three / four operand groups per observation slot, four / two slots resident (one for short
       // data), the rest streamed -- tools/dispatch_audit.py found these models on the general kernel at 0.10 of the fp64 peak where
       // p = 7 runs at 0.44
-      else if (m->p <= 11 && m->n > NT && m->n < (1ll << 29)) { mfma_ng = 3; mfma_ext = (m->n > (long long)NT * 4) ? 4 : 1; }
-      else if (m->p <= 15 && m->n > NT && m->n < (1ll << 29)) { mfma_ng = 4; mfma_ext = (m->n > (long long)NT * 2) ? 2 : 1; }
+      else if (m->p <= 11 && m->n > nt_min && m->n < (1ll << 29)) { mfma_ng = 3; mfma_ext = (m->n > (long long)NT * 4) ? 4 : 1; }
+      else if (m->p <= 15 && m->n > nt_min && m->n < (1ll << 29)) { mfma_ng = 4; mfma_ext = (m->n > (long long)NT * 2) ? 2 : 1; }
       // (the wave-specialised VALU kernel, which overlaps owners and evaluation, used to win at its small shape
       //  (p = 1, n ~ 1000); since the instruction diet of the owner phase the MFMA kernel is 1.2-1.35x ahead there too:
       //  tools/bench_small.py.  Knob mfma=0 still selects it.)
@@ -730,7 +734,7 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
         mfma_ad = reg_owner ? 1 : 2;
         mfma_ng = ng;
         mfma_ext = nsr;
-      } else if (m->n > NT && ((reg_owner && ((kn->kind == FMCMC_KERNEL_RAM && ram_bounded) || m->p == 0)) || (!reg_owner && !(kn->kind == FMCMC_KERNEL_RAM && ram_bounded) && run->nchains <= 2048 /* (beyond: level with the general kernel at eight chains per workgroup) */))) {
+      } else if (m->n > nt_min && ((reg_owner && ((kn->kind == FMCMC_KERNEL_RAM && ram_bounded) || m->p == 0)) || (!reg_owner && !(kn->kind == FMCMC_KERNEL_RAM && ram_bounded) && run->nchains <= 2048 /* (beyond: level with the general kernel at eight chains per workgroup) */))) {
         // short data (one slot resident, the rest streamed) for what the wave-specialised kernel does not take: the bounded
         // kernel_ram, 8 .. 15 covariates, no covariate at all (iid Normal)
         mfma_ad = reg_owner ? 1 : 2;
@@ -749,7 +753,7 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
       const long long nsl2 = (((m->n + NT - 1) / NT) + 1) & ~1ll;
       if (K.specmirror != 0 && (m->p >= 1 || (m->p == 0 && m->intercept && K.specp0 != 0)) && m->p <= 7 && nsl2 <= fmh::k_spec_optmax(m->p, kn->kind) && fmh::k_spec(m->p, kn->kind)) pipe_opt = (int)nsl2;
       else
-      if (m->p <= 15 && m->n > NT && m->n < (1ll << 29)) { mfma_ad = 3; mfma_ng = ng; mfma_ext = (m->n > (long long)NT * nsr) ? nsr : 1; }
+      if (m->p <= 15 && m->n > nt_min && m->n < (1ll << 29)) { mfma_ad = 3; mfma_ng = ng; mfma_ext = (m->n > (long long)NT * nsr) ? nsr : 1; }
     }
     // ---- the LATENCY form (round 5): fewer than four chains per compute unit.  The reference scales a FIXED number of chains
     // over its workers (R/mcmc.R:536-641), and a sharded call leaves every GPU nchains / G of them: with four chains per
@@ -905,6 +909,9 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
     const int ns_all = (int)((m->n + NT - 1) / NT), next = ns_all - mfma_ext;
     double* mfs = nullptr;
     const size_t nd = (size_t)NW * next * mfma_ng * 64 * 4;
+    if (next <= 0) {              // (everything resident: no stream)
+      A.mf_stream = nullptr; A.mf_next = 0;
+    } else
     if (hipMallocAsync((void**)&mfs, sizeof(double) * nd, stream) != hipSuccess) {
       (void)hipGetLastError();
       mfma_ng = 0; mfma_ext = 0; mfma_ad = 0; pipe_opt = 0; lat_normal = false;

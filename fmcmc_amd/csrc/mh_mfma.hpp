@@ -207,10 +207,12 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
       const mf_d4* sp = reinterpret_cast<const mf_d4*>(A.mf_stream) + ((long long)wave * next * NG) * 64 + lane;
       mf_d4 ring[EXT ? RD : 1][NG];
       if constexpr (EXT) {
+        if (next > 0) {   // (round 5: next == 0 -- up to 512 observations at 8 .. 15 covariates -- streams nothing: the resident slot is the last)
 #pragma unroll
-        for (int r = 0; r < RD; r++)
+          for (int r = 0; r < RD; r++)
 #pragma unroll
-          for (int q = 0; q < NG; q++) ring[r][q] = sp[(((r < next) ? r : next - 1) * NG + q) * 64];
+            for (int q = 0; q < NG; q++) ring[r][q] = sp[(((r < next) ? r : next - 1) * NG + q) * 64];
+        }
       }
       // batches of MB independent MFMA chains followed by their MB dependent FMAs: the result latency of one MFMA is
       // covered by issuing the next ones, and the batch shape (not the allocator's leftovers) bounds the live results
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
           for (int u = 0; u < MB; u++)
             if (u < nu) {
               const int t = t0 + u;
-              const double cm = (!EXT && t >= LAST) ? (((vbits >> (t - LAST)) & 1u) ? cop : 0.0) : cop;
+              const double cm = ((!EXT || next == 0) && t >= LAST) ? (((vbits >> (t - LAST)) & 1u) ? cop : 0.0) : cop;
               d[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(areg[0][t], bop[0], cm, 0, 0, 0);
             }
 #pragma unroll

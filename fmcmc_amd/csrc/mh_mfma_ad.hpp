@@ -132,15 +132,20 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma_ad(const SweepArgs A) {
     const double cop = ic ? tj[0] : 0.0;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     mf_d4 ring[RD][NG];                          // the first streamed slots are requested before the resident ones run
+    if (next > 0) {   // (round 5: next == 0 -- up to 512 observations -- streams nothing: the one resident slot is the last, with its padding)
 #pragma unroll
-    for (int r = 0; r < RD; r++)
+      for (int r = 0; r < RD; r++)
 #pragma unroll
-      for (int q = 0; q < NG; q++) ring[r][q] = sp[(((r < next) ? r : next - 1) * NG + q) * 64];
+        for (int q = 0; q < NG; q++) ring[r][q] = sp[(((r < next) ? r : next - 1) * NG + q) * 64];
+    }
+    double cml[4];                               // C operands of the LAST slot: 0 where it is padding (-r == 0 exactly)
+#pragma unroll
+    for (int g = 0; g < 4; g++) cml[g] = ((vbits >> g) & 1u) ? cop : 0.0;
 #pragma unroll
     for (int t0 = 0; t0 < TN; t0 += MB) {
       double d[MB];
 #pragma unroll
-      for (int u = 0; u < MB; u++) d[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(areg[0][t0 + u], bop[0], cop, 0, 0, 0);
+      for (int u = 0; u < MB; u++) d[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(areg[0][t0 + u], bop[0], (next == 0 && t0 + u >= TN - 4) ? cml[(t0 + u) & 3] : cop, 0, 0, 0);
 #pragma unroll
       for (int q = 1; q < NG; q++)
 #pragma unroll
@@ -148,9 +153,6 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma_ad(const SweepArgs A) {
 #pragma unroll
       for (int u = 0; u < MB; u++) acc[u & 3] = fmh_fma(d[u], d[u], acc[u & 3]);
     }
-    double cml[4];                               // C operands of the LAST slot: 0 where it is padding (-r == 0 exactly)
-#pragma unroll
-    for (int g = 0; g < 4; g++) cml[g] = ((vbits >> g) & 1u) ? cop : 0.0;
     for (int e0 = 0; e0 < next; e0 += RD) {
 #pragma unroll
       for (int r = 0; r < RD; r++) {

@@ -1097,6 +1097,37 @@ def test_mfma_kernel_with_eight_to_fifteen_covariates(E, O, monkeypatch, n, p, i
     assert abi.last_kernel() == "mfma-streamed"
 
 
+@pytest.mark.parametrize("n,p,intercept", [(1, 8, True), (17, 9, False), (60, 12, True), (200, 10, True), (300, 15, False), (511, 13, True), (512, 8, True)])
+def test_eight_to_fifteen_covariates_on_small_data(E, O, monkeypatch, n, p, intercept):
+    """Round 5: 8 <= p <= 15 with up to 512 observations (a regression with ten covariates on two hundred observations) ran on the general
+    kernel: 2.4 - 5 us per step under the normal kernels, 9 - 26 under kernel_adapt, where p = 7 takes 0.7 / 2.4.  The streamed MFMA forms
+    (mh_sweep_mfma<.., EXT>, mh_sweep_mfma_ad) with nothing streamed: their one resident slot is the last, with its padding.  Every proposal
+    kernel, n = 1 .. 512, with and without intercept, two calls: the oracle's bits; knob tinymfma=0: the old route."""
+    from fmcmc_amd import _abi as abi
+    X, y = synth_linreg(n, p, 8300 + n + p, beta=np.linspace(0.8, -0.8, p + 1))
+    k = p + 1 + (1 if intercept else 0)
+    sd = float(np.std(y)) if n > 1 else 1.0
+    init = jitter_init(([0.0] if intercept else []) + [0.0] * p + [sd + 0.5], 6, 96 + p)
+    init[:, -1] = np.abs(init[:, -1])
+    kw = dict(intercept=intercept)
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, k, init, nsteps=60, burnin=3, thin=2, calls=2, scale=0.02, **kw)
+    assert abi.last_kernel() == "mfma-streamed", abi.last_kernel()
+    fixed = [False] * k
+    fixed[2] = True
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_UNIF_REFLECTIVE, k, init, nsteps=50, min_=-0.3, max_=0.3, lb=-6.0, ub=9.0, fixed=fixed, **kw)
+    assert abi.last_kernel() == "mfma-streamed"
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_ADAPT, k, init, nsteps=70, calls=2, warmup=15, **kw)
+    assert abi.last_kernel() == "mfma-adaptive", abi.last_kernel()
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, k, init, nsteps=60, calls=2, burnin=2, thin=3, **kw)
+    assert abi.last_kernel() == "mfma-adaptive"
+    base = list(init[0])
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_NMIRROR, k, init, nsteps=90, calls=2, mu=base, scale=0.15, warmup=60, nadapt=6, lb=[-30.0] * (k - 1) + [0.05], ub=30.0, **kw)
+    assert abi.last_kernel() == "mfma-adaptive"
+    set_knob(monkeypatch, "tinymfma", "0")
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, k, init, nsteps=40, scale=0.02, **kw)
+    assert abi.last_kernel() not in ("mfma-streamed", "mfma-adaptive")
+
+
 @pytest.mark.parametrize("n,p,intercept", [(10241, 3, True), (20000, 3, True), (12001, 3, False), (30000, 2, True), (5121, 5, True), (6500, 6, True), (9000, 4, False), (6000, 7, True), (8200, 7, False), (7000, 3, True), (10000, 3, True), (3100, 5, True), (2000, 3, True), (700, 1, False), (1000, 6, True)])
 def test_adaptive_kernels_on_the_streamed_mfma_evaluation(E, O, monkeypatch, n, p, intercept):
     """mh_sweep_mfma_ad (round 4): kernel_adapt / kernel_ram beyond mh_sweep_spec's registers -- the streamed MFMA evaluation of
