@@ -3,11 +3,12 @@
 #include "mh_lat.hpp"
 
 namespace fmh {
+FMH_HIDDEN const void* k_lat_lg1c();   // k_lat_l1c.hip: p = 3
 FMH_HIDDEN const void* k_lat_lg1a(int p) {
   switch (p) {
     case 1: return (const void*)mh_sweep_lat<1, 1, 20, FMCMC_FAM_LOGISTIC>;
     case 2: return (const void*)mh_sweep_lat<1, 2, 20, FMCMC_FAM_LOGISTIC>;
-    case 3: return (const void*)mh_sweep_lat<1, 3, 20, FMCMC_FAM_LOGISTIC>;
+    case 3: return k_lat_lg1c();
     default: return nullptr;
   }
 }

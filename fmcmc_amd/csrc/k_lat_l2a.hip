@@ -3,11 +3,12 @@
 #include "mh_lat.hpp"
 
 namespace fmh {
+FMH_HIDDEN const void* k_lat_lg2c();   // k_lat_l2c.hip: p = 3
 FMH_HIDDEN const void* k_lat_lg2a(int p) {
   switch (p) {
     case 1: return (const void*)mh_sweep_lat<2, 1, 20, FMCMC_FAM_LOGISTIC>;
     case 2: return (const void*)mh_sweep_lat<2, 2, 20, FMCMC_FAM_LOGISTIC>;
-    case 3: return (const void*)mh_sweep_lat<2, 3, 20, FMCMC_FAM_LOGISTIC>;
+    case 3: return k_lat_lg2c();
     default: return nullptr;
   }
 }
