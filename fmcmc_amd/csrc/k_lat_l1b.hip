@@ -15,9 +15,11 @@ FMH_HIDDEN const void* k_lat_lg1b(int p) {
 FMH_HIDDEN const void* k_lat_lg1a(int p);
 FMH_HIDDEN const void* k_lat_lg2a(int p);
 FMH_HIDDEN const void* k_lat_lg2b(int p);
+FMH_HIDDEN const void* k_lat_lg1w(int p);   // k_lat_l3a.hip / k_lat_l3b.hip: p = 8 .. 15
+FMH_HIDDEN const void* k_lat_lg2w(int p);
 FMH_HIDDEN const void* k_lat_logit(int p, int kind) {
-  if (kind == FMCMC_KERNEL_NORMAL) return p <= 3 ? k_lat_lg1a(p) : k_lat_lg1b(p);
-  if (kind == FMCMC_KERNEL_NORMAL_REFLECTIVE) return p <= 3 ? k_lat_lg2a(p) : k_lat_lg2b(p);
+  if (kind == FMCMC_KERNEL_NORMAL) return p <= 3 ? k_lat_lg1a(p) : (p <= 7 ? k_lat_lg1b(p) : k_lat_lg1w(p));
+  if (kind == FMCMC_KERNEL_NORMAL_REFLECTIVE) return p <= 3 ? k_lat_lg2a(p) : (p <= 7 ? k_lat_lg2b(p) : k_lat_lg2w(p));
   return nullptr;
 }
 FMH_HIDDEN size_t k_lat_logit_lds() { return lat_logit_lds_bytes(); }

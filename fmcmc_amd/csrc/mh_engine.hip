@@ -810,7 +810,11 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
   // (a fixed parameter under the normal / uniform kernels: the latency form's candidate wave handles it, the owners of mh_sweep_spec do not)
   const bool lg_lat_fixed = kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE && kn->kind >= FMCMC_KERNEL_NORMAL && kn->scheme == FMCMC_SCHEME_JOINT &&
                             kf != kn->k && K.lat != 0 && K.speclogit != 2;
-  if (!force && !nopipe && K.speclogit != 0 && K.shard < 0 && m->family == FMCMC_FAM_LOGISTIC && !mirror && m->p >= 1 && m->p <= 7 &&
+  // (8 .. 15 covariates, k <= 16, up to 2048 observations, the normal / uniform kernels: the latency form only -- four slots of P doubles
+  //  per lane; they ran on the general kernel, 3 - 4.5 us per step at n = 200)
+  const bool lg_lat_wide = m->p >= 8 && m->p <= 15 && kn->k <= PIPE_KMAX && kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE && kn->kind >= FMCMC_KERNEL_NORMAL &&
+                           K.lat != 0 && K.speclogit != 2 && kf >= 1 && (kn->scheme == FMCMC_SCHEME_JOINT || single_lat);
+  if (!force && !nopipe && K.speclogit != 0 && K.shard < 0 && m->family == FMCMC_FAM_LOGISTIC && !mirror && m->p >= 1 && (m->p <= 7 || lg_lat_wide) &&
       kn->k == m->p + (m->intercept ? 1 : 0) && ((kf == kn->k && A.kz == kn->k) || single_lat || (lg_lat_fixed && kf >= 1)) &&
       (((kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE) && (kn->scheme == FMCMC_SCHEME_JOINT || single_lat)) ||
        (kn->kind == FMCMC_KERNEL_ADAPT && (!adapt_hist || adapt_ring)) || (kn->kind == FMCMC_KERNEL_RAM && !kn->constr && (!ram_bounded || K.specbnd != 0))) &&
@@ -818,9 +822,9 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
       (unsigned long long)kn->k * (unsigned long long)A.ldS * 8ull < (1ull << 32)) {
     const long long nsl2 = (((m->n + NT - 1) / NT) + 1) & ~1ll;
     const long long per_cu = (run->nchains + ncu - 1) / ncu;
-    if ((kn->scheme != FMCMC_SCHEME_JOINT || lg_lat_fixed) && kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE) {
+    if ((kn->scheme != FMCMC_SCHEME_JOINT || lg_lat_fixed || lg_lat_wide) && kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE) {
       // single-parameter schemes: the latency form's candidate wave, one to four chains per workgroup (as for the linear model above)
-      if (per_cu <= 4 && nsl2 <= (lg_lat_fixed ? 12 : fmh::k_spec_optmax(m->p, kn->kind)) && fmh::k_lat_logit(m->p, kn->kind)) {
+      if (per_cu <= 4 && nsl2 <= (lg_lat_wide ? 4 : (lg_lat_fixed ? 12 : fmh::k_spec_optmax(m->p, kn->kind))) && fmh::k_lat_logit(m->p, kn->kind)) {
         pipe_opt = (int)nsl2; spec_logit = true; lat_normal = true;
         spec_cw = (K.lat >= 1 && K.lat <= 3) ? K.lat : (int)per_cu;
       }

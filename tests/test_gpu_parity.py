@@ -917,6 +917,37 @@ def test_logistic_on_the_wave_specialised_kernel_and_its_latency_forms(E, O, mon
     assert abi.last_kernel().startswith("spec-logit") and ro.accept_count.sum() > 0
 
 
+@pytest.mark.parametrize("n,p,intercept,chains", [(200, 8, True, 3), (50, 12, True, 300), (1, 9, False, 2), (2048, 15, True, 5), (1500, 10, False, 700), (513, 15, False, 1000)])
+def test_logistic_with_eight_to_fifteen_covariates_on_the_latency_form(E, O, monkeypatch, n, p, intercept, chains):
+    """Round 5: the logistic family with 8 .. 15 covariates (k <= 16) on up to 2048 observations under the normal / uniform kernels:
+    mh_sweep_lat<KIND, P, 4, LOGISTIC>, one to four chains per workgroup (they ran on the general kernel, 3 - 4.5 us per step at n = 200).
+    Joint and single-parameter schemes, a fixed parameter, reflective bounds, two calls with burn-in and thinning: the oracle's bits."""
+    from fmcmc_amd import _abi as abi
+    rng = np.random.default_rng(100 * p + n + chains)
+    X = rng.standard_normal((n, p))
+    beta = np.linspace(0.5, -0.5, p + 1)
+    eta = (beta[0] if intercept else 0.0) + X @ beta[1:]
+    y = (rng.uniform(size=n) < 1 / (1 + np.exp(-eta))).astype(np.float64)
+    k = p + (1 if intercept else 0)
+    init = jitter_init(list(beta[(0 if intercept else 1):]), chains, 17 + p)
+    steps = 60 if chains < 100 else 24
+    want = "lat-logit%d" % min(4, (chains + 255) // 256)
+    kw = dict(nsteps=steps, intercept=intercept)
+    run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_NORMAL, k, init, scale=0.05, burnin=3, thin=2, calls=2, prior_div=8.0, **kw)
+    assert abi.last_kernel() == want, abi.last_kernel()
+    run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_NORMAL_REFLECTIVE, k, np.clip(init, -0.65, 0.65), scale=0.2, lb=-0.7, ub=0.7, **kw)
+    assert abi.last_kernel() == want
+    fixed = [False] * k
+    fixed[1] = True
+    run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_UNIF, k, init, min_=-0.04, max_=0.05, fixed=fixed, prior_div=8.0, **kw)
+    assert abi.last_kernel() == want
+    run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_NORMAL, k, init, scale=0.05, scheme="random", prior_div=8.0, **kw)
+    assert abi.last_kernel() == want
+    set_knob(monkeypatch, "speclogit", "0")
+    run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_NORMAL, k, init, scale=0.05, prior_div=8.0, **kw)
+    assert not abi.last_kernel().startswith("lat-logit")
+
+
 @pytest.mark.parametrize("form", ["shadow", "spec"])
 def test_logistic_round5_kernels_edge_cases(E, O, monkeypatch, form):
     """mh_sweep_logit2 ("logistic-shadow", forced by shard=1) and the logistic family on mh_sweep_spec ("spec-logit") at the edges: two
