@@ -228,8 +228,22 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
             }
             wave_sync_lds();
             if (lane < kf) {
+              // (round 5: four columns' LDS reads in flight -- one element per LDS round trip made this loop and the factor's ~7 us
+              //  of a step at k = 14; same operations per element, same bits)
               const double c1 = (t - 1) / t, c2 = 1.0 / t;
-              for (int b = 0; b < kf; b++) {
+              int b = 0;
+              for (; b + 4 <= kf; b += 4) {
+                double pb[4], tb[4], xb[4], sb[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { pb[u] = vmp[b + u]; tb[u] = vmt[b + u]; xb[u] = vv[b + u]; sb[u] = SigA[lane * LD + b + u]; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                  const double ik = (b + u == lane) ? 1.0 * A.eps : 0.0;
+                  const double inner = t * (mp * pb[u]) - (t + 1) * (mt * tb[u]) + x * xb[u] + 1e-5 * ik;
+                  SigA[lane * LD + b + u] = c1 * sb[u] + c2 * inner;
+                }
+              }
+              for (; b < kf; b++) {
                 double ik = (b == lane) ? 1.0 * A.eps : 0.0;
                 double inner = t * (mp * vmp[b]) - (t + 1) * (mt * vmt[b]) + x * vv[b] + 1e-5 * ik;
                 SigA[lane * LD + b] = c1 * SigA[lane * LD + b] + c2 * inner;
@@ -247,9 +261,17 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
             double sacc = 0.0;
             if (lane >= j && lane < kf) {
               sacc = SigA[lane * LD + j];
-              for (int b = 0; b < j; b++) sacc = fmh_fma(-SigB[lane * LD + b], SigB[b * LD + j], sacc);
+              int b = 0;
+              for (; b + 4 <= j; b += 4) {
+                double lb4[4], wb4[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { lb4[u] = SigB[lane * LD + b + u]; wb4[u] = SigB[(b + u) * LD + j]; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) sacc = fmh_fma(-lb4[u], wb4[u], sacc);
+              }
+              for (; b < j; b++) sacc = fmh_fma(-SigB[lane * LD + b], SigB[b * LD + j], sacc);
             }
-            double d = shfl_d(sacc, j);
+            const double d = readlane_d(sacc, j);     // (the pivot as a scalar: no LDS round trip of a ds_bpermute)
             if (!(d > 0.0) || !fmh_isfinite(d)) { notpd = true; break; }
             if (lane == j) { SigB[j * LD + j] = 1.0; vv[j] = d; }
             else if (lane > j && lane < kf) { SigB[lane * LD + j] = sacc / d; SigB[j * LD + lane] = sacc; }
@@ -266,7 +288,13 @@ __device__ __forceinline__ void spec_owner_adaptive(const SweepArgs& A, int myc,
             wave_sync_lds();
             if (lane < kf) {
               double sacc = 0.0;
-              for (int b = 0; b <= lane; b++) sacc = fmh_fma(SigB[lane * LD + b], vz[b], sacc);
+              for (int b = 0; b < kf; b += 4) {     // (terms b <= lane, in order; four columns' reads in flight, clamped inside the row)
+                double lb4[4], zb4[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const int bb = (b + u < kf) ? b + u : kf - 1; lb4[u] = SigB[lane * LD + bb]; zb4[u] = vz[bb]; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const double nx = fmh_fma(lb4[u], zb4[u], sacc); sacc = (b + u <= lane) ? nx : sacc; }
+              }
               const int j = which[lane];
               th1[j] = reflect1(th0[j] + (s_mu[j] + sacc), s_lb[j], s_ub[j]);
             }
