@@ -702,7 +702,7 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
           // owner's ~550 vector instructions at k = 5); here a column is its fma chain and one division, W = the numerators
           // before the division stand in for L D in the sums, and sqrt(D) is one element-wise square root at proposal time.
           bool notpd = false;
-          if (status == FMCMC_CHAIN_OK && sig_dirty) {
+          if (!RING || (status == FMCMC_CHAIN_OK && sig_dirty)) {   // (without the stride: every step, no test)
           Dl = 0.0;
           static_for<KA>([&](auto j_) {
             constexpr int j = decltype(j_)::value;
@@ -731,7 +731,7 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
           });
           }
           SPEC_ST(4);
-          if (notpd || status != FMCMC_CHAIN_OK) {
+          if (notpd || (RING && status != FMCMC_CHAIN_OK)) {
             if (notpd) status = FMCMC_CHAIN_NOT_PD;
             if (lane == 0) { A.status[cl] = status; A.status_step[cl] = i + ioff; }
             if (rl) A.status_theta[(long long)cl * k + lane] = th1;
