@@ -6,7 +6,13 @@
 namespace fmh {
 FMH_HIDDEN const void* k_spec_normal(int p, int kind);
 FMH_HIDDEN const void* k_spec_mirror(int p, int kind);
+FMH_HIDDEN const void* k_spec_w1(int p);   // k_spec_w1..4.hip: p = 8 .. 14
+FMH_HIDDEN const void* k_spec_w2(int p);
+FMH_HIDDEN const void* k_spec_w3(int p);
+FMH_HIDDEN const void* k_spec_w4(int p);
 const void* k_spec(int p, int kind) {
+  if (p >= 8 && kind == FMCMC_KERNEL_ADAPT) return p <= 11 ? k_spec_w1(p) : k_spec_w2(p);
+  if (p >= 8 && kind == FMCMC_KERNEL_RAM) return p <= 11 ? k_spec_w3(p) : k_spec_w4(p);
   if (kind == FMCMC_KERNEL_NORMAL || kind == FMCMC_KERNEL_NORMAL_REFLECTIVE) return k_spec_normal(p, kind);
   if (kind == FMCMC_KERNEL_NMIRROR || kind == FMCMC_KERNEL_UMIRROR) return k_spec_mirror(p, kind);
   if (kind != FMCMC_KERNEL_ADAPT && kind != FMCMC_KERNEL_RAM) return nullptr;

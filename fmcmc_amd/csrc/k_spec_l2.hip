@@ -3,7 +3,10 @@
 #include "mh_spec.hpp"
 
 namespace fmh {
+FMH_HIDDEN const void* k_spec_lw1(int p);   // k_spec_lw1/2.hip: p = 8 .. 15
+FMH_HIDDEN const void* k_spec_lw2(int p);
 FMH_HIDDEN const void* k_spec_logit_a(int p, int kind) {
+  if (p >= 8) return kind == 3 ? k_spec_lw1(p) : k_spec_lw2(p);
 #define SPEC_L(PV, OV) ((kind == 3) ? (const void*)mh_sweep_spec<PV, OV, 3, FMCMC_FAM_LOGISTIC> : (const void*)mh_sweep_spec<PV, OV, 4, FMCMC_FAM_LOGISTIC>)
   switch (p) {
     case 1: return SPEC_L(1, 20);

@@ -398,6 +398,7 @@ static SweepArgs chain_window(const SweepArgs& A, long long off, long long cnt, 
 //   specbnd=0    the bounded kernel_ram: not on the wave-specialised kernel (SpecSyncB)
 //   specmirror=0 the mirror kernels: not on the wave-specialised kernel
 //   tinymfma=0   the streamed MFMA forms (8 .. 15 covariates, mirror / adaptive kernels) only from 513 observations on
+//   specwide=0   kernel_adapt / kernel_ram with 8 .. 14 covariates on small data: not on the wave-specialised kernel
 //   specp0=0     models without a covariate (iid Normal): adaptive / mirror kernels not on the wave-specialised kernel
 //   turn=<t>     logit_shard's issue-priority turn (timing only): thousandths of the younger wave's passes it starts from, + 10000: and
 //                stays at, + 100000 x (lead in units of 256 cycles it is regulated towards); turn=0: no turn
@@ -405,14 +406,14 @@ static SweepArgs chain_window(const SweepArgs& A, long long off, long long cnt, 
 // The kernel a call ended up on is reported by fmcmc_last_kernel(); DESIGN.md section 5 has the shape -> kernel table.
 struct Knobs {
   int streamed = -1, cw = -1, pipe = -1, lat = -1, mfma = -1, shard = -1, shard_mfma = -1, wide2 = -1, groups = -1, tiles = -1, t10 = -1, window = -1, mode = 0;
-  int shadow = -1, turn = -1, speclogit = -1, specbnd = -1, specmirror = -1, specp0 = -1, tinymfma = -1;
+  int shadow = -1, turn = -1, speclogit = -1, specbnd = -1, specmirror = -1, specp0 = -1, tinymfma = -1, specwide = -1;
 };
 static Knobs read_knobs() {
   Knobs K;
   const char* e = getenv("FMCMC_AMD_DEBUG");
   if (!e) return K;
   struct { const char* name; int* dst; } tab[] = {{"streamed", &K.streamed}, {"cw", &K.cw}, {"pipe", &K.pipe}, {"lat", &K.lat},
-      {"mfma", &K.mfma}, {"shard_mfma", &K.shard_mfma}, {"shard", &K.shard}, {"wide2", &K.wide2}, {"groups", &K.groups}, {"tiles", &K.tiles}, {"t10", &K.t10}, {"window", &K.window}, {"mode", &K.mode}, {"shadow", &K.shadow}, {"turn", &K.turn}, {"speclogit", &K.speclogit}, {"specbnd", &K.specbnd}, {"specmirror", &K.specmirror}, {"specp0", &K.specp0}, {"tinymfma", &K.tinymfma}};
+      {"mfma", &K.mfma}, {"shard_mfma", &K.shard_mfma}, {"shard", &K.shard}, {"wide2", &K.wide2}, {"groups", &K.groups}, {"tiles", &K.tiles}, {"t10", &K.t10}, {"window", &K.window}, {"mode", &K.mode}, {"shadow", &K.shadow}, {"turn", &K.turn}, {"speclogit", &K.speclogit}, {"specbnd", &K.specbnd}, {"specmirror", &K.specmirror}, {"specp0", &K.specp0}, {"tinymfma", &K.tinymfma}, {"specwide", &K.specwide}};
   while (*e) {
     const char* eq = strchr(e, '=');
     const char* end = strchr(e, ',');
@@ -691,7 +692,9 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
     // its compute loops: any n <= 10240 at p <= 3, n <= 5120 at p = 4, 5, n <= 4096 at p = 6, 7 (OPTMAX P doubles per lane)
     {
       const long long nsl = (m->n + NT - 1) / NT, nsl2 = (nsl + 1) & ~1ll;
-      const int optmax = (m->p >= 0 && m->p <= 3) ? 20 : (m->p <= 5 ? 10 : (m->p <= 7 ? 8 : 0));
+      // (round 5: 8 .. 14 covariates on up to 2048 observations -- four slots of P doubles per compute lane, the register owner at the
+      //  compile-time width k <= 16; knob specwide=0: the streamed MFMA evaluation with the owners in LDS, as before)
+      const int optmax = (m->p >= 0 && m->p <= 3) ? 20 : (m->p <= 5 ? 10 : (m->p <= 7 ? 8 : ((m->p <= 14 && K.specwide != 0) ? 4 : 0)));
       // (the bounded kernel_ram decides on f of the REFLECTED proposal: a second evaluation in the steps in which the reflection
       //  moved something -- the barrier-synchronised owners of mh_sweep_mfma_ad ask for it between barriers, this kernel's register
       //  owners through a second evaluation slot per step (round 5, SpecSyncB: k <= 8, no fixed parameter; knob specbnd=0: off))
@@ -814,7 +817,11 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
   //  per lane; they ran on the general kernel, 3 - 4.5 us per step at n = 200)
   const bool lg_lat_wide = m->p >= 8 && m->p <= 15 && kn->k <= PIPE_KMAX && kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE && kn->kind >= FMCMC_KERNEL_NORMAL &&
                            K.lat != 0 && K.speclogit != 2 && kf >= 1 && (kn->scheme == FMCMC_SCHEME_JOINT || single_lat);
-  if (!force && !nopipe && K.speclogit != 0 && K.shard < 0 && m->family == FMCMC_FAM_LOGISTIC && !mirror && m->p >= 1 && (m->p <= 7 || lg_lat_wide) &&
+  // (and under kernel_adapt / kernel_ram -- unbounded, stride 1, no fixed parameter --: mh_sweep_spec<P, 4, KIND, LOGISTIC> with the register
+  //  owner at the compile-time width k <= 16; general kernel: 6 - 14 us per step at n = 200.  Knob specwide=0: off)
+  const bool lg_spec_wide = m->p >= 8 && m->p <= 15 && kn->k <= PIPE_KMAX && K.specwide != 0 &&
+                            ((kn->kind == FMCMC_KERNEL_ADAPT && !adapt_hist) || (kn->kind == FMCMC_KERNEL_RAM && !ram_bounded && !kn->constr));
+  if (!force && !nopipe && K.speclogit != 0 && K.shard < 0 && m->family == FMCMC_FAM_LOGISTIC && !mirror && m->p >= 1 && (m->p <= 7 || lg_lat_wide || lg_spec_wide) &&
       kn->k == m->p + (m->intercept ? 1 : 0) && ((kf == kn->k && A.kz == kn->k) || single_lat || (lg_lat_fixed && kf >= 1)) &&
       (((kn->kind == FMCMC_KERNEL_NORMAL || kn->kind == FMCMC_KERNEL_NORMAL_REFLECTIVE) && (kn->scheme == FMCMC_SCHEME_JOINT || single_lat)) ||
        (kn->kind == FMCMC_KERNEL_ADAPT && (!adapt_hist || adapt_ring)) || (kn->kind == FMCMC_KERNEL_RAM && !kn->constr && (!ram_bounded || K.specbnd != 0))) &&

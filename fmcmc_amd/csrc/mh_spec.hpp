@@ -1205,7 +1205,7 @@ __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
     for (int j = 0; j < k; j++) nofixed = nofixed && (A.fixed[j] == 0);
     SpecSync sync{s_ready, s_done, s_tr, myc};
     if constexpr (LG) {   // (the host takes this kernel for k = P + intercept, no fixed parameter: the register owner)
-      if constexpr (KIND == FMCMC_KERNEL_RAM) {
+      if constexpr (KIND == FMCMC_KERNEL_RAM && P <= 7) {   // (8 .. 15 covariates: no bounded kernel_ram here, the host's condition)
         if (s_need) {
           SpecSyncB syncb{s_ready, s_done, s_tr, myc};
           if (k == P + 1) spec_owner_adaptive_reg<KIND, P + 1, SpecSyncB, true, FMCMC_FAM_LOGISTIC>(A, myc, cl, s_th1, syncb);
@@ -1219,6 +1219,15 @@ __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
       }
       if (k == P + 1) spec_owner_adaptive_reg<KIND, P + 1, SpecSync, false, FMCMC_FAM_LOGISTIC>(A, myc, cl, s_th1, sync);
       else spec_owner_adaptive_reg<KIND, (P > 0 ? P : 1), SpecSync, false, FMCMC_FAM_LOGISTIC>(A, myc, cl, s_th1, sync);
+      return;
+    }
+    if constexpr (P >= 8) {
+      // 8 .. 14 covariates on up to 2048 observations (round 5): the register owner at the compile-time width k = P + 2 / P + 1 <= 16 -- the
+      // owner waves of THIS kernel hold no operands (rows of 16 lost their registers to the operand groups in mh_sweep_mfma_ad); a fixed
+      // parameter: the owners with their matrices in LDS.  (No bounded kernel_ram, no stride here: the host's conditions.)
+      if (k == P + 2 && nofixed && A.kz == k) spec_owner_adaptive_reg<KIND, P + 2>(A, myc, cl, s_th1, sync);
+      else if (k == P + 1 && nofixed && A.kz == k) spec_owner_adaptive_reg<KIND, P + 1>(A, myc, cl, s_th1, sync);
+      else spec_owner_adaptive<KIND>(A, myc, cl, s_th1, s_par, sync, s_ad + myc * SPEC_ADS);
       return;
     }
     if constexpr (KIND == FMCMC_KERNEL_RAM) {

@@ -943,6 +943,17 @@ def test_logistic_with_eight_to_fifteen_covariates_on_the_latency_form(E, O, mon
     assert abi.last_kernel() == want
     run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_NORMAL, k, init, scale=0.05, scheme="random", prior_div=8.0, **kw)
     assert abi.last_kernel() == want
+    # kernel_adapt / kernel_ram: mh_sweep_spec<P, 4, KIND, LOGISTIC>, the register owner at the compile-time width k <= 16
+    want_a = "spec-logit" if chains > 768 else "spec-logit-lat%d" % ((chains + 255) // 256)
+    run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_ADAPT, k, init, warmup=6, calls=2, burnin=2, thin=3, prior_div=8.0, **kw)
+    assert abi.last_kernel() == want_a, abi.last_kernel()
+    run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_ADAPT, k, np.clip(init, -0.65, 0.65), warmup=4, lb=-0.7, ub=0.7, **kw)
+    assert abi.last_kernel() == want_a
+    run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_RAM, k, init, calls=2, prior_div=8.0, **kw)
+    assert abi.last_kernel() == want_a
+    set_knob(monkeypatch, "specwide", "0")
+    run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_RAM, k, init, prior_div=8.0, **kw)
+    assert not abi.last_kernel().startswith("spec-logit")
     set_knob(monkeypatch, "speclogit", "0")
     run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_NORMAL, k, init, scale=0.05, prior_div=8.0, **kw)
     assert not abi.last_kernel().startswith("lat-logit")
@@ -1147,6 +1158,12 @@ def test_eight_to_fifteen_covariates_on_small_data(E, O, monkeypatch, n, p, inte
     fixed[2] = True
     run_both(E, O, O.FAM_LINREG, X, y, O.K_UNIF_REFLECTIVE, k, init, nsteps=50, min_=-0.3, max_=0.3, lb=-6.0, ub=9.0, fixed=fixed, **kw)
     assert abi.last_kernel() == "mfma-streamed"
+    wide = "spec" if p <= 14 else "mfma-adaptive"      # (8 .. 14 covariates: the wave-specialised kernel, test_adaptive_kernels_with_eight_to_fourteen_covariates...)
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_ADAPT, k, init, nsteps=70, calls=2, warmup=15, **kw)
+    assert abi.last_kernel() == wide, abi.last_kernel()
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, k, init, nsteps=60, calls=2, burnin=2, thin=3, **kw)
+    assert abi.last_kernel() == wide
+    set_knob(monkeypatch, "specwide", "0")
     run_both(E, O, O.FAM_LINREG, X, y, O.K_ADAPT, k, init, nsteps=70, calls=2, warmup=15, **kw)
     assert abi.last_kernel() == "mfma-adaptive", abi.last_kernel()
     run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, k, init, nsteps=60, calls=2, burnin=2, thin=3, **kw)
@@ -1157,6 +1174,41 @@ def test_eight_to_fifteen_covariates_on_small_data(E, O, monkeypatch, n, p, inte
     set_knob(monkeypatch, "tinymfma", "0")
     run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, k, init, nsteps=40, scale=0.02, **kw)
     assert abi.last_kernel() not in ("mfma-streamed", "mfma-adaptive")
+
+
+@pytest.mark.parametrize("chains,n,p,intercept,fix", [(3, 200, 8, True, False), (300, 50, 12, True, False), (700, 2048, 14, True, False), (1001, 1537, 9, False, False),
+                                                      (1030, 600, 13, False, False), (5, 1024, 11, True, True), (2, 1, 10, True, False)])
+def test_adaptive_kernels_with_eight_to_fourteen_covariates_on_the_wave_specialised_kernel_and_its_latency_forms(E, O, monkeypatch, chains, n, p, intercept, fix):
+    """Round 5: kernel_adapt / kernel_ram with 8 .. 14 covariates (k <= 16) on up to 2048 observations: mh_sweep_spec<P, 4, KIND> with the
+    register owner at the compile-time width k = P + 2 / P + 1 -- in this kernel the owner waves hold no operands, so rows of 16 fit (the
+    streamed MFMA evaluation with the owners' matrices in LDS took 4.3 - 9.5 us per step at n = 200).  One to four chains per workgroup, a ragged
+    last workgroup, a fixed parameter (the LDS owners of the same kernel), warm-up / until, freq of kernel_ram, two calls with burn-in and
+    thinning, step windows: the oracle's bits."""
+    from fmcmc_amd import _abi as abi
+    X, y = synth_linreg(n, p, 6600 + n + p, beta=np.linspace(0.7, -0.7, p + 1))
+    k = p + 1 + (1 if intercept else 0)
+    sd = float(np.std(y)) if n > 1 else 1.0
+    init = jitter_init(([0.0] if intercept else []) + [0.0] * p + [sd + 0.3], chains, 98 + p)
+    init[:, -1] = np.abs(init[:, -1])
+    fixed = [False] * k
+    if fix:
+        fixed[1] = True
+    steps = 80 if chains < 100 else 30
+    want = "spec" if chains > 768 else "spec-lat%d" % ((chains + 255) // 256)
+    kw = dict(intercept=intercept, fixed=fixed)
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_ADAPT, k, init, nsteps=steps, calls=2, warmup=10, burnin=3, thin=2, **kw)
+    assert abi.last_kernel() == want, abi.last_kernel()
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_ADAPT, k, init, nsteps=steps, warmup=5, lb=-4.0, ub=9.0, until=float(steps - 8), **kw)
+    assert abi.last_kernel() == want
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, k, init, nsteps=steps, calls=2, burnin=2, thin=3, **kw)
+    assert abi.last_kernel() == want
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, k, init, nsteps=steps, ram_qfun=1, warmup=4, freq=2, **kw)
+    assert abi.last_kernel() == want
+    set_knob(monkeypatch, "window", "16")
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_ADAPT, k, init, nsteps=steps, calls=2, warmup=10, **kw)
+    assert abi.last_kernel() == want
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, k, init, nsteps=steps, calls=2, **kw)
+    assert abi.last_kernel() == want
 
 
 @pytest.mark.parametrize("n,p,intercept", [(10241, 3, True), (20000, 3, True), (12001, 3, False), (30000, 2, True), (5121, 5, True), (6500, 6, True), (9000, 4, False), (6000, 7, True), (8200, 7, False), (7000, 3, True), (10000, 3, True), (3100, 5, True), (2000, 3, True), (700, 1, False), (1000, 6, True)])
@@ -1226,6 +1278,10 @@ def test_adaptive_kernels_with_their_matrices_in_lds_on_the_streamed_mfma_evalua
     general kernel (tools/dispatch_audit.py: 22 .. 55 us per step at n = 1e4)."""
     set_knob(monkeypatch, "shard", "0")     # (few chains on long data would take the long-data form: test_few_chains_on_long_data)
     from fmcmc_amd import _abi as abi
+    # (round 5: 8 .. 14 covariates on up to 2048 observations run on the wave-specialised kernel -- register owners of width k, or, with
+    #  a fixed parameter, the same owners in LDS there; knob specwide=0 keeps this test on the kernel it was written for)
+    want = "mfma-adaptive"
+    set_knob(monkeypatch, "specwide", "0")
     X, y = synth_linreg(n, p, 6400 + n + p, beta=np.linspace(0.7, -0.7, p + 1))
     k = p + 1 + (1 if intercept else 0)
     init = jitter_init(([0.0] if intercept else []) + [0.0] * p + [float(np.std(y))], 6, 98 + p)
@@ -1234,13 +1290,13 @@ def test_adaptive_kernels_with_their_matrices_in_lds_on_the_streamed_mfma_evalua
     if fix:
         fixed[1] = True
     run_both(E, O, O.FAM_LINREG, X, y, O.K_ADAPT, k, init, nsteps=70, calls=2, warmup=15, intercept=intercept, fixed=fixed)
-    assert abi.last_kernel() == "mfma-adaptive"
+    assert abi.last_kernel() == want
     run_both(E, O, O.FAM_LINREG, X, y, O.K_ADAPT, k, init, nsteps=50, warmup=10, intercept=intercept, fixed=fixed, lb=-4.0, ub=9.0, until=30.0)
-    assert abi.last_kernel() == "mfma-adaptive"
+    assert abi.last_kernel() == want
     run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, k, init, nsteps=60, calls=2, intercept=intercept, fixed=fixed, burnin=2, thin=3)
-    assert abi.last_kernel() == "mfma-adaptive"
+    assert abi.last_kernel() == want
     run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, k, init, nsteps=40, intercept=intercept, fixed=fixed, ram_qfun=1, warmup=4, freq=2)
-    assert abi.last_kernel() == "mfma-adaptive"
+    assert abi.last_kernel() == want
 
 
 @pytest.mark.parametrize("k", [65, 100, 128])
