@@ -431,11 +431,27 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
   constexpr bool LG = FAM == FMCMC_FAM_LOGISTIC;
   constexpr int KA = KX > 0 ? KX : SPEC_KA;
   const int lane = threadIdx.x & 63;
-  const int k = KX > 0 ? KX : A.k, kf = k, kz = KX > 0 ? KX : A.kz;
+  const int k = KX > 0 ? KX : A.k, kz = KX > 0 ? KX : A.kz, kf = (KX > 0 || LG) ? k : kz;
   const int nsteps = (int)A.nsteps, burnin = (int)A.burnin, thin = (int)A.thin;
-  const bool rl = lane < k;                 // row lane == parameter lane (no fixed parameters)
+  const bool rl = lane < k;                 // a lane with a parameter (its row of the chain, its entry of the published vector)
   const int jl = rl ? lane : 0;
-  const double mu_l = A.mu[jl], lb_l = A.lb[jl], ub_l = A.ub[jl];
+  // KX == 0 (run-time width, k <= 8) takes FIXED parameters too (round 5: they ran on the owners with their matrices in LDS): the kf free
+  // parameters on lanes 0 .. kf - 1 -- all the arithmetic, in the space the reference's `which` spans --, the fixed ones behind them as
+  // passengers that keep their value (pj: a lane's parameter; sig_lane: the lane that holds sigma).  Compile-time widths: the identity.
+  const bool fl = lane < kf;                // a lane with a FREE parameter
+  int pj = jl, sig_lane = k - 1;
+  if constexpr (KX == 0 && !LG) {
+    int nfree = 0, nfix = 0, mine = 0;
+    for (int j = 0; j < k; j++) {
+      const bool fx = A.fixed[j] != 0;
+      const int pos = fx ? (kf + nfix) : nfree;
+      if (pos == lane) mine = j;
+      if (j == k - 1) sig_lane = pos;
+      nfree += fx ? 0 : 1; nfix += fx ? 1 : 0;
+    }
+    pj = rl ? mine : 0;
+  }
+  const double mu_l = A.mu[pj], lb_l = A.lb[pj], ub_l = A.ub[pj];
   double Srow[KA], Lrow[KA];                // Sigma (adapt) or S (ram) row `lane`; row of the unit lower factor L (adapt)
   double Wrow[KIND == FMCMC_KERNEL_ADAPT ? KA : 1];   // adapt: the numerators W_ib = L_ib D_b of the factor's row
   double (&Grow)[KA] = Lrow;                // ram: G_ib, the partial sums of the proposal's (S z)_lane chain
@@ -444,10 +460,10 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
 #pragma unroll
   for (int b = 0; b < KA; b++) {
     Lrow[b] = 0.0;
-    Srow[b] = (rl && b < kf) ? (A.fresh ? ((b == lane) ? 1.0 * A.eps : 0.0)
+    Srow[b] = (fl && b < kf) ? (A.fresh ? ((b == lane) ? 1.0 * A.eps : 0.0)
                                         : ((b <= lane || KIND == FMCMC_KERNEL_ADAPT) ? A.Sigma[((long long)cl * kf + lane) * kf + b] : 0.0)) : 0.0;
   }
-  double th0 = rl ? A.theta0[(long long)cl * k + lane] : 0.0, th1 = th0;
+  double th0 = rl ? A.theta0[(long long)cl * k + pj] : 0.0, th1 = th0;
   double f0 = 0.0, mean_prev = 0.0, run_sum = 0.0, zcur = 0.0;
   double Dl = 0.0;                          // adapt: D_lane of the factor (kept between the steps that form it)
   long long abs_iter = 0;
@@ -460,7 +476,7 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
     if (A.nerrors) nerr = A.nerrors[cl];
     if (KIND == FMCMC_KERNEL_ADAPT) {
       have_mean = A.have_mean[cl];
-      if (rl) mean_prev = A.mean_prev[(long long)cl * kf + lane];
+      if (fl) mean_prev = A.mean_prev[(long long)cl * kf + lane];
     }
   }
   // (row stores and variates: wave-uniform 64-bit bases of the chain's own blocks + 32-bit offsets -- 32-bit offsets from the
@@ -469,16 +485,16 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
   char* const s_base = reinterpret_cast<char*>(A.samples) + ((long long)cl * k) * A.ldS * 8;
   char* const d_base = A.draws ? reinterpret_cast<char*>(A.draws) + ((long long)cl * k) * A.ldS * 8 : nullptr;
   char* const l_base = A.logpost ? reinterpret_cast<char*>(A.logpost) + (long long)cl * A.ldS * 8 : nullptr;
-  const unsigned int lane_off = (unsigned int)((long long)jl * A.ldS * 8);
+  const unsigned int lane_off = (unsigned int)((long long)pj * A.ldS * 8);
   unsigned int srow8 = 0;
   const char* const z_base = reinterpret_cast<const char*>(A.fed_z) + ((long long)cl * nsteps) * kz * 8;   // wave-uniform
-  const unsigned int z_lane = (unsigned int)(jl) * 8u;
+  const unsigned int z_lane = (unsigned int)(fl ? lane : 0) * 8u;
   const double* const lu_row = A.fed_logu + (long long)cl * nsteps;
   const double dn = uniform_d((double)A.n);
   auto ld_z = [&](int row) -> double {
     return *reinterpret_cast<const double*>(z_base + (z_lane + (unsigned int)row * (unsigned int)(kz * 8)));
   };
-  double z_nx = (rl && nsteps >= 2) ? ld_z(1) : 0.0;
+  double z_nx = (fl && nsteps >= 2) ? ld_z(1) : 0.0;
   double lu_nx = (nsteps >= 2) ? lu_row[1] : 0.0;
   bool ram_gate = false;
   auto flush_bits = [&](int i) {
@@ -536,7 +552,7 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
       }
       return;
     }
-    const double sigma = readlane_d(th1, k - 1);
+    const double sigma = readlane_d(th1, sig_lane);
     const unsigned sg_hi = (unsigned)(fmh_d2u(sigma) >> 32);
     const bool sg_fast = (sg_hi - 0x00100000u) < 0x7fe00000u;            // positive, finite, normal
     const double sg = sg_fast ? sigma : 1.0;
@@ -571,14 +587,14 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
       if (A.prior_div != 0.0) f1 = f1 - pre_pri;
       if (A.guard && !fmh_isfinite(f1)) f1 = -fmh_inf();
     } else if (pre_ok && mfr_div_safe(h)) f1 = -pre_nt1 - div_finish(h, pre_ss, pre_rs);   // (finite: the guard has nothing to do)
-    else f1 = logpost_of(tot, readlane_d(th1, k - 1));
+    else f1 = logpost_of(tot, readlane_d(th1, sig_lane));
     bool st_row = false;
     double st_th0 = 0.0;
     double st_dr = th1;
     SPEC_ST(1);
     if (v == 1) {
       f0 = f1;
-      run_sum = (A.win_cont && A.win_sum && rl) ? A.win_sum[(long long)cl * kf + lane] : th0;
+      run_sum = (A.win_cont && A.win_sum && fl) ? A.win_sum[(long long)cl * kf + lane] : th0;
       if (1 > burnin) { thin_ctr += 1; if (thin_ctr == thin) { thin_ctr = 0; st_row = true; st_th0 = th0; } }
       if constexpr (BND) sync.second_idle();
     } else if (status != FMCMC_CHAIN_OK) {
@@ -597,7 +613,7 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
           if (cp != 0.0 && fmh_isfinite(cp)) {
             double dl, kl;
             const bool okl = ram_coef(cp, Pj, Pj1, zcur, dl, kl);
-            if (__any(rl && !okl)) {
+            if (__any(fl && !okl)) {
               nerr += 1;
             } else {
               static_for<KA>([&](auto j_) {
@@ -612,12 +628,12 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
         }
         abs_iter += 1;
         if constexpr (BND) {
-          const double th1r = reflect1(th1, lb_l, ub_l);
-          const bool moved = __any(rl && !(th1r == th1));
+          const double th1r = fl ? reflect1(th1, lb_l, ub_l) : th1;
+          const bool moved = __any(fl && !(th1r == th1));
           th1 = th1r;
           st_dr = th1r;                               // (the row of draws is the proposal the kernel returns: reflected)
           double tot2 = 0.0;
-          const bool again = sync.second(moved, [&]() { if (rl) s_th1[myc * PIPE_KMAX + lane] = th1; }, tot2);
+          const bool again = sync.second(moved, [&]() { if (rl) s_th1[myc * PIPE_KMAX + pj] = th1; }, tot2);
           if (again && moved) {                       // (not moved: the same vector, the same f)
             if constexpr (LG) {                       // (the linear part and the prior term of the REFLECTED proposal: prepare()'s chains)
               double lin = 0.0, ss = 0.0;
@@ -630,7 +646,7 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
               if (A.prior_div != 0.0) f1 = f1 - ss / A.prior_div;
               if (A.guard && !fmh_isfinite(f1)) f1 = -fmh_inf();
             } else {
-              f1 = logpost_of(tot2, readlane_d(th1, k - 1));
+              f1 = logpost_of(tot2, readlane_d(th1, sig_lane));
             }
           }
         }
@@ -640,7 +656,7 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
       if (status == FMCMC_CHAIN_OK && fmh_isnan(ratio)) status = FMCMC_CHAIN_NAN_RATIO;
       if (status != FMCMC_CHAIN_OK) {
         if (lane == 0) { A.status[cl] = status; A.status_step[cl] = i + ioff; }
-        if (rl) A.status_theta[(long long)cl * k + lane] = th1;
+        if (rl) A.status_theta[(long long)cl * k + pj] = th1;
         flush_bits(i);
       } else {
         const double lu = lu_nx;
@@ -659,13 +675,13 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
     SPEC_ST(2);
     // kernel_adapt(freq > 1): row v of the chain into the ring (rows (i - freq) .. (i - 1) are folded in together at step i)
     const int afreq = (KIND == FMCMC_KERNEL_ADAPT && RING) ? A.freq : 1;
-    if (KIND == FMCMC_KERNEL_ADAPT && afreq > 1 && ring && rl) ring[(v & (SPEC_FREQMAX - 1)) * PIPE_KMAX + lane] = th0;
+    if (KIND == FMCMC_KERNEL_ADAPT && afreq > 1 && ring && fl) ring[(v & (SPEC_FREQMAX - 1)) * PIPE_KMAX + lane] = th0;
     // ---- proposal of loop step i = v + 1
     if (v < nsteps) {
       if (status == FMCMC_CHAIN_OK) {
         const int i = v + 1;
         zcur = z_nx;
-        z_nx = rl ? ld_z(v + 1 < nsteps ? v + 1 : nsteps - 1) : 0.0;
+        z_nx = fl ? ld_z(v + 1 < nsteps ? v + 1 : nsteps - 1) : 0.0;
         bool sig_dirty = (afreq == 1) || v == 1;         // (freq > 1: the factor is formed again only when Sigma has moved)
         if (KIND == FMCMC_KERNEL_ADAPT) {
           if (A.until > (double)abs_iter && abs_iter > A.warmup && i + ioff > 2 && (afreq == 1 || ((i + ioff) % afreq) == 0)) {   // R/kernel_adapt.R:118-166
@@ -675,7 +691,7 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
               // rows (i - freq):(i - 1) folded in one by one, t = abs_iter - freq + (row - 1) (R/recursive.R:79-108,:129-136)
               for (int jr = 0; jr < afreq; jr++) {
                 const double t = (double)(abs_iter - afreq + jr);
-                const double x = (afreq == 1) ? th0 : (rl ? ring[((i - afreq + jr) & (SPEC_FREQMAX - 1)) * PIPE_KMAX + lane] : 0.0);
+                const double x = (afreq == 1) ? th0 : (fl ? ring[((i - afreq + jr) & (SPEC_FREQMAX - 1)) * PIPE_KMAX + lane] : 0.0);
                 const double mp = have_mean ? mean_prev : (run_sum / (double)(i + ioff - 1));
                 const double mt = (mp * t + x) / (t + 1);
                 // (freq = 1: the two step-only quotients were prepared while this wave waited for the partials)
@@ -734,7 +750,7 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
           if (notpd || (RING && status != FMCMC_CHAIN_OK)) {
             if (notpd) status = FMCMC_CHAIN_NOT_PD;
             if (lane == 0) { A.status[cl] = status; A.status_step[cl] = i + ioff; }
-            if (rl) A.status_theta[(long long)cl * k + lane] = th1;
+            if (rl) A.status_theta[(long long)cl * k + pj] = th1;
             if (((v - 1) & 31) != 31) flush_bits(v);   // (the accept bits of the steps decided so far; a full word has just been flushed)
           } else {
             const double ul = fmh_sqrt(Dl) * zcur;    // (beyond the parameters: D = 0, z = 0)
@@ -743,7 +759,7 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
               constexpr int b = decltype(b_)::value;
               if (b < kf) sacc = fmac_row_bcast<b>(sacc, ul, Lrow[b]);   // b > lane add +-0 exactly)
             });
-            th1 = reflect1(th0 + (mu_l + sacc), lb_l, ub_l);
+            th1 = (KX != 0 || LG || fl) ? reflect1(th0 + (mu_l + sacc), lb_l, ub_l) : th0;
           }
         } else {  // RAM P1 (R/kernel_ram.R:123-126)
           double sacc = 0.0;
@@ -751,10 +767,10 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
             constexpr int b = KA - 1 - decltype(r_)::value;
             if (b < kf) { Grow[b] = sacc; sacc = fmac_row_bcast<b>(sacc, zcur, Srow[b]); }   // (+0 above the diagonal adds +0)
           });
-          th1 = th0 + sacc;
+          th1 = (KX != 0 || LG || fl) ? th0 + sacc : th0;
           ram_gate = (A.until > (double)abs_iter && abs_iter > A.warmup && ((v + 1 + ioff) % A.freq) == 0);
         }
-        if (rl) s_th1[myc * PIPE_KMAX + lane] = th1;
+        if (rl) s_th1[myc * PIPE_KMAX + pj] = th1;
       }
       sync.publish(v + 1);
     } else {
@@ -779,7 +795,7 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
 #endif
 #undef SPEC_ST
   // ---- write state back
-  if (rl) A.theta0[(long long)cl * k + lane] = th0;
+  if (rl) A.theta0[(long long)cl * k + pj] = th0;
   if (lane == 0) {
     A.f0[cl] = f0;
     A.accept_count[cl] = nacc;
@@ -790,9 +806,9 @@ __device__ __forceinline__ void spec_owner_adaptive_reg(const SweepArgs& A, int 
   }
 #pragma unroll
   for (int b = 0; b < KA; b++)
-    if (rl && b < kf) A.Sigma[((long long)cl * kf + lane) * kf + b] = (b <= lane || KIND == FMCMC_KERNEL_ADAPT) ? Srow[b] : 0.0;
-  if (KIND == FMCMC_KERNEL_ADAPT && rl) A.mean_prev[(long long)cl * kf + lane] = mean_prev;
-  if (KIND == FMCMC_KERNEL_ADAPT && A.win_sum && rl) A.win_sum[(long long)cl * kf + lane] = run_sum;
+    if (fl && b < kf) A.Sigma[((long long)cl * kf + lane) * kf + b] = (b <= lane || KIND == FMCMC_KERNEL_ADAPT) ? Srow[b] : 0.0;
+  if (KIND == FMCMC_KERNEL_ADAPT && fl) A.mean_prev[(long long)cl * kf + lane] = mean_prev;
+  if (KIND == FMCMC_KERNEL_ADAPT && A.win_sum && fl) A.win_sum[(long long)cl * kf + lane] = run_sum;
 }
 
 // The mirror kernels' owner (kernel_nmirror / kernel_umirror, R/kernel_mirror.R:66-131, :203-262; twin of the general kernel's
@@ -1246,7 +1262,7 @@ __global__ __launch_bounds__(SPEC_NT) void mh_sweep_spec(const SweepArgs A) {
       spec_owner_adaptive_reg<KIND, P + 2>(A, myc, cl, s_th1, sync);
     else if (k == P + 1 && nofixed && A.kz == k && !(A.debug & 16))   // no intercept
       spec_owner_adaptive_reg<KIND, P + 1>(A, myc, cl, s_th1, sync);
-    else if (k <= SPEC_KA && nofixed && !(A.debug & 16))
+    else if (k <= SPEC_KA && A.kz >= 1 && !(A.debug & 16))       // (run-time width: fixed parameters too)
       spec_owner_adaptive_reg<KIND, 0>(A, myc, cl, s_th1, sync);
     else
       spec_owner_adaptive<KIND>(A, myc, cl, s_th1, s_par, sync, s_ad + myc * SPEC_ADS);

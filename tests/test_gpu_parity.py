@@ -1176,6 +1176,39 @@ def test_eight_to_fifteen_covariates_on_small_data(E, O, monkeypatch, n, p, inte
     assert abi.last_kernel() not in ("mfma-streamed", "mfma-adaptive")
 
 
+@pytest.mark.parametrize("chains,n,p,intercept,fixed_idx", [(2, 1000, 3, True, [1]), (300, 100, 3, True, [0, 2]), (700, 3000, 2, False, [2]), (1001, 777, 5, True, [6]),
+                                                            (1030, 100, 6, False, [0, 1, 2, 3, 4, 5]), (6, 4000, 6, True, [3]), (5, 2000, 1, True, [0])])
+def test_fixed_parameters_on_the_register_owner_and_its_latency_forms(E, O, monkeypatch, chains, n, p, intercept, fixed_idx):
+    """Round 5: kernel_adapt / kernel_ram with FIXED parameters (R/kernel.R `fixed`, R/kernel_adapt.R:84-182 and R/kernel_ram.R:90-160 work in
+    the space `which` spans) on mh_sweep_spec's register owner of run-time width: the free parameters on the first lanes, the fixed ones behind
+    them as passengers (they ran on the owners with their matrices in LDS: 3.8 / 3.1 against 1.8 / 2.1 us per step at the README's size).  One
+    or several fixed parameters -- the first, the last (sigma), all but one --, bounds, until, kernel_ram's freq / qfun, two calls with
+    burn-in and thinning, step windows: the oracle's bits."""
+    from fmcmc_amd import _abi as abi
+    X, y = synth_linreg(n, p, 7700 + n + p, beta=np.linspace(0.7, -0.7, p + 1))
+    k = p + 1 + (1 if intercept else 0)
+    init = jitter_init(([0.1] if intercept else []) + [0.1] * p + [float(np.std(y))], chains, 77 + p)
+    init[:, -1] = np.abs(init[:, -1]) + 0.2
+    fixed = [j in fixed_idx for j in range(k)]
+    steps = 90 if chains < 100 else 30
+    want = "spec" if chains > 768 else "spec-lat%d" % ((chains + 255) // 256)
+    kw = dict(intercept=intercept, fixed=fixed)
+    rg, ro = run_both(E, O, O.FAM_LINREG, X, y, O.K_ADAPT, k, init, nsteps=steps, calls=2, warmup=10, burnin=3, thin=2, **kw)
+    assert abi.last_kernel() == want, abi.last_kernel()
+    assert np.all(ro.samples_cks[:, fixed, :] == init[:, fixed, None])
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_ADAPT, k, init, nsteps=steps, warmup=5, lb=-4.0, ub=9.0, until=float(steps - 8), **kw)
+    assert abi.last_kernel() == want
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, k, init, nsteps=steps, calls=2, burnin=2, thin=3, **kw)
+    assert abi.last_kernel() == want
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, k, init, nsteps=steps, ram_qfun=1, warmup=4, freq=2, **kw)
+    assert abi.last_kernel() == want
+    set_knob(monkeypatch, "window", "16")
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_ADAPT, k, init, nsteps=steps, calls=2, warmup=10, **kw)
+    assert abi.last_kernel() == want
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, k, init, nsteps=steps, calls=2, **kw)
+    assert abi.last_kernel() == want
+
+
 @pytest.mark.parametrize("chains,n,p,intercept,fix", [(3, 200, 8, True, False), (300, 50, 12, True, False), (700, 2048, 14, True, False), (1001, 1537, 9, False, False),
                                                       (1030, 600, 13, False, False), (5, 1024, 11, True, True), (2, 1, 10, True, False)])
 def test_adaptive_kernels_with_eight_to_fourteen_covariates_on_the_wave_specialised_kernel_and_its_latency_forms(E, O, monkeypatch, chains, n, p, intercept, fix):
