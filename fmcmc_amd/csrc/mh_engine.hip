@@ -730,7 +730,8 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
     //  the general kernel, 7x the time of the normal kernels at the same shape)
     // (mfma_ad == 2: the owners with their matrices in LDS -- 8 .. 15 covariates, or a fixed parameter; not the bounded kernel_ram)
     if (K.mfma != 0 && !pipe_opt && !adapt_hist && (kn->kind == FMCMC_KERNEL_ADAPT || kn->kind == FMCMC_KERNEL_RAM) && m->p >= 0 && m->p <= 15 && m->n < (1ll << 29)) {   // (p = 0: iid Normal)
-      const bool reg_owner = m->p <= 7 && kf == kn->k && (kn->k <= SPEC_KA || kn->k == 9) && A.kz == kn->k;
+      // (round 5: the run-time-width register owner takes fixed parameters -- free ones first, the fixed ones as passengers)
+      const bool reg_owner = m->p <= 7 && A.kz == kf && kf >= 1 && ((kf == kn->k && (kn->k <= SPEC_KA || kn->k == 9)) || (kf < kn->k && kn->k <= SPEC_KA));
       const int ng = (m->p <= 3) ? 1 : (m->p <= 7 ? 2 : (m->p <= 11 ? 3 : 4));
       const int nsr = (ng == 1) ? MfmaAdShape<1>::NSR : (ng == 2 ? MfmaAdShape<2>::NSR : MfmaAdShape<3>::NSR);
       if (m->n > (long long)NT * nsr && (reg_owner || !(kn->kind == FMCMC_KERNEL_RAM && ram_bounded))) {   // (its resident slots are all full)
@@ -991,7 +992,7 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
           // kernel_adapt / kernel_ram / mirror kernels: the adaptive owners between the barriers of the streamed evaluation (mh_mfma_ad.hpp)
           g_kernel = "mfma-adaptive";
           const bool ad_short = mfma_ext == 1;    // (short data: one resident slot)
-          const int kx = (mfma_ad == 3) ? -2 : (mfma_ad == 2) ? -1 : (mfma_ng == 1 ? (kn->k == 5 ? 5 : 0) : (kn->k == 9 ? 9 : 0));
+          const int kx = (mfma_ad == 3) ? -2 : (mfma_ad == 2) ? -1 : ((kf != kn->k) ? 0 : (mfma_ng == 1 ? (kn->k == 5 ? 5 : 0) : (kn->k == 9 ? 9 : 0)));
           const bool bnd = mfma_ad == 1 && kn->kind == FMCMC_KERNEL_RAM && ram_bounded;
           e = launch_k(fmh::k_mfma_ad(kn->kind, mfma_ng, kx, bnd ? 1 : 0, ad_short ? 1 : 0), pblk, NT, mfma_ad_lds_bytes(mfma_ad == 2), stream, A);
         } else if (mfma_ext) {

@@ -1177,7 +1177,8 @@ def test_eight_to_fifteen_covariates_on_small_data(E, O, monkeypatch, n, p, inte
 
 
 @pytest.mark.parametrize("chains,n,p,intercept,fixed_idx", [(2, 1000, 3, True, [1]), (300, 100, 3, True, [0, 2]), (700, 3000, 2, False, [2]), (1001, 777, 5, True, [6]),
-                                                            (1030, 100, 6, False, [0, 1, 2, 3, 4, 5]), (6, 4000, 6, True, [3]), (5, 2000, 1, True, [0])])
+                                                            (1030, 100, 6, False, [0, 1, 2, 3, 4, 5]), (6, 4000, 6, True, [3]), (5, 2000, 1, True, [0]),
+                                                            (6, 12001, 3, True, [1]), (5, 6000, 6, False, [0, 6])])
 def test_fixed_parameters_on_the_register_owner_and_its_latency_forms(E, O, monkeypatch, chains, n, p, intercept, fixed_idx):
     """Round 5: kernel_adapt / kernel_ram with FIXED parameters (R/kernel.R `fixed`, R/kernel_adapt.R:84-182 and R/kernel_ram.R:90-160 work in
     the space `which` spans) on mh_sweep_spec's register owner of run-time width: the free parameters on the first lanes, the fixed ones behind
@@ -1192,10 +1193,16 @@ def test_fixed_parameters_on_the_register_owner_and_its_latency_forms(E, O, monk
     fixed = [j in fixed_idx for j in range(k)]
     steps = 90 if chains < 100 else 30
     want = "spec" if chains > 768 else "spec-lat%d" % ((chains + 255) // 256)
+    if n > 512 * (20 if p <= 3 else (10 if p <= 5 else 8)):     # (beyond mh_sweep_spec's registers: the same owner between the barriers of mh_sweep_mfma_ad)
+        want = "mfma-adaptive"
+        set_knob(monkeypatch, "shard", "0")
     kw = dict(intercept=intercept, fixed=fixed)
     rg, ro = run_both(E, O, O.FAM_LINREG, X, y, O.K_ADAPT, k, init, nsteps=steps, calls=2, warmup=10, burnin=3, thin=2, **kw)
     assert abi.last_kernel() == want, abi.last_kernel()
     assert np.all(ro.samples_cks[:, fixed, :] == init[:, fixed, None])
+    if want == "mfma-adaptive":      # (and the bounded kernel_ram there)
+        run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, k, init, nsteps=steps, lb=[-0.4] * (k - 1) + [0.3], ub=[0.4] * (k - 1) + [float(np.std(y)) + 0.5], **kw)
+        assert abi.last_kernel() == want
     run_both(E, O, O.FAM_LINREG, X, y, O.K_ADAPT, k, init, nsteps=steps, warmup=5, lb=-4.0, ub=9.0, until=float(steps - 8), **kw)
     assert abi.last_kernel() == want
     run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, k, init, nsteps=steps, calls=2, burnin=2, thin=3, **kw)
