@@ -16,6 +16,13 @@ FMH_HIDDEN const void* k_spec_mirror(int p, int kind) {
     case 5: return SPEC_M(5, 10);
     case 6: return SPEC_M(6, 8);
     case 7: return SPEC_M(7, 8);
+    case 8: return SPEC_M(8, 4);     // (8 .. 14 covariates on up to 2048 observations)
+    case 9: return SPEC_M(9, 4);
+    case 10: return SPEC_M(10, 4);
+    case 11: return SPEC_M(11, 4);
+    case 12: return SPEC_M(12, 4);
+    case 13: return SPEC_M(13, 4);
+    case 14: return SPEC_M(14, 4);
     default: return nullptr;
   }
 #undef SPEC_M

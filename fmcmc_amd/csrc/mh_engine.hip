@@ -755,7 +755,7 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
       // (round 5: within mh_sweep_spec's registers their owner runs there -- beside the evaluation instead of between barriers, and in
       //  the latency forms; up to 512 observations they ran on the general kernel.  Knob specmirror=0: off)
       const long long nsl2 = (((m->n + NT - 1) / NT) + 1) & ~1ll;
-      if (K.specmirror != 0 && (m->p >= 1 || (m->p == 0 && m->intercept && K.specp0 != 0)) && m->p <= 7 && nsl2 <= fmh::k_spec_optmax(m->p, kn->kind) && fmh::k_spec(m->p, kn->kind)) pipe_opt = (int)nsl2;
+      if (K.specmirror != 0 && (m->p >= 1 || (m->p == 0 && m->intercept && K.specp0 != 0)) && (m->p <= 7 || (m->p <= 14 && K.specwide != 0)) && nsl2 <= fmh::k_spec_optmax(m->p, kn->kind) && fmh::k_spec(m->p, kn->kind)) pipe_opt = (int)nsl2;
       else
       if (m->p <= 15 && m->n > nt_min && m->n < (1ll << 29)) { mfma_ad = 3; mfma_ng = ng; mfma_ext = (m->n > (long long)NT * nsr) ? nsr : 1; }
     }
@@ -920,17 +920,15 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
   if (!launched_long && mfma_ng && mfma_ext) {
     const int ns_all = (int)((m->n + NT - 1) / NT), next = ns_all - mfma_ext;
     double* mfs = nullptr;
-    const size_t nd = (size_t)NW * next * mfma_ng * 64 * 4;
-    if (next <= 0) {              // (everything resident: no stream)
-      A.mf_stream = nullptr; A.mf_next = 0;
-    } else
+    const size_t nd = (size_t)NW * (next > 0 ? next : 1) * mfma_ng * 64 * 4;   // (everything resident: one slot of stand-in, read and never used)
     if (hipMallocAsync((void**)&mfs, sizeof(double) * nd, stream) != hipSuccess) {
       (void)hipGetLastError();
       mfma_ng = 0; mfma_ext = 0; mfma_ad = 0; pipe_opt = 0; lat_normal = false;
     } else {
       mfs_guard.p = mfs; mfs_guard.s = stream;
-      hipLaunchKernelGGL(mfma_build_stream, dim3(512), dim3(256), 0, stream, m->X, m->y, (long long)m->n, m->p, mfma_ng, mfma_ext, next, mfs);
-      A.mf_stream = mfs; A.mf_next = next;
+      if (next > 0) hipLaunchKernelGGL(mfma_build_stream, dim3(512), dim3(256), 0, stream, m->X, m->y, (long long)m->n, m->p, mfma_ng, mfma_ext, next, mfs);
+      else (void)hipMemsetAsync(mfs, 0, sizeof(double) * nd, stream);
+      A.mf_stream = mfs; A.mf_next = next > 0 ? next : 0;
     }
   }
   if (launched_long) {

@@ -207,12 +207,13 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma(const SweepArgs A) {
       const mf_d4* sp = reinterpret_cast<const mf_d4*>(A.mf_stream) + ((long long)wave * next * NG) * 64 + lane;
       mf_d4 ring[EXT ? RD : 1][NG];
       if constexpr (EXT) {
-        if (next > 0) {   // (round 5: next == 0 -- up to 512 observations at 8 .. 15 covariates -- streams nothing: the resident slot is the last)
+        // (round 5: next == 0 -- up to 512 observations at 8 .. 15 covariates -- streams nothing, the resident slot is the last: these
+        //  requests then read slot 0 of a stand-in buffer and nobody uses them; a branch around them cost the streamed forms 7 - 10 %)
+        const int rlast = next > 0 ? next - 1 : 0;
 #pragma unroll
-          for (int r = 0; r < RD; r++)
+        for (int r = 0; r < RD; r++)
 #pragma unroll
-            for (int q = 0; q < NG; q++) ring[r][q] = sp[(((r < next) ? r : next - 1) * NG + q) * 64];
-        }
+          for (int q = 0; q < NG; q++) ring[r][q] = sp[(((r < next) ? r : rlast) * NG + q) * 64];
       }
       // batches of MB independent MFMA chains followed by their MB dependent FMAs: the result latency of one MFMA is
       // covered by issuing the next ones, and the batch shape (not the allocator's leftovers) bounds the live results

@@ -132,12 +132,13 @@ __global__ __launch_bounds__(NT) void mh_sweep_mfma_ad(const SweepArgs A) {
     const double cop = ic ? tj[0] : 0.0;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     mf_d4 ring[RD][NG];                          // the first streamed slots are requested before the resident ones run
-    if (next > 0) {   // (round 5: next == 0 -- up to 512 observations -- streams nothing: the one resident slot is the last, with its padding)
+    // (round 5: next == 0 -- up to 512 observations -- streams nothing, the one resident slot is the last, with its padding: these requests
+    //  then read slot 0 of a stand-in buffer and nobody uses them; a branch around them cost the streamed forms 7 - 10 %)
+    const int rlast = next > 0 ? next - 1 : 0;
 #pragma unroll
-      for (int r = 0; r < RD; r++)
+    for (int r = 0; r < RD; r++)
 #pragma unroll
-        for (int q = 0; q < NG; q++) ring[r][q] = sp[(((r < next) ? r : next - 1) * NG + q) * 64];
-    }
+      for (int q = 0; q < NG; q++) ring[r][q] = sp[(((r < next) ? r : rlast) * NG + q) * 64];
     double cml[4];                               // C operands of the LAST slot: 0 where it is padding (-r == 0 exactly)
 #pragma unroll
     for (int g = 0; g < 4; g++) cml[g] = ((vbits >> g) & 1u) ? cop : 0.0;

@@ -785,7 +785,7 @@ def test_mirror_kernels_on_the_streamed_mfma_evaluation(E, O, monkeypatch, kind_
     kind = O.K_NMIRROR if kind_name == "nmirror" else O.K_UMIRROR
     rg, ro = run_both(E, O, O.FAM_LINREG, X, y, kind, k, init, nsteps=150, calls=2, mu=base, scale=0.15, warmup=110, nadapt=6,
                       lb=[-30.0] * (k - 1) + [0.05], ub=30.0, intercept=intercept, burnin=3, thin=2)
-    in_spec = p <= 7 and n <= 512 * (20 if p <= 3 else (10 if p <= 5 else 8))     # (round 5: there their owner runs on mh_sweep_spec)
+    in_spec = (p <= 7 and n <= 512 * (20 if p <= 3 else (10 if p <= 5 else 8))) or (p <= 14 and n <= 2048)     # (round 5: there their owner runs on mh_sweep_spec)
     assert abi.last_kernel() == ("spec" if in_spec else "mfma-adaptive")
     assert np.all(np.isfinite(ro.state.obs_arate)) and np.all(ro.state.abs_iter == 298)
     if in_spec:
@@ -1244,6 +1244,12 @@ def test_adaptive_kernels_with_eight_to_fourteen_covariates_on_the_wave_speciali
     assert abi.last_kernel() == want
     run_both(E, O, O.FAM_LINREG, X, y, O.K_RAM, k, init, nsteps=steps, ram_qfun=1, warmup=4, freq=2, **kw)
     assert abi.last_kernel() == want
+    if not fix:      # (the mirror kernels: joint scheme, no fixed parameter)
+        run_both(E, O, O.FAM_LINREG, X, y, O.K_NMIRROR, k, init, nsteps=steps, calls=2, mu=list(init[0]), scale=0.1, warmup=steps - 10, nadapt=6,
+                 lb=[-30.0] * (k - 1) + [0.05], ub=30.0, intercept=intercept)
+        assert abi.last_kernel() == want
+        run_both(E, O, O.FAM_LINREG, X, y, O.K_UMIRROR, k, init, nsteps=steps, mu=list(init[0]), scale=0.1, warmup=steps - 10, nadapt=6, intercept=intercept)
+        assert abi.last_kernel() == want
     set_knob(monkeypatch, "window", "16")
     run_both(E, O, O.FAM_LINREG, X, y, O.K_ADAPT, k, init, nsteps=steps, calls=2, warmup=10, **kw)
     assert abi.last_kernel() == want
