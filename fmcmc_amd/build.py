@@ -75,7 +75,7 @@ def build(force=False, verbose=False, extra_flags=(), out=None, jobs=None):
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < dep_t:
             todo.append((src, obj))
     # (longest first: the units that instantiate the most kernels decide the wall time when they start last)
-    HEAVY = ("k_lat_l2a", "k_lat_l1a", "k_wide.", "k_spec_a", "k_lat2a", "k_lat1a", "k_lat2c", "k_lat_l2b", "k_lat_l1b", "k_lat1c", "k_mfma_ad", "k_spec_l2", "k_spec_w1", "k_spec_w3", "k_spec_lw1", "k_spec_lw2", "k_lat_l3a", "k_lat_l3b", "k_logit1", "k_lat_l2c", "k_lat_l1c", "k_lat2b", "k_lat1b", "k_lat2d", "k_lat1d", "k_logit2", "k_mfma2", "k_mfma1", "k_general", "k_logit0", "k_spec_r")
+    HEAVY = ("k_lat_l2a", "k_lat_l1a", "k_wide.", "k_spec_a", "k_lat2a", "k_lat1a", "k_lat2c", "k_lat_l2b", "k_lat_l1b", "k_lat1c", "k_mfma_ad", "k_spec_l2", "k_spec_w1", "k_spec_w3", "k_spec_lw1", "k_spec_lw2", "k_lat_l3a", "k_lat_l3b", "k_lat3a", "k_lat3b", "k_logit1", "k_lat_l2c", "k_lat_l1c", "k_lat2b", "k_lat1b", "k_lat2d", "k_lat1d", "k_logit2", "k_mfma2", "k_mfma1", "k_general", "k_logit0", "k_spec_r")
     def cost(so):
         b = os.path.basename(so[0])
         for i, h in enumerate(HEAVY):

@@ -17,9 +17,11 @@ FMH_HIDDEN const void* k_lat_kv1b(int p);
 FMH_HIDDEN const void* k_lat_kv2a(int p);
 FMH_HIDDEN const void* k_lat_kv2b(int p);
 FMH_HIDDEN const void* k_lat_kv2c(int p);
+FMH_HIDDEN const void* k_lat_kv1w(int p);   // k_lat3a.hip / k_lat3b.hip: p = 8 .. 15
+FMH_HIDDEN const void* k_lat_kv2w(int p);
 const void* k_lat(int p, int kind) {
-  if (kind == FMCMC_KERNEL_NORMAL) return p <= 2 ? k_lat_kv1a(p) : (p == 3 ? k_lat_kv1b(p) : k_lat_kv1c(p));
-  if (kind == FMCMC_KERNEL_NORMAL_REFLECTIVE) return p <= 2 ? k_lat_kv2a(p) : (p == 3 ? k_lat_kv2b(p) : k_lat_kv2c(p));
+  if (kind == FMCMC_KERNEL_NORMAL) return p <= 2 ? k_lat_kv1a(p) : (p == 3 ? k_lat_kv1b(p) : (p <= 7 ? k_lat_kv1c(p) : k_lat_kv1w(p)));
+  if (kind == FMCMC_KERNEL_NORMAL_REFLECTIVE) return p <= 2 ? k_lat_kv2a(p) : (p == 3 ? k_lat_kv2b(p) : (p <= 7 ? k_lat_kv2c(p) : k_lat_kv2w(p)));
   return nullptr;
 }
 }  // namespace fmh

@@ -767,9 +767,18 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
     // lanes hold in registers: kernel_adapt / kernel_ram on mh_sweep_spec (its owners no longer queue behind the evaluation of
     // other chains), the normal / uniform kernels on mh_sweep_lat (mh_lat.hpp: chain state replicated in every wave, ONE barrier
     // per step).  Same canonical lanes and tree: the bits do not depend on the form.  Knob lat=0: off; lat=1|2|3: forced.
+    // (8 .. 15 covariates on up to 2048 observations, round 5: mh_sweep_lat<KIND, P, 4> -- the joint scheme with ONE chain per compute unit
+    //  (1.2 us per step on the streamed MFMA form at any chain count), the single-parameter schemes up to four (general kernel before))
+    const long long nsl2w = (((m->n + NT - 1) / NT) + 1) & ~1ll, per_cuw = (run->nchains + ncu - 1) / ncu;
+    const bool wide_lat = K.lat != 0 && K.specwide != 0 && !mirror && m->p >= 8 && m->p <= 15 && kn->k <= PIPE_KMAX && nsl2w <= 4 &&
+                          kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE && kn->kind >= FMCMC_KERNEL_NORMAL && kf >= 1 && fmh::k_lat(m->p, kn->kind) != nullptr;
+    if (wide_lat && kn->scheme == FMCMC_SCHEME_JOINT && (per_cuw <= 1 || (K.lat >= 1 && K.lat <= 3))) {
+      pipe_opt = (int)nsl2w; mfma_ng = 0; mfma_ext = 0; lat_normal = true;
+      spec_cw = (K.lat >= 1 && K.lat <= 3) ? K.lat : 1;
+    } else
     if (single_lat && !mirror) {
       const long long per_cu = (run->nchains + ncu - 1) / ncu, nsl2 = (((m->n + NT - 1) / NT) + 1) & ~1ll;
-      if (per_cu <= 4 && m->p >= 0 && m->p <= 7 && nsl2 <= fmh::k_spec_optmax(m->p, kn->kind) && fmh::k_lat(m->p, kn->kind)) {
+      if (per_cu <= 4 && m->p >= 0 && (m->p <= 7 ? nsl2 <= fmh::k_spec_optmax(m->p, kn->kind) : wide_lat) && fmh::k_lat(m->p, kn->kind)) {
         pipe_opt = (int)nsl2; mfma_ng = 0; lat_normal = true;
         spec_cw = (K.lat >= 1 && K.lat <= 3) ? K.lat : (int)per_cu;
       }

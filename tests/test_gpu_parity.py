@@ -1176,6 +1176,35 @@ def test_eight_to_fifteen_covariates_on_small_data(E, O, monkeypatch, n, p, inte
     assert abi.last_kernel() not in ("mfma-streamed", "mfma-adaptive")
 
 
+@pytest.mark.parametrize("chains,n,p,intercept", [(2, 200, 8, True), (200, 50, 12, True), (300, 2048, 14, True), (1000, 1537, 15, False), (3, 1, 10, True)])
+def test_eight_to_fifteen_covariates_on_the_latency_form(E, O, monkeypatch, chains, n, p, intercept):
+    """Round 5: the normal / uniform kernels of the linear model with 8 .. 15 covariates (k <= 16) on up to 2048 observations on
+    mh_sweep_lat<KIND, P, 4>: the joint scheme with one chain per compute unit (beyond, the streamed MFMA form), the single-parameter
+    schemes with up to four (they ran on the general kernel).  Reflective bounds, a fixed parameter, two calls with burn-in and thinning:
+    the oracle's bits and the oracle's plan."""
+    from fmcmc_amd import _abi as abi
+    X, y = synth_linreg(n, p, 8800 + n + p, beta=np.linspace(0.8, -0.8, p + 1))
+    k = p + 1 + (1 if intercept else 0)
+    sd = float(np.std(y)) if n > 1 else 1.0
+    init = jitter_init(([0.0] if intercept else []) + [0.0] * p + [sd + 0.5], chains, 96 + p)
+    init[:, -1] = np.abs(init[:, -1])
+    per_cu = (chains + 255) // 256
+    steps = 60 if chains < 100 else 24
+    kw = dict(nsteps=steps, intercept=intercept)
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, k, init, burnin=3, thin=2, calls=2, scale=0.02, **kw)
+    assert abi.last_kernel() == ("lat1" if per_cu == 1 else "mfma-streamed"), abi.last_kernel()
+    fixed = [False] * k
+    fixed[2] = True
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_UNIF_REFLECTIVE, k, init, min_=-0.3, max_=0.3, lb=-6.0, ub=9.0, fixed=fixed, **kw)
+    assert abi.last_kernel() == ("lat1" if per_cu == 1 else "mfma-streamed")
+    for scheme in ("ordered", "random"):
+        run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, k, init, scale=0.05, scheme=scheme, calls=2, **kw)
+        assert abi.last_kernel() == "lat%d" % per_cu, abi.last_kernel()
+    set_knob(monkeypatch, "specwide", "0")
+    run_both(E, O, O.FAM_LINREG, X, y, O.K_NORMAL, k, init, scale=0.02, **kw)
+    assert abi.last_kernel() == "mfma-streamed"
+
+
 @pytest.mark.parametrize("chains,n,p,intercept,fixed_idx", [(2, 1000, 3, True, [1]), (300, 100, 3, True, [0, 2]), (700, 3000, 2, False, [2]), (1001, 777, 5, True, [6]),
                                                             (1030, 100, 6, False, [0, 1, 2, 3, 4, 5]), (6, 4000, 6, True, [3]), (5, 2000, 1, True, [0]),
                                                             (6, 12001, 3, True, [1]), (5, 6000, 6, False, [0, 6])])
