@@ -841,7 +841,7 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
     const long long per_cu = (run->nchains + ncu - 1) / ncu;
     if ((kn->scheme != FMCMC_SCHEME_JOINT || lg_lat_fixed || lg_lat_wide) && kn->kind <= FMCMC_KERNEL_NORMAL_REFLECTIVE) {
       // single-parameter schemes: the latency form's candidate wave, one to four chains per workgroup (as for the linear model above)
-      if (per_cu <= 4 && nsl2 <= (lg_lat_wide ? 4 : (lg_lat_fixed ? 12 : fmh::k_spec_optmax(m->p, kn->kind))) && fmh::k_lat_logit(m->p, kn->kind)) {
+      if (per_cu <= 4 && nsl2 <= (lg_lat_wide ? 4 : (lg_lat_fixed && fmh::k_spec_optmax(m->p, kn->kind) > 12 ? 12 : fmh::k_spec_optmax(m->p, kn->kind))) && fmh::k_lat_logit(m->p, kn->kind)) {   // (never beyond the kernel's own slot count: the randomised soak's case 1566)
         pipe_opt = (int)nsl2; spec_logit = true; lat_normal = true;
         spec_cw = (K.lat >= 1 && K.lat <= 3) ? K.lat : (int)per_cu;
       }

@@ -959,6 +959,23 @@ def test_logistic_with_eight_to_fifteen_covariates_on_the_latency_form(E, O, mon
     assert not abi.last_kernel().startswith("lat-logit")
 
 
+def test_logistic_fixed_parameter_beyond_the_latency_kernel_s_slots(E, O):
+    """Found by the randomised soak at the end of round 5 (test_randomised_option_cases[1566]): a fixed parameter under kernel_normal on the
+    logistic family went to the latency form up to 12 slots per lane whatever the kernel holds -- p = 6 holds 8 (n <= 4096): at n = 4097 the
+    launch ran no loop at all and returned zeros.  The oracle's bits at the slot-count edges of p = 4 .. 7."""
+    from fmcmc_amd import _abi as abi
+    for n, p in ((4097, 6), (4096, 6), (5121, 5), (5120, 4), (4097, 7), (6000, 3)):
+        rng = np.random.default_rng(n + p)
+        X = rng.standard_normal((n, p))
+        beta = np.linspace(0.5, -0.5, p)
+        y = (rng.uniform(size=n) < 1 / (1 + np.exp(-(X @ beta)))).astype(np.float64)
+        init = jitter_init(list(beta), 2, 5)
+        fixed = [True] + [False] * (p - 2) + [True]
+        rg, ro = run_both(E, O, O.FAM_LOGISTIC, X, y, O.K_NORMAL, p, init, nsteps=70, burnin=1, calls=2, chain_base=3, intercept=False, prior_div=8.0,
+                          fixed=fixed, scale=0.01)
+        assert ro.accept_count.sum() > 0
+
+
 @pytest.mark.parametrize("form", ["shadow", "spec"])
 def test_logistic_round5_kernels_edge_cases(E, O, monkeypatch, form):
     """mh_sweep_logit2 ("logistic-shadow", forced by shard=1) and the logistic family on mh_sweep_spec ("spec-logit") at the edges: two
@@ -1835,7 +1852,7 @@ def _random_case(seed):
                 chain_base=int(rng.choice([0, 0, 5, 1000])))
 
 
-@pytest.mark.parametrize("case", range(int(os.environ.get("FMCMC_TEST_RANDOM_CASES", "160"))))   # soak: 3000 passed
+@pytest.mark.parametrize("case", range(int(os.environ.get("FMCMC_TEST_RANDOM_CASES", "160"))))   # soak: 3000 passed (round 5, last code: 3000)
 def test_randomised_dispatch_cases(E, O, case):
     c = _random_case(case)
     rng = np.random.default_rng(17 + case)
@@ -2185,7 +2202,7 @@ def test_c4_exact_shape_equals_the_oracle(E, O):
     assert abi.last_kernel() == "wide-dataflow"
 
 
-@pytest.mark.parametrize("case", range(int(os.environ.get("FMCMC_TEST_RANDOM_CASES2", "80"))))   # soak: 2000 passed
+@pytest.mark.parametrize("case", range(int(os.environ.get("FMCMC_TEST_RANDOM_CASES2", "80"))))   # soak: 2000 passed (round 5, last code: 6000 -- case 1566 found a launch without a loop, see test_logistic_fixed_parameter_beyond...)
 def test_randomised_option_cases(E, O, case):
     """Second randomised sweep, over the options the first one leaves at their defaults: unguarded log-posteriors,
     flat / Gaussian priors, non-zero proposal means, explicit update sequences, kernel_ram's constr mask and target rate,
