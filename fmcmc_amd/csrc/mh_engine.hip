@@ -859,6 +859,15 @@ static int launch_sweep(const fmcmc_model* m_in, const fmcmc_kernel* kn_in, cons
           nsl2 <= (spec_cw == 1 ? 12 : 6)) lat_normal = true;
     }
   }
+  // (a launch with a slot count its instantiation does not hold would run no loop and hand back zeros -- round 5's soak found one such
+  //  route --: whatever the rules above decided, a count beyond the kernel's own goes to the general kernels)
+  if (pipe_opt && !mfma_ng) {
+    const int own = (m->p <= 3) ? 20 : (m->p <= 5 ? 10 : (m->p <= 7 ? 8 : 4));
+    if (pipe_opt > own || (pipe_opt & 1)) {
+      if (A.debug) fprintf(stderr, "fmcmc_amd: slot count %d beyond the register kernels' %d at p = %d: general kernel\n", pipe_opt, own, m->p);
+      pipe_opt = 0; lat_normal = false; spec_logit = false; spec_cw = 4;
+    }
+  }
   A.spec_opt = pipe_opt;
   A.spec_cw = spec_cw;
   A.nsteps_call = run->nsteps;
